@@ -1,0 +1,334 @@
+/*
+ * belt_oracle.c -- TEST INFRASTRUCTURE (see oracle.h).
+ *
+ * CPU restatement of STB 34.101.31 belt: S-box, block encryption, CTR, MAC,
+ * compress and hash.  Written from the algorithm as pinned by the STB vectors;
+ * one S-box byte table + explicit G-function (no pre-rotated tables), explicit
+ * register rotation per round (no macro-argument permutation).
+ *
+ * Follows:
+ *   H generator      src/crypto/belt/belt_block.c:21-35 (comment recipe), :43-60
+ *   beltKeyExpand2   src/crypto/belt/belt_block.c:88-106
+ *   G / R / E        src/crypto/belt/belt_block.c:210-269
+ *   beltBlockEncr*   src/crypto/belt/belt_block.c:302-334
+ *   CTR              src/crypto/belt/belt_ctr.c:27-135
+ *   MAC              src/crypto/belt/belt_mac.c:47-203
+ *   compress         src/crypto/belt/belt_compr.c:27-87
+ *   hash             src/crypto/belt/belt_hash.c:43-190, belt_lcl.c:25-51
+ */
+#include "oracle.h"
+#include "orc_threads.h"
+#include <string.h>
+
+/* ---------------------------------------------------------------- S-box --- */
+static uint8_t g_H[256];
+static pthread_once_t g_H_once = PTHREAD_ONCE_INIT;
+
+static void gen_H(void)
+{
+    /* H[10] = 0, H[11] = 0x8E, then an 8-bit LFSR stepped 116 times per entry */
+    g_H[10] = 0x00; g_H[11] = 0x8E;
+    for (unsigned x = 12; x < 10 + 256; ++x) {
+        unsigned t = g_H[(x - 1) % 256];
+        for (int i = 0; i < 116; ++i) {
+            unsigned par = __builtin_parity(t & 0x63);
+            t = (t >> 1) | (par << 7);
+        }
+        g_H[x % 256] = (uint8_t)t;
+    }
+}
+
+const uint8_t *orc_beltH(void)
+{
+    pthread_once(&g_H_once, gen_H);
+    return g_H;
+}
+
+/* ------------------------------------------------------------ primitives --- */
+static inline uint32_t rotl32(uint32_t x, unsigned r) { return (x << r) | (x >> (32 - r)); }
+static inline uint32_t load32le(const uint8_t *p)
+{
+    return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+}
+static inline void store32le(uint8_t *p, uint32_t v)
+{
+    p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+}
+
+static inline uint32_t G(const uint8_t *H, uint32_t x, unsigned r)
+{
+    uint32_t y = (uint32_t)H[x & 255] | (uint32_t)H[(x >> 8) & 255] << 8 |
+                 (uint32_t)H[(x >> 16) & 255] << 16 | (uint32_t)H[x >> 24] << 24;
+    return rotl32(y, r);
+}
+
+void orc_beltKeyExpand2(uint32_t key_[8], const uint8_t *key, size_t len)
+{
+    for (size_t i = 0; i < len / 4; ++i) key_[i] = load32le(key + 4 * i);
+    if (len == 16) {
+        for (int i = 0; i < 4; ++i) key_[4 + i] = key_[i];
+    } else if (len == 24) {
+        key_[6] = key_[0] ^ key_[1] ^ key_[2];
+        key_[7] = key_[3] ^ key_[4] ^ key_[5];
+    }
+}
+
+void orc_beltBlockEncr2(uint32_t block[4], const uint32_t K[8])
+{
+    const uint8_t *H = orc_beltH();
+    uint32_t a = block[0], b = block[1], c = block[2], d = block[3], e, t;
+    for (unsigned i = 1; i <= 8; ++i) {
+        const unsigned base = 7 * i - 7;
+#define KEY(j) K[(base + (j)) & 7]
+        b ^= G(H, a + KEY(0), 5);
+        c ^= G(H, d + KEY(1), 21);
+        a -= G(H, b + KEY(2), 13);
+        e = G(H, b + c + KEY(3), 21) ^ i;
+        b += e;
+        c -= e;
+        d += G(H, c + KEY(4), 13);
+        b ^= G(H, a + KEY(5), 21);
+        c ^= G(H, d + KEY(6), 5);
+#undef KEY
+        /* (a,b,c,d) <- (b,d,a,c) */
+        t = a; a = b; b = d; d = c; c = t;
+    }
+    /* output (b,d,a,c): belt_block.c:267-269 */
+    block[0] = b; block[1] = d; block[2] = a; block[3] = c;
+}
+
+void orc_beltBlockEncr(uint8_t block[16], const uint32_t key[8])
+{
+    uint32_t w[4];
+    for (int i = 0; i < 4; ++i) w[i] = load32le(block + 4 * i);
+    orc_beltBlockEncr2(w, key);
+    for (int i = 0; i < 4; ++i) store32le(block + 4 * i, w[i]);
+}
+
+/* ------------------------------------------------------------------- CTR --- */
+static inline void ctr_add(uint32_t out[4], const uint32_t in[4], uint64_t add)
+{
+    /* 128-bit little-endian integer + 64-bit offset (belt_ctr.c:27-35 applied `add` times) */
+    uint64_t lo = (uint64_t)in[0] | (uint64_t)in[1] << 32;
+    uint64_t hi = (uint64_t)in[2] | (uint64_t)in[3] << 32;
+    uint64_t nlo = lo + add;
+    hi += (nlo < lo);
+    out[0] = (uint32_t)nlo; out[1] = (uint32_t)(nlo >> 32);
+    out[2] = (uint32_t)hi; out[3] = (uint32_t)(hi >> 32);
+}
+
+void orc_beltCTRStart(orc_belt_ctr_st *st, const uint8_t *key, size_t len, const uint8_t iv[16])
+{
+    orc_beltKeyExpand2(st->key, key, len);
+    for (int i = 0; i < 4; ++i) st->ctr[i] = load32le(iv + 4 * i);
+    orc_beltBlockEncr2(st->ctr, st->key);
+    memset(st->block, 0, 16);
+    st->reserved = 0;
+}
+
+static void ctr_next_gamma(orc_belt_ctr_st *st)
+{
+    uint32_t g[4];
+    ctr_add(st->ctr, st->ctr, 1);
+    memcpy(g, st->ctr, 16);
+    orc_beltBlockEncr2(g, st->key);
+    for (int i = 0; i < 4; ++i) store32le(st->block + 4 * i, g[i]);
+}
+
+void orc_beltCTRStepE(void *buf_, size_t count, orc_belt_ctr_st *st)
+{
+    uint8_t *buf = (uint8_t *)buf_;
+    if (st->reserved) {                                   /* belt_ctr.c:70-83 */
+        size_t take = st->reserved < count ? st->reserved : count;
+        const uint8_t *g = st->block + 16 - st->reserved;
+        for (size_t i = 0; i < take; ++i) buf[i] ^= g[i];
+        st->reserved -= take; buf += take; count -= take;
+        if (!count) return;
+    }
+    while (count >= 16) {                                 /* :85-97 */
+        ctr_next_gamma(st);
+        for (int i = 0; i < 16; ++i) buf[i] ^= st->block[i];
+        buf += 16; count -= 16;
+    }
+    if (count) {                                          /* :98-110 */
+        ctr_next_gamma(st);
+        for (size_t i = 0; i < count; ++i) buf[i] ^= st->block[i];
+        st->reserved = 16 - count;
+    }
+}
+
+uint32_t orc_beltCTR(void *dest, const void *src, size_t count,
+                     const uint8_t *key, size_t len, const uint8_t iv[16])
+{
+    orc_belt_ctr_st st;
+    if (len != 16 && len != 24 && len != 32) return ORC_BAD_INPUT;
+    orc_beltCTRStart(&st, key, len, iv);
+    memmove(dest, src, count);
+    orc_beltCTRStepE(dest, count, &st);
+    return ORC_OK;
+}
+
+typedef struct { uint8_t *buf; const uint32_t *key; const uint32_t *ctr0; uint64_t first; } ctr_job;
+static void ctr_range(void *ctx, size_t lo, size_t hi)
+{
+    ctr_job *j = (ctr_job *)ctx;
+    for (size_t i = lo; i < hi; ++i) {
+        uint32_t g[4];
+        uint8_t *p = j->buf + 16 * i;
+        ctr_add(g, j->ctr0, j->first + (uint64_t)i + 1);
+        orc_beltBlockEncr2(g, j->key);
+        for (int k = 0; k < 4; ++k) store32le(p + 4 * k, load32le(p + 4 * k) ^ g[k]);
+    }
+}
+void orc_beltCTR_blocks(uint8_t *buf, size_t nblocks, const uint32_t key[8],
+                        const uint32_t ctr0[4], uint64_t first, int nthreads)
+{
+    ctr_job j = {buf, key, ctr0, first};
+    (void)orc_beltH();
+    orc_parallel_for(nblocks, nthreads, ctr_range, &j);
+}
+
+/* ------------------------------------------------------------------- MAC --- */
+void orc_beltMACStart(orc_belt_mac_st *st, const uint8_t *key, size_t len)
+{
+    orc_beltKeyExpand2(st->key, key, len);
+    memset(st->s, 0, 16);
+    memset(st->r, 0, 16);
+    orc_beltBlockEncr2(st->r, st->key);
+    memset(st->block, 0, 16);
+    st->filled = 0;
+}
+
+static void mac_absorb_block(orc_belt_mac_st *st)
+{
+    for (int i = 0; i < 4; ++i) st->s[i] ^= load32le(st->block + 4 * i);
+    orc_beltBlockEncr2(st->s, st->key);
+}
+
+void orc_beltMACStepA(const void *buf_, size_t count, orc_belt_mac_st *st)
+{
+    const uint8_t *buf = (const uint8_t *)buf_;
+    /* one block of look-ahead: a full buffered block is absorbed only when more
+       data arrives (belt_mac.c:58-99) */
+    while (count) {
+        if (st->filled == 16) { mac_absorb_block(st); st->filled = 0; }
+        size_t take = 16 - st->filled;
+        if (take > count) take = count;
+        memcpy(st->block + st->filled, buf, take);
+        st->filled += take; buf += take; count -= take;
+    }
+}
+
+void orc_beltMACStepG(uint8_t mac[8], const orc_belt_mac_st *st)
+{
+    uint32_t m[4], x[4];
+    uint8_t blk[16];
+    const uint32_t *r = st->r;
+    memcpy(blk, st->block, 16);
+    if (st->filled == 16) {                               /* belt_mac.c:105-119 */
+        for (int i = 0; i < 4; ++i) x[i] = load32le(blk + 4 * i);
+        m[0] = st->s[0] ^ x[0] ^ r[1];
+        m[1] = st->s[1] ^ x[1] ^ r[2];
+        m[2] = st->s[2] ^ x[2] ^ r[3];
+        m[3] = st->s[3] ^ x[3] ^ r[0] ^ r[1];
+    } else {                                              /* :121-136 */
+        blk[st->filled] = 0x80;
+        memset(blk + st->filled + 1, 0, 16 - st->filled - 1);
+        for (int i = 0; i < 4; ++i) x[i] = load32le(blk + 4 * i);
+        m[0] = st->s[0] ^ x[0] ^ r[0] ^ r[3];
+        m[1] = st->s[1] ^ x[1] ^ r[0];
+        m[2] = st->s[2] ^ x[2] ^ r[1];
+        m[3] = st->s[3] ^ x[3] ^ r[2];
+    }
+    orc_beltBlockEncr2(m, st->key);
+    store32le(mac, m[0]);
+    store32le(mac + 4, m[1]);
+}
+
+uint32_t orc_beltMAC(uint8_t mac[8], const void *src, size_t count,
+                     const uint8_t *key, size_t len)
+{
+    orc_belt_mac_st st;
+    if (len != 16 && len != 24 && len != 32) return ORC_BAD_INPUT;
+    orc_beltMACStart(&st, key, len);
+    orc_beltMACStepA(src, count, &st);
+    orc_beltMACStepG(mac, &st);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------- compress / hash --- */
+/* sigma1(h, X) = E_X(h0 ^ h1) ^ h0 ^ h1 ; returns it in s1, updates h <- sigma2 */
+static void compress_core(uint32_t s1[4], uint32_t h[8], const uint32_t X[8])
+{
+    uint32_t u[4], k1[8], k2[8], y0[4], y1[4];
+    for (int i = 0; i < 4; ++i) u[i] = h[i] ^ h[4 + i];
+    memcpy(s1, u, 16);
+    orc_beltBlockEncr2(s1, X);
+    for (int i = 0; i < 4; ++i) s1[i] ^= u[i];
+    /* K1 = s1 || h1 ; K2 = ~s1 || h0 */
+    for (int i = 0; i < 4; ++i) { k1[i] = s1[i]; k1[4 + i] = h[4 + i]; k2[i] = ~s1[i]; k2[4 + i] = h[i]; }
+    memcpy(y0, X, 16);     orc_beltBlockEncr2(y0, k1);
+    memcpy(y1, X + 4, 16); orc_beltBlockEncr2(y1, k2);
+    for (int i = 0; i < 4; ++i) { h[i] = y0[i] ^ X[i]; h[4 + i] = y1[i] ^ X[4 + i]; }
+}
+
+void orc_beltCompr(uint32_t h[8], const uint32_t X[8])
+{
+    uint32_t s1[4];
+    compress_core(s1, h, X);
+}
+
+uint32_t orc_beltHash(uint8_t hash[32], const void *src_, size_t count)
+{
+    const uint8_t *src = (const uint8_t *)src_;
+    const uint8_t *H = orc_beltH();
+    uint32_t ls[8], h[8], X[8], s1[4];
+    uint8_t blk[32];
+    memset(ls, 0, sizeof ls);
+    /* len as a 128-bit LE bit count (belt_lcl.c:25-51) */
+    {
+        uint64_t bits_lo = (uint64_t)count << 3, bits_hi = (uint64_t)count >> 61;
+        ls[0] = (uint32_t)bits_lo; ls[1] = (uint32_t)(bits_lo >> 32);
+        ls[2] = (uint32_t)bits_hi; ls[3] = (uint32_t)(bits_hi >> 32);
+    }
+    for (int i = 0; i < 8; ++i) h[i] = load32le(H + 4 * i);
+    while (count >= 32) {
+        for (int i = 0; i < 8; ++i) X[i] = load32le(src + 4 * i);
+        compress_core(s1, h, X);
+        for (int i = 0; i < 4; ++i) ls[4 + i] ^= s1[i];
+        src += 32; count -= 32;
+    }
+    if (count) {
+        memset(blk, 0, 32);
+        memcpy(blk, src, count);
+        for (int i = 0; i < 8; ++i) X[i] = load32le(blk + 4 * i);
+        compress_core(s1, h, X);
+        for (int i = 0; i < 4; ++i) ls[4 + i] ^= s1[i];
+    }
+    orc_beltCompr(h, ls);
+    for (int i = 0; i < 8; ++i) store32le(hash + 4 * i, h[i]);
+    return ORC_OK;
+}
+
+/* ----------------------------------------- H4: bash512 + beltMAC / message --- */
+typedef struct {
+    const uint8_t *msgs; size_t msg_len; const uint8_t *key; size_t key_len;
+    uint8_t *digests; uint8_t *tags;
+} mixed_job;
+static void mixed_range(void *ctx, size_t lo, size_t hi)
+{
+    mixed_job *j = (mixed_job *)ctx;
+    for (size_t i = lo; i < hi; ++i) {
+        const uint8_t *m = j->msgs + i * j->msg_len;
+        orc_bashHash(j->digests + 64 * i, 256, m, j->msg_len);
+        orc_beltMAC(j->tags + 8 * i, m, j->msg_len, j->key, j->key_len);
+    }
+}
+void orc_bash512_beltMAC_batch(const uint8_t *msgs, size_t msg_len, size_t n,
+                               const uint8_t *key, size_t key_len,
+                               uint8_t *digests, uint8_t *tags, int nthreads)
+{
+    mixed_job j = {msgs, msg_len, key, key_len, digests, tags};
+    (void)orc_beltH();
+    orc_parallel_for(n, nthreads, mixed_range, &j);
+}
