@@ -1,0 +1,193 @@
+"""ctypes view of oracle/liboracle.so -- the CPU checker (test infrastructure).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this."""
+import ctypes
+import json
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORC_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+GOLD = os.path.join(ROOT, "tests", "golden")
+_sz = ctypes.c_size_t
+_u8p = ctypes.c_char_p
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.orc_beltH.restype = ctypes.POINTER(ctypes.c_ubyte)
+        lib.orc_bashHash.restype = ctypes.c_uint32
+        lib.orc_beltCTR.restype = ctypes.c_uint32
+        lib.orc_beltMAC.restype = ctypes.c_uint32
+        lib.orc_beltHash.restype = ctypes.c_uint32
+        lib.orc_bign128Verify.restype = ctypes.c_uint32
+        lib.orc_bign128Verify_ex.restype = ctypes.c_uint32
+
+    # --- bash
+    def beltH(self):
+        p = self.lib.orc_beltH()
+        return bytes(p[i] for i in range(256))
+
+    def bashF(self, state):
+        b = ctypes.create_string_buffer(bytes(state), 192)
+        self.lib.orc_bashF(b)
+        return b.raw
+
+    def bashF_batch(self, states, nthreads=1):
+        n = len(states) // 192
+        b = ctypes.create_string_buffer(bytes(states), len(states))
+        self.lib.orc_bashF_batch(b, _sz(n), ctypes.c_int(nthreads))
+        return b.raw
+
+    def bashF_batch_np(self, arr, nthreads=1):
+        """in-place on a contiguous numpy uint8 array of n*192 bytes"""
+        assert arr.flags["C_CONTIGUOUS"] and arr.nbytes % 192 == 0
+        self.lib.orc_bashF_batch(ctypes.c_void_p(arr.ctypes.data), _sz(arr.nbytes // 192),
+                                 ctypes.c_int(nthreads))
+
+    def bashHash(self, l, msg):
+        out = ctypes.create_string_buffer(max(l // 4, 1))
+        code = self.lib.orc_bashHash(out, _sz(l), bytes(msg), _sz(len(msg)))
+        return code, out.raw[: l // 4]
+
+    def bashHash_steps(self, l, msg, splits):
+        st = ctypes.create_string_buffer(192 + 16)
+        self.lib.orc_bashHashStart(st, _sz(l))
+        off = 0
+        for s in splits:
+            self.lib.orc_bashHashStepH(bytes(msg[off:off + s]), _sz(s), st)
+            off += s
+        out = ctypes.create_string_buffer(l // 4)
+        self.lib.orc_bashHashStepG(out, _sz(l // 4), st)
+        return out.raw
+
+    # --- belt
+    def key_expand(self, key):
+        k = (ctypes.c_uint32 * 8)()
+        self.lib.orc_beltKeyExpand2(k, bytes(key), _sz(len(key)))
+        return k
+
+    def block_encr(self, block, key):
+        b = ctypes.create_string_buffer(bytes(block), 16)
+        self.lib.orc_beltBlockEncr(b, self.key_expand(key))
+        return b.raw
+
+    def ctr(self, msg, key, iv, splits=None):
+        st = ctypes.create_string_buffer(32 + 16 + 16 + 8)
+        self.lib.orc_beltCTRStart(st, bytes(key), _sz(len(key)), bytes(iv))
+        buf = ctypes.create_string_buffer(bytes(msg), max(len(msg), 1))
+        off = 0
+        for s in (splits if splits is not None else [len(msg)]):
+            self.lib.orc_beltCTRStepE(ctypes.byref(buf, off), _sz(s), st)
+            off += s
+        return buf.raw[: len(msg)]
+
+    def ctr_start(self, key, iv):
+        """(expanded key u32[8], ctr0 u32[4]) as bytes"""
+        st = ctypes.create_string_buffer(32 + 16 + 16 + 8)
+        self.lib.orc_beltCTRStart(st, bytes(key), _sz(len(key)), bytes(iv))
+        return st.raw[:32], st.raw[32:48]
+
+    def ctr_blocks_np(self, arr, key_words, ctr0_words, first=0, nthreads=1):
+        assert arr.flags["C_CONTIGUOUS"] and arr.nbytes % 16 == 0
+        self.lib.orc_beltCTR_blocks(ctypes.c_void_p(arr.ctypes.data), _sz(arr.nbytes // 16),
+                                    bytes(key_words), bytes(ctr0_words), ctypes.c_uint64(first),
+                                    ctypes.c_int(nthreads))
+
+    def mac(self, msg, key):
+        out = ctypes.create_string_buffer(8)
+        code = self.lib.orc_beltMAC(out, bytes(msg), _sz(len(msg)), bytes(key), _sz(len(key)))
+        assert code == 0
+        return out.raw
+
+    def mac_steps(self, msg, key, splits):
+        st = ctypes.create_string_buffer(32 + 16 + 16 + 16 + 8)
+        self.lib.orc_beltMACStart(st, bytes(key), _sz(len(key)))
+        off = 0
+        for s in splits:
+            self.lib.orc_beltMACStepA(bytes(msg[off:off + s]), _sz(s), st)
+            off += s
+        out = ctypes.create_string_buffer(8)
+        self.lib.orc_beltMACStepG(out, st)
+        return out.raw
+
+    def belt_hash(self, msg):
+        out = ctypes.create_string_buffer(32)
+        self.lib.orc_beltHash(out, bytes(msg), _sz(len(msg)))
+        return out.raw
+
+    # --- bign
+    def verify(self, h, s, p):
+        return self.lib.orc_bign128Verify(bytes(h), bytes(s), bytes(p))
+
+    def verify_rx(self, h, s, p):
+        rx = ctypes.create_string_buffer(32)
+        code = self.lib.orc_bign128Verify_ex(bytes(h), bytes(s), bytes(p), rx)
+        return code, rx.raw
+
+    def verify_batch(self, hashes, sigs, pubs, nthreads=1):
+        n = len(hashes) // 32
+        codes = (ctypes.c_uint32 * n)()
+        self.lib.orc_bign128Verify_batch(bytes(hashes), bytes(sigs), bytes(pubs), _sz(n), codes,
+                                         ctypes.c_int(nthreads))
+        return list(codes)
+
+    # --- mixed
+    def mixed_batch(self, msgs, msg_len, key, nthreads=1):
+        n = len(msgs) // msg_len if msg_len else 0
+        dig = ctypes.create_string_buffer(64 * n)
+        tag = ctypes.create_string_buffer(8 * n)
+        self.lib.orc_bash512_beltMAC_batch(bytes(msgs), _sz(msg_len), _sz(n), bytes(key),
+                                           _sz(len(key)), dig, tag, ctypes.c_int(nthreads))
+        return dig.raw, tag.raw
+
+    def fill(self, nbytes, seed):
+        buf = ctypes.create_string_buffer(nbytes)
+        self.lib.orc_fill_splitmix64(buf, _sz(nbytes), ctypes.c_uint64(seed))
+        return buf.raw
+
+    def fill_np(self, arr, seed):
+        self.lib.orc_fill_splitmix64(ctypes.c_void_p(arr.ctypes.data), _sz(arr.nbytes),
+                                     ctypes.c_uint64(seed))
+
+
+_cached = None
+
+
+def load():
+    global _cached
+    if _cached is None:
+        if not os.path.exists(ORC_SO):
+            build()
+        _cached = Oracle(ctypes.CDLL(ORC_SO))
+    return _cached
+
+
+class Golden:
+    """committed fixtures written by tools/make_golden.py (outputs of the reference)"""
+
+    def __init__(self):
+        with open(os.path.join(GOLD, "stb_kat.json")) as f:
+            self.kat = json.load(f)
+        with open(os.path.join(GOLD, "belt_bash_random.json")) as f:
+            self.belt_bash = json.load(f)
+        with open(os.path.join(GOLD, "bign_edge.json")) as f:
+            self.bign_edge = json.load(f)
+        with open(os.path.join(GOLD, "bash256_1MiB.json")) as f:
+            self.big = json.load(f)
+        raw = open(os.path.join(GOLD, "bashf_random.bin"), "rb").read()
+        self.bashf_in, self.bashf_out = raw[: len(raw) // 2], raw[len(raw) // 2:]
+        raw = open(os.path.join(GOLD, "bign_base.bin"), "rb").read()
+        self.bign_base = [(raw[i:i + 32], raw[i + 32:i + 80], raw[i + 80:i + 144])
+                          for i in range(0, len(raw), 144)]
+        self.H = bytes.fromhex(self.kat["beltH"])
+
+    def bign_base_arrays(self):
+        hs = b"".join(t[0] for t in self.bign_base)
+        ss = b"".join(t[1] for t in self.bign_base)
+        ps = b"".join(t[2] for t in self.bign_base)
+        return hs, ss, ps

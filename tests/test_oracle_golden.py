@@ -1,0 +1,107 @@
+"""CPU tests: the oracle (oracle/liboracle.so) against the committed golden vectors,
+i.e. against the STB annex KATs and outputs of the reference itself
+(tools/make_golden.py).  Mirrors test/crypto/{bash,belt,bign,bign128}_test.c."""
+
+
+def test_belt_sbox_matches_standard(orc, golden):
+    assert orc.beltH() == golden.H                    # belt_test.c:174-177
+
+
+def test_bashF_A2(orc, golden):
+    k = golden.kat["bashF_A2"]                        # bash_test.c:41-57
+    assert orc.bashF(bytes.fromhex(k["in"])).hex() == k["out"]
+
+
+def test_bashF_random_batch(orc, golden):
+    assert orc.bashF_batch(golden.bashf_in) == golden.bashf_out
+    assert orc.bashF_batch(golden.bashf_in, nthreads=4) == golden.bashf_out
+
+
+def test_bash_hash_A3(orc, golden):
+    for k in golden.kat["bash_hash"]:                 # bash_test.c:58-154
+        code, d = orc.bashHash(k["l"], golden.H[: k["len"]])
+        assert code == 0 and d.hex() == k["out"], k["name"]
+        n = k["len"]
+        assert orc.bashHash_steps(k["l"], golden.H[:n], [n // 3, n - n // 3]).hex() == k["out"]
+
+
+def test_bash_hash_bad_level(orc):
+    assert orc.bashHash(0, b"")[0] == 502             # ERR_BAD_PARAMS, bash_hash.c:122-123
+    assert orc.bashHash(24, b"")[0] == 502
+    assert orc.bashHash(272, b"")[0] == 502
+
+
+def test_belt_block_A1(orc, golden):
+    k = golden.kat["belt_block_A1"]                   # belt_test.c:178-184
+    assert orc.block_encr(bytes.fromhex(k["in"]), bytes.fromhex(k["key"])).hex() == k["out"]
+
+
+def test_belt_ctr_A15_A16(orc, golden):
+    for k in golden.kat["belt_ctr"]:                  # belt_test.c:423-451
+        msg, key, iv = (bytes.fromhex(k[x]) for x in ("in", "key", "iv"))
+        assert orc.ctr(msg, key, iv, k["splits"]).hex() == k["out"], k["name"]
+        assert orc.ctr(msg, key, iv).hex() == k["out"]
+
+
+def test_belt_mac_A17(orc, golden):
+    for k in golden.kat["belt_mac"]:                  # belt_test.c:452-472
+        msg, key = bytes.fromhex(k["in"]), bytes.fromhex(k["key"])
+        assert orc.mac(msg, key).hex() == k["out"]
+        assert orc.mac_steps(msg, key, [len(msg) // 2, len(msg) - len(msg) // 2]).hex() == k["out"]
+
+
+def test_belt_hash_A23(orc, golden):
+    for k in golden.kat["belt_hash"]:                 # belt_test.c:593-627
+        assert orc.belt_hash(golden.H[: k["len"]]).hex() == k["out"]
+
+
+def test_belt_bash_random_cases(orc, golden):
+    for c in golden.belt_bash:
+        msg, key, iv = (bytes.fromhex(c[x]) for x in ("msg", "key", "iv"))
+        assert orc.ctr(msg, key, iv, c["splits"]).hex() == c["ctr"]
+        assert orc.ctr(msg, key, iv).hex() == c["ctr"]
+        assert orc.mac(msg, key).hex() == c["mac"]
+        assert orc.mac_steps(msg, key, c["splits"]).hex() == c["mac"]
+        assert orc.belt_hash(msg).hex() == c["belt_hash"]
+        assert orc.bashHash(128, msg)[1].hex() == c["bash256"]
+        assert orc.bashHash(192, msg)[1].hex() == c["bash384"]
+        assert orc.bashHash(256, msg)[1].hex() == c["bash512"]
+        assert orc.bashHash_steps(256, msg, c["splits"]).hex() == c["bash512"]
+
+
+def test_config0_bash256_1MiB(orc, golden):
+    """BASELINE.json configs[0]: bash256 of a 1 MiB buffer on the CPU path."""
+    big = orc.fill(golden.big["len"], golden.big["seed"])
+    assert orc.bashHash(128, big)[1].hex() == golden.big["bash256"]
+    assert orc.bashHash(256, big)[1].hex() == golden.big["bash512"]
+    assert orc.belt_hash(big).hex() == golden.big["belt_hash"]
+    assert orc.mac(big, golden.H[128:160]).hex() == golden.big["belt_mac_keyA17"]
+
+
+def test_bign_G2_G3(orc, golden):
+    for k in golden.kat["bign_verify"]:               # bign_test.c:338-357,388-400
+        got = orc.verify(*(bytes.fromhex(k[x]) for x in ("hash", "sig", "pubkey")))
+        assert got == k["code"], k["name"]
+
+
+def test_bign_edge_cases(orc, golden):
+    for k in golden.bign_edge:
+        got = orc.verify(*(bytes.fromhex(k[x]) for x in ("hash", "sig", "pubkey")))
+        assert got == k["code"], k["name"]
+
+
+def test_bign_base_batch(orc, golden):
+    hs, ss, ps = golden.bign_base_arrays()
+    n = 512
+    codes = orc.verify_batch(hs[: 32 * n], ss[: 48 * n], ps[: 64 * n], nthreads=4)
+    assert codes == [0] * n
+
+
+def test_mixed_batch_matches_single(orc, golden):
+    msgs = orc.fill(8 * 4096, 0x4D1C)
+    key = golden.H[128:160]
+    dig, tag = orc.mixed_batch(msgs, 4096, key, nthreads=2)
+    for i in range(8):
+        m = msgs[4096 * i: 4096 * (i + 1)]
+        assert dig[64 * i: 64 * i + 64] == orc.bashHash(256, m)[1]
+        assert tag[8 * i: 8 * i + 8] == orc.mac(m, key)

@@ -1,0 +1,89 @@
+"""CPU tests, build container only: the oracle restatement against the REFERENCE itself
+(oracle/_ref/libbee2ref.so = agievich/bee2 compiled by oracle/Makefile) on seeded random
+inputs.  Skipped where _ref is absent.  tools/pin_oracle.py runs the same comparison at
+>= 1e5 items per primitive."""
+import ctypes
+import random
+
+import pytest
+
+import refgen
+
+pytestmark = pytest.mark.skipif(not refgen.have_ref(), reason="oracle/_ref not built")
+_sz = ctypes.c_size_t
+
+
+def test_bashF_100k_states(orc):
+    L = refgen.ref()
+    n = 100_000
+    data = orc.fill(192 * n, 0xBA5F)
+    ref = ctypes.create_string_buffer(data, len(data))
+    base = ctypes.addressof(ref)
+    for i in range(n):
+        L.bashF(ctypes.c_void_p(base + 192 * i), None)
+    assert orc.bashF_batch(data, nthreads=4) == ref.raw
+
+
+def test_belt_ctr_100k_blocks(orc):
+    L = refgen.ref()
+    n = 100_000
+    data = orc.fill(16 * n + 5, 0xBE17)
+    H = orc.beltH()
+    out = ctypes.create_string_buffer(len(data))
+    assert L.beltCTR(out, data, _sz(len(data)), H[128:160], _sz(32), H[192:208]) == 0
+    assert orc.ctr(data, H[128:160], H[192:208]) == out.raw
+    # block-indexed form used by the GPU sharding: E_K(ctr0 + first + i + 1)
+    import numpy as np
+    key_w, ctr0_w = orc.ctr_start(H[128:160], H[192:208])
+    arr = np.frombuffer(data[16 * 1000: 16 * 3000], dtype=np.uint8).copy()
+    orc.ctr_blocks_np(arr, key_w, ctr0_w, first=1000, nthreads=3)
+    assert arr.tobytes() == out.raw[16 * 1000: 16 * 3000]
+
+
+def test_belt_mac_hash_random(orc):
+    L = refgen.ref()
+    rnd = random.Random(5)
+    for _ in range(2000):
+        n = rnd.choice((0, 1, 15, 16, 17, 32, 33, 64, 75, 100, 256, 1000))
+        msg, key = rnd.randbytes(n), rnd.randbytes(rnd.choice((16, 24, 32)))
+        a = ctypes.create_string_buffer(8)
+        L.beltMAC(a, msg, _sz(n), key, _sz(len(key)))
+        assert a.raw == orc.mac(msg, key)
+        a = ctypes.create_string_buffer(32)
+        L.beltHash(a, msg, _sz(n))
+        assert a.raw == orc.belt_hash(msg)
+
+
+def test_bash_hash_random(orc):
+    L = refgen.ref()
+    rnd = random.Random(6)
+    for _ in range(1500):
+        l = rnd.choice(range(16, 257, 16))
+        n = rnd.choice((0, 1, 63, 64, 65, 95, 96, 127, 128, 129, 191, 192, 193, 500, 4096))
+        msg = rnd.randbytes(n)
+        a = ctypes.create_string_buffer(l // 4)
+        assert L.bashHash(a, _sz(l), msg, _sz(n)) == 0
+        assert a.raw == orc.bashHash(l, msg)[1]
+
+
+def test_verify_random_and_corrupted(orc):
+    rnd = random.Random(7)
+    triples = refgen.make_triples(1500, 0x1234)
+    seen = set()
+    for i, (h, s, p) in enumerate(triples):
+        kind = i % 6
+        h, s, p = bytearray(h), bytearray(s), bytearray(p)
+        if kind == 1:
+            s[rnd.randrange(16)] ^= 1 << rnd.randrange(8)
+        elif kind == 2:
+            s[16 + rnd.randrange(32)] ^= 1 << rnd.randrange(8)
+        elif kind == 3:
+            h[rnd.randrange(32)] ^= 1 << rnd.randrange(8)
+        elif kind == 4:
+            p[rnd.randrange(64)] ^= 1 << rnd.randrange(8)
+        elif kind == 5:
+            p[31] |= 0xFF; p[30] = 0xFF; p[24:30] = b"\xff" * 6
+        want = refgen.verify(bytes(h), bytes(s), bytes(p))
+        assert orc.verify(h, s, p) == want, (i, kind)
+        seen.add(want)
+    assert seen >= {0, 510}

@@ -1,0 +1,366 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REFERENCE itself (oracle/_ref/libbee2ref.so,
+compiled from /root/reference by oracle/Makefile).  Build-container only; the
+fixtures it writes are data (inputs + expected outputs) and are committed.
+
+    python tools/make_golden.py
+
+STB hex strings below are the standards' annex vectors as held by the reference's
+own tests (test/crypto/bash_test.c:41-154, belt_test.c:178-215,423-472,593-627,
+bign_test.c:303-357,388-400, bign128_test.c:101-163); the script re-derives each
+one with the reference and refuses to write a fixture that disagrees.
+"""
+import ctypes
+import json
+import os
+import struct
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import refgen  # noqa: E402
+
+ROOT = refgen.ROOT
+GOLD = os.path.join(ROOT, "tests", "golden")
+_sz = ctypes.c_size_t
+L = refgen.ref()
+H = refgen.beltH()
+
+Q_ORDER = int.from_bytes(bytes.fromhex(
+    "07663D2699BF5A7EFC4DFB0DD68E5CD9FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF"), "little")
+P_FIELD = 2 ** 256 - 189
+
+
+def splitmix_bytes(n, seed):
+    out = bytearray()
+    i = 0
+    M = (1 << 64) - 1
+    while len(out) < n:
+        z = (seed + (i + 1) * 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z ^= z >> 31
+        out += struct.pack("<Q", z)
+        i += 1
+    return bytes(out[:n])
+
+
+# ----------------------------------------------------------------------------- helpers
+def r_bashF(state):
+    b = ctypes.create_string_buffer(state, 192)
+    L.bashF(b, None)
+    return b.raw
+
+
+def r_bashHash(l, msg):
+    out = ctypes.create_string_buffer(l // 4)
+    assert L.bashHash(out, _sz(l), msg, _sz(len(msg))) == 0
+    return out.raw
+
+
+def r_keyexpand(key):
+    k = (ctypes.c_uint32 * 8)()
+    L.beltKeyExpand2(k, key, _sz(len(key)))
+    return k
+
+
+def r_block_encr(block, key):
+    b = ctypes.create_string_buffer(block, 16)
+    L.beltBlockEncr(b, r_keyexpand(key))
+    return b.raw
+
+
+def r_ctr(msg, key, iv, splits=None):
+    st = ctypes.create_string_buffer(L.beltCTR_keep())
+    L.beltCTR_keep.restype = _sz
+    st = ctypes.create_string_buffer(L.beltCTR_keep())
+    L.beltCTRStart(st, key, _sz(len(key)), iv)
+    buf = ctypes.create_string_buffer(msg, len(msg))
+    if splits is None:
+        splits = [len(msg)]
+    off = 0
+    for s in splits:
+        L.beltCTRStepE(ctypes.byref(buf, off), _sz(s), st)
+        off += s
+    assert off == len(msg)
+    return buf.raw
+
+
+def r_mac(msg, key):
+    out = ctypes.create_string_buffer(8)
+    assert L.beltMAC(out, msg, _sz(len(msg)), key, _sz(len(key))) == 0
+    return out.raw
+
+
+def r_belt_hash(msg):
+    out = ctypes.create_string_buffer(32)
+    assert L.beltHash(out, msg, _sz(len(msg))) == 0
+    return out.raw
+
+
+def check(name, got, want_hex):
+    if got.hex().upper() != want_hex.upper():
+        raise SystemExit(f"reference disagrees with STB vector {name}: {got.hex()} != {want_hex}")
+
+
+# ----------------------------------------------------------------------------- STB KATs
+def stb_kats():
+    kat = {"beltH": H.hex()}
+    # STB 34.101.77 A.2 / A.3
+    a2 = ("8FE727775EA7F140B95BB6A200CBB28C7F0809C0C0BC68B7DC5AEDC841BD94E4"
+          "03630C301FC255DF5B67DB53EF65E376E8A4D797A6172F2271BA48093173D329"
+          "C3502AC946767326A2891971392D3F7089959F5D61621238655975E00E2132A0"
+          "D5018CEEDB17731CCD88FC50151D37C0D4A3359506AEDC2E6109511E7703AFBB"
+          "014642348D8568AA1A5D9868C4C7E6DFA756B1690C7C2608A2DC136F5997AB8F"
+          "BB3F4D9F033C87CA6070E117F099C4094972ACD9D976214B7CED8E3F8B6E058E")
+    check("77/A.2", r_bashF(H[:192]), a2)
+    kat["bashF_A2"] = {"in": H[:192].hex(), "out": a2.lower()}
+    bash = [
+        ("A.3.1", 128, 0, "114C3DFAE373D9BCBC3602D6386F2D6A2059BA1BF9048DBAA5146A6CB775709D"),
+        ("A.3.2", 128, 127, "3D7F4EFA00E9BA33FEED259986567DCF5C6D12D51057A968F14F06CC0F905961"),
+        ("A.3.3", 128, 128, "D7F428311254B8B2D00F7F9EEFBD8F3025FA87C4BABD1BDDBE87E35B7AC80DD6"),
+        ("A.3.4", 128, 135, "1393FA1B65172F2D18946AEAE576FA1CF54FDD354A0CB2974A997DC4865D3100"),
+        ("A.3.5", 192, 95, "64334AF830D33F63E9ACDFA184E32522103FFF5C6860110A2CD369EDBC04387C"
+                           "501D8F92F749AE4DE15A8305C353D64D"),
+        ("A.3.6", 192, 96, "D06EFBC16FD6C0880CBFC6A4E3D65AB101FA82826934190FAABEBFBFFEDE93B2"
+                           "2B85EA72A7FB3147A133A5A8FEBD8320"),
+        ("A.3.7", 192, 108, "FF763296571E2377E71A1538070CC0DE88888606F32EEE6B082788D246686B00"
+                            "FC05A17405C5517699DA44B7EF5F55AB"),
+        ("A.3.8", 256, 63, "2A66C87C189C12E255239406123BDEDBF19955EAF0808B2AD705E249220845E2"
+                           "0F4786FB6765D0B5C48984B1B16556EF19EA8192B985E4233D9C09508D6339E7"),
+        ("A.3.9", 256, 64, "07ABBF8580E7E5A321E9B940F667AE209E2952CEF557978AE743DB086BAB4885"
+                           "B708233C3F5541DF8AAFC3611482FDE498E58B3379A6622DAC2664C9C118A162"),
+        ("A.3.10", 256, 127, "526073918F97928E9D15508385F42F03ADE3211A23900A30131F8A1E3E1EE21C"
+                             "C09D13CFF6981101235D895746A4643F0AA62B0A7BC98A269E4507A257F0D4EE"),
+        ("A.3.11", 256, 192, "8724C7FF8A2A83F22E38CB9763777B96A70ABA3444F214C763D93CD6D19FCFDE"
+                             "6C3D3931857C4FF6CCCD49BD99852FE9EAA7495ECCDD96B571E0EDCF47F89768"),
+    ]
+    kat["bash_hash"] = []
+    for name, l, n, want in bash:
+        check("77/" + name, r_bashHash(l, H[:n]), want)
+        kat["bash_hash"].append({"name": name, "l": l, "len": n, "out": want.lower()})
+    # STB 34.101.31 A.1 block, A.15/A.16 CTR, A.17 MAC, A.23 hash
+    check("31/A.1", r_block_encr(H[:16], H[128:160]), "69CCA1C93557C9E3D66BC3E0FA88FA6E")
+    kat["belt_block_A1"] = {"in": H[:16].hex(), "key": H[128:160].hex(),
+                            "out": "69cca1c93557c9e3d66bc3e0fa88fa6e"}
+    a15 = "52C9AF96FF50F64435FC43DEF56BD797D5B5B1FF79FB41257AB9CDF6E63E81F8F00341473EAE409833622DE05213773A"
+    check("31/A.15", r_ctr(H[:48], H[128:160], H[192:208], [15, 7, 26]), a15)
+    a16 = "DF181ED008A20F43DCBBB93650DAD34B389CDEE5826D40E2D4BD80F49A93F5D212F6333166456F169043CC5F"
+    check("31/A.16", r_ctr(H[64:108], H[160:192], H[208:224], [11, 5, 28]), a16)
+    kat["belt_ctr"] = [
+        {"name": "A.15", "in": H[:48].hex(), "key": H[128:160].hex(), "iv": H[192:208].hex(),
+         "splits": [15, 7, 26], "out": a15.lower()},
+        {"name": "A.16", "in": H[64:108].hex(), "key": H[160:192].hex(), "iv": H[208:224].hex(),
+         "splits": [11, 5, 28], "out": a16.lower()},
+    ]
+    check("31/A.17-1", r_mac(H[:13], H[128:160]), "7260DA60138F96C9")
+    check("31/A.17-2", r_mac(H[:48], H[128:160]), "2DAB59771B4B16D0")
+    kat["belt_mac"] = [
+        {"name": "A.17-1", "in": H[:13].hex(), "key": H[128:160].hex(), "out": "7260da60138f96c9"},
+        {"name": "A.17-2", "in": H[:48].hex(), "key": H[128:160].hex(), "out": "2dab59771b4b16d0"},
+    ]
+    hv = [("A.23-1", 13, "ABEF9725D4C5A83597A367D14494CC2542F20F659DDFECC961A3EC550CBA8C75"),
+          ("A.23-2", 32, "749E4C3653AECE5E48DB4761227742EB6DBE13F4A80F7BEFF1A9CF8D10EE7786"),
+          ("A.23-3", 48, "9D02EE446FB6A29FE5C982D4B13AF9D3E90861BC4CEF27CF306BFB0B174A154A")]
+    kat["belt_hash"] = []
+    for name, n, want in hv:
+        check("31/" + name, r_belt_hash(H[:n]), want)
+        kat["belt_hash"].append({"name": name, "len": n, "out": want.lower()})
+    # STB 34.101.45 G.1 key pair, G.2 / G.3 signatures (+ the tests' bit-flip negatives)
+    priv = bytes.fromhex("1F66B5B84B7339674533F0329C74F21834281FED0732429E0C79235FC273E269")
+    pub = bytes.fromhex("BD1A5650179D79E03FCEE49D4C2BD5DDF54CE46D0CF11E4FF87BF7A890857FD0"
+                        "7AC6A60361E8C8173491686D461B2826190C2EDA5909054A9AB84D2AB9D99A90")
+    pc = ctypes.create_string_buffer(64)
+    assert L.bign128PubkeyCalc(pc, priv) == 0
+    check("45/G.1", pc.raw, pub.hex())
+    sigs = [("G.2", 13, "E36B7F0377AE4C524027C387FADF1B20CE72F1530B71F2B5FD3A8C584FE2E1AE"
+                        "D20082E30C8AF65011F4FB54649DFD3D"),
+            ("G.3", 48, "47A63C8B9C936E94B5FAB3D9CBD78366290F3210E163EEC8DB4E921E8479D413"
+                        "8F112CC23E6DCE65EC5FF21DF4231C28")]
+    kat["bign_verify"] = []
+    for name, n, sighex in sigs:
+        h = r_belt_hash(H[:n])
+        sig = bytes.fromhex(sighex)
+        assert refgen.verify(h, sig, pub) == 0, name
+        s_bad = bytes([sig[0] ^ 1]) + sig[1:]
+        p_bad = bytes([pub[0] ^ 1]) + pub[1:]
+        for tag, hh, ss, pp in ((name, h, sig, pub), (name + "/sig^1", h, s_bad, pub),
+                                (name + "/pub^1", h, sig, p_bad)):
+            kat["bign_verify"].append({"name": tag, "hash": hh.hex(), "sig": ss.hex(),
+                                       "pubkey": pp.hex(), "code": refgen.verify(hh, ss, pp)})
+    assert [k["code"] for k in kat["bign_verify"]] == [0, 510, 510, 0, 510, 510]
+    return kat
+
+
+# ----------------------------------------------------------------------------- random batches
+def bashf_random(n=256, seed=0xBA5F):
+    inp = splitmix_bytes(192 * n, seed)
+    inp = H[:192] + inp[192:]                      # slot 0 = STB A.2 input
+    out = b"".join(r_bashF(inp[192 * i:192 * (i + 1)]) for i in range(n))
+    return inp, out
+
+
+def belt_random(seed=0xBE17):
+    import random
+    rnd = random.Random(seed)
+    cases = []
+    lens = [0, 1, 15, 16, 17, 31, 32, 33, 47, 48, 63, 64, 65, 100, 255, 256, 257, 1000, 4096]
+    for i, n in enumerate(lens):
+        klen = (16, 24, 32)[i % 3]
+        key = rnd.randbytes(klen)
+        iv = rnd.randbytes(16)
+        msg = rnd.randbytes(n)
+        splits, left = [], n
+        while left:
+            s = min(left, rnd.choice((1, 3, 7, 15, 16, 17, 32, 100)))
+            splits.append(s)
+            left -= s
+        cases.append({"key": key.hex(), "iv": iv.hex(), "msg": msg.hex(), "splits": splits,
+                      "ctr": r_ctr(msg, key, iv, splits).hex(), "mac": r_mac(msg, key).hex(),
+                      "belt_hash": r_belt_hash(msg).hex(),
+                      "bash256": r_bashHash(128, msg).hex(), "bash384": r_bashHash(192, msg).hex(),
+                      "bash512": r_bashHash(256, msg).hex()})
+    return cases
+
+
+def int_le(x, n):
+    return x.to_bytes(n, "little")
+
+
+OID_DER = bytes.fromhex("06092A7000020022651F51")
+G_Y = int.from_bytes(bytes.fromhex(
+    "936A510418CF291E52F608C4663991785D83D651A3C9E45C9FD616FB3CFCF76B"), "little")
+
+
+def py_mul_base_x(k):
+    """x(kG) on bign-curve256v1 with affine big-int arithmetic (fixture signer only)."""
+    p = P_FIELD
+
+    def add(P, Q):
+        if P is None:
+            return Q
+        if Q is None:
+            return P
+        (x1, y1), (x2, y2) = P, Q
+        if x1 == x2:
+            if (y1 + y2) % p == 0:
+                return None
+            lam = (3 * x1 * x1 - 3) * pow(2 * y1, -1, p) % p
+        else:
+            lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+        x3 = (lam * lam - x1 - x2) % p
+        return x3, (lam * (x1 - x3) - y1) % p
+
+    R, B = None, (0, G_Y)
+    while k:
+        if k & 1:
+            R = add(R, B)
+        B = add(B, B)
+        k >>= 1
+    return R[0]
+
+
+def bign_sets(seed=0xB164, n_base=2048):
+    """base: n_base genuine triples.  edge: crafted cases that hit the exceptional
+    branches (Q = +-G, small multiples, R = O, s1 >= q, coordinate >= p, off-curve Q,
+    hash >= q), each with the code the reference returns."""
+    import random
+    rnd = random.Random(seed)
+    base = refgen.make_triples(n_base, seed & 0xFFFFFFFF)
+    codes = [refgen.verify(*t) for t in base]
+    assert all(c == 0 for c in codes)
+    edge = []
+
+    def add(name, h, s, p):
+        edge.append({"name": name, "hash": h.hex(), "sig": s.hex(), "pubkey": p.hex(),
+                     "code": refgen.verify(h, s, p)})
+
+    # small / extreme private keys: Q = dG makes the two NAF tables collide inside ecAddMulA
+    for d in (1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 33, Q_ORDER - 1, Q_ORDER - 2, Q_ORDER - 3,
+              Q_ORDER - 16, (Q_ORDER + 1) // 2, 2 ** 128, 2 ** 128 + 1, 2 ** 129 - 1):
+        priv = int_le(d, 32)
+        pub = ctypes.create_string_buffer(64)
+        assert L.bign128PubkeyCalc(pub, priv) == 0
+        for k in range(3):
+            h = rnd.randbytes(32)
+            sig = refgen.sign2(h, priv)
+            add(f"d={d if d < 2**64 else hex(d)}/valid{k}", h, sig, pub.raw)
+            bad = bytearray(sig)
+            bad[rnd.randrange(48)] ^= 1 << rnd.randrange(8)
+            add(f"d={d if d < 2**64 else hex(d)}/flip{k}", h, bytes(bad), pub.raw)
+        # R = O: pick s0, force s1 = -(s0 + 2^128) d - H  (mod q)
+        for k in range(2):
+            h = rnd.randbytes(32)
+            s0 = rnd.getrandbits(128)
+            hh = int.from_bytes(h, "little")
+            if hh >= Q_ORDER:
+                hh -= Q_ORDER
+            s1 = (-(s0 + 2 ** 128) * d - hh) % Q_ORDER
+            add(f"d={d if d < 2**64 else hex(d)}/R=O{k}", h, int_le(s0, 16) + int_le(s1, 32), pub.raw)
+    # range checks
+    t = base[0]
+    add("s1=q", t[0], t[1][:16] + int_le(Q_ORDER, 32), t[2])
+    add("s1=q-1", t[0], t[1][:16] + int_le(Q_ORDER - 1, 32), t[2])
+    add("s1=2^256-1", t[0], t[1][:16] + b"\xff" * 32, t[2])
+    add("s1=0", t[0], t[1][:16] + bytes(32), t[2])
+    add("s0=0,s1=0", t[0], bytes(48), t[2])
+    add("xQ=p", t[0], t[1], int_le(P_FIELD, 32) + t[2][32:])
+    add("yQ=p", t[0], t[1], t[2][:32] + int_le(P_FIELD, 32))
+    add("xQ=p-1", t[0], t[1], int_le(P_FIELD - 1, 32) + t[2][32:])
+    add("xQ=2^256-1", t[0], t[1], b"\xff" * 32 + t[2][32:])
+    add("Q=(0,0)", t[0], t[1], bytes(64))
+    add("Q=(0,1)", t[0], t[1], bytes(32) + int_le(1, 32))
+    add("Q=(1,0)", t[0], t[1], int_le(1, 32) + bytes(32))
+    # hash >= q still verifies (one conditional subtraction, bign_sign.c:320-327).  The
+    # reference SIGNER requires H < q (zzSubMod precondition), so these are signed here with
+    # big-int arithmetic (STB 34.101.45 7.1.3) and only VERIFIED by the reference.
+    priv, pub = refgen.keypair(refgen.Combo(99))
+    d = int.from_bytes(priv, "little")
+    for hv in (Q_ORDER, Q_ORDER + 5, 2 ** 256 - 1, Q_ORDER - 1, 0):
+        h = int_le(hv, 32)
+        k = rnd.randrange(1, Q_ORDER)
+        rx = py_mul_base_x(k)
+        s0 = int.from_bytes(r_belt_hash(OID_DER + int_le(rx, 32) + h)[:16], "little")
+        s1 = (k - (s0 + 2 ** 128) * d - hv) % Q_ORDER
+        add(f"H={hex(hv)[:12]}", h, int_le(s0, 16) + int_le(s1, 32), pub)
+    # seeded bit-flip negatives over the base set (the bench recipe)
+    for i in range(0, 256):
+        h, s, p = (bytearray(x) for x in base[i])
+        kind = i % 4
+        tgt = (s, s, h, p)[kind]
+        lo, hi = ((0, 16), (16, 48), (0, 32), (0, 64))[kind]
+        tgt[rnd.randrange(lo, hi)] ^= 1 << rnd.randrange(8)
+        add(f"flip{i}/k{kind}", bytes(h), bytes(s), bytes(p))
+    return base, edge
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    with open(os.path.join(GOLD, "stb_kat.json"), "w") as f:
+        json.dump(stb_kats(), f, indent=1)
+    inp, out = bashf_random()
+    with open(os.path.join(GOLD, "bashf_random.bin"), "wb") as f:
+        f.write(inp + out)
+    with open(os.path.join(GOLD, "belt_bash_random.json"), "w") as f:
+        json.dump(belt_random(), f, indent=1)
+    base, edge = bign_sets()
+    with open(os.path.join(GOLD, "bign_base.bin"), "wb") as f:      # n x (hash32 | sig48 | pub64)
+        for h, s, p in base:
+            f.write(h + s + p)
+    with open(os.path.join(GOLD, "bign_edge.json"), "w") as f:
+        json.dump(edge, f, indent=1)
+    # H0: bash256 of 1 MiB (config[0])
+    big = splitmix_bytes(1 << 20, 0xBA5F)
+    with open(os.path.join(GOLD, "bash256_1MiB.json"), "w") as f:
+        json.dump({"seed": 0xBA5F, "len": 1 << 20, "gen": "splitmix64 LE words, x_i = mix(seed+(i+1)*golden)",
+                   "bash256": r_bashHash(128, big).hex(), "bash512": r_bashHash(256, big).hex(),
+                   "belt_hash": r_belt_hash(big).hex(),
+                   "belt_mac_keyA17": r_mac(big, H[128:160]).hex()}, f, indent=1)
+    from collections import Counter
+    print("edge codes:", Counter(e["code"] for e in edge))
+    print("golden written to", GOLD)
+
+
+if __name__ == "__main__":
+    if not refgen.have_ref():
+        raise SystemExit("oracle/_ref/libbee2ref.so missing: run `make -C oracle ref` in the build container")
+    main()
