@@ -1,0 +1,142 @@
+// bash_dev.hpp -- bash-f (STB 34.101.77) for one CDNA4 lane.
+//
+// Replaces bee2's bashF (include/bee2/crypto/bash.h:136; bodies
+// src/crypto/bash/bash_f64.c:142-187, bash_favx512.c:236-249).
+//
+// MI355X mapping: one wavefront lane owns one 1536-bit state = 24 x u64 held as
+// 48 x 32-bit VGPRs (lo/hi halves).  gfx950 has no 64-bit rotate, so rotl64 by a
+// constant is two v_alignbit_b32; the three-input S-box logic maps to
+// v_bitop3_b32 / v_xor3_b32.  The word permutation of each round is pure
+// register renaming: rounds are unrolled in groups of 6 (the permutation has
+// order 6), so after each group the words are back in canonical slots and no
+// v_mov is ever issued.  Round constants come from the LFSR recurrence
+// (bash_f64.c:50-59) evaluated on the scalar unit (wave-uniform).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bee2hip {
+
+struct u64x2 { uint32_t lo, hi; };
+
+__device__ __forceinline__ u64x2 rotl64c(u64x2 x, int n)
+{
+    // n is a compile-time constant in 1..63, never 32 on this path
+    u64x2 r;
+    if (n < 32) {
+        r.lo = __builtin_amdgcn_alignbit(x.lo, x.hi, 32 - n);   // (lo << n) | (hi >> (32-n))
+        r.hi = __builtin_amdgcn_alignbit(x.hi, x.lo, 32 - n);
+    } else if (n == 32) {
+        r.lo = x.hi; r.hi = x.lo;
+    } else {
+        r.lo = __builtin_amdgcn_alignbit(x.hi, x.lo, 64 - n);
+        r.hi = __builtin_amdgcn_alignbit(x.lo, x.hi, 64 - n);
+    }
+    return r;
+}
+
+// 3-input boolean function by truth table (v_bitop3_b32); table = f(0xF0, 0xCC, 0xAA)
+template <int TT>
+__device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+}
+constexpr int TT_XOR3 = 0xF0 ^ 0xCC ^ 0xAA;                       // a ^ b ^ c
+constexpr int TT_S0 = 0xF0 ^ ((~0xAA & 0xFF) | 0xCC);             // a ^ (~c | b)
+constexpr int TT_S1 = 0xCC ^ (0xF0 | 0xAA);                       // b ^ (a | c)
+constexpr int TT_S2 = 0xAA ^ (0xF0 & 0xCC);                       // c ^ (a & b)
+
+// column S-box, bash_f64.c:32-44 / bash_favx512.c:124-132.
+// 8 v_alignbit + 4 v_xor + 10 v_bitop3 = 22 VALU ops per column.
+template <int M1, int N1, int M2, int N2>
+__device__ __forceinline__ void bash_s(u64x2 &w0, u64x2 &w1, u64x2 &w2)
+{
+    u64x2 u0, t, u1, u2, r, r2;
+    u0.lo = bitop3<TT_XOR3>(w0.lo, w1.lo, w2.lo);
+    u0.hi = bitop3<TT_XOR3>(w0.hi, w1.hi, w2.hi);
+    r = rotl64c(u0, N1);  t.lo = w1.lo ^ r.lo;  t.hi = w1.hi ^ r.hi;
+    r = rotl64c(w0, M1);  u1.lo = t.lo ^ r.lo;  u1.hi = t.hi ^ r.hi;
+    r = rotl64c(w2, M2);
+    r2 = rotl64c(t, N2);
+    u2.lo = bitop3<TT_XOR3>(w2.lo, r.lo, r2.lo);
+    u2.hi = bitop3<TT_XOR3>(w2.hi, r.hi, r2.hi);
+    w0.lo = bitop3<TT_S0>(u0.lo, u1.lo, u2.lo);  w0.hi = bitop3<TT_S0>(u0.hi, u1.hi, u2.hi);
+    w1.lo = bitop3<TT_S1>(u0.lo, u1.lo, u2.lo);  w1.hi = bitop3<TT_S1>(u0.hi, u1.hi, u2.hi);
+    w2.lo = bitop3<TT_S2>(u0.lo, u1.lo, u2.lo);  w2.hi = bitop3<TT_S2>(u0.hi, u1.hi, u2.hi);
+}
+
+// S-layer over the 8 columns; row r of the 3x8 matrix is s[8r .. 8r+7]
+__device__ __forceinline__ void bash_s_layer(u64x2 (&a)[24], const int (&ix)[24])
+{
+    // ix[k] = register slot currently holding logical word k
+    bash_s< 8, 53, 14,  1>(a[ix[0]], a[ix[ 8]], a[ix[16]]);
+    bash_s<56, 51, 34,  7>(a[ix[1]], a[ix[ 9]], a[ix[17]]);
+    bash_s< 8, 37, 46, 49>(a[ix[2]], a[ix[10]], a[ix[18]]);
+    bash_s<56,  3,  2, 23>(a[ix[3]], a[ix[11]], a[ix[19]]);
+    bash_s< 8, 21, 14, 33>(a[ix[4]], a[ix[12]], a[ix[20]]);
+    bash_s<56, 19, 34, 39>(a[ix[5]], a[ix[13]], a[ix[21]]);
+    bash_s< 8,  5, 46, 17>(a[ix[6]], a[ix[14]], a[ix[22]]);
+    bash_s<56, 35,  2, 55>(a[ix[7]], a[ix[15]], a[ix[23]]);
+}
+
+// logical word k of the next round = logical word BASH_PERM[k] of this round:
+// new_row0 = pi1(row1), new_row1 = pi2(row2), new_row2 = pi0(row0)
+// (bash_f64.c:100-134 "P1", explicit in bash_favx512.c:140-171)
+struct BashPerm {
+    int v[24];
+    constexpr BashPerm() : v{} {
+        constexpr int pi0[8] = {6, 3, 0, 5, 2, 7, 4, 1};
+        constexpr int pi1[8] = {7, 2, 1, 4, 3, 6, 5, 0};
+        constexpr int pi2[8] = {1, 0, 3, 2, 5, 4, 7, 6};
+        for (int k = 0; k < 8; ++k) {
+            v[k] = 8 + pi1[k];
+            v[8 + k] = 16 + pi2[k];
+            v[16 + k] = pi0[k];
+        }
+    }
+};
+
+// slot map after r rounds (r = 0..6); map[6] is the identity again
+struct BashSlots {
+    int m[7][24];
+    constexpr BashSlots() : m{} {
+        constexpr BashPerm P{};
+        for (int k = 0; k < 24; ++k) m[0][k] = k;
+        for (int r = 1; r < 7; ++r)
+            for (int k = 0; k < 24; ++k) m[r][k] = m[r - 1][P.v[k]];
+    }
+};
+
+__device__ __forceinline__ uint64_t bash_next_const(uint64_t c)
+{
+    return (c >> 1) ^ (0xDC2BE1997FE0D8AEull & (0ull - (c & 1ull)));
+}
+
+template <int R>
+__device__ __forceinline__ void bash_round(u64x2 (&a)[24], uint64_t &c)
+{
+    constexpr BashSlots S{};
+    bash_s_layer(a, S.m[R]);
+    // after the word permutation the constant lands on logical word 23 of the next round
+    constexpr int slot = S.m[R + 1][23];
+    a[slot].lo ^= (uint32_t)c;
+    a[slot].hi ^= (uint32_t)(c >> 32);
+    c = bash_next_const(c);
+}
+
+// the permutation: 4 x 6 rounds
+__device__ __forceinline__ void bash_f(u64x2 (&a)[24])
+{
+    uint64_t c = 0x3BF5080AC8BA94B1ull;
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {
+        bash_round<0>(a, c);
+        bash_round<1>(a, c);
+        bash_round<2>(a, c);
+        bash_round<3>(a, c);
+        bash_round<4>(a, c);
+        bash_round<5>(a, c);
+    }
+}
+
+}  // namespace bee2hip

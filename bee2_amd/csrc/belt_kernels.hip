@@ -1,0 +1,162 @@
+// belt_kernels.hip -- belt CTR bulk encryption and plain block encryption on gfx950.
+//
+// beltCTR_blocks_kernel : H2 of SURVEY.md 8a.  Replaces the hot loop of
+//   beltCTRStepE (src/crypto/belt/belt_ctr.c:85-97): block i of the stream is
+//   X_i ^ E_K(ctr0 + first + i + 1), the counter being a 128-bit little-endian
+//   integer (beltBlockIncU32, belt_ctr.c:27-35).  Blocks are independent, so one
+//   lane takes one 16-byte block per step; a wavefront reads/writes 1 KiB per
+//   global_load/store_dwordx4 (perfectly coalesced).  Algorithmic traffic:
+//   32 B per block (16 read + 16 written), in place.
+//
+//   Launch shape: persistent, one 1024-thread workgroup per CU (256 total) because
+//   the bank-private S-box tables take 128 KiB of LDS (belt_dev.hpp); the 16
+//   wavefronts per CU (4 per SIMD) hide the ~56 dependent LDS round trips of E_K,
+//   and each lane carries CTR_ILP independent blocks for more overlap.
+//
+// belt_encr_blocks_kernel : E_K over n blocks in place (ctr0 = E_K(iv) of
+//   beltCTRStart, belt_ctr.c:55-64; r = E_K(0) of beltMACStart, belt_mac.c:47-56;
+//   the drop-in beltBlockEncr*).
+#include "belt_dev.hpp"
+#include "common.hpp"
+
+namespace bee2hip {
+
+__constant__ uint8_t c_beltH[256];
+
+constexpr int CTR_WG = 1024;
+constexpr int CTR_ILP = 2;          // independent blocks per lane per step
+
+struct BeltKey { uint32_t k[8]; };
+struct BeltCtr { uint32_t c[4]; };
+
+__device__ __forceinline__ void ctr_at(uint32_t (&x)[4], const BeltCtr &c0, uint64_t add)
+{
+    // (c0 + add) mod 2^128, 64-bit offset
+    const uint64_t lo = ((uint64_t)c0.c[1] << 32) | c0.c[0];
+    const uint64_t hi = ((uint64_t)c0.c[3] << 32) | c0.c[2];
+    const uint64_t nlo = lo + add;
+    const uint64_t nhi = hi + (nlo < lo ? 1u : 0u);
+    x[0] = (uint32_t)nlo; x[1] = (uint32_t)(nlo >> 32);
+    x[2] = (uint32_t)nhi; x[3] = (uint32_t)(nhi >> 32);
+}
+
+__global__ __launch_bounds__(CTR_WG)
+void beltCTR_blocks_kernel(uint4 *__restrict__ buf, size_t nblocks, BeltKey key, BeltCtr ctr0,
+                           uint64_t first, uint4 *__restrict__ last_gamma)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    BeltTabWide::fill(smem, threadIdx.x, CTR_WG);
+    __syncthreads();
+    const BeltTabWide T(smem);
+
+    uint32_t K[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) K[i] = key.k[i];
+
+    // tile = CTR_WG * CTR_ILP consecutive blocks; tiles are dealt round-robin to workgroups
+    const size_t tile = (size_t)CTR_WG * CTR_ILP;
+    for (size_t t0 = (size_t)blockIdx.x * tile; t0 < nblocks; t0 += (size_t)gridDim.x * tile) {
+        uint4 data[CTR_ILP];
+        uint32_t g[CTR_ILP][4];
+        bool live[CTR_ILP];
+#pragma unroll
+        for (int u = 0; u < CTR_ILP; ++u) {
+            const size_t i = t0 + (size_t)u * CTR_WG + threadIdx.x;
+            live[u] = i < nblocks;
+            if (live[u]) data[u] = buf[i];
+            ctr_at(g[u], ctr0, first + i + 1);
+        }
+#pragma unroll
+        for (int u = 0; u < CTR_ILP; ++u) belt_encr(T, g[u], K);
+#pragma unroll
+        for (int u = 0; u < CTR_ILP; ++u) {
+            const size_t i = t0 + (size_t)u * CTR_WG + threadIdx.x;
+            if (live[u]) {
+                uint4 o;
+                o.x = data[u].x ^ g[u][0]; o.y = data[u].y ^ g[u][1];
+                o.z = data[u].z ^ g[u][2]; o.w = data[u].w ^ g[u][3];
+                buf[i] = o;
+                // streaming state needs the gamma of the final block (belt_ctr.c:89-96)
+                if (last_gamma && i == nblocks - 1)
+                    *last_gamma = make_uint4(g[u][0], g[u][1], g[u][2], g[u][3]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64)
+void belt_encr_blocks_kernel(uint4 *__restrict__ blocks, size_t nblocks, BeltKey key)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[BeltTabSmall::kBytes];
+    BeltTabSmall::fill(smem, threadIdx.x, 64);
+    __syncthreads();
+    const BeltTabSmall T(smem);
+    uint32_t K[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) K[i] = key.k[i];
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= nblocks) return;
+    const uint4 v = blocks[i];
+    uint32_t x[4] = {v.x, v.y, v.z, v.w};
+    belt_encr(T, x, K);
+    blocks[i] = make_uint4(x[0], x[1], x[2], x[3]);
+}
+
+static int g_num_cus = 0;
+static int num_cus()
+{
+    if (!g_num_cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            g_num_cus = n;
+        else
+            g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+err_t upload_beltH(const uint8_t *H)
+{
+    B2H_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_beltH), H, 256));
+    return ERR_OK;
+}
+
+err_t launch_belt_ctr_blocks(void *d_buf, size_t nblocks, const uint32_t key[8],
+                             const uint32_t ctr0[4], uint64_t first, void *d_last_gamma,
+                             hipStream_t st)
+{
+    if (nblocks == 0) return ERR_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(beltCTR_blocks_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, BeltTabWide::kBytes));
+        attr_set = true;
+    }
+    BeltKey k; BeltCtr c;
+    for (int i = 0; i < 8; ++i) k.k[i] = key[i];
+    for (int i = 0; i < 4; ++i) c.c[i] = ctr0[i];
+    const size_t tile = (size_t)CTR_WG * CTR_ILP;
+    size_t grid = (nblocks + tile - 1) / tile;
+    const size_t cap = (size_t)num_cus();
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(beltCTR_blocks_kernel, dim3((unsigned)grid), dim3(CTR_WG), BeltTabWide::kBytes,
+                       st, (uint4 *)d_buf, nblocks, k, c, first, (uint4 *)d_last_gamma);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
+err_t launch_belt_encr_blocks(void *d_blocks, size_t nblocks, const uint32_t key[8], hipStream_t st)
+{
+    if (nblocks == 0) return ERR_OK;
+    BeltKey k;
+    for (int i = 0; i < 8; ++i) k.k[i] = key[i];
+    const size_t grid = (nblocks + 63) / 64;
+    if (grid > 0x7fffffffull) return ERR_BAD_INPUT;
+    hipLaunchKernelGGL(belt_encr_blocks_kernel, dim3((unsigned)grid), dim3(64), 0, st,
+                       (uint4 *)d_blocks, nblocks, k);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
+}  // namespace bee2hip

@@ -1,0 +1,35 @@
+// common.hpp -- shared host-side plumbing of libbee2hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/bee2hip.h"
+
+namespace bee2hip {
+
+// record a HIP failure for bee2hip_last_error(); returns ERR_BEE2HIP_DEVICE
+err_t hip_fail(hipError_t e, const char *what);
+
+#define B2H_TRY(call)                                                   \
+    do {                                                                \
+        hipError_t e_ = (call);                                         \
+        if (e_ != hipSuccess) return ::bee2hip::hip_fail(e_, #call);    \
+    } while (0)
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- kernel launchers (defined next to their kernels) ----
+err_t launch_bashF_batch(void *d_states, size_t n, hipStream_t st);
+err_t launch_bashHash_beltMAC(const void *d_msgs, size_t msg_len, size_t n, size_t l,
+                              const uint32_t key[8], bool do_hash, bool do_mac,
+                              void *d_digests, void *d_tags, hipStream_t st);
+// one lane absorbs `count` bytes into one sponge state (drop-in bashHashStepH)
+err_t launch_belt_ctr_blocks(void *d_buf, size_t nblocks, const uint32_t key[8],
+                             const uint32_t ctr0[4], uint64_t first, void *d_last_gamma,
+                             hipStream_t st);
+err_t launch_belt_encr_blocks(void *d_blocks, size_t nblocks, const uint32_t key[8], hipStream_t st);
+err_t launch_bign_verify(const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
+                         const void *d_sigs, const void *d_pubkeys, size_t n, void *d_codes,
+                         hipStream_t st);
+
+}  // namespace bee2hip

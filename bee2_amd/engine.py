@@ -1,0 +1,291 @@
+"""ctypes binding of libbee2hip.so (include/bee2hip.h) and a small host-side mirror of
+the bee2 interfaces it replaces.  Names follow bee2: bashF, bashHash, beltCTR, beltMAC,
+bign128Verify ... (include/bee2/crypto/{bash,belt,bign,bign128}.h)."""
+import ctypes
+import os
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+LIB_PATH = os.path.join(PKG, "lib", "libbee2hip.so")
+
+ERR_OK = 0
+ERR_BAD_INPUT = 109
+ERR_OUTOFMEMORY = 110
+ERR_NOT_IMPLEMENTED = 119
+ERR_BAD_OID = 301
+ERR_BAD_PARAMS = 502
+ERR_BAD_PUBKEY = 505
+ERR_BAD_SIG = 510
+ERR_BEE2HIP_DEVICE = 0x4850
+
+OID_BELT_HASH_DER = bytes.fromhex("06092A7000020022651F51")   # bign128.c:151-153
+
+_sz = ctypes.c_size_t
+_vp = ctypes.c_void_p
+_u32 = ctypes.c_uint32
+_u64 = ctypes.c_uint64
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """compile libbee2hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)"""
+    cmd = ["make", "-C", os.path.join(PKG, "csrc")]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+# every symbol include/bee2hip.h declares; tests check the built library exports them all
+DROPIN_SYMBOLS = [
+    "bashF", "bashF_deep", "bash_platform", "bashHash_keep", "bashHashStart", "bashHashStepH",
+    "bashHashStepG", "bashHashStepV", "bashHash",
+    "beltH", "beltKeyExpand2", "beltBlockEncr", "beltBlockEncr2", "beltBlockEncr3",
+    "beltCTR_keep", "beltCTRStart", "beltCTRStepE", "beltCTR",
+    "beltMAC_keep", "beltMACStart", "beltMACStepA", "beltMACStepG", "beltMACStepG2",
+    "beltMACStepV", "beltMACStepV2", "beltMAC",
+    "bignParamsStd", "bignVerify", "bign128Verify",
+]
+BATCH_SYMBOLS = [
+    "bee2hip_bashF_batch", "bee2hip_beltCTR_bulk", "bee2hip_bignVerify_batch",
+    "bee2hip_bashHash_beltMAC_batch",
+    "bee2hip_bashF_batch_dev", "bee2hip_beltCTR_blocks_dev", "bee2hip_beltBlockEncr_dev",
+    "bee2hip_bign128Verify_batch_dev", "bee2hip_bignVerify_batch_dev",
+    "bee2hip_bashHash_beltMAC_batch_dev",
+    "bee2hip_set_device", "bee2hip_sync", "bee2hip_last_error", "bee2hip_version",
+    "bee2hip_time_kernel",
+]
+
+
+def lib_exports(path=LIB_PATH):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+
+class bign_params(ctypes.Structure):            # include/bee2/crypto/bign.h:65-74
+    _fields_ = [("l", _sz), ("p", ctypes.c_ubyte * 64), ("a", ctypes.c_ubyte * 64),
+                ("b", ctypes.c_ubyte * 64), ("q", ctypes.c_ubyte * 64),
+                ("yG", ctypes.c_ubyte * 64), ("seed", ctypes.c_ubyte * 8)]
+
+
+class Engine:
+    """One per process/GPU.  Device-pointer methods take torch CUDA tensors (uint8/int32,
+    contiguous) and are asynchronous on torch's current stream."""
+
+    def __init__(self, lib):
+        self.lib = L = lib
+        for name in ("bee2hip_last_error", "bee2hip_version"):
+            getattr(L, name).restype = ctypes.c_char_p
+        L.beltH.restype = ctypes.POINTER(ctypes.c_ubyte)
+        for name in ("bashF_deep", "bashHash_keep", "beltCTR_keep", "beltMAC_keep"):
+            getattr(L, name).restype = _sz
+        for name in DROPIN_SYMBOLS + BATCH_SYMBOLS:
+            f = getattr(L, name, None)
+            if f is not None and name.startswith(("bee2hip_", "bash", "belt", "bign")) and \
+                    name not in ("bee2hip_last_error", "bee2hip_version", "beltH", "bashF_deep",
+                                 "bashHash_keep", "beltCTR_keep", "beltMAC_keep", "bash_platform"):
+                f.restype = _u32
+
+    # ------------------------------------------------------------------ util
+    def _check(self, code, what):
+        if code != ERR_OK:
+            raise EngineError(f"{what}: err {code} {self.lib.bee2hip_last_error().decode()}")
+
+    def version(self):
+        return self.lib.bee2hip_version().decode()
+
+    def set_device(self, dev):
+        self._check(self.lib.bee2hip_set_device(int(dev)), "bee2hip_set_device")
+
+    @staticmethod
+    def _stream():
+        import torch
+        return _vp(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _ptr(t):
+        assert t.is_cuda and t.is_contiguous()
+        return _vp(t.data_ptr())
+
+    def sync(self):
+        self._check(self.lib.bee2hip_sync(self._stream()), "bee2hip_sync")
+
+    # --------------------------------------------------- device-pointer batch
+    def bashF_batch_dev(self, states):
+        """states: uint8 CUDA tensor of n*192 bytes, permuted in place"""
+        n = states.numel() // 192
+        assert states.numel() == n * 192
+        self._check(self.lib.bee2hip_bashF_batch_dev(self._ptr(states), _sz(n), self._stream()),
+                    "bashF_batch_dev")
+
+    def beltCTR_blocks_dev(self, buf, key_words, ctr0_words, first_block=0):
+        """buf: uint8 CUDA tensor, multiple of 16 bytes; key_words 32 B, ctr0_words 16 B
+        (host bytes holding u32[8] / u32[4] little-endian)"""
+        n = buf.numel() // 16
+        assert buf.numel() == n * 16
+        self._check(self.lib.bee2hip_beltCTR_blocks_dev(self._ptr(buf), _sz(n), bytes(key_words),
+                                                        bytes(ctr0_words), _u64(first_block),
+                                                        self._stream()), "beltCTR_blocks_dev")
+
+    def beltBlockEncr_dev(self, blocks, key_words):
+        n = blocks.numel() // 16
+        self._check(self.lib.bee2hip_beltBlockEncr_dev(self._ptr(blocks), _sz(n), bytes(key_words),
+                                                       self._stream()), "beltBlockEncr_dev")
+
+    def bign128Verify_batch_dev(self, hashes, sigs, pubkeys, codes):
+        n = hashes.numel() // 32
+        assert sigs.numel() == 48 * n and pubkeys.numel() == 64 * n and codes.numel() >= n
+        self._check(self.lib.bee2hip_bign128Verify_batch_dev(
+            self._ptr(hashes), self._ptr(sigs), self._ptr(pubkeys), _sz(n), self._ptr(codes),
+            self._stream()), "bign128Verify_batch_dev")
+
+    def bashHash_beltMAC_batch_dev(self, msgs, msg_len, l, key, digests, tags):
+        n = msgs.numel() // msg_len if msg_len else 0
+        self._check(self.lib.bee2hip_bashHash_beltMAC_batch_dev(
+            self._ptr(msgs), _sz(msg_len), _sz(n), _sz(l), bytes(key), _sz(len(key)),
+            self._ptr(digests) if digests is not None else None,
+            self._ptr(tags) if tags is not None else None, self._stream()),
+            "bashHash_beltMAC_batch_dev")
+
+    def time_kernel(self, which, reps, a=None, b=None, c=None, d=None, n=0, aux=0):
+        ms = ctypes.c_float(0)
+        p = [self._ptr(t) if t is not None else None for t in (a, b, c, d)]
+        self._check(self.lib.bee2hip_time_kernel(int(which), int(reps), p[0], p[1], p[2], p[3],
+                                                 _sz(n), _sz(aux), self._stream(),
+                                                 ctypes.byref(ms)), "time_kernel")
+        return ms.value
+
+    # ------------------------------------------------------ host-pointer batch
+    def bashF_batch(self, states):
+        buf = ctypes.create_string_buffer(bytes(states), len(states))
+        self._check(self.lib.bee2hip_bashF_batch(buf, _sz(len(states) // 192)), "bashF_batch")
+        return buf.raw
+
+    def bignVerify_batch(self, hashes, sigs, pubkeys, oid_der=OID_BELT_HASH_DER, params=None):
+        n = len(hashes) // 32
+        codes = (_u32 * max(n, 1))()
+        if params is None:
+            params = self.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
+        code = self.lib.bee2hip_bignVerify_batch(ctypes.byref(params), bytes(oid_der),
+                                                 _sz(len(oid_der)), bytes(hashes), bytes(sigs),
+                                                 bytes(pubkeys), _sz(n), codes)
+        return code, list(codes)[:n]
+
+    def bashHash_beltMAC_batch(self, msgs, msg_len, l, key, want_hash=True, want_mac=True):
+        n = len(msgs) // msg_len if msg_len else 0
+        dig = ctypes.create_string_buffer(max(1, n * (l // 4))) if want_hash else None
+        tag = ctypes.create_string_buffer(max(1, n * 8)) if want_mac else None
+        self._check(self.lib.bee2hip_bashHash_beltMAC_batch(bytes(msgs), _sz(msg_len), _sz(n), _sz(l),
+                                                            bytes(key), _sz(len(key)), dig, tag),
+                    "bashHash_beltMAC_batch")
+        return (dig.raw[: n * (l // 4)] if dig else None), (tag.raw[: n * 8] if tag else None)
+
+    # ------------------------------------------------- bee2 drop-in interface
+    def beltH(self):
+        p = self.lib.beltH()
+        return bytes(p[i] for i in range(256))
+
+    def bashF(self, block):
+        b = ctypes.create_string_buffer(bytes(block), 192)
+        self.lib.bashF(b, None)
+        return b.raw
+
+    def bashHash(self, l, src):
+        out = ctypes.create_string_buffer(max(l // 4, 1))
+        code = self.lib.bashHash(out, _sz(l), bytes(src), _sz(len(src)))
+        return code, out.raw[: l // 4]
+
+    def bashHash_steps(self, l, src, splits):
+        st = ctypes.create_string_buffer(self.lib.bashHash_keep())
+        self.lib.bashHashStart(st, _sz(l))
+        off = 0
+        for s in splits:
+            self.lib.bashHashStepH(bytes(src[off:off + s]), _sz(s), st)
+            off += s
+        out = ctypes.create_string_buffer(l // 4)
+        self.lib.bashHashStepG(out, _sz(l // 4), st)
+        ok = self.lib.bashHashStepV(out, _sz(l // 4), st)
+        return out.raw, bool(ok)
+
+    def beltKeyExpand2(self, key):
+        k = (_u32 * 8)()
+        self.lib.beltKeyExpand2(k, bytes(key), _sz(len(key)))
+        return bytes(k)
+
+    def beltBlockEncr(self, block, key):
+        b = ctypes.create_string_buffer(bytes(block), 16)
+        self.lib.beltBlockEncr(b, self.beltKeyExpand2(key))
+        return b.raw
+
+    def beltCTR(self, src, key, iv):
+        out = ctypes.create_string_buffer(max(len(src), 1))
+        code = self.lib.beltCTR(out, bytes(src), _sz(len(src)), bytes(key), _sz(len(key)), bytes(iv))
+        return code, out.raw[: len(src)]
+
+    def beltCTR_steps(self, src, key, iv, splits):
+        """Start / StepE*; returns (ciphertext, final state bytes)"""
+        st = ctypes.create_string_buffer(self.lib.beltCTR_keep())
+        self.lib.beltCTRStart(st, bytes(key), _sz(len(key)), bytes(iv))
+        buf = ctypes.create_string_buffer(bytes(src), max(len(src), 1))
+        off = 0
+        for s in splits:
+            self.lib.beltCTRStepE(ctypes.byref(buf, off), _sz(s), st)
+            off += s
+        return buf.raw[: len(src)], st.raw
+
+    def beltCTRStart(self, key, iv):
+        st = ctypes.create_string_buffer(self.lib.beltCTR_keep())
+        self.lib.beltCTRStart(st, bytes(key), _sz(len(key)), bytes(iv))
+        return st.raw[:32], st.raw[32:48]
+
+    def beltMAC(self, src, key):
+        out = ctypes.create_string_buffer(8)
+        code = self.lib.beltMAC(out, bytes(src), _sz(len(src)), bytes(key), _sz(len(key)))
+        return code, out.raw
+
+    def beltMAC_steps(self, src, key, splits):
+        st = ctypes.create_string_buffer(self.lib.beltMAC_keep())
+        self.lib.beltMACStart(st, bytes(key), _sz(len(key)))
+        off = 0
+        for s in splits:
+            self.lib.beltMACStepA(bytes(src[off:off + s]), _sz(s), st)
+            off += s
+        out = ctypes.create_string_buffer(8)
+        self.lib.beltMACStepG(out, st)
+        ok = self.lib.beltMACStepV(out, st)
+        out4 = ctypes.create_string_buffer(4)
+        self.lib.beltMACStepG2(out4, _sz(4), st)
+        ok2 = self.lib.beltMACStepV2(out4, _sz(4), st)
+        return out.raw, bool(ok) and bool(ok2) and out4.raw == out.raw[:4]
+
+    def bignParamsStd(self, name):
+        p = bign_params()
+        code = self.lib.bignParamsStd(ctypes.byref(p), name.encode())
+        if code != ERR_OK:
+            raise EngineError(f"bignParamsStd({name}): err {code}")
+        return p
+
+    def bignVerify(self, params, oid_der, hash_, sig, pubkey):
+        return self.lib.bignVerify(ctypes.byref(params), bytes(oid_der), _sz(len(oid_der)),
+                                   bytes(hash_), bytes(sig), bytes(pubkey))
+
+    def bign128Verify(self, hash_, sig, pubkey):
+        return self.lib.bign128Verify(bytes(hash_), bytes(sig), bytes(pubkey))
+
+
+_engine = None
+
+
+def load(path=LIB_PATH):
+    """Load libbee2hip.so.  Fails loudly if it is missing -- there is no fallback path."""
+    global _engine
+    if _engine is None:
+        if not os.path.exists(path):
+            raise EngineError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(bee2_amd has no CPU fallback)")
+        _engine = Engine(ctypes.CDLL(path))
+    return _engine

@@ -1,0 +1,186 @@
+/*
+ * bee2hip.h -- C ABI of libbee2hip.so, the MI355X (gfx950) batch-primitive engine
+ * for bee2's three data-parallel hot paths.
+ *
+ * Three groups of entry points, all `extern "C"`, plain pointers and sizes:
+ *
+ *  (1) bee2 DROP-IN symbols: same names, signatures, state layouts and error
+ *      behaviour as the bee2 functions they replace, so a bee2 caller can link
+ *      this library instead of those objects.  Every primitive evaluation
+ *      (bashF, E_K, the double-scalar multiplication) runs on the GPU; there is
+ *      no CPU fallback.  Each declaration cites the bee2 interface it replaces.
+ *
+ *  (2) bee2hip_*  host-pointer batch API: the caller hands host buffers; the
+ *      library stages H2D, launches, stages D2H.
+ *
+ *  (3) bee2hip_*_dev  device-pointer batch API: buffers already resident in HBM
+ *      (e.g. torch tensors' data_ptr()); asynchronous on `stream` (a hipStream_t
+ *      passed as void*, NULL = default stream).  This is what bench.py times.
+ *
+ * All octet strings are little-endian, exactly as in bee2.
+ */
+#ifndef BEE2HIP_H
+#define BEE2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)      /* everything declared here is exported */
+#endif
+
+/* ---- bee2 base types (include/bee2/defs.h:269,441,463,520) ---------------- */
+typedef uint8_t octet;
+typedef uint32_t u32;
+typedef int bool_t;
+typedef uint32_t err_t;
+#ifndef TRUE
+#define TRUE 1
+#define FALSE 0
+#endif
+
+/* ---- bee2 error codes on the path (include/bee2/core/err.h) --------------- */
+#define ERR_OK               ((err_t)0)
+#define ERR_BAD_INPUT        ((err_t)109)   /* err.h:72  */
+#define ERR_OUTOFMEMORY      ((err_t)110)   /* err.h:74  */
+#define ERR_NOT_IMPLEMENTED  ((err_t)119)   /* err.h:92  */
+#define ERR_FILE_NOT_FOUND    ((err_t)202)   /* err.h:105 */
+#define ERR_BAD_OID          ((err_t)301)   /* err.h:132 */
+#define ERR_BAD_PARAMS       ((err_t)502)   /* err.h:180 */
+#define ERR_BAD_PUBKEY       ((err_t)505)   /* err.h:186 */
+#define ERR_BAD_SIG          ((err_t)510)   /* err.h:196 */
+/* engine-specific: a HIP runtime call failed (no bee2 equivalent; the reference
+   has no device).  bee2hip_last_error() returns the HIP message. */
+#define ERR_BEE2HIP_DEVICE   ((err_t)0x4850)
+
+/* ======================================================================== *
+ * (1) bee2 drop-in symbols
+ * ======================================================================== */
+
+/* ---- bash: include/bee2/crypto/bash.h ------------------------------------ */
+/* bash.h:136  (the BASH_PLATFORM slot, src/crypto/bash/bash_f.c:26-44) */
+void bashF(octet block[192], void *stack);
+/* bash.h:139 */
+size_t bashF_deep(void);
+/* src/crypto/bash/bash_f.c:27-43, consumed by test/crypto/bash_bench.c:27,47 */
+extern const char bash_platform[];
+/* bash.h:152-225, src/crypto/bash/bash_hash.c:25-137 */
+size_t bashHash_keep(void);
+void bashHashStart(void *state, size_t l);
+void bashHashStepH(const void *buf, size_t count, void *state);
+void bashHashStepG(octet hash[], size_t hash_len, void *state);
+bool_t bashHashStepV(const octet hash[], size_t hash_len, void *state);
+err_t bashHash(octet hash[], size_t l, const void *src, size_t count);
+
+/* ---- belt: include/bee2/crypto/belt.h ------------------------------------ */
+/* belt.h:148, src/crypto/belt/belt_block.c:62-66 */
+const octet *beltH(void);
+/* belt.h:170-176, belt_block.c:88-106 */
+void beltKeyExpand2(u32 key_[8], const octet key[], size_t len);
+/* belt.h:186-221, belt_block.c:302-334 */
+void beltBlockEncr(octet block[16], const u32 key[8]);
+void beltBlockEncr2(u32 block[4], const u32 key[8]);
+void beltBlockEncr3(u32 *a, u32 *b, u32 *c, u32 *d, const u32 key[8]);
+/* belt.h:692-743, src/crypto/belt/belt_ctr.c:46-135; state = belt_ctr_st,
+   src/crypto/belt/belt_lcl.h:135-141 (key[8], ctr[4], block[16], reserved) */
+size_t beltCTR_keep(void);
+void beltCTRStart(void *state, const octet key[], size_t len, const octet iv[16]);
+void beltCTRStepE(void *buf, size_t count, void *state);
+#define beltCTRStepD beltCTRStepE                 /* belt.h:724 */
+err_t beltCTR(void *dest, const void *src, size_t count, const octet key[], size_t len,
+              const octet iv[16]);
+/* belt.h:756-854, src/crypto/belt/belt_mac.c:32-203 */
+size_t beltMAC_keep(void);
+void beltMACStart(void *state, const octet key[], size_t len);
+void beltMACStepA(const void *buf, size_t count, void *state);
+void beltMACStepG(octet mac[8], void *state);
+void beltMACStepG2(octet mac[], size_t mac_len, void *state);
+bool_t beltMACStepV(const octet mac[8], void *state);
+bool_t beltMACStepV2(const octet mac[], size_t mac_len, void *state);
+err_t beltMAC(octet mac[8], const void *src, size_t count, const octet key[], size_t len);
+
+/* ---- bign: include/bee2/crypto/bign.h, bign128.h -------------------------- */
+/* bign.h:65-74 */
+typedef struct {
+    size_t l;
+    octet p[64];
+    octet a[64];
+    octet b[64];
+    octet q[64];
+    octet yG[64];
+    octet seed[8];
+} bign_params;
+/* bign.h:100-107, src/crypto/bign/bign_params.c:180-230 (only "1.2.112.0.2.0.34.101.45.3.1") */
+err_t bignParamsStd(bign_params *params, const char *name);
+/* bign.h:395-402, src/crypto/bign/bign_sign.c:349-361 */
+err_t bignVerify(const bign_params *params, const octet oid_der[], size_t oid_len,
+                 const octet hash[], const octet sig[], const octet pubkey[]);
+/* include/bee2/crypto/bign128.h:174-178, src/crypto/bign/bign128.c:177-185 */
+err_t bign128Verify(const octet hash[32], const octet sig[48], const octet pubkey[64]);
+
+/* ======================================================================== *
+ * (2) host-pointer batch API (new; SURVEY.md 8b "batch extension")
+ * ======================================================================== */
+
+/* n independent 192-byte states, contiguous, permuted in place (batched bashF) */
+err_t bee2hip_bashF_batch(octet *states, size_t n);
+/* bulk CTR over host memory, exactly equivalent to beltCTRStepE(buf, count, state)
+   including the ctr / block / reserved fields it leaves behind (belt_ctr.c:66-111) */
+err_t bee2hip_beltCTR_bulk(void *buf, size_t count, void *ctr_state);
+/* n signatures: hashes n*32, sigs n*48, pubkeys n*64 -> codes[n] = what
+   bignVerify(params, oid_der, oid_len, ...) returns per item (bign_sign.c:268-361) */
+err_t bee2hip_bignVerify_batch(const bign_params *params, const octet oid_der[], size_t oid_len,
+                               const octet *hashes, const octet *sigs, const octet *pubkeys,
+                               size_t n, err_t *codes);
+/* n messages of msg_len bytes each (contiguous): bashHash(l) digest (l/4 bytes each,
+   digests may be NULL) and beltMAC tag (8 bytes each, tags may be NULL) per message */
+err_t bee2hip_bashHash_beltMAC_batch(const octet *msgs, size_t msg_len, size_t n, size_t l,
+                                     const octet key[], size_t key_len,
+                                     octet *digests, octet *tags);
+
+/* ======================================================================== *
+ * (3) device-pointer batch API (buffers in HBM; async on `stream`)
+ * ======================================================================== */
+err_t bee2hip_bashF_batch_dev(void *d_states, size_t n, void *stream);
+/* full 16-byte blocks only: block i (0-based) ^= E_K(ctr0 + first_block + i + 1),
+   the 128-bit little-endian counter arithmetic of belt_ctr.c:27-35 */
+err_t bee2hip_beltCTR_blocks_dev(void *d_buf, size_t nblocks, const u32 key[8],
+                                 const u32 ctr0[4], uint64_t first_block, void *stream);
+/* ECB-style E_K over n blocks in place (used for ctr0 = E_K(iv), r = E_K(0)) */
+err_t bee2hip_beltBlockEncr_dev(void *d_blocks, size_t nblocks, const u32 key[8], void *stream);
+err_t bee2hip_bign128Verify_batch_dev(const void *d_hashes, const void *d_sigs,
+                                      const void *d_pubkeys, size_t n, void *d_codes,
+                                      void *stream);
+err_t bee2hip_bignVerify_batch_dev(const octet oid_der[], size_t oid_len,
+                                   const void *d_hashes, const void *d_sigs,
+                                   const void *d_pubkeys, size_t n, void *d_codes,
+                                   void *stream);
+err_t bee2hip_bashHash_beltMAC_batch_dev(const void *d_msgs, size_t msg_len, size_t n, size_t l,
+                                         const octet key[], size_t key_len,
+                                         void *d_digests, void *d_tags, void *stream);
+
+/* ---- engine management --------------------------------------------------- */
+/* bind the calling thread's engine to HIP device `device` (default: current) */
+err_t bee2hip_set_device(int device);
+/* block until everything queued on `stream` is done */
+err_t bee2hip_sync(void *stream);
+/* text of the last HIP failure on this thread ("" if none) */
+const char *bee2hip_last_error(void);
+/* "bee2hip <ver> gfx950" */
+const char *bee2hip_version(void);
+/* time `reps` launches of one kernel with hipEvents on `stream`; returns the
+   average milliseconds per launch in *ms (used by bench.py's roofline object).
+   which: 0 bashF_batch, 1 beltCTR_blocks, 2 bign128Verify_batch, 3 bashHash_beltMAC */
+err_t bee2hip_time_kernel(int which, int reps, void *d_a, void *d_b, void *d_c, void *d_d,
+                          size_t n, size_t aux, void *stream, float *ms);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEE2HIP_H */
