@@ -3,4 +3,5 @@
 // as one TU avoids relocatable device code.  Build: see bee2_amd/csrc/Makefile.
 #include "bash_kernels.hip"
 #include "belt_kernels.hip"
+#include "bign_kernels.hip"
 #include "capi.hip"

@@ -297,3 +297,172 @@ extern "C" err_t beltCTR(void *dest, const void *src, size_t count, const octet 
     delete st;
     return code;
 }
+
+// ==================================================================== bign ===
+// STB 34.101.45 annex B.1 = "1.2.112.0.2.0.34.101.45.3.1" (bign_params.c:33-73)
+static const octet k_curve256v1_p[32] = {
+    0x43, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF,
+    0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
+static const octet k_curve256v1_a[32] = {
+    0x40, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF,
+    0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
+static const octet k_curve256v1_b[32] = {
+    0xF1, 0x03, 0x9C, 0xD6, 0x6B, 0x7D, 0x2E, 0xB2, 0x53, 0x92, 0x8B, 0x97, 0x69, 0x50, 0xF5, 0x4C,
+    0xBE, 0xFB, 0xD8, 0xE4, 0xAB, 0x3A, 0xC1, 0xD2, 0xED, 0xA8, 0xF3, 0x15, 0x15, 0x6C, 0xCE, 0x77};
+static const octet k_curve256v1_seed[8] = {0x5E, 0x38, 0x01, 0x00, 0x00, 0x00, 0x00, 0x00};
+static const octet k_curve256v1_q[32] = {
+    0x07, 0x66, 0x3D, 0x26, 0x99, 0xBF, 0x5A, 0x7E, 0xFC, 0x4D, 0xFB, 0x0D, 0xD6, 0x8E, 0x5C, 0xD9,
+    0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
+static const octet k_curve256v1_yG[32] = {
+    0x93, 0x6A, 0x51, 0x04, 0x18, 0xCF, 0x29, 0x1E, 0x52, 0xF6, 0x08, 0xC4, 0x66, 0x39, 0x91, 0x78,
+    0x5D, 0x83, 0xD6, 0x51, 0xA3, 0xC9, 0xE4, 0x5C, 0x9F, 0xD6, 0x16, 0xFB, 0x3C, 0xFC, 0xF7, 0x6B};
+// DER(1.2.112.0.2.0.34.101.31.81): belt-hash (bign128.c:151-153)
+static const octet k_oid_belt_hash[11] = {0x06, 0x09, 0x2A, 0x70, 0x00, 0x02, 0x00, 0x22, 0x65, 0x1F, 0x51};
+
+extern "C" err_t bignParamsStd(bign_params *params, const char *name)
+{
+    if (!params || !name) return ERR_BAD_INPUT;
+    memset(params, 0, sizeof *params);
+    if (strcmp(name, "1.2.112.0.2.0.34.101.45.3.1") == 0) {
+        params->l = 128;
+        memcpy(params->p, k_curve256v1_p, 32);
+        memcpy(params->a, k_curve256v1_a, 32);
+        memcpy(params->seed, k_curve256v1_seed, 8);
+        memcpy(params->b, k_curve256v1_b, 32);
+        memcpy(params->q, k_curve256v1_q, 32);
+        memcpy(params->yG, k_curve256v1_yG, 32);
+        return ERR_OK;
+    }
+    // bign-curve384v1 / 512v1 (l = 192 / 256) are SURVEY.md 8f "next"
+    return ERR_FILE_NOT_FOUND;
+}
+
+static bool all_zero(const octet *p, size_t n)
+{
+    octet acc = 0;
+    for (size_t i = 0; i < n; ++i) acc |= p[i];
+    return acc == 0;
+}
+
+// bignParamsCheck (bign_params.c:244-280), then: only the standard 256-bit curve has
+// device constants; other valid-looking parameter sets report ERR_NOT_IMPLEMENTED.
+static err_t params_check(const bign_params *params)
+{
+    if (!params) return ERR_BAD_INPUT;
+    if (2 * params->l % 64) return ERR_NOT_IMPLEMENTED;
+    const size_t no = 2 * params->l / 8;
+    if (no == 0 || no > 64) return ERR_BAD_PARAMS;
+    const bool ok = params->p[0] % 4 == 3 && params->q[0] % 2 == 1 && params->p[no - 1] >= 128 &&
+                    params->q[no - 1] >= 128 && all_zero(params->p + no, 64 - no) &&
+                    !all_zero(params->a, no) && !all_zero(params->b, no) &&
+                    all_zero(params->a + no, 64 - no) && all_zero(params->b + no, 64 - no) &&
+                    all_zero(params->q + no, 64 - no) && all_zero(params->yG + no, 64 - no);
+    if (!ok) return ERR_BAD_PARAMS;
+    if (params->l % 64) return ERR_NOT_IMPLEMENTED;
+    if (params->l != 128 && params->l != 192 && params->l != 256) return ERR_BAD_PARAMS;
+    if (params->l != 128 || memcmp(params->p, k_curve256v1_p, 32) || memcmp(params->a, k_curve256v1_a, 32) ||
+        memcmp(params->b, k_curve256v1_b, 32) || memcmp(params->q, k_curve256v1_q, 32) ||
+        memcmp(params->yG, k_curve256v1_yG, 32))
+        return ERR_NOT_IMPLEMENTED;
+    return ERR_OK;
+}
+
+// oidFromDER(0, der, count) != SIZE_MAX  (src/core/oid.c:94-101, src/core/der.c:114-258,921-975):
+// tag 0x06, definite minimal length covering the whole buffer, sub-identifiers without a
+// leading 0x80 octet and below 2^32.
+static bool oid_der_valid(const octet *der, size_t count)
+{
+    if (!der || count < 2 || count == (size_t)-1) return false;
+    if (der[0] != 0x06) return false;
+    size_t len, hdr;
+    if (der[1] < 128) { len = der[1]; hdr = 2; }
+    else {
+        const size_t r = der[1] - 128;
+        if (der[1] == 128 || der[1] == 255 || r > sizeof(size_t) || count < 2 + r) return false;
+        if (der[2] == 0 || (r == 1 && der[2] < 128)) return false;
+        len = 0;
+        for (size_t i = 0; i < r; ++i) len = (len << 8) | der[2 + i];
+        hdr = 2 + r;
+    }
+    if (hdr + len != count) return false;
+    const octet *v = der + hdr;
+    u32 val = 0;
+    for (size_t pos = 0; pos < len; ++pos) {
+        if (val & 0xFE000000u) return false;
+        if (val == 0 && v[pos] == 128) return false;
+        val = (val << 7) | (v[pos] & 127u);
+        if ((v[pos] & 128) == 0) val = 0;
+    }
+    return true;
+}
+
+extern "C" err_t bee2hip_bignVerify_batch_dev(const octet oid_der[], size_t oid_len,
+                                              const void *d_hashes, const void *d_sigs,
+                                              const void *d_pubkeys, size_t n, void *d_codes,
+                                              void *stream)
+{
+    if (n && (!d_hashes || !d_sigs || !d_pubkeys || !d_codes)) return ERR_BAD_INPUT;
+    if (!oid_der_valid(oid_der, oid_len)) return ERR_BAD_OID;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    return launch_bign_verify(oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, as_stream(stream));
+}
+
+extern "C" err_t bee2hip_bign128Verify_batch_dev(const void *d_hashes, const void *d_sigs,
+                                                 const void *d_pubkeys, size_t n, void *d_codes,
+                                                 void *stream)
+{
+    return bee2hip_bignVerify_batch_dev(k_oid_belt_hash, sizeof k_oid_belt_hash, d_hashes, d_sigs,
+                                        d_pubkeys, n, d_codes, stream);
+}
+
+extern "C" err_t bee2hip_bignVerify_batch(const bign_params *params, const octet oid_der[], size_t oid_len,
+                                          const octet *hashes, const octet *sigs, const octet *pubkeys,
+                                          size_t n, err_t *codes)
+{
+    // order of checks as bignVerify: params first (bign_sign.c:355-356), then inputs, then OID
+    err_t code = params_check(params);
+    if (code != ERR_OK) return code;
+    if (n && (!hashes || !sigs || !pubkeys || !codes)) return ERR_BAD_INPUT;
+    if (!oid_der_valid(oid_der, oid_len)) return ERR_BAD_OID;
+    if (n == 0) return ERR_OK;
+    code = ensure_device();
+    if (code != ERR_OK) return code;
+    Scratch &s = t_scr[3];
+    const size_t in_bytes = n * 144, total = in_bytes + n * 4;
+    code = s.need(total);
+    if (code != ERR_OK) return code;
+    octet *d = (octet *)s.p;
+    octet *dh = d, *ds = d + 32 * n, *dp = d + 80 * n, *dc = d + 144 * n;
+    B2H_TRY(hipMemcpy(dh, hashes, 32 * n, hipMemcpyHostToDevice));
+    B2H_TRY(hipMemcpy(ds, sigs, 48 * n, hipMemcpyHostToDevice));
+    B2H_TRY(hipMemcpy(dp, pubkeys, 64 * n, hipMemcpyHostToDevice));
+    code = launch_bign_verify(oid_der, oid_len, dh, ds, dp, n, dc, nullptr);
+    if (code != ERR_OK) return code;
+    B2H_TRY(hipMemcpy(codes, dc, 4 * n, hipMemcpyDeviceToHost));
+    return ERR_OK;
+}
+
+extern "C" err_t bignVerify(const bign_params *params, const octet oid_der[], size_t oid_len,
+                            const octet hash[], const octet sig[], const octet pubkey[])
+{
+    err_t one = ERR_BAD_SIG;
+    if (!hash || !sig || !pubkey) {
+        const err_t pc = params_check(params);
+        return pc != ERR_OK ? pc : ERR_BAD_INPUT;
+    }
+    const err_t code = bee2hip_bignVerify_batch(params, oid_der, oid_len, hash, sig, pubkey, 1, &one);
+    return code != ERR_OK ? code : one;
+}
+
+extern "C" err_t bign128Verify(const octet hash[32], const octet sig[48], const octet pubkey[64])
+{
+    bign_params params;
+    bignParamsStd(&params, "1.2.112.0.2.0.34.101.45.3.1");
+    return bignVerify(&params, k_oid_belt_hash, sizeof k_oid_belt_hash, hash, sig, pubkey);
+}
+
+extern "C" err_t bee2hip_debug_fe(int op, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream)
+{
+    return launch_bign_debug_fe(op, d_a, d_b, d_out, n, as_stream(stream));
+}

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 #include "../../include/bee2hip.h"
 
 namespace bee2hip {
@@ -31,5 +32,7 @@ err_t launch_belt_encr_blocks(void *d_blocks, size_t nblocks, const uint32_t key
 err_t launch_bign_verify(const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
                          const void *d_sigs, const void *d_pubkeys, size_t n, void *d_codes,
                          hipStream_t st);
+
+err_t launch_bign_debug_fe(int op, const void *a, const void *b, void *out, size_t n, hipStream_t st);
 
 }  // namespace bee2hip

@@ -82,7 +82,8 @@ class Engine:
             getattr(L, name).restype = ctypes.c_char_p
         L.beltH.restype = ctypes.POINTER(ctypes.c_ubyte)
         for name in ("bashF_deep", "bashHash_keep", "beltCTR_keep", "beltMAC_keep"):
-            getattr(L, name).restype = _sz
+            if hasattr(L, name):
+                getattr(L, name).restype = _sz
         for name in DROPIN_SYMBOLS + BATCH_SYMBOLS:
             f = getattr(L, name, None)
             if f is not None and name.startswith(("bee2hip_", "bash", "belt", "bign")) and \

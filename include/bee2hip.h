@@ -177,6 +177,10 @@ const char *bee2hip_version(void);
 err_t bee2hip_time_kernel(int which, int reps, void *d_a, void *d_b, void *d_c, void *d_d,
                           size_t n, size_t aux, void *stream, float *ms);
 
+/* self-test hook: element-wise GF(2^256-189) ops on device arrays of 8 x u32 limbs
+   (op: 0 mul, 1 sqr, 2 add, 3 sub, 4 inv, 5 3*mul, 6 8*sqr, 7 canon, 8 x(2P)) */
+err_t bee2hip_debug_fe(int op, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif
