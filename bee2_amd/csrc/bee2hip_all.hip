@@ -4,4 +4,5 @@
 #include "bash_kernels.hip"
 #include "belt_kernels.hip"
 #include "bign_kernels.hip"
+#include "mixed_kernels.hip"
 #include "capi.hip"

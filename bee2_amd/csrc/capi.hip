@@ -466,3 +466,224 @@ extern "C" err_t bee2hip_debug_fe(int op, const void *d_a, const void *d_b, void
 {
     return launch_bign_debug_fe(op, d_a, d_b, d_out, n, as_stream(stream));
 }
+
+// ============================================================= bash hashing ===
+// bash_hash_st / belt_mac_st (bee2 layouts) are defined in mixed_kernels.hip
+extern "C" size_t bashHash_keep(void) { return sizeof(bash_hash_st); }   // + bashF_deep() == 0
+
+extern "C" void bashHashStart(void *state, size_t l)
+{
+    bash_hash_st *st = (bash_hash_st *)state;
+    memset(st->s, 0, sizeof st->s);
+    st->s[192 - 8] = (octet)(l / 4);
+    st->buf_len = 192 - l / 2;
+    st->pos = 0;
+}
+
+// run the device sponge over `count` host bytes for one state
+static err_t sponge_host(bash_hash_st *st, const octet *buf, size_t count)
+{
+    Scratch &s = t_scr[0];
+    err_t code = s.need(sizeof(bash_hash_st) + count + 16);
+    if (code != ERR_OK) return code;
+    octet *d = (octet *)s.p;
+    B2H_TRY(hipMemcpy(d, st, sizeof *st, hipMemcpyHostToDevice));
+    B2H_TRY(hipMemcpy(d + sizeof *st, buf, count, hipMemcpyHostToDevice));
+    code = launch_bash_sponge(d, d + sizeof *st, 0, count, 1, 0, nullptr);
+    if (code != ERR_OK) return code;
+    B2H_TRY(hipMemcpy(st, d, sizeof *st, hipMemcpyDeviceToHost));
+    return ERR_OK;
+}
+
+extern "C" void bashHashStepH(const void *buf, size_t count, void *state)
+{
+    bash_hash_st *st = (bash_hash_st *)state;
+    // not a full rate block yet: buffering only, no permutation (bash_hash.c:57-62)
+    if (count < st->buf_len - st->pos) {
+        memcpy(st->s + st->pos, buf, count);
+        st->pos += count;
+        return;
+    }
+    die_on(sponge_host(st, (const octet *)buf, count), "bashHashStepH");
+}
+
+static void hash_final(bash_hash_st *st)
+{
+    // s1 = s, pad with 0x40 0.. (bash_hash.c:86-100), one more bashF -- on the GPU
+    memcpy(st->s1, st->s, 192);
+    memset(st->s1 + st->pos, 0, st->buf_len - st->pos);
+    st->s1[st->pos] = 0x40;
+    die_on(bee2hip_bashF_batch(st->s1, 1), "bashHashStepG");
+}
+
+extern "C" void bashHashStepG(octet hash[], size_t hash_len, void *state)
+{
+    bash_hash_st *st = (bash_hash_st *)state;
+    hash_final(st);
+    memmove(hash, st->s1, hash_len);
+}
+
+extern "C" bool_t bashHashStepV(const octet hash[], size_t hash_len, void *state)
+{
+    bash_hash_st *st = (bash_hash_st *)state;
+    hash_final(st);
+    return memcmp(hash, st->s1, hash_len) == 0;
+}
+
+extern "C" err_t bashHash(octet hash[], size_t l, const void *src, size_t count)
+{
+    if (l == 0 || l % 16 != 0 || l > 256) return ERR_BAD_PARAMS;
+    if ((count && !src) || !hash) return ERR_BAD_INPUT;
+    bash_hash_st *st = new (std::nothrow) bash_hash_st;
+    if (!st) return ERR_OUTOFMEMORY;
+    bashHashStart(st, l);
+    bashHashStepH(src, count, st);
+    bashHashStepG(hash, l / 4, st);
+    delete st;
+    return ERR_OK;
+}
+
+// ================================================================ belt MAC ===
+extern "C" size_t beltMAC_keep(void) { return sizeof(belt_mac_st); }
+
+static err_t mac_host(belt_mac_st *st, const octet *buf, size_t count, int mode)
+{
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    Scratch &s = t_scr[1];
+    code = s.need(sizeof(belt_mac_st) + 8 + count + 16);
+    if (code != ERR_OK) return code;
+    octet *d = (octet *)s.p;
+    const size_t off = (sizeof(belt_mac_st) + 15) & ~(size_t)15;
+    B2H_TRY(hipMemcpy(d, st, sizeof *st, hipMemcpyHostToDevice));
+    if (count) B2H_TRY(hipMemcpy(d + off, buf, count, hipMemcpyHostToDevice));
+    code = launch_belt_mac(d, d + off, 0, count, 1, mode, nullptr);
+    if (code != ERR_OK) return code;
+    B2H_TRY(hipMemcpy(st, d, sizeof *st, hipMemcpyDeviceToHost));
+    return ERR_OK;
+}
+
+extern "C" void beltMACStart(void *state, const octet key[], size_t len)
+{
+    belt_mac_st *st = (belt_mac_st *)state;
+    beltKeyExpand2(st->key, key, len);
+    die_on(mac_host(st, nullptr, 0, 1), "beltMACStart");     // s = 0, r = E_K(0), filled = 0
+}
+
+extern "C" void beltMACStepA(const void *buf, size_t count, void *state)
+{
+    belt_mac_st *st = (belt_mac_st *)state;
+    // still filling the look-ahead block: no cipher work (belt_mac.c:63-70)
+    if (st->filled < 16 && count <= 16 - st->filled) {
+        memcpy(st->block + st->filled, buf, count);
+        st->filled += count;
+        return;
+    }
+    die_on(mac_host(st, (const octet *)buf, count, 2), "beltMACStepA");
+}
+
+extern "C" void beltMACStepG2(octet mac[], size_t mac_len, void *state)
+{
+    belt_mac_st *st = (belt_mac_st *)state;
+    die_on(mac_host(st, nullptr, 0, 4), "beltMACStepG");
+    octet full[8];
+    store32le(full, st->mac[0]);
+    store32le(full + 4, st->mac[1]);
+    memcpy(mac, full, mac_len);
+}
+extern "C" void beltMACStepG(octet mac[8], void *state) { beltMACStepG2(mac, 8, state); }
+
+extern "C" bool_t beltMACStepV2(const octet mac[], size_t mac_len, void *state)
+{
+    octet full[8];
+    beltMACStepG2(full, 8, state);
+    return memcmp(mac, full, mac_len) == 0;
+}
+extern "C" bool_t beltMACStepV(const octet mac[8], void *state) { return beltMACStepV2(mac, 8, state); }
+
+extern "C" err_t beltMAC(octet mac[8], const void *src, size_t count, const octet key[], size_t len)
+{
+    if ((len != 16 && len != 24 && len != 32) || (count && !src) || !key || !mac) return ERR_BAD_INPUT;
+    belt_mac_st *st = new (std::nothrow) belt_mac_st;
+    if (!st) return ERR_OUTOFMEMORY;
+    beltMACStart(st, key, len);
+    beltMACStepA(src, count, st);
+    beltMACStepG(mac, st);
+    delete st;
+    return ERR_OK;
+}
+
+// ====================================================== mixed batch (H4) ===
+extern "C" err_t bee2hip_bashHash_beltMAC_batch_dev(const void *d_msgs, size_t msg_len, size_t n, size_t l,
+                                                    const octet key[], size_t key_len,
+                                                    void *d_digests, void *d_tags, void *stream)
+{
+    const bool do_hash = d_digests != nullptr, do_mac = d_tags != nullptr;
+    if (do_hash && (l == 0 || l % 16 != 0 || l > 256)) return ERR_BAD_PARAMS;      // bash_hash.c:122-123
+    if (do_mac && ((key_len != 16 && key_len != 24 && key_len != 32) || !key)) return ERR_BAD_INPUT;
+    if (n && msg_len && !d_msgs) return ERR_BAD_INPUT;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    u32 kw[8] = {0};
+    if (do_mac) beltKeyExpand2(kw, key, key_len);
+    return launch_bashHash_beltMAC(d_msgs, msg_len, n, l, kw, do_hash, do_mac, d_digests, d_tags,
+                                   as_stream(stream));
+}
+
+extern "C" err_t bee2hip_bashHash_beltMAC_batch(const octet *msgs, size_t msg_len, size_t n, size_t l,
+                                                const octet key[], size_t key_len,
+                                                octet *digests, octet *tags)
+{
+    if (digests && (l == 0 || l % 16 != 0 || l > 256)) return ERR_BAD_PARAMS;
+    if (tags && ((key_len != 16 && key_len != 24 && key_len != 32) || !key)) return ERR_BAD_INPUT;
+    if (n && msg_len && !msgs) return ERR_BAD_INPUT;
+    if (n == 0) return ERR_OK;
+    const size_t dlen = digests ? l / 4 : 0;
+    const size_t in_b = (n * msg_len + 15) & ~(size_t)15, dg_b = (n * dlen + 15) & ~(size_t)15;
+    Scratch &s = t_scr[3];
+    err_t code = s.need(in_b + dg_b + n * 8 + 16);
+    if (code != ERR_OK) return code;
+    octet *d = (octet *)s.p;
+    if (n * msg_len) B2H_TRY(hipMemcpy(d, msgs, n * msg_len, hipMemcpyHostToDevice));
+    code = bee2hip_bashHash_beltMAC_batch_dev(d, msg_len, n, l, key, key_len, digests ? d + in_b : nullptr,
+                                              tags ? d + in_b + dg_b : nullptr, nullptr);
+    if (code != ERR_OK) return code;
+    if (digests) B2H_TRY(hipMemcpy(digests, d + in_b, n * dlen, hipMemcpyDeviceToHost));
+    if (tags) B2H_TRY(hipMemcpy(tags, d + in_b + dg_b, n * 8, hipMemcpyDeviceToHost));
+    return ERR_OK;
+}
+
+// ============================================================ kernel timing ===
+extern "C" err_t bee2hip_time_kernel(int which, int reps, void *d_a, void *d_b, void *d_c, void *d_d,
+                                     size_t n, size_t aux, void *stream, float *ms)
+{
+    if (reps <= 0 || !ms) return ERR_BAD_INPUT;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    hipStream_t st = as_stream(stream);
+    const octet *H = host_beltH();
+    u32 kw[8], c0[4];
+    beltKeyExpand2(kw, H + 128, 32);
+    for (int i = 0; i < 4; ++i) c0[i] = load32le(H + 192 + 4 * i);
+    hipEvent_t e0, e1;
+    B2H_TRY(hipEventCreate(&e0));
+    B2H_TRY(hipEventCreate(&e1));
+    B2H_TRY(hipEventRecord(e0, st));
+    for (int r = 0; r < reps && code == ERR_OK; ++r) {
+        switch (which) {
+        case 0: code = launch_bashF_batch(d_a, n, st); break;
+        case 1: code = launch_belt_ctr_blocks(d_a, n, kw, c0, 0, nullptr, st); break;
+        case 2: code = launch_bign_verify(k_oid_belt_hash, sizeof k_oid_belt_hash, d_a, d_b, d_c, n, d_d, st); break;
+        case 3: code = launch_bashHash_beltMAC(d_a, aux, n, 256, kw, d_b != nullptr, d_c != nullptr, d_b, d_c, st); break;
+        default: code = ERR_BAD_INPUT;
+        }
+    }
+    B2H_TRY(hipEventRecord(e1, st));
+    B2H_TRY(hipEventSynchronize(e1));
+    float total = 0;
+    B2H_TRY(hipEventElapsedTime(&total, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms = total / (float)reps;
+    return code;
+}

@@ -33,6 +33,10 @@ err_t launch_bign_verify(const uint8_t *oid_der, size_t oid_len, const void *d_h
                          const void *d_sigs, const void *d_pubkeys, size_t n, void *d_codes,
                          hipStream_t st);
 
+err_t launch_bash_sponge(void *d_states, const void *d_data, size_t stride, size_t count, size_t n,
+                         int fin, hipStream_t st);
+err_t launch_belt_mac(void *d_states, const void *d_data, size_t stride, size_t count, size_t n,
+                      int mode, hipStream_t st);
 err_t launch_bign_debug_fe(int op, const void *a, const void *b, void *out, size_t n, hipStream_t st);
 
 }  // namespace bee2hip

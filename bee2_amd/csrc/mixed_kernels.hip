@@ -1,0 +1,408 @@
+// mixed_kernels.hip -- bash sponge hashing and belt MAC over batches of messages (gfx950).
+//
+// H4 of SURVEY.md 8a: per message a bashHash(l) digest (src/crypto/bash/bash_hash.c:38-137)
+// and a beltMAC tag (src/crypto/belt/belt_mac.c:47-203).  Both are strictly serial per
+// message (sponge chain / CBC-MAC chain), so the parallel axis is the message: one lane
+// per message, 64 messages per wavefront.
+//
+//  hash_mac_fused_kernel<RW,..> : the batch kernel.  Message length a multiple of 16,
+//      level l in {128,192,256} (bash256/384/512: rate RW = 16/12/8 u64 words).  Each lane
+//      streams its own message with 16-byte loads, prefetching the next rate block while
+//      the current one is absorbed.  Per-lane strided loads are fine here: the path does
+//      ~145 integer ops per byte, so the TA cost of 64 distinct lines per load is noise
+//      and every fetched line is consumed in full by its lane (lines stay in L2 between
+//      the two halves).  The MAC's belt tables are the bank-private 128 KiB LDS layout
+//      (belt_dev.hpp): with 257 E_K per 4 KiB message the LDS lookup pipe is ~40 % busy
+//      even conflict-free, so conflicts would make it the bottleneck.
+//      Algorithmic HBM bytes: msg_len read once + l/4 + 8 written per message.
+//
+//  bash_sponge_kernel / belt_mac_kernel : generic lane-per-state forms (any level, any
+//      byte count, state resident in memory in bee2's own layout).  They back the drop-in
+//      streaming API (bashHashStepH / beltMACStepA / StepG) and batches whose shape the
+//      fused kernel does not take.
+#include "bash_dev.hpp"
+#include "belt_dev.hpp"
+#include "common.hpp"
+
+namespace bee2hip {
+
+struct MacKey { uint32_t k[8]; };
+
+// phi1 / phi2 tweaks of the last block (belt_mac.c:112-115,129-132)
+__device__ __forceinline__ void mac_phi1(uint32_t (&m)[4], const uint32_t (&r)[4])
+{
+    m[0] ^= r[1]; m[1] ^= r[2]; m[2] ^= r[3]; m[3] ^= r[0] ^ r[1];
+}
+__device__ __forceinline__ void mac_phi2(uint32_t (&m)[4], const uint32_t (&r)[4])
+{
+    m[0] ^= r[0] ^ r[3]; m[1] ^= r[0]; m[2] ^= r[1]; m[3] ^= r[2];
+}
+
+constexpr int FUSED_WG = 1024;
+
+template <int RW, bool HASH, bool MAC>
+__global__ __launch_bounds__(FUSED_WG)
+void hash_mac_fused_kernel(const uint4 *__restrict__ msgs, size_t msg_len, size_t n, uint32_t level,
+                           MacKey key, uint8_t *__restrict__ digests, uint8_t *__restrict__ tags)
+{
+    constexpr int RB = RW / 2;                   // 16-byte blocks per rate block
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (MAC) {
+        BeltTabWide::fill(smem, threadIdx.x, FUSED_WG);
+        __syncthreads();
+    }
+    const BeltTabWide T(smem);
+    const size_t idx = (size_t)blockIdx.x * FUSED_WG + threadIdx.x;
+    if (idx >= n) return;
+
+    const size_t nb16 = msg_len / 16;            // 16-byte blocks per message
+    const uint4 *m = msgs + idx * nb16;
+    const size_t nchunks = nb16 / RB;            // full rate blocks
+    const int tail = (int)(nb16 % RB);           // leftover 16-byte blocks
+
+    // ---- states
+    u64x2 a[24];
+    if (HASH) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) a[i].lo = a[i].hi = 0;
+        a[23].lo = level / 4;                    // s[192 - 8] = l / 4 (bash_hash.c:43-45)
+    }
+    uint32_t K[8], s[4] = {0, 0, 0, 0}, r[4] = {0, 0, 0, 0}, last[4] = {0, 0, 0, 0};
+    if (MAC) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) K[i] = key.k[i];
+        belt_encr(T, r, K);                      // r = E_K(0) (belt_mac.c:52-54)
+    }
+
+    // ---- full rate blocks, software-prefetched one block ahead
+    uint4 nxt[RB];
+    if (nchunks) {
+#pragma unroll
+        for (int j = 0; j < RB; ++j) nxt[j] = m[j];
+    }
+#pragma unroll 1
+    for (size_t c = 0; c < nchunks; ++c) {
+        uint4 x[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) x[j] = nxt[j];
+        if (c + 1 < nchunks) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j) nxt[j] = m[(c + 1) * RB + j];
+        }
+        if (MAC) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const size_t bi = c * RB + j;
+                if (bi + 1 < nb16) {             // every block but the last: s = E_K(s ^ X)
+                    s[0] ^= x[j].x; s[1] ^= x[j].y; s[2] ^= x[j].z; s[3] ^= x[j].w;
+                    belt_encr(T, s, K);
+                } else {
+                    last[0] = x[j].x; last[1] = x[j].y; last[2] = x[j].z; last[3] = x[j].w;
+                }
+            }
+        }
+        if (HASH) {
+            // absorb = overwrite the first RW words (bash_hash.c:69-75)
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                a[2 * j].lo = x[j].x; a[2 * j].hi = x[j].y;
+                a[2 * j + 1].lo = x[j].z; a[2 * j + 1].hi = x[j].w;
+            }
+            bash_f(a);
+        }
+    }
+    // ---- tail blocks + padding (uniform across the batch: msg_len is)
+    {
+        uint4 x[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            x[j] = make_uint4(0, 0, 0, 0);
+            if (j < tail) x[j] = m[nchunks * RB + j];
+        }
+        if (MAC) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                if (j < tail) {
+                    const size_t bi = nchunks * RB + j;
+                    if (bi + 1 < nb16) {
+                        s[0] ^= x[j].x; s[1] ^= x[j].y; s[2] ^= x[j].z; s[3] ^= x[j].w;
+                        belt_encr(T, s, K);
+                    } else {
+                        last[0] = x[j].x; last[1] = x[j].y; last[2] = x[j].z; last[3] = x[j].w;
+                    }
+                }
+            }
+            uint32_t mac[4];
+            if (nb16) {                          // full last block (belt_mac.c:105-119)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mac[i] = s[i] ^ last[i];
+                mac_phi1(mac, r);
+            } else {                             // empty message: block 80 00.. (belt_mac.c:121-136)
+                mac[0] = s[0] ^ 0x80u; mac[1] = s[1]; mac[2] = s[2]; mac[3] = s[3];
+                mac_phi2(mac, r);
+            }
+            belt_encr(T, mac, K);
+            *reinterpret_cast<uint2 *>(tags + 8 * idx) = make_uint2(mac[0], mac[1]);
+        }
+        if (HASH) {
+            // last block: tail || 0x40 || 0..  (bash_hash.c:81-102); pad word index = 2*tail
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                if (j == tail) x[j].x = 0x40u;
+                a[2 * j].lo = x[j].x; a[2 * j].hi = x[j].y;
+                a[2 * j + 1].lo = x[j].z; a[2 * j + 1].hi = x[j].w;
+            }
+            bash_f(a);
+            const int nw = (int)(level / 32);    // digest = l/4 bytes = l/32 words
+            uint64_t *d = reinterpret_cast<uint64_t *>(digests + (size_t)(level / 4) * idx);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < nw) d[i] = ((uint64_t)a[i].hi << 32) | a[i].lo;
+        }
+    }
+}
+
+// ----------------------------------------------------------------- generic ---
+// bash hash state in bee2's layout (bash_hash.c:25-31): s[192], s1[192], buf_len, pos
+struct bash_hash_st {
+    uint8_t s[192];
+    uint8_t s1[192];
+    size_t buf_len;
+    size_t pos;
+};
+
+__device__ __forceinline__ void bashF_mem(uint8_t *s)
+{
+    u64x2 a[24];
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(s);
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { a[i].lo = w[2 * i]; a[i].hi = w[2 * i + 1]; }
+    bash_f(a);
+    uint32_t *o = reinterpret_cast<uint32_t *>(s);
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { o[2 * i] = a[i].lo; o[2 * i + 1] = a[i].hi; }
+}
+
+// item i absorbs `count` bytes at data + i*stride into states[i] (bashHashStepH,
+// bash_hash.c:52-79).  fin != 0: also run the final padded permutation on the s1 copy
+// (bashHashStepG_internal, bash_hash.c:81-102).
+__global__ __launch_bounds__(64)
+void bash_sponge_kernel(bash_hash_st *__restrict__ states, const uint8_t *__restrict__ data,
+                        size_t stride, size_t count, size_t n, int fin)
+{
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    bash_hash_st *st = states + i;
+    const uint8_t *p = data + i * stride;
+    size_t pos = st->pos;
+    const size_t buf_len = st->buf_len;
+    for (size_t k = 0; k < count; ++k) {
+        st->s[pos++] = p[k];
+        if (pos == buf_len) { bashF_mem(st->s); pos = 0; }
+    }
+    st->pos = pos;
+    if (fin) {
+        for (int k = 0; k < 192; ++k) st->s1[k] = st->s[k];
+        for (size_t k = pos; k < buf_len; ++k) st->s1[k] = 0;
+        st->s1[pos] = 0x40;
+        bashF_mem(st->s1);
+    }
+}
+
+// belt MAC state in bee2's layout (belt_mac.c:32-40)
+struct belt_mac_st {
+    uint32_t key[8];
+    uint32_t s[4];
+    uint32_t r[4];
+    uint32_t mac[4];
+    uint8_t block[16];
+    size_t filled;
+};
+
+// mode bit 0: start (s = 0, r = E_K(0), filled = 0; key already expanded in the state)
+// mode bit 1: absorb `count` bytes (beltMACStepA, belt_mac.c:58-99)
+// mode bit 2: finalise into st->mac without disturbing s/block (beltMACStepG_internal, :101-138)
+__global__ __launch_bounds__(64)
+void belt_mac_kernel(belt_mac_st *__restrict__ states, const uint8_t *__restrict__ data,
+                     size_t stride, size_t count, size_t n, int mode)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[BeltTabSmall::kBytes];
+    BeltTabSmall::fill(smem, threadIdx.x, 64);
+    __syncthreads();
+    const BeltTabSmall T(smem);
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    belt_mac_st *st = states + i;
+    uint32_t K[8], s[4], r[4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) K[k] = st->key[k];
+    if (mode & 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s[k] = 0; r[k] = 0; }
+        belt_encr(T, r, K);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { st->s[k] = 0; st->r[k] = r[k]; }
+        st->filled = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s[k] = st->s[k]; r[k] = st->r[k]; }
+    size_t filled = st->filled;
+    if (mode & 2) {
+        const uint8_t *p = data + i * stride;
+        for (size_t k = 0; k < count; ++k) {
+            if (filled == 16) {                  // absorb the buffered block only when more data follows
+                const uint32_t *b = reinterpret_cast<const uint32_t *>(st->block);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s[q] ^= b[q];
+                belt_encr(T, s, K);
+                filled = 0;
+            }
+            st->block[filled++] = p[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st->s[k] = s[k];
+        st->filled = filled;
+    }
+    if (mode & 4) {
+        uint32_t mac[4];
+        if (filled == 16) {
+            const uint32_t *b = reinterpret_cast<const uint32_t *>(st->block);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mac[q] = s[q] ^ b[q];
+            mac_phi1(mac, r);
+        } else {
+            // pad 80 00.. in place, as bee2 does (belt_mac.c:123-124)
+            st->block[filled] = 0x80;
+            for (size_t k = filled + 1; k < 16; ++k) st->block[k] = 0;
+            const uint32_t *b = reinterpret_cast<const uint32_t *>(st->block);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mac[q] = s[q] ^ b[q];
+            mac_phi2(mac, r);
+        }
+        belt_encr(T, mac, K);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st->mac[q] = mac[q];
+    }
+}
+
+// gather digests / tags of the generic batch path out of the per-item states
+__global__ void gather_results_kernel(const bash_hash_st *hs, const belt_mac_st *ms, size_t n,
+                                      size_t dlen, uint8_t *digests, uint8_t *tags)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (hs && digests)
+        for (size_t k = 0; k < dlen; ++k) digests[i * dlen + k] = hs[i].s1[k];
+    if (ms && tags)
+        for (int k = 0; k < 8; ++k) tags[i * 8 + k] = (uint8_t)(ms[i].mac[k >> 2] >> (8 * (k & 3)));
+}
+__global__ void init_states_kernel(bash_hash_st *hs, belt_mac_st *ms, size_t n, uint32_t level, MacKey key)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (hs) {
+        for (int k = 0; k < 192; ++k) hs[i].s[k] = 0;
+        hs[i].s[184] = (uint8_t)(level / 4);
+        hs[i].buf_len = 192 - level / 2;
+        hs[i].pos = 0;
+    }
+    if (ms)
+        for (int k = 0; k < 8; ++k) ms[i].key[k] = key.k[k];
+}
+
+// ------------------------------------------------------------------ launchers ---
+err_t launch_bash_sponge(void *d_states, const void *d_data, size_t stride, size_t count, size_t n,
+                         int fin, hipStream_t st)
+{
+    if (n == 0) return ERR_OK;
+    hipLaunchKernelGGL(bash_sponge_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st,
+                       (bash_hash_st *)d_states, (const uint8_t *)d_data, stride, count, n, fin);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+err_t launch_belt_mac(void *d_states, const void *d_data, size_t stride, size_t count, size_t n,
+                      int mode, hipStream_t st)
+{
+    if (n == 0) return ERR_OK;
+    hipLaunchKernelGGL(belt_mac_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st,
+                       (belt_mac_st *)d_states, (const uint8_t *)d_data, stride, count, n, mode);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
+template <int RW, bool HASH, bool MAC>
+static err_t launch_fused_t(const void *d_msgs, size_t msg_len, size_t n, size_t l, const MacKey &key,
+                            void *d_digests, void *d_tags, hipStream_t st)
+{
+    auto kern = hash_mac_fused_kernel<RW, HASH, MAC>;
+    const size_t lds = MAC ? (size_t)BeltTabWide::kBytes : 0;
+    if (MAC) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+    }
+    const size_t grid = (n + FUSED_WG - 1) / FUSED_WG;
+    if (grid > 0x7fffffffull) return ERR_BAD_INPUT;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FUSED_WG), lds, st, (const uint4 *)d_msgs, msg_len, n,
+                       (uint32_t)l, key, (uint8_t *)d_digests, (uint8_t *)d_tags);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
+template <int RW>
+static err_t launch_fused_rw(const void *d_msgs, size_t msg_len, size_t n, size_t l, const MacKey &key,
+                             bool do_hash, bool do_mac, void *d_digests, void *d_tags, hipStream_t st)
+{
+    if (do_hash && do_mac) return launch_fused_t<RW, true, true>(d_msgs, msg_len, n, l, key, d_digests, d_tags, st);
+    if (do_hash) return launch_fused_t<RW, true, false>(d_msgs, msg_len, n, l, key, d_digests, d_tags, st);
+    return launch_fused_t<RW, false, true>(d_msgs, msg_len, n, l, key, d_digests, d_tags, st);
+}
+
+// scratch for the generic batch path (per device, grown on demand)
+static void *g_mixed_scratch[64];
+static size_t g_mixed_scratch_bytes[64];
+
+err_t launch_bashHash_beltMAC(const void *d_msgs, size_t msg_len, size_t n, size_t l,
+                              const uint32_t key[8], bool do_hash, bool do_mac,
+                              void *d_digests, void *d_tags, hipStream_t st)
+{
+    if (n == 0 || (!do_hash && !do_mac)) return ERR_OK;
+    MacKey k;
+    for (int i = 0; i < 8; ++i) k.k[i] = do_mac ? key[i] : 0u;
+    const bool aligned = msg_len % 16 == 0 && ((uintptr_t)d_msgs % 16) == 0 &&
+                         (!do_hash || ((uintptr_t)d_digests % 8) == 0) && (!do_mac || ((uintptr_t)d_tags % 8) == 0);
+    if (aligned && (!do_hash || l == 128 || l == 192 || l == 256)) {
+        if (!do_hash || l == 256) return launch_fused_rw<8>(d_msgs, msg_len, n, 256, k, do_hash, do_mac, d_digests, d_tags, st);
+        if (l == 192) return launch_fused_rw<12>(d_msgs, msg_len, n, l, k, do_hash, do_mac, d_digests, d_tags, st);
+        return launch_fused_rw<16>(d_msgs, msg_len, n, l, k, do_hash, do_mac, d_digests, d_tags, st);
+    }
+    // generic shapes: per-item states in scratch, byte-granular kernels
+    int dev = 0;
+    B2H_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return ERR_BAD_INPUT;
+    const size_t need = n * (sizeof(bash_hash_st) + sizeof(belt_mac_st));
+    if (g_mixed_scratch_bytes[dev] < need) {
+        if (g_mixed_scratch[dev]) (void)hipFree(g_mixed_scratch[dev]);
+        g_mixed_scratch[dev] = nullptr; g_mixed_scratch_bytes[dev] = 0;
+        if (hipMalloc(&g_mixed_scratch[dev], need) != hipSuccess) return ERR_OUTOFMEMORY;
+        g_mixed_scratch_bytes[dev] = need;
+    }
+    bash_hash_st *hs = (bash_hash_st *)g_mixed_scratch[dev];
+    belt_mac_st *ms = (belt_mac_st *)(hs + n);
+    const unsigned g = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(init_states_kernel, dim3(g), dim3(256), 0, st, do_hash ? hs : nullptr,
+                       do_mac ? ms : nullptr, n, (uint32_t)l, k);
+    err_t code = ERR_OK;
+    if (do_hash) code = launch_bash_sponge(hs, d_msgs, msg_len, msg_len, n, 1, st);
+    if (code == ERR_OK && do_mac) code = launch_belt_mac(ms, d_msgs, msg_len, msg_len, n, 1 | 2 | 4, st);
+    if (code != ERR_OK) return code;
+    hipLaunchKernelGGL(gather_results_kernel, dim3(g), dim3(256), 0, st, do_hash ? hs : nullptr,
+                       do_mac ? ms : nullptr, n, l / 4, (uint8_t *)d_digests, (uint8_t *)d_tags);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
+}  // namespace bee2hip

@@ -144,8 +144,9 @@ class Engine:
             self._ptr(hashes), self._ptr(sigs), self._ptr(pubkeys), _sz(n), self._ptr(codes),
             self._stream()), "bign128Verify_batch_dev")
 
-    def bashHash_beltMAC_batch_dev(self, msgs, msg_len, l, key, digests, tags):
-        n = msgs.numel() // msg_len if msg_len else 0
+    def bashHash_beltMAC_batch_dev(self, msgs, msg_len, l, key, digests, tags, n=None):
+        if n is None:
+            n = msgs.numel() // msg_len if msg_len else 0
         self._check(self.lib.bee2hip_bashHash_beltMAC_batch_dev(
             self._ptr(msgs), _sz(msg_len), _sz(n), _sz(l), bytes(key), _sz(len(key)),
             self._ptr(digests) if digests is not None else None,
@@ -176,8 +177,9 @@ class Engine:
                                                  bytes(pubkeys), _sz(n), codes)
         return code, list(codes)[:n]
 
-    def bashHash_beltMAC_batch(self, msgs, msg_len, l, key, want_hash=True, want_mac=True):
-        n = len(msgs) // msg_len if msg_len else 0
+    def bashHash_beltMAC_batch(self, msgs, msg_len, l, key, want_hash=True, want_mac=True, n=None):
+        if n is None:
+            n = len(msgs) // msg_len if msg_len else 0
         dig = ctypes.create_string_buffer(max(1, n * (l // 4))) if want_hash else None
         tag = ctypes.create_string_buffer(max(1, n * 8)) if want_mac else None
         self._check(self.lib.bee2hip_bashHash_beltMAC_batch(bytes(msgs), _sz(msg_len), _sz(n), _sz(l),

@@ -1,0 +1,90 @@
+"""CPU tests of the drop-in boundary: libbee2hip.so builds for gfx950 without a GPU,
+loads, and exports every symbol include/bee2hip.h declares.  No compute calls here."""
+import ctypes
+import os
+import re
+import shutil
+
+import pytest
+
+import bee2_amd
+from bee2_amd import engine as E
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    if not os.path.exists(E.LIB_PATH):
+        if shutil.which("hipcc") is None:
+            pytest.skip("libbee2hip.so not built and hipcc unavailable")
+        E.build()
+    return E.LIB_PATH
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "bee2hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text))
+    names |= set(re.findall(r"extern const char (\w+)\[\]", text))
+    keep = {n for n in names if n.startswith(("bee2hip_", "bash", "belt", "bign"))}
+    keep.discard("beltCTRStepD")           # a macro alias, as in belt.h:724
+    return keep
+
+
+def test_header_lists_the_expected_interface():
+    syms = header_symbols()
+    assert set(E.DROPIN_SYMBOLS) <= syms
+    assert set(E.BATCH_SYMBOLS) <= syms
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    exported = E.lib_exports(lib_path)
+    missing = sorted(header_symbols() - exported)
+    assert not missing, f"declared in include/bee2hip.h but not exported: {missing}"
+
+
+def test_library_loads_and_reports_version(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    lib.bee2hip_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.bee2hip_version()
+    lib.bashF_deep.restype = ctypes.c_size_t
+    assert lib.bashF_deep() == 0                           # bash_f64.c:189-192 contract
+    name = (ctypes.c_char * 16).in_dll(lib, "bash_platform").value
+    assert name.startswith(b"BASH_HIP")
+    # state sizes equal bee2's (bash_hash.c:25-36, belt_lcl.h:135-141, belt_mac.c:32-45)
+    for fn, want in (("bashHash_keep", 400), ("beltCTR_keep", 72), ("beltMAC_keep", 104)):
+        f = getattr(lib, fn)
+        f.restype = ctypes.c_size_t
+        assert f() == want, fn
+
+
+def test_sbox_generated_by_the_library_matches_standard(lib_path, golden):
+    lib = ctypes.CDLL(lib_path)
+    lib.beltH.restype = ctypes.POINTER(ctypes.c_ubyte)
+    p = lib.beltH()
+    assert bytes(p[i] for i in range(256)) == golden.H
+
+
+def test_argument_checks_need_no_gpu(lib_path):
+    """error paths that bee2 takes before touching data (bash_hash.c:122-123,
+    belt_ctr.c:117-123, bign_params.c:244-280, oid.c:94-101)"""
+    eng = bee2_amd.load(lib_path)
+    assert eng.bashHash(0, b"")[0] == E.ERR_BAD_PARAMS
+    assert eng.bashHash(100, b"")[0] == E.ERR_BAD_PARAMS
+    assert eng.beltCTR(b"x" * 16, b"k" * 17, b"i" * 16)[0] == E.ERR_BAD_INPUT
+    assert eng.beltMAC(b"x", b"k" * 5)[0] == E.ERR_BAD_INPUT
+    p = eng.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
+    assert p.l == 128 and bytes(p.p)[:2] == b"\x43\xff"
+    with pytest.raises(E.EngineError):
+        eng.bignParamsStd("1.2.3")
+    h, s, k = b"\0" * 32, b"\0" * 48, b"\0" * 64
+    assert eng.bignVerify(p, b"\x06\x01", h, s, k) == E.ERR_BAD_OID          # truncated DER
+    assert eng.bignVerify(p, b"\x05\x00", h, s, k) == E.ERR_BAD_OID          # wrong tag
+    assert eng.bignVerify(p, b"\x06\x02\x80\x01", h, s, k) == E.ERR_BAD_OID  # leading 0x80
+    bad = eng.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
+    bad.p[0] = 0x42
+    assert eng.bignVerify(bad, E.OID_BELT_HASH_DER, h, s, k) == E.ERR_BAD_PARAMS
+    other = eng.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
+    other.b[0] ^= 1                       # a different (valid-looking) curve: no device constants
+    assert eng.bignVerify(other, E.OID_BELT_HASH_DER, h, s, k) == E.ERR_NOT_IMPLEMENTED

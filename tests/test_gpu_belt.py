@@ -1,0 +1,151 @@
+"""-m gpu: belt block / CTR kernels and the belt drop-in layer (mirrors
+test/crypto/belt_test.c:178-215,423-472)."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from gpulib import dev, engine, host
+
+pytestmark = pytest.mark.gpu
+
+
+def test_belt_block_A1_dropin(golden):
+    eng = engine()
+    k = golden.kat["belt_block_A1"]
+    assert eng.beltBlockEncr(bytes.fromhex(k["in"]), bytes.fromhex(k["key"])).hex() == k["out"]
+
+
+def test_belt_block_encr_many(orc, golden):
+    eng = engine()
+    key = golden.H[128:160]
+    kw = orc.key_expand(key)
+    data = orc.fill(16 * 1000, 3)
+    t = dev(data)
+    eng.beltBlockEncr_dev(t, bytes(kw))
+    torch.cuda.synchronize()
+    out = host(t)
+    for i in (0, 1, 63, 64, 500, 999):
+        assert out[16 * i: 16 * i + 16] == orc.block_encr(data[16 * i: 16 * i + 16], key)
+
+
+def test_belt_ctr_A15_A16_dropin_with_state(orc, golden):
+    eng = engine()
+    for k in golden.kat["belt_ctr"]:
+        msg, key, iv = (bytes.fromhex(k[x]) for x in ("in", "key", "iv"))
+        ct, st = eng.beltCTR_steps(msg, key, iv, k["splits"])
+        assert ct.hex() == k["out"], k["name"]
+        # the streaming state must end up exactly as beltCTRStepE leaves it
+        ost = ctypes.create_string_buffer(72)
+        orc.lib.orc_beltCTRStart(ost, key, ctypes.c_size_t(len(key)), iv)
+        buf = ctypes.create_string_buffer(msg, len(msg))
+        off = 0
+        for s in k["splits"]:
+            orc.lib.orc_beltCTRStepE(ctypes.byref(buf, off), ctypes.c_size_t(s), ost)
+            off += s
+        assert st == ost.raw
+        code, one = eng.beltCTR(msg, key, iv)
+        assert code == 0 and one.hex() == k["out"]
+
+
+def test_belt_ctr_golden_random_cases(golden):
+    eng = engine()
+    for c in golden.belt_bash:
+        msg, key, iv = (bytes.fromhex(c[x]) for x in ("msg", "key", "iv"))
+        ct, _ = eng.beltCTR_steps(msg, key, iv, c["splits"])
+        assert ct.hex() == c["ctr"]
+        assert eng.beltCTR(msg, key, iv)[1].hex() == c["ctr"]
+
+
+@pytest.mark.parametrize("nblocks", [1, 2, 63, 64, 1023, 1024, 2047, 2048, 2049, 100_000, 1 << 20])
+def test_belt_ctr_blocks_dev_vs_oracle(orc, golden, nblocks):
+    eng = engine()
+    kw, c0 = orc.ctr_start(golden.H[128:160], golden.H[192:208])
+    data = np.frombuffer(orc.fill(16 * nblocks, nblocks), dtype=np.uint8).copy()
+    t = torch.from_numpy(data.copy()).cuda()
+    first = 12345
+    eng.beltCTR_blocks_dev(t, kw, c0, first)
+    torch.cuda.synchronize()
+    want = data.copy()
+    orc.ctr_blocks_np(want, kw, c0, first=first, nthreads=8)
+    assert np.array_equal(t.cpu().numpy(), want)
+
+
+def test_belt_ctr_counter_carries(orc, golden):
+    """128-bit little-endian counter: carries across every 32-bit word (belt_ctr.c:27-35)"""
+    eng = engine()
+    kw = bytes(orc.key_expand(golden.H[128:160]))
+    for c0_int in (2 ** 32 - 3, 2 ** 64 - 3, 2 ** 96 - 3, 2 ** 128 - 3, 2 ** 64 - 1 - 2 ** 20):
+        c0 = c0_int.to_bytes(16, "little")
+        for first in (0, 2 ** 33, 2 ** 64 - 10):
+            data = np.frombuffer(orc.fill(16 * 4096, 9), dtype=np.uint8).copy()
+            t = torch.from_numpy(data.copy()).cuda()
+            eng.beltCTR_blocks_dev(t, kw, c0, first)
+            torch.cuda.synchronize()
+            want = data.copy()
+            orc.ctr_blocks_np(want, kw, c0, first=first)
+            assert np.array_equal(t.cpu().numpy(), want), (hex(c0_int), first)
+
+
+def test_belt_ctr_streaming_split_invariance(orc, golden):
+    """any split of the stream gives the same bytes and the same final state"""
+    eng = engine()
+    rnd = random.Random(11)
+    key, iv = golden.H[128:160], golden.H[192:208]
+    msg = orc.fill(5000, 5)
+    want = orc.ctr(msg, key, iv)
+    for _ in range(6):
+        splits, left = [], len(msg)
+        while left:
+            s = min(left, rnd.choice((1, 5, 15, 16, 17, 31, 33, 64, 255, 1000)))
+            splits.append(s)
+            left -= s
+        ct, _ = eng.beltCTR_steps(msg, key, iv, splits)
+        assert ct == want
+
+
+def test_belt_ctr_full_size_16GiB(orc, golden):
+    """BASELINE.json configs[2]: 16 GiB stream, one key.  Sampled windows vs the oracle,
+    plus the size-independent property E(E(x)) = x over the whole buffer."""
+    eng = engine()
+    nbytes = 16 << 30
+    free, _ = torch.cuda.mem_get_info()
+    if free < nbytes + (2 << 30):
+        pytest.skip("not enough HBM free for the 16 GiB case")
+    kw, c0 = orc.ctr_start(golden.H[128:160], golden.H[192:208])
+    buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    buf.view(torch.int64).random_()                   # synthetic stream, generated in HBM
+    nblocks = nbytes // 16
+    win = 1 << 16                                      # 64 KiB windows
+    offs = [0, nbytes - win] + [((i * 2654435761) % (nblocks - win // 16)) * 16 for i in range(1, 40)]
+    before = {o: buf[o:o + win].cpu().numpy().copy() for o in offs}
+    checksum0 = int(buf.view(torch.int64).sum().item())
+    eng.beltCTR_blocks_dev(buf, kw, c0, 0)
+    torch.cuda.synchronize()
+    for o in offs:
+        want = before[o].copy()
+        orc.ctr_blocks_np(want, kw, c0, first=o // 16, nthreads=4)
+        assert np.array_equal(buf[o:o + win].cpu().numpy(), want), o
+    assert int(buf.view(torch.int64).sum().item()) != checksum0
+    eng.beltCTR_blocks_dev(buf, kw, c0, 0)             # decrypt = encrypt
+    torch.cuda.synchronize()
+    for o in offs:
+        assert np.array_equal(buf[o:o + win].cpu().numpy(), before[o])
+    assert int(buf.view(torch.int64).sum().item()) == checksum0
+
+
+def test_belt_mac_A17_and_golden_dropin(orc, golden):
+    eng = engine()
+    for k in golden.kat["belt_mac"]:
+        msg, key = bytes.fromhex(k["in"]), bytes.fromhex(k["key"])
+        code, tag = eng.beltMAC(msg, key)
+        assert code == 0 and tag.hex() == k["out"]
+        tag2, ok = eng.beltMAC_steps(msg, key, [len(msg) // 2, len(msg) - len(msg) // 2])
+        assert tag2.hex() == k["out"] and ok
+    for c in golden.belt_bash:
+        msg, key = bytes.fromhex(c["msg"]), bytes.fromhex(c["key"])
+        assert eng.beltMAC(msg, key)[1].hex() == c["mac"]
+        tag, ok = eng.beltMAC_steps(msg, key, c["splits"])
+        assert tag.hex() == c["mac"] and ok

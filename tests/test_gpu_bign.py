@@ -1,0 +1,146 @@
+"""-m gpu: GF(2^256-189) layer and batched bign verify (mirrors
+test/crypto/bign_test.c:338-357,388-400, bign128_test.c:101-163, math/zz_test.c)."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from bee2_amd import engine as E
+from gpulib import dev, engine, host
+
+pytestmark = pytest.mark.gpu
+P = 2 ** 256 - 189
+
+
+def _fe_run(eng, op, A, B):
+    ta = dev(b"".join(x.to_bytes(32, "little") for x in A))
+    tb = dev(b"".join(x.to_bytes(32, "little") for x in B))
+    out = torch.empty_like(ta)
+    code = eng.lib.bee2hip_debug_fe(op, ctypes.c_void_p(ta.data_ptr()), ctypes.c_void_p(tb.data_ptr()),
+                                    ctypes.c_void_p(out.data_ptr()), ctypes.c_size_t(len(A)), None)
+    assert code == 0
+    torch.cuda.synchronize()
+    raw = host(out)
+    return [int.from_bytes(raw[i:i + 32], "little") for i in range(0, len(raw), 32)]
+
+
+def test_field_ops_vs_python_ints():
+    """regular GF(p) routines against big-int arithmetic on random and boundary values,
+    including non-canonical inputs in [p, 2^256) (the kernels keep values weakly reduced)"""
+    eng = engine()
+    rnd = random.Random(1)
+    special = [0, 1, 2, 188, 189, 190, P - 2, P - 1, P, P + 1, P + 188, 2 ** 256 - 1, 2 ** 255,
+               2 ** 128, 2 ** 128 - 1, 2 ** 224 - 1, (1 << 256) - (1 << 32)]
+    pool = special + [rnd.getrandbits(256) for _ in range(300)]
+    A = special * len(special) + [rnd.choice(pool) for _ in range(4096)]
+    B = [b for b in special for _ in special] + [rnd.choice(pool) for _ in range(4096)]
+    ops = {0: lambda a, b: a * b % P, 1: lambda a, b: a * a % P, 2: lambda a, b: (a + b) % P,
+           3: lambda a, b: (a - b) % P, 4: lambda a, b: pow(a, P - 2, P), 5: lambda a, b: 3 * a * b % P,
+           6: lambda a, b: 8 * a * a % P, 7: lambda a, b: a % P}
+    for op, f in ops.items():
+        got = _fe_run(eng, op, A, B)
+        want = [f(a, b) for a, b in zip(A, B)]
+        assert got == want, f"field op {op}"
+
+
+def test_bign_G2_G3_dropin(golden):
+    eng = engine()
+    params = eng.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
+    for k in golden.kat["bign_verify"]:
+        h, s, p = (bytes.fromhex(k[x]) for x in ("hash", "sig", "pubkey"))
+        assert eng.bign128Verify(h, s, p) == k["code"], k["name"]
+        assert eng.bignVerify(params, E.OID_BELT_HASH_DER, h, s, p) == k["code"], k["name"]
+
+
+def test_bign_base_set_all_valid(golden):
+    eng = engine()
+    hs, ss, ps = golden.bign_base_arrays()
+    n = len(hs) // 32
+    codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    eng.bign128Verify_batch_dev(dev(hs), dev(ss), dev(ps), codes)
+    torch.cuda.synchronize()
+    assert int((codes != 0).sum()) == 0
+    code, host_codes = eng.bignVerify_batch(hs[: 32 * 100], ss[: 48 * 100], ps[: 64 * 100])
+    assert code == 0 and host_codes == [0] * 100
+
+
+def test_bign_edge_cases_match_reference_codes(golden):
+    """Q = +-G and small multiples, R = O, s1 >= q, coordinates >= p, off-curve Q, H >= q,
+    bit flips: the err_t of the reference for each (tools/make_golden.py)"""
+    eng = engine()
+    Ecases = golden.bign_edge
+    eh = b"".join(bytes.fromhex(e["hash"]) for e in Ecases)
+    es = b"".join(bytes.fromhex(e["sig"]) for e in Ecases)
+    ep = b"".join(bytes.fromhex(e["pubkey"]) for e in Ecases)
+    codes = torch.full((len(Ecases),), -1, dtype=torch.int32, device="cuda")
+    eng.bign128Verify_batch_dev(dev(eh), dev(es), dev(ep), codes)
+    torch.cuda.synchronize()
+    got = [int(c) & 0xFFFFFFFF for c in codes.cpu().numpy()]
+    bad = [(e["name"], g, e["code"]) for e, g in zip(Ecases, got) if g != e["code"]]
+    assert not bad, bad[:10]
+    assert {0, 505, 510} <= set(got)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 257, 1000])
+def test_bign_ragged_batch_sizes(orc, golden, n):
+    eng = engine()
+    hs, ss, ps = golden.bign_base_arrays()
+    hs, ss, ps = bytearray(hs[: 32 * n]), bytearray(ss[: 48 * n]), bytearray(ps[: 64 * n])
+    for i in range(0, n, 3):
+        ss[48 * i + (i % 48)] ^= 0x10
+    codes = torch.full((n + 8,), 0x7777, dtype=torch.int32, device="cuda")
+    eng.bign128Verify_batch_dev(dev(hs), dev(ss), dev(ps), codes)
+    torch.cuda.synchronize()
+    got = [int(c) & 0xFFFFFFFF for c in codes.cpu().numpy()]
+    assert got[:n] == orc.verify_batch(hs, ss, ps, nthreads=8)
+    assert got[n:] == [0x7777] * 8
+
+
+def test_bign_other_oid_and_errors(orc, golden):
+    eng = engine()
+    params = eng.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
+    h, s, p = golden.bign_base[0]
+    # a different (valid) OID changes the hashed message: the belt-hash OID signature fails
+    other = bytes.fromhex("06092A7000020022651F52")
+    assert eng.bignVerify(params, other, h, s, p) == E.ERR_BAD_SIG
+    assert eng.bignVerify(params, b"\x06\x01", h, s, p) == E.ERR_BAD_OID
+    code, _ = eng.bignVerify_batch(h, s, p, oid_der=b"\x07\x01\x00")
+    assert code == E.ERR_BAD_OID
+
+
+def test_bign_full_size_2pow18_tiled_and_corrupted(orc, golden):
+    """BASELINE.json configs[3]: 2^18 signatures.  The 2048 genuine triples are tiled
+    128x and a seeded 1/16 of the entries corrupted; every corrupted entry
+    is checked against the oracle, every untouched one must verify."""
+    eng = engine()
+    hs, ss, ps = golden.bign_base_arrays()
+    nb = len(hs) // 32
+    reps = (1 << 18) // nb
+    H = np.tile(np.frombuffer(hs, dtype=np.uint8), reps).reshape(-1, 32).copy()
+    S = np.tile(np.frombuffer(ss, dtype=np.uint8), reps).reshape(-1, 48).copy()
+    K = np.tile(np.frombuffer(ps, dtype=np.uint8), reps).reshape(-1, 64).copy()
+    n = H.shape[0]
+    rnd = random.Random(0xB164)
+    bad_idx = sorted(rnd.sample(range(n), n // 16))
+    for i in bad_idx:
+        kind = rnd.randrange(4)
+        if kind == 0:
+            S[i, rnd.randrange(16)] ^= 1 << rnd.randrange(8)
+        elif kind == 1:
+            S[i, 16 + rnd.randrange(32)] ^= 1 << rnd.randrange(8)
+        elif kind == 2:
+            H[i, rnd.randrange(32)] ^= 1 << rnd.randrange(8)
+        else:
+            K[i, rnd.randrange(64)] ^= 1 << rnd.randrange(8)
+    codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    eng.bign128Verify_batch_dev(dev(H.reshape(-1)), dev(S.reshape(-1)), dev(K.reshape(-1)), codes)
+    torch.cuda.synchronize()
+    got = codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    want_bad = orc.verify_batch(H[bad_idx].tobytes(), S[bad_idx].tobytes(), K[bad_idx].tobytes(), nthreads=16)
+    assert [int(got[i]) for i in bad_idx] == want_bad
+    mask = np.ones(n, dtype=bool)
+    mask[bad_idx] = False
+    assert int((got[mask] != 0).sum()) == 0
+    assert set(want_bad) <= {0, 505, 510} and 510 in want_bad
