@@ -1,0 +1,366 @@
+#!/usr/bin/env python3
+"""bench.py -- bee2 hot path on MI355X: bashF perms/s (headline), beltCTR GiB/s,
+bign-curve256v1 verifies/s, bash512+beltMAC messages/s.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU.  A "step" is one pass of the hot path over one batch of synthetic
+input already resident in HBM: the headline step is bashF over 2^20 independent 192-byte
+states (BASELINE.json configs[1]).  Batches are independent, so ranks shard by index with
+no data-path collective ("weak" scaling: per-GPU work fixed); RCCL is used for the one
+parameter broadcast (key / ctr0) and for the max-over-ranks of the timed region.
+
+Rank 0 prints ONE JSON line.  `value` = perms/s summed over all ranks.  Extra objects:
+  roofline      dominant kernel (bashF_batch_kernel): algorithmic bytes / avg launch time,
+                launch time measured inside this run with hipEvents on the launch stream
+  cpu_baseline  the reference itself (oracle/_ref, bee2 compiled by oracle/Makefile) or the
+                oracle port, timed on this box's host cores on a bounded sample (rank 0, N=1)
+  others        the other two headline metrics of BASELINE.json + the H4 mixed job, each
+                timed the same way (K steps, barrier + synchronize on both sides)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bee2_amd  # noqa: E402
+from bee2_amd import shard  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BASHF_BYTES = 384                # algorithmic bytes per permutation (192 read + 192 written)
+CTR_BYTES_PER_BLOCK = 32         # 16 read + 16 written per 16-byte block
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--only", default="", help="comma list of {bashF,ctr,verify,mixed}; default all")
+    ap.add_argument("--ctr-gib", type=float, default=16.0)
+    return ap.parse_args()
+
+
+class Dist:
+    def __init__(self, want):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.on = self.world > 1
+        if self.on:
+            import torch.distributed as dist
+            self.dist = dist
+            torch.cuda.set_device(self.local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local))
+        else:
+            torch.cuda.set_device(0)
+        if want != self.world and self.rank == 0:
+            print(f"[bench] note: --gpus {want} but WORLD_SIZE={self.world}; using {self.world}", file=sys.stderr)
+
+    def barrier(self):
+        if self.on:
+            self.dist.barrier()
+
+    def max(self, x):
+        if not self.on:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def bcast_bytes(self, b, n):
+        """rank 0's bytes to everyone (the only payload that crosses GPUs: <= 48 bytes)"""
+        t = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        if self.rank == 0:
+            t.copy_(torch.frombuffer(bytearray(b), dtype=torch.uint8))
+        if self.on:
+            self.dist.broadcast(t, src=0)
+        return t.cpu().numpy().tobytes()
+
+    def close(self):
+        if self.on:
+            self.dist.destroy_process_group()
+
+
+def timed(dist, steps, warmup, fn):
+    """W untimed steps, then exactly K timed steps between barrier+synchronize pairs;
+    returns the max over ranks of the elapsed seconds"""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    return dist.max(time.perf_counter() - t0)
+
+
+# ------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(which, cores):
+    """Time the reference (or the oracle port) on `cores` host threads.  Returns dict."""
+    import orclib
+    import refgen
+    orc = orclib.load()
+    cpuflags = open("/proc/cpuinfo").read() if os.path.exists("/proc/cpuinfo") else ""
+    have_avx512 = " avx512f" in cpuflags
+    ref = None
+    kind = "port"
+    variant = "oracle scalar C"
+    if refgen.have_ref():
+        path = refgen.REF_AVX512_SO if (which == "bashF" and have_avx512 and os.path.exists(refgen.REF_AVX512_SO)) else refgen.REF_SO
+        ref = ctypes.CDLL(path)
+        kind = "reference"
+        variant = "bee2 BASH_AVX512" if path == refgen.REF_AVX512_SO else "bee2 BASH_64 / scalar C"
+    fnptr = lambda name: ctypes.cast(getattr(ref, name), ctypes.c_void_p)  # noqa: E731
+    H = orc.beltH()
+    out = {"cores": cores, "kind": kind, "impl": variant}
+
+    def clock(run, units, min_s=2.0, max_reps=64):
+        run()                                     # warm caches / lazy init
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            run()
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt >= min_s or reps >= max_reps:
+                return units * reps / dt, reps
+
+    if which == "bashF":
+        n = 1 << 20
+        buf = np.empty(192 * n, dtype=np.uint8)
+        orc.fill_np(buf, 0xBA5F)
+        p = ctypes.c_void_p(buf.ctypes.data)
+        if ref is not None:
+            run = lambda th: orc.lib.orc_drive_ref_bashF(fnptr("bashF"), p, ctypes.c_size_t(n), th)  # noqa: E731
+        else:
+            run = lambda th: orc.lib.orc_bashF_batch(p, ctypes.c_size_t(n), th)  # noqa: E731
+        v1, _ = clock(lambda: run(1), n)
+        vall, reps = clock(lambda: run(cores), n, min_s=4.0)
+        out.update(value=vall, unit="perms/s", single_thread=v1,
+                   sample=f"{reps} passes over the same 2^20-state batch, {cores} threads over disjoint slices")
+        if ref is not None and variant != "bee2 BASH_64 / scalar C":
+            ref64 = ctypes.CDLL(refgen.REF_SO)
+            f64 = ctypes.cast(ref64.bashF, ctypes.c_void_p)
+            v64, _ = clock(lambda: orc.lib.orc_drive_ref_bashF(f64, p, ctypes.c_size_t(n), cores), n)
+            v64_1, _ = clock(lambda: orc.lib.orc_drive_ref_bashF(f64, p, ctypes.c_size_t(n), 1), n)
+            out["bash64_all_cores"] = v64
+            out["bash64_single_thread"] = v64_1
+    elif which == "ctr":
+        nbytes = 256 << 20
+        buf = np.zeros(nbytes, dtype=np.uint8)
+        kw, c0 = orc.ctr_start(H[128:160], H[192:208])
+        p = ctypes.c_void_p(buf.ctypes.data)
+        nb = nbytes // 16
+        if ref is not None:
+            run = lambda th: orc.lib.orc_drive_ref_ctr(fnptr("beltCTRStepE"), p, ctypes.c_size_t(nb), kw, c0, ctypes.c_uint64(0), th)  # noqa: E731
+        else:
+            run = lambda th: orc.lib.orc_beltCTR_blocks(p, ctypes.c_size_t(nb), kw, c0, ctypes.c_uint64(0), th)  # noqa: E731
+        v1, _ = clock(lambda: run(1), nbytes / 2 ** 30, min_s=2.0, max_reps=2)
+        vall, reps = clock(lambda: run(cores), nbytes / 2 ** 30, min_s=4.0)
+        out.update(value=vall, unit="GiB/s", single_thread=v1,
+                   sample=f"{reps} passes over a 256 MiB prefix of the stream, {cores} threads")
+    elif which == "verify":
+        G = orclib.Golden()
+        hs, ss, ps = G.bign_base_arrays()
+        n = len(hs) // 32
+        codes = (ctypes.c_uint32 * n)()
+        if ref is not None:
+            ref.bign128Verify.restype = ctypes.c_uint32
+            run = lambda th: orc.lib.orc_drive_ref_verify(fnptr("bign128Verify"), hs, ss, ps, ctypes.c_size_t(n), codes, th)  # noqa: E731
+        else:
+            run = lambda th: orc.lib.orc_bign128Verify_batch(hs, ss, ps, ctypes.c_size_t(n), codes, th)  # noqa: E731
+        v1, _ = clock(lambda: orc.lib.orc_drive_ref_verify(fnptr("bign128Verify"), hs, ss, ps, ctypes.c_size_t(256), codes, 1)
+                      if ref is not None else orc.lib.orc_bign128Verify_batch(hs, ss, ps, ctypes.c_size_t(256), codes, 1),
+                      256, min_s=1.0, max_reps=8)
+        vall, reps = clock(lambda: run(cores), n, min_s=4.0)
+        assert all(c == 0 for c in codes)
+        out.update(value=vall, unit="verifies/s", single_thread=v1,
+                   sample=f"{reps} passes over the 2048 genuine signatures of tests/golden/bign_base.bin, {cores} threads")
+    elif which == "mixed":
+        n, ml = 1 << 12, 4096
+        msgs = orc.fill(n * ml, 0x4D1C)
+        dig = ctypes.create_string_buffer(64 * n)
+        tag = ctypes.create_string_buffer(8 * n)
+        key = H[128:160]
+        if ref is not None:
+            run = lambda th: orc.lib.orc_drive_ref_mixed(fnptr("bashHash"), fnptr("beltMAC"), msgs, ctypes.c_size_t(ml), ctypes.c_size_t(n), key, ctypes.c_size_t(32), dig, tag, th)  # noqa: E731
+        else:
+            run = lambda th: orc.lib.orc_bash512_beltMAC_batch(msgs, ctypes.c_size_t(ml), ctypes.c_size_t(n), key, ctypes.c_size_t(32), dig, tag, th)  # noqa: E731
+        vall, reps = clock(lambda: run(cores), n, min_s=4.0)
+        out.update(value=vall, unit="messages/s", sample=f"{reps} passes over 2^12 x 4 KiB messages, {cores} threads")
+    return out
+
+
+# --------------------------------------------------------------------------------- main
+def main():
+    args = parse()
+    dist = Dist(args.gpus)
+    eng = bee2_amd.load()                     # fails loudly without libbee2hip.so
+    eng.set_device(torch.cuda.current_device())
+    only = set(x for x in args.only.split(",") if x) or {"bashF", "ctr", "verify", "mixed"}
+    K, W, N = args.steps, args.warmup, dist.world
+    do_cpu = (not args.no_cpu) and dist.rank == 0 and N == 1
+    cores = os.cpu_count() or 1
+    H = eng.beltH()
+
+    # the only cross-GPU payload: expanded key (32 B) + ctr0 (16 B), broadcast once over RCCL
+    if dist.rank == 0:
+        kw, c0 = eng.beltCTRStart(H[128:160], H[192:208])      # ctr0 = E_K(iv) on the GPU
+    else:
+        kw, c0 = bytes(32), bytes(16)
+    blob = dist.bcast_bytes(kw + c0, 48)
+    kw, c0 = blob[:32], blob[32:]
+
+    result = {}
+    others = {}
+
+    # ---------------------------------------------------------------- bashF (headline)
+    if "bashF" in only:
+        n = 1 << 20
+        st = torch.empty(192 * n, dtype=torch.uint8, device="cuda")
+        g = torch.Generator(device="cuda")
+        g.manual_seed(0xBA5F + dist.rank)
+        st.view(torch.int64).random_(generator=g)                # synthetic states, generated in HBM
+        el = timed(dist, K, W, lambda: eng.bashF_batch_dev(st))
+        value = N * n * K / el
+        ms_launch = eng.time_kernel(0, max(K, 20), st, n=n)       # hipEvents on the launch stream
+        ach = BASHF_BYTES * n / (ms_launch * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "r01_bashF_pmc.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "bashF perms/s", "value": value, "unit": "perms/s", "n_gpus": N, "steps": K, "warmup": W,
+            "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "bashF batch: 2^20 independent 192-byte sponge states per GPU (BASELINE configs[1])",
+                       "states_per_gpu": n, "parallelism": f"dp{N} (index-sharded, no data-path collective)"},
+            "roofline": {"kernel": "bashF_batch_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": ms_launch, "algorithmic_bytes_per_launch": BASHF_BYTES * n,
+                         "note": "VALU-bound in practice: ~5760 issue-slot units per permutation (DESIGN.md)"},
+        }
+        if do_cpu:
+            result["cpu_baseline"] = cpu_baseline("bashF", cores)
+        del st
+
+    # ------------------------------------------------------------------------ beltCTR
+    if "ctr" in only:
+        nbytes = int(args.ctr_gib * (1 << 30)) // 16 * 16
+        free, _ = torch.cuda.mem_get_info()
+        if free < nbytes + (1 << 30):
+            nbytes = (int(free * 0.5) // (1 << 20)) << 20
+        buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        buf.view(torch.int64).random_()
+        nb = nbytes // 16
+        _, _, first = shard.ctr_shard(dist.rank, N, nbytes * N)     # rank r owns blocks [r nb, (r+1) nb)
+        kc = max(3, min(K, 10))
+        el = timed(dist, kc, 2, lambda: eng.beltCTR_blocks_dev(buf, kw, c0, first))
+        ms_launch = eng.time_kernel(1, kc, buf, n=nb)
+        ach = CTR_BYTES_PER_BLOCK * nb / (ms_launch * 1e-3) / 1e9
+        others["beltCTR"] = {
+            "metric": "beltCTR GiB/s", "value": N * nbytes * kc / el / 2 ** 30, "unit": "GiB/s", "steps": kc,
+            "ms_per_step": el / kc * 1e3,
+            "config": {"workload": f"beltCTR bulk encrypt, {nbytes / 2**30:.1f} GiB stream per GPU, one key (BASELINE configs[2])"},
+            "roofline": {"kernel": "beltCTR_blocks_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms_launch,
+                         "note": "LDS-lookup bound: 224 ds_read_b32 per block (DESIGN.md)"},
+        }
+        if do_cpu:
+            others["beltCTR"]["cpu_baseline"] = cpu_baseline("ctr", cores)
+        del buf
+
+    # ------------------------------------------------------------------------- verify
+    if "verify" in only:
+        import orclib
+        G = orclib.Golden()
+        hs, ss, ps = G.bign_base_arrays()
+        nbase = len(hs) // 32
+        reps = (1 << 18) // nbase
+        # tile the 2048 genuine triples to 2^18 and corrupt a seeded 1/16;
+        # verification cost does not depend on the values, so tiling does not flatter it
+        Hh = np.tile(np.frombuffer(hs, dtype=np.uint8), reps).reshape(-1, 32).copy()
+        Ss = np.tile(np.frombuffer(ss, dtype=np.uint8), reps).reshape(-1, 48).copy()
+        Kk = np.tile(np.frombuffer(ps, dtype=np.uint8), reps).reshape(-1, 64).copy()
+        n = Hh.shape[0]
+        rng = np.random.default_rng(0xB164 + dist.rank)
+        bad = rng.choice(n, n // 16, replace=False)
+        Ss[bad, rng.integers(0, 48, bad.size)] ^= (1 << rng.integers(0, 8, bad.size)).astype(np.uint8)
+        dh, ds, dk = (torch.from_numpy(x.reshape(-1)).cuda() for x in (Hh, Ss, Kk))
+        codes = torch.empty(n, dtype=torch.int32, device="cuda")
+        kv = max(3, min(K, 10))
+        el = timed(dist, kv, 2, lambda: eng.bign128Verify_batch_dev(dh, ds, dk, codes))
+        ms_launch = eng.time_kernel(2, kv, dh, ds, dk, codes, n=n)
+        got = codes.cpu().numpy()
+        okmask = np.ones(n, dtype=bool)
+        okmask[bad] = False
+        sane = bool((got[okmask] == 0).all() and (got[bad] == 510).all())
+        others["bignVerify"] = {
+            "metric": "bign-curve256v1 verifies/s", "value": N * n * kv / el, "unit": "verifies/s", "steps": kv,
+            "ms_per_step": el / kv * 1e3, "verdicts_as_expected": sane,
+            "config": {"workload": "bignVerify batch: 2^18 signatures per GPU on bign-curve256v1 (BASELINE configs[3]); "
+                                   "2048 genuine triples tiled 128x, seeded 1/16 corrupted"},
+            "roofline": {"kernels": "bign_prep+main+slow+tail", "bound": "valu-int", "avg_batch_ms": ms_launch,
+                         "note": "integer-multiplier bound; HBM irrelevant (148 B/signature)"},
+        }
+        if do_cpu:
+            others["bignVerify"]["cpu_baseline"] = cpu_baseline("verify", cores)
+        del dh, ds, dk, codes
+
+    # -------------------------------------------------------------------------- mixed
+    if "mixed" in only:
+        n, ml = 1 << 21, 4096                                      # 2^24 / 8 messages per GPU
+        free, _ = torch.cuda.mem_get_info()
+        while n * ml + (1 << 30) > free and n > 1024:
+            n //= 2
+        msgs = torch.empty(n * ml, dtype=torch.uint8, device="cuda")
+        msgs.view(torch.int64).random_()
+        dig = torch.empty(n * 64, dtype=torch.uint8, device="cuda")
+        tag = torch.empty(n * 8, dtype=torch.uint8, device="cuda")
+        km = max(2, min(K, 5))
+        el = timed(dist, km, 1, lambda: eng.bashHash_beltMAC_batch_dev(msgs, ml, 256, H[128:160], dig, tag))
+        others["bash512_beltMAC"] = {
+            "metric": "bash512+beltMAC messages/s", "value": N * n * km / el, "unit": "messages/s", "steps": km,
+            "ms_per_step": el / km * 1e3, "GiB_per_s": N * n * ml * km / el / 2 ** 30,
+            "config": {"workload": f"bash512 + beltMAC over {n} x 4 KiB messages per GPU (BASELINE configs[4] share of one GPU)"},
+        }
+        if do_cpu:
+            others["bash512_beltMAC"]["cpu_baseline"] = cpu_baseline("mixed", cores)
+        del msgs, dig, tag
+
+    if not result:                        # --only without bashF: promote the first other metric
+        k0 = next(iter(others))
+        o = others.pop(k0)
+        result = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "n_gpus": N, "steps": o["steps"],
+                  "warmup": W, "ms_per_step": o["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                  "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": o["config"]}
+        for k in ("roofline", "cpu_baseline"):
+            if k in o:
+                result[k] = o[k]
+    result["others"] = others
+    result["host"] = {"cpu_count": cores, "device": torch.cuda.get_device_name(torch.cuda.current_device()),
+                      "engine": eng.version()}
+    if dist.rank == 0:
+        print(json.dumps(result))
+    dist.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -147,3 +147,20 @@ void orc_fill_splitmix64(uint8_t *buf, size_t nbytes, uint64_t seed)
     }
     for (size_t i = nw * 8; i < nbytes; ++i) buf[i] = (uint8_t)(seed + i);
 }
+
+/* ---- drivers for timing the REFERENCE itself (oracle/_ref) on many host threads ----
+ * bench.py loads libbee2ref*.so with ctypes and hands the function pointers in; the
+ * loops live here so that no per-call Python overhead is timed. */
+typedef void (*ref_bashF_fn)(uint8_t *block, void *stack);
+typedef struct { uint8_t *states; ref_bashF_fn f; } ref_bashF_job;
+static void ref_bashF_range(void *ctx, size_t lo, size_t hi)
+{
+    ref_bashF_job *j = (ref_bashF_job *)ctx;
+    uint8_t stack[256];                       /* bashF_deep() <= 200 on every platform */
+    for (size_t i = lo; i < hi; ++i) j->f(j->states + 192 * i, stack);
+}
+void orc_drive_ref_bashF(void *fn, uint8_t *states, size_t n, int nthreads)
+{
+    ref_bashF_job j = {states, (ref_bashF_fn)fn};
+    orc_parallel_for(n, nthreads, ref_bashF_range, &j);
+}

@@ -332,3 +332,47 @@ void orc_bash512_beltMAC_batch(const uint8_t *msgs, size_t msg_len, size_t n,
     (void)orc_beltH();
     orc_parallel_for(n, nthreads, mixed_range, &j);
 }
+
+/* ---- reference drivers (see bash_oracle.c) ---- */
+typedef void (*ref_ctr_step_fn)(void *buf, size_t count, void *state);
+typedef struct { uint8_t *buf; const uint32_t *key; const uint32_t *ctr0; uint64_t first; ref_ctr_step_fn f; } ref_ctr_job;
+static void ref_ctr_range(void *ctx, size_t lo, size_t hi)
+{
+    ref_ctr_job *j = (ref_ctr_job *)ctx;
+    /* a belt_ctr_st (belt_lcl.h:135-141) positioned at block `first + lo`: the reference
+       has no seek, but its state is a flat POD the caller may construct */
+    orc_belt_ctr_st st;
+    memcpy(st.key, j->key, 32);
+    ctr_add(st.ctr, j->ctr0, j->first + lo);
+    memset(st.block, 0, 16);
+    st.reserved = 0;
+    j->f(j->buf + 16 * lo, 16 * (hi - lo), &st);
+}
+void orc_drive_ref_ctr(void *step_fn, uint8_t *buf, size_t nblocks, const uint32_t key[8],
+                       const uint32_t ctr0[4], uint64_t first, int nthreads)
+{
+    ref_ctr_job j = {buf, key, ctr0, first, (ref_ctr_step_fn)step_fn};
+    orc_parallel_for(nblocks, nthreads, ref_ctr_range, &j);
+}
+
+typedef uint32_t (*ref_hash_fn)(uint8_t *hash, size_t l, const void *src, size_t count);
+typedef uint32_t (*ref_mac_fn)(uint8_t mac[8], const void *src, size_t count, const uint8_t *key, size_t len);
+typedef struct {
+    const uint8_t *msgs; size_t msg_len; const uint8_t *key; size_t key_len;
+    uint8_t *digests; uint8_t *tags; ref_hash_fn h; ref_mac_fn m;
+} ref_mixed_job;
+static void ref_mixed_range(void *ctx, size_t lo, size_t hi)
+{
+    ref_mixed_job *j = (ref_mixed_job *)ctx;
+    for (size_t i = lo; i < hi; ++i) {
+        const uint8_t *p = j->msgs + i * j->msg_len;
+        j->h(j->digests + 64 * i, 256, p, j->msg_len);
+        j->m(j->tags + 8 * i, p, j->msg_len, j->key, j->key_len);
+    }
+}
+void orc_drive_ref_mixed(void *hash_fn, void *mac_fn, const uint8_t *msgs, size_t msg_len, size_t n,
+                         const uint8_t *key, size_t key_len, uint8_t *digests, uint8_t *tags, int nthreads)
+{
+    ref_mixed_job j = {msgs, msg_len, key, key_len, digests, tags, (ref_hash_fn)hash_fn, (ref_mac_fn)mac_fn};
+    orc_parallel_for(n, nthreads, ref_mixed_range, &j);
+}

@@ -360,3 +360,21 @@ void orc_bign128Verify_batch(const uint8_t *hashes, const uint8_t *sigs, const u
     (void)orc_beltH();
     orc_parallel_for(n, nthreads, verify_range, &j);
 }
+
+/* ---- reference driver (see bash_oracle.c) ---- */
+typedef uint32_t (*ref_verify_fn)(const uint8_t *hash, const uint8_t *sig, const uint8_t *pubkey);
+typedef struct { const uint8_t *h, *s, *k; uint32_t *codes; ref_verify_fn f; } ref_vjob;
+static void ref_verify_range(void *ctx, size_t lo, size_t hi)
+{
+    ref_vjob *j = (ref_vjob *)ctx;
+    for (size_t i = lo; i < hi; ++i) j->codes[i] = j->f(j->h + 32 * i, j->s + 48 * i, j->k + 64 * i);
+}
+void orc_drive_ref_verify(void *fn, const uint8_t *hashes, const uint8_t *sigs, const uint8_t *pubkeys,
+                          size_t n, uint32_t *codes, int nthreads)
+{
+    ref_vjob j = {hashes, sigs, pubkeys, codes, (ref_verify_fn)fn};
+    /* bign128Verify builds its process-global curve object on first use (bign128.c:34-88):
+       take that hit once, single-threaded, before fanning out */
+    if (n) codes[0] = j.f(hashes, sigs, pubkeys);
+    orc_parallel_for(n, nthreads, ref_verify_range, &j);
+}

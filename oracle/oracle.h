@@ -108,6 +108,18 @@ void orc_bash512_beltMAC_batch(const uint8_t *msgs, size_t msg_len, size_t n,
                                uint8_t *digests /* n*64 */, uint8_t *tags /* n*8 */,
                                int nthreads);
 
+/* ---- drivers that time the REFERENCE (oracle/_ref/libbee2ref*.so) on host threads:
+   the caller passes the reference's own function pointers (bashF, beltCTRStepE,
+   bign128Verify, bashHash, beltMAC) obtained with dlsym/ctypes ---------------------- */
+void orc_drive_ref_bashF(void *bashF_fn, uint8_t *states, size_t n, int nthreads);
+void orc_drive_ref_ctr(void *beltCTRStepE_fn, uint8_t *buf, size_t nblocks, const uint32_t key[8],
+                       const uint32_t ctr0[4], uint64_t first, int nthreads);
+void orc_drive_ref_verify(void *bign128Verify_fn, const uint8_t *hashes, const uint8_t *sigs,
+                          const uint8_t *pubkeys, size_t n, uint32_t *codes, int nthreads);
+void orc_drive_ref_mixed(void *bashHash_fn, void *beltMAC_fn, const uint8_t *msgs, size_t msg_len,
+                         size_t n, const uint8_t *key, size_t key_len, uint8_t *digests,
+                         uint8_t *tags, int nthreads);
+
 /* deterministic synthetic-input generator shared by tests and bench:
    x_i = splitmix64(seed + i), written little-endian */
 void orc_fill_splitmix64(uint8_t *buf, size_t nbytes, uint64_t seed);

@@ -1,0 +1,106 @@
+"""CPU tests of the N>1 path: world_size-2 gloo.  Each rank processes its index shard (the
+oracle stands in for the kernels -- no GPU here); the concatenation must equal the
+single-stream result and the parameter block must arrive by broadcast."""
+import os
+import socket
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import orclib
+    from bee2_amd import shard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = orclib.load()
+    H = orc.beltH()
+    # parameters exist on rank 0 only and travel once
+    blob = b"".join(orc.ctr_start(H[128:160], H[192:208])) if rank == 0 else bytes(48)
+    blob = shard.broadcast_params(dist, blob)
+    kw, c0 = blob[:32], blob[32:]
+    # CTR: ragged stream, rank-local counter offset
+    nbytes = 16 * 1001 + 5
+    stream = orc.fill(nbytes, 0xBE17)
+    lo, hi, first = shard.ctr_shard(rank, world, nbytes)
+    part = np.frombuffer(stream[lo:hi], dtype=np.uint8).copy()
+    full_blocks = (hi - lo) // 16 * 16
+    head = part[:full_blocks].copy()
+    orc.ctr_blocks_np(head, kw, c0, first=first)
+    out = head.tobytes()
+    if hi - lo > full_blocks:          # ragged tail on the last rank: one more gamma block
+        tail = np.zeros(16, dtype=np.uint8)
+        tail[: hi - lo - full_blocks] = part[full_blocks:]
+        orc.ctr_blocks_np(tail, kw, c0, first=first + full_blocks // 16)
+        out += tail.tobytes()[: hi - lo - full_blocks]
+    # bashF: independent states
+    n = 1001
+    states = orc.fill(192 * n, 0xBA5F)
+    slo, shi = shard.shard_range(rank, world, n)
+    bout = orc.bashF_batch(states[192 * slo: 192 * shi])
+    # gather for the check (results only; nothing like this is on the data path)
+    sizes = [None] * world
+    dist.all_gather_object(sizes, (lo, hi, slo, shi))
+    t = torch.tensor([len(out), len(bout)])
+    dist.all_reduce(t)
+    with open(os.path.join(outdir, f"r{rank}.bin"), "wb") as f:
+        f.write(out + bout)
+    with open(os.path.join(outdir, f"r{rank}.meta"), "w") as f:
+        f.write(f"{len(out)} {len(bout)} {int(t[0])} {int(t[1])} {sizes}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_ctr_and_bashF_equal_single_stream(tmp_path, orc):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    H = orc.beltH()
+    nbytes = 16 * 1001 + 5
+    stream = orc.fill(nbytes, 0xBE17)
+    want_ctr = orc.ctr(stream, H[128:160], H[192:208])
+    states = orc.fill(192 * 1001, 0xBA5F)
+    want_bash = orc.bashF_batch(states)
+    got_ctr, got_bash = b"", b""
+    for r in range(world):
+        raw = open(tmp_path / f"r{r}.bin", "rb").read()
+        meta = open(tmp_path / f"r{r}.meta").read().split()
+        a, b = int(meta[0]), int(meta[1])
+        assert int(meta[2]) == nbytes and int(meta[3]) == 192 * 1001      # all-reduce saw every item
+        got_ctr += raw[:a]
+        got_bash += raw[a:a + b]
+    assert got_ctr == want_ctr
+    assert got_bash == want_bash
+
+
+def test_shard_ranges_cover_and_balance():
+    from bee2_amd import shard
+    for n in (0, 1, 7, 8, 1000, 2 ** 20 + 3):
+        for world in (1, 2, 3, 8):
+            cuts = [shard.shard_range(r, world, n) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard.shard_range(2, 2, 10)
+    lo, hi, first = shard.ctr_shard(1, 2, 16 * 10 + 3)
+    assert (lo, hi, first) == (80, 163, 5)

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof (rocprofv3 output of tools/profile_r01.sh) into the small,
+committed summaries under profiles/.   usage: python tools/summarize_prof.py r01"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+DST = os.path.join(ROOT, "profiles")
+
+
+def short(name):
+    n = name.split("(")[0]
+    n = n.replace("void ", "").replace("bee2hip::", "")
+    return n.strip()
+
+
+def agg(path):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        d[k]["duration_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        meta[k] = {"grid": int(r["Grid_Size"]), "workgroup": int(r["Workgroup_Size"]),
+                   "lds_block_size": int(r["LDS_Block_Size"]), "vgpr_count": int(r["VGPR_Count"]),
+                   "sgpr_count": int(r["SGPR_Count"]), "scratch": int(r["Scratch_Size"])}
+    out = {}
+    for k, v in d.items():
+        if "rocclr" in k or "at::" in k or "elementwise" in k:
+            continue
+        out[k] = dict(meta[k], **{c: sum(x) / len(x) for c, x in v.items()})
+    return out
+
+
+def main(tag):
+    os.makedirs(DST, exist_ok=True)
+    shutil.copy(os.path.join(SRC, "stats", "bench_kernel_stats.csv"), os.path.join(DST, f"{tag}_kernel_stats.csv"))
+    summary = {"command": "rocprofv3 --kernel-trace --stats / --pmc <set> -- python bench.py --steps 20 --warmup 3 --no-cpu "
+                          "(PMC passes: --ctr-gib 4; FETCH/WRITE passes: --only bashF,ctr)",
+               "note": "counter values are per-launch averages; FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts "
+                       "half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM) -> doubled in hbm_bytes_per_launch"}
+    for f in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_sq1", "pmc_sq2"):
+        p = os.path.join(SRC, f, "bench_counter_collection.csv")
+        if os.path.exists(p):
+            summary[f] = agg(p)
+    with open(os.path.join(DST, f"{tag}_pmc_summary.json"), "w") as fh:
+        json.dump(summary, fh, indent=1)
+    # per-kernel HBM traffic for bench.py's roofline.traffic
+    for kern, fname, alg in (("bashF_batch_kernel", f"{tag}_bashF_pmc.json", 384 * (1 << 20)),):
+        fe = summary.get("pmc_FETCH_SIZE", {}).get(kern)
+        wr = summary.get("pmc_WRITE_SIZE", {}).get(kern)
+        if fe and wr:
+            hbm = (2 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024
+            with open(os.path.join(DST, fname), "w") as fh:
+                json.dump({"kernel": kern, "FETCH_SIZE_KiB": fe["FETCH_SIZE"], "WRITE_SIZE_KiB": wr["WRITE_SIZE"],
+                           "fetch_correction": "x2 (gfx950 wide coalesced reads)", "hbm_bytes_per_launch": hbm,
+                           "algorithmic_bytes_per_launch": alg, "ratio": hbm / alg,
+                           "avg_duration_ns_under_pmc": fe["duration_ns"]}, fh, indent=1)
+    print(open(os.path.join(DST, f"{tag}_kernel_stats.csv")).read()[:3000])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
