@@ -12,7 +12,8 @@
 //                 = 128 KiB of the CU's 160 KiB LDS.  Lane l only ever touches bank
 //                 (l & 31), and ds_read_b32 services lanes 0-31 / 32-63 as separate
 //                 groups, so every lookup is conflict-free: 2 LDS cycles per
-//                 wave-instruction instead of ~7 with a shared 1 KiB table.
+//                 wave-instruction instead of ~7 with a shared 1 KiB table
+//                 (SQ_LDS_BANK_CONFLICT = 0 measured, profiles/r01_pmc_summary.json).
 //   BeltTabSmall  the same 4 tables without replication (4 KiB) for kernels where
 //                 belt is a sliver of the work (bign verify tail, single blocks).
 #pragma once
@@ -30,72 +31,124 @@ __device__ __forceinline__ uint32_t rotl32c(uint32_t x, int r)
     return __builtin_amdgcn_alignbit(x, x, 32 - r);
 }
 
+// (a & b) | c in one full-rate op
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, (0xF0 & 0xCC) | 0xAA);
+}
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xF0 ^ 0xCC ^ 0xAA);
+}
+
+// opaque shifts: written as asm so that LLVM's demanded-bits logic cannot rewrite
+// "(x >> 7) & 0x1FE00" into v_bfe_u32 + shift or an SDWA form (both half rate)
+template <int N>
+__device__ __forceinline__ uint32_t shl_c(uint32_t x)
+{
+    uint32_t r;
+    asm("v_lshlrev_b32 %0, %1, %2" : "=v"(r) : "n"(N), "v"(x));
+    return r;
+}
+template <int N>
+__device__ __forceinline__ uint32_t shr_c(uint32_t x)
+{
+    uint32_t r;
+    asm("v_lshrrev_b32 %0, %1, %2" : "=v"(r) : "n"(N), "v"(x));
+    return r;
+}
+
+// the four table values of one G-box; the consumer folds them with v_bitop3 (xor3)
+struct GParts { uint32_t p, q; };          // G = p ^ q, p already = t0 ^ t1 ^ t2
+
 struct BeltTabWide {
-    static constexpr int kBytes = 4 * 256 * 32 * 4;        // 131072
-    const uint8_t *base;                                    // LDS base + (lane & 31) * 4
+    // dword index = byte*128 + R*32 + bank: the table selector R sits in the instruction's
+    // immediate offset (R*128 bytes), the byte in address bits [16:9], the bank-private copy
+    // in bits [6:2].  Address = (x_shifted & 0x1FE00) | bank4 is ONE v_bitop3 (full rate) after
+    // ONE shift, instead of v_bfe + v_lshl_add (both half rate on gfx950).
+    static constexpr int kBytes = 256 * 4 * 32 * 4;        // 131072
+    typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+    uint32_t base;          // LDS byte address of the table + (lane & 31) * 4
     // fill from every thread of the workgroup; caller must __syncthreads() afterwards
     __device__ static void fill(uint8_t *lds, int tid, int nthreads)
     {
         uint32_t *t = reinterpret_cast<uint32_t *>(lds);
-        for (int i = tid; i < 4 * 256 * 32; i += nthreads) {
-            const int e = i >> 5;                           // (r, idx); low 5 bits = bank copy
-            const int r = e >> 8, idx = e & 255;
+        for (int i = tid; i < 256 * 4 * 32; i += nthreads) {
+            const int r = (i >> 5) & 3, idx = i >> 7;
             t[i] = rotl32c((uint32_t)c_beltH[idx], 5 + 8 * r);
         }
     }
-    __device__ explicit BeltTabWide(const uint8_t *lds) : base(lds + ((threadIdx.x & 31) << 2)) {}
-    template <int R>   // R = 0..3  ->  rotl by 5, 13, 21, 29
-    __device__ __forceinline__ uint32_t get(uint32_t byte) const
+    __device__ explicit BeltTabWide(const uint8_t *l)
     {
-        return *reinterpret_cast<const uint32_t *>(base + R * 32768 + (byte << 7));
+        const uint32_t tab = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)l;
+        // the OR-composed address needs the table 128 KiB aligned in LDS, i.e. at LDS address 0
+        // (dynamic LDS with no static __shared__ in the kernel)
+        if (tab & (kBytes - 1)) __builtin_trap();
+        base = tab + ((threadIdx.x & 31) << 2);
+    }
+    template <int R0>
+    __device__ __forceinline__ GParts g(uint32_t x) const
+    {
+        constexpr uint32_t M = 0x1FE00u;
+        const uint32_t a0 = and_or(shl_c<9>(x), M, base), a1 = and_or(shl_c<1>(x), M, base);
+        const uint32_t a2 = and_or(shr_c<7>(x), M, base), a3 = and_or(shr_c<15>(x), M, base);
+        const uint32_t t0 = *(lds_u32 *)(uintptr_t)(a0 + ((R0 + 0) & 3) * 128);
+        const uint32_t t1 = *(lds_u32 *)(uintptr_t)(a1 + ((R0 + 1) & 3) * 128);
+        const uint32_t t2 = *(lds_u32 *)(uintptr_t)(a2 + ((R0 + 2) & 3) * 128);
+        const uint32_t t3 = *(lds_u32 *)(uintptr_t)(a3 + ((R0 + 3) & 3) * 128);
+        GParts r;
+        r.p = xor3(t0, t1, t2);
+        r.q = t3;
+        return r;
     }
 };
 
 struct BeltTabSmall {
     static constexpr int kBytes = 4 * 256 * 4;             // 4096
-    const uint8_t *base;
+    const uint8_t *lds;
     __device__ static void fill(uint8_t *lds, int tid, int nthreads)
     {
         uint32_t *t = reinterpret_cast<uint32_t *>(lds);
         for (int i = tid; i < 4 * 256; i += nthreads)
             t[i] = rotl32c((uint32_t)c_beltH[i & 255], 5 + 8 * (i >> 8));
     }
-    __device__ explicit BeltTabSmall(const uint8_t *lds) : base(lds) {}
-    template <int R>
-    __device__ __forceinline__ uint32_t get(uint32_t byte) const
+    __device__ explicit BeltTabSmall(const uint8_t *l) : lds(l) {}
+    template <int R0>
+    __device__ __forceinline__ GParts g(uint32_t x) const
     {
-        return *reinterpret_cast<const uint32_t *>(base + R * 1024 + (byte << 2));
+        const uint32_t b0 = x & 255u, b1 = (x >> 8) & 255u, b2 = (x >> 16) & 255u, b3 = x >> 24;
+        const uint32_t t0 = *reinterpret_cast<const uint32_t *>(lds + ((R0 + 0) & 3) * 1024 + (b0 << 2));
+        const uint32_t t1 = *reinterpret_cast<const uint32_t *>(lds + ((R0 + 1) & 3) * 1024 + (b1 << 2));
+        const uint32_t t2 = *reinterpret_cast<const uint32_t *>(lds + ((R0 + 2) & 3) * 1024 + (b2 << 2));
+        const uint32_t t3 = *reinterpret_cast<const uint32_t *>(lds + ((R0 + 3) & 3) * 1024 + (b3 << 2));
+        GParts r;
+        r.p = xor3(t0, t1, t2);
+        r.q = t3;
+        return r;
     }
 };
 
-// G_r(x), r = 5 + 8*R0: belt_block.c:210-215.  Table (R0 + k) & 3 serves byte k.
-template <int R0, class Tab>
-__device__ __forceinline__ uint32_t belt_G(const Tab &T, uint32_t x)
-{
-    const uint32_t b0 = x & 255u, b1 = (x >> 8) & 255u, b2 = (x >> 16) & 255u, b3 = x >> 24;
-    return T.template get<(R0 + 0) & 3>(b0) ^ T.template get<(R0 + 1) & 3>(b1) ^
-           T.template get<(R0 + 2) & 3>(b2) ^ T.template get<(R0 + 3) & 3>(b3);
-}
-#define BELT_G5(T, x)  belt_G<0>(T, x)
-#define BELT_G13(T, x) belt_G<1>(T, x)
-#define BELT_G21(T, x) belt_G<2>(T, x)
+// G_r(x), r = 5 + 8*R0 (belt_block.c:210-215): table (R0 + k) & 3 serves byte k of x.
+// G5 = g<0>, G13 = g<1>, G21 = g<2>.
 
 // one round, steps 2.1-2.9 of the standard (belt_block.c:231-240); I = round number,
-// key index (7 I - 7 + j) mod 8 (subkey_e, :242)
+// key index (7 I - 7 + j) mod 8 (subkey_e, :242).  Every "x ^= G" is one more xor3.
 template <int I, class Tab>
 __device__ __forceinline__ void belt_round(const Tab &T, uint32_t &a, uint32_t &b, uint32_t &c,
                                            uint32_t &d, const uint32_t (&K)[8])
 {
     constexpr int o = 7 * I - 7;
-    b ^= BELT_G5(T, a + K[(o + 0) & 7]);
-    c ^= BELT_G21(T, d + K[(o + 1) & 7]);
-    a -= BELT_G13(T, b + K[(o + 2) & 7]);
-    const uint32_t e = BELT_G21(T, b + c + K[(o + 3) & 7]) ^ (uint32_t)I;
+    GParts g;
+    g = T.template g<0>(a + K[(o + 0) & 7]);   b = xor3(b, g.p, g.q);                 // b ^= G5(a + k)
+    g = T.template g<2>(d + K[(o + 1) & 7]);   c = xor3(c, g.p, g.q);                 // c ^= G21(d + k)
+    g = T.template g<1>(b + K[(o + 2) & 7]);   a -= g.p ^ g.q;                        // a -= G13(b + k)
+    g = T.template g<2>(b + c + K[(o + 3) & 7]);
+    const uint32_t e = xor3(g.p, g.q, (uint32_t)I);                                   // G21(b + c + k) ^ i
     b += e;
     c -= e;
-    d += BELT_G13(T, c + K[(o + 4) & 7]);
-    b ^= BELT_G21(T, a + K[(o + 5) & 7]);
-    c ^= BELT_G5(T, d + K[(o + 6) & 7]);
+    g = T.template g<1>(c + K[(o + 4) & 7]);   d += g.p ^ g.q;                        // d += G13(c + k)
+    g = T.template g<2>(a + K[(o + 5) & 7]);   b = xor3(b, g.p, g.q);                 // b ^= G21(a + k)
+    g = T.template g<0>(d + K[(o + 6) & 7]);   c = xor3(c, g.p, g.q);                 // c ^= G5(d + k)
 }
 
 // E_K on (x0..x3): eight rounds with the (a,b,c,d) <- (b,d,a,c) role change realised by
@@ -113,6 +166,67 @@ __device__ __forceinline__ void belt_encr(const Tab &T, uint32_t (&x)[4], const 
     belt_round<7>(T, d, c, b, a, K);
     belt_round<8>(T, c, a, d, b, K);
     x[0] = b; x[1] = d; x[2] = a; x[3] = c;
+}
+
+// N independent blocks in lockstep: each G-box step is issued for all N blocks before the
+// next step, so 4N LDS reads are in flight per wave (the LDS round trip, not the VALU, is
+// what a single E_K chain waits on).
+template <int N, int I, class Tab>
+__device__ __forceinline__ void belt_round_n(const Tab &T, uint32_t (&a)[N], uint32_t (&b)[N],
+                                             uint32_t (&c)[N], uint32_t (&d)[N], const uint32_t (&K)[8])
+{
+    constexpr int o = 7 * I - 7;
+    GParts g[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) g[u] = T.template g<0>(a[u] + K[(o + 0) & 7]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) b[u] = xor3(b[u], g[u].p, g[u].q);
+#pragma unroll
+    for (int u = 0; u < N; ++u) g[u] = T.template g<2>(d[u] + K[(o + 1) & 7]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) c[u] = xor3(c[u], g[u].p, g[u].q);
+#pragma unroll
+    for (int u = 0; u < N; ++u) g[u] = T.template g<1>(b[u] + K[(o + 2) & 7]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) a[u] -= g[u].p ^ g[u].q;
+#pragma unroll
+    for (int u = 0; u < N; ++u) g[u] = T.template g<2>(b[u] + c[u] + K[(o + 3) & 7]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const uint32_t e = xor3(g[u].p, g[u].q, (uint32_t)I);
+        b[u] += e;
+        c[u] -= e;
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u) g[u] = T.template g<1>(c[u] + K[(o + 4) & 7]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) d[u] += g[u].p ^ g[u].q;
+#pragma unroll
+    for (int u = 0; u < N; ++u) g[u] = T.template g<2>(a[u] + K[(o + 5) & 7]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) b[u] = xor3(b[u], g[u].p, g[u].q);
+#pragma unroll
+    for (int u = 0; u < N; ++u) g[u] = T.template g<0>(d[u] + K[(o + 6) & 7]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) c[u] = xor3(c[u], g[u].p, g[u].q);
+}
+
+template <int N, class Tab>
+__device__ __forceinline__ void belt_encr_n(const Tab &T, uint32_t (&x)[N][4], const uint32_t (&K)[8])
+{
+    uint32_t a[N], b[N], c[N], d[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) { a[u] = x[u][0]; b[u] = x[u][1]; c[u] = x[u][2]; d[u] = x[u][3]; }
+    belt_round_n<N, 1>(T, a, b, c, d, K);
+    belt_round_n<N, 2>(T, b, d, a, c, K);
+    belt_round_n<N, 3>(T, d, c, b, a, K);
+    belt_round_n<N, 4>(T, c, a, d, b, K);
+    belt_round_n<N, 5>(T, a, b, c, d, K);
+    belt_round_n<N, 6>(T, b, d, a, c, K);
+    belt_round_n<N, 7>(T, d, c, b, a, K);
+    belt_round_n<N, 8>(T, c, a, d, b, K);
+#pragma unroll
+    for (int u = 0; u < N; ++u) { x[u][0] = b[u]; x[u][1] = d[u]; x[u][2] = a[u]; x[u][3] = c[u]; }
 }
 
 // sigma1/sigma2 of belt-compress (src/crypto/belt/belt_compr.c:27-87):

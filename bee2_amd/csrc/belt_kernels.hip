@@ -24,7 +24,7 @@ namespace bee2hip {
 __constant__ uint8_t c_beltH[256];
 
 constexpr int CTR_WG = 1024;
-constexpr int CTR_ILP = 2;          // independent blocks per lane per step
+constexpr int CTR_ILP = 4;          // independent blocks per lane per step
 
 struct BeltKey { uint32_t k[8]; };
 struct BeltCtr { uint32_t c[4]; };
@@ -66,8 +66,7 @@ void beltCTR_blocks_kernel(uint4 *__restrict__ buf, size_t nblocks, BeltKey key,
             if (live[u]) data[u] = buf[i];
             ctr_at(g[u], ctr0, first + i + 1);
         }
-#pragma unroll
-        for (int u = 0; u < CTR_ILP; ++u) belt_encr(T, g[u], K);
+        belt_encr_n<CTR_ILP>(T, g, K);
 #pragma unroll
         for (int u = 0; u < CTR_ILP; ++u) {
             const size_t i = t0 + (size_t)u * CTR_WG + threadIdx.x;

@@ -287,6 +287,7 @@ def load(path=LIB_PATH):
     """Load libbee2hip.so.  Fails loudly if it is missing -- there is no fallback path."""
     global _engine
     if _engine is None:
+        path = os.environ.get("BEE2HIP_LIB", path)       # experiments only (tools/ubench)
         if not os.path.exists(path):
             raise EngineError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(bee2_amd has no CPU fallback)")

@@ -43,8 +43,8 @@ CTR_BYTES_PER_BLOCK = 32         # 16 read + 16 written per 16-byte block
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--only", default="", help="comma list of {bashF,ctr,verify,mixed}; default all")
     ap.add_argument("--ctr-gib", type=float, default=16.0)
@@ -93,8 +93,14 @@ class Dist:
 
 
 def timed(dist, steps, warmup, fn):
-    """W untimed steps, then exactly K timed steps between barrier+synchronize pairs;
-    returns the max over ranks of the elapsed seconds"""
+    """clock pre-warm, W untimed steps, then exactly K timed steps between
+    barrier+synchronize pairs; returns the max over ranks of the elapsed seconds"""
+    # the chip needs a few hundred ms of load to reach its sustained clock (DVFS); without this
+    # the first launches of a short run are ~8 % slower than steady state (tools/gap_test.py)
+    t_end = time.perf_counter() + 0.3
+    while time.perf_counter() < t_end:
+        fn()
+        torch.cuda.synchronize()
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -237,7 +243,7 @@ def main():
         st.view(torch.int64).random_(generator=g)                # synthetic states, generated in HBM
         el = timed(dist, K, W, lambda: eng.bashF_batch_dev(st))
         value = N * n * K / el
-        ms_launch = eng.time_kernel(0, max(K, 20), st, n=n)       # hipEvents on the launch stream
+        ms_launch = eng.time_kernel(0, max(K, 50), st, n=n)       # hipEvents on the launch stream
         ach = BASHF_BYTES * n / (ms_launch * 1e-3) / 1e9
         traffic = None
         prof = os.path.join(ROOT, "profiles", "r01_bashF_pmc.json")

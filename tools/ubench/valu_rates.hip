@@ -59,20 +59,21 @@ template<int OP> __global__ void k(uint32_t* out, uint32_t seed){
     uint32_t r=c; for(int i=0;i<8;i++){ r^=a[i]^(uint32_t)w[i]^(uint32_t)(w[i]>>32)^(uint32_t)d[i]; }
     out[blockIdx.x*blockDim.x+threadIdx.x]=r;
 }
+static int g_wps=8;
 template<int OP> int run(const char* name, int ops_per){
     uint32_t* d; CHK(hipMalloc(&d, 1024*1024*16));
-    int blocks=256*8, threads=256;   // 8 WG/CU x 4 waves = 8 waves/SIMD
+    int blocks=256*g_wps, threads=256;   // g_wps WG/CU x 4 waves = g_wps waves/SIMD
     hipEvent_t e0,e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     k<OP><<<blocks,threads>>>(d,12345); CHK(hipDeviceSynchronize());
     CHK(hipEventRecord(e0)); k<OP><<<blocks,threads>>>(d,12345); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
     float ms; CHK(hipEventElapsedTime(&ms,e0,e1));
     double waves=(double)blocks*threads/64, instr=waves*ITERS*8*ops_per;
     // cycles per wave-instruction per SIMD at 2.4 GHz, 1024 SIMDs
-    double cyc = ms*1e-3*2.4e9*1024/instr;
+    double cyc = ms*1e-3*2.4e9*1024/instr; if(g_wps!=8) { printf("[wps=%d] ", g_wps); }
     printf("%-22s %8.3f ms  %6.2f cyc/wave-instr/SIMD (@2.4GHz)  %.2f Tinstr-lanes/s\n", name, ms, cyc, instr*64/ms*1e-9);
     hipFree(d); return 0;
 }
-int main(){
+int main(int argc,char**argv){ if(argc>1){ for(int w : {1,2,4,8}){ g_wps=w; run<4>("v_add_u32",1); run<9>("v_bitop3_b32",1); run<8>("v_alignbit_b32",1); run<0>("v_mad_u64_u32",1);} return 0; }
     run<4>("v_add_u32",1); run<8>("v_alignbit_b32",1); run<9>("v_bitop3_b32",1);
     run<0>("v_mad_u64_u32 (vcc)",1); run<10>("v_mad_u64_u32 (sgpr)",1);
     run<1>("v_mul_lo_u32",1); run<2>("v_mul_hi_u32",1);
