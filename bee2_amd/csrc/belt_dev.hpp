@@ -103,6 +103,60 @@ struct BeltTabWide {
     }
 };
 
+// Two-table variant, 64 KiB: T5[b] = S(b) << 5 and T29[b] = rotl(S(b), 29).  S(b) << 5
+// spans bits 5..12, so the rotations by 13 and 21 are plain left shifts of the same entry
+// (no wrap-around); only the byte that lands on bits 29..36 needs the wrapped table:
+//   G5  = T5[b0] ^ T5[b1]<<8  ^ T5[b2]<<16 ^ T29[b3]
+//   G13 = T5[b0]<<8 ^ T5[b1]<<16 ^ T29[b2] ^ T5[b3]
+//   G21 = T5[b0]<<16 ^ T29[b1] ^ T5[b2]    ^ T5[b3]<<8
+// Two extra full-rate shifts per G-box buy a 64 KiB footprint, i.e. TWO 1024-thread
+// workgroups (8 wavefronts per SIMD) per CU -- a single wavefront can issue a VALU op only
+// every ~6 cycles on gfx950 (tools/ubench), so occupancy, not instruction count, was what
+// capped the 128 KiB variant.
+struct BeltTabTwo {
+    // dword index = byte*64 + t*32 + bank  (t = 0: T5, t = 1: T29): byte in address bits
+    // [15:8], table select in the immediate offset (t*128), bank copy in bits [6:2]
+    static constexpr int kBytes = 256 * 2 * 32 * 4;        // 65536
+    typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+    uint32_t base;
+    __device__ static void fill(uint8_t *lds, int tid, int nthreads)
+    {
+        uint32_t *t = reinterpret_cast<uint32_t *>(lds);
+        for (int i = tid; i < 256 * 2 * 32; i += nthreads) {
+            const int sel = (i >> 5) & 1, idx = i >> 6;
+            const uint32_t sv = c_beltH[idx];
+            t[i] = sel ? rotl32c(sv, 29) : (sv << 5);
+        }
+    }
+    __device__ explicit BeltTabTwo(const uint8_t *l)
+    {
+        const uint32_t tab = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)l;
+        if (tab & (kBytes - 1)) __builtin_trap();          // OR-composed addresses need 64 KiB alignment
+        base = tab + ((threadIdx.x & 31) << 2);
+    }
+    template <int R0>
+    __device__ __forceinline__ GParts g(uint32_t x) const
+    {
+        constexpr uint32_t M = 0xFF00u;
+        const uint32_t a0 = and_or(shl_c<8>(x), M, base), a1 = and_or(x, M, base);
+        const uint32_t a2 = and_or(shr_c<8>(x), M, base), a3 = and_or(shr_c<16>(x), M, base);
+        // byte k gets rotation 5 + 8*((R0 + k) & 3): 29 -> wrapped table, else T5 << 8*((R0+k)&3)
+        constexpr int r0 = (R0 + 0) & 3, r1 = (R0 + 1) & 3, r2 = (R0 + 2) & 3, r3 = (R0 + 3) & 3;
+        uint32_t t0 = *(lds_u32 *)(uintptr_t)(a0 + (r0 == 3 ? 128 : 0));
+        uint32_t t1 = *(lds_u32 *)(uintptr_t)(a1 + (r1 == 3 ? 128 : 0));
+        uint32_t t2 = *(lds_u32 *)(uintptr_t)(a2 + (r2 == 3 ? 128 : 0));
+        uint32_t t3 = *(lds_u32 *)(uintptr_t)(a3 + (r3 == 3 ? 128 : 0));
+        if (r0 == 1 || r0 == 2) t0 <<= 8 * r0;
+        if (r1 == 1 || r1 == 2) t1 <<= 8 * r1;
+        if (r2 == 1 || r2 == 2) t2 <<= 8 * r2;
+        if (r3 == 1 || r3 == 2) t3 <<= 8 * r3;
+        GParts r;
+        r.p = xor3(t0, t1, t2);
+        r.q = t3;
+        return r;
+    }
+};
+
 struct BeltTabSmall {
     static constexpr int kBytes = 4 * 256 * 4;             // 4096
     const uint8_t *lds;

@@ -8,10 +8,12 @@
 //   global_load/store_dwordx4 (perfectly coalesced).  Algorithmic traffic:
 //   32 B per block (16 read + 16 written), in place.
 //
-//   Launch shape: persistent, one 1024-thread workgroup per CU (256 total) because
-//   the bank-private S-box tables take 128 KiB of LDS (belt_dev.hpp); the 16
-//   wavefronts per CU (4 per SIMD) hide the ~56 dependent LDS round trips of E_K,
-//   and each lane carries CTR_ILP independent blocks for more overlap.
+//   Launch shape: persistent, two 1024-thread workgroups per CU (512 total): the
+//   bank-private two-table S-box layout takes 64 KiB of LDS (belt_dev.hpp, BeltTabTwo),
+//   so 32 wavefronts per CU (8 per SIMD) hide the ~56 dependent LDS round trips of E_K;
+//   each lane carries CTR_ILP independent blocks.  Measured cost model on MI355X
+//   (tools/ubench): per SIMD a block costs ~2.5 cycles per VALU op plus
+//   ~3.7 issue cycles per ds_read_b32 -- VALU and LDS issue do not overlap within a SIMD.
 //
 // belt_encr_blocks_kernel : E_K over n blocks in place (ctr0 = E_K(iv) of
 //   beltCTRStart, belt_ctr.c:55-64; r = E_K(0) of beltMACStart, belt_mac.c:47-56;
@@ -24,7 +26,8 @@ namespace bee2hip {
 __constant__ uint8_t c_beltH[256];
 
 constexpr int CTR_WG = 1024;
-constexpr int CTR_ILP = 4;          // independent blocks per lane per step
+typedef BeltTabTwo CtrTab;          // 64 KiB: two workgroups (32 wavefronts) per CU
+constexpr int CTR_ILP = 2;          // independent blocks per lane per step
 
 struct BeltKey { uint32_t k[8]; };
 struct BeltCtr { uint32_t c[4]; };
@@ -45,9 +48,9 @@ void beltCTR_blocks_kernel(uint4 *__restrict__ buf, size_t nblocks, BeltKey key,
                            uint64_t first, uint4 *__restrict__ last_gamma)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    BeltTabWide::fill(smem, threadIdx.x, CTR_WG);
+    CtrTab::fill(smem, threadIdx.x, CTR_WG);
     __syncthreads();
-    const BeltTabWide T(smem);
+    const CtrTab T(smem);
 
     uint32_t K[8];
 #pragma unroll
@@ -101,18 +104,26 @@ void belt_encr_blocks_kernel(uint4 *__restrict__ blocks, size_t nblocks, BeltKey
     blocks[i] = make_uint4(x[0], x[1], x[2], x[3]);
 }
 
-static int g_num_cus = 0;
+// per-device launch facts (several devices may be driven from one process)
+static int g_num_cus[64];
+static bool g_ctr_attr[64];
+static int cur_dev()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    return dev;
+}
 static int num_cus()
 {
-    if (!g_num_cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            g_num_cus = n;
+    const int dev = cur_dev();
+    if (!g_num_cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            g_num_cus[dev] = n;
         else
-            g_num_cus = 256;
+            g_num_cus[dev] = 256;
     }
-    return g_num_cus;
+    return g_num_cus[dev];
 }
 
 err_t upload_beltH(const uint8_t *H)
@@ -126,20 +137,19 @@ err_t launch_belt_ctr_blocks(void *d_buf, size_t nblocks, const uint32_t key[8],
                              hipStream_t st)
 {
     if (nblocks == 0) return ERR_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!g_ctr_attr[cur_dev()]) {
         B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(beltCTR_blocks_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, BeltTabWide::kBytes));
-        attr_set = true;
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, CtrTab::kBytes));
+        g_ctr_attr[cur_dev()] = true;
     }
     BeltKey k; BeltCtr c;
     for (int i = 0; i < 8; ++i) k.k[i] = key[i];
     for (int i = 0; i < 4; ++i) c.c[i] = ctr0[i];
     const size_t tile = (size_t)CTR_WG * CTR_ILP;
     size_t grid = (nblocks + tile - 1) / tile;
-    const size_t cap = (size_t)num_cus();
+    const size_t cap = (size_t)num_cus() * (BeltTabWide::kBytes / CtrTab::kBytes);
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(beltCTR_blocks_kernel, dim3((unsigned)grid), dim3(CTR_WG), BeltTabWide::kBytes,
+    hipLaunchKernelGGL(beltCTR_blocks_kernel, dim3((unsigned)grid), dim3(CTR_WG), CtrTab::kBytes,
                        st, (uint4 *)d_buf, nblocks, k, c, first, (uint4 *)d_last_gamma);
     B2H_TRY(hipGetLastError());
     return ERR_OK;

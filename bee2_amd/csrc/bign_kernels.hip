@@ -28,6 +28,7 @@
 // integer multiplier rate.
 #include "belt_dev.hpp"
 #include "bign_dev.hpp"
+#include <mutex>
 #include "common.hpp"
 
 namespace bee2hip {
@@ -405,6 +406,7 @@ struct BignDevice {
     size_t scratch_bytes = 0;
 };
 static BignDevice g_bign[64];
+static std::mutex g_bign_mu;          // table / scratch bookkeeping is per device, shared by threads
 
 static err_t bign_device(BignDevice **out, hipStream_t st)
 {
@@ -451,6 +453,7 @@ err_t launch_bign_verify(const uint8_t *oid_der, size_t oid_len, const void *d_h
 {
     if (n == 0) return ERR_OK;
     if (oid_len > OID_MAX) return ERR_NOT_IMPLEMENTED;
+    std::lock_guard<std::mutex> lk(g_bign_mu);
     BignDevice *D = nullptr;
     err_t code = bign_device(&D, st);
     if (code != ERR_OK) return code;

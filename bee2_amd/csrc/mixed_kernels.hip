@@ -337,11 +337,12 @@ static err_t launch_fused_t(const void *d_msgs, size_t msg_len, size_t n, size_t
     auto kern = hash_mac_fused_kernel<RW, HASH, MAC>;
     const size_t lds = MAC ? (size_t)BeltTabWide::kBytes : 0;
     if (MAC) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_set[64];
+        const int dev = cur_dev();
+        if (!attr_set[dev]) {
             B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
+            attr_set[dev] = true;
         }
     }
     const size_t grid = (n + FUSED_WG - 1) / FUSED_WG;
