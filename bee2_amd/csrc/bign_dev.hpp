@@ -38,13 +38,6 @@ __device__ __forceinline__ void mac(uint64_t &acc, uint32_t &c2, uint32_t a, uin
     asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(a), "v"(b));
     asm("v_addc_co_u32 %0, %1, 0, %0, %1" : "+v"(c2), "+s"(cy));
 }
-// acc += 2*a*b as two macs (used by the squarer's cross terms)
-__device__ __forceinline__ void mac2(uint64_t &acc, uint32_t &c2, uint32_t a, uint32_t b)
-{
-    mac(acc, c2, a, b);
-    mac(acc, c2, a, b);
-}
-
 __device__ __forceinline__ void fe_set_zero(fe &r)
 {
 #pragma unroll
@@ -185,25 +178,37 @@ __device__ __forceinline__ void fe_mul(fe &r, const fe &a, const fe &b)
     fe_reduce<K>(r, w);
 }
 
+// Squaring with 44 multiplications instead of 64: row i multiplies a_i by the vector
+// (a_i, e_{i+1}, d_{i+2}, .., d_8) where d = limbs of 2a (9 limbs, d_8 = top bit) and
+// e_j = a_j << 1 is the doubled limb WITHOUT the bit shifted in from a_{j-1} (that bit belongs
+// to the part of 2a below position i+1, which row i does not use).  Same product-scanning
+// accumulator as fe_mul (cf. zzSqr, src/math/zz/zz_mul.c:112-154, which doubles afterwards).
 template <uint32_t K = 1>
 __device__ __forceinline__ void fe_sqr(fe &r, const fe &a)
 {
+    uint32_t d[9], e[8];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+        e[j] = a.v[j] << 1;
+        d[j] = __builtin_amdgcn_alignbit(a.v[j], a.v[j - 1], 31);       // (a_j << 1) | (a_{j-1} >> 31)
+    }
+    d[8] = a.v[7] >> 31;
     uint32_t w[16];
     uint64_t acc = 0;
     uint32_t c2 = 0;
 #pragma unroll
-    for (int k = 0; k < 15; ++k) {
+    for (int k = 0; k < 16; ++k) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int j = k - i;
-            if (j > i && j < 8) mac2(acc, c2, a.v[i], a.v[j]);
+            const int j = k - i;                     // position inside row i's vector
+            if (j == i) mac(acc, c2, a.v[i], a.v[i]);
+            else if (j == i + 1 && j < 8) mac(acc, c2, a.v[i], e[j]);
+            else if (j >= i + 2 && j <= 8) mac(acc, c2, a.v[i], d[j]);
         }
-        if ((k & 1) == 0) mac(acc, c2, a.v[k / 2], a.v[k / 2]);
         w[k] = (uint32_t)acc;
         acc = (acc >> 32) | ((uint64_t)c2 << 32);
         c2 = 0;
     }
-    w[15] = (uint32_t)acc;
     fe_reduce<K>(r, w);
 }
 

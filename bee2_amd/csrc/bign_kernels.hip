@@ -8,9 +8,10 @@
 // (ecAddMulA, src/math/ec.c:1183-1273): data-dependent branching, 257 doublings.  Any
 // correct algorithm yields the same affine R, so the GPU uses a wavefront-friendly
 // schedule instead:
-//   * G part: fixed-base comb, 32 windows x 8 bits, table of 32 x 255 affine points
-//     (512 KiB, built once per device by bign_gtable_kernel) -> 32 mixed additions,
-//     NO doublings for the 256-bit scalar;
+//   * G part: fixed-base comb, 16 windows x 16 bits, table of 16 x 65535 affine points
+//     (64 MiB, built once per device: bign_gtable_kernel makes the 8-bit seed table by
+//     double-and-add, bign_gtable16_kernel combines it) -> 16 mixed additions, NO
+//     doublings for the 256-bit scalar;
 //   * Q part: signed radix-16 digits of the 129-bit scalar (uniform 4 doublings + 1
 //     addition per digit, 33 digits), per-signature table 1Q..8Q kept in an HBM scratch
 //     laid out [entry][limb][signature] so table reads coalesce across the wavefront.
@@ -46,6 +47,10 @@ __constant__ uint32_t c_bign_yG[8] = {0x04516A93u, 0x1E29CF18u, 0xC408F652u, 0x7
 
 constexpr int GT_WINDOWS = 32;
 constexpr int GT_ENTRIES = 256;                  // entry 0 unused (the neutral element)
+// second-level comb: 16 windows x 16 bits, entry (w, b) = b * 2^(16 w) * G, 64 MiB of HBM
+// (fits the 256 MiB Infinity Cache), built from the 8-bit table by one addition per entry
+constexpr int GT16_WINDOWS = 16;
+constexpr int GT16_ENTRIES = 65536;
 
 struct VerifyScratch {          // all arrays are [..][n_pad] (signature index fastest)
     uint32_t *status;           // [n_pad]
@@ -88,6 +93,15 @@ __device__ __forceinline__ void load_jac(jac &P, const VerifyScratch &S, int e, 
     load_soa(P.X, b, S.n_pad, idx);
     load_soa(P.Y, b + 8 * S.n_pad, S.n_pad, idx);
     load_soa(P.Z, b + 16 * S.n_pad, S.n_pad, idx);
+}
+
+__device__ __forceinline__ void load_aff(aff &E, const uint4 *e)
+{
+    const uint4 x0 = e[0], x1 = e[1], y0 = e[2], y1 = e[3];
+    E.x.v[0] = x0.x; E.x.v[1] = x0.y; E.x.v[2] = x0.z; E.x.v[3] = x0.w;
+    E.x.v[4] = x1.x; E.x.v[5] = x1.y; E.x.v[6] = x1.z; E.x.v[7] = x1.w;
+    E.y.v[0] = y0.x; E.y.v[1] = y0.y; E.y.v[2] = y0.z; E.y.v[3] = y0.w;
+    E.y.v[4] = y1.x; E.y.v[5] = y1.y; E.y.v[6] = y1.z; E.y.v[7] = y1.w;
 }
 
 // --------------------------------------------------------------------- prep ---
@@ -206,23 +220,18 @@ void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
             ok &= jac_add(T, E);
         }
     }
-    // + u G : comb over the 32 bytes of u
+    // + u G : comb over the 16 halfwords of u (16 mixed additions, no doublings)
     fe u;
     load_soa(u, S.u, S.n_pad, idx);
 #pragma unroll 1
-    for (int win = 0; win < GT_WINDOWS; ++win) {
-        const uint32_t b = u.v[0] & 255u;
+    for (int win = 0; win < GT16_WINDOWS; ++win) {
+        const uint32_t b = u.v[0] & 0xFFFFu;
 #pragma unroll
-        for (int l = 0; l < 7; ++l) u.v[l] = (u.v[l] >> 8) | (u.v[l + 1] << 24);
-        u.v[7] >>= 8;
+        for (int l = 0; l < 7; ++l) u.v[l] = (u.v[l] >> 16) | (u.v[l + 1] << 16);
+        u.v[7] >>= 16;
         if (b != 0) {
-            const uint4 *e = gtab + ((size_t)win * GT_ENTRIES + b) * 4;
-            const uint4 x0 = e[0], x1 = e[1], y0 = e[2], y1 = e[3];
             aff E;
-            E.x.v[0] = x0.x; E.x.v[1] = x0.y; E.x.v[2] = x0.z; E.x.v[3] = x0.w;
-            E.x.v[4] = x1.x; E.x.v[5] = x1.y; E.x.v[6] = x1.z; E.x.v[7] = x1.w;
-            E.y.v[0] = y0.x; E.y.v[1] = y0.y; E.y.v[2] = y0.z; E.y.v[3] = y0.w;
-            E.y.v[4] = y1.x; E.y.v[5] = y1.y; E.y.v[6] = y1.z; E.y.v[7] = y1.w;
+            load_aff(E, gtab + ((size_t)win * GT16_ENTRIES + b) * 4);
             ok &= jac_madd(T, E);
         }
     }
@@ -368,6 +377,43 @@ void bign_gtable_kernel(uint4 *__restrict__ gtab)
     e[3] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
 }
 
+// 16-bit table from the 8-bit one: entry16(w, b) = entry8(2w, b & 255) + entry8(2w+1, b >> 8).
+__global__ __launch_bounds__(256)
+void bign_gtable16_kernel(const uint4 *__restrict__ gtab8, uint4 *__restrict__ gtab16)
+{
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)GT16_WINDOWS * GT16_ENTRIES) return;
+    const int win = (int)(id / GT16_ENTRIES), b = (int)(id % GT16_ENTRIES);
+    const int lo = b & 255, hi = b >> 8;
+    uint4 *e = gtab16 + id * 4;
+    if (b == 0) { e[0] = e[1] = e[2] = e[3] = make_uint4(0, 0, 0, 0); return; }
+    const uint4 *elo = gtab8 + ((size_t)(2 * win) * GT_ENTRIES + lo) * 4;
+    const uint4 *ehi = gtab8 + ((size_t)(2 * win + 1) * GT_ENTRIES + hi) * 4;
+    if (hi == 0 || lo == 0) {                     // one summand is the neutral element: copy
+        const uint4 *src = hi == 0 ? elo : ehi;
+        e[0] = src[0]; e[1] = src[1]; e[2] = src[2]; e[3] = src[3];
+        return;
+    }
+    aff A, B;
+    load_aff(A, elo);
+    load_aff(B, ehi);
+    jac T, E;
+    T.X = A.x; T.Y = A.y; fe_set_one(T.Z);
+    E.X = B.x; E.Y = B.y; fe_set_one(E.Z);
+    jac_add_complete(T, E);                       // distinct multiples of G below the group order: never O
+    fe zi = fe_inv(T.Z), zi2, x, y;
+    fe_sqr(zi2, zi);
+    fe_mul(x, T.X, zi2);
+    fe_mul(zi2, zi2, zi);
+    fe_mul(y, T.Y, zi2);
+    fe_canon(x, x);
+    fe_canon(y, y);
+    e[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    e[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    e[2] = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
+    e[3] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+}
+
 // --------------------------------------------------------- debug / self-test ---
 // element-wise field ops over arrays of 8-limb values, used by tests/test_gpu_field.py
 // to check the GF(p) layer against Python big integers.  op: 0 mul, 1 sqr, 2 add, 3 sub,
@@ -401,7 +447,7 @@ __global__ void bign_debug_fe_kernel(int op, const uint32_t *a, const uint32_t *
 
 // ------------------------------------------------------------------ host side ---
 struct BignDevice {
-    uint4 *gtab = nullptr;            // 512 KiB comb table
+    uint4 *gtab = nullptr;            // 64 MiB 16-bit comb table (the 512 KiB 8-bit one is its seed)
     void *scratch = nullptr;          // VerifyScratch backing store
     size_t scratch_bytes = 0;
 };
@@ -415,12 +461,19 @@ static err_t bign_device(BignDevice **out, hipStream_t st)
     if (dev < 0 || dev >= 64) return ERR_BAD_INPUT;
     BignDevice &D = g_bign[dev];
     if (!D.gtab) {
-        uint4 *t = nullptr;
-        if (hipMalloc((void **)&t, (size_t)GT_WINDOWS * GT_ENTRIES * 64) != hipSuccess) return ERR_OUTOFMEMORY;
-        hipLaunchKernelGGL(bign_gtable_kernel, dim3(GT_WINDOWS * GT_ENTRIES / 64), dim3(64), 0, st, t);
+        uint4 *t8 = nullptr, *t16 = nullptr;
+        if (hipMalloc((void **)&t8, (size_t)GT_WINDOWS * GT_ENTRIES * 64) != hipSuccess) return ERR_OUTOFMEMORY;
+        if (hipMalloc((void **)&t16, (size_t)GT16_WINDOWS * GT16_ENTRIES * 64) != hipSuccess) {
+            (void)hipFree(t8);
+            return ERR_OUTOFMEMORY;
+        }
+        hipLaunchKernelGGL(bign_gtable_kernel, dim3(GT_WINDOWS * GT_ENTRIES / 64), dim3(64), 0, st, t8);
+        hipLaunchKernelGGL(bign_gtable16_kernel, dim3(GT16_WINDOWS * GT16_ENTRIES / 256), dim3(256), 0, st,
+                           (const uint4 *)t8, t16);
         B2H_TRY(hipGetLastError());
         B2H_TRY(hipStreamSynchronize(st));
-        D.gtab = t;
+        (void)hipFree(t8);
+        D.gtab = t16;
     }
     *out = &D;
     return ERR_OK;
