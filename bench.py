@@ -52,18 +52,26 @@ def parse():
 
 
 class Dist:
+    """one process per GPU; RCCL ('nccl') by default.  BEE2_BENCH_BACKEND=gloo runs the same
+    code with CPU-side collectives (lets the N>1 path be exercised on a box with one GPU)."""
+
     def __init__(self, want):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         self.on = self.world > 1
+        self.backend = os.environ.get("BEE2_BENCH_BACKEND", "nccl")
+        ndev = max(1, torch.cuda.device_count())
+        self.device = self.local % ndev
+        torch.cuda.set_device(self.device)
         if self.on:
             import torch.distributed as dist
             self.dist = dist
-            torch.cuda.set_device(self.local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local))
-        else:
-            torch.cuda.set_device(0)
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.device))
+            else:
+                dist.init_process_group(self.backend)
+        self.cdev = "cuda" if self.backend == "nccl" else "cpu"
         if want != self.world and self.rank == 0:
             print(f"[bench] note: --gpus {want} but WORLD_SIZE={self.world}; using {self.world}", file=sys.stderr)
 
@@ -74,13 +82,13 @@ class Dist:
     def max(self, x):
         if not self.on:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device=self.cdev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def bcast_bytes(self, b, n):
         """rank 0's bytes to everyone (the only payload that crosses GPUs: <= 48 bytes)"""
-        t = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        t = torch.zeros(n, dtype=torch.uint8, device=self.cdev)
         if self.rank == 0:
             t.copy_(torch.frombuffer(bytearray(b), dtype=torch.uint8))
         if self.on:
@@ -89,6 +97,7 @@ class Dist:
 
     def close(self):
         if self.on:
+            self.dist.barrier()
             self.dist.destroy_process_group()
 
 

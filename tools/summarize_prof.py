@@ -52,8 +52,9 @@ def main(tag):
         json.dump(summary, fh, indent=1)
     # per-kernel HBM traffic for bench.py's roofline.traffic
     for kern, fname, alg in (("bashF_batch_kernel", f"{tag}_bashF_pmc.json", 384 * (1 << 20)),):
-        fe = summary.get("pmc_FETCH_SIZE", {}).get(kern)
-        wr = summary.get("pmc_WRITE_SIZE", {}).get(kern)
+        pick = lambda d: next((v for k, v in d.items() if k.startswith(kern)), None)  # noqa: E731
+        fe = pick(summary.get("pmc_FETCH_SIZE", {}))
+        wr = pick(summary.get("pmc_WRITE_SIZE", {}))
         if fe and wr:
             hbm = (2 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024
             with open(os.path.join(DST, fname), "w") as fh:
