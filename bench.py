@@ -38,6 +38,8 @@ from bee2_amd import shard  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BASHF_BYTES = 384                # algorithmic bytes per permutation (192 read + 192 written)
 CTR_BYTES_PER_BLOCK = 32         # 16 read + 16 written per 16-byte block
+MADS_PER_VERIFY = 1025 * 72 + 939 * 52 + 3000   # v_mad_u64_u32 per signature
+MAD_PEAK_T = 30.0                # measured: 256 CU x 4 SIMD x 64 lanes x 2.31 GHz / 5.05 cycles
 
 
 def parse():
@@ -333,7 +335,14 @@ def main():
             "config": {"workload": "bignVerify batch: 2^18 signatures per GPU on bign-curve256v1 (BASELINE configs[3]); "
                                    "2048 genuine triples tiled 128x, seeded 1/16 corrupted"},
             "roofline": {"kernels": "bign_prep+main+slow+tail", "bound": "valu-int", "avg_batch_ms": ms_launch,
-                         "note": "integer-multiplier bound; HBM irrelevant (148 B/signature)"},
+                         # 32x32+64 multiply-adds per verify: 1025 M x 72 + 939 S x 52 + scaled folds
+                         "mads_per_verify": MADS_PER_VERIFY,
+                         "achieved": MADS_PER_VERIFY * n / (ms_launch * 1e-3) / 1e12,
+                         "peak": MAD_PEAK_T, "unit": "T v_mad_u64_u32 lane-ops/s",
+                         "frac": MADS_PER_VERIFY * n / (ms_launch * 1e-3) / 1e12 / MAD_PEAK_T,
+                         "note": "integer-multiplier bound; HBM irrelevant (148 B/signature); peak = measured "
+                                 "v_mad_u64_u32 micro-benchmark (profiles/r01_valu_rates_ubench.txt); every mad is "
+                                 "paired with a half-rate v_addc_co_u32, so 0.5 is the practical ceiling"},
         }
         if do_cpu:
             others["bignVerify"]["cpu_baseline"] = cpu_baseline("verify", cores)
