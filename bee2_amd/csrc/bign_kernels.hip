@@ -448,8 +448,6 @@ __global__ void bign_debug_fe_kernel(int op, const uint32_t *a, const uint32_t *
 // ------------------------------------------------------------------ host side ---
 struct BignDevice {
     uint4 *gtab = nullptr;            // 64 MiB 16-bit comb table (the 512 KiB 8-bit one is its seed)
-    void *scratch = nullptr;          // VerifyScratch backing store
-    size_t scratch_bytes = 0;
 };
 static BignDevice g_bign[64];
 static std::mutex g_bign_mu;          // table / scratch bookkeeping is per device, shared by threads
@@ -479,18 +477,14 @@ static err_t bign_device(BignDevice **out, hipStream_t st)
     return ERR_OK;
 }
 
-static err_t bign_scratch(BignDevice &D, size_t n, VerifyScratch &S)
+static err_t bign_scratch(hipStream_t st, size_t n, VerifyScratch &S)
 {
     const size_t n_pad = (n + 63) & ~(size_t)63;
     const size_t words = n_pad * (1 + 8 + 5 + 8 * 24 + 8);
-    const size_t bytes = words * 4;
-    if (D.scratch_bytes < bytes) {
-        if (D.scratch) (void)hipFree(D.scratch);
-        D.scratch = nullptr; D.scratch_bytes = 0;
-        if (hipMalloc(&D.scratch, bytes) != hipSuccess) return ERR_OUTOFMEMORY;
-        D.scratch_bytes = bytes;
-    }
-    uint32_t *p = (uint32_t *)D.scratch;
+    void *base = nullptr;
+    err_t code = scratch_for_stream(st, 0, words * 4, &base);
+    if (code != ERR_OK) return code;
+    uint32_t *p = (uint32_t *)base;
     S.n_pad = n_pad;
     S.status = p; p += n_pad;
     S.u = p; p += 8 * n_pad;
@@ -506,12 +500,15 @@ err_t launch_bign_verify(const uint8_t *oid_der, size_t oid_len, const void *d_h
 {
     if (n == 0) return ERR_OK;
     if (oid_len > OID_MAX) return ERR_NOT_IMPLEMENTED;
-    std::lock_guard<std::mutex> lk(g_bign_mu);
     BignDevice *D = nullptr;
-    err_t code = bign_device(&D, st);
+    err_t code;
+    {
+        std::lock_guard<std::mutex> lk(g_bign_mu);     // table construction happens once per device
+        code = bign_device(&D, st);
+    }
     if (code != ERR_OK) return code;
     VerifyScratch S;
-    code = bign_scratch(*D, n, S);
+    code = bign_scratch(st, n, S);
     if (code != ERR_OK) return code;
     OidArg oid;
     memset(&oid, 0, sizeof oid);

@@ -62,6 +62,37 @@ err_t ensure_device()
     return ERR_OK;
 }
 
+struct PoolEntry { int dev; hipStream_t st; int slot; void *p; size_t bytes; };
+static std::mutex g_pool_mu;
+static PoolEntry g_pool[256];
+static int g_pool_n = 0;
+
+err_t scratch_for_stream(hipStream_t st, int slot, size_t bytes, void **out)
+{
+    int dev = 0;
+    B2H_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    PoolEntry *e = nullptr;
+    for (int i = 0; i < g_pool_n; ++i)
+        if (g_pool[i].dev == dev && g_pool[i].st == st && g_pool[i].slot == slot) { e = &g_pool[i]; break; }
+    if (!e) {
+        if (g_pool_n == 256) return ERR_OUTOFMEMORY;
+        e = &g_pool[g_pool_n++];
+        e->dev = dev; e->st = st; e->slot = slot; e->p = nullptr; e->bytes = 0;
+    }
+    if (e->bytes < bytes) {
+        if (e->p) {
+            B2H_TRY(hipStreamSynchronize(st));            // earlier batches may still use the old block
+            (void)hipFree(e->p);
+            e->p = nullptr; e->bytes = 0;
+        }
+        if (hipMalloc(&e->p, bytes) != hipSuccess) { e->p = nullptr; return ERR_OUTOFMEMORY; }
+        e->bytes = bytes;
+    }
+    *out = e->p;
+    return ERR_OK;
+}
+
 // scratch device buffer for the host-pointer API, grown on demand, per thread
 struct Scratch {
     void *p = nullptr;

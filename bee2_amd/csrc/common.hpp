@@ -19,6 +19,11 @@ err_t hip_fail(hipError_t e, const char *what);
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Library-owned device scratch, cached per (device, stream): two batches in flight on
+// different streams never share a buffer, two on the same stream are ordered by the stream.
+// Grown on demand; growing frees the old block only after the stream has drained.
+err_t scratch_for_stream(hipStream_t st, int slot, size_t bytes, void **out);
+
 // ---- kernel launchers (defined next to their kernels) ----
 err_t launch_bashF_batch(void *d_states, size_t n, hipStream_t st);
 err_t launch_bashHash_beltMAC(const void *d_msgs, size_t msg_len, size_t n, size_t l,

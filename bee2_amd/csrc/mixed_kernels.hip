@@ -362,10 +362,6 @@ static err_t launch_fused_rw(const void *d_msgs, size_t msg_len, size_t n, size_
     return launch_fused_t<RW, false, true>(d_msgs, msg_len, n, l, key, d_digests, d_tags, st);
 }
 
-// scratch for the generic batch path (per device, grown on demand)
-static void *g_mixed_scratch[64];
-static size_t g_mixed_scratch_bytes[64];
-
 err_t launch_bashHash_beltMAC(const void *d_msgs, size_t msg_len, size_t n, size_t l,
                               const uint32_t key[8], bool do_hash, bool do_mac,
                               void *d_digests, void *d_tags, hipStream_t st)
@@ -381,17 +377,13 @@ err_t launch_bashHash_beltMAC(const void *d_msgs, size_t msg_len, size_t n, size
         return launch_fused_rw<16>(d_msgs, msg_len, n, l, k, do_hash, do_mac, d_digests, d_tags, st);
     }
     // generic shapes: per-item states in scratch, byte-granular kernels
-    int dev = 0;
-    B2H_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return ERR_BAD_INPUT;
     const size_t need = n * (sizeof(bash_hash_st) + sizeof(belt_mac_st));
-    if (g_mixed_scratch_bytes[dev] < need) {
-        if (g_mixed_scratch[dev]) (void)hipFree(g_mixed_scratch[dev]);
-        g_mixed_scratch[dev] = nullptr; g_mixed_scratch_bytes[dev] = 0;
-        if (hipMalloc(&g_mixed_scratch[dev], need) != hipSuccess) return ERR_OUTOFMEMORY;
-        g_mixed_scratch_bytes[dev] = need;
+    void *base = nullptr;
+    {
+        const err_t sc = scratch_for_stream(st, 1, need, &base);
+        if (sc != ERR_OK) return sc;
     }
-    bash_hash_st *hs = (bash_hash_st *)g_mixed_scratch[dev];
+    bash_hash_st *hs = (bash_hash_st *)base;
     belt_mac_st *ms = (belt_mac_st *)(hs + n);
     const unsigned g = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(init_states_kernel, dim3(g), dim3(256), 0, st, do_hash ? hs : nullptr,

@@ -144,3 +144,26 @@ def test_bign_full_size_2pow18_tiled_and_corrupted(orc, golden):
     mask[bad_idx] = False
     assert int((got[mask] != 0).sum()) == 0
     assert set(want_bad) <= {0, 505, 510} and 510 in want_bad
+
+
+def test_concurrent_batches_on_two_streams_do_not_share_scratch(orc, golden):
+    """two verify batches in flight on different streams (library scratch is per stream)"""
+    eng = engine()
+    hs, ss, ps = golden.bign_base_arrays()
+    n = 2048
+    bad = bytearray(ss)
+    for i in range(n):
+        bad[48 * i] ^= 1                              # every signature of the second batch is invalid
+    dh, ds, dp, db = dev(hs), dev(ss), dev(ps), dev(bytes(bad))
+    c1 = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    c2 = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            eng.bign128Verify_batch_dev(dh, ds, dp, c1)
+        with torch.cuda.stream(s2):
+            eng.bign128Verify_batch_dev(dh, db, dp, c2)
+    torch.cuda.synchronize()
+    assert int((c1 != 0).sum()) == 0
+    assert int((c2 != 510).sum()) == 0
