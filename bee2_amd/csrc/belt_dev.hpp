@@ -222,6 +222,42 @@ __device__ __forceinline__ void belt_encr(const Tab &T, uint32_t (&x)[4], const 
     x[0] = b; x[1] = d; x[2] = a; x[3] = c;
 }
 
+// D_K: the same round with the subkeys taken in reverse (subkey_d, belt_block.c:243), rounds
+// 8..1, role change (a,b,c,d) <- (c,a,d,b) by argument order, output order (c,a,d,b)
+// (belt_block.c:286-295).
+template <int I, class Tab>
+__device__ __forceinline__ void belt_round_d(const Tab &T, uint32_t &a, uint32_t &b, uint32_t &c,
+                                             uint32_t &d, const uint32_t (&K)[8])
+{
+    constexpr int o = 7 * I - 1;
+    GParts g;
+    g = T.template g<0>(a + K[(o - 0) & 7]);   b = xor3(b, g.p, g.q);
+    g = T.template g<2>(d + K[(o - 1) & 7]);   c = xor3(c, g.p, g.q);
+    g = T.template g<1>(b + K[(o - 2) & 7]);   a -= g.p ^ g.q;
+    g = T.template g<2>(b + c + K[(o - 3) & 7]);
+    const uint32_t e = xor3(g.p, g.q, (uint32_t)I);
+    b += e;
+    c -= e;
+    g = T.template g<1>(c + K[(o - 4) & 7]);   d += g.p ^ g.q;
+    g = T.template g<2>(a + K[(o - 5) & 7]);   b = xor3(b, g.p, g.q);
+    g = T.template g<0>(d + K[(o - 6) & 7]);   c = xor3(c, g.p, g.q);
+}
+
+template <class Tab>
+__device__ __forceinline__ void belt_decr(const Tab &T, uint32_t (&x)[4], const uint32_t (&K)[8])
+{
+    uint32_t a = x[0], b = x[1], c = x[2], d = x[3];
+    belt_round_d<8>(T, a, b, c, d, K);
+    belt_round_d<7>(T, c, a, d, b, K);
+    belt_round_d<6>(T, d, c, b, a, K);
+    belt_round_d<5>(T, b, d, a, c, K);
+    belt_round_d<4>(T, a, b, c, d, K);
+    belt_round_d<3>(T, c, a, d, b, K);
+    belt_round_d<2>(T, d, c, b, a, K);
+    belt_round_d<1>(T, b, d, a, c, K);
+    x[0] = c; x[1] = a; x[2] = d; x[3] = b;
+}
+
 // N independent blocks in lockstep: each G-box step is issued for all N blocks before the
 // next step, so 4N LDS reads are in flight per wave (the LDS round trip, not the VALU, is
 // what a single E_K chain waits on).

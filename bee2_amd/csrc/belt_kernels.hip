@@ -104,6 +104,81 @@ void belt_encr_blocks_kernel(uint4 *__restrict__ blocks, size_t nblocks, BeltKey
     blocks[i] = make_uint4(x[0], x[1], x[2], x[3]);
 }
 
+// ---- block-parallel modes on the same block function -------------------
+// mode 0: ECB encrypt   dst[i] = E(src[i])                      (belt_ecb.c:63-84)
+// mode 1: ECB decrypt   dst[i] = D(src[i])                      (belt_ecb.c:86-107)
+// mode 2: CBC decrypt   dst[i] = D(src[i]) ^ (i ? src[i-1] : iv)  (belt_cbc.c:101-116); src != dst
+template <int MODE>
+__global__ __launch_bounds__(CTR_WG)
+void belt_modes_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t nblocks,
+                       BeltKey key, BeltCtr iv)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    CtrTab::fill(smem, threadIdx.x, CTR_WG);
+    __syncthreads();
+    const CtrTab T(smem);
+    uint32_t K[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) K[i] = key.k[i];
+    for (size_t i = (size_t)blockIdx.x * CTR_WG + threadIdx.x; i < nblocks; i += (size_t)gridDim.x * CTR_WG) {
+        const uint4 v = src[i];
+        uint32_t x[4] = {v.x, v.y, v.z, v.w};
+        if (MODE == 0) belt_encr(T, x, K);
+        else belt_decr(T, x, K);
+        if (MODE == 2) {
+            uint4 p = make_uint4(iv.c[0], iv.c[1], iv.c[2], iv.c[3]);
+            if (i) p = src[i - 1];
+            x[0] ^= p.x; x[1] ^= p.y; x[2] ^= p.z; x[3] ^= p.w;
+        }
+        dst[i] = make_uint4(x[0], x[1], x[2], x[3]);
+    }
+}
+
+// CBC encryption is a serial chain per message (belt_cbc.c:63-84): one lane per message,
+// n messages of nblk full blocks each, per-message iv, in place.  ivs[m] receives the last
+// ciphertext block (the chaining value bee2 keeps in belt_cbc_st.block).
+__global__ __launch_bounds__(64)
+void belt_cbc_encr_kernel(uint4 *__restrict__ msgs, size_t nblk, size_t n, BeltKey key, uint4 *__restrict__ ivs)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[BeltTabSmall::kBytes];
+    BeltTabSmall::fill(smem, threadIdx.x, 64);
+    __syncthreads();
+    const BeltTabSmall T(smem);
+    const size_t m = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (m >= n) return;
+    uint32_t K[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) K[i] = key.k[i];
+    uint4 c = ivs[m];
+    uint32_t x[4] = {c.x, c.y, c.z, c.w};
+    uint4 *p = msgs + m * nblk;
+    for (size_t i = 0; i < nblk; ++i) {
+        const uint4 v = p[i];
+        x[0] ^= v.x; x[1] ^= v.y; x[2] ^= v.z; x[3] ^= v.w;
+        belt_encr(T, x, K);
+        p[i] = make_uint4(x[0], x[1], x[2], x[3]);
+    }
+    ivs[m] = make_uint4(x[0], x[1], x[2], x[3]);
+}
+
+__global__ __launch_bounds__(64)
+void belt_decr_blocks_kernel(uint4 *__restrict__ blocks, size_t nblocks, BeltKey key)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[BeltTabSmall::kBytes];
+    BeltTabSmall::fill(smem, threadIdx.x, 64);
+    __syncthreads();
+    const BeltTabSmall T(smem);
+    uint32_t K[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) K[i] = key.k[i];
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= nblocks) return;
+    const uint4 v = blocks[i];
+    uint32_t x[4] = {v.x, v.y, v.z, v.w};
+    belt_decr(T, x, K);
+    blocks[i] = make_uint4(x[0], x[1], x[2], x[3]);
+}
+
 // per-device launch facts (several devices may be driven from one process)
 static int g_num_cus[64];
 static bool g_ctr_attr[64];
@@ -151,6 +226,62 @@ err_t launch_belt_ctr_blocks(void *d_buf, size_t nblocks, const uint32_t key[8],
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(beltCTR_blocks_kernel, dim3((unsigned)grid), dim3(CTR_WG), CtrTab::kBytes,
                        st, (uint4 *)d_buf, nblocks, k, c, first, (uint4 *)d_last_gamma);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
+template <int MODE>
+static err_t launch_modes_t(const void *d_src, void *d_dst, size_t nblocks, const BeltKey &k, const BeltCtr &iv,
+                            hipStream_t st)
+{
+    static bool attr[64];
+    auto kern = belt_modes_kernel<MODE>;
+    if (!attr[cur_dev()]) {
+        B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, CtrTab::kBytes));
+        attr[cur_dev()] = true;
+    }
+    size_t grid = (nblocks + CTR_WG - 1) / CTR_WG;
+    const size_t cap = (size_t)num_cus() * (BeltTabWide::kBytes / CtrTab::kBytes);
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CTR_WG), CtrTab::kBytes, st, (const uint4 *)d_src,
+                       (uint4 *)d_dst, nblocks, k, iv);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
+// mode: 0 ECB encrypt, 1 ECB decrypt (src may equal dst), 2 CBC decrypt (src != dst)
+err_t launch_belt_modes(int mode, const void *d_src, void *d_dst, size_t nblocks, const uint32_t key[8],
+                        const uint32_t iv[4], hipStream_t st)
+{
+    if (nblocks == 0) return ERR_OK;
+    BeltKey k; BeltCtr c;
+    for (int i = 0; i < 8; ++i) k.k[i] = key[i];
+    for (int i = 0; i < 4; ++i) c.c[i] = iv ? iv[i] : 0u;
+    if (mode == 0) return launch_modes_t<0>(d_src, d_dst, nblocks, k, c, st);
+    if (mode == 1) return launch_modes_t<1>(d_src, d_dst, nblocks, k, c, st);
+    if (mode == 2) { if (d_src == d_dst) return ERR_BAD_INPUT; return launch_modes_t<2>(d_src, d_dst, nblocks, k, c, st); }
+    return ERR_BAD_INPUT;
+}
+
+err_t launch_belt_cbc_encr(void *d_msgs, size_t nblk, size_t n, const uint32_t key[8], void *d_ivs, hipStream_t st)
+{
+    if (n == 0) return ERR_OK;
+    BeltKey k;
+    for (int i = 0; i < 8; ++i) k.k[i] = key[i];
+    hipLaunchKernelGGL(belt_cbc_encr_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (uint4 *)d_msgs,
+                       nblk, n, k, (uint4 *)d_ivs);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
+err_t launch_belt_decr_blocks(void *d_blocks, size_t nblocks, const uint32_t key[8], hipStream_t st)
+{
+    if (nblocks == 0) return ERR_OK;
+    BeltKey k;
+    for (int i = 0; i < 8; ++i) k.k[i] = key[i];
+    hipLaunchKernelGGL(belt_decr_blocks_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, st,
+                       (uint4 *)d_blocks, nblocks, k);
     B2H_TRY(hipGetLastError());
     return ERR_OK;
 }

@@ -718,3 +718,208 @@ extern "C" err_t bee2hip_time_kernel(int which, int reps, void *d_a, void *d_b, 
     *ms = total / (float)reps;
     return code;
 }
+
+// ============================================ 8f-1: block decrypt, ECB, CBC ===
+static err_t decr_host_blocks(uint32_t *blocks, size_t n, const u32 key[8])
+{
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    Scratch &s = t_scr[1];
+    code = s.need(n * 16);
+    if (code != ERR_OK) return code;
+    B2H_TRY(hipMemcpy(s.p, blocks, n * 16, hipMemcpyHostToDevice));
+    code = launch_belt_decr_blocks(s.p, n, key, nullptr);
+    if (code != ERR_OK) return code;
+    B2H_TRY(hipMemcpy(blocks, s.p, n * 16, hipMemcpyDeviceToHost));
+    return ERR_OK;
+}
+
+extern "C" void beltBlockDecr2(u32 block[4], const u32 key[8])
+{
+    die_on(decr_host_blocks(block, 1, key), "beltBlockDecr2");
+}
+extern "C" void beltBlockDecr(octet block[16], const u32 key[8])
+{
+    u32 w[4];
+    for (int i = 0; i < 4; ++i) w[i] = load32le(block + 4 * i);
+    beltBlockDecr2(w, key);
+    for (int i = 0; i < 4; ++i) store32le(block + 4 * i, w[i]);
+}
+extern "C" void beltBlockDecr3(u32 *a, u32 *b, u32 *c, u32 *d, const u32 key[8])
+{
+    u32 w[4] = {*a, *b, *c, *d};
+    beltBlockDecr2(w, key);
+    *a = w[0]; *b = w[1]; *c = w[2]; *d = w[3];
+}
+
+extern "C" err_t bee2hip_beltModes_blocks_dev(int mode, const void *d_src, void *d_dst, size_t nblocks,
+                                              const u32 key[8], const u32 iv[4], void *stream)
+{
+    if ((nblocks && (!d_src || !d_dst)) || !key || (mode == 2 && !iv)) return ERR_BAD_INPUT;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    return launch_belt_modes(mode, d_src, d_dst, nblocks, key, iv, as_stream(stream));
+}
+
+extern "C" err_t bee2hip_beltCBCEncr_batch_dev(void *d_msgs, size_t nblk, size_t n, const u32 key[8],
+                                               void *d_ivs, void *stream)
+{
+    if ((n && (!d_msgs || !d_ivs)) || !key) return ERR_BAD_INPUT;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    return launch_belt_cbc_encr(d_msgs, nblk, n, key, d_ivs, as_stream(stream));
+}
+
+// whole blocks of a host buffer through one of the block-parallel modes
+static err_t modes_host(int mode, octet *buf, size_t nblocks, const u32 key[8], const octet chain[16])
+{
+    if (nblocks == 0) return ERR_OK;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    Scratch &s = t_scr[2];
+    const size_t bytes = nblocks * 16;
+    code = s.need(2 * bytes);
+    if (code != ERR_OK) return code;
+    octet *d = (octet *)s.p;
+    u32 iv[4] = {0, 0, 0, 0};
+    if (chain) for (int i = 0; i < 4; ++i) iv[i] = load32le(chain + 4 * i);
+    B2H_TRY(hipMemcpy(d, buf, bytes, hipMemcpyHostToDevice));
+    code = launch_belt_modes(mode, d, d + bytes, nblocks, key, iv, nullptr);
+    if (code != ERR_OK) return code;
+    B2H_TRY(hipMemcpy(buf, d + bytes, bytes, hipMemcpyDeviceToHost));
+    return ERR_OK;
+}
+
+struct belt_ecb_st {          // belt_ecb.c:42-46
+    u32 key[8];
+    octet block[16];
+};
+extern "C" size_t beltECB_keep(void) { return sizeof(belt_ecb_st); }
+extern "C" void beltECBStart(void *state, const octet key[], size_t len)
+{
+    beltKeyExpand2(((belt_ecb_st *)state)->key, key, len);
+}
+
+static void ecb_step(void *buf_, size_t count, belt_ecb_st *st, int decr)
+{
+    octet *buf = (octet *)buf_;
+    const size_t full = count / 16, tail = count % 16;
+    die_on(modes_host(decr ? 1 : 0, buf, full, st->key, nullptr), decr ? "beltECBStepD" : "beltECBStepE");
+    if (tail) {
+        // ciphertext stealing (belt_ecb.c:74-83,97-106): data shuffling on the host, the block on the GPU
+        octet *p = buf + full * 16;
+        memcpy(st->block, p, tail);
+        memcpy(st->block + tail, p - 16 + tail, 16 - tail);
+        if (decr) beltBlockDecr(st->block, st->key); else beltBlockEncr(st->block, st->key);
+        memcpy(p, p - 16, tail);
+        memcpy(p - 16, st->block, 16);
+    }
+}
+extern "C" void beltECBStepE(void *buf, size_t count, void *state) { ecb_step(buf, count, (belt_ecb_st *)state, 0); }
+extern "C" void beltECBStepD(void *buf, size_t count, void *state) { ecb_step(buf, count, (belt_ecb_st *)state, 1); }
+
+static err_t ecb_oneshot(void *dest, const void *src, size_t count, const octet key[], size_t len, int decr)
+{
+    if (count < 16 || (len != 16 && len != 24 && len != 32) || !src || !dest || !key) return ERR_BAD_INPUT;
+    belt_ecb_st st;
+    beltECBStart(&st, key, len);
+    memmove(dest, src, count);
+    ecb_step(dest, count, &st, decr);
+    return ERR_OK;
+}
+extern "C" err_t beltECBEncr(void *dest, const void *src, size_t count, const octet key[], size_t len)
+{
+    return ecb_oneshot(dest, src, count, key, len, 0);
+}
+extern "C" err_t beltECBDecr(void *dest, const void *src, size_t count, const octet key[], size_t len)
+{
+    return ecb_oneshot(dest, src, count, key, len, 1);
+}
+
+struct belt_cbc_st {          // belt_cbc.c:63-68
+    u32 key[8];
+    octet block[16];
+    octet block1[16];
+};
+extern "C" size_t beltCBC_keep(void) { return sizeof(belt_cbc_st); }
+extern "C" void beltCBCStart(void *state, const octet key[], size_t len, const octet iv[16])
+{
+    belt_cbc_st *st = (belt_cbc_st *)state;
+    beltKeyExpand2(st->key, key, len);
+    memcpy(st->block, iv, 16);
+}
+
+extern "C" void beltCBCStepE(void *buf_, size_t count, void *state)
+{
+    belt_cbc_st *st = (belt_cbc_st *)state;
+    octet *buf = (octet *)buf_;
+    const size_t full = count / 16, tail = count % 16;
+    if (full) {
+        // the serial chain runs on one lane of the per-message kernel (n = 1)
+        err_t code = ensure_device();
+        Scratch &s = t_scr[2];
+        if (code == ERR_OK) code = s.need(full * 16 + 16);
+        die_on(code, "beltCBCStepE");
+        octet *d = (octet *)s.p;
+        die_on(hipMemcpy(d, buf, full * 16, hipMemcpyHostToDevice) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
+        die_on(hipMemcpy(d + full * 16, st->block, 16, hipMemcpyHostToDevice) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
+        die_on(launch_belt_cbc_encr(d, full, 1, st->key, d + full * 16, nullptr), "beltCBCStepE");
+        die_on(hipMemcpy(buf, d, full * 16, hipMemcpyDeviceToHost) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
+        die_on(hipMemcpy(st->block, d + full * 16, 16, hipMemcpyDeviceToHost) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
+    }
+    if (tail) {                                   // stealing, belt_cbc.c:86-93
+        octet *p = buf + full * 16;
+        for (size_t i = 0; i < tail; ++i) st->block1[i] = p[i] ^ st->block[i];
+        memcpy(st->block1 + tail, p - 16 + tail, 16 - tail);
+        beltBlockEncr(st->block1, st->key);
+        memcpy(p, p - 16, tail);
+        memcpy(p - 16, st->block1, 16);
+    }
+}
+
+extern "C" void beltCBCStepD(void *buf_, size_t count, void *state)
+{
+    belt_cbc_st *st = (belt_cbc_st *)state;
+    octet *buf = (octet *)buf_;
+    // whole blocks handled by the parallel kernel: all of them, or all but the last full one
+    // when a partial tail follows (belt_cbc.c:101-116: "while (count >= 32 || count == 16)")
+    const size_t tail = count % 16;
+    const size_t par = tail ? count / 16 - 1 : count / 16;
+    if (par) {
+        octet last[16];
+        memcpy(last, buf + (par - 1) * 16, 16);               // becomes the next chaining value
+        die_on(modes_host(2, buf, par, st->key, st->block), "beltCBCStepD");
+        memcpy(st->block, last, 16);
+    }
+    if (tail) {                                   // 16 < rest < 32, belt_cbc.c:118-130
+        octet *p = buf + par * 16;
+        const size_t r = tail;
+        memcpy(st->block1, p, 16);
+        beltBlockDecr(st->block1, st->key);
+        for (size_t i = 0; i < r; ++i) { octet x = st->block1[i]; st->block1[i] = p[16 + i]; p[16 + i] = x; }
+        for (size_t i = 0; i < r; ++i) p[16 + i] ^= st->block1[i];
+        beltBlockDecr(st->block1, st->key);
+        for (int i = 0; i < 16; ++i) p[i] = st->block1[i] ^ st->block[i];
+    }
+}
+
+static err_t cbc_oneshot(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                         const octet iv[16], int decr)
+{
+    if (count < 16 || (len != 16 && len != 24 && len != 32) || !src || !dest || !key || !iv) return ERR_BAD_INPUT;
+    belt_cbc_st st;
+    beltCBCStart(&st, key, len, iv);
+    memmove(dest, src, count);
+    if (decr) beltCBCStepD(dest, count, &st); else beltCBCStepE(dest, count, &st);
+    return ERR_OK;
+}
+extern "C" err_t beltCBCEncr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                             const octet iv[16])
+{
+    return cbc_oneshot(dest, src, count, key, len, iv, 0);
+}
+extern "C" err_t beltCBCDecr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                             const octet iv[16])
+{
+    return cbc_oneshot(dest, src, count, key, len, iv, 1);
+}

@@ -34,6 +34,11 @@ err_t launch_belt_ctr_blocks(void *d_buf, size_t nblocks, const uint32_t key[8],
                              const uint32_t ctr0[4], uint64_t first, void *d_last_gamma,
                              hipStream_t st);
 err_t launch_belt_encr_blocks(void *d_blocks, size_t nblocks, const uint32_t key[8], hipStream_t st);
+err_t launch_belt_decr_blocks(void *d_blocks, size_t nblocks, const uint32_t key[8], hipStream_t st);
+// mode: 0 ECB encrypt, 1 ECB decrypt (src may equal dst), 2 CBC decrypt (src != dst)
+err_t launch_belt_modes(int mode, const void *d_src, void *d_dst, size_t nblocks, const uint32_t key[8],
+                        const uint32_t iv[4], hipStream_t st);
+err_t launch_belt_cbc_encr(void *d_msgs, size_t nblk, size_t n, const uint32_t key[8], void *d_ivs, hipStream_t st);
 err_t launch_bign_verify(const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
                          const void *d_sigs, const void *d_pubkeys, size_t n, void *d_codes,
                          hipStream_t st);

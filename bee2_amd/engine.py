@@ -46,6 +46,9 @@ DROPIN_SYMBOLS = [
     "bashHashStepG", "bashHashStepV", "bashHash",
     "beltH", "beltKeyExpand2", "beltBlockEncr", "beltBlockEncr2", "beltBlockEncr3",
     "beltCTR_keep", "beltCTRStart", "beltCTRStepE", "beltCTR",
+    "beltBlockDecr", "beltBlockDecr2", "beltBlockDecr3",
+    "beltECB_keep", "beltECBStart", "beltECBStepE", "beltECBStepD", "beltECBEncr", "beltECBDecr",
+    "beltCBC_keep", "beltCBCStart", "beltCBCStepE", "beltCBCStepD", "beltCBCEncr", "beltCBCDecr",
     "beltMAC_keep", "beltMACStart", "beltMACStepA", "beltMACStepG", "beltMACStepG2",
     "beltMACStepV", "beltMACStepV2", "beltMAC",
     "bignParamsStd", "bignVerify", "bign128Verify",
@@ -54,6 +57,7 @@ BATCH_SYMBOLS = [
     "bee2hip_bashF_batch", "bee2hip_beltCTR_bulk", "bee2hip_bignVerify_batch",
     "bee2hip_bashHash_beltMAC_batch",
     "bee2hip_bashF_batch_dev", "bee2hip_beltCTR_blocks_dev", "bee2hip_beltBlockEncr_dev",
+    "bee2hip_beltModes_blocks_dev", "bee2hip_beltCBCEncr_batch_dev",
     "bee2hip_bign128Verify_batch_dev", "bee2hip_bignVerify_batch_dev",
     "bee2hip_bashHash_beltMAC_batch_dev",
     "bee2hip_set_device", "bee2hip_sync", "bee2hip_last_error", "bee2hip_version",
@@ -81,14 +85,15 @@ class Engine:
         for name in ("bee2hip_last_error", "bee2hip_version"):
             getattr(L, name).restype = ctypes.c_char_p
         L.beltH.restype = ctypes.POINTER(ctypes.c_ubyte)
-        for name in ("bashF_deep", "bashHash_keep", "beltCTR_keep", "beltMAC_keep"):
+        for name in ("bashF_deep", "bashHash_keep", "beltCTR_keep", "beltMAC_keep", "beltECB_keep", "beltCBC_keep"):
             if hasattr(L, name):
                 getattr(L, name).restype = _sz
         for name in DROPIN_SYMBOLS + BATCH_SYMBOLS:
             f = getattr(L, name, None)
             if f is not None and name.startswith(("bee2hip_", "bash", "belt", "bign")) and \
                     name not in ("bee2hip_last_error", "bee2hip_version", "beltH", "bashF_deep",
-                                 "bashHash_keep", "beltCTR_keep", "beltMAC_keep", "bash_platform"):
+                                 "bashHash_keep", "beltCTR_keep", "beltMAC_keep", "beltECB_keep",
+                                 "beltCBC_keep", "bash_platform"):
                 f.restype = _u32
 
     # ------------------------------------------------------------------ util
@@ -136,6 +141,20 @@ class Engine:
         n = blocks.numel() // 16
         self._check(self.lib.bee2hip_beltBlockEncr_dev(self._ptr(blocks), _sz(n), bytes(key_words),
                                                        self._stream()), "beltBlockEncr_dev")
+
+    def beltModes_blocks_dev(self, mode, src, dst, key_words, iv_words=None):
+        """mode 0 ECB encrypt, 1 ECB decrypt, 2 CBC decrypt (src != dst); full blocks"""
+        n = src.numel() // 16
+        assert src.numel() == 16 * n and dst.numel() == 16 * n
+        self._check(self.lib.bee2hip_beltModes_blocks_dev(int(mode), self._ptr(src), self._ptr(dst), _sz(n),
+                                                          bytes(key_words), bytes(iv_words) if iv_words else None,
+                                                          self._stream()), "beltModes_blocks_dev")
+
+    def beltCBCEncr_batch_dev(self, msgs, nblk, key_words, ivs):
+        n = ivs.numel() // 16
+        assert msgs.numel() == n * nblk * 16
+        self._check(self.lib.bee2hip_beltCBCEncr_batch_dev(self._ptr(msgs), _sz(nblk), _sz(n), bytes(key_words),
+                                                           self._ptr(ivs), self._stream()), "beltCBCEncr_batch_dev")
 
     def bign128Verify_batch_dev(self, hashes, sigs, pubkeys, codes):
         n = hashes.numel() // 32
@@ -244,6 +263,36 @@ class Engine:
         st = ctypes.create_string_buffer(self.lib.beltCTR_keep())
         self.lib.beltCTRStart(st, bytes(key), _sz(len(key)), bytes(iv))
         return st.raw[:32], st.raw[32:48]
+
+    def beltBlockDecr(self, block, key):
+        b = ctypes.create_string_buffer(bytes(block), 16)
+        self.lib.beltBlockDecr(b, self.beltKeyExpand2(key))
+        return b.raw
+
+    def belt_mode(self, fn, src, key, iv=None):
+        """one-shot beltECBEncr / beltECBDecr / beltCBCEncr / beltCBCDecr"""
+        out = ctypes.create_string_buffer(max(len(src), 1))
+        f = getattr(self.lib, fn)
+        if iv is None:
+            code = f(out, bytes(src), _sz(len(src)), bytes(key), _sz(len(key)))
+        else:
+            code = f(out, bytes(src), _sz(len(src)), bytes(key), _sz(len(key)), bytes(iv))
+        return code, out.raw[: len(src)]
+
+    def belt_mode_steps(self, mode, decr, src, key, iv, splits):
+        """Start / Step{E,D}* of beltECB (mode 'ECB') or beltCBC ('CBC')"""
+        st = ctypes.create_string_buffer(getattr(self.lib, f"belt{mode}_keep")())
+        if mode == "ECB":
+            self.lib.beltECBStart(st, bytes(key), _sz(len(key)))
+        else:
+            self.lib.beltCBCStart(st, bytes(key), _sz(len(key)), bytes(iv))
+        step = getattr(self.lib, f"belt{mode}Step{'D' if decr else 'E'}")
+        buf = ctypes.create_string_buffer(bytes(src), len(src))
+        off = 0
+        for s in splits:
+            step(ctypes.byref(buf, off), _sz(s), st)
+            off += s
+        return buf.raw[: len(src)]
 
     def beltMAC(self, src, key):
         out = ctypes.create_string_buffer(8)

@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--only", default="", help="comma list of {bashF,ctr,verify,mixed}; default all")
+    ap.add_argument("--only", default="", help="comma list of {bashF,ctr,verify,mixed,modes}; default all")
     ap.add_argument("--ctr-gib", type=float, default=16.0)
     return ap.parse_args()
 
@@ -228,7 +228,7 @@ def main():
     dist = Dist(args.gpus)
     eng = bee2_amd.load()                     # fails loudly without libbee2hip.so
     eng.set_device(torch.cuda.current_device())
-    only = set(x for x in args.only.split(",") if x) or {"bashF", "ctr", "verify", "mixed"}
+    only = set(x for x in args.only.split(",") if x) or {"bashF", "ctr", "verify", "mixed", "modes"}
     K, W, N = args.steps, args.warmup, dist.world
     do_cpu = (not args.no_cpu) and dist.rank == 0 and N == 1
     cores = os.cpu_count() or 1
@@ -368,6 +368,48 @@ def main():
         if do_cpu:
             others["bash512_beltMAC"]["cpu_baseline"] = cpu_baseline("mixed", cores)
         del msgs, dig, tag
+
+    # ------------------------------------------------- 8f-1: ECB / CBC-decrypt bulk modes
+    if "modes" in only:
+        nbytes = 4 << 30
+        free, _ = torch.cuda.mem_get_info()
+        if free < 2 * nbytes + (1 << 30):
+            nbytes = (int(free * 0.3) // (1 << 20)) << 20
+        src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        src.view(torch.int64).random_()
+        dst = torch.empty_like(src)
+        km = max(3, min(K, 10))
+        entry = {"metric": "belt ECB/CBC bulk GiB/s", "unit": "GiB/s", "steps": km,
+                 "config": {"workload": f"{nbytes / 2**30:.0f} GiB of full blocks per GPU, one key (SURVEY 8f-1)"}}
+        for name, mode in (("ecb_encr", 0), ("ecb_decr", 1), ("cbc_decr", 2)):
+            el = timed(dist, km, 1, lambda: eng.beltModes_blocks_dev(mode, src, dst, kw, c0))
+            entry[name] = N * nbytes * km / el / 2 ** 30
+        entry["value"] = entry["ecb_encr"]
+        entry["ms_per_step"] = nbytes / 2 ** 30 / entry["ecb_encr"] * 1e3 * N
+        if do_cpu:
+            import orclib
+            import refgen
+            if refgen.have_ref():
+                orc = orclib.load()
+                ref = ctypes.CDLL(refgen.REF_SO)
+                hb = np.zeros(64 << 20, dtype=np.uint8)
+                ho = np.empty_like(hb)
+                cpu = {"cores": cores, "kind": "reference", "unit": "GiB/s",
+                       "sample": "64 MiB of full blocks, threads over disjoint slices"}
+                for name, fn, iv in (("ecb_encr", "beltECBEncr", None), ("ecb_decr", "beltECBDecr", None),
+                                     ("cbc_decr", "beltCBCDecr", H[192:208])):
+                    fp = ctypes.cast(getattr(ref, fn), ctypes.c_void_p)
+                    t0, reps = time.perf_counter(), 0
+                    while time.perf_counter() - t0 < 1.5:
+                        orc.lib.orc_drive_ref_mode(fp, ctypes.c_void_p(hb.ctypes.data), ctypes.c_void_p(ho.ctypes.data),
+                                                   ctypes.c_size_t(hb.nbytes // 16), H[128:160], ctypes.c_size_t(32),
+                                                   iv, cores)
+                        reps += 1
+                    cpu[name] = reps * hb.nbytes / 2 ** 30 / (time.perf_counter() - t0)
+                cpu["value"] = cpu["ecb_encr"]
+                entry["cpu_baseline"] = cpu
+        others["belt_modes"] = entry
+        del src, dst
 
     if not result:                        # --only without bashF: promote the first other metric
         k0 = next(iter(others))

@@ -92,6 +92,28 @@ void beltCTRStepE(void *buf, size_t count, void *state);
 #define beltCTRStepD beltCTRStepE                 /* belt.h:724 */
 err_t beltCTR(void *dest, const void *src, size_t count, const octet key[], size_t len,
               const octet iv[16]);
+/* ---- SURVEY.md 8f-1 ("next" row): block decryption and the block-parallel modes ---- */
+/* belt.h:230-262, belt_block.c:341-373 */
+void beltBlockDecr(octet block[16], const u32 key[8]);
+void beltBlockDecr2(u32 block[4], const u32 key[8]);
+void beltBlockDecr3(u32 *a, u32 *b, u32 *c, u32 *d, const u32 key[8]);
+/* belt.h:430-505, src/crypto/belt/belt_ecb.c:42-159; state = belt_ecb_st (key[8], block[16]) */
+size_t beltECB_keep(void);
+void beltECBStart(void *state, const octet key[], size_t len);
+void beltECBStepE(void *buf, size_t count, void *state);
+void beltECBStepD(void *buf, size_t count, void *state);
+err_t beltECBEncr(void *dest, const void *src, size_t count, const octet key[], size_t len);
+err_t beltECBDecr(void *dest, const void *src, size_t count, const octet key[], size_t len);
+/* belt.h:520-600, src/crypto/belt/belt_cbc.c:43-193; state = belt_cbc_st (key[8], block[16], block1[16]) */
+size_t beltCBC_keep(void);
+void beltCBCStart(void *state, const octet key[], size_t len, const octet iv[16]);
+void beltCBCStepE(void *buf, size_t count, void *state);
+void beltCBCStepD(void *buf, size_t count, void *state);
+err_t beltCBCEncr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                  const octet iv[16]);
+err_t beltCBCDecr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                  const octet iv[16]);
+
 /* belt.h:756-854, src/crypto/belt/belt_mac.c:32-203 */
 size_t beltMAC_keep(void);
 void beltMACStart(void *state, const octet key[], size_t len);
@@ -151,6 +173,14 @@ err_t bee2hip_beltCTR_blocks_dev(void *d_buf, size_t nblocks, const u32 key[8],
                                  const u32 ctr0[4], uint64_t first_block, void *stream);
 /* ECB-style E_K over n blocks in place (used for ctr0 = E_K(iv), r = E_K(0)) */
 err_t bee2hip_beltBlockEncr_dev(void *d_blocks, size_t nblocks, const u32 key[8], void *stream);
+/* 8f-1: full blocks, device resident.  mode 0 = ECB encrypt, 1 = ECB decrypt (d_src may equal
+   d_dst), 2 = CBC decrypt with chaining value iv[4] (u32 words; d_src != d_dst) */
+err_t bee2hip_beltModes_blocks_dev(int mode, const void *d_src, void *d_dst, size_t nblocks,
+                                   const u32 key[8], const u32 iv[4], void *stream);
+/* n independent messages of nblk full blocks each, CBC-encrypted in place, one lane per
+   message; d_ivs[n][16] holds each message's iv on entry and its last ciphertext block on exit */
+err_t bee2hip_beltCBCEncr_batch_dev(void *d_msgs, size_t nblk, size_t n, const u32 key[8],
+                                    void *d_ivs, void *stream);
 err_t bee2hip_bign128Verify_batch_dev(const void *d_hashes, const void *d_sigs,
                                       const void *d_pubkeys, size_t n, void *d_codes,
                                       void *stream);

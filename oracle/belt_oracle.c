@@ -376,3 +376,126 @@ void orc_drive_ref_mixed(void *hash_fn, void *mac_fn, const uint8_t *msgs, size_
     ref_mixed_job j = {msgs, msg_len, key, key_len, digests, tags, (ref_hash_fn)hash_fn, (ref_mac_fn)mac_fn};
     orc_parallel_for(n, nthreads, ref_mixed_range, &j);
 }
+
+/* ------------------------------------------- ECB / CBC --- */
+/* D_K: the same round function with the subkeys in reverse order
+   (belt_block.c:242-243 subkey_d, :286-295 macro D, :341-373 beltBlockDecr*) */
+void orc_beltBlockDecr2(uint32_t block[4], const uint32_t K[8])
+{
+    const uint8_t *H = orc_beltH();
+    uint32_t a = block[0], b = block[1], c = block[2], d = block[3], e, t;
+    for (unsigned i = 8; i >= 1; --i) {
+        const unsigned base = 7 * i - 1;
+#define KEY(j) K[(base - (j)) & 7]
+        b ^= G(H, a + KEY(0), 5);
+        c ^= G(H, d + KEY(1), 21);
+        a -= G(H, b + KEY(2), 13);
+        e = G(H, b + c + KEY(3), 21) ^ i;
+        b += e;
+        c -= e;
+        d += G(H, c + KEY(4), 13);
+        b ^= G(H, a + KEY(5), 21);
+        c ^= G(H, d + KEY(6), 5);
+#undef KEY
+        /* (a,b,c,d) <- (c,a,d,b) */
+        t = a; a = c; c = d; d = b; b = t;
+    }
+    /* output (c,a,d,b): belt_block.c:293-295 */
+    block[0] = c; block[1] = a; block[2] = d; block[3] = b;
+}
+
+static void blk_load(uint32_t w[4], const uint8_t *p) { for (int i = 0; i < 4; ++i) w[i] = load32le(p + 4 * i); }
+static void blk_store(uint8_t *p, const uint32_t w[4]) { for (int i = 0; i < 4; ++i) store32le(p + 4 * i, w[i]); }
+static void blk_crypt(uint8_t *p, const uint32_t key[8], int decr)
+{
+    uint32_t w[4];
+    blk_load(w, p);
+    if (decr) orc_beltBlockDecr2(w, key); else orc_beltBlockEncr2(w, key);
+    blk_store(p, w);
+}
+
+/* beltECBEncr / beltECBDecr with ciphertext stealing (belt_ecb.c:52-159) */
+uint32_t orc_beltECB(void *dest, const void *src, size_t count, const uint8_t *key, size_t len, int decr)
+{
+    uint32_t K[8];
+    uint8_t *buf = (uint8_t *)dest, blk[16];
+    if (count < 16 || (len != 16 && len != 24 && len != 32)) return ORC_BAD_INPUT;
+    orc_beltKeyExpand2(K, key, len);
+    memmove(dest, src, count);
+    while (count >= 16) { blk_crypt(buf, K, decr); buf += 16; count -= 16; }
+    if (count) {
+        memcpy(blk, buf, count);
+        memcpy(blk + count, buf - 16 + count, 16 - count);
+        blk_crypt(blk, K, decr);
+        memcpy(buf, buf - 16, count);
+        memcpy(buf - 16, blk, 16);
+    }
+    return ORC_OK;
+}
+
+/* beltCBCEncr / beltCBCDecr with ciphertext stealing (belt_cbc.c:63-193) */
+uint32_t orc_beltCBC(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
+                     const uint8_t iv[16], int decr)
+{
+    uint32_t K[8];
+    uint8_t *buf = (uint8_t *)dest, chain[16], t[16];
+    if (count < 16 || (len != 16 && len != 24 && len != 32)) return ORC_BAD_INPUT;
+    orc_beltKeyExpand2(K, key, len);
+    memmove(dest, src, count);
+    memcpy(chain, iv, 16);
+    if (!decr) {
+        while (count >= 16) {
+            for (int i = 0; i < 16; ++i) chain[i] ^= buf[i];
+            blk_crypt(chain, K, 0);
+            memcpy(buf, chain, 16);
+            buf += 16; count -= 16;
+        }
+        if (count) {
+            for (size_t i = 0; i < count; ++i) t[i] = buf[i] ^ chain[i];
+            memcpy(t + count, buf - 16 + count, 16 - count);
+            blk_crypt(t, K, 0);
+            memcpy(buf, buf - 16, count);
+            memcpy(buf - 16, t, 16);
+        }
+    } else {
+        while (count >= 32 || count == 16) {
+            memcpy(t, buf, 16);
+            blk_crypt(t, K, 1);
+            for (int i = 0; i < 16; ++i) t[i] ^= chain[i];
+            memcpy(chain, buf, 16);
+            memcpy(buf, t, 16);
+            buf += 16; count -= 16;
+        }
+        if (count) {
+            const size_t r = count - 16;
+            memcpy(t, buf, 16);
+            blk_crypt(t, K, 1);
+            for (size_t i = 0; i < r; ++i) { uint8_t x = t[i]; t[i] = buf[16 + i]; buf[16 + i] = x; }
+            for (size_t i = 0; i < r; ++i) buf[16 + i] ^= t[i];
+            blk_crypt(t, K, 1);
+            for (int i = 0; i < 16; ++i) buf[i] = t[i] ^ chain[i];
+        }
+    }
+    return ORC_OK;
+}
+
+/* reference driver for the 8f-1 modes: fn = beltECBEncr / beltECBDecr (iv == NULL) or
+   beltCBCDecr (iv given; slice k chains from the ciphertext block before it) */
+typedef uint32_t (*ref_ecb_fn)(void *dest, const void *src, size_t count, const uint8_t *key, size_t len);
+typedef uint32_t (*ref_cbc_fn)(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
+                               const uint8_t *iv);
+typedef struct { const uint8_t *src; uint8_t *dst; const uint8_t *key; size_t klen; const uint8_t *iv; void *fn; } ref_mode_job;
+static void ref_mode_range(void *ctx, size_t lo, size_t hi)
+{
+    ref_mode_job *j = (ref_mode_job *)ctx;
+    if (hi == lo) return;
+    if (!j->iv) ((ref_ecb_fn)j->fn)(j->dst + 16 * lo, j->src + 16 * lo, 16 * (hi - lo), j->key, j->klen);
+    else ((ref_cbc_fn)j->fn)(j->dst + 16 * lo, j->src + 16 * lo, 16 * (hi - lo), j->key, j->klen,
+                             lo ? j->src + 16 * (lo - 1) : j->iv);
+}
+void orc_drive_ref_mode(void *fn, const uint8_t *src, uint8_t *dst, size_t nblocks, const uint8_t *key,
+                        size_t klen, const uint8_t *iv, int nthreads)
+{
+    ref_mode_job j = {src, dst, key, klen, iv, fn};
+    orc_parallel_for(nblocks, nthreads, ref_mode_range, &j);
+}

@@ -87,6 +87,13 @@ void orc_beltMACStepG(uint8_t mac[8], const orc_belt_mac_st *st);
 uint32_t orc_beltMAC(uint8_t mac[8], const void *src, size_t count,
                      const uint8_t *key, size_t len);
 
+/* block decryption and the block-parallel modes built on it */
+void orc_beltBlockDecr2(uint32_t block[4], const uint32_t key[8]);          /* belt_block.c:341-373 */
+uint32_t orc_beltECB(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
+                     int decr);                                              /* belt_ecb.c:52-159 */
+uint32_t orc_beltCBC(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
+                     const uint8_t iv[16], int decr);                        /* belt_cbc.c:63-193 */
+
 void orc_beltCompr(uint32_t h[8], const uint32_t X[8]);        /* belt_compr.c:27-51 */
 uint32_t orc_beltHash(uint8_t hash[32], const void *src, size_t count); /* belt_hash.c:173-190 */
 
@@ -116,6 +123,8 @@ void orc_drive_ref_ctr(void *beltCTRStepE_fn, uint8_t *buf, size_t nblocks, cons
                        const uint32_t ctr0[4], uint64_t first, int nthreads);
 void orc_drive_ref_verify(void *bign128Verify_fn, const uint8_t *hashes, const uint8_t *sigs,
                           const uint8_t *pubkeys, size_t n, uint32_t *codes, int nthreads);
+void orc_drive_ref_mode(void *fn, const uint8_t *src, uint8_t *dst, size_t nblocks, const uint8_t *key,
+                        size_t klen, const uint8_t *iv, int nthreads);
 void orc_drive_ref_mixed(void *bashHash_fn, void *beltMAC_fn, const uint8_t *msgs, size_t msg_len,
                          size_t n, const uint8_t *key, size_t key_len, uint8_t *digests,
                          uint8_t *tags, int nthreads);

@@ -98,6 +98,21 @@ class Oracle:
                                     bytes(key_words), bytes(ctr0_words), ctypes.c_uint64(first),
                                     ctypes.c_int(nthreads))
 
+    def ecb(self, msg, key, decr=False):
+        out = ctypes.create_string_buffer(max(len(msg), 1))
+        code = self.lib.orc_beltECB(out, bytes(msg), _sz(len(msg)), bytes(key), _sz(len(key)), int(decr))
+        return code, out.raw[: len(msg)]
+
+    def cbc(self, msg, key, iv, decr=False):
+        out = ctypes.create_string_buffer(max(len(msg), 1))
+        code = self.lib.orc_beltCBC(out, bytes(msg), _sz(len(msg)), bytes(key), _sz(len(key)), bytes(iv), int(decr))
+        return code, out.raw[: len(msg)]
+
+    def block_decr(self, block, key):
+        w = (ctypes.c_uint32 * 4).from_buffer_copy(bytes(block))
+        self.lib.orc_beltBlockDecr2(w, self.key_expand(key))
+        return bytes(w)
+
     def mac(self, msg, key):
         out = ctypes.create_string_buffer(8)
         code = self.lib.orc_beltMAC(out, bytes(msg), _sz(len(msg)), bytes(key), _sz(len(key)))

@@ -105,3 +105,29 @@ def test_mixed_batch_matches_single(orc, golden):
         m = msgs[4096 * i: 4096 * (i + 1)]
         assert dig[64 * i: 64 * i + 64] == orc.bashHash(256, m)[1]
         assert tag[8 * i: 8 * i + 8] == orc.mac(m, key)
+
+
+def test_belt_ecb_cbc_A9_A12(orc, golden):
+    """ECB / CBC incl. ciphertext stealing (belt_test.c:288-396)"""
+    for k in golden.kat["belt_modes"]:
+        msg, key = bytes.fromhex(k["in"]), bytes.fromhex(k["key"])
+        decr = k["fn"].endswith("Decr")
+        if "ECB" in k["fn"]:
+            code, out = orc.ecb(msg, key, decr)
+        else:
+            code, out = orc.cbc(msg, key, bytes.fromhex(k["iv"]), decr)
+        assert code == 0 and out.hex() == k["out"], k["name"]
+
+
+def test_belt_ecb_cbc_random_cases(orc, golden):
+    for c in golden.belt_bash:
+        if "ecb_e" not in c:
+            continue
+        msg, key, iv = (bytes.fromhex(c[x]) for x in ("msg", "key", "iv"))
+        assert orc.ecb(msg, key)[1].hex() == c["ecb_e"]
+        assert orc.ecb(msg, key, True)[1].hex() == c["ecb_d"]
+        assert orc.cbc(msg, key, iv)[1].hex() == c["cbc_e"]
+        assert orc.cbc(msg, key, iv, True)[1].hex() == c["cbc_d"]
+        assert orc.ecb(orc.ecb(msg, key)[1], key, True)[1] == msg            # D(E(x)) = x
+        assert orc.cbc(orc.cbc(msg, key, iv)[1], key, iv, True)[1] == msg
+    assert orc.ecb(b"x" * 15, b"k" * 32)[0] == 109                           # count < 16: ERR_BAD_INPUT

@@ -85,6 +85,17 @@ def r_ctr(msg, key, iv, splits=None):
     return buf.raw
 
 
+def r_mode(fn, msg, key, iv=None):
+    """beltECBEncr/Decr, beltCBCEncr/Decr of the reference (belt_ecb.c:109-159, belt_cbc.c:143-193)"""
+    out = ctypes.create_string_buffer(len(msg))
+    if iv is None:
+        code = getattr(L, fn)(out, msg, _sz(len(msg)), key, _sz(len(key)))
+    else:
+        code = getattr(L, fn)(out, msg, _sz(len(msg)), key, _sz(len(key)), iv)
+    assert code == 0, (fn, code)
+    return out.raw
+
+
 def r_mac(msg, key):
     out = ctypes.create_string_buffer(8)
     assert L.beltMAC(out, msg, _sz(len(msg)), key, _sz(len(key))) == 0
@@ -152,6 +163,31 @@ def stb_kats():
         {"name": "A.16", "in": H[64:108].hex(), "key": H[160:192].hex(), "iv": H[208:224].hex(),
          "splits": [11, 5, 28], "out": a16.lower()},
     ]
+    # STB 34.101.31 A.9 / A.10 (ECB) and A.11 / A.12 (CBC), incl. the ciphertext-stealing cases
+    # (belt_test.c:288-396)
+    modes = [
+        ("A.9-1", "beltECBEncr", H[:48], H[128:160], None,
+         "69CCA1C93557C9E3D66BC3E0FA88FA6E5F23102EF109710775017F73806DA9DC46FB2ED2CE771F26DCB5E5D1569F9AB0"),
+        ("A.9-2", "beltECBEncr", H[:47], H[128:160], None,
+         "69CCA1C93557C9E3D66BC3E0FA88FA6E36F00CFED6D1CA1498C12798F4BEB2075F23102EF109710775017F73806DA9"),
+        ("A.10-1", "beltECBDecr", H[64:112], H[160:192], None,
+         "0DC5300600CAB840B38448E5E993F421E55A239F2AB5C5D5FDB6E81B40938E2A54120CA3E6E19C7AD750FC3531DAEAB7"),
+        ("A.10-2", "beltECBDecr", H[64:100], H[160:192], None,
+         "0DC5300600CAB840B38448E5E993F4215780A6E2B69EAFBB258726D7B6718523E55A239F"),
+        ("A.11-1", "beltCBCEncr", H[:48], H[128:160], H[192:208],
+         "10116EFAE6AD58EE14852E11DA1B8A745CF2480E8D03F1C19492E53ED3A70F60657C1EE8C0E0AE5B58388BF8A68E3309"),
+        ("A.11-2", "beltCBCEncr", H[:36], H[128:160], H[192:208],
+         "10116EFAE6AD58EE14852E11DA1B8A746A9BBADCAF73F968F875DEDC0A44F6B15CF2480E"),
+        ("A.12-1", "beltCBCDecr", H[64:112], H[160:192], H[208:224],
+         "730894D6158E17CC1600185A8F411CAB0471FF85C83792398D8924EBD57D03DB95B97A9B7907E4B020960455E46176F8"),
+        ("A.12-2", "beltCBCDecr", H[64:100], H[160:192], H[208:224],
+         "730894D6158E17CC1600185A8F411CABB6AB7AF8541CF85755B8EA27239F08D2166646E4"),
+    ]
+    kat["belt_modes"] = []
+    for name, fn, msg, key, iv, want in modes:
+        check("31/" + name, r_mode(fn, msg, key, iv), want)
+        kat["belt_modes"].append({"name": name, "fn": fn, "in": msg.hex(), "key": key.hex(),
+                                  "iv": iv.hex() if iv else None, "out": want.lower()})
     check("31/A.17-1", r_mac(H[:13], H[128:160]), "7260DA60138F96C9")
     check("31/A.17-2", r_mac(H[:48], H[128:160]), "2DAB59771B4B16D0")
     kat["belt_mac"] = [
@@ -214,7 +250,11 @@ def belt_random(seed=0xBE17):
             s = min(left, rnd.choice((1, 3, 7, 15, 16, 17, 32, 100)))
             splits.append(s)
             left -= s
-        cases.append({"key": key.hex(), "iv": iv.hex(), "msg": msg.hex(), "splits": splits,
+        modes = {}
+        if n >= 16:
+            modes = {"ecb_e": r_mode("beltECBEncr", msg, key).hex(), "ecb_d": r_mode("beltECBDecr", msg, key).hex(),
+                     "cbc_e": r_mode("beltCBCEncr", msg, key, iv).hex(), "cbc_d": r_mode("beltCBCDecr", msg, key, iv).hex()}
+        cases.append({**modes, "key": key.hex(), "iv": iv.hex(), "msg": msg.hex(), "splits": splits,
                       "ctr": r_ctr(msg, key, iv, splits).hex(), "mac": r_mac(msg, key).hex(),
                       "belt_hash": r_belt_hash(msg).hex(),
                       "bash256": r_bashHash(128, msg).hex(), "bash384": r_bashHash(192, msg).hex(),
