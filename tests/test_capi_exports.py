@@ -88,3 +88,18 @@ def test_argument_checks_need_no_gpu(lib_path):
     other = eng.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
     other.b[0] ^= 1                       # a different (valid-looking) curve: no device constants
     assert eng.bignVerify(other, E.OID_BELT_HASH_DER, h, s, k) == E.ERR_NOT_IMPLEMENTED
+
+
+def test_oid_der_validation_matches_reference_on_invalid_inputs(lib_path):
+    """every DER string the reference's oidFromDER rejects must give ERR_BAD_OID before any
+    device work (valid ones are exercised on the GPU in tests/test_gpu_bign.py)"""
+    import json
+    eng = bee2_amd.load(lib_path)
+    p = eng.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "oid_der_cases.json")))
+    h, s, k = b"\0" * 32, b"\0" * 48, b"\0" * 64
+    bad = [c for c in cases if not c["valid"]]
+    assert len(bad) > 100
+    for c in bad:
+        der = bytes.fromhex(c["der"])
+        assert eng.bignVerify(p, der, h, s, k) == E.ERR_BAD_OID, c["der"]

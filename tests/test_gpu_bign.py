@@ -167,3 +167,24 @@ def test_concurrent_batches_on_two_streams_do_not_share_scratch(orc, golden):
     torch.cuda.synchronize()
     assert int((c1 != 0).sum()) == 0
     assert int((c2 != 510).sum()) == 0
+
+
+def test_oid_der_validation_matches_reference(golden):
+    """valid / invalid verdicts of oidFromDER (tests/golden/oid_der_cases.json) through bignVerify:
+    invalid -> ERR_BAD_OID, valid -> the signature check runs (here: ERR_BAD_SIG for a null signature,
+    or ERR_NOT_IMPLEMENTED for an OID longer than the kernel stages)"""
+    import json
+    import os
+    eng = engine()
+    p = eng.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oid_der_cases.json")
+    h, s, k = golden.bign_base[0]
+    for c in json.load(open(path)):
+        der = bytes.fromhex(c["der"])
+        got = eng.bignVerify(p, der, h, s, k)
+        if not c["valid"]:
+            assert got == E.ERR_BAD_OID, c["der"]
+        elif der == E.OID_BELT_HASH_DER:
+            assert got == 0
+        else:
+            assert got in (E.ERR_BAD_SIG, E.ERR_NOT_IMPLEMENTED), (c["der"], got)

@@ -373,8 +373,43 @@ def bign_sets(seed=0xB164, n_base=2048):
     return base, edge
 
 
+def oid_cases(seed=0x01D):
+    """DER strings with the verdict of the reference's oidFromDER (src/core/oid.c:94-101), which is
+    what bignVerify applies to oid_der (bign_sign.c:289-290)."""
+    import random
+    rnd = random.Random(seed)
+    L.oidFromDER.restype = _sz
+    cases = []
+
+    def add(der):
+        ok = L.oidFromDER(None, bytes(der), _sz(len(der))) != (1 << 64) - 1
+        cases.append({"der": bytes(der).hex(), "valid": bool(ok)})
+
+    base = bytes.fromhex("06092A7000020022651F51")
+    add(base)
+    for i in range(len(base)):                 # single-byte mutations of the belt-hash OID
+        for v in (0x00, 0x80, 0xFF, base[i] ^ 0x80, (base[i] + 1) & 0xFF):
+            m = bytearray(base)
+            m[i] = v
+            add(m)
+    for cut in range(0, len(base)):
+        add(base[:cut])
+    add(base + b"\x00")
+    for _ in range(300):                       # random well-formed-ish and random garbage
+        n = rnd.randrange(0, 20)
+        body = bytes(rnd.choice((rnd.randrange(256), rnd.randrange(128), 0x80, 0x81)) for _ in range(n))
+        add(bytes([0x06, n]) + body)
+        add(bytes(rnd.randrange(256) for _ in range(rnd.randrange(0, 12))))
+    add(bytes([0x06, 0x81, 0x80]) + bytes([1] * 128))      # long-form length, 128-byte body
+    add(bytes([0x06, 0x81, 0x7F]) + bytes([1] * 127))      # non-minimal long form
+    add(bytes([0x06, 0x7F]) + bytes([1] * 127))
+    return cases
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    with open(os.path.join(GOLD, "oid_der_cases.json"), "w") as f:
+        json.dump(oid_cases(), f)
     with open(os.path.join(GOLD, "stb_kat.json"), "w") as f:
         json.dump(stb_kats(), f, indent=1)
     inp, out = bashf_random()
