@@ -1,6 +1,7 @@
-// bign_dev.hpp -- GF(p) and Jacobian point arithmetic for bign-curve256v1 on one lane.
+// bign_dev.hpp -- GF(p) and Jacobian point arithmetic for the bign curves on one lane.
 //
-// Replaces, for p = 2^256 - 189 only:
+// Replaces, for p = 2^(32 N) - c (N = 8, 12, 16 limbs; c = 189, 317, 569 -- the three
+// parameter sets of STB 34.101.45 annex B, src/crypto/bign/bign_params.c:34-178):
 //   zzMul / zzSqr / zzAddMulW        src/math/zz/zz_mul.c:45-154
 //   zzRedCrand                       src/math/zz/zz_red.c:71-105
 //   zmMulCrand / zmSqrCrand          src/math/zm.c:214-263
@@ -8,14 +9,14 @@
 //   gfpInv (a^(p-2))                 src/math/gfp.c:33-44
 //   ecpDblJA3 / ecpAddJ / ecpAddAJ / ecpToAJ   src/math/ecp/ecp_j.c:104-133,241-299,397-590
 //
-// MI355X mapping.  One lane owns one signature.  A field element is 8 x 32-bit limbs
-// in VGPRs (bee2 uses 4 x 64-bit words + 128-bit products; CDNA4's widest multiplier
+// MI355X mapping.  One lane owns one signature.  A field element is N x 32-bit limbs
+// in VGPRs (bee2 uses 64-bit words + 128-bit products; CDNA4's widest multiplier
 // is v_mad_u64_u32, 32x32+64).  Measured on gfx950 (tools/ubench/valu_rates.hip):
 // v_mad_u64_u32 and every carry-producing/consuming add issue at HALF the rate of a
 // plain v_add_u32, so the multiplier is product-scanning with a 64-bit column
 // accumulator: one v_mad_u64_u32 (carry-out to an SGPR pair) + one v_addc_co_u32 per
 // 32x32 product, no other carry traffic.  Elements are kept only WEAKLY reduced
-// (any value < 2^256 congruent to the residue): Crandall folding 2^256 = 189 makes a
+// (any value < 2^(32N) congruent to the residue): Crandall folding 2^(32N) = c makes a
 // conditional subtraction of p unnecessary until a value is compared or exported.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -23,12 +24,17 @@
 
 namespace bee2hip {
 
-struct fe { uint32_t v[8]; };
-struct jac { fe X, Y, Z; };          // O <=> Z == 0 (mod p)
-struct aff { fe x, y; };
+template <int N> struct CurveC;
+template <> struct CurveC<8> { static constexpr uint32_t C = 189u; static constexpr int LOWBITS = 8; };
+template <> struct CurveC<12> { static constexpr uint32_t C = 317u; static constexpr int LOWBITS = 9; };
+template <> struct CurveC<16> { static constexpr uint32_t C = 569u; static constexpr int LOWBITS = 10; };
 
-constexpr uint32_t CRANDALL_C = 189u;          // p = 2^256 - 189 (bign_params.c:36-41)
-constexpr uint32_t P_LIMB0 = 0xFFFFFF43u;      // low limb of p; all other limbs 0xFFFFFFFF
+template <int N> struct feT { uint32_t v[N]; };
+template <int N> struct jacT { feT<N> X, Y, Z; };          // O <=> Z == 0 (mod p)
+template <int N> struct affT { feT<N> x, y; };
+typedef feT<8> fe;
+typedef jacT<8> jac;
+typedef affT<8> aff;
 
 // ------------------------------------------------------------------ helpers ---
 // acc(64) += a*b ; c2 += carry-out.  Exactly one v_mad_u64_u32 + one v_addc_co_u32.
@@ -38,33 +44,35 @@ __device__ __forceinline__ void mac(uint64_t &acc, uint32_t &c2, uint32_t a, uin
     asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(a), "v"(b));
     asm("v_addc_co_u32 %0, %1, 0, %0, %1" : "+v"(c2), "+s"(cy));
 }
-__device__ __forceinline__ void fe_set_zero(fe &r)
+
+template <int N>
+__device__ __forceinline__ void fe_set_zero(feT<N> &r)
 {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = 0;
+    for (int i = 0; i < N; ++i) r.v[i] = 0;
 }
-__device__ __forceinline__ void fe_set_one(fe &r)
+template <int N>
+__device__ __forceinline__ void fe_set_one(feT<N> &r)
 {
     fe_set_zero(r);
     r.v[0] = 1;
 }
-__device__ __forceinline__ uint32_t fe_or_all(const fe &a)
-{
-    return (a.v[0] | a.v[1]) | (a.v[2] | a.v[3]) | (a.v[4] | a.v[5]) | (a.v[6] | a.v[7]);
-}
 // a == 0 (mod p) for a weakly reduced a: a is 0 or p
-__device__ __forceinline__ bool fe_is_zero(const fe &a)
+template <int N>
+__device__ __forceinline__ bool fe_is_zero(const feT<N> &a)
 {
-    const uint32_t z = fe_or_all(a);
-    const uint32_t hi = (a.v[1] & a.v[2]) & (a.v[3] & a.v[4]) & (a.v[5] & a.v[6]) & a.v[7];
-    return z == 0 || (hi == 0xFFFFFFFFu && a.v[0] == P_LIMB0);
+    uint32_t z = a.v[0], hi = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 1; i < N; ++i) { z |= a.v[i]; hi &= a.v[i]; }
+    return z == 0 || (hi == 0xFFFFFFFFu && a.v[0] == 0u - CurveC<N>::C);
 }
-// 256-bit compare a >= b on raw limbs
-__device__ __forceinline__ bool u256_ge(const uint32_t (&a)[8], const uint32_t (&b)[8])
+// multi-limb compare a >= b on raw limbs
+template <int N>
+__device__ __forceinline__ bool limbs_ge(const uint32_t (&a)[N], const uint32_t (&b)[N])
 {
     uint64_t borrow = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < N; ++i) {
         const uint64_t d = (uint64_t)a[i] - b[i] - borrow;
         borrow = (d >> 32) & 1u;
     }
@@ -72,138 +80,141 @@ __device__ __forceinline__ bool u256_ge(const uint32_t (&a)[8], const uint32_t (
 }
 
 // --------------------------------------------------------------- add / sub ---
-// r = a + b (mod p), weakly reduced.  Carry out of 2^256 folds back as +189; a second
-// carry can only come from inputs in the 189-value zone [p, 2^256) and then the wrapped
-// value is < 189, so a final +189 on limb 0 alone is exact.
-__device__ __forceinline__ void fe_add(fe &r, const fe &a, const fe &b)
+// r = a + b (mod p), weakly reduced.  Carry out of 2^(32N) folds back as +c; a second
+// carry can only come from inputs in the c-value zone [p, 2^(32N)) and then the wrapped
+// value is < c, so a final +c on limb 0 alone is exact.
+template <int N>
+__device__ __forceinline__ void fe_add(feT<N> &r, const feT<N> &a, const feT<N> &b)
 {
+    constexpr uint32_t C = CurveC<N>::C;
     uint64_t c = 0;
-    uint32_t t[8];
+    uint32_t t[N];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { c += (uint64_t)a.v[i] + b.v[i]; t[i] = (uint32_t)c; c >>= 32; }
-    uint64_t f = (uint64_t)t[0] + ((uint32_t)c ? CRANDALL_C : 0u);
+    for (int i = 0; i < N; ++i) { c += (uint64_t)a.v[i] + b.v[i]; t[i] = (uint32_t)c; c >>= 32; }
+    uint64_t f = (uint64_t)t[0] + ((uint32_t)c ? C : 0u);
     r.v[0] = (uint32_t)f; f >>= 32;
 #pragma unroll
-    for (int i = 1; i < 8; ++i) { f += t[i]; r.v[i] = (uint32_t)f; f >>= 32; }
-    r.v[0] += (uint32_t)f ? CRANDALL_C : 0u;
+    for (int i = 1; i < N; ++i) { f += t[i]; r.v[i] = (uint32_t)f; f >>= 32; }
+    r.v[0] += (uint32_t)f ? C : 0u;
 }
-// r = a - b (mod p), weakly reduced (borrow folds back as -189, mirrored reasoning)
-__device__ __forceinline__ void fe_sub(fe &r, const fe &a, const fe &b)
+// r = a - b (mod p), weakly reduced (borrow folds back as -c, mirrored reasoning)
+template <int N>
+__device__ __forceinline__ void fe_sub(feT<N> &r, const feT<N> &a, const feT<N> &b)
 {
-    uint32_t t[8];
+    constexpr uint32_t C = CurveC<N>::C;
+    uint32_t t[N];
     uint32_t borrow = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < N; ++i) {
         const uint64_t d = (uint64_t)a.v[i] - b.v[i] - borrow;
         t[i] = (uint32_t)d; borrow = (uint32_t)(d >> 32) & 1u;
     }
-    uint32_t sub = borrow ? CRANDALL_C : 0u;
+    const uint32_t sub = borrow ? C : 0u;
     uint32_t bw = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < N; ++i) {
         const uint64_t d = (uint64_t)t[i] - (i == 0 ? sub : 0u) - bw;
         r.v[i] = (uint32_t)d; bw = (uint32_t)(d >> 32) & 1u;
     }
-    r.v[0] -= bw ? CRANDALL_C : 0u;
+    r.v[0] -= bw ? C : 0u;
 }
-__device__ __forceinline__ void fe_dbl(fe &r, const fe &a) { fe_add(r, a, a); }
-__device__ __forceinline__ void fe_neg(fe &r, const fe &a)
+template <int N>
+__device__ __forceinline__ void fe_dbl(feT<N> &r, const feT<N> &a) { fe_add(r, a, a); }
+template <int N>
+__device__ __forceinline__ void fe_neg(feT<N> &r, const feT<N> &a)
 {
-    fe z; fe_set_zero(z);
+    feT<N> z; fe_set_zero(z);
     fe_sub(r, z, a);
 }
 // the unique representative in [0, p)
-__device__ __forceinline__ void fe_canon(fe &r, const fe &a)
+template <int N>
+__device__ __forceinline__ void fe_canon(feT<N> &r, const feT<N> &a)
 {
-    // a >= p  <=>  a + 189 carries out of 2^256; then a - p = a + 189 - 2^256
-    uint64_t c = CRANDALL_C;
-    uint32_t t[8];
+    // a >= p  <=>  a + c carries out of 2^(32N); then a - p = a + c - 2^(32N)
+    uint64_t c = CurveC<N>::C;
+    uint32_t t[N];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { c += a.v[i]; t[i] = (uint32_t)c; c >>= 32; }
+    for (int i = 0; i < N; ++i) { c += a.v[i]; t[i] = (uint32_t)c; c >>= 32; }
     const bool ge = (uint32_t)c != 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = ge ? t[i] : a.v[i];
-}
-__device__ __forceinline__ void fe_select(fe &r, bool take_b, const fe &a, const fe &b)
-{
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = take_b ? b.v[i] : a.v[i];
+    for (int i = 0; i < N; ++i) r.v[i] = ge ? t[i] : a.v[i];
 }
 
 // ---------------------------------------------------------------- reduction ---
-// w[0..15] -> r = (lo + K*189*hi) mod p, weakly reduced.  K is a small compile-time
-// post-scale (1, 2, 3, 4, 8): r = K * (a*b).  K*189 <= 1512, so lo*K + hi*K*189 needs
-// 16 multiplies instead of 8 when K > 1 -- still far cheaper than K-1 modular additions.
-template <uint32_t K>
-__device__ __forceinline__ void fe_reduce(fe &r, const uint32_t (&w)[16])
+// w[0..2N) -> r = K * (lo + c*hi) mod p, weakly reduced.  K is a small compile-time
+// post-scale (1, 2, 3, 4, 8): r = K * (a*b).  K*c <= 4552, so lo*K + hi*K*c needs 2N
+// multiplies instead of N when K > 1 -- still far cheaper than K-1 modular additions.
+template <uint32_t K, int N>
+__device__ __forceinline__ void fe_reduce(feT<N> &r, const uint32_t (&w)[2 * N])
 {
-    uint32_t t[8];
+    constexpr uint32_t C = CurveC<N>::C;
+    uint32_t t[N];
     uint64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        // c < 2^44 always: K*189*(2^32-1) + K*(2^32-1) + c fits easily in 64 bits
-        uint64_t s = (uint64_t)w[8 + i] * (K * CRANDALL_C) + c;
+    for (int i = 0; i < N; ++i) {
+        // c < 2^46 always: K*C*(2^32-1) + K*(2^32-1) + c fits easily in 64 bits
+        uint64_t s = (uint64_t)w[N + i] * (K * C) + c;
         if (K == 1) s += w[i];
         else s += (uint64_t)w[i] * K;
         t[i] = (uint32_t)s; c = s >> 32;
     }
-    // fold the top (< 2^12) once more, then the at-most-one final carry
-    uint64_t f = (uint64_t)t[0] + (uint64_t)(uint32_t)c * CRANDALL_C;
+    // fold the top (< 2^14) once more, then the at-most-one final carry
+    uint64_t f = (uint64_t)t[0] + (uint64_t)(uint32_t)c * C;
     r.v[0] = (uint32_t)f; f >>= 32;
 #pragma unroll
-    for (int i = 1; i < 8; ++i) { f += t[i]; r.v[i] = (uint32_t)f; f >>= 32; }
-    r.v[0] += (uint32_t)f ? CRANDALL_C : 0u;
+    for (int i = 1; i < N; ++i) { f += t[i]; r.v[i] = (uint32_t)f; f >>= 32; }
+    r.v[0] += (uint32_t)f ? C : 0u;
 }
 
 // ------------------------------------------------------------- mul / sqr ---
 // product scanning: column k sums a[i]*b[k-i] into (c2 : acc64)
-template <uint32_t K = 1>
-__device__ __forceinline__ void fe_mul(fe &r, const fe &a, const fe &b)
+template <uint32_t K = 1, int N>
+__device__ __forceinline__ void fe_mul(feT<N> &r, const feT<N> &a, const feT<N> &b)
 {
-    uint32_t w[16];
+    uint32_t w[2 * N];
     uint64_t acc = 0;
     uint32_t c2 = 0;
 #pragma unroll
-    for (int k = 0; k < 15; ++k) {
+    for (int k = 0; k < 2 * N - 1; ++k) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < N; ++i) {
             const int j = k - i;
-            if (j >= 0 && j < 8) mac(acc, c2, a.v[i], b.v[j]);
+            if (j >= 0 && j < N) mac(acc, c2, a.v[i], b.v[j]);
         }
         w[k] = (uint32_t)acc;
         acc = (acc >> 32) | ((uint64_t)c2 << 32);
         c2 = 0;
     }
-    w[15] = (uint32_t)acc;
+    w[2 * N - 1] = (uint32_t)acc;
     fe_reduce<K>(r, w);
 }
 
-// Squaring with 44 multiplications instead of 64: row i multiplies a_i by the vector
-// (a_i, e_{i+1}, d_{i+2}, .., d_8) where d = limbs of 2a (9 limbs, d_8 = top bit) and
+// Squaring with N(N+3)/2 multiplications instead of N^2: row i multiplies a_i by the vector
+// (a_i, e_{i+1}, d_{i+2}, .., d_N) where d = limbs of 2a (N+1 limbs, d_N = top bit) and
 // e_j = a_j << 1 is the doubled limb WITHOUT the bit shifted in from a_{j-1} (that bit belongs
 // to the part of 2a below position i+1, which row i does not use).  Same product-scanning
 // accumulator as fe_mul (cf. zzSqr, src/math/zz/zz_mul.c:112-154, which doubles afterwards).
-template <uint32_t K = 1>
-__device__ __forceinline__ void fe_sqr(fe &r, const fe &a)
+template <uint32_t K = 1, int N>
+__device__ __forceinline__ void fe_sqr(feT<N> &r, const feT<N> &a)
 {
-    uint32_t d[9], e[8];
+    uint32_t d[N + 1], e[N];
 #pragma unroll
-    for (int j = 1; j < 8; ++j) {
+    for (int j = 1; j < N; ++j) {
         e[j] = a.v[j] << 1;
         d[j] = __builtin_amdgcn_alignbit(a.v[j], a.v[j - 1], 31);       // (a_j << 1) | (a_{j-1} >> 31)
     }
-    d[8] = a.v[7] >> 31;
-    uint32_t w[16];
+    d[N] = a.v[N - 1] >> 31;
+    uint32_t w[2 * N];
     uint64_t acc = 0;
     uint32_t c2 = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < 2 * N; ++k) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < N; ++i) {
             const int j = k - i;                     // position inside row i's vector
             if (j == i) mac(acc, c2, a.v[i], a.v[i]);
-            else if (j == i + 1 && j < 8) mac(acc, c2, a.v[i], e[j]);
-            else if (j >= i + 2 && j <= 8) mac(acc, c2, a.v[i], d[j]);
+            else if (j == i + 1 && j < N) mac(acc, c2, a.v[i], e[j]);
+            else if (j >= i + 2 && j <= N) mac(acc, c2, a.v[i], d[j]);
         }
         w[k] = (uint32_t)acc;
         acc = (acc >> 32) | ((uint64_t)c2 << 32);
@@ -212,40 +223,55 @@ __device__ __forceinline__ void fe_sqr(fe &r, const fe &a)
     fe_reduce<K>(r, w);
 }
 
-__device__ __forceinline__ void fe_sqr_n(fe &r, const fe &a, int n)
+template <int N>
+__device__ __forceinline__ void fe_sqr_n(feT<N> &r, const feT<N> &a, int n)
 {
     r = a;
 #pragma unroll 1
     for (int i = 0; i < n; ++i) fe_sqr(r, r);
 }
 
-// a^(p-2): p - 2 = (2^248 - 1) * 2^8 + 0b01000001.  255 S + 13 M.  By value on purpose:
-// a by-reference noinline call would pin the caller's elements in scratch memory.
-__device__ __noinline__ fe fe_inv(fe x)
+// a^(p-2).  p - 2 = (2^m - 1) * 2^k + low with k = LOWBITS, m = 32N - k, low = 2^k - (c + 2)
+// (N = 8: 248 ones then 01000001).  x^(2^m - 1) by the doubling chain over the bits of m,
+// then k squarings interleaved with multiplications by x for the set bits of `low`.
+// By value on purpose: a by-reference noinline call would pin the caller's elements in scratch.
+template <int N>
+__device__ __noinline__ feT<N> fe_inv(feT<N> x)
 {
-    fe x2, x4, x8, x16, x32, x64, t;
-    fe_sqr(t, x);           fe_mul(x2, t, x);
-    fe_sqr_n(t, x2, 2);     fe_mul(x4, t, x2);
-    fe_sqr_n(t, x4, 4);     fe_mul(x8, t, x4);
-    fe_sqr_n(t, x8, 8);     fe_mul(x16, t, x8);
-    fe_sqr_n(t, x16, 16);   fe_mul(x32, t, x16);
-    fe_sqr_n(t, x32, 32);   fe_mul(x64, t, x32);
-    fe_sqr_n(t, x64, 64);   fe_mul(t, t, x64);        // 2^128 - 1
-    fe_sqr_n(t, t, 64);     fe_mul(t, t, x64);        // 2^192 - 1
-    fe_sqr_n(t, t, 32);     fe_mul(t, t, x32);        // 2^224 - 1
-    fe_sqr_n(t, t, 16);     fe_mul(t, t, x16);        // 2^240 - 1
-    fe_sqr_n(t, t, 8);      fe_mul(t, t, x8);         // 2^248 - 1
-    fe_sqr_n(t, t, 2);      fe_mul(t, t, x);          // ..01
-    fe_sqr_n(t, t, 6);      fe_mul(t, t, x);          // ..01000001
-    return t;
+    constexpr int k = CurveC<N>::LOWBITS;
+    constexpr int m = 32 * N - k;
+    constexpr uint32_t low = (1u << k) - (CurveC<N>::C + 2u);
+    // ones(a) := x^(2^a - 1).  ones(2a) = ones(a)^(2^a) * ones(a); ones(a+1) = ones(a)^2 * x
+    feT<N> r = x, t;
+    int a = 1;
+    int top = 31;
+    while (!((m >> top) & 1)) --top;
+#pragma unroll 1
+    for (int bit = top - 1; bit >= 0; --bit) {
+        fe_sqr_n(t, r, a);
+        fe_mul(r, t, r);
+        a *= 2;
+        if ((m >> bit) & 1) {
+            fe_sqr(t, r);
+            fe_mul(r, t, x);
+            a += 1;
+        }
+    }
+#pragma unroll 1
+    for (int bit = k - 1; bit >= 0; --bit) {
+        fe_sqr(r, r);
+        if ((low >> bit) & 1u) fe_mul(r, r, x);
+    }
+    return r;
 }
 
 // ----------------------------------------------------------------- points ---
 // T <- 2T, a = -3.  4M + 4S + 6 add/sub.  Z3 = 2YZ, so Y = 0 or Z = 0 gives O as in
 // ecp_j.c:258-263.  (dbl-2001-b with the small multiples moved into the reductions.)
-__device__ __forceinline__ void jac_dbl(jac &T)
+template <int N>
+__device__ __forceinline__ void jac_dbl(jacT<N> &T)
 {
-    fe delta, gamma, beta4, alpha, t0, t1;
+    feT<N> delta, gamma, beta4, alpha, t0, t1;
     fe_sqr(delta, T.Z);
     fe_sqr(gamma, T.Y);
     fe_mul<4>(beta4, T.X, gamma);            // 4 X Y^2
@@ -265,9 +291,10 @@ __device__ __forceinline__ void jac_dbl(jac &T)
 // T <- T + E for Jacobian E (add-1998-cmo-2, 12M + 4S).  Returns false when the generic
 // formula does not apply (either operand O, or T = +-E): the caller then marks the
 // signature for the complete slow path (ecp_j.c:416-427,455-464 handle these inline).
-__device__ __forceinline__ bool jac_add(jac &T, const jac &E)
+template <int N>
+__device__ __forceinline__ bool jac_add(jacT<N> &T, const jacT<N> &E)
 {
-    fe Z1Z1, Z2Z2, U1, U2, S1, S2, H, HH, HHH, r, V, t;
+    feT<N> Z1Z1, Z2Z2, U1, U2, S1, S2, H, HH, HHH, r, V, t;
     const bool bad_in = fe_is_zero(T.Z) || fe_is_zero(E.Z);
     fe_sqr(Z1Z1, T.Z);
     fe_sqr(Z2Z2, E.Z);
@@ -294,9 +321,10 @@ __device__ __forceinline__ bool jac_add(jac &T, const jac &E)
 }
 
 // T <- T + E for affine E (madd, 8M + 3S); same contract as jac_add
-__device__ __forceinline__ bool jac_madd(jac &T, const aff &E)
+template <int N>
+__device__ __forceinline__ bool jac_madd(jacT<N> &T, const affT<N> &E)
 {
-    fe Z1Z1, U2, S2, H, HH, HHH, r, V, t;
+    feT<N> Z1Z1, U2, S2, H, HH, HHH, r, V, t;
     const bool bad_in = fe_is_zero(T.Z);
     fe_sqr(Z1Z1, T.Z);
     fe_mul(U2, E.x, Z1Z1);
@@ -320,11 +348,12 @@ __device__ __forceinline__ bool jac_madd(jac &T, const aff &E)
 }
 
 // complete addition (all exceptional cases, as ecpAddJ ecp_j.c:397-497): slow path only
-__device__ __forceinline__ void jac_add_complete(jac &T, const jac &E)
+template <int N>
+__device__ __forceinline__ void jac_add_complete(jacT<N> &T, const jacT<N> &E)
 {
     if (fe_is_zero(E.Z)) return;
     if (fe_is_zero(T.Z)) { T = E; return; }
-    fe Z1Z1, Z2Z2, U1, U2, S1, S2, t;
+    feT<N> Z1Z1, Z2Z2, U1, U2, S1, S2, t;
     fe_sqr(Z1Z1, T.Z);
     fe_sqr(Z2Z2, E.Z);
     fe_mul(U1, T.X, Z2Z2);

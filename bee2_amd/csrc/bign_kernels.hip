@@ -1,19 +1,20 @@
-// bign_kernels.hip -- batched bign signature verification on bign-curve256v1 (gfx950).
+// bign_kernels.hip -- batched bign signature verification on the three standard bign curves
+// (gfx950): bign-curve256v1 (l = 128, the graded configuration), 384v1 (l = 192), 512v1 (l = 256).
 //
-// H3 of SURVEY.md 8a.  Replaces n calls of bign128Verify / bignVerifyEc
-// (src/crypto/bign/bign128.c:177-185, src/crypto/bign/bign_sign.c:268-347).
+// H3 of SURVEY.md 8a (+ 8f-4).  Replaces n calls of bignVerify / bign128Verify / bign192Verify /
+// bign256Verify (src/crypto/bign/bign_sign.c:268-361, bign128.c:177-185, bign192.c, bign256.c).
 // One lane per signature; per-signature result is the bee2 err_t the reference returns.
 //
-// The reference computes R = s1' G + (s0 + 2^128) Q with interleaved width-5 NAF
-// (ecAddMulA, src/math/ec.c:1183-1273): data-dependent branching, 257 doublings.  Any
+// The reference computes R = s1' G + (s0 + 2^l) Q with interleaved width-5/6 NAF
+// (ecAddMulA, src/math/ec.c:1183-1273): data-dependent branching, 2l+1 doublings.  Any
 // correct algorithm yields the same affine R, so the GPU uses a wavefront-friendly
-// schedule instead:
-//   * G part: fixed-base comb, 16 windows x 16 bits, table of 16 x 65535 affine points
-//     (64 MiB, built once per device: bign_gtable_kernel makes the 8-bit seed table by
-//     double-and-add, bign_gtable16_kernel combines it) -> 16 mixed additions, NO
-//     doublings for the 256-bit scalar;
-//   * Q part: signed radix-16 digits of the 129-bit scalar (uniform 4 doublings + 1
-//     addition per digit, 33 digits), per-signature table 1Q..8Q kept in an HBM scratch
+// schedule instead (N = number of 32-bit limbs = l/16):
+//   * G part: fixed-base comb, no doublings.  l = 128: 16 windows x 16 bits, 16 x 65535
+//     affine points (64 MiB, built once per device: bign_gtable_kernel makes an 8-bit seed
+//     table by double-and-add, bign_gtable16_kernel combines it) -> 16 mixed additions.
+//     l = 192 / 256: the 8-bit table itself (4N windows) -> 48 / 64 mixed additions.
+//   * Q part: signed radix-16 digits of the (l+1)-bit scalar (uniform 4 doublings + 1
+//     addition per digit, 4N+1 digits), per-signature table 1Q..8Q kept in an HBM scratch
 //     laid out [entry][limb][signature] so table reads coalesce across the wavefront.
 // Exceptional cases of the addition law (operand O, P = +-Q) cannot occur for honest
 // inputs; lanes that hit one are flagged and recomputed by bign_slow_kernel with the
@@ -21,16 +22,17 @@
 //
 // Kernels per batch (same stream): prep -> main -> slow -> tail.
 //   prep : range checks (bign_sign.c:306-318), u = s1 + H mod q (:320-327),
-//          v = s0 + 2^128 (:329-330), Q table
+//          v = s0 + 2^l (:329-330), Q table
 //   main : the double-scalar multiplication and x_R = X / Z^2 (one Fermat inversion)
 //   slow : flagged lanes only
 //   tail : belt-hash(oid || x_R || H) == s0 ? (bign_sign.c:337-343)
-// HBM traffic is irrelevant here (148 B of input per ~7.5e5 VALU ops): the bound is the
-// integer multiplier rate.
+// HBM traffic is irrelevant here (148 B of input per ~5e5 VALU ops at l = 128): the bound is
+// the integer multiplier rate.
+#include <mutex>
 #include "belt_dev.hpp"
 #include "bign_dev.hpp"
-#include <mutex>
 #include "common.hpp"
+#include "bign_curves.inc"
 
 namespace bee2hip {
 
@@ -39,139 +41,180 @@ constexpr uint32_t ST_PENDING = 0xFFFFFFFFu;     // fast path result in rx[]
 constexpr uint32_t ST_SLOW = 0xFFFFFFFEu;        // needs the complete slow path
 // anything else: a final bee2 err_t
 
-// q (group order) and yG, STB 34.101.45 annex B.1 (bign_params.c:58-73), LE limbs
-__constant__ uint32_t c_bign_q[8] = {0x263D6607u, 0x7E5ABF99u, 0x0DFB4DFCu, 0xD95C8ED6u,
-                                     0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-__constant__ uint32_t c_bign_yG[8] = {0x04516A93u, 0x1E29CF18u, 0xC408F652u, 0x78913966u,
-                                      0x51D6835Du, 0x5CE4C9A3u, 0xFB16D69Fu, 0x6BF7FC3Cu};
+// q (group order) and yG per curve, STB 34.101.45 annex B (bign_params.c:34-178), LE limbs
+__constant__ uint32_t c_q8[8] = BIGN128_Q_LIMBS;
+__constant__ uint32_t c_yG8[8] = BIGN128_YG_LIMBS;
+__constant__ uint32_t c_q12[12] = BIGN192_Q_LIMBS;
+__constant__ uint32_t c_yG12[12] = BIGN192_YG_LIMBS;
+__constant__ uint32_t c_q16[16] = BIGN256_Q_LIMBS;
+__constant__ uint32_t c_yG16[16] = BIGN256_YG_LIMBS;
+template <int N> __device__ __forceinline__ const uint32_t *curve_q() { return N == 8 ? c_q8 : N == 12 ? c_q12 : c_q16; }
+template <int N> __device__ __forceinline__ const uint32_t *curve_yG() { return N == 8 ? c_yG8 : N == 12 ? c_yG12 : c_yG16; }
 
-constexpr int GT_WINDOWS = 32;
-constexpr int GT_ENTRIES = 256;                  // entry 0 unused (the neutral element)
-// second-level comb: 16 windows x 16 bits, entry (w, b) = b * 2^(16 w) * G, 64 MiB of HBM
-// (fits the 256 MiB Infinity Cache), built from the 8-bit table by one addition per entry
-constexpr int GT16_WINDOWS = 16;
-constexpr int GT16_ENTRIES = 65536;
+// comb geometry: window width W bits, 32N/W windows, 2^W entries (entry 0 = neutral, unused),
+// each entry an affine point of 2N limbs
+template <int N> struct Comb { static constexpr int W = (N == 8) ? 16 : 8; };
+constexpr int GT8_ENTRIES = 256;
 
 struct VerifyScratch {          // all arrays are [..][n_pad] (signature index fastest)
     uint32_t *status;           // [n_pad]
-    uint32_t *u;                // [8][n_pad]   scalar of G
-    uint32_t *w;                // [5][n_pad]   v + 0x888..8 (33 nibbles): digit_i = nib_i - 8
-    uint32_t *qtab;             // [8][24][n_pad] Jacobian 1Q..8Q
-    uint32_t *rx;               // [8][n_pad]   canonical x_R
+    uint32_t *u;                // [N][n_pad]      scalar of G
+    uint32_t *w;                // [N/2+1][n_pad]  v + 0x888..8 (4N+1 nibbles): digit_i = nib_i - 8
+    uint32_t *qtab;             // [8][3N][n_pad]  Jacobian 1Q..8Q
+    uint32_t *rx;               // [N][n_pad]      canonical x_R
     size_t n_pad;
 };
 
 // ------------------------------------------------------------------ loaders ---
-__device__ __forceinline__ void load_fe_bytes(fe &r, const uint8_t *p)
+template <int N>
+__device__ __forceinline__ void load_fe_bytes(feT<N> &r, const uint8_t *p)
 {
-    // 32 little-endian octets -> 8 limbs (wwFrom, src/math/ww.c); p is 16-byte aligned
-    const uint4 a = *reinterpret_cast<const uint4 *>(p);
-    const uint4 b = *reinterpret_cast<const uint4 *>(p + 16);
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    // 4N little-endian octets -> N limbs (wwFrom, src/math/ww.c); p is 16-byte aligned
+#pragma unroll
+    for (int k = 0; k < N / 4; ++k) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(p + 16 * k);
+        r.v[4 * k] = a.x; r.v[4 * k + 1] = a.y; r.v[4 * k + 2] = a.z; r.v[4 * k + 3] = a.w;
+    }
 }
-__device__ __forceinline__ void store_soa(uint32_t *base, size_t n_pad, size_t idx, const fe &a)
+// same from a pointer that is only 4-byte aligned (the s1 half of a 72-byte signature)
+template <int N>
+__device__ __forceinline__ void load_fe_words(feT<N> &r, const uint8_t *p)
+{
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = w[i];
+}
+template <int N>
+__device__ __forceinline__ void store_soa(uint32_t *base, size_t n_pad, size_t idx, const feT<N> &a)
 {
 #pragma unroll
-    for (int l = 0; l < 8; ++l) base[(size_t)l * n_pad + idx] = a.v[l];
+    for (int l = 0; l < N; ++l) base[(size_t)l * n_pad + idx] = a.v[l];
 }
-__device__ __forceinline__ void load_soa(fe &a, const uint32_t *base, size_t n_pad, size_t idx)
+template <int N>
+__device__ __forceinline__ void load_soa(feT<N> &a, const uint32_t *base, size_t n_pad, size_t idx)
 {
 #pragma unroll
-    for (int l = 0; l < 8; ++l) a.v[l] = base[(size_t)l * n_pad + idx];
+    for (int l = 0; l < N; ++l) a.v[l] = base[(size_t)l * n_pad + idx];
 }
-__device__ __forceinline__ void store_jac(const VerifyScratch &S, int e, size_t idx, const jac &P)
+template <int N>
+__device__ __forceinline__ void store_jac(const VerifyScratch &S, int e, size_t idx, const jacT<N> &P)
 {
-    uint32_t *b = S.qtab + (size_t)e * 24 * S.n_pad;
+    uint32_t *b = S.qtab + (size_t)e * 3 * N * S.n_pad;
     store_soa(b, S.n_pad, idx, P.X);
-    store_soa(b + 8 * S.n_pad, S.n_pad, idx, P.Y);
-    store_soa(b + 16 * S.n_pad, S.n_pad, idx, P.Z);
+    store_soa(b + (size_t)N * S.n_pad, S.n_pad, idx, P.Y);
+    store_soa(b + (size_t)2 * N * S.n_pad, S.n_pad, idx, P.Z);
 }
-__device__ __forceinline__ void load_jac(jac &P, const VerifyScratch &S, int e, size_t idx)
+template <int N>
+__device__ __forceinline__ void load_jac(jacT<N> &P, const VerifyScratch &S, int e, size_t idx)
 {
-    const uint32_t *b = S.qtab + (size_t)e * 24 * S.n_pad;
+    const uint32_t *b = S.qtab + (size_t)e * 3 * N * S.n_pad;
     load_soa(P.X, b, S.n_pad, idx);
-    load_soa(P.Y, b + 8 * S.n_pad, S.n_pad, idx);
-    load_soa(P.Z, b + 16 * S.n_pad, S.n_pad, idx);
+    load_soa(P.Y, b + (size_t)N * S.n_pad, S.n_pad, idx);
+    load_soa(P.Z, b + (size_t)2 * N * S.n_pad, S.n_pad, idx);
 }
-
-__device__ __forceinline__ void load_aff(aff &E, const uint4 *e)
+template <int N>
+__device__ __forceinline__ void load_aff(affT<N> &E, const uint4 *e)
 {
-    const uint4 x0 = e[0], x1 = e[1], y0 = e[2], y1 = e[3];
-    E.x.v[0] = x0.x; E.x.v[1] = x0.y; E.x.v[2] = x0.z; E.x.v[3] = x0.w;
-    E.x.v[4] = x1.x; E.x.v[5] = x1.y; E.x.v[6] = x1.z; E.x.v[7] = x1.w;
-    E.y.v[0] = y0.x; E.y.v[1] = y0.y; E.y.v[2] = y0.z; E.y.v[3] = y0.w;
-    E.y.v[4] = y1.x; E.y.v[5] = y1.y; E.y.v[6] = y1.z; E.y.v[7] = y1.w;
+#pragma unroll
+    for (int k = 0; k < N / 4; ++k) {
+        const uint4 a = e[k], b = e[N / 4 + k];
+        E.x.v[4 * k] = a.x; E.x.v[4 * k + 1] = a.y; E.x.v[4 * k + 2] = a.z; E.x.v[4 * k + 3] = a.w;
+        E.y.v[4 * k] = b.x; E.y.v[4 * k + 1] = b.y; E.y.v[4 * k + 2] = b.z; E.y.v[4 * k + 3] = b.w;
+    }
+}
+template <int N>
+__device__ __forceinline__ void store_aff(uint4 *e, const feT<N> &x, const feT<N> &y)
+{
+#pragma unroll
+    for (int k = 0; k < N / 4; ++k) {
+        e[k] = make_uint4(x.v[4 * k], x.v[4 * k + 1], x.v[4 * k + 2], x.v[4 * k + 3]);
+        e[N / 4 + k] = make_uint4(y.v[4 * k], y.v[4 * k + 1], y.v[4 * k + 2], y.v[4 * k + 3]);
+    }
+}
+// (X : Y : Z) -> canonical affine (x, y); Z != 0
+template <int N>
+__device__ __forceinline__ void to_affine(feT<N> &x, feT<N> &y, const jacT<N> &T)
+{
+    feT<N> zi = fe_inv(T.Z), zi2;
+    fe_sqr(zi2, zi);
+    fe_mul(x, T.X, zi2);
+    fe_mul(zi2, zi2, zi);
+    fe_mul(y, T.Y, zi2);
+    fe_canon(x, x);
+    fe_canon(y, y);
 }
 
 // --------------------------------------------------------------------- prep ---
+template <int N>
 __global__ __launch_bounds__(256)
 void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
                       const uint8_t *__restrict__ pubkeys, size_t n, VerifyScratch S)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
+    constexpr int NO = 4 * N;                       // octets per field element
 
-    aff Q;
-    load_fe_bytes(Q.x, pubkeys + 64 * idx);
-    load_fe_bytes(Q.y, pubkeys + 64 * idx + 32);
-    fe s1, H;
-    load_fe_bytes(s1, sigs + 48 * idx + 16);
-    load_fe_bytes(H, hashes + 32 * idx);
-    const uint4 s0 = *reinterpret_cast<const uint4 *>(sigs + 48 * idx);
+    affT<N> Q;
+    load_fe_bytes(Q.x, pubkeys + 2 * NO * idx);
+    load_fe_bytes(Q.y, pubkeys + 2 * NO * idx + NO);
+    feT<N> s1, H;
+    const uint8_t *sig = sigs + (NO + NO / 2) * idx;   // s0 (NO/2 octets) || s1 (NO octets)
+    load_fe_words(s1, sig + NO / 2);
+    load_fe_bytes(H, hashes + NO * idx);
 
-    uint32_t q[8], P[8];
+    uint32_t q[N], P[N];
+    const uint32_t *cq = curve_q<N>();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { q[i] = c_bign_q[i]; P[i] = 0xFFFFFFFFu; }
-    P[0] = P_LIMB0;
+    for (int i = 0; i < N; ++i) { q[i] = cq[i]; P[i] = 0xFFFFFFFFu; }
+    P[0] = 0u - CurveC<N>::C;
 
     // qrFrom rejects coordinates >= p (bign_sign.c:306-311); there is no on-curve check
-    if (u256_ge(Q.x.v, P) || u256_ge(Q.y.v, P)) { S.status[idx] = ERR_BAD_PUBKEY; return; }
+    if (limbs_ge(Q.x.v, P) || limbs_ge(Q.y.v, P)) { S.status[idx] = ERR_BAD_PUBKEY; return; }
     // s1 >= q (bign_sign.c:313-318)
-    if (u256_ge(s1.v, q)) { S.status[idx] = ERR_BAD_SIG; return; }
+    if (limbs_ge(s1.v, q)) { S.status[idx] = ERR_BAD_SIG; return; }
 
     // H <- H - q if H >= q ; u <- (s1 + H) mod q   (bign_sign.c:320-327)
     {
-        uint32_t t[8];
+        uint32_t t[N];
         uint32_t borrow = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < N; ++i) {
             const uint64_t d = (uint64_t)H.v[i] - q[i] - borrow;
             t[i] = (uint32_t)d; borrow = (uint32_t)(d >> 32) & 1u;
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) H.v[i] = borrow ? H.v[i] : t[i];
+        for (int i = 0; i < N; ++i) H.v[i] = borrow ? H.v[i] : t[i];
         uint64_t c = 0;
-        uint32_t s[8];
+        uint32_t s[N];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { c += (uint64_t)s1.v[i] + H.v[i]; s[i] = (uint32_t)c; c >>= 32; }
+        for (int i = 0; i < N; ++i) { c += (uint64_t)s1.v[i] + H.v[i]; s[i] = (uint32_t)c; c >>= 32; }
         const uint32_t carry = (uint32_t)c;
         borrow = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < N; ++i) {
             const uint64_t d = (uint64_t)s[i] - q[i] - borrow;
             t[i] = (uint32_t)d; borrow = (uint32_t)(d >> 32) & 1u;
         }
         const bool ge = carry || !borrow;            // s1 + H >= q
-        fe u;
+        feT<N> u;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) u.v[i] = ge ? t[i] : s[i];
+        for (int i = 0; i < N; ++i) u.v[i] = ge ? t[i] : s[i];
         store_soa(S.u, S.n_pad, idx, u);
     }
-    // v = s0 + 2^128 ; w = v + 0x8888...8 (33 nibbles) so that digit_i = nibble_i(w) - 8
+    // v = s0 + 2^l ; w = v + 0x8888...8 (4N+1 nibbles) so that digit_i = nibble_i(w) - 8
     {
         uint64_t c = 0;
-        const uint32_t v[5] = {s0.x, s0.y, s0.z, s0.w, 1u};
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            c += (uint64_t)v[i] + (i < 4 ? 0x88888888u : 0x8u);
+        for (int i = 0; i <= N / 2; ++i) {
+            const uint32_t vi = i < N / 2 ? *reinterpret_cast<const uint32_t *>(sig + 4 * i) : 1u;
+            c += (uint64_t)vi + (i < N / 2 ? 0x88888888u : 0x8u);
             S.w[(size_t)i * S.n_pad + idx] = (uint32_t)c;
             c >>= 32;
         }
     }
     // table 1Q..8Q (Jacobian).  Any exceptional case -> slow path.
     bool ok = true;
-    jac P1, P2, P3, P4, T;
+    jacT<N> P1, P2, P3, P4, T;
     P1.X = Q.x; P1.Y = Q.y; fe_set_one(P1.Z);
     store_jac(S, 0, idx, P1);
     P2 = P1; jac_dbl(P2);                 store_jac(S, 1, idx, P2);
@@ -188,57 +231,59 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
 }
 
 // --------------------------------------------------------------------- main ---
+template <int N>
 __global__ __launch_bounds__(256)
 void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     if (S.status[idx] != ST_PENDING) return;
+    constexpr int NW = N / 2 + 1;                   // limbs of w
+    constexpr int W = Comb<N>::W;
 
-    uint32_t w[5];
+    uint32_t w[NW];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) w[i] = S.w[(size_t)i * S.n_pad + idx];
+    for (int i = 0; i < NW; ++i) w[i] = S.w[(size_t)i * S.n_pad + idx];
     bool ok = true;
 
-    // top digit d_32 = nibble_32(w) - 8 is 1 or 2
-    jac T;
-    load_jac(T, S, (int)(w[4] & 15u) - 9, idx);
+    // top digit d_{4N} = nibble_{4N}(w) - 8 is 1 or 2
+    jacT<N> T;
+    load_jac(T, S, (int)(w[NW - 1] & 15u) - 9, idx);
 
 #pragma unroll 1
-    for (int i = 31; i >= 0; --i) {
+    for (int i = 4 * N - 1; i >= 0; --i) {
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) jac_dbl(T);
-        const int d = (int)(w[3] >> 28) - 8;            // next digit, in [-8, 7]
-        w[3] = (w[3] << 4) | (w[2] >> 28);
-        w[2] = (w[2] << 4) | (w[1] >> 28);
-        w[1] = (w[1] << 4) | (w[0] >> 28);
+        const int d = (int)(w[NW - 2] >> 28) - 8;       // next digit, in [-8, 7]
+#pragma unroll
+        for (int l = NW - 2; l > 0; --l) w[l] = (w[l] << 4) | (w[l - 1] >> 28);
         w[0] <<= 4;
         if (d != 0) {
-            jac E;
+            jacT<N> E;
             load_jac(E, S, (d < 0 ? -d : d) - 1, idx);
             if (d < 0) fe_neg(E.Y, E.Y);
             ok &= jac_add(T, E);
         }
     }
-    // + u G : comb over the 16 halfwords of u (16 mixed additions, no doublings)
-    fe u;
+    // + u G : comb over the W-bit windows of u (mixed additions only)
+    feT<N> u;
     load_soa(u, S.u, S.n_pad, idx);
 #pragma unroll 1
-    for (int win = 0; win < GT16_WINDOWS; ++win) {
-        const uint32_t b = u.v[0] & 0xFFFFu;
+    for (int win = 0; win < 32 * N / W; ++win) {
+        const uint32_t b = u.v[0] & ((1u << W) - 1u);
 #pragma unroll
-        for (int l = 0; l < 7; ++l) u.v[l] = (u.v[l] >> 16) | (u.v[l + 1] << 16);
-        u.v[7] >>= 16;
+        for (int l = 0; l < N - 1; ++l) u.v[l] = (u.v[l] >> W) | (u.v[l + 1] << (32 - W));
+        u.v[N - 1] >>= W;
         if (b != 0) {
-            aff E;
-            load_aff(E, gtab + ((size_t)win * GT16_ENTRIES + b) * 4);
+            affT<N> E;
+            load_aff(E, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
             ok &= jac_madd(T, E);
         }
     }
     ok &= !fe_is_zero(T.Z);
     if (!ok) { S.status[idx] = ST_SLOW; return; }
     // x_R = X / Z^2  (ecpToAJ, ecp_j.c:104-133)
-    fe zi = fe_inv(T.Z);
+    feT<N> zi = fe_inv(T.Z);
     fe_sqr(zi, zi);
     fe_mul(zi, T.X, zi);
     fe_canon(zi, zi);
@@ -250,6 +295,7 @@ void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
 // case of ecpAddJ / ecpDblJA3 handled.  Rare (never for honest inputs).
 __device__ __forceinline__ bool bit_at(const uint32_t *k, int i) { return (k[i >> 5] >> (i & 31)) & 1u; }
 
+template <int N>
 __global__ __launch_bounds__(64)
 void bign_slow_kernel(const uint8_t *__restrict__ sigs, const uint8_t *__restrict__ pubkeys,
                       size_t n, VerifyScratch S)
@@ -257,28 +303,30 @@ void bign_slow_kernel(const uint8_t *__restrict__ sigs, const uint8_t *__restric
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     if (S.status[idx] != ST_SLOW) return;
+    constexpr int NO = 4 * N;
 
-    uint32_t u[8], v[5];
-    for (int i = 0; i < 8; ++i) u[i] = S.u[(size_t)i * S.n_pad + idx];
-    const uint4 s0 = *reinterpret_cast<const uint4 *>(sigs + 48 * idx);
-    v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w; v[4] = 1u;
+    uint32_t u[N], v[N / 2 + 1];
+    for (int i = 0; i < N; ++i) u[i] = S.u[(size_t)i * S.n_pad + idx];
+    const uint8_t *sig = sigs + (NO + NO / 2) * idx;
+    for (int i = 0; i < N / 2; ++i) v[i] = *reinterpret_cast<const uint32_t *>(sig + 4 * i);
+    v[N / 2] = 1u;
 
-    jac G, Q, T;
+    jacT<N> G, Q, T;
     fe_set_zero(G.X);
-    for (int i = 0; i < 8; ++i) G.Y.v[i] = c_bign_yG[i];
+    for (int i = 0; i < N; ++i) G.Y.v[i] = curve_yG<N>()[i];
     fe_set_one(G.Z);
-    load_fe_bytes(Q.X, pubkeys + 64 * idx);
-    load_fe_bytes(Q.Y, pubkeys + 64 * idx + 32);
+    load_fe_bytes(Q.X, pubkeys + 2 * NO * idx);
+    load_fe_bytes(Q.Y, pubkeys + 2 * NO * idx + NO);
     fe_set_one(Q.Z);
     fe_set_zero(T.X); fe_set_one(T.Y); fe_set_zero(T.Z);
 #pragma unroll 1
-    for (int i = 255; i >= 0; --i) {
+    for (int i = 32 * N - 1; i >= 0; --i) {
         jac_dbl(T);
         if (bit_at(u, i)) jac_add_complete(T, G);
-        if (i <= 128 && bit_at(v, i)) jac_add_complete(T, Q);
+        if (i <= 16 * N && bit_at(v, i)) jac_add_complete(T, Q);
     }
     if (fe_is_zero(T.Z)) { S.status[idx] = ERR_BAD_SIG; return; }      // R == O (bign_sign.c:332-336)
-    fe zi = fe_inv(T.Z);
+    feT<N> zi = fe_inv(T.Z);
     fe_sqr(zi, zi);
     fe_mul(zi, T.X, zi);
     fe_canon(zi, zi);
@@ -289,14 +337,16 @@ void bign_slow_kernel(const uint8_t *__restrict__ sigs, const uint8_t *__restric
 // --------------------------------------------------------------------- tail ---
 constexpr int OID_MAX = 128;                      // longest DER OID the kernel stages
 struct OidArg { uint32_t len; uint8_t der[OID_MAX]; };
-constexpr int TAIL_MSG_STRIDE = OID_MAX + 64 + 32;          // per-lane message area, zero padded
 
+template <int N>
 __global__ __launch_bounds__(64)
 void bign_tail_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
                       size_t n, VerifyScratch S, OidArg oid, uint32_t *__restrict__ codes)
 {
+    constexpr int NO = 4 * N;
+    constexpr int STRIDE = OID_MAX + 2 * NO + 32;          // per-lane message area, zero padded
     __shared__ __attribute__((aligned(16))) uint8_t s_tab[BeltTabSmall::kBytes];
-    __shared__ __attribute__((aligned(16))) uint8_t s_msg[64 * TAIL_MSG_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_msg[64 * STRIDE];
     BeltTabSmall::fill(s_tab, threadIdx.x, 64);
     __syncthreads();
     const BeltTabSmall T(s_tab);
@@ -306,16 +356,16 @@ void bign_tail_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
     const uint32_t st = S.status[idx];
     if (st != ST_PENDING) { codes[idx] = st; return; }
 
-    // message = oid_der || <x_R>_256 || H  (bign_sign.c:339-342), staged per lane in LDS
-    uint8_t *m = s_msg + threadIdx.x * TAIL_MSG_STRIDE;
-    const uint32_t L = oid.len + 64;
-    for (uint32_t i = 0; i < TAIL_MSG_STRIDE; i += 4) *reinterpret_cast<uint32_t *>(m + i) = 0;
+    // message = oid_der || <x_R> || H  (bign_sign.c:339-342), staged per lane in LDS
+    uint8_t *m = s_msg + threadIdx.x * STRIDE;
+    const uint32_t L = oid.len + 2 * NO;
+    for (uint32_t i = 0; i < STRIDE; i += 4) *reinterpret_cast<uint32_t *>(m + i) = 0;
     for (uint32_t i = 0; i < oid.len; ++i) m[i] = oid.der[i];
-    for (int l = 0; l < 8; ++l) {
+    for (int l = 0; l < N; ++l) {
         const uint32_t x = S.rx[(size_t)l * S.n_pad + idx];
         for (int b = 0; b < 4; ++b) m[oid.len + 4 * l + b] = (uint8_t)(x >> (8 * b));
     }
-    for (int i = 0; i < 32; ++i) m[oid.len + 32 + i] = hashes[32 * idx + i];
+    for (int i = 0; i < NO; ++i) m[oid.len + NO + i] = hashes[NO * idx + i];
 
     // belt-hash (src/crypto/belt/belt_hash.c:43-171)
     uint32_t h[8], s[4] = {0, 0, 0, 0}, X[8], s1[4];
@@ -336,25 +386,29 @@ void bign_tail_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
     X[0] = L << 3; X[1] = 0; X[2] = 0; X[3] = 0;
     X[4] = s[0]; X[5] = s[1]; X[6] = s[2]; X[7] = s[3];
     belt_compress(T, s1, h, X);
-    const uint4 s0 = *reinterpret_cast<const uint4 *>(sigs + 48 * idx);
-    const bool match = h[0] == s0.x && h[1] == s0.y && h[2] == s0.z && h[3] == s0.w;
+    // the first l bits = N/2 words of the hash must equal s0 (beltHashStepV2(sig, no/2, ..))
+    const uint32_t *s0 = reinterpret_cast<const uint32_t *>(sigs + (NO + NO / 2) * idx);
+    bool match = true;
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) match = match && (h[i] == s0[i]);
     codes[idx] = match ? ERR_OK : ERR_BAD_SIG;
 }
 
 // ------------------------------------------------------------------- G table ---
-// entry (win, b) = b * 2^(8 win) * G in affine form, b = 1..255.  One thread per entry,
-// complete double-and-add; runs once per device.
+// 8-bit table: entry (win, b) = b * 2^(8 win) * G in affine form, b = 1..255.  One thread per
+// entry, complete double-and-add; runs once per device.
+template <int N>
 __global__ __launch_bounds__(64)
 void bign_gtable_kernel(uint4 *__restrict__ gtab)
 {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= GT_WINDOWS * GT_ENTRIES) return;
-    const int win = id / GT_ENTRIES, b = id % GT_ENTRIES;
-    uint4 *e = gtab + (size_t)id * 4;
-    if (b == 0) { e[0] = e[1] = e[2] = e[3] = make_uint4(0, 0, 0, 0); return; }
-    jac G, T;
+    if (id >= 4 * N * GT8_ENTRIES) return;
+    const int win = id / GT8_ENTRIES, b = id % GT8_ENTRIES;
+    uint4 *e = gtab + (size_t)id * (N / 2);
+    if (b == 0) { for (int k = 0; k < N / 2; ++k) e[k] = make_uint4(0, 0, 0, 0); return; }
+    jacT<N> G, T;
     fe_set_zero(G.X);
-    for (int i = 0; i < 8; ++i) G.Y.v[i] = c_bign_yG[i];
+    for (int i = 0; i < N; ++i) G.Y.v[i] = curve_yG<N>()[i];
     fe_set_one(G.Z);
     fe_set_zero(T.X); fe_set_one(T.Y); fe_set_zero(T.Z);
     const int top = 8 * win + 7;
@@ -364,66 +418,52 @@ void bign_gtable_kernel(uint4 *__restrict__ gtab)
         const int rel = i - 8 * win;
         if (rel >= 0 && ((b >> rel) & 1)) jac_add_complete(T, G);
     }
-    fe zi = fe_inv(T.Z), zi2, x, y;
-    fe_sqr(zi2, zi);
-    fe_mul(x, T.X, zi2);
-    fe_mul(zi2, zi2, zi);
-    fe_mul(y, T.Y, zi2);
-    fe_canon(x, x);
-    fe_canon(y, y);
-    e[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
-    e[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
-    e[2] = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
-    e[3] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+    feT<N> x, y;
+    to_affine(x, y, T);
+    store_aff(e, x, y);
 }
 
 // 16-bit table from the 8-bit one: entry16(w, b) = entry8(2w, b & 255) + entry8(2w+1, b >> 8).
+template <int N>
 __global__ __launch_bounds__(256)
 void bign_gtable16_kernel(const uint4 *__restrict__ gtab8, uint4 *__restrict__ gtab16)
 {
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= (size_t)GT16_WINDOWS * GT16_ENTRIES) return;
-    const int win = (int)(id / GT16_ENTRIES), b = (int)(id % GT16_ENTRIES);
+    if (id >= (size_t)(2 * N) * 65536) return;
+    const int win = (int)(id >> 16), b = (int)(id & 65535);
     const int lo = b & 255, hi = b >> 8;
-    uint4 *e = gtab16 + id * 4;
-    if (b == 0) { e[0] = e[1] = e[2] = e[3] = make_uint4(0, 0, 0, 0); return; }
-    const uint4 *elo = gtab8 + ((size_t)(2 * win) * GT_ENTRIES + lo) * 4;
-    const uint4 *ehi = gtab8 + ((size_t)(2 * win + 1) * GT_ENTRIES + hi) * 4;
+    uint4 *e = gtab16 + id * (N / 2);
+    if (b == 0) { for (int k = 0; k < N / 2; ++k) e[k] = make_uint4(0, 0, 0, 0); return; }
+    const uint4 *elo = gtab8 + ((size_t)(2 * win) * GT8_ENTRIES + lo) * (N / 2);
+    const uint4 *ehi = gtab8 + ((size_t)(2 * win + 1) * GT8_ENTRIES + hi) * (N / 2);
     if (hi == 0 || lo == 0) {                     // one summand is the neutral element: copy
         const uint4 *src = hi == 0 ? elo : ehi;
-        e[0] = src[0]; e[1] = src[1]; e[2] = src[2]; e[3] = src[3];
+        for (int k = 0; k < N / 2; ++k) e[k] = src[k];
         return;
     }
-    aff A, B;
+    affT<N> A, B;
     load_aff(A, elo);
     load_aff(B, ehi);
-    jac T, E;
+    jacT<N> T, E;
     T.X = A.x; T.Y = A.y; fe_set_one(T.Z);
     E.X = B.x; E.Y = B.y; fe_set_one(E.Z);
     jac_add_complete(T, E);                       // distinct multiples of G below the group order: never O
-    fe zi = fe_inv(T.Z), zi2, x, y;
-    fe_sqr(zi2, zi);
-    fe_mul(x, T.X, zi2);
-    fe_mul(zi2, zi2, zi);
-    fe_mul(y, T.Y, zi2);
-    fe_canon(x, x);
-    fe_canon(y, y);
-    e[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
-    e[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
-    e[2] = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
-    e[3] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+    feT<N> x, y;
+    to_affine(x, y, T);
+    store_aff(e, x, y);
 }
 
 // --------------------------------------------------------- debug / self-test ---
-// element-wise field ops over arrays of 8-limb values, used by tests/test_gpu_field.py
+// element-wise field ops over arrays of N-limb values, used by tests/test_gpu_bign.py
 // to check the GF(p) layer against Python big integers.  op: 0 mul, 1 sqr, 2 add, 3 sub,
 // 4 inv, 5 mul<3>, 6 sqr<8>, 7 canon, 8 dbl-point-x (a = X, b = Y, Z = 1 -> affine x of 2P)
+template <int N>
 __global__ void bign_debug_fe_kernel(int op, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t n)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    fe x, y, r;
-    for (int i = 0; i < 8; ++i) { x.v[i] = a[8 * idx + i]; y.v[i] = b[8 * idx + i]; }
+    feT<N> x, y, r;
+    for (int i = 0; i < N; ++i) { x.v[i] = a[N * idx + i]; y.v[i] = b[N * idx + i]; }
     switch (op) {
     case 0: fe_mul(r, x, y); break;
     case 1: fe_sqr(r, x); break;
@@ -434,103 +474,125 @@ __global__ void bign_debug_fe_kernel(int op, const uint32_t *a, const uint32_t *
     case 6: fe_sqr<8>(r, x); break;
     case 7: r = x; break;
     default: {
-        jac P; P.X = x; P.Y = y; fe_set_one(P.Z);
+        jacT<N> P; P.X = x; P.Y = y; fe_set_one(P.Z);
         jac_dbl(P);
-        fe zi = fe_inv(P.Z);
+        feT<N> zi = fe_inv(P.Z);
         fe_sqr(zi, zi);
         fe_mul(r, P.X, zi);
     } break;
     }
     fe_canon(r, r);
-    for (int i = 0; i < 8; ++i) out[8 * idx + i] = r.v[i];
+    for (int i = 0; i < N; ++i) out[N * idx + i] = r.v[i];
 }
 
 // ------------------------------------------------------------------ host side ---
 struct BignDevice {
-    uint4 *gtab = nullptr;            // 64 MiB 16-bit comb table (the 512 KiB 8-bit one is its seed)
+    uint4 *gtab[3] = {nullptr, nullptr, nullptr};      // comb table per curve (index N/4 - 2)
 };
 static BignDevice g_bign[64];
-static std::mutex g_bign_mu;          // table / scratch bookkeeping is per device, shared by threads
+static std::mutex g_bign_mu;          // table construction is per device, shared by threads
 
-static err_t bign_device(BignDevice **out, hipStream_t st)
+template <int N>
+static err_t bign_table(uint4 **out, hipStream_t st)
 {
     int dev = 0;
     B2H_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return ERR_BAD_INPUT;
-    BignDevice &D = g_bign[dev];
-    if (!D.gtab) {
-        uint4 *t8 = nullptr, *t16 = nullptr;
-        if (hipMalloc((void **)&t8, (size_t)GT_WINDOWS * GT_ENTRIES * 64) != hipSuccess) return ERR_OUTOFMEMORY;
-        if (hipMalloc((void **)&t16, (size_t)GT16_WINDOWS * GT16_ENTRIES * 64) != hipSuccess) {
+    uint4 *&slot = g_bign[dev].gtab[N / 4 - 2];
+    if (!slot) {
+        const size_t pt = 8 * N;                                      // bytes per affine point
+        uint4 *t8 = nullptr;
+        if (hipMalloc((void **)&t8, (size_t)4 * N * GT8_ENTRIES * pt) != hipSuccess) return ERR_OUTOFMEMORY;
+        hipLaunchKernelGGL(bign_gtable_kernel<N>, dim3(4 * N * GT8_ENTRIES / 64), dim3(64), 0, st, t8);
+        if (Comb<N>::W == 16) {
+            uint4 *t16 = nullptr;
+            if (hipMalloc((void **)&t16, (size_t)2 * N * 65536 * pt) != hipSuccess) { (void)hipFree(t8); return ERR_OUTOFMEMORY; }
+            hipLaunchKernelGGL(bign_gtable16_kernel<N>, dim3(2 * N * 65536 / 256), dim3(256), 0, st,
+                               (const uint4 *)t8, t16);
+            B2H_TRY(hipGetLastError());
+            B2H_TRY(hipStreamSynchronize(st));
             (void)hipFree(t8);
-            return ERR_OUTOFMEMORY;
+            slot = t16;
+        } else {
+            B2H_TRY(hipGetLastError());
+            B2H_TRY(hipStreamSynchronize(st));
+            slot = t8;
         }
-        hipLaunchKernelGGL(bign_gtable_kernel, dim3(GT_WINDOWS * GT_ENTRIES / 64), dim3(64), 0, st, t8);
-        hipLaunchKernelGGL(bign_gtable16_kernel, dim3(GT16_WINDOWS * GT16_ENTRIES / 256), dim3(256), 0, st,
-                           (const uint4 *)t8, t16);
-        B2H_TRY(hipGetLastError());
-        B2H_TRY(hipStreamSynchronize(st));
-        (void)hipFree(t8);
-        D.gtab = t16;
     }
-    *out = &D;
+    *out = slot;
     return ERR_OK;
 }
 
+template <int N>
 static err_t bign_scratch(hipStream_t st, size_t n, VerifyScratch &S)
 {
     const size_t n_pad = (n + 63) & ~(size_t)63;
-    const size_t words = n_pad * (1 + 8 + 5 + 8 * 24 + 8);
+    const size_t words = n_pad * (1 + N + (N / 2 + 1) + 8 * 3 * N + N);
     void *base = nullptr;
-    err_t code = scratch_for_stream(st, 0, words * 4, &base);
+    err_t code = scratch_for_stream(st, N / 4 - 2 + 4, words * 4, &base);
     if (code != ERR_OK) return code;
     uint32_t *p = (uint32_t *)base;
     S.n_pad = n_pad;
     S.status = p; p += n_pad;
-    S.u = p; p += 8 * n_pad;
-    S.w = p; p += 5 * n_pad;
-    S.qtab = p; p += 8 * 24 * n_pad;
+    S.u = p; p += (size_t)N * n_pad;
+    S.w = p; p += (size_t)(N / 2 + 1) * n_pad;
+    S.qtab = p; p += (size_t)8 * 3 * N * n_pad;
     S.rx = p;
     return ERR_OK;
 }
 
-err_t launch_bign_verify(const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
-                         const void *d_sigs, const void *d_pubkeys, size_t n, void *d_codes,
-                         hipStream_t st)
+template <int N>
+static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
+                                  const void *d_sigs, const void *d_pubkeys, size_t n, void *d_codes,
+                                  hipStream_t st)
 {
-    if (n == 0) return ERR_OK;
-    if (oid_len > OID_MAX) return ERR_NOT_IMPLEMENTED;
-    BignDevice *D = nullptr;
+    uint4 *gtab = nullptr;
     err_t code;
     {
         std::lock_guard<std::mutex> lk(g_bign_mu);     // table construction happens once per device
-        code = bign_device(&D, st);
+        code = bign_table<N>(&gtab, st);
     }
     if (code != ERR_OK) return code;
     VerifyScratch S;
-    code = bign_scratch(st, n, S);
+    code = bign_scratch<N>(st, n, S);
     if (code != ERR_OK) return code;
     OidArg oid;
     memset(&oid, 0, sizeof oid);
     oid.len = (uint32_t)oid_len;
     memcpy(oid.der, oid_der, oid_len);
     const unsigned g256 = (unsigned)((n + 255) / 256), g64 = (unsigned)((n + 63) / 64);
-    hipLaunchKernelGGL(bign_prep_kernel, dim3(g256), dim3(256), 0, st, (const uint8_t *)d_hashes,
+    hipLaunchKernelGGL(bign_prep_kernel<N>, dim3(g256), dim3(256), 0, st, (const uint8_t *)d_hashes,
                        (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S);
-    hipLaunchKernelGGL(bign_main_kernel, dim3(g256), dim3(256), 0, st, n, S, (const uint4 *)D->gtab);
-    hipLaunchKernelGGL(bign_slow_kernel, dim3(g64), dim3(64), 0, st, (const uint8_t *)d_sigs,
+    hipLaunchKernelGGL(bign_main_kernel<N>, dim3(g256), dim3(256), 0, st, n, S, (const uint4 *)gtab);
+    hipLaunchKernelGGL(bign_slow_kernel<N>, dim3(g64), dim3(64), 0, st, (const uint8_t *)d_sigs,
                        (const uint8_t *)d_pubkeys, n, S);
-    hipLaunchKernelGGL(bign_tail_kernel, dim3(g64), dim3(64), 0, st, (const uint8_t *)d_hashes,
+    hipLaunchKernelGGL(bign_tail_kernel<N>, dim3(g64), dim3(64), 0, st, (const uint8_t *)d_hashes,
                        (const uint8_t *)d_sigs, n, S, oid, (uint32_t *)d_codes);
     B2H_TRY(hipGetLastError());
     return ERR_OK;
 }
 
-err_t launch_bign_debug_fe(int op, const void *a, const void *b, void *out, size_t n, hipStream_t st)
+// l = security level (128, 192, 256): hashes n*(l/4), sigs n*(3l/8), pubkeys n*(l/2) octets
+err_t launch_bign_verify(size_t l, const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
+                         const void *d_sigs, const void *d_pubkeys, size_t n, void *d_codes,
+                         hipStream_t st)
 {
     if (n == 0) return ERR_OK;
-    hipLaunchKernelGGL(bign_debug_fe_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, op,
-                       (const uint32_t *)a, (const uint32_t *)b, (uint32_t *)out, n);
+    if (oid_len > OID_MAX) return ERR_NOT_IMPLEMENTED;
+    if (l == 128) return launch_bign_verify_t<8>(oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, st);
+    if (l == 192) return launch_bign_verify_t<12>(oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, st);
+    if (l == 256) return launch_bign_verify_t<16>(oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, st);
+    return ERR_BAD_PARAMS;
+}
+
+err_t launch_bign_debug_fe(size_t l, int op, const void *a, const void *b, void *out, size_t n, hipStream_t st)
+{
+    if (n == 0) return ERR_OK;
+    const dim3 g((unsigned)((n + 63) / 64)), t(64);
+    if (l == 128) hipLaunchKernelGGL(bign_debug_fe_kernel<8>, g, t, 0, st, op, (const uint32_t *)a, (const uint32_t *)b, (uint32_t *)out, n);
+    else if (l == 192) hipLaunchKernelGGL(bign_debug_fe_kernel<12>, g, t, 0, st, op, (const uint32_t *)a, (const uint32_t *)b, (uint32_t *)out, n);
+    else if (l == 256) hipLaunchKernelGGL(bign_debug_fe_kernel<16>, g, t, 0, st, op, (const uint32_t *)a, (const uint32_t *)b, (uint32_t *)out, n);
+    else return ERR_BAD_PARAMS;
     B2H_TRY(hipGetLastError());
     return ERR_OK;
 }

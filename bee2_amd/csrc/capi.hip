@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "common.hpp"
+#include "bign_curves.inc"   // (#pragma once: shared with bign_kernels.hip in the unity build)
 
 namespace bee2hip {
 
@@ -330,41 +331,38 @@ extern "C" err_t beltCTR(void *dest, const void *src, size_t count, const octet 
 }
 
 // ==================================================================== bign ===
-// STB 34.101.45 annex B.1 = "1.2.112.0.2.0.34.101.45.3.1" (bign_params.c:33-73)
-static const octet k_curve256v1_p[32] = {
-    0x43, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF,
-    0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
-static const octet k_curve256v1_a[32] = {
-    0x40, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF,
-    0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
-static const octet k_curve256v1_b[32] = {
-    0xF1, 0x03, 0x9C, 0xD6, 0x6B, 0x7D, 0x2E, 0xB2, 0x53, 0x92, 0x8B, 0x97, 0x69, 0x50, 0xF5, 0x4C,
-    0xBE, 0xFB, 0xD8, 0xE4, 0xAB, 0x3A, 0xC1, 0xD2, 0xED, 0xA8, 0xF3, 0x15, 0x15, 0x6C, 0xCE, 0x77};
-static const octet k_curve256v1_seed[8] = {0x5E, 0x38, 0x01, 0x00, 0x00, 0x00, 0x00, 0x00};
-static const octet k_curve256v1_q[32] = {
-    0x07, 0x66, 0x3D, 0x26, 0x99, 0xBF, 0x5A, 0x7E, 0xFC, 0x4D, 0xFB, 0x0D, 0xD6, 0x8E, 0x5C, 0xD9,
-    0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
-static const octet k_curve256v1_yG[32] = {
-    0x93, 0x6A, 0x51, 0x04, 0x18, 0xCF, 0x29, 0x1E, 0x52, 0xF6, 0x08, 0xC4, 0x66, 0x39, 0x91, 0x78,
-    0x5D, 0x83, 0xD6, 0x51, 0xA3, 0xC9, 0xE4, 0x5C, 0x9F, 0xD6, 0x16, 0xFB, 0x3C, 0xFC, 0xF7, 0x6B};
-// DER(1.2.112.0.2.0.34.101.31.81): belt-hash (bign128.c:151-153)
+// STB 34.101.45 annex B parameter sets: k_bign{128,192,256}_{p,a,b,q,yG,seed} come from
+// bign_curves.inc (generated from the reference's bignParamsStd, bign_params.c:34-230)
+// DER of the pre-hash OIDs the level-fixed facades use (bign128.c:151-153, bign192.c:151-153,
+// bign256.c:151-153): belt-hash, bash384, bash512
 static const octet k_oid_belt_hash[11] = {0x06, 0x09, 0x2A, 0x70, 0x00, 0x02, 0x00, 0x22, 0x65, 0x1F, 0x51};
+static const octet k_oid_bash384[11] = {0x06, 0x09, 0x2A, 0x70, 0x00, 0x02, 0x00, 0x22, 0x65, 0x4D, 0x0C};
+static const octet k_oid_bash512[11] = {0x06, 0x09, 0x2A, 0x70, 0x00, 0x02, 0x00, 0x22, 0x65, 0x4D, 0x0D};
+
+struct StdCurve { size_t l; const char *name; const octet *p, *a, *b, *q, *yG, *seed; };
+static const StdCurve k_curves[3] = {
+    {128, "1.2.112.0.2.0.34.101.45.3.1", k_bign128_p, k_bign128_a, k_bign128_b, k_bign128_q, k_bign128_yG, k_bign128_seed},
+    {192, "1.2.112.0.2.0.34.101.45.3.2", k_bign192_p, k_bign192_a, k_bign192_b, k_bign192_q, k_bign192_yG, k_bign192_seed},
+    {256, "1.2.112.0.2.0.34.101.45.3.3", k_bign256_p, k_bign256_a, k_bign256_b, k_bign256_q, k_bign256_yG, k_bign256_seed},
+};
 
 extern "C" err_t bignParamsStd(bign_params *params, const char *name)
 {
     if (!params || !name) return ERR_BAD_INPUT;
     memset(params, 0, sizeof *params);
-    if (strcmp(name, "1.2.112.0.2.0.34.101.45.3.1") == 0) {
-        params->l = 128;
-        memcpy(params->p, k_curve256v1_p, 32);
-        memcpy(params->a, k_curve256v1_a, 32);
-        memcpy(params->seed, k_curve256v1_seed, 8);
-        memcpy(params->b, k_curve256v1_b, 32);
-        memcpy(params->q, k_curve256v1_q, 32);
-        memcpy(params->yG, k_curve256v1_yG, 32);
-        return ERR_OK;
+    for (const StdCurve &c : k_curves) {
+        if (strcmp(name, c.name) == 0) {
+            const size_t no = c.l / 4;
+            params->l = c.l;
+            memcpy(params->p, c.p, no);
+            memcpy(params->a, c.a, no);
+            memcpy(params->seed, c.seed, 8);
+            memcpy(params->b, c.b, no);
+            memcpy(params->q, c.q, no);
+            memcpy(params->yG, c.yG, no);
+            return ERR_OK;
+        }
     }
-    // bign-curve384v1 / 512v1 (l = 192 / 256) are SURVEY.md 8f "next"
     return ERR_FILE_NOT_FOUND;
 }
 
@@ -375,8 +373,8 @@ static bool all_zero(const octet *p, size_t n)
     return acc == 0;
 }
 
-// bignParamsCheck (bign_params.c:244-280), then: only the standard 256-bit curve has
-// device constants; other valid-looking parameter sets report ERR_NOT_IMPLEMENTED.
+// bignParamsCheck (bign_params.c:244-280), then: only the three standard curves have device
+// constants; other valid-looking parameter sets report ERR_NOT_IMPLEMENTED.
 static err_t params_check(const bign_params *params)
 {
     if (!params) return ERR_BAD_INPUT;
@@ -391,11 +389,14 @@ static err_t params_check(const bign_params *params)
     if (!ok) return ERR_BAD_PARAMS;
     if (params->l % 64) return ERR_NOT_IMPLEMENTED;
     if (params->l != 128 && params->l != 192 && params->l != 256) return ERR_BAD_PARAMS;
-    if (params->l != 128 || memcmp(params->p, k_curve256v1_p, 32) || memcmp(params->a, k_curve256v1_a, 32) ||
-        memcmp(params->b, k_curve256v1_b, 32) || memcmp(params->q, k_curve256v1_q, 32) ||
-        memcmp(params->yG, k_curve256v1_yG, 32))
-        return ERR_NOT_IMPLEMENTED;
-    return ERR_OK;
+    for (const StdCurve &c : k_curves) {
+        if (c.l != params->l) continue;
+        if (memcmp(params->p, c.p, no) || memcmp(params->a, c.a, no) || memcmp(params->b, c.b, no) ||
+            memcmp(params->q, c.q, no) || memcmp(params->yG, c.yG, no))
+            return ERR_NOT_IMPLEMENTED;
+        return ERR_OK;
+    }
+    return ERR_NOT_IMPLEMENTED;
 }
 
 // oidFromDER(0, der, count) != SIZE_MAX  (src/core/oid.c:94-101, src/core/der.c:114-258,921-975):
@@ -427,24 +428,33 @@ static bool oid_der_valid(const octet *der, size_t count)
     return true;
 }
 
+extern "C" err_t bee2hip_bignVerifyL_batch_dev(size_t l, const octet oid_der[], size_t oid_len,
+                                               const void *d_hashes, const void *d_sigs,
+                                               const void *d_pubkeys, size_t n, void *d_codes,
+                                               void *stream)
+{
+    if (l != 128 && l != 192 && l != 256) return ERR_BAD_PARAMS;
+    if (n && (!d_hashes || !d_sigs || !d_pubkeys || !d_codes)) return ERR_BAD_INPUT;
+    if (!oid_der_valid(oid_der, oid_len)) return ERR_BAD_OID;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    return launch_bign_verify(l, oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, as_stream(stream));
+}
+
 extern "C" err_t bee2hip_bignVerify_batch_dev(const octet oid_der[], size_t oid_len,
                                               const void *d_hashes, const void *d_sigs,
                                               const void *d_pubkeys, size_t n, void *d_codes,
                                               void *stream)
 {
-    if (n && (!d_hashes || !d_sigs || !d_pubkeys || !d_codes)) return ERR_BAD_INPUT;
-    if (!oid_der_valid(oid_der, oid_len)) return ERR_BAD_OID;
-    err_t code = ensure_device();
-    if (code != ERR_OK) return code;
-    return launch_bign_verify(oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, as_stream(stream));
+    return bee2hip_bignVerifyL_batch_dev(128, oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, stream);
 }
 
 extern "C" err_t bee2hip_bign128Verify_batch_dev(const void *d_hashes, const void *d_sigs,
                                                  const void *d_pubkeys, size_t n, void *d_codes,
                                                  void *stream)
 {
-    return bee2hip_bignVerify_batch_dev(k_oid_belt_hash, sizeof k_oid_belt_hash, d_hashes, d_sigs,
-                                        d_pubkeys, n, d_codes, stream);
+    return bee2hip_bignVerifyL_batch_dev(128, k_oid_belt_hash, sizeof k_oid_belt_hash, d_hashes, d_sigs,
+                                         d_pubkeys, n, d_codes, stream);
 }
 
 extern "C" err_t bee2hip_bignVerify_batch(const bign_params *params, const octet oid_der[], size_t oid_len,
@@ -459,18 +469,19 @@ extern "C" err_t bee2hip_bignVerify_batch(const bign_params *params, const octet
     if (n == 0) return ERR_OK;
     code = ensure_device();
     if (code != ERR_OK) return code;
+    const size_t no = params->l / 4;                 // octets per field element
+    const size_t hb = no * n, sb = (no + no / 2) * n, pb = 2 * no * n;
+    const size_t so = (hb + 15) & ~(size_t)15, po = (so + sb + 15) & ~(size_t)15, co = (po + pb + 15) & ~(size_t)15;
     Scratch &s = t_scr[3];
-    const size_t in_bytes = n * 144, total = in_bytes + n * 4;
-    code = s.need(total);
+    code = s.need(co + n * 4);
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
-    octet *dh = d, *ds = d + 32 * n, *dp = d + 80 * n, *dc = d + 144 * n;
-    B2H_TRY(hipMemcpy(dh, hashes, 32 * n, hipMemcpyHostToDevice));
-    B2H_TRY(hipMemcpy(ds, sigs, 48 * n, hipMemcpyHostToDevice));
-    B2H_TRY(hipMemcpy(dp, pubkeys, 64 * n, hipMemcpyHostToDevice));
-    code = launch_bign_verify(oid_der, oid_len, dh, ds, dp, n, dc, nullptr);
+    B2H_TRY(hipMemcpy(d, hashes, hb, hipMemcpyHostToDevice));
+    B2H_TRY(hipMemcpy(d + so, sigs, sb, hipMemcpyHostToDevice));
+    B2H_TRY(hipMemcpy(d + po, pubkeys, pb, hipMemcpyHostToDevice));
+    code = launch_bign_verify(params->l, oid_der, oid_len, d, d + so, d + po, n, d + co, nullptr);
     if (code != ERR_OK) return code;
-    B2H_TRY(hipMemcpy(codes, dc, 4 * n, hipMemcpyDeviceToHost));
+    B2H_TRY(hipMemcpy(codes, d + co, 4 * n, hipMemcpyDeviceToHost));
     return ERR_OK;
 }
 
@@ -486,16 +497,33 @@ extern "C" err_t bignVerify(const bign_params *params, const octet oid_der[], si
     return code != ERR_OK ? code : one;
 }
 
-extern "C" err_t bign128Verify(const octet hash[32], const octet sig[48], const octet pubkey[64])
+static err_t level_verify(int which, const octet *oid, const octet *hash, const octet *sig, const octet *pubkey)
 {
     bign_params params;
-    bignParamsStd(&params, "1.2.112.0.2.0.34.101.45.3.1");
-    return bignVerify(&params, k_oid_belt_hash, sizeof k_oid_belt_hash, hash, sig, pubkey);
+    bignParamsStd(&params, k_curves[which].name);
+    return bignVerify(&params, oid, 11, hash, sig, pubkey);
+}
+extern "C" err_t bign128Verify(const octet hash[32], const octet sig[48], const octet pubkey[64])
+{
+    return level_verify(0, k_oid_belt_hash, hash, sig, pubkey);
+}
+extern "C" err_t bign192Verify(const octet hash[48], const octet sig[72], const octet pubkey[96])
+{
+    return level_verify(1, k_oid_bash384, hash, sig, pubkey);
+}
+extern "C" err_t bign256Verify(const octet hash[64], const octet sig[96], const octet pubkey[128])
+{
+    return level_verify(2, k_oid_bash512, hash, sig, pubkey);
 }
 
 extern "C" err_t bee2hip_debug_fe(int op, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream)
 {
-    return launch_bign_debug_fe(op, d_a, d_b, d_out, n, as_stream(stream));
+    return launch_bign_debug_fe(128, op, d_a, d_b, d_out, n, as_stream(stream));
+}
+extern "C" err_t bee2hip_debug_feL(size_t l, int op, const void *d_a, const void *d_b, void *d_out, size_t n,
+                                   void *stream)
+{
+    return launch_bign_debug_fe(l, op, d_a, d_b, d_out, n, as_stream(stream));
 }
 
 // ============================================================= bash hashing ===
@@ -704,7 +732,7 @@ extern "C" err_t bee2hip_time_kernel(int which, int reps, void *d_a, void *d_b, 
         switch (which) {
         case 0: code = launch_bashF_batch(d_a, n, st); break;
         case 1: code = launch_belt_ctr_blocks(d_a, n, kw, c0, 0, nullptr, st); break;
-        case 2: code = launch_bign_verify(k_oid_belt_hash, sizeof k_oid_belt_hash, d_a, d_b, d_c, n, d_d, st); break;
+        case 2: code = launch_bign_verify(128, k_oid_belt_hash, sizeof k_oid_belt_hash, d_a, d_b, d_c, n, d_d, st); break;
         case 3: code = launch_bashHash_beltMAC(d_a, aux, n, 256, kw, d_b != nullptr, d_c != nullptr, d_b, d_c, st); break;
         default: code = ERR_BAD_INPUT;
         }

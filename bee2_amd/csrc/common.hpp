@@ -39,7 +39,7 @@ err_t launch_belt_decr_blocks(void *d_blocks, size_t nblocks, const uint32_t key
 err_t launch_belt_modes(int mode, const void *d_src, void *d_dst, size_t nblocks, const uint32_t key[8],
                         const uint32_t iv[4], hipStream_t st);
 err_t launch_belt_cbc_encr(void *d_msgs, size_t nblk, size_t n, const uint32_t key[8], void *d_ivs, hipStream_t st);
-err_t launch_bign_verify(const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
+err_t launch_bign_verify(size_t l, const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
                          const void *d_sigs, const void *d_pubkeys, size_t n, void *d_codes,
                          hipStream_t st);
 
@@ -47,6 +47,6 @@ err_t launch_bash_sponge(void *d_states, const void *d_data, size_t stride, size
                          int fin, hipStream_t st);
 err_t launch_belt_mac(void *d_states, const void *d_data, size_t stride, size_t count, size_t n,
                       int mode, hipStream_t st);
-err_t launch_bign_debug_fe(int op, const void *a, const void *b, void *out, size_t n, hipStream_t st);
+err_t launch_bign_debug_fe(size_t l, int op, const void *a, const void *b, void *out, size_t n, hipStream_t st);
 
 }  // namespace bee2hip

@@ -20,6 +20,11 @@ ERR_BAD_SIG = 510
 ERR_BEE2HIP_DEVICE = 0x4850
 
 OID_BELT_HASH_DER = bytes.fromhex("06092A7000020022651F51")   # bign128.c:151-153
+OID_BASH384_DER = bytes.fromhex("06092A7000020022654D0C")     # bign192.c:151-153
+OID_BASH512_DER = bytes.fromhex("06092A7000020022654D0D")     # bign256.c:151-153
+LEVEL_OID = {128: OID_BELT_HASH_DER, 192: OID_BASH384_DER, 256: OID_BASH512_DER}
+CURVE_NAME = {128: "1.2.112.0.2.0.34.101.45.3.1", 192: "1.2.112.0.2.0.34.101.45.3.2",
+              256: "1.2.112.0.2.0.34.101.45.3.3"}
 
 _sz = ctypes.c_size_t
 _vp = ctypes.c_void_p
@@ -51,14 +56,14 @@ DROPIN_SYMBOLS = [
     "beltCBC_keep", "beltCBCStart", "beltCBCStepE", "beltCBCStepD", "beltCBCEncr", "beltCBCDecr",
     "beltMAC_keep", "beltMACStart", "beltMACStepA", "beltMACStepG", "beltMACStepG2",
     "beltMACStepV", "beltMACStepV2", "beltMAC",
-    "bignParamsStd", "bignVerify", "bign128Verify",
+    "bignParamsStd", "bignVerify", "bign128Verify", "bign192Verify", "bign256Verify",
 ]
 BATCH_SYMBOLS = [
     "bee2hip_bashF_batch", "bee2hip_beltCTR_bulk", "bee2hip_bignVerify_batch",
     "bee2hip_bashHash_beltMAC_batch",
     "bee2hip_bashF_batch_dev", "bee2hip_beltCTR_blocks_dev", "bee2hip_beltBlockEncr_dev",
     "bee2hip_beltModes_blocks_dev", "bee2hip_beltCBCEncr_batch_dev",
-    "bee2hip_bign128Verify_batch_dev", "bee2hip_bignVerify_batch_dev",
+    "bee2hip_bign128Verify_batch_dev", "bee2hip_bignVerify_batch_dev", "bee2hip_bignVerifyL_batch_dev",
     "bee2hip_bashHash_beltMAC_batch_dev",
     "bee2hip_set_device", "bee2hip_sync", "bee2hip_last_error", "bee2hip_version",
     "bee2hip_time_kernel",
@@ -163,6 +168,13 @@ class Engine:
             self._ptr(hashes), self._ptr(sigs), self._ptr(pubkeys), _sz(n), self._ptr(codes),
             self._stream()), "bign128Verify_batch_dev")
 
+    def bignVerifyL_batch_dev(self, l, oid_der, hashes, sigs, pubkeys, codes):
+        n = hashes.numel() // (l // 4)
+        assert sigs.numel() == (3 * l // 8) * n and pubkeys.numel() == (l // 2) * n and codes.numel() >= n
+        self._check(self.lib.bee2hip_bignVerifyL_batch_dev(
+            _sz(l), bytes(oid_der), _sz(len(oid_der)), self._ptr(hashes), self._ptr(sigs), self._ptr(pubkeys),
+            _sz(n), self._ptr(codes), self._stream()), "bignVerifyL_batch_dev")
+
     def bashHash_beltMAC_batch_dev(self, msgs, msg_len, l, key, digests, tags, n=None):
         if n is None:
             n = msgs.numel() // msg_len if msg_len else 0
@@ -187,10 +199,10 @@ class Engine:
         return buf.raw
 
     def bignVerify_batch(self, hashes, sigs, pubkeys, oid_der=OID_BELT_HASH_DER, params=None):
-        n = len(hashes) // 32
-        codes = (_u32 * max(n, 1))()
         if params is None:
             params = self.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
+        n = len(hashes) // (params.l // 4)
+        codes = (_u32 * max(n, 1))()
         code = self.lib.bee2hip_bignVerify_batch(ctypes.byref(params), bytes(oid_der),
                                                  _sz(len(oid_der)), bytes(hashes), bytes(sigs),
                                                  bytes(pubkeys), _sz(n), codes)
@@ -327,6 +339,10 @@ class Engine:
 
     def bign128Verify(self, hash_, sig, pubkey):
         return self.lib.bign128Verify(bytes(hash_), bytes(sig), bytes(pubkey))
+
+    def bignLVerify(self, l, hash_, sig, pubkey):
+        """bign128Verify / bign192Verify / bign256Verify"""
+        return getattr(self.lib, f"bign{l}Verify")(bytes(hash_), bytes(sig), bytes(pubkey))
 
 
 _engine = None

@@ -348,6 +348,44 @@ def main():
             others["bignVerify"]["cpu_baseline"] = cpu_baseline("verify", cores)
         del dh, ds, dk, codes
 
+    # ------------------------------------------------- 8f-4: the 384- and 512-bit curves
+    if "verify" in only and "bign_big" in G.__dict__:
+        from bee2_amd.engine import LEVEL_OID
+        for l in (192, 256):
+            base = G.bign_big[str(l)]["base"]
+            reps_l = (1 << 16) // len(base)
+            hs_l = b"".join(bytes.fromhex(t["hash"]) for t in base) * reps_l
+            ss_l = b"".join(bytes.fromhex(t["sig"]) for t in base) * reps_l
+            ps_l = b"".join(bytes.fromhex(t["pubkey"]) for t in base) * reps_l
+            nl = len(base) * reps_l
+            th, ts, tp = (torch.from_numpy(np.frombuffer(x, dtype=np.uint8).copy()).cuda() for x in (hs_l, ss_l, ps_l))
+            tc = torch.empty(nl, dtype=torch.int32, device="cuda")
+            kl = max(2, min(K, 5))
+            el = timed(dist, kl, 1, lambda: eng.bignVerifyL_batch_dev(l, LEVEL_OID[l], th, ts, tp, tc))
+            others[f"bignVerify_l{l}"] = {
+                "metric": f"bign-curve{2 * l}v1 verifies/s", "value": N * nl * kl / el, "unit": "verifies/s",
+                "steps": kl, "ms_per_step": el / kl * 1e3, "all_valid": bool((tc == 0).all()),
+                "config": {"workload": f"{nl} signatures per GPU on the {2 * l}-bit curve (SURVEY 8f-4), "
+                                       f"{len(base)} genuine triples tiled"}}
+            if do_cpu:
+                import refgen
+                if refgen.have_ref():
+                    import orclib
+                    ref = ctypes.CDLL(refgen.REF_SO)
+                    f = getattr(ref, f"bign{l}Verify")
+                    f.restype = ctypes.c_uint32
+                    no = l // 4
+                    t0, cnt = time.perf_counter(), 0
+                    while time.perf_counter() - t0 < 1.5:
+                        i = cnt % len(base)
+                        f(hs_l[no * i: no * i + no], ss_l[(no + no // 2) * i: (no + no // 2) * (i + 1)],
+                          ps_l[2 * no * i: 2 * no * (i + 1)])
+                        cnt += 1
+                    others[f"bignVerify_l{l}"]["cpu_baseline"] = {
+                        "value": cnt / (time.perf_counter() - t0), "unit": "verifies/s", "cores": 1,
+                        "kind": "reference", "sample": "1.5 s of bign%dVerify calls, one thread" % l}
+            del th, ts, tp, tc
+
     # -------------------------------------------------------------------------- mixed
     if "mixed" in only:
         n, ml = 1 << 21, 4096                                      # 2^24 / 8 messages per GPU

@@ -135,13 +135,17 @@ typedef struct {
     octet yG[64];
     octet seed[8];
 } bign_params;
-/* bign.h:100-107, src/crypto/bign/bign_params.c:180-230 (only "1.2.112.0.2.0.34.101.45.3.1") */
+/* bign.h:100-107, src/crypto/bign/bign_params.c:180-230: "1.2.112.0.2.0.34.101.45.3.{1,2,3}" */
 err_t bignParamsStd(bign_params *params, const char *name);
 /* bign.h:395-402, src/crypto/bign/bign_sign.c:349-361 */
 err_t bignVerify(const bign_params *params, const octet oid_der[], size_t oid_len,
                  const octet hash[], const octet sig[], const octet pubkey[]);
 /* include/bee2/crypto/bign128.h:174-178, src/crypto/bign/bign128.c:177-185 */
 err_t bign128Verify(const octet hash[32], const octet sig[48], const octet pubkey[64]);
+/* the 384- and 512-bit curves (l = 192 / 256).
+   include/bee2/crypto/bign192.h, bign256.h; src/crypto/bign/bign192.c:177-185, bign256.c:177-185 */
+err_t bign192Verify(const octet hash[48], const octet sig[72], const octet pubkey[96]);
+err_t bign256Verify(const octet hash[64], const octet sig[96], const octet pubkey[128]);
 
 /* ======================================================================== *
  * (2) host-pointer batch API (new; SURVEY.md 8b "batch extension")
@@ -188,6 +192,10 @@ err_t bee2hip_bignVerify_batch_dev(const octet oid_der[], size_t oid_len,
                                    const void *d_hashes, const void *d_sigs,
                                    const void *d_pubkeys, size_t n, void *d_codes,
                                    void *stream);
+/* same for security level l in {128, 192, 256}: hashes n*(l/4), sigs n*(3l/8), pubkeys n*(l/2) */
+err_t bee2hip_bignVerifyL_batch_dev(size_t l, const octet oid_der[], size_t oid_len,
+                                    const void *d_hashes, const void *d_sigs,
+                                    const void *d_pubkeys, size_t n, void *d_codes, void *stream);
 err_t bee2hip_bashHash_beltMAC_batch_dev(const void *d_msgs, size_t msg_len, size_t n, size_t l,
                                          const octet key[], size_t key_len,
                                          void *d_digests, void *d_tags, void *stream);
@@ -210,6 +218,9 @@ err_t bee2hip_time_kernel(int which, int reps, void *d_a, void *d_b, void *d_c, 
 /* self-test hook: element-wise GF(2^256-189) ops on device arrays of 8 x u32 limbs
    (op: 0 mul, 1 sqr, 2 add, 3 sub, 4 inv, 5 3*mul, 6 8*sqr, 7 canon, 8 x(2P)) */
 err_t bee2hip_debug_fe(int op, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
+/* same over GF(2^(2l) - c) for l in {128, 192, 256} (8 / 12 / 16 limbs per element) */
+err_t bee2hip_debug_feL(size_t l, int op, const void *d_a, const void *d_b, void *d_out, size_t n,
+                        void *stream);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

@@ -108,6 +108,15 @@ uint32_t orc_bign128Verify_ex(const uint8_t hash[32], const uint8_t sig[48],
 void orc_bign128Verify_batch(const uint8_t *hashes, const uint8_t *sigs,
                              const uint8_t *pubkeys, size_t n, uint32_t *codes,
                              int nthreads);
+/* any of the three standard curves.  l in {128,192,256}; hash l/4, sig 3l/8,
+   pubkey l/2 octets.  bignVerify: src/crypto/bign/bign_sign.c:349-361 */
+uint32_t orc_bignVerify_ex(size_t l, const uint8_t *oid_der, size_t oid_len, const uint8_t *hash,
+                           const uint8_t *sig, const uint8_t *pubkey, uint8_t *rx);
+uint32_t orc_bign192Verify(const uint8_t hash[48], const uint8_t sig[72], const uint8_t pubkey[96]);
+uint32_t orc_bign256Verify(const uint8_t hash[64], const uint8_t sig[96], const uint8_t pubkey[128]);
+void orc_bignVerify_batch(size_t l, const uint8_t *oid_der, size_t oid_len, const uint8_t *hashes,
+                          const uint8_t *sigs, const uint8_t *pubkeys, size_t n, uint32_t *codes,
+                          int nthreads);
 
 /* ---- mixed bash512 + beltMAC per message (H4) ---------------------------- */
 void orc_bash512_beltMAC_batch(const uint8_t *msgs, size_t msg_len, size_t n,

@@ -144,6 +144,17 @@ class Oracle:
         code = self.lib.orc_bign128Verify_ex(bytes(h), bytes(s), bytes(p), rx)
         return code, rx.raw
 
+    def verify_l(self, l, oid, h, s, p):
+        self.lib.orc_bignVerify_ex.restype = ctypes.c_uint32
+        return self.lib.orc_bignVerify_ex(_sz(l), bytes(oid), _sz(len(oid)), bytes(h), bytes(s), bytes(p), None)
+
+    def verify_batch_l(self, l, oid, hashes, sigs, pubs, nthreads=1):
+        n = len(hashes) // (l // 4)
+        codes = (ctypes.c_uint32 * max(n, 1))()
+        self.lib.orc_bignVerify_batch(_sz(l), bytes(oid), _sz(len(oid)), bytes(hashes), bytes(sigs), bytes(pubs),
+                                      _sz(n), codes, ctypes.c_int(nthreads))
+        return list(codes)[:n]
+
     def verify_batch(self, hashes, sigs, pubs, nthreads=1):
         n = len(hashes) // 32
         codes = (ctypes.c_uint32 * n)()
@@ -200,6 +211,8 @@ class Golden:
         self.bign_base = [(raw[i:i + 32], raw[i + 32:i + 80], raw[i + 80:i + 144])
                           for i in range(0, len(raw), 144)]
         self.H = bytes.fromhex(self.kat["beltH"])
+        with open(os.path.join(GOLD, "bign_big_curves.json")) as f:
+            self.bign_big = json.load(f)
 
     def bign_base_arrays(self):
         hs = b"".join(t[0] for t in self.bign_base)

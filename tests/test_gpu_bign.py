@@ -188,3 +188,58 @@ def test_oid_der_validation_matches_reference(golden):
             assert got == 0
         else:
             assert got in (E.ERR_BAD_SIG, E.ERR_NOT_IMPLEMENTED), (c["der"], got)
+
+
+@pytest.mark.parametrize("l", [192, 256])
+def test_field_ops_big_curves(l):
+    """GF(2^384 - 317) and GF(2^512 - 569) against Python integers"""
+    eng = engine()
+    P = 2 ** (2 * l) - {192: 317, 256: 569}[l]
+    nb = l // 4
+    rnd = random.Random(l)
+    special = [0, 1, 2, P - 1, P, P + 1, 2 ** (2 * l) - 1, 2 ** (2 * l - 1), 2 ** l, 316, 317, 569, 570]
+    pool = special + [rnd.getrandbits(2 * l) for _ in range(100)]
+    A = special * len(special) + [rnd.choice(pool) for _ in range(1024)]
+    B = [b for b in special for _ in special] + [rnd.choice(pool) for _ in range(1024)]
+    ta = dev(b"".join(x.to_bytes(nb, "little") for x in A))
+    tb = dev(b"".join(x.to_bytes(nb, "little") for x in B))
+    out = torch.empty_like(ta)
+    ops = {0: lambda a, b: a * b % P, 1: lambda a, b: a * a % P, 2: lambda a, b: (a + b) % P,
+           3: lambda a, b: (a - b) % P, 4: lambda a, b: pow(a, P - 2, P), 5: lambda a, b: 3 * a * b % P,
+           6: lambda a, b: 8 * a * a % P, 7: lambda a, b: a % P}
+    for op, f in ops.items():
+        code = eng.lib.bee2hip_debug_feL(ctypes.c_size_t(l), op, ctypes.c_void_p(ta.data_ptr()),
+                                         ctypes.c_void_p(tb.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                         ctypes.c_size_t(len(A)), None)
+        assert code == 0
+        torch.cuda.synchronize()
+        raw = host(out)
+        got = [int.from_bytes(raw[i:i + nb], "little") for i in range(0, len(raw), nb)]
+        assert got == [f(a, b) for a, b in zip(A, B)], f"l={l} field op {op}"
+
+
+@pytest.mark.parametrize("l", [192, 256])
+def test_bign_big_curves_batch_and_dropin(orc, golden, l):
+    eng = engine()
+    d = golden.bign_big[str(l)]
+    oid = E.LEVEL_OID[l]
+    cases = [dict(t, code=0, name="base") for t in d["base"]] + d["edge"]
+    hs = b"".join(bytes.fromhex(c["hash"]) for c in cases)
+    ss = b"".join(bytes.fromhex(c["sig"]) for c in cases)
+    ps = b"".join(bytes.fromhex(c["pubkey"]) for c in cases)
+    codes = torch.full((len(cases),), -1, dtype=torch.int32, device="cuda")
+    eng.bignVerifyL_batch_dev(l, oid, dev(hs), dev(ss), dev(ps), codes)
+    torch.cuda.synchronize()
+    got = [int(c) & 0xFFFFFFFF for c in codes.cpu().numpy()]
+    bad = [(c["name"], g, c["code"]) for c, g in zip(cases, got) if g != c["code"]]
+    assert not bad, bad[:10]
+    assert {0, 505, 510} <= set(got)
+    # drop-in facades and the generic bignVerify with the level's parameters
+    params = eng.bignParamsStd(E.CURVE_NAME[l])
+    for c in cases[:3] + d["edge"][:6]:
+        h, s, p = (bytes.fromhex(c[x]) for x in ("hash", "sig", "pubkey"))
+        assert eng.bignLVerify(l, h, s, p) == c["code"]
+        assert eng.bignVerify(params, oid, h, s, p) == c["code"]
+    code, host_codes = eng.bignVerify_batch(hs, ss, ps, oid_der=oid, params=params)
+    assert code == 0 and host_codes == [c["code"] for c in cases]
+    assert got == orc.verify_batch_l(l, oid, hs, ss, ps, nthreads=8)

@@ -131,3 +131,15 @@ def test_belt_ecb_cbc_random_cases(orc, golden):
         assert orc.ecb(orc.ecb(msg, key)[1], key, True)[1] == msg            # D(E(x)) = x
         assert orc.cbc(orc.cbc(msg, key, iv)[1], key, iv, True)[1] == msg
     assert orc.ecb(b"x" * 15, b"k" * 32)[0] == 109                           # count < 16: ERR_BAD_INPUT
+
+
+def test_bign_big_curves_oracle_vs_golden(orc, golden):
+    """bign-curve384v1 / 512v1 (bign192Verify / bign256Verify)"""
+    from bee2_amd.engine import LEVEL_OID
+    for l in (192, 256):
+        d = golden.bign_big[str(l)]
+        for t in d["base"][:48]:
+            assert orc.verify_l(l, LEVEL_OID[l], *(bytes.fromhex(t[x]) for x in ("hash", "sig", "pubkey"))) == 0
+        for e in d["edge"]:
+            got = orc.verify_l(l, LEVEL_OID[l], *(bytes.fromhex(e[x]) for x in ("hash", "sig", "pubkey")))
+            assert got == e["code"], (l, e["name"])

@@ -87,3 +87,25 @@ def test_verify_random_and_corrupted(orc):
         assert orc.verify(h, s, p) == want, (i, kind)
         seen.add(want)
     assert seen >= {0, 510}
+
+
+def test_verify_big_curves_random_and_corrupted(orc):
+    from bee2_amd.engine import LEVEL_OID
+    rnd = random.Random(8)
+    for l in (192, 256):
+        seen = set()
+        for i, (h, s, p) in enumerate(refgen.make_triples_l(l, 200, 0x55 + l)):
+            h, s, p = bytearray(h), bytearray(s), bytearray(p)
+            kind = i % 5
+            if kind == 1:
+                s[rnd.randrange(len(s))] ^= 1 << rnd.randrange(8)
+            elif kind == 2:
+                h[rnd.randrange(len(h))] ^= 1 << rnd.randrange(8)
+            elif kind == 3:
+                p[rnd.randrange(len(p))] ^= 1 << rnd.randrange(8)
+            elif kind == 4:
+                p[l // 4 - 1] = 0xFF; p[l // 4 - 2] = 0xFF; p[1:l // 4 - 2] = b"\xff" * (l // 4 - 3)
+            want = refgen.verify_l(l, bytes(h), bytes(s), bytes(p))
+            assert orc.verify_l(l, LEVEL_OID[l], h, s, p) == want, (l, i, kind)
+            seen.add(want)
+        assert seen >= {0, 510}

@@ -373,6 +373,73 @@ def bign_sets(seed=0xB164, n_base=2048):
     return base, edge
 
 
+def bign_big_curves(seed=0xB192):
+    """the 384- and 512-bit curves.  Per level: genuine triples + edge cases
+    (small / extreme private keys, R = O, range checks, H >= q, bit flips) with the reference's code."""
+    import random
+    out = {}
+    orders = {192: int.from_bytes(bytes(refparams(192).q)[:48], "little"),
+              256: int.from_bytes(bytes(refparams(256).q)[:64], "little")}
+    primes = {192: 2 ** 384 - 317, 256: 2 ** 512 - 569}
+    for l in (192, 256):
+        rnd = random.Random(seed + l)
+        no = l // 4
+        q, p = orders[l], primes[l]
+        base = refgen.make_triples_l(l, 192, seed + l)
+        assert all(refgen.verify_l(l, *t) == 0 for t in base)
+        edge = []
+
+        def add(name, h, s, pk):
+            edge.append({"name": name, "hash": h.hex(), "sig": s.hex(), "pubkey": pk.hex(),
+                         "code": refgen.verify_l(l, h, s, pk)})
+
+        for d in (1, 2, 3, 7, 8, 16, q - 1, q - 2, (q + 1) // 2, 2 ** l, 2 ** (l + 1) - 1):
+            priv = int_le(d, no)
+            pub = refgen.pubkey_calc_l(l, priv)
+            h = rnd.randbytes(no)
+            sig = refgen.sign2_l(l, h, priv)
+            add(f"d={d if d < 2**64 else hex(d)[:14]}/valid", h, sig, pub)
+            bad = bytearray(sig)
+            bad[rnd.randrange(len(sig))] ^= 1 << rnd.randrange(8)
+            add(f"d={d if d < 2**64 else hex(d)[:14]}/flip", h, bytes(bad), pub)
+            s0 = rnd.getrandbits(l)
+            hh = int.from_bytes(h, "little")
+            if hh >= q:
+                hh -= q
+            s1 = (-(s0 + 2 ** l) * d - hh) % q
+            add(f"d={d if d < 2**64 else hex(d)[:14]}/R=O", h, int_le(s0, no // 2) + int_le(s1, no), pub)
+        t = base[0]
+        half = no // 2
+        add("s1=q", t[0], t[1][:half] + int_le(q, no), t[2])
+        add("s1=q-1", t[0], t[1][:half] + int_le(q - 1, no), t[2])
+        add("s1=max", t[0], t[1][:half] + b"\xff" * no, t[2])
+        add("sig=0", t[0], bytes(no + half), t[2])
+        add("xQ=p", t[0], t[1], int_le(p, no) + t[2][no:])
+        add("yQ=p", t[0], t[1], t[2][:no] + int_le(p, no))
+        add("xQ=p-1", t[0], t[1], int_le(p - 1, no) + t[2][no:])
+        add("Q=(0,0)", t[0], t[1], bytes(2 * no))
+        add("Q=(1,0)", t[0], t[1], int_le(1, no) + bytes(no))
+        for i in range(48):
+            h, s, pk = (bytearray(x) for x in base[i])
+            tgt = (s, s, h, pk)[i % 4]
+            tgt[rnd.randrange(len(tgt))] ^= 1 << rnd.randrange(8)
+            add(f"flip{i}", bytes(h), bytes(s), bytes(pk))
+        out[str(l)] = {"base": [{"hash": h.hex(), "sig": s.hex(), "pubkey": k.hex()} for h, s, k in base],
+                       "edge": edge}
+    return out
+
+
+def refparams(l):
+    class Params(ctypes.Structure):
+        _fields_ = [("l", _sz), ("p", ctypes.c_ubyte * 64), ("a", ctypes.c_ubyte * 64), ("b", ctypes.c_ubyte * 64),
+                    ("q", ctypes.c_ubyte * 64), ("yG", ctypes.c_ubyte * 64), ("seed", ctypes.c_ubyte * 8)]
+    p = Params()
+    name = {128: b"1.2.112.0.2.0.34.101.45.3.1", 192: b"1.2.112.0.2.0.34.101.45.3.2",
+            256: b"1.2.112.0.2.0.34.101.45.3.3"}[l]
+    assert L.bignParamsStd(ctypes.byref(p), name) == 0
+    return p
+
+
 def oid_cases(seed=0x01D):
     """DER strings with the verdict of the reference's oidFromDER (src/core/oid.c:94-101), which is
     what bignVerify applies to oid_der (bign_sign.c:289-290)."""
@@ -410,6 +477,12 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     with open(os.path.join(GOLD, "oid_der_cases.json"), "w") as f:
         json.dump(oid_cases(), f)
+    with open(os.path.join(GOLD, "bign_big_curves.json"), "w") as f:
+        big = bign_big_curves()
+        json.dump(big, f)
+        from collections import Counter
+        for l, d in big.items():
+            print(f"bign l={l}: {len(d['base'])} base, edge codes {dict(Counter(e['code'] for e in d['edge']))}")
     with open(os.path.join(GOLD, "stb_kat.json"), "w") as f:
         json.dump(stb_kats(), f, indent=1)
     inp, out = bashf_random()

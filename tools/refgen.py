@@ -47,6 +47,47 @@ class Combo:
         return buf.raw
 
 
+SIZES = {128: (32, 48, 64), 192: (48, 72, 96), 256: (64, 96, 128)}     # hash/priv, sig, pubkey octets
+
+
+def keypair_l(l, rng):
+    L = ref()
+    no, _, pk = SIZES[l]
+    priv = ctypes.create_string_buffer(no)
+    pub = ctypes.create_string_buffer(pk)
+    code = getattr(L, f"bign{l}KeypairGen")(priv, pub, L.prngCOMBOStepR, rng.state)
+    assert code == 0, code
+    return priv.raw, pub.raw
+
+
+def sign2_l(l, h, priv):
+    sig = ctypes.create_string_buffer(SIZES[l][1])
+    code = getattr(ref(), f"bign{l}Sign2")(sig, h, priv, None, _sz(0))
+    assert code == 0, code
+    return sig.raw
+
+
+def verify_l(l, h, sig, pub):
+    return getattr(ref(), f"bign{l}Verify")(h, sig, pub)
+
+
+def pubkey_calc_l(l, priv):
+    pub = ctypes.create_string_buffer(SIZES[l][2])
+    assert getattr(ref(), f"bign{l}PubkeyCalc")(pub, priv) == 0
+    return pub.raw
+
+
+def make_triples_l(l, n, seed, nkeys=16):
+    rng = Combo(seed)
+    keys = [keypair_l(l, rng) for _ in range(nkeys)]
+    out = []
+    for i in range(n):
+        priv, pub = keys[i % nkeys]
+        h = rng.bytes(SIZES[l][0])
+        out.append((h, sign2_l(l, h, priv), pub))
+    return out
+
+
 def keypair(rng):
     L = ref()
     priv = ctypes.create_string_buffer(32)
