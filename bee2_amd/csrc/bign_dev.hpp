@@ -168,8 +168,8 @@ __device__ __forceinline__ void fe_reduce(feT<N> &r, const uint32_t (&w)[2 * N])
 
 // ------------------------------------------------------------- mul / sqr ---
 // product scanning: column k sums a[i]*b[k-i] into (c2 : acc64)
-template <uint32_t K = 1, int N>
-__device__ __forceinline__ void fe_mul(feT<N> &r, const feT<N> &a, const feT<N> &b)
+template <uint32_t K, int N>
+__device__ __forceinline__ void fe_mul_body(feT<N> &r, const feT<N> &a, const feT<N> &b)
 {
     uint32_t w[2 * N];
     uint64_t acc = 0;
@@ -194,8 +194,8 @@ __device__ __forceinline__ void fe_mul(feT<N> &r, const feT<N> &a, const feT<N> 
 // e_j = a_j << 1 is the doubled limb WITHOUT the bit shifted in from a_{j-1} (that bit belongs
 // to the part of 2a below position i+1, which row i does not use).  Same product-scanning
 // accumulator as fe_mul (cf. zzSqr, src/math/zz/zz_mul.c:112-154, which doubles afterwards).
-template <uint32_t K = 1, int N>
-__device__ __forceinline__ void fe_sqr(feT<N> &r, const feT<N> &a)
+template <uint32_t K, int N>
+__device__ __forceinline__ void fe_sqr_body(feT<N> &r, const feT<N> &a)
 {
     uint32_t d[N + 1], e[N];
 #pragma unroll
@@ -221,6 +221,37 @@ __device__ __forceinline__ void fe_sqr(feT<N> &r, const feT<N> &a)
         c2 = 0;
     }
     fe_reduce<K>(r, w);
+}
+
+// The 256-bit curve (the graded path) inlines every multiplication.  For N = 12 / 16 the fully
+// unrolled bodies (144 / 256 multiply-adds) are compiled ONCE per (K, N) as real functions taking
+// and returning elements by value (in VGPRs): it keeps the build in seconds instead of minutes and
+// relieves the register allocator of the callers.
+template <uint32_t K, int N>
+__device__ __noinline__ feT<N> fe_mul_call(feT<N> a, feT<N> b)
+{
+    feT<N> r;
+    fe_mul_body<K>(r, a, b);
+    return r;
+}
+template <uint32_t K, int N>
+__device__ __noinline__ feT<N> fe_sqr_call(feT<N> a)
+{
+    feT<N> r;
+    fe_sqr_body<K>(r, a);
+    return r;
+}
+template <uint32_t K = 1, int N>
+__device__ __forceinline__ void fe_mul(feT<N> &r, const feT<N> &a, const feT<N> &b)
+{
+    if (N == 8) fe_mul_body<K>(r, a, b);
+    else r = fe_mul_call<K, N>(a, b);
+}
+template <uint32_t K = 1, int N>
+__device__ __forceinline__ void fe_sqr(feT<N> &r, const feT<N> &a)
+{
+    if (N == 8) fe_sqr_body<K>(r, a);
+    else r = fe_sqr_call<K, N>(a);
 }
 
 template <int N>
