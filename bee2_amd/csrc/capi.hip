@@ -951,3 +951,37 @@ extern "C" err_t beltCBCDecr(void *dest, const void *src, size_t count, const oc
 {
     return cbc_oneshot(dest, src, count, key, len, iv, 1);
 }
+
+// ================================================= 8f-3: ragged hash batches ===
+extern "C" err_t bee2hip_hash_ragged_dev(size_t alg, const void *d_data, const void *d_offsets, size_t n,
+                                         void *d_digests, void *stream)
+{
+    if (alg != 0 && alg != 128 && alg != 192 && alg != 256) return ERR_BAD_PARAMS;
+    if (n && (!d_offsets || !d_digests)) return ERR_BAD_INPUT;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    return launch_hash_ragged(alg, d_data, d_offsets, n, d_digests, as_stream(stream));
+}
+
+extern "C" err_t bee2hip_hash_ragged(size_t alg, const octet *data, const uint64_t *offsets, size_t n,
+                                     octet *digests)
+{
+    if (alg != 0 && alg != 128 && alg != 192 && alg != 256) return ERR_BAD_PARAMS;
+    if (n == 0) return ERR_OK;
+    if (!offsets || !digests) return ERR_BAD_INPUT;
+    for (size_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i]) return ERR_BAD_INPUT;
+    const size_t total = (size_t)offsets[n] , dlen = alg ? alg / 4 : 32;
+    if (total && !data) return ERR_BAD_INPUT;
+    const size_t ob = (n + 1) * 8, oo = (total + 15) & ~(size_t)15, go = (oo + ob + 15) & ~(size_t)15;
+    Scratch &s = t_scr[3];
+    err_t code = s.need(go + n * dlen + 16);
+    if (code != ERR_OK) return code;
+    octet *d = (octet *)s.p;
+    if (total) B2H_TRY(hipMemcpy(d, data, total, hipMemcpyHostToDevice));
+    B2H_TRY(hipMemcpy(d + oo, offsets, ob, hipMemcpyHostToDevice));
+    code = bee2hip_hash_ragged_dev(alg, d, d + oo, n, d + go, nullptr);
+    if (code != ERR_OK) return code;
+    B2H_TRY(hipMemcpy(digests, d + go, n * dlen, hipMemcpyDeviceToHost));
+    return ERR_OK;
+}

@@ -310,6 +310,136 @@ __global__ void init_states_kernel(bash_hash_st *hs, belt_mac_st *ms, size_t n, 
         for (int k = 0; k < 8; ++k) ms[i].key[k] = key.k[k];
 }
 
+// ------------------------------------------------ 8f-3: ragged batches of messages ---
+// n messages of different lengths packed back to back: message i = data[off[i] .. off[i+1]).
+// One lane per message (lanes of a wavefront finish at different times; that is the nature of
+// ragged input).  This is the device side of a `bee2cmd bsum`-style front-end that hashes many
+// files per launch instead of one file per bashHashStepH loop (cmd/bsum/bsum.c:133-221).
+__device__ __forceinline__ uint64_t load64_any(const uint8_t *p)
+{
+    if (((uintptr_t)p & 3) == 0) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+        return ((uint64_t)w[1] << 32) | w[0];
+    }
+    uint64_t v = 0;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) v = (v << 8) | p[k];
+    return v;
+}
+
+// ALG = 8 / 12 / 16: bash512 / bash384 / bash256 (rate in u64 words); digests are l/4 bytes each
+template <int RW>
+__global__ __launch_bounds__(64)
+void bash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off, size_t n,
+                        uint32_t level, uint8_t *__restrict__ digests)
+{
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *p = data + off[i];
+    size_t left = (size_t)(off[i + 1] - off[i]);
+    constexpr int RATE = 8 * RW;
+    u64x2 a[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) a[k].lo = a[k].hi = 0;
+    a[23].lo = level / 4;
+    while (left >= RATE) {
+#pragma unroll
+        for (int w = 0; w < RW; ++w) {
+            const uint64_t v = load64_any(p + 8 * w);
+            a[w].lo = (uint32_t)v; a[w].hi = (uint32_t)(v >> 32);
+        }
+        bash_f(a);
+        p += RATE; left -= RATE;
+    }
+    // tail || 0x40 || 0..
+#pragma unroll
+    for (int w = 0; w < RW; ++w) {
+        uint64_t v = 0;
+#pragma unroll
+        for (int k = 7; k >= 0; --k) {
+            const size_t pos = (size_t)(8 * w + k);
+            const uint32_t b = pos < left ? p[pos] : (pos == left ? 0x40u : 0u);
+            v = (v << 8) | b;
+        }
+        a[w].lo = (uint32_t)v; a[w].hi = (uint32_t)(v >> 32);
+    }
+    bash_f(a);
+    uint8_t *d = digests + (size_t)(level / 4) * i;
+    const int nw = (int)(level / 32);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        if (w < nw) {
+            const uint64_t v = ((uint64_t)a[w].hi << 32) | a[w].lo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[8 * w + k] = (uint8_t)(v >> (8 * k));
+        }
+    }
+}
+
+// belt-hash of ragged messages (src/crypto/belt/belt_hash.c:43-171): 32-byte digests
+__global__ __launch_bounds__(64)
+void belt_hash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off, size_t n,
+                             uint8_t *__restrict__ digests)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[BeltTabSmall::kBytes];
+    BeltTabSmall::fill(smem, threadIdx.x, 64);
+    __syncthreads();
+    const BeltTabSmall T(smem);
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *p = data + off[i];
+    const size_t len = (size_t)(off[i + 1] - off[i]);
+    size_t left = len;
+    uint32_t h[8], s[4] = {0, 0, 0, 0}, X[8], s1[4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        h[k] = (uint32_t)c_beltH[4 * k] | (uint32_t)c_beltH[4 * k + 1] << 8 |
+               (uint32_t)c_beltH[4 * k + 2] << 16 | (uint32_t)c_beltH[4 * k + 3] << 24;
+    while (left) {
+        const size_t take = left < 32 ? left : 32;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 3; b >= 0; --b) {
+                const size_t pos = (size_t)(4 * k + b);
+                v = (v << 8) | (pos < take ? p[pos] : 0u);
+            }
+            X[k] = v;
+        }
+        belt_compress(T, s1, h, X);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] ^= s1[k];
+        p += take; left -= take;
+    }
+    const uint64_t bits_lo = (uint64_t)len << 3, bits_hi = (uint64_t)len >> 61;
+    X[0] = (uint32_t)bits_lo; X[1] = (uint32_t)(bits_lo >> 32); X[2] = (uint32_t)bits_hi; X[3] = 0;
+    X[4] = s[0]; X[5] = s[1]; X[6] = s[2]; X[7] = s[3];
+    belt_compress(T, s1, h, X);
+    uint8_t *d = digests + 32 * i;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) d[4 * k + b] = (uint8_t)(h[k] >> (8 * b));
+}
+
+// alg: 0 = belt-hash; 128 / 192 / 256 = bash256 / bash384 / bash512
+err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, size_t n, void *d_digests, hipStream_t st)
+{
+    if (n == 0) return ERR_OK;
+    const dim3 g((unsigned)((n + 63) / 64)), t(64);
+    const uint8_t *data = (const uint8_t *)d_data;
+    const uint64_t *off = (const uint64_t *)d_off;
+    uint8_t *dig = (uint8_t *)d_digests;
+    if (alg == 0) hipLaunchKernelGGL(belt_hash_ragged_kernel, g, t, 0, st, data, off, n, dig);
+    else if (alg == 256) hipLaunchKernelGGL(bash_ragged_kernel<8>, g, t, 0, st, data, off, n, 256u, dig);
+    else if (alg == 192) hipLaunchKernelGGL(bash_ragged_kernel<12>, g, t, 0, st, data, off, n, 192u, dig);
+    else if (alg == 128) hipLaunchKernelGGL(bash_ragged_kernel<16>, g, t, 0, st, data, off, n, 128u, dig);
+    else return ERR_NOT_IMPLEMENTED;
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
 // ------------------------------------------------------------------ launchers ---
 err_t launch_bash_sponge(void *d_states, const void *d_data, size_t stride, size_t count, size_t n,
                          int fin, hipStream_t st)

@@ -60,7 +60,7 @@ DROPIN_SYMBOLS = [
 ]
 BATCH_SYMBOLS = [
     "bee2hip_bashF_batch", "bee2hip_beltCTR_bulk", "bee2hip_bignVerify_batch",
-    "bee2hip_bashHash_beltMAC_batch",
+    "bee2hip_bashHash_beltMAC_batch", "bee2hip_hash_ragged", "bee2hip_hash_ragged_dev",
     "bee2hip_bashF_batch_dev", "bee2hip_beltCTR_blocks_dev", "bee2hip_beltBlockEncr_dev",
     "bee2hip_beltModes_blocks_dev", "bee2hip_beltCBCEncr_batch_dev",
     "bee2hip_bign128Verify_batch_dev", "bee2hip_bignVerify_batch_dev", "bee2hip_bignVerifyL_batch_dev",
@@ -217,6 +217,19 @@ class Engine:
                                                             bytes(key), _sz(len(key)), dig, tag),
                     "bashHash_beltMAC_batch")
         return (dig.raw[: n * (l // 4)] if dig else None), (tag.raw[: n * 8] if tag else None)
+
+    def hash_ragged(self, alg, messages):
+        """alg 0 = belt-hash, 128/192/256 = bash256/384/512; messages: list of bytes"""
+        import struct
+        offs = [0]
+        for m in messages:
+            offs.append(offs[-1] + len(m))
+        data = b"".join(messages)
+        n = len(messages)
+        dlen = alg // 4 if alg else 32
+        out = ctypes.create_string_buffer(max(1, n * dlen))
+        code = self.lib.bee2hip_hash_ragged(_sz(alg), data, struct.pack(f"<{n + 1}Q", *offs), _sz(n), out)
+        return code, [out.raw[i * dlen:(i + 1) * dlen] for i in range(n)]
 
     # ------------------------------------------------- bee2 drop-in interface
     def beltH(self):

@@ -167,6 +167,15 @@ err_t bee2hip_bashHash_beltMAC_batch(const octet *msgs, size_t msg_len, size_t n
                                      const octet key[], size_t key_len,
                                      octet *digests, octet *tags);
 
+/* SURVEY.md 8f-3 (batch front-end for `bee2cmd bsum`, cmd/bsum/bsum.c:133-221): n messages of
+   different lengths packed back to back, message i = data[offsets[i] .. offsets[i+1]).
+   alg = 0: belt-hash (32-byte digests, src/crypto/belt/belt_hash.c:173-190);
+   alg = 128 / 192 / 256: bash256 / bash384 / bash512 (alg/4-byte digests, bash_hash.c:118-137) */
+err_t bee2hip_hash_ragged(size_t alg, const octet *data, const uint64_t *offsets, size_t n,
+                          octet *digests);
+err_t bee2hip_hash_ragged_dev(size_t alg, const void *d_data, const void *d_offsets, size_t n,
+                              void *d_digests, void *stream);
+
 /* ======================================================================== *
  * (3) device-pointer batch API (buffers in HBM; async on `stream`)
  * ======================================================================== */

@@ -71,3 +71,47 @@ def test_mixed_per_gpu_share_of_config4(orc, golden):
     eng.bashHash_beltMAC_batch_dev(msgs, msg_len, 256, key, dig, tag)
     torch.cuda.synchronize()
     assert torch.equal(dig, d1) and torch.equal(tag, t1)
+
+
+def test_ragged_hash_batches(orc, golden):
+    """messages of different lengths in one launch, vs the oracle and the golden set"""
+    import random
+    eng = engine()
+    rnd = random.Random(21)
+    msgs = [bytes.fromhex(c["msg"]) for c in golden.belt_bash]
+    msgs += [orc.fill(n, n) for n in (0, 1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 192, 193, 5000)]
+    msgs += [rnd.randbytes(rnd.randrange(0, 3000)) for _ in range(200)]
+    for alg in (0, 128, 192, 256):
+        code, digs = eng.hash_ragged(alg, msgs)
+        assert code == 0
+        for m, d in zip(msgs, digs):
+            want = orc.belt_hash(m) if alg == 0 else orc.bashHash(alg, m)[1]
+            assert d == want, (alg, len(m))
+    for c, d in zip(golden.belt_bash, eng.hash_ragged(256, [bytes.fromhex(c["msg"]) for c in golden.belt_bash])[1]):
+        assert d.hex() == c["bash512"]
+    assert eng.hash_ragged(100, [b"x"])[0] == 502
+
+
+def test_bsum_front_end_example(orc, golden, tmp_path):
+    """build examples/bsum_hip.c against the C ABI and compare its output with bsum's format"""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("cc") is None:
+        pytest.skip("no C compiler on this box")
+    exe = tmp_path / "bsum_hip"
+    lib = os.path.join(root, "bee2_amd", "lib")
+    subprocess.check_call(["cc", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "bsum_hip.c"),
+                           "-L" + lib, "-lbee2hip", "-Wl,-rpath," + lib, "-o", str(exe)])
+    names = []
+    for i, n in enumerate((0, 1, 100, 4096, 70000)):
+        p = tmp_path / f"f{i}.bin"
+        p.write_bytes(orc.fill(n, 77 + i))
+        names.append(str(p))
+    for flag, alg in (("-belt-hash", 0), ("-bash256", 128), ("-bash512", 256)):
+        out = subprocess.check_output([str(exe), flag] + names, text=True).splitlines()
+        for line, name in zip(out, names):
+            data = open(name, "rb").read()
+            want = orc.belt_hash(data) if alg == 0 else orc.bashHash(alg, data)[1]
+            assert line == f"{want.hex().upper()}  {name}"
