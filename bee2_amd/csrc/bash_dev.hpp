@@ -79,6 +79,87 @@ __device__ __forceinline__ void bash_s_layer(u64x2 (&a)[24], const int (&ix)[24]
     bash_s<56, 35,  2, 55>(a[ix[7]], a[ix[15]], a[ix[23]]);
 }
 
+// ---- staged S-layer -------------------------------------------------------------------------
+// The same 22 ops per column as bash_s, but issued stage by stage across all 8 columns, every op a
+// volatile asm so the issue order is exactly the written one: per round X16 A48 X32 A16 X64
+// (X = full-rate v_bitop3/v_xor, A = half-rate v_alignbit).  Left to itself the compiler
+// interleaves the two classes almost one for one (290 class switches per 6 rounds; staged: 24) and
+// puts consumers right behind their producers; gfx950 issues that order 3 % slower on the whole
+// bashF kernel (profiles/r01_valu_rates_ubench.txt "class-switch cost", tools/ab_bashf.sh).
+// Costs ~40 more live VGPRs (113 in bashF_batch_kernel), so kernels that are register-bound keep
+// the compact order.
+template <int TT> __device__ __forceinline__ uint32_t vbitop3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4" : "=v"(r) : "v"(a), "v"(b), "v"(c), "n"(TT));
+    return r;
+}
+__device__ __forceinline__ uint32_t vxor(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int SH> __device__ __forceinline__ uint32_t valign(uint32_t hi, uint32_t lo)
+{
+    uint32_t r;
+    asm volatile("v_alignbit_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "n"(SH));
+    return r;
+}
+template <int N> __device__ __forceinline__ u64x2 vrotl64(u64x2 x)
+{
+    static_assert(N > 0 && N < 64 && N != 32, "rotation amount");
+    u64x2 r;
+    if constexpr (N < 32) { r.lo = valign<32 - N>(x.lo, x.hi); r.hi = valign<32 - N>(x.hi, x.lo); }
+    else                  { r.lo = valign<64 - N>(x.hi, x.lo); r.hi = valign<64 - N>(x.lo, x.hi); }
+    return r;
+}
+template <int C> struct BashRotC;
+template <> struct BashRotC<0> { static constexpr int m1 =  8, n1 = 53, m2 = 14, n2 =  1; };
+template <> struct BashRotC<1> { static constexpr int m1 = 56, n1 = 51, m2 = 34, n2 =  7; };
+template <> struct BashRotC<2> { static constexpr int m1 =  8, n1 = 37, m2 = 46, n2 = 49; };
+template <> struct BashRotC<3> { static constexpr int m1 = 56, n1 =  3, m2 =  2, n2 = 23; };
+template <> struct BashRotC<4> { static constexpr int m1 =  8, n1 = 21, m2 = 14, n2 = 33; };
+template <> struct BashRotC<5> { static constexpr int m1 = 56, n1 = 19, m2 = 34, n2 = 39; };
+template <> struct BashRotC<6> { static constexpr int m1 =  8, n1 =  5, m2 = 46, n2 = 17; };
+template <> struct BashRotC<7> { static constexpr int m1 = 56, n1 = 35, m2 =  2, n2 = 55; };
+
+struct BashStage { u64x2 u0[8], ra[8], rb[8], rc[8], t[8], u1[8], r2[8]; };
+template <int C> __device__ __forceinline__ void st_rot3(BashStage &q, u64x2 (&a)[24], const int (&ix)[24])
+{
+    q.ra[C] = vrotl64<BashRotC<C>::n1>(q.u0[C]);
+    q.rb[C] = vrotl64<BashRotC<C>::m1>(a[ix[C]]);
+    q.rc[C] = vrotl64<BashRotC<C>::m2>(a[ix[16 + C]]);
+}
+template <int C> __device__ __forceinline__ void st_rot1(BashStage &q) { q.r2[C] = vrotl64<BashRotC<C>::n2>(q.t[C]); }
+
+__device__ __forceinline__ void bash_s_layer_staged(u64x2 (&a)[24], const int (&ix)[24])
+{
+    BashStage q;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        q.u0[c].lo = vbitop3<TT_XOR3>(a[ix[c]].lo, a[ix[8 + c]].lo, a[ix[16 + c]].lo);
+        q.u0[c].hi = vbitop3<TT_XOR3>(a[ix[c]].hi, a[ix[8 + c]].hi, a[ix[16 + c]].hi);
+    }
+    st_rot3<0>(q, a, ix); st_rot3<1>(q, a, ix); st_rot3<2>(q, a, ix); st_rot3<3>(q, a, ix);
+    st_rot3<4>(q, a, ix); st_rot3<5>(q, a, ix); st_rot3<6>(q, a, ix); st_rot3<7>(q, a, ix);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        q.t[c].lo = vxor(a[ix[8 + c]].lo, q.ra[c].lo);  q.t[c].hi = vxor(a[ix[8 + c]].hi, q.ra[c].hi);
+        q.u1[c].lo = vxor(q.t[c].lo, q.rb[c].lo);       q.u1[c].hi = vxor(q.t[c].hi, q.rb[c].hi);
+    }
+    st_rot1<0>(q); st_rot1<1>(q); st_rot1<2>(q); st_rot1<3>(q); st_rot1<4>(q); st_rot1<5>(q); st_rot1<6>(q); st_rot1<7>(q);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        u64x2 u2;
+        u2.lo = vbitop3<TT_XOR3>(a[ix[16 + c]].lo, q.rc[c].lo, q.r2[c].lo);
+        u2.hi = vbitop3<TT_XOR3>(a[ix[16 + c]].hi, q.rc[c].hi, q.r2[c].hi);
+        a[ix[c]].lo = vbitop3<TT_S0>(q.u0[c].lo, q.u1[c].lo, u2.lo);       a[ix[c]].hi = vbitop3<TT_S0>(q.u0[c].hi, q.u1[c].hi, u2.hi);
+        a[ix[8 + c]].lo = vbitop3<TT_S1>(q.u0[c].lo, q.u1[c].lo, u2.lo);   a[ix[8 + c]].hi = vbitop3<TT_S1>(q.u0[c].hi, q.u1[c].hi, u2.hi);
+        a[ix[16 + c]].lo = vbitop3<TT_S2>(q.u0[c].lo, q.u1[c].lo, u2.lo);  a[ix[16 + c]].hi = vbitop3<TT_S2>(q.u0[c].hi, q.u1[c].hi, u2.hi);
+    }
+}
+
 // logical word k of the next round = logical word BASH_PERM[k] of this round:
 // new_row0 = pi1(row1), new_row1 = pi2(row2), new_row2 = pi0(row0)
 // (bash_f64.c:100-134 "P1", explicit in bash_favx512.c:140-171)
@@ -112,11 +193,12 @@ __device__ __forceinline__ uint64_t bash_next_const(uint64_t c)
     return (c >> 1) ^ (0xDC2BE1997FE0D8AEull & (0ull - (c & 1ull)));
 }
 
-template <int R>
+template <int R, bool STAGED>
 __device__ __forceinline__ void bash_round(u64x2 (&a)[24], uint64_t &c)
 {
     constexpr BashSlots S{};
-    bash_s_layer(a, S.m[R]);
+    if constexpr (STAGED) bash_s_layer_staged(a, S.m[R]);
+    else                  bash_s_layer(a, S.m[R]);
     // after the word permutation the constant lands on logical word 23 of the next round
     constexpr int slot = S.m[R + 1][23];
     a[slot].lo ^= (uint32_t)c;
@@ -124,18 +206,19 @@ __device__ __forceinline__ void bash_round(u64x2 (&a)[24], uint64_t &c)
     c = bash_next_const(c);
 }
 
-// the permutation: 4 x 6 rounds
+// the permutation: 4 x 6 rounds.  STAGED picks the issue order of the S-layer (see above).
+template <bool STAGED = false>
 __device__ __forceinline__ void bash_f(u64x2 (&a)[24])
 {
     uint64_t c = 0x3BF5080AC8BA94B1ull;
 #pragma unroll 1
     for (int g = 0; g < 4; ++g) {
-        bash_round<0>(a, c);
-        bash_round<1>(a, c);
-        bash_round<2>(a, c);
-        bash_round<3>(a, c);
-        bash_round<4>(a, c);
-        bash_round<5>(a, c);
+        bash_round<0, STAGED>(a, c);
+        bash_round<1, STAGED>(a, c);
+        bash_round<2, STAGED>(a, c);
+        bash_round<3, STAGED>(a, c);
+        bash_round<4, STAGED>(a, c);
+        bash_round<5, STAGED>(a, c);
     }
 }
 

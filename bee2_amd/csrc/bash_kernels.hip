@@ -86,7 +86,7 @@ void bashF_batch_kernel(uint8_t *__restrict__ states, size_t n)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 
-    bash_f(a);
+    bash_f<true>(a);          // staged issue order: +3 % here (bash_dev.hpp)
 
     // ---- store: mirror image
 #pragma unroll
