@@ -24,6 +24,17 @@
 
 namespace bee2hip {
 
+// compile-time loop: f(integral_constant<int, I>) for I = Begin .. End-1, in order
+template <int I> struct IntC { static constexpr int value = I; };
+template <int Begin, int End, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (Begin < End) {
+        f(IntC<Begin>{});
+        static_for<Begin + 1, End>(f);
+    }
+}
+
 template <int N> struct CurveC;
 template <> struct CurveC<8> { static constexpr uint32_t C = 189u; static constexpr int LOWBITS = 8; };
 template <> struct CurveC<12> { static constexpr uint32_t C = 317u; static constexpr int LOWBITS = 9; };
@@ -207,19 +218,24 @@ __device__ __forceinline__ void fe_sqr_body(feT<N> &r, const feT<N> &a)
     uint32_t w[2 * N];
     uint64_t acc = 0;
     uint32_t c2 = 0;
-#pragma unroll
-    for (int k = 0; k < 2 * N; ++k) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int j = k - i;                     // position inside row i's vector
-            if (j == i) mac(acc, c2, a.v[i], a.v[i]);
-            else if (j == i + 1 && j < N) mac(acc, c2, a.v[i], e[j]);
-            else if (j >= i + 2 && j <= N) mac(acc, c2, a.v[i], d[j]);
-        }
+    // Column k sums row i's element at position j = k - i.  The (k, i) pairs are enumerated at
+    // compile time (static_for + if constexpr), not with `#pragma unroll` over the 2N x N square:
+    // for N = 16 that is 512 bodies, the unroller gives up, and what is left evaluates the three
+    // index conditions at run time -- 1 456 scalar instructions and 472 branches per squaring
+    // (profiles/r01_bign512_sqr_fix.txt: SQ_INSTS_SALU > SQ_INSTS_VALU in bign_main_kernel<16>).
+    static_for<0, 2 * N>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int j = k - i;                 // position inside row i's vector
+            if constexpr (j == i) mac(acc, c2, a.v[i], a.v[i]);
+            else if constexpr (j == i + 1 && j < N) mac(acc, c2, a.v[i], e[j]);
+            else if constexpr (j >= i + 2 && j <= N) mac(acc, c2, a.v[i], d[j]);
+        });
         w[k] = (uint32_t)acc;
         acc = (acc >> 32) | ((uint64_t)c2 << 32);
         c2 = 0;
-    }
+    });
     fe_reduce<K>(r, w);
 }
 

@@ -42,6 +42,9 @@ MADS_PER_VERIFY = 1025 * 72 + 939 * 52 + 3000   # v_mad_u64_u32 per signature (D
 MAD_PEAK_T = 30.0                # measured: 256 CU x 4 SIMD x 64 lanes x 2.31 GHz / 5.05 cycles
 
 
+WORKLOADS = ("bashF", "ctr", "verify", "mixed", "modes")
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,7 +53,11 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--only", default="", help="comma list of {bashF,ctr,verify,mixed,modes}; default all")
     ap.add_argument("--ctr-gib", type=float, default=16.0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    bad = set(x for x in args.only.split(",") if x) - set(WORKLOADS)
+    if bad:                                # fail before any GPU work, not with an empty JSON line
+        ap.error(f"unknown --only name(s) {sorted(bad)}; choose from {list(WORKLOADS)}")
+    return args
 
 
 class Dist:
@@ -228,7 +235,7 @@ def main():
     dist = Dist(args.gpus)
     eng = bee2_amd.load()                     # fails loudly without libbee2hip.so
     eng.set_device(torch.cuda.current_device())
-    only = set(x for x in args.only.split(",") if x) or {"bashF", "ctr", "verify", "mixed", "modes"}
+    only = set(x for x in args.only.split(",") if x) or set(WORKLOADS)
     K, W, N = args.steps, args.warmup, dist.world
     do_cpu = (not args.no_cpu) and dist.rank == 0 and N == 1
     cores = os.cpu_count() or 1
