@@ -55,6 +55,19 @@ __device__ __forceinline__ void mac(uint64_t &acc, uint32_t &c2, uint32_t a, uin
     asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(a), "v"(b));
     asm("v_addc_co_u32 %0, %1, 0, %0, %1" : "+v"(c2), "+s"(cy));
 }
+// The first product of a column WRITES c2 (= 0 + 0 + carry) instead of accumulating into it, so
+// the counter needs no zero-initialising v_mov per column.
+template <bool FIRST>
+__device__ __forceinline__ void mac_col(uint64_t &acc, uint32_t &c2, uint32_t a, uint32_t b)
+{
+    if constexpr (FIRST) {
+        uint64_t cy;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(a), "v"(b));
+        asm("v_addc_co_u32 %0, %1, 0, 0, %1" : "=v"(c2), "+s"(cy));
+    } else {
+        mac(acc, c2, a, b);
+    }
+}
 
 template <int N>
 __device__ __forceinline__ void fe_set_zero(feT<N> &r)
@@ -185,17 +198,16 @@ __device__ __forceinline__ void fe_mul_body(feT<N> &r, const feT<N> &a, const fe
     uint32_t w[2 * N];
     uint64_t acc = 0;
     uint32_t c2 = 0;
-#pragma unroll
-    for (int k = 0; k < 2 * N - 1; ++k) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int j = k - i;
-            if (j >= 0 && j < N) mac(acc, c2, a.v[i], b.v[j]);
-        }
+    static_for<0, 2 * N - 1>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int i0 = k < N ? 0 : k - N + 1;          // first row with a product in column k
+        static_for<i0, (k < N ? k : N - 1) + 1>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            mac_col<i == i0>(acc, c2, a.v[i], b.v[k - i]);
+        });
         w[k] = (uint32_t)acc;
         acc = (acc >> 32) | ((uint64_t)c2 << 32);
-        c2 = 0;
-    }
+    });
     w[2 * N - 1] = (uint32_t)acc;
     fe_reduce<K>(r, w);
 }
@@ -228,9 +240,10 @@ __device__ __forceinline__ void fe_sqr_body(feT<N> &r, const feT<N> &a)
         static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
             constexpr int j = k - i;                 // position inside row i's vector
-            if constexpr (j == i) mac(acc, c2, a.v[i], a.v[i]);
-            else if constexpr (j == i + 1 && j < N) mac(acc, c2, a.v[i], e[j]);
-            else if constexpr (j >= i + 2 && j <= N) mac(acc, c2, a.v[i], d[j]);
+            constexpr bool first = i == (k < N ? 0 : k - N);   // column k's first product (k <= 2N-2)
+            if constexpr (j == i) mac_col<first>(acc, c2, a.v[i], a.v[i]);
+            else if constexpr (j == i + 1 && j < N) mac_col<first>(acc, c2, a.v[i], e[j]);
+            else if constexpr (j >= i + 2 && j <= N) mac_col<first>(acc, c2, a.v[i], d[j]);
         });
         w[k] = (uint32_t)acc;
         acc = (acc >> 32) | ((uint64_t)c2 << 32);
