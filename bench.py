@@ -134,6 +134,26 @@ def timed(dist, steps, warmup, fn):
 
 
 # ------------------------------------------------------------------------- CPU baseline
+
+def fill_seeded(t, seed):
+    """synthetic input generated in HBM by torch's counter-based generator (Philox) with the seed
+    SURVEY.md 8d assigns to the workload (+ rank, so ranks hold different data)"""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    t.view(torch.int64).random_(generator=g)
+
+
+def host_api_rate(call, units, reps=3):
+    """PCIe-inclusive rate of a host-pointer C-ABI entry (H2D + kernels + D2H inside the call, host
+    buffers in ordinary pageable memory, as a C caller of the drop-in would have).  Reported beside
+    `value`, never as `value`."""
+    call()                                                  # first call pays allocation / table set-up
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        call()
+    dt = (time.perf_counter() - t0) / reps
+    return units / dt, dt * 1e3
+
 def cpu_baseline(which, cores):
     """Time the reference (or the oracle port) on `cores` host threads.  Returns dict."""
     import orclib
@@ -256,9 +276,7 @@ def main():
     if "bashF" in only:
         n = 1 << 20
         st = torch.empty(192 * n, dtype=torch.uint8, device="cuda")
-        g = torch.Generator(device="cuda")
-        g.manual_seed(0xBA5F + dist.rank)
-        st.view(torch.int64).random_(generator=g)                # synthetic states, generated in HBM
+        fill_seeded(st, 0xBA5F + dist.rank)                      # synthetic states, generated in HBM
         el = timed(dist, K, W, lambda: eng.bashF_batch_dev(st))
         value = N * n * K / el
         ms_launch = eng.time_kernel(0, max(K, 50), st, n=n)       # hipEvents on the launch stream
@@ -281,6 +299,13 @@ def main():
                          "avg_launch_ms": ms_launch, "algorithmic_bytes_per_launch": BASHF_BYTES * n,
                          "note": "VALU-bound in practice: ~5760 issue-slot units per permutation (DESIGN.md)"},
         }
+        if dist.rank == 0:
+            host = st.cpu().numpy()                               # pageable host copy of the same batch
+            hp = ctypes.c_void_p(host.ctypes.data)
+            v, ms = host_api_rate(lambda: eng._check(eng.lib.bee2hip_bashF_batch(hp, ctypes.c_size_t(n)), "bashF_batch"), n)
+            result["host_api"] = {"entry": "bee2hip_bashF_batch", "value": v, "unit": "perms/s", "ms_per_call": ms,
+                                  "note": "host pointers, PCIe both ways inside the call; 1 GPU; not `value`"}
+            del host
         if do_cpu:
             result["cpu_baseline"] = cpu_baseline("bashF", cores)
         del st
@@ -292,7 +317,7 @@ def main():
         if free < nbytes + (1 << 30):
             nbytes = (int(free * 0.5) // (1 << 20)) << 20
         buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        buf.view(torch.int64).random_()
+        fill_seeded(buf, 0xBE17 + dist.rank)
         nb = nbytes // 16
         _, _, first = shard.ctr_shard(dist.rank, N, nbytes * N)     # rank r owns blocks [r nb, (r+1) nb)
         kc = max(3, min(K, 10))
@@ -305,16 +330,28 @@ def main():
             "config": {"workload": f"beltCTR bulk encrypt, {nbytes / 2**30:.1f} GiB stream per GPU, one key (BASELINE configs[2])"},
             "roofline": {"kernel": "beltCTR_blocks_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms_launch,
-                         "note": "LDS-lookup bound: 224 ds_read_b32 per block (DESIGN.md)"},
+                         "note": "VALU/LDS-issue bound, not HBM: per block ~695 VALU ops (floor 930 GiB/s) and "
+                                 "224 ds_read_b32 (floor 1146 GiB/s), DESIGN.md 2 and 4.2"},
         }
+        if dist.rank == 0:
+            hn = 1 << 30                                          # 1 GiB through the drop-in one-shot beltCTR
+            host = np.zeros(hn, dtype=np.uint8)
+            hp = ctypes.c_void_p(host.ctypes.data)
+            key, iv = bytes(H[128:160]), bytes(H[192:208])
+            v, ms = host_api_rate(lambda: eng._check(eng.lib.beltCTR(hp, hp, ctypes.c_size_t(hn), key,
+                                                                       ctypes.c_size_t(32), iv), "beltCTR"), 1.0)
+            others["beltCTR"]["host_api"] = {"entry": "beltCTR (bee2 drop-in, belt.h:734)", "value": v, "unit": "GiB/s",
+                                             "ms_per_call": ms, "sample": "1 GiB, in place",
+                                             "note": "host pointers, PCIe both ways inside the call; 1 GPU; not `value`"}
+            del host
         if do_cpu:
             others["beltCTR"]["cpu_baseline"] = cpu_baseline("ctr", cores)
         del buf
 
     # ------------------------------------------------------------------------- verify
     if "verify" in only:
-        import orclib
-        G = orclib.Golden()
+        import goldenlib                      # committed fixtures only; the oracle is not imported here
+        G = goldenlib.Golden()
         hs, ss, ps = G.bign_base_arrays()
         nbase = len(hs) // 32
         reps = (1 << 18) // nbase
@@ -351,6 +388,18 @@ def main():
                                  "v_mad_u64_u32 micro-benchmark (profiles/r01_valu_rates_ubench.txt); every mad is "
                                  "paired with a half-rate v_addc_co_u32, so 0.5 is the practical ceiling"},
         }
+        if dist.rank == 0:
+            hcodes = np.empty(n, dtype=np.uint32)
+            prm = eng.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
+            from bee2_amd.engine import OID_BELT_HASH_DER
+            oid = bytes(OID_BELT_HASH_DER)
+            args_h = (ctypes.byref(prm), oid, ctypes.c_size_t(len(oid)), ctypes.c_void_p(Hh.ctypes.data),
+                      ctypes.c_void_p(Ss.ctypes.data), ctypes.c_void_p(Kk.ctypes.data), ctypes.c_size_t(n),
+                      ctypes.c_void_p(hcodes.ctypes.data))
+            v, ms = host_api_rate(lambda: eng._check(eng.lib.bee2hip_bignVerify_batch(*args_h), "bignVerify_batch"), n)
+            others["bignVerify"]["host_api"] = {"entry": "bee2hip_bignVerify_batch", "value": v, "unit": "verifies/s",
+                                                "ms_per_call": ms, "same_verdicts": bool((hcodes == got.astype(np.uint32)).all()),
+                                                "note": "host pointers, PCIe both ways inside the call; 1 GPU; not `value`"}
         if do_cpu:
             others["bignVerify"]["cpu_baseline"] = cpu_baseline("verify", cores)
         del dh, ds, dk, codes
@@ -377,7 +426,6 @@ def main():
             if do_cpu:
                 import refgen
                 if refgen.have_ref():
-                    import orclib
                     ref = ctypes.CDLL(refgen.REF_SO)
                     f = getattr(ref, f"bign{l}Verify")
                     f.restype = ctypes.c_uint32
@@ -400,7 +448,7 @@ def main():
         while n * ml + (1 << 30) > free and n > 1024:
             n //= 2
         msgs = torch.empty(n * ml, dtype=torch.uint8, device="cuda")
-        msgs.view(torch.int64).random_()
+        fill_seeded(msgs, 0x4D1C + dist.rank)
         dig = torch.empty(n * 64, dtype=torch.uint8, device="cuda")
         tag = torch.empty(n * 8, dtype=torch.uint8, device="cuda")
         km = max(2, min(K, 5))
@@ -421,7 +469,7 @@ def main():
         if free < 2 * nbytes + (1 << 30):
             nbytes = (int(free * 0.3) // (1 << 20)) << 20
         src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        src.view(torch.int64).random_()
+        fill_seeded(src, 0xBE17 + dist.rank)
         dst = torch.empty_like(src)
         km = max(3, min(K, 10))
         entry = {"metric": "belt ECB/CBC bulk GiB/s", "unit": "GiB/s", "steps": km,

@@ -4,9 +4,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np, torch
-import bee2_amd, orclib
+import bee2_amd, goldenlib
 eng = bee2_amd.load(); eng.set_device(0)
-G = orclib.Golden(); H = eng.beltH()
+G = goldenlib.Golden(); H = eng.beltH()
 print("bashF: states  us/launch  Gperm/s  TB/s")
 for e in range(12, 25, 2):
     n = 1 << e
