@@ -4,8 +4,10 @@
 // C functions line for line in *behaviour* (same names, same state layouts, same
 // error codes); every primitive evaluation is a kernel launch.  There is no CPU
 // implementation of bashF / E_K / EC arithmetic in this library.
+#include <algorithm>
 #include <mutex>
 #include <new>
+#include <vector>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -953,14 +955,20 @@ extern "C" err_t beltCBCDecr(void *dest, const void *src, size_t count, const oc
 }
 
 // ================================================= 8f-3: ragged hash batches ===
-extern "C" err_t bee2hip_hash_ragged_dev(size_t alg, const void *d_data, const void *d_offsets, size_t n,
-                                         void *d_digests, void *stream)
+extern "C" err_t bee2hip_hash_ragged_ordered_dev(size_t alg, const void *d_data, const void *d_offsets,
+                                                 const void *d_order, size_t n, void *d_digests, void *stream)
 {
     if (alg != 0 && alg != 128 && alg != 192 && alg != 256) return ERR_BAD_PARAMS;
     if (n && (!d_offsets || !d_digests)) return ERR_BAD_INPUT;
     err_t code = ensure_device();
     if (code != ERR_OK) return code;
-    return launch_hash_ragged(alg, d_data, d_offsets, n, d_digests, as_stream(stream));
+    return launch_hash_ragged(alg, d_data, d_offsets, d_order, n, d_digests, as_stream(stream));
+}
+
+extern "C" err_t bee2hip_hash_ragged_dev(size_t alg, const void *d_data, const void *d_offsets, size_t n,
+                                         void *d_digests, void *stream)
+{
+    return bee2hip_hash_ragged_ordered_dev(alg, d_data, d_offsets, nullptr, n, d_digests, stream);
 }
 
 extern "C" err_t bee2hip_hash_ragged(size_t alg, const octet *data, const uint64_t *offsets, size_t n,
@@ -973,14 +981,24 @@ extern "C" err_t bee2hip_hash_ragged(size_t alg, const octet *data, const uint64
         if (offsets[i + 1] < offsets[i]) return ERR_BAD_INPUT;
     const size_t total = (size_t)offsets[n] , dlen = alg ? alg / 4 : 32;
     if (total && !data) return ERR_BAD_INPUT;
-    const size_t ob = (n + 1) * 8, oo = (total + 15) & ~(size_t)15, go = (oo + ob + 15) & ~(size_t)15;
+    if (n > 0xffffffffull) return ERR_BAD_INPUT;
+    // longest first: the 64 lanes of a wavefront then hold messages of similar length and the long
+    // serial chains start at once (bench.py "hash_ragged": +20 % belt-hash, +57 % bash256)
+    std::vector<uint32_t> ord(n);
+    for (size_t i = 0; i < n; ++i) ord[i] = (uint32_t)i;
+    std::stable_sort(ord.begin(), ord.end(), [offsets](uint32_t a, uint32_t b) {
+        return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b];
+    });
+    const size_t ob = (n + 1) * 8, oo = (total + 15) & ~(size_t)15, ro = (oo + ob + 15) & ~(size_t)15,
+                 go = (ro + n * 4 + 15) & ~(size_t)15;
     Scratch &s = t_scr[3];
     err_t code = s.need(go + n * dlen + 16);
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
     if (total) B2H_TRY(hipMemcpy(d, data, total, hipMemcpyHostToDevice));
     B2H_TRY(hipMemcpy(d + oo, offsets, ob, hipMemcpyHostToDevice));
-    code = bee2hip_hash_ragged_dev(alg, d, d + oo, n, d + go, nullptr);
+    B2H_TRY(hipMemcpy(d + ro, ord.data(), n * 4, hipMemcpyHostToDevice));
+    code = bee2hip_hash_ragged_ordered_dev(alg, d, d + oo, d + ro, n, d + go, nullptr);
     if (code != ERR_OK) return code;
     B2H_TRY(hipMemcpy(digests, d + go, n * dlen, hipMemcpyDeviceToHost));
     return ERR_OK;

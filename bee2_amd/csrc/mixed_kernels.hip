@@ -330,11 +330,13 @@ __device__ __forceinline__ uint64_t load64_any(const uint8_t *p)
 // ALG = 8 / 12 / 16: bash512 / bash384 / bash256 (rate in u64 words); digests are l/4 bytes each
 template <int RW>
 __global__ __launch_bounds__(64)
-void bash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off, size_t n,
+void bash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off,
+                        const uint32_t *__restrict__ order, size_t n,
                         uint32_t level, uint8_t *__restrict__ digests)
 {
-    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
+    const size_t slot = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (slot >= n) return;
+    const size_t i = order ? order[slot] : slot;      // lane `slot` hashes message order[slot]
     const uint8_t *p = data + off[i];
     size_t left = (size_t)(off[i + 1] - off[i]);
     constexpr int RATE = 8 * RW;
@@ -378,15 +380,16 @@ void bash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *__rest
 
 // belt-hash of ragged messages (src/crypto/belt/belt_hash.c:43-171): 32-byte digests
 __global__ __launch_bounds__(64)
-void belt_hash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off, size_t n,
-                             uint8_t *__restrict__ digests)
+void belt_hash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off,
+                             const uint32_t *__restrict__ order, size_t n, uint8_t *__restrict__ digests)
 {
     __shared__ __attribute__((aligned(16))) uint8_t smem[BeltTabSmall::kBytes];
     BeltTabSmall::fill(smem, threadIdx.x, 64);
     __syncthreads();
     const BeltTabSmall T(smem);
-    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
+    const size_t slot = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (slot >= n) return;
+    const size_t i = order ? order[slot] : slot;
     const uint8_t *p = data + off[i];
     const size_t len = (size_t)(off[i + 1] - off[i]);
     size_t left = len;
@@ -424,17 +427,23 @@ void belt_hash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *_
 }
 
 // alg: 0 = belt-hash; 128 / 192 / 256 = bash256 / bash384 / bash512
-err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, size_t n, void *d_digests, hipStream_t st)
+// d_order (may be null): a permutation of 0..n-1; lane k hashes message d_order[k].  Lanes of a
+// wavefront run until the longest of their 64 messages is done, so callers pass the messages
+// sorted by decreasing length (the host entry point does) -- digests still land at index i.
+err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, const void *d_order, size_t n,
+                         void *d_digests, hipStream_t st)
 {
     if (n == 0) return ERR_OK;
+    if (n > 0xffffffffull) return ERR_BAD_INPUT;
+    const uint32_t *ord = (const uint32_t *)d_order;
     const dim3 g((unsigned)((n + 63) / 64)), t(64);
     const uint8_t *data = (const uint8_t *)d_data;
     const uint64_t *off = (const uint64_t *)d_off;
     uint8_t *dig = (uint8_t *)d_digests;
-    if (alg == 0) hipLaunchKernelGGL(belt_hash_ragged_kernel, g, t, 0, st, data, off, n, dig);
-    else if (alg == 256) hipLaunchKernelGGL(bash_ragged_kernel<8>, g, t, 0, st, data, off, n, 256u, dig);
-    else if (alg == 192) hipLaunchKernelGGL(bash_ragged_kernel<12>, g, t, 0, st, data, off, n, 192u, dig);
-    else if (alg == 128) hipLaunchKernelGGL(bash_ragged_kernel<16>, g, t, 0, st, data, off, n, 128u, dig);
+    if (alg == 0) hipLaunchKernelGGL(belt_hash_ragged_kernel, g, t, 0, st, data, off, ord, n, dig);
+    else if (alg == 256) hipLaunchKernelGGL(bash_ragged_kernel<8>, g, t, 0, st, data, off, ord, n, 256u, dig);
+    else if (alg == 192) hipLaunchKernelGGL(bash_ragged_kernel<12>, g, t, 0, st, data, off, ord, n, 192u, dig);
+    else if (alg == 128) hipLaunchKernelGGL(bash_ragged_kernel<16>, g, t, 0, st, data, off, ord, n, 128u, dig);
     else return ERR_NOT_IMPLEMENTED;
     B2H_TRY(hipGetLastError());
     return ERR_OK;

@@ -60,7 +60,7 @@ DROPIN_SYMBOLS = [
 ]
 BATCH_SYMBOLS = [
     "bee2hip_bashF_batch", "bee2hip_beltCTR_bulk", "bee2hip_bignVerify_batch",
-    "bee2hip_bashHash_beltMAC_batch", "bee2hip_hash_ragged", "bee2hip_hash_ragged_dev",
+    "bee2hip_bashHash_beltMAC_batch", "bee2hip_hash_ragged", "bee2hip_hash_ragged_dev", "bee2hip_hash_ragged_ordered_dev",
     "bee2hip_bashF_batch_dev", "bee2hip_beltCTR_blocks_dev", "bee2hip_beltBlockEncr_dev",
     "bee2hip_beltModes_blocks_dev", "bee2hip_beltCBCEncr_batch_dev",
     "bee2hip_bign128Verify_batch_dev", "bee2hip_bignVerify_batch_dev", "bee2hip_bignVerifyL_batch_dev",
@@ -183,6 +183,15 @@ class Engine:
             self._ptr(digests) if digests is not None else None,
             self._ptr(tags) if tags is not None else None, self._stream()),
             "bashHash_beltMAC_batch_dev")
+
+    def hash_ragged_dev(self, alg, data, offsets, digests, n, order=None):
+        """alg 0 = belt-hash, 128/192/256 = bash256/384/512; data (u8), offsets (int64, n+1),
+        digests (u8) and the optional launch order (int32 permutation, longest message first) are
+        device tensors"""
+        o = self._ptr(order) if order is not None else None
+        self._check(self.lib.bee2hip_hash_ragged_ordered_dev(_sz(alg), self._ptr(data), self._ptr(offsets), o,
+                                                             _sz(n), self._ptr(digests), self._stream()),
+                    "hash_ragged_ordered_dev")
 
     def time_kernel(self, which, reps, a=None, b=None, c=None, d=None, n=0, aux=0):
         ms = ctypes.c_float(0)

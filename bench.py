@@ -42,7 +42,7 @@ MADS_PER_VERIFY = 1025 * 72 + 939 * 52 + 3000   # v_mad_u64_u32 per signature (D
 MAD_PEAK_T = 30.0                # measured: 256 CU x 4 SIMD x 64 lanes x 2.31 GHz / 5.05 cycles
 
 
-WORKLOADS = ("bashF", "ctr", "verify", "mixed", "modes")
+WORKLOADS = ("bashF", "ctr", "verify", "mixed", "modes", "ragged")
 
 
 def parse():
@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--only", default="", help="comma list of {bashF,ctr,verify,mixed,modes}; default all")
+    ap.add_argument("--only", default="", help="comma list of {bashF,ctr,verify,mixed,modes,ragged}; default all")
     ap.add_argument("--ctr-gib", type=float, default=16.0)
     args = ap.parse_args()
     bad = set(x for x in args.only.split(",") if x) - set(WORKLOADS)
@@ -462,6 +462,68 @@ def main():
             others["bash512_beltMAC"]["cpu_baseline"] = cpu_baseline("mixed", cores)
         del msgs, dig, tag
 
+    # ------------------------------------------------- 8f-3: ragged hash batches (bsum front-end)
+    if "ragged" in only:
+        nm = 1 << 16
+        rng = np.random.default_rng(0x4D1C + dist.rank)
+        lens = np.floor(2.0 ** (18.0 * rng.random(nm))).astype(np.int64) - 1      # log-uniform in [0, 256 KiB)
+        entry = {"metric": "ragged hash GiB/s", "unit": "GiB/s",
+                 "config": {"workload": f"{nm} messages per GPU, lengths log-uniform in [0, 256 KiB) (seed 0x4D1C), "
+                                        f"{int(lens.sum()) / 2**30:.2f} GiB, packed back to back (SURVEY 8f-3)"}}
+        kr = max(2, min(K, 5))
+        offs = np.zeros(nm + 1, dtype=np.int64)
+        np.cumsum(lens, out=offs[1:])
+        total = int(offs[-1])
+        data = torch.empty(max(total, 8) // 8 * 8 + 8, dtype=torch.uint8, device="cuda")
+        fill_seeded(data, 0x4D1C + dist.rank)
+        doff = torch.from_numpy(offs).cuda()
+        # launch order: longest message first (what the host entry point bee2hip_hash_ragged does itself)
+        dord = torch.from_numpy(np.argsort(-lens, kind="stable").astype(np.int32)).cuda()
+        for name, alg, dl in (("belt_hash", 0, 32), ("bash256", 128, 32)):
+            dig = torch.empty(nm * dl, dtype=torch.uint8, device="cuda")
+            for order, o in (("caller_order", None), ("longest_first", dord)):
+                el = timed(dist, kr, 1, lambda: eng.hash_ragged_dev(alg, data, doff, dig, nm, order=o))
+                entry[f"{name}_{order}"] = N * total * kr / el / 2 ** 30
+            if name == "belt_hash":                               # bsum's default algorithm (bsum.c:392-394)
+                entry["value"] = entry["belt_hash_longest_first"]
+                entry["steps"] = kr
+                entry["ms_per_step"] = el / kr * 1e3
+            if do_cpu:
+                import refgen
+                if refgen.have_ref():
+                    from concurrent.futures import ThreadPoolExecutor
+                    ref = ctypes.CDLL(refgen.REF_SO)
+                    sub = min(nm, 8192)                                # bounded sample: the first 8192 messages
+                    host = data[: int(offs[sub])].cpu().numpy()
+                    base = host.ctypes.data
+                    outs = np.empty((sub, dl), dtype=np.uint8)
+
+                    def work(r, name=name, outs=outs, base=base):
+                        for i in r:
+                            src, cnt = ctypes.c_void_p(base + int(offs[i])), ctypes.c_size_t(int(lens[i]))
+                            dst = ctypes.c_void_p(outs[i].ctypes.data)
+                            if name == "belt_hash":
+                                ref.beltHash(dst, src, cnt)
+                            else:
+                                ref.bashHash(dst, ctypes.c_size_t(128), src, cnt)
+                    nthr = min(cores, 64)
+                    parts = [range(t, sub, nthr) for t in range(nthr)]
+                    t0 = time.perf_counter()
+                    with ThreadPoolExecutor(nthr) as ex:
+                        list(ex.map(work, parts))
+                    dt = time.perf_counter() - t0
+                    gpu = dig[: sub * dl].cpu().numpy().reshape(sub, dl)
+                    entry.setdefault("cpu_baseline", {"kind": "reference", "cores": nthr, "unit": "GiB/s",
+                                                      "sample": f"first {sub} messages, {nthr} threads calling "
+                                                                "beltHash / bashHash of the reference"})
+                    entry["cpu_baseline"][name] = int(offs[sub]) / dt / 2 ** 30
+                    entry["cpu_baseline"][f"{name}_digests_equal"] = bool((gpu == outs).all())
+                    if name == "belt_hash":
+                        entry["cpu_baseline"]["value"] = entry["cpu_baseline"][name]
+            del dig
+        del data, doff, dord
+        others["hash_ragged"] = entry
+
     # ------------------------------------------------- 8f-1: ECB / CBC-decrypt bulk modes
     if "modes" in only:
         nbytes = 4 << 30
@@ -510,9 +572,8 @@ def main():
         result = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "n_gpus": N, "steps": o["steps"],
                   "warmup": W, "ms_per_step": o["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                   "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": o["config"]}
-        for k in ("roofline", "cpu_baseline"):
-            if k in o:
-                result[k] = o[k]
+        for k, v in o.items():            # keep the workload's own fields (roofline, cpu_baseline, extras)
+            result.setdefault(k, v)
     result["others"] = others
     result["host"] = {"cpu_count": cores, "device": torch.cuda.get_device_name(torch.cuda.current_device()),
                       "engine": eng.version()}

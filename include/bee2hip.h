@@ -175,6 +175,12 @@ err_t bee2hip_hash_ragged(size_t alg, const octet *data, const uint64_t *offsets
                           octet *digests);
 err_t bee2hip_hash_ragged_dev(size_t alg, const void *d_data, const void *d_offsets, size_t n,
                               void *d_digests, void *stream);
+/* same with a launch order: d_order = n x uint32, a permutation of 0..n-1 (or NULL = identity);
+   wavefront lane k hashes message d_order[k], digest i still lands at d_digests + i*dlen.  A
+   wavefront runs until the longest of its 64 messages is done: pass the messages sorted by
+   decreasing length (bee2hip_hash_ragged does so itself). */
+err_t bee2hip_hash_ragged_ordered_dev(size_t alg, const void *d_data, const void *d_offsets,
+                                      const void *d_order, size_t n, void *d_digests, void *stream);
 
 /* ======================================================================== *
  * (3) device-pointer batch API (buffers in HBM; async on `stream`)

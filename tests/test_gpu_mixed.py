@@ -92,6 +92,36 @@ def test_ragged_hash_batches(orc, golden):
     assert eng.hash_ragged(100, [b"x"])[0] == 502
 
 
+def test_ragged_hash_device_api_with_launch_order(orc):
+    """bee2hip_hash_ragged[_ordered]_dev: digests land at the caller's index whatever the launch order
+    (identity, longest-first, a random permutation); unaligned message starts included"""
+    import random
+    import numpy as np
+    import torch
+    eng = engine()
+    rnd = random.Random(77)
+    msgs = [rnd.randbytes(rnd.choice((0, 1, 5, 31, 32, 33, 127, 128, 129, 1000, 4097))) for _ in range(300)]
+    offs = np.zeros(len(msgs) + 1, dtype=np.int64)
+    np.cumsum([len(m) for m in msgs], out=offs[1:])
+    blob = b"".join(msgs)
+    data = torch.from_numpy(np.frombuffer(blob + b"\0" * 16, dtype=np.uint8).copy()).cuda()
+    doff = torch.from_numpy(offs).cuda()
+    n = len(msgs)
+    lens = np.diff(offs)
+    orders = {"identity": None,
+              "longest_first": np.argsort(-lens, kind="stable").astype(np.int32),
+              "random": np.array(rnd.sample(range(n), n), dtype=np.int32)}
+    for alg, dl in ((0, 32), (128, 32), (192, 48), (256, 64)):
+        want = [orc.belt_hash(m) if alg == 0 else orc.bashHash(alg, m)[1] for m in msgs]
+        for name, o in orders.items():
+            dig = torch.zeros(n * dl, dtype=torch.uint8, device="cuda")
+            eng.hash_ragged_dev(alg, data, doff, dig, n, order=None if o is None else torch.from_numpy(o).cuda())
+            eng.sync()
+            got = dig.cpu().numpy().tobytes()
+            for i in range(n):
+                assert got[i * dl:(i + 1) * dl] == want[i], (alg, name, i, len(msgs[i]))
+
+
 def test_bsum_front_end_example(orc, golden, tmp_path):
     """build examples/bsum_hip.c against the C ABI and compare its output with bsum's format"""
     import os
