@@ -85,7 +85,7 @@ __device__ __forceinline__ void bash_s_layer(u64x2 (&a)[24], const int (&ix)[24]
 // (X = full-rate v_bitop3/v_xor, A = half-rate v_alignbit).  Left to itself the compiler
 // interleaves the two classes almost one for one (290 class switches per 6 rounds; staged: 24) and
 // puts consumers right behind their producers; gfx950 issues that order 3 % slower on the whole
-// bashF kernel (profiles/r01_valu_rates_ubench.txt "class-switch cost", tools/ab_bashf.sh).
+// bashF kernel (profiles/r01_valu_rates_ubench.txt "class-switch cost"; A/B log profiles/r01_bashF_ab_staged.txt).
 // Costs ~40 more live VGPRs (113 in bashF_batch_kernel), so kernels that are register-bound keep
 // the compact order.
 template <int TT> __device__ __forceinline__ uint32_t vbitop3(uint32_t a, uint32_t b, uint32_t c)
