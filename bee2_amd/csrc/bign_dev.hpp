@@ -182,12 +182,19 @@ __device__ __forceinline__ void fe_reduce(feT<N> &r, const uint32_t (&w)[2 * N])
         else s += (uint64_t)w[i] * K;
         t[i] = (uint32_t)s; c = s >> 32;
     }
-    // fold the top (< 2^14) once more, then the at-most-one final carry
-    uint64_t f = (uint64_t)t[0] + (uint64_t)(uint32_t)c * C;
-    r.v[0] = (uint32_t)f; f >>= 32;
+    // fold the top (c <= K*(C+1) < 2^14, so c*C < 2^24) once more, then the at-most-one final carry.
+    // A plain 32-bit carry chain: one half-rate op per limb.  (Written as 64-bit adds the compiler
+    // zero-extends every limb into a register pair: 2 v_mov + 1 v_lshl_add_u64 per limb.)
+    const uint32_t cc = (uint32_t)c * C;
+    uint64_t cy;
+    asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(r.v[0]), "=s"(cy) : "v"(t[0]), "v"(cc));
 #pragma unroll
-    for (int i = 1; i < N; ++i) { f += t[i]; r.v[i] = (uint32_t)f; f >>= 32; }
-    r.v[0] += (uint32_t)f ? C : 0u;
+    for (int i = 1; i < N; ++i)
+        asm("v_addc_co_u32 %0, %1, 0, %2, %1" : "=v"(r.v[i]), "+s"(cy) : "v"(t[i]));
+    // carry out of the top limb: the value wrapped past 2^(32N) (what is left is < 2^24), add C once
+    uint32_t top;
+    asm("v_addc_co_u32 %0, %1, 0, 0, %1" : "=v"(top), "+s"(cy));
+    r.v[0] += (0u - top) & C;
 }
 
 // ------------------------------------------------------------- mul / sqr ---

@@ -473,6 +473,11 @@ __global__ void bign_debug_fe_kernel(int op, const uint32_t *a, const uint32_t *
     case 5: fe_mul<3>(r, x, y); break;
     case 6: fe_sqr<8>(r, x); break;
     case 7: r = x; break;
+    case 9: case 10: {                    // fe_reduce on a raw 2N-limb value: a = low half, b = high half
+        uint32_t w[2 * N];
+        for (int i = 0; i < N; ++i) { w[i] = x.v[i]; w[N + i] = y.v[i]; }
+        if (op == 9) fe_reduce<1>(r, w); else fe_reduce<3>(r, w);
+    } break;
     default: {
         jacT<N> P; P.X = x; P.Y = y; fe_set_one(P.Z);
         jac_dbl(P);

@@ -218,6 +218,51 @@ def test_field_ops_big_curves(l):
         assert got == [f(a, b) for a, b in zip(A, B)], f"l={l} field op {op}"
 
 
+@pytest.mark.parametrize("l", [128, 192, 256])
+def test_crandall_reduction_carry_ripple(l):
+    """fe_reduce on raw 2N-limb values (debug ops 9 / 10 = K 1 / 3) crafted so that the second fold
+    lands within +-2 of 2^(32N): the carry of `t[0] + c*C` then ripples through every limb and (for
+    delta >= 0) out of the top.  Random products almost never exercise that chain."""
+    eng = engine()
+    rnd = random.Random(l)
+    C = {128: 189, 192: 317, 256: 569}[l]
+    bits = 2 * l
+    R = 1 << bits
+    P = R - C
+    nb = bits // 8
+    Ls, Hs = [], []
+    his = [0, 1, 2, (1 << 32) - 1, 1 << 32, 1 << (bits - 1), R - 1, R - 2] + [rnd.getrandbits(bits) for _ in range(40)]
+    for K in (1, 3):
+        for H in his:
+            for delta in (-2, -1, 0, 1, 2, 1 << 31, (1 << 32) - 1, 1 << 32, (1 << 64) - 1):
+                # want K*(L + C*H) = c*R + (R - c*C + delta) with 0 <= L < R: the top part c is
+                # about K*C*H / R; try its neighbours and keep every c that gives a valid L
+                base = K * C * H
+                for c in range(max(0, base // R - 1), base // R + K + 2):
+                    target = c * R + (R - c * C + delta)
+                    target += (-target) % K                 # K | target (moves delta by < K)
+                    L = (target - base) // K
+                    if 0 <= L < R and (K * (L + C * H)) // R == c:
+                        Ls.append(L); Hs.append(H)
+    Ls += [R - 1, R - 1, 0, R - 1] + [rnd.getrandbits(bits) for _ in range(500)]
+    Hs += [0, 1, R - 1, R - 1] + [rnd.getrandbits(bits) for _ in range(500)]
+    assert len(Ls) > 600
+    ta = dev(b"".join(x.to_bytes(nb, "little") for x in Ls))
+    tb = dev(b"".join(x.to_bytes(nb, "little") for x in Hs))
+    out = torch.empty_like(ta)
+    for op, K in ((9, 1), (10, 3)):
+        code = eng.lib.bee2hip_debug_feL(ctypes.c_size_t(l), op, ctypes.c_void_p(ta.data_ptr()),
+                                         ctypes.c_void_p(tb.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                         ctypes.c_size_t(len(Ls)), None)
+        assert code == 0
+        torch.cuda.synchronize()
+        raw = host(out)
+        got = [int.from_bytes(raw[i:i + nb], "little") for i in range(0, len(raw), nb)]
+        want = [K * (a + R * b) % P for a, b in zip(Ls, Hs)]
+        bad = [(i, hex(Ls[i]), hex(Hs[i])) for i in range(len(Ls)) if got[i] != want[i]]
+        assert not bad, (l, K, len(bad), bad[:3])
+
+
 @pytest.mark.parametrize("l", [192, 256])
 def test_bign_big_curves_batch_and_dropin(orc, golden, l):
     eng = engine()
