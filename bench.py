@@ -42,6 +42,21 @@ MADS_PER_VERIFY = 1025 * 72 + 939 * 52 + 3000   # v_mad_u64_u32 per signature (D
 MAD_PEAK_T = 30.0                # measured: 256 CU x 4 SIMD x 64 lanes x 2.31 GHz / 5.05 cycles
 
 
+# VALU-issue picture: a wave64 full-rate op occupies its SIMD for 2 cycles, a half-rate op
+# for 4 (157 TFLOP/s fp32 = 1024 SIMDs x 2.4 GHz x 32 lanes x 2); tools/ubench/valu_rates.hip sustains
+# 80 % of that.  Per-unit instruction counts are the ISA's (hipcc -S), not estimates.
+SIMD_CYCLES_PER_S = 1024 * 2.4e9
+BASHF_VALU = {"full_rate": 4 * 684, "half_rate": 4 * 384}          # per permutation-wavefront (24 rounds)
+CTR_VALU = {"full_rate": 695, "half_rate": 19, "ds_read_b32": 224}  # per block-wavefront
+
+
+def valu_picture(units_per_s, mix, lanes=64):
+    """fraction of the SIMDs' issue cycles the arithmetic itself needs at the measured rate"""
+    cyc = 2 * mix["full_rate"] + 4 * mix["half_rate"]
+    return {"issue_cycles_per_wave_unit": cyc, "frac_of_simd_cycles": units_per_s / lanes * cyc / SIMD_CYCLES_PER_S,
+            "mix": mix}
+
+
 WORKLOADS = ("bashF", "ctr", "verify", "mixed", "modes", "ragged")
 
 
@@ -297,7 +312,8 @@ def main():
             "roofline": {"kernel": "bashF_batch_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": ms_launch, "algorithmic_bytes_per_launch": BASHF_BYTES * n,
-                         "note": "VALU-bound in practice: ~5760 issue-slot units per permutation (DESIGN.md)"},
+                         "note": "VALU-issue bound in practice, see `valu` (DESIGN.md 2, 4.1)",
+                         "valu": valu_picture(n / (ms_launch * 1e-3), BASHF_VALU)},
         }
         if dist.rank == 0:
             host = st.cpu().numpy()                               # pageable host copy of the same batch
@@ -331,7 +347,8 @@ def main():
             "roofline": {"kernel": "beltCTR_blocks_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms_launch,
                          "note": "VALU/LDS-issue bound, not HBM: per block ~695 VALU ops (floor 930 GiB/s) and "
-                                 "224 ds_read_b32 (floor 1146 GiB/s), DESIGN.md 2 and 4.2"},
+                                 "224 ds_read_b32 (floor 1146 GiB/s), DESIGN.md 2 and 4.2",
+                         "valu": valu_picture(nb / (ms_launch * 1e-3), CTR_VALU)},
         }
         if dist.rank == 0:
             hn = 1 << 30                                          # 1 GiB through the drop-in one-shot beltCTR
