@@ -433,6 +433,40 @@ uint32_t orc_beltECB(void *dest, const void *src, size_t count, const uint8_t *k
     return ORC_OK;
 }
 
+/* s <- s * x in GF(2^128) = GF(2)[x] / (x^128 + x^7 + x^2 + x + 1); s is the 128-bit little-endian
+   value s[0] + 2^32 s[1] + ... (beltBlockMulC, belt_lcl.c:99-108) */
+static void gf128_double(uint32_t s[4])
+{
+    const uint32_t out = s[3] >> 31;                 /* coefficient of x^127 leaves the block */
+    int i;
+    for (i = 3; i > 0; --i) s[i] = (s[i] << 1) | (s[i - 1] >> 31);
+    s[0] = (s[0] << 1) ^ (out ? 0x87u : 0u);        /* x^128 = x^7 + x^2 + x + 1 */
+}
+
+/* beltBDEEncr / beltBDEDecr (belt_bde.c:40-133): s <- E_K(iv); for every block
+   s <- s * x, Y = E_K(X ^ s) ^ s (decryption: D_K).  Whole blocks only. */
+uint32_t orc_beltBDE(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
+                     const uint8_t iv[16], int decr)
+{
+    uint32_t K[8], s[4], w[4];
+    uint8_t *buf = (uint8_t *)dest;
+    int i;
+    if (count < 16 || count % 16 || (len != 16 && len != 24 && len != 32)) return ORC_BAD_INPUT;
+    orc_beltKeyExpand2(K, key, len);
+    blk_load(s, iv);
+    orc_beltBlockEncr2(s, K);
+    memmove(dest, src, count);
+    for (; count; count -= 16, buf += 16) {
+        gf128_double(s);
+        blk_load(w, buf);
+        for (i = 0; i < 4; ++i) w[i] ^= s[i];
+        if (decr) orc_beltBlockDecr2(w, K); else orc_beltBlockEncr2(w, K);
+        for (i = 0; i < 4; ++i) w[i] ^= s[i];
+        blk_store(buf, w);
+    }
+    return ORC_OK;
+}
+
 /* beltCBCEncr / beltCBCDecr with ciphertext stealing (belt_cbc.c:63-193) */
 uint32_t orc_beltCBC(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
                      const uint8_t iv[16], int decr)

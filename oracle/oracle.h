@@ -93,6 +93,8 @@ uint32_t orc_beltECB(void *dest, const void *src, size_t count, const uint8_t *k
                      int decr);                                              /* belt_ecb.c:52-159 */
 uint32_t orc_beltCBC(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
                      const uint8_t iv[16], int decr);                        /* belt_cbc.c:63-193 */
+uint32_t orc_beltBDE(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
+                     const uint8_t iv[16], int decr);                        /* belt_bde.c:40-133 */
 
 void orc_beltCompr(uint32_t h[8], const uint32_t X[8]);        /* belt_compr.c:27-51 */
 uint32_t orc_beltHash(uint8_t hash[32], const void *src, size_t count); /* belt_hash.c:173-190 */

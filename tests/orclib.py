@@ -108,6 +108,11 @@ class Oracle:
         code = self.lib.orc_beltCBC(out, bytes(msg), _sz(len(msg)), bytes(key), _sz(len(key)), bytes(iv), int(decr))
         return code, out.raw[: len(msg)]
 
+    def bde(self, msg, key, iv, decr=False):
+        out = ctypes.create_string_buffer(max(len(msg), 1))
+        code = self.lib.orc_beltBDE(out, bytes(msg), _sz(len(msg)), bytes(key), _sz(len(key)), bytes(iv), int(decr))
+        return code, out.raw[: len(msg)]
+
     def block_decr(self, block, key):
         w = (ctypes.c_uint32 * 4).from_buffer_copy(bytes(block))
         self.lib.orc_beltBlockDecr2(w, self.key_expand(key))

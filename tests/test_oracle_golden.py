@@ -114,9 +114,25 @@ def test_belt_ecb_cbc_A9_A12(orc, golden):
         decr = k["fn"].endswith("Decr")
         if "ECB" in k["fn"]:
             code, out = orc.ecb(msg, key, decr)
-        else:
+        elif "CBC" in k["fn"]:
             code, out = orc.cbc(msg, key, bytes.fromhex(k["iv"]), decr)
+        else:                                                # belt-bde, A.24-1 / A.25-1 (belt_test.c:628-660)
+            assert "BDE" in k["fn"]
+            code, out = orc.bde(msg, key, bytes.fromhex(k["iv"]), decr)
         assert code == 0 and out.hex() == k["out"], k["name"]
+
+
+def test_belt_bde_random_cases(orc, golden):
+    """belt-bde of the reference on 1..1000 blocks, all key sizes (tools/make_golden.py bde_random)"""
+    assert len(golden.belt_bde) >= 18
+    for c in golden.belt_bde:
+        msg, key, iv = (bytes.fromhex(c[x]) for x in ("msg", "key", "iv"))
+        assert orc.bde(msg, key, iv) == (0, bytes.fromhex(c["bde_e"])), c["blocks"]
+        assert orc.bde(msg, key, iv, True) == (0, bytes.fromhex(c["bde_d"])), c["blocks"]
+        assert orc.bde(bytes.fromhex(c["bde_e"]), key, iv, True)[1] == msg       # D(E(x)) = x
+    for bad in (b"", b"x" * 15, b"x" * 17):                                      # whole blocks only, >= 1
+        assert orc.bde(bad, b"k" * 32, b"i" * 16)[0] == 109
+    assert orc.bde(b"x" * 16, b"k" * 31, b"i" * 16)[0] == 109
 
 
 def test_belt_ecb_cbc_random_cases(orc, golden):

@@ -182,6 +182,11 @@ def stb_kats():
          "730894D6158E17CC1600185A8F411CAB0471FF85C83792398D8924EBD57D03DB95B97A9B7907E4B020960455E46176F8"),
         ("A.12-2", "beltCBCDecr", H[64:100], H[160:192], H[208:224],
          "730894D6158E17CC1600185A8F411CABB6AB7AF8541CF85755B8EA27239F08D2166646E4"),
+        # belt-bde (belt_test.c:628-660)
+        ("A.24-1", "beltBDEEncr", H[:48], H[128:160], H[192:208],
+         "E9CAB32D879CC50C10378EB07C10F26307257E2DBE2B854CBC9F38282D59D6A77F952001C5D1244F53210A27C216D4BB"),
+        ("A.25-1", "beltBDEDecr", H[64:112], H[160:192], H[208:224],
+         "7041BC226352C706D00EA8EF23CFE46AFAE118577D037FACDC36E4ECC1F6574609F236943FB809E1BEE4A1C686C13ACC"),
     ]
     kat["belt_modes"] = []
     for name, fn, msg, key, iv, want in modes:
@@ -259,6 +264,20 @@ def belt_random(seed=0xBE17):
                       "belt_hash": r_belt_hash(msg).hex(),
                       "bash256": r_bashHash(128, msg).hex(), "bash384": r_bashHash(192, msg).hex(),
                       "bash512": r_bashHash(256, msg).hex()})
+    return cases
+
+
+def bde_random(seed=0xBDE):
+    """beltBDEEncr / beltBDEDecr of the reference (belt_bde.c:87-133) on whole-block messages;
+    block counts straddle the 64-lane wavefront and the per-wavefront chunk boundaries of the kernel"""
+    import random
+    rnd = random.Random(seed)
+    cases = []
+    for i, nb in enumerate((1, 2, 3, 4, 5, 31, 63, 64, 65, 127, 128, 129, 191, 255, 256, 257, 511, 1000)):
+        key, iv, msg = rnd.randbytes((16, 24, 32)[i % 3]), rnd.randbytes(16), rnd.randbytes(16 * nb)
+        cases.append({"blocks": nb, "key": key.hex(), "iv": iv.hex(), "msg": msg.hex(),
+                      "bde_e": r_mode("beltBDEEncr", msg, key, iv).hex(),
+                      "bde_d": r_mode("beltBDEDecr", msg, key, iv).hex()})
     return cases
 
 
@@ -490,6 +509,8 @@ def main():
         f.write(inp + out)
     with open(os.path.join(GOLD, "belt_bash_random.json"), "w") as f:
         json.dump(belt_random(), f, indent=1)
+    with open(os.path.join(GOLD, "belt_bde_random.json"), "w") as f:
+        json.dump(bde_random(), f, indent=1)
     base, edge = bign_sets()
     with open(os.path.join(GOLD, "bign_base.bin"), "wb") as f:      # n x (hash32 | sig48 | pub64)
         for h, s, p in base:

@@ -32,6 +32,18 @@ def main(n_verify=100_000):
     L.beltCTR(out, data, _sz(len(data)), H[128:160], _sz(32), H[192:208])
     print(f"beltCTR 1e6 blocks     equal={orc.ctr(data, H[128:160], H[192:208]) == out.raw}  {time.time()-t0:.1f}s")
     t0 = time.time()
+    rnd = random.Random(5)
+    ok, nblk = True, 0
+    for _ in range(400):                                   # belt-bde (8f-1): lengths 1..2000 blocks, all key sizes
+        nb = rnd.choice((1, 2, 3, 63, 64, 65, 127, 128, 129)) if rnd.random() < 0.5 else rnd.randrange(1, 2000)
+        msg, key, iv = rnd.randbytes(16 * nb), rnd.randbytes(rnd.choice((16, 24, 32))), rnd.randbytes(16)
+        for fn, decr in (("beltBDEEncr", False), ("beltBDEDecr", True)):
+            out = ctypes.create_string_buffer(len(msg))
+            assert getattr(L, fn)(out, msg, _sz(len(msg)), key, _sz(len(key)), iv) == 0
+            ok = ok and orc.bde(msg, key, iv, decr) == (0, out.raw)
+        nblk += 2 * nb
+    print(f"beltBDE {nblk} blocks     equal={ok}  {time.time()-t0:.1f}s")
+    t0 = time.time()
     rnd = random.Random(3)
     base_tr = refgen.make_triples(4096, 0xB164)
     hs, ss, ps, want = bytearray(), bytearray(), bytearray(), []
