@@ -342,4 +342,61 @@ __device__ __forceinline__ void belt_compress(const Tab &T, uint32_t (&s1)[4], u
     for (int i = 0; i < 4; ++i) { h[i] = y0[i] ^ X[i]; h[4 + i] = y1[i] ^ X[4 + i]; }
 }
 
+// ---------------------------------------------------------------- GF(2^128) ---
+// belt-bde tweaks (belt_bde.c:58, belt_lcl.c:99-108): elements of GF(2)[x] / (x^128 + x^7 + x^2 + x + 1),
+// bit i of the 128-bit little-endian block = coefficient of x^i.  Only multiplications by powers
+// of x are needed on the data path; the general product serves the jump-ahead of the tweak kernel.
+struct Gf128 { uint64_t lo, hi; };
+
+// r ^= over * (x^7 + x^2 + x + 1), i.e. `over` x^128 reduced; over < 2^64 so the product is < 2^71
+__device__ __forceinline__ Gf128 gf_fold(Gf128 r, uint64_t over)
+{
+    r.lo ^= over ^ (over << 1) ^ (over << 2) ^ (over << 7);
+    r.hi ^= (over >> 63) ^ (over >> 62) ^ (over >> 57);
+    return r;
+}
+// s * x^k, 0 <= k < 64 (k may differ per lane)
+__device__ __forceinline__ Gf128 gf_mul_xk(Gf128 s, unsigned k)
+{
+    if (k == 0) return s;
+    Gf128 r;
+    r.hi = (s.hi << k) | (s.lo >> (64 - k));
+    r.lo = s.lo << k;
+    return gf_fold(r, s.hi >> (64 - k));
+}
+// s * x^64: the halves move up, the old high half comes back folded
+__device__ __forceinline__ Gf128 gf_mul_x64(Gf128 s)
+{
+    Gf128 r;
+    r.hi = s.lo;
+    r.lo = 0;
+    return gf_fold(r, s.hi);
+}
+// general product (shift-and-add over the bits of b); jump-ahead only
+__device__ inline Gf128 gf_mul(Gf128 a, Gf128 b)
+{
+    Gf128 r = {0, 0};
+#pragma unroll 1
+    for (int i = 0; i < 128; ++i) {
+        const uint64_t bit = ((i < 64 ? b.lo >> i : b.hi >> (i - 64)) & 1ull);
+        const uint64_t m = 0ull - bit;
+        r.lo ^= a.lo & m;
+        r.hi ^= a.hi & m;
+        a = gf_mul_xk(a, 1);
+    }
+    return r;
+}
+// s * x^e for any 64-bit e
+__device__ inline Gf128 gf_mul_xpow(Gf128 s, uint64_t e)
+{
+    Gf128 base = {2, 0};                 // x
+#pragma unroll 1
+    while (e) {
+        if (e & 1) s = gf_mul(s, base);
+        e >>= 1;
+        if (e) base = gf_mul(base, base);
+    }
+    return s;
+}
+
 }  // namespace bee2hip

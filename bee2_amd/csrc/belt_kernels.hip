@@ -134,6 +134,61 @@ void belt_modes_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, s
     }
 }
 
+// ---------------------------------------------------------------- belt-bde ---
+// Block i (0-based, counted from the Start of the stream) uses the tweak s * x^(i+1) and
+// Y = E_K(X ^ t) ^ t (belt_bde.c:51-85).  A wavefront owns one contiguous chunk of the stream;
+// lane l starts at block c0 + l with t = B * x^l, where B = s * x^(c0+1) comes from
+// bde_tweak_kernel, and steps 64 blocks at a time: t <- t * x^64, a swap of halves plus one fold.
+// Every global access is 64 consecutive blocks = 1 KiB per wave-instruction.
+//
+// tweaks[w] = s * x^(first + w*chunk + 1) for w < nwaves; tweaks[nwaves] = s * x^(first + nblocks),
+// the value beltBDEStepE leaves in belt_bde_st.s.
+__global__ __launch_bounds__(64)
+void bde_tweak_kernel(BeltCtr s0, uint64_t first, uint64_t chunk, uint64_t nblocks, unsigned nwaves,
+                      uint4 *__restrict__ tweaks)
+{
+    const unsigned w = blockIdx.x * 64 + threadIdx.x;
+    if (w > nwaves) return;
+    Gf128 s;
+    s.lo = (uint64_t)s0.c[0] | (uint64_t)s0.c[1] << 32;
+    s.hi = (uint64_t)s0.c[2] | (uint64_t)s0.c[3] << 32;
+    const uint64_t e = w < nwaves ? first + (uint64_t)w * chunk + 1 : first + nblocks;
+    s = gf_mul_xpow(s, e);
+    tweaks[w] = make_uint4((uint32_t)s.lo, (uint32_t)(s.lo >> 32), (uint32_t)s.hi, (uint32_t)(s.hi >> 32));
+}
+
+template <int DECR>
+__global__ __launch_bounds__(CTR_WG)
+void belt_bde_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t nblocks, uint64_t chunk,
+                     BeltKey key, const uint4 *__restrict__ tweaks)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    CtrTab::fill(smem, threadIdx.x, CTR_WG);
+    __syncthreads();
+    const CtrTab T(smem);
+    uint32_t K[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) K[i] = key.k[i];
+    const unsigned lane = threadIdx.x & 63u;
+    const uint64_t w = (uint64_t)blockIdx.x * (CTR_WG / 64) + (threadIdx.x >> 6);     // global wavefront
+    const uint64_t c0 = w * chunk;
+    if (c0 >= nblocks) return;
+    const uint64_t end = c0 + chunk < nblocks ? c0 + chunk : nblocks;
+    const uint4 b = tweaks[w];
+    Gf128 t;
+    t.lo = (uint64_t)b.x | (uint64_t)b.y << 32;
+    t.hi = (uint64_t)b.z | (uint64_t)b.w << 32;
+    t = gf_mul_xk(t, lane);
+    for (uint64_t i = c0 + lane; i < end; i += 64) {
+        const uint4 v = src[i];
+        const uint32_t t0 = (uint32_t)t.lo, t1 = (uint32_t)(t.lo >> 32), t2 = (uint32_t)t.hi, t3 = (uint32_t)(t.hi >> 32);
+        uint32_t x[4] = {v.x ^ t0, v.y ^ t1, v.z ^ t2, v.w ^ t3};
+        if (DECR) belt_decr(T, x, K); else belt_encr(T, x, K);
+        dst[i] = make_uint4(x[0] ^ t0, x[1] ^ t1, x[2] ^ t2, x[3] ^ t3);
+        t = gf_mul_x64(t);
+    }
+}
+
 // CBC encryption is a serial chain per message (belt_cbc.c:63-84): one lane per message,
 // n messages of nblk full blocks each, per-message iv, in place.  ivs[m] receives the last
 // ciphertext block (the chaining value bee2 keeps in belt_cbc_st.block).
@@ -262,6 +317,58 @@ err_t launch_belt_modes(int mode, const void *d_src, void *d_dst, size_t nblocks
     if (mode == 1) return launch_modes_t<1>(d_src, d_dst, nblocks, k, c, st);
     if (mode == 2) { if (d_src == d_dst) return ERR_BAD_INPUT; return launch_modes_t<2>(d_src, d_dst, nblocks, k, c, st); }
     return ERR_BAD_INPUT;
+}
+
+template <int DECR>
+static err_t launch_bde_t(const void *d_src, void *d_dst, uint64_t nblocks, uint64_t chunk, unsigned grid,
+                          const BeltKey &k, const uint4 *tweaks, hipStream_t st)
+{
+    static bool attr[64];
+    auto kern = belt_bde_kernel<DECR>;
+    if (!attr[cur_dev()]) {
+        B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, CtrTab::kBytes));
+        attr[cur_dev()] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(CTR_WG), CtrTab::kBytes, st, (const uint4 *)d_src, (uint4 *)d_dst,
+                       nblocks, chunk, k, tweaks);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
+// belt-bde over nblocks whole blocks that start `first` blocks after beltBDEStart (s = E_K(iv), as
+// words); d_src may equal d_dst.  d_s_out (may be null) receives s * x^(first + nblocks), 16 bytes.
+err_t launch_belt_bde(int decr, const void *d_src, void *d_dst, size_t nblocks, const uint32_t key[8],
+                      const uint32_t s[4], uint64_t first, void *d_s_out, hipStream_t st)
+{
+    if (nblocks == 0 && !d_s_out) return ERR_OK;
+    BeltKey k; BeltCtr s0;
+    for (int i = 0; i < 8; ++i) k.k[i] = key[i];
+    for (int i = 0; i < 4; ++i) s0.c[i] = s[i];
+    // persistent grid as for CTR; every wavefront gets one contiguous chunk (a multiple of 64 blocks)
+    const size_t wg_waves = CTR_WG / 64;
+    size_t grid = (nblocks + CTR_WG - 1) / CTR_WG;
+    const size_t cap = (size_t)num_cus() * (BeltTabWide::kBytes / CtrTab::kBytes);
+    if (grid > cap) grid = cap;
+    if (grid == 0) grid = 1;
+    const uint64_t nwaves = grid * wg_waves;
+    uint64_t chunk = (nblocks + nwaves - 1) / nwaves;
+    chunk = (chunk + 63) / 64 * 64;
+    if (chunk == 0) chunk = 64;
+    void *tw = nullptr;
+    err_t code = scratch_for_stream(st, 8, (nwaves + 1) * 16, &tw);
+    if (code != ERR_OK) return code;
+    hipLaunchKernelGGL(bde_tweak_kernel, dim3((unsigned)((nwaves + 1 + 63) / 64)), dim3(64), 0, st, s0,
+                       (uint64_t)first, chunk, (uint64_t)nblocks, (unsigned)nwaves, (uint4 *)tw);
+    B2H_TRY(hipGetLastError());
+    if (nblocks) {
+        code = decr ? launch_bde_t<1>(d_src, d_dst, nblocks, chunk, (unsigned)grid, k, (const uint4 *)tw, st)
+                    : launch_bde_t<0>(d_src, d_dst, nblocks, chunk, (unsigned)grid, k, (const uint4 *)tw, st);
+        if (code != ERR_OK) return code;
+    }
+    if (d_s_out)
+        B2H_TRY(hipMemcpyAsync(d_s_out, (const uint4 *)tw + nwaves, 16, hipMemcpyDeviceToDevice, st));
+    return ERR_OK;
 }
 
 err_t launch_belt_cbc_encr(void *d_msgs, size_t nblk, size_t n, const uint32_t key[8], void *d_ivs, hipStream_t st)

@@ -866,6 +866,86 @@ extern "C" err_t beltECBDecr(void *dest, const void *src, size_t count, const oc
     return ecb_oneshot(dest, src, count, key, len, 1);
 }
 
+// ------------------------------------------------------------------ belt-bde ---
+struct belt_bde_st {          // belt_bde.c:26-32
+    u32 key[8];
+    u32 s[4];
+    octet block[16];
+    octet block1[16];
+};
+extern "C" size_t beltBDE_keep(void) { return sizeof(belt_bde_st); }
+extern "C" void beltBDEStart(void *state, const octet key[], size_t len, const octet iv[16])
+{
+    belt_bde_st *st = (belt_bde_st *)state;
+    beltKeyExpand2(st->key, key, len);
+    for (int i = 0; i < 4; ++i) st->s[i] = load32le(iv + 4 * i);
+    beltBlockEncr2(st->s, st->key);                 // s = E_K(iv), on the GPU
+}
+
+extern "C" err_t bee2hip_beltBDE_blocks_dev(int decr, const void *d_src, void *d_dst, size_t nblocks,
+                                            const u32 key[8], const u32 s[4], uint64_t first_block,
+                                            void *d_s_out, void *stream)
+{
+    if ((nblocks && (!d_src || !d_dst)) || !key || !s || (decr != 0 && decr != 1)) return ERR_BAD_INPUT;
+    if (first_block + nblocks < first_block || first_block + nblocks == ~(uint64_t)0) return ERR_BAD_INPUT;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    return launch_belt_bde(decr, d_src, d_dst, nblocks, key, s, first_block, d_s_out, as_stream(stream));
+}
+
+// whole blocks of a host buffer; advances st->s exactly as the reference's loop does
+static err_t bde_host(int decr, octet *buf, size_t nblocks, belt_bde_st *st)
+{
+    if (nblocks == 0) return ERR_OK;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    Scratch &sc = t_scr[2];
+    const size_t bytes = nblocks * 16;
+    code = sc.need(bytes + 16);
+    if (code != ERR_OK) return code;
+    octet *d = (octet *)sc.p;
+    B2H_TRY(hipMemcpy(d, buf, bytes, hipMemcpyHostToDevice));
+    code = launch_belt_bde(decr, d, d, nblocks, st->key, st->s, 0, d + bytes, nullptr);
+    if (code != ERR_OK) return code;
+    octet snew[16];
+    B2H_TRY(hipMemcpy(buf, d, bytes, hipMemcpyDeviceToHost));
+    B2H_TRY(hipMemcpy(snew, d + bytes, 16, hipMemcpyDeviceToHost));
+    // what the reference's last iteration leaves behind (belt_bde.c:56-63): s, block = <s>, block1 = Y ^ <s>
+    for (int i = 0; i < 4; ++i) st->s[i] = load32le(snew + 4 * i);
+    memcpy(st->block, snew, 16);
+    for (int i = 0; i < 16; ++i) st->block1[i] = buf[bytes - 16 + i] ^ snew[i];
+    return ERR_OK;
+}
+extern "C" void beltBDEStepE(void *buf, size_t count, void *state)
+{
+    die_on(bde_host(0, (octet *)buf, count / 16, (belt_bde_st *)state), "beltBDEStepE");
+}
+extern "C" void beltBDEStepD(void *buf, size_t count, void *state)
+{
+    die_on(bde_host(1, (octet *)buf, count / 16, (belt_bde_st *)state), "beltBDEStepD");
+}
+static err_t bde_oneshot(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                         const octet iv[16], int decr)
+{
+    // belt_bde.c:93-100, 118-125
+    if (count % 16 != 0 || count < 16 || (len != 16 && len != 24 && len != 32) || !src || !dest || !key || !iv)
+        return ERR_BAD_INPUT;
+    belt_bde_st st;
+    beltBDEStart(&st, key, len, iv);
+    memmove(dest, src, count);
+    return bde_host(decr, (octet *)dest, count / 16, &st);
+}
+extern "C" err_t beltBDEEncr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                             const octet iv[16])
+{
+    return bde_oneshot(dest, src, count, key, len, iv, 0);
+}
+extern "C" err_t beltBDEDecr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                             const octet iv[16])
+{
+    return bde_oneshot(dest, src, count, key, len, iv, 1);
+}
+
 struct belt_cbc_st {          // belt_cbc.c:63-68
     u32 key[8];
     octet block[16];

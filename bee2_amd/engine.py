@@ -54,6 +54,7 @@ DROPIN_SYMBOLS = [
     "beltBlockDecr", "beltBlockDecr2", "beltBlockDecr3",
     "beltECB_keep", "beltECBStart", "beltECBStepE", "beltECBStepD", "beltECBEncr", "beltECBDecr",
     "beltCBC_keep", "beltCBCStart", "beltCBCStepE", "beltCBCStepD", "beltCBCEncr", "beltCBCDecr",
+    "beltBDE_keep", "beltBDEStart", "beltBDEStepE", "beltBDEStepD", "beltBDEEncr", "beltBDEDecr",
     "beltMAC_keep", "beltMACStart", "beltMACStepA", "beltMACStepG", "beltMACStepG2",
     "beltMACStepV", "beltMACStepV2", "beltMAC",
     "bignParamsStd", "bignVerify", "bign128Verify", "bign192Verify", "bign256Verify",
@@ -62,7 +63,7 @@ BATCH_SYMBOLS = [
     "bee2hip_bashF_batch", "bee2hip_beltCTR_bulk", "bee2hip_bignVerify_batch",
     "bee2hip_bashHash_beltMAC_batch", "bee2hip_hash_ragged", "bee2hip_hash_ragged_dev", "bee2hip_hash_ragged_ordered_dev",
     "bee2hip_bashF_batch_dev", "bee2hip_beltCTR_blocks_dev", "bee2hip_beltBlockEncr_dev",
-    "bee2hip_beltModes_blocks_dev", "bee2hip_beltCBCEncr_batch_dev",
+    "bee2hip_beltModes_blocks_dev", "bee2hip_beltCBCEncr_batch_dev", "bee2hip_beltBDE_blocks_dev",
     "bee2hip_bign128Verify_batch_dev", "bee2hip_bignVerify_batch_dev", "bee2hip_bignVerifyL_batch_dev",
     "bee2hip_bashHash_beltMAC_batch_dev",
     "bee2hip_set_device", "bee2hip_sync", "bee2hip_last_error", "bee2hip_version",
@@ -154,6 +155,23 @@ class Engine:
         self._check(self.lib.bee2hip_beltModes_blocks_dev(int(mode), self._ptr(src), self._ptr(dst), _sz(n),
                                                           bytes(key_words), bytes(iv_words) if iv_words else None,
                                                           self._stream()), "beltModes_blocks_dev")
+
+    def beltBDEStart(self, key, iv):
+        """-> (expanded key, s = E_K(iv)) as 32 + 16 bytes of u32 words, for beltBDE_blocks_dev"""
+        st = ctypes.create_string_buffer(self.lib.beltBDE_keep())
+        self.lib.beltBDEStart(st, bytes(key), _sz(len(key)), bytes(iv))
+        return st.raw[:32], st.raw[32:48]
+
+    def beltBDE_blocks_dev(self, decr, src, dst, key_words, s_words, first_block=0, s_out=None):
+        """belt-bde on whole blocks in HBM; the piece starts first_block blocks into the stream;
+        s_out (16-byte device tensor, optional) receives the state after the piece"""
+        n = src.numel() // 16
+        assert src.numel() == 16 * n and dst.numel() == 16 * n
+        self._check(self.lib.bee2hip_beltBDE_blocks_dev(int(decr), self._ptr(src), self._ptr(dst), _sz(n),
+                                                        bytes(key_words), bytes(s_words),
+                                                        ctypes.c_uint64(first_block),
+                                                        self._ptr(s_out) if s_out is not None else None,
+                                                        self._stream()), "beltBDE_blocks_dev")
 
     def beltCBCEncr_batch_dev(self, msgs, nblk, key_words, ivs):
         n = ivs.numel() // 16
@@ -304,7 +322,7 @@ class Engine:
         return b.raw
 
     def belt_mode(self, fn, src, key, iv=None):
-        """one-shot beltECBEncr / beltECBDecr / beltCBCEncr / beltCBCDecr"""
+        """one-shot beltECBEncr / beltECBDecr / beltCBCEncr / beltCBCDecr / beltBDEEncr / beltBDEDecr"""
         out = ctypes.create_string_buffer(max(len(src), 1))
         f = getattr(self.lib, fn)
         if iv is None:
@@ -314,12 +332,12 @@ class Engine:
         return code, out.raw[: len(src)]
 
     def belt_mode_steps(self, mode, decr, src, key, iv, splits):
-        """Start / Step{E,D}* of beltECB (mode 'ECB') or beltCBC ('CBC')"""
+        """Start / Step{E,D}* of beltECB (mode 'ECB'), beltCBC ('CBC') or beltBDE ('BDE')"""
         st = ctypes.create_string_buffer(getattr(self.lib, f"belt{mode}_keep")())
         if mode == "ECB":
             self.lib.beltECBStart(st, bytes(key), _sz(len(key)))
         else:
-            self.lib.beltCBCStart(st, bytes(key), _sz(len(key)), bytes(iv))
+            getattr(self.lib, f"belt{mode}Start")(st, bytes(key), _sz(len(key)), bytes(iv))
         step = getattr(self.lib, f"belt{mode}Step{'D' if decr else 'E'}")
         buf = ctypes.create_string_buffer(bytes(src), len(src))
         off = 0

@@ -551,10 +551,16 @@ def main():
         fill_seeded(src, 0xBE17 + dist.rank)
         dst = torch.empty_like(src)
         km = max(3, min(K, 10))
-        entry = {"metric": "belt ECB/CBC bulk GiB/s", "unit": "GiB/s", "steps": km,
+        entry = {"metric": "belt ECB/CBC/BDE bulk GiB/s", "unit": "GiB/s", "steps": km,
                  "config": {"workload": f"{nbytes / 2**30:.0f} GiB of full blocks per GPU, one key (SURVEY 8f-1)"}}
         for name, mode in (("ecb_encr", 0), ("ecb_decr", 1), ("cbc_decr", 2)):
             el = timed(dist, km, 1, lambda: eng.beltModes_blocks_dev(mode, src, dst, kw, c0))
+            entry[name] = N * nbytes * km / el / 2 ** 30
+        # belt-bde: rank r owns blocks [r*nb, (r+1)*nb) of one stream (first_block), like CTR
+        bkw, bs0 = eng.beltBDEStart(H[128:160], H[192:208])
+        for name, decr in (("bde_encr", 0), ("bde_decr", 1)):
+            el = timed(dist, km, 1, lambda: eng.beltBDE_blocks_dev(decr, src, dst, bkw, bs0,
+                                                                   first_block=dist.rank * (nbytes // 16)))
             entry[name] = N * nbytes * km / el / 2 ** 30
         entry["value"] = entry["ecb_encr"]
         entry["ms_per_step"] = nbytes / 2 ** 30 / entry["ecb_encr"] * 1e3 * N
@@ -569,7 +575,8 @@ def main():
                 cpu = {"cores": cores, "kind": "reference", "unit": "GiB/s",
                        "sample": "64 MiB of full blocks, threads over disjoint slices"}
                 for name, fn, iv in (("ecb_encr", "beltECBEncr", None), ("ecb_decr", "beltECBDecr", None),
-                                     ("cbc_decr", "beltCBCDecr", H[192:208])):
+                                     ("cbc_decr", "beltCBCDecr", H[192:208]), ("bde_encr", "beltBDEEncr", H[192:208]),
+                                     ("bde_decr", "beltBDEDecr", H[192:208])):
                     fp = ctypes.cast(getattr(ref, fn), ctypes.c_void_p)
                     t0, reps = time.perf_counter(), 0
                     while time.perf_counter() - t0 < 1.5:

@@ -114,6 +114,20 @@ err_t beltCBCEncr(void *dest, const void *src, size_t count, const octet key[], 
 err_t beltCBCDecr(void *dest, const void *src, size_t count, const octet key[], size_t len,
                   const octet iv[16]);
 
+/* belt-bde, block-wise disk encryption (belt.h:1360-1455, src/crypto/belt/belt_bde.c:26-133):
+   s <- E_K(iv); for every 16-byte block s <- s*x in GF(2^128), Y = E_K(X ^ s) ^ s (StepD: D_K).
+   count must be a multiple of 16; the one-shots return ERR_BAD_INPUT for count < 16 or
+   count % 16 != 0 (belt_bde.c:93-100).  belt-sde is NOT provided: it wraps belt-wbl, a serial
+   wide-block construction over the whole sector (belt_sde.c:38-71, belt_wbl.c). */
+size_t beltBDE_keep(void);
+void beltBDEStart(void *state, const octet key[], size_t len, const octet iv[16]);
+void beltBDEStepE(void *buf, size_t count, void *state);
+void beltBDEStepD(void *buf, size_t count, void *state);
+err_t beltBDEEncr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                  const octet iv[16]);
+err_t beltBDEDecr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                  const octet iv[16]);
+
 /* belt.h:756-854, src/crypto/belt/belt_mac.c:32-203 */
 size_t beltMAC_keep(void);
 void beltMACStart(void *state, const octet key[], size_t len);
@@ -200,6 +214,14 @@ err_t bee2hip_beltModes_blocks_dev(int mode, const void *d_src, void *d_dst, siz
    message; d_ivs[n][16] holds each message's iv on entry and its last ciphertext block on exit */
 err_t bee2hip_beltCBCEncr_batch_dev(void *d_msgs, size_t nblk, size_t n, const u32 key[8],
                                     void *d_ivs, void *stream);
+/* belt-bde on nblocks whole blocks, device resident, d_src may equal d_dst.  s[4] = E_K(iv) as
+   u32 words (what beltBDEStart leaves in the state); the blocks are the ones first_block ..
+   first_block + nblocks - 1 of the stream, i.e. block j uses the tweak s * x^(j+1) -- a stream can
+   be cut into pieces (or sharded across GPUs) at any block boundary.  decr = 0 / 1.
+   d_s_out (may be NULL) receives s * x^(first_block + nblocks), 16 bytes: the state after the piece. */
+err_t bee2hip_beltBDE_blocks_dev(int decr, const void *d_src, void *d_dst, size_t nblocks,
+                                 const u32 key[8], const u32 s[4], uint64_t first_block,
+                                 void *d_s_out, void *stream);
 err_t bee2hip_bign128Verify_batch_dev(const void *d_hashes, const void *d_sigs,
                                       const void *d_pubkeys, size_t n, void *d_codes,
                                       void *stream);

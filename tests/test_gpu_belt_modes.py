@@ -29,7 +29,7 @@ def test_ecb_cbc_A9_A12_dropin(golden):
         iv = bytes.fromhex(k["iv"]) if k["iv"] else None
         code, out = eng.belt_mode(k["fn"], msg, key, iv)
         assert code == 0 and out.hex() == k["out"], k["name"]
-        mode = "ECB" if "ECB" in k["fn"] else "CBC"
+        mode = k["fn"][4:7]                                   # ECB / CBC / BDE
         decr = k["fn"].endswith("Decr")
         # the reference's own split pattern: 16 or 32 bytes first, the rest (with the steal) second
         first = 32 if len(msg) == 48 and not decr else 16
