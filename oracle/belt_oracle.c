@@ -467,6 +467,112 @@ uint32_t orc_beltBDE(void *dest, const void *src, size_t count, const uint8_t *k
     return ORC_OK;
 }
 
+/* ---- belt-dwp: CTR encryption + polynomial MAC over GF(2^128) ------------
+   State machine of belt_dwp.c:27-196.  The authenticator is t <- (t ^ X) * r for every 16-byte
+   block X of the open data, then of the critical data (each zero-padded to whole blocks), then of
+   the block <bit length of open data>_64 || <bit length of critical data>_64; mac = E_K(t)[0..8). */
+static void gf128_mul(uint32_t c[4], const uint32_t a_[4], const uint32_t b[4])     /* belt_lcl.c:119-132 */
+{
+    uint32_t a[4] = {a_[0], a_[1], a_[2], a_[3]}, r[4] = {0, 0, 0, 0};
+    int i, j;
+    for (i = 0; i < 128; ++i) {
+        if ((b[i >> 5] >> (i & 31)) & 1u) for (j = 0; j < 4; ++j) r[j] ^= a[j];
+        gf128_double(a);
+    }
+    for (j = 0; j < 4; ++j) c[j] = r[j];
+}
+static void dwp_absorb(uint32_t t[4], const uint8_t block[16], const uint32_t r[4])
+{
+    uint32_t x[4];
+    int i;
+    blk_load(x, block);
+    for (i = 0; i < 4; ++i) x[i] ^= t[i];
+    gf128_mul(t, x, r);
+}
+void orc_beltDWPStart(orc_belt_dwp_st *st, const uint8_t *key, size_t len, const uint8_t iv[16])
+{
+    int i;
+    orc_beltCTRStart(&st->ctr, key, len, iv);                   /* ctr = E_K(iv) */
+    for (i = 0; i < 4; ++i) st->r[i] = st->ctr.ctr[i];
+    orc_beltBlockEncr2(st->r, st->ctr.key);                     /* r = E_K(ctr), belt_dwp.c:52-54 */
+    blk_load(st->t, orc_beltH());                               /* t = H[0..16), :59 */
+    st->bits_open = st->bits_crit = 0;
+    st->filled = 0;
+}
+void orc_beltDWPStepE(void *buf, size_t count, orc_belt_dwp_st *st) { orc_beltCTRStepE(buf, count, &st->ctr); }
+static void dwp_feed(orc_belt_dwp_st *st, const uint8_t *p, size_t count)
+{
+    while (count) {
+        size_t take = 16 - st->filled;
+        if (take > count) take = count;
+        memcpy(st->block + st->filled, p, take);
+        st->filled += take; p += take; count -= take;
+        if (st->filled == 16) { dwp_absorb(st->t, st->block, st->r); st->filled = 0; }
+    }
+}
+static void dwp_flush(orc_belt_dwp_st *st)
+{
+    if (st->filled) {
+        memset(st->block + st->filled, 0, 16 - st->filled);
+        dwp_absorb(st->t, st->block, st->r);
+        st->filled = 0;
+    }
+}
+void orc_beltDWPStepI(const void *buf, size_t count, orc_belt_dwp_st *st)       /* belt_dwp.c:68-107 */
+{
+    st->bits_open += (uint64_t)count * 8;
+    dwp_feed(st, (const uint8_t *)buf, count);
+}
+void orc_beltDWPStepA(const void *buf, size_t count, orc_belt_dwp_st *st)       /* belt_dwp.c:109-155 */
+{
+    if (count && st->bits_crit == 0) dwp_flush(st);        /* open data ends on a block boundary */
+    st->bits_crit += (uint64_t)count * 8;
+    dwp_feed(st, (const uint8_t *)buf, count);
+}
+void orc_beltDWPStepG(uint8_t mac[8], const orc_belt_dwp_st *st)                /* belt_dwp.c:162-189 */
+{
+    orc_belt_dwp_st c = *st;                               /* the state itself is not disturbed */
+    uint8_t lenblk[16], out[16];
+    int i;
+    dwp_flush(&c);
+    for (i = 0; i < 8; ++i) {
+        lenblk[i] = (uint8_t)(c.bits_open >> (8 * i));
+        lenblk[8 + i] = (uint8_t)(c.bits_crit >> (8 * i));
+    }
+    dwp_absorb(c.t, lenblk, c.r);
+    orc_beltBlockEncr2(c.t, c.ctr.key);
+    blk_store(out, c.t);
+    memcpy(mac, out, 8);
+}
+uint32_t orc_beltDWPWrap(void *dest, uint8_t mac[8], const void *src1, size_t count1, const void *src2,
+                         size_t count2, const uint8_t *key, size_t len, const uint8_t iv[16])
+{
+    orc_belt_dwp_st st;
+    if (len != 16 && len != 24 && len != 32) return ORC_BAD_INPUT;
+    orc_beltDWPStart(&st, key, len, iv);
+    orc_beltDWPStepI(src2, count2, &st);
+    memmove(dest, src1, count1);
+    orc_beltDWPStepE(dest, count1, &st);
+    orc_beltDWPStepA(dest, count1, &st);
+    orc_beltDWPStepG(mac, &st);
+    return ORC_OK;
+}
+uint32_t orc_beltDWPUnwrap(void *dest, const void *src1, size_t count1, const void *src2, size_t count2,
+                           const uint8_t mac[8], const uint8_t *key, size_t len, const uint8_t iv[16])
+{
+    orc_belt_dwp_st st;
+    uint8_t m[8];
+    if (len != 16 && len != 24 && len != 32) return ORC_BAD_INPUT;
+    orc_beltDWPStart(&st, key, len, iv);
+    orc_beltDWPStepI(src2, count2, &st);
+    orc_beltDWPStepA(src1, count1, &st);
+    orc_beltDWPStepG(m, &st);
+    if (memcmp(m, mac, 8)) return ORC_BAD_MAC;             /* ERR_BAD_MAC, nothing is decrypted */
+    memmove(dest, src1, count1);
+    orc_beltDWPStepE(dest, count1, &st);
+    return ORC_OK;
+}
+
 /* beltCBCEncr / beltCBCDecr with ciphertext stealing (belt_cbc.c:63-193) */
 uint32_t orc_beltCBC(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
                      const uint8_t iv[16], int decr)

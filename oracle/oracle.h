@@ -33,6 +33,7 @@ extern "C" {
 #define ORC_BAD_OID       301u
 #define ORC_BAD_PARAMS    502u
 #define ORC_BAD_PUBKEY    505u
+#define ORC_BAD_MAC       511u   /* err.h:198 */
 #define ORC_BAD_SIG       510u
 
 /* ---- bash (STB 34.101.77) ------------------------------------------------ */
@@ -95,6 +96,24 @@ uint32_t orc_beltCBC(void *dest, const void *src, size_t count, const uint8_t *k
                      const uint8_t iv[16], int decr);                        /* belt_cbc.c:63-193 */
 uint32_t orc_beltBDE(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
                      const uint8_t iv[16], int decr);                        /* belt_bde.c:40-133 */
+
+/* belt-dwp, authenticated encryption (belt_dwp.c:27-274) */
+typedef struct {
+    orc_belt_ctr_st ctr;
+    uint32_t r[4], t[4];
+    uint64_t bits_open, bits_crit;
+    uint8_t block[16];
+    size_t filled;
+} orc_belt_dwp_st;
+void orc_beltDWPStart(orc_belt_dwp_st *st, const uint8_t *key, size_t len, const uint8_t iv[16]);
+void orc_beltDWPStepE(void *buf, size_t count, orc_belt_dwp_st *st);            /* = StepD */
+void orc_beltDWPStepI(const void *buf, size_t count, orc_belt_dwp_st *st);
+void orc_beltDWPStepA(const void *buf, size_t count, orc_belt_dwp_st *st);
+void orc_beltDWPStepG(uint8_t mac[8], const orc_belt_dwp_st *st);
+uint32_t orc_beltDWPWrap(void *dest, uint8_t mac[8], const void *src1, size_t count1, const void *src2,
+                         size_t count2, const uint8_t *key, size_t len, const uint8_t iv[16]);
+uint32_t orc_beltDWPUnwrap(void *dest, const void *src1, size_t count1, const void *src2, size_t count2,
+                           const uint8_t mac[8], const uint8_t *key, size_t len, const uint8_t iv[16]);
 
 void orc_beltCompr(uint32_t h[8], const uint32_t X[8]);        /* belt_compr.c:27-51 */
 uint32_t orc_beltHash(uint8_t hash[32], const void *src, size_t count); /* belt_hash.c:173-190 */

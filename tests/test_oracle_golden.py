@@ -122,6 +122,51 @@ def test_belt_ecb_cbc_A9_A12(orc, golden):
         assert code == 0 and out.hex() == k["out"], k["name"]
 
 
+def _dwp_ops_from_kat(k):
+    """the step pattern of belt_test.c:473-543 as orclib ops (E/D consume the plaintext/ciphertext that
+    is being transformed, I the open data, A the ciphertext)"""
+    crit, op = bytes.fromhex(k["crit"]), bytes.fromhex(k["open"])
+    out = bytes.fromhex(k["out"])
+    ct = out if k["op"] == "wrap" else crit                  # what is authenticated is always the ciphertext
+    pos = {"E": 0, "D": 0, "I": 0, "A": 0}
+    src = {"E": crit, "D": crit, "I": op, "A": ct}
+    ops = []
+    for st in k["steps"]:
+        if st[0] == "G":
+            ops.append(("G",))
+        else:
+            ops.append((st[0], src[st[0]][pos[st[0]]: pos[st[0]] + st[1]]))
+            pos[st[0]] += st[1]
+    return ops
+
+
+def test_belt_dwp_A19_A20_and_golden(orc, golden):
+    """belt-dwp (belt_test.c:473-543) -- STB A.19-1 / A.20-1 with the reference's incremental
+    pattern (tags taken mid-stream), the reference's outputs on short inputs, and on long seeded ones"""
+    g = golden.belt_dwp
+    for k in g["kat"]:
+        key, iv = bytes.fromhex(k["key"]), bytes.fromhex(k["iv"])
+        out, macs = orc.dwp_steps(key, iv, _dwp_ops_from_kat(k))
+        assert out.hex() == k["out"] and macs[-1].hex() == k["mac"], k["name"]
+        crit, op = bytes.fromhex(k["crit"]), bytes.fromhex(k["open"])
+        if k["op"] == "wrap":
+            assert orc.dwp_wrap(crit, op, key, iv) == (0, bytes.fromhex(k["out"]), bytes.fromhex(k["mac"]))
+        else:
+            assert orc.dwp_unwrap(crit, op, bytes.fromhex(k["mac"]), key, iv) == (0, bytes.fromhex(k["out"]))
+    for c in g["short"]:
+        key, iv, crit, op = (bytes.fromhex(c[x]) for x in ("key", "iv", "crit", "open"))
+        assert orc.dwp_wrap(crit, op, key, iv) == (0, bytes.fromhex(c["out"]), bytes.fromhex(c["mac"]))
+        assert orc.dwp_unwrap(bytes.fromhex(c["out"]), op, bytes.fromhex(c["mac"]), key, iv) == (0, crit)
+        bad = bytes([int(c["mac"][:2], 16) ^ 0x80]) + bytes.fromhex(c["mac"])[1:]
+        assert orc.dwp_unwrap(bytes.fromhex(c["out"]), op, bad, key, iv)[0] == 511        # ERR_BAD_MAC
+    for c in g["long"]:
+        key, iv = bytes.fromhex(c["key"]), bytes.fromhex(c["iv"])
+        crit, op = orc.fill(c["crit_len"], c["crit_seed"]), orc.fill(c["open_len"], c["open_seed"])
+        code, out, mac = orc.dwp_wrap(crit, op, key, iv)
+        assert code == 0 and mac.hex() == c["mac"] and orc.belt_hash(out).hex() == c["out_belt_hash"], c["crit_len"]
+    assert orc.dwp_wrap(b"x", b"y", b"k" * 31, b"i" * 16)[0] == 109
+
+
 def test_belt_bde_random_cases(orc, golden):
     """belt-bde of the reference on 1..1000 blocks, all key sizes (tools/make_golden.py bde_random)"""
     assert len(golden.belt_bde) >= 18

@@ -109,3 +109,74 @@ def test_verify_big_curves_random_and_corrupted(orc):
             assert orc.verify_l(l, LEVEL_OID[l], h, s, p) == want, (l, i, kind)
             seen.add(want)
         assert seen >= {0, 510}
+
+
+def test_belt_bde_random(orc):
+    """8f-1 belt-bde: one-shots of the reference on whole-block messages of every key size"""
+    L = refgen.ref()
+    rnd = random.Random(5)
+    for _ in range(200):
+        nb = rnd.choice((1, 2, 3, 63, 64, 65, 127, 128, 129, rnd.randrange(1, 800)))
+        msg, key, iv = rnd.randbytes(16 * nb), rnd.randbytes(rnd.choice((16, 24, 32))), rnd.randbytes(16)
+        for fn, decr in (("beltBDEEncr", False), ("beltBDEDecr", True)):
+            out = ctypes.create_string_buffer(len(msg))
+            assert getattr(L, fn)(out, msg, _sz(len(msg)), key, _sz(len(key)), iv) == 0
+            assert orc.bde(msg, key, iv, decr) == (0, out.raw), (fn, nb)
+
+
+def test_belt_dwp_step_sequences_with_midstream_tags(orc):
+    """8f-2 belt-dwp: the same randomly cut Step{I,E,A,G} sequence through the reference's state and the
+    oracle's -- every tag taken mid-stream and the ciphertext must agree; then Wrap / Unwrap incl. bad mac"""
+    L = refgen.ref()
+    L.beltDWP_keep.restype = _sz
+    rnd = random.Random(19)
+
+    def cut(b):
+        parts = []
+        while b:
+            k = rnd.choice((1, 3, 7, 15, 16, 17, 33, 64))
+            parts.append(b[:k])
+            b = b[k:]
+        return parts
+    for _ in range(400):
+        crit = rnd.randbytes(rnd.choice((0, 1, 7, 15, 16, 17, 31, 32, 33, 100, rnd.randrange(0, 600))))
+        op = rnd.randbytes(rnd.choice((0, 1, 15, 16, 17, 32, 47, rnd.randrange(0, 300))))
+        key, iv = rnd.randbytes(rnd.choice((16, 24, 32))), rnd.randbytes(16)
+        st = ctypes.create_string_buffer(L.beltDWP_keep())
+        L.beltDWPStart(st, key, _sz(len(key)), iv)
+        ops, refout, refmacs = [], b"", []
+
+        def tag():
+            m = ctypes.create_string_buffer(8)
+            L.beltDWPStepG(m, st)
+            refmacs.append(m.raw)
+            ops.append(("G",))
+        for part in cut(op):
+            ops.append(("I", part))
+            L.beltDWPStepI(part, _sz(len(part)), st)
+            if rnd.random() < 0.3:
+                tag()
+        for part in cut(crit):
+            b = ctypes.create_string_buffer(part, len(part))
+            L.beltDWPStepE(b, _sz(len(part)), st)
+            refout += b.raw[: len(part)]
+            ops.append(("E", part))
+        for part in cut(refout):
+            ops.append(("A", part))
+            L.beltDWPStepA(part, _sz(len(part)), st)
+            if rnd.random() < 0.3:
+                tag()
+        tag()
+        assert orc.dwp_steps(key, iv, ops) == (refout, refmacs)
+        d, m = ctypes.create_string_buffer(max(len(crit), 1)), ctypes.create_string_buffer(8)
+        assert L.beltDWPWrap(d, m, crit, _sz(len(crit)), op, _sz(len(op)), key, _sz(len(key)), iv) == 0
+        assert (d.raw[: len(crit)], m.raw) == (refout, refmacs[-1])
+        assert orc.dwp_wrap(crit, op, key, iv) == (0, refout, m.raw)
+        bad = bytes([m.raw[0] ^ 1]) + m.raw[1:]
+        d2 = ctypes.create_string_buffer(max(len(crit), 1))
+        for mac in (m.raw, bad):
+            rc = L.beltDWPUnwrap(d2, refout, _sz(len(refout)), op, _sz(len(op)), mac, key, _sz(len(key)), iv)
+            oc, od = orc.dwp_unwrap(refout, op, mac, key, iv)
+            assert rc == oc == (0 if mac == m.raw else 511)
+            if rc == 0:
+                assert od == d2.raw[: len(crit)] == crit

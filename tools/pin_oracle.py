@@ -44,6 +44,24 @@ def main(n_verify=100_000):
         nblk += 2 * nb
     print(f"beltBDE {nblk} blocks     equal={ok}  {time.time()-t0:.1f}s")
     t0 = time.time()
+    rnd = random.Random(19)
+    ok = True
+    for _ in range(3000):                                  # belt-dwp (8f-2): wrap, unwrap (incl. bad mac)
+        crit = rnd.randbytes(rnd.choice((0, 1, 7, 15, 16, 17, 31, 32, 33, 100, rnd.randrange(0, 600))))
+        op = rnd.randbytes(rnd.choice((0, 1, 15, 16, 17, 32, 47, rnd.randrange(0, 300))))
+        key, iv = rnd.randbytes(rnd.choice((16, 24, 32))), rnd.randbytes(16)
+        d, m = ctypes.create_string_buffer(max(len(crit), 1)), ctypes.create_string_buffer(8)
+        assert L.beltDWPWrap(d, m, crit, _sz(len(crit)), op, _sz(len(op)), key, _sz(len(key)), iv) == 0
+        ct = d.raw[: len(crit)]
+        ok = ok and orc.dwp_wrap(crit, op, key, iv) == (0, ct, m.raw)
+        mac = m.raw if rnd.random() < 0.7 else bytes([m.raw[0] ^ 1]) + m.raw[1:]
+        d2 = ctypes.create_string_buffer(max(len(crit), 1))
+        rc = L.beltDWPUnwrap(d2, ct, _sz(len(ct)), op, _sz(len(op)), mac, key, _sz(len(key)), iv)
+        oc, od = orc.dwp_unwrap(ct, op, mac, key, iv)
+        ok = ok and rc == oc and (rc != 0 or od == d2.raw[: len(crit)] == crit)
+    print(f"beltDWP 3000 wrap/unwrap  equal={ok}  {time.time()-t0:.1f}s   (step sequences with mid-stream "
+          f"StepG: tests/test_oracle_vs_ref.py)")
+    t0 = time.time()
     rnd = random.Random(3)
     base_tr = refgen.make_triples(4096, 0xB164)
     hs, ss, ps, want = bytearray(), bytearray(), bytearray(), []
