@@ -399,4 +399,68 @@ __device__ inline Gf128 gf_mul_xpow(Gf128 s, uint64_t e)
     return s;
 }
 
+// base^e by square-and-multiply (jump-ahead of the polynomial MAC)
+__device__ inline Gf128 gf_pow(Gf128 base, uint64_t e)
+{
+    Gf128 r = {1, 0};
+#pragma unroll 1
+    while (e) {
+        if (e & 1) r = gf_mul(r, base);
+        e >>= 1;
+        if (e) base = gf_mul(base, base);
+    }
+    return r;
+}
+__device__ __forceinline__ Gf128 gf_from(const uint4 v)
+{
+    Gf128 a;
+    a.lo = (uint64_t)v.x | (uint64_t)v.y << 32;
+    a.hi = (uint64_t)v.z | (uint64_t)v.w << 32;
+    return a;
+}
+__device__ __forceinline__ uint4 gf_to(const Gf128 a)
+{
+    return make_uint4((uint32_t)a.lo, (uint32_t)(a.lo >> 32), (uint32_t)a.hi, (uint32_t)(a.hi >> 32));
+}
+
+// Multiplication by one FIXED element R through 4-bit windows: a * R = XOR_p T[p][nibble_p(a)] with
+// T[p][v] = (v * x^(4p)) * R, 32 x 16 entries of 16 bytes = 8 KiB of LDS.  All lanes read row p in
+// the same instruction and entry v occupies banks 4v..4v+3, so distinct nibbles never conflict and
+// equal nibbles broadcast.  (beltPolyMul with one operand fixed, belt_lcl.c:119-132.)
+struct GfMulTab {
+    static constexpr int kBytes = 32 * 16 * 16;
+    const uint4 *t;
+    __device__ explicit GfMulTab(const uint8_t *lds) : t(reinterpret_cast<const uint4 *>(lds)) {}
+    static __device__ void fill(uint8_t *lds, Gf128 R, int tid, int nthreads)
+    {
+        uint4 *t = reinterpret_cast<uint4 *>(lds);
+        for (int idx = tid; idx < 512; idx += nthreads) {
+            const int p = idx >> 4, v = idx & 15;
+            Gf128 b = R;                                   // R * x^(4p)
+            unsigned k = 4u * p;
+            if (k >= 64) { b = gf_mul_x64(b); k -= 64; }
+            b = gf_mul_xk(b, k);
+            Gf128 e = {0, 0};
+#pragma unroll
+            for (int bit = 0; bit < 4; ++bit) {
+                if ((v >> bit) & 1) { e.lo ^= b.lo; e.hi ^= b.hi; }
+                b = gf_mul_xk(b, 1);
+            }
+            t[idx] = gf_to(e);
+        }
+    }
+    __device__ __forceinline__ Gf128 mul(const Gf128 a) const
+    {
+        const uint32_t w[4] = {(uint32_t)a.lo, (uint32_t)(a.lo >> 32), (uint32_t)a.hi, (uint32_t)(a.hi >> 32)};
+        uint4 acc = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 32; ++p) {
+            const uint32_t v = (w[p >> 3] >> (4 * (p & 7))) & 15u;
+            const uint4 e = t[p * 16 + v];
+            acc.x ^= e.x; acc.y ^= e.y; acc.z ^= e.z; acc.w ^= e.w;
+        }
+        return gf_from(acc);
+    }
+};
+
 }  // namespace bee2hip

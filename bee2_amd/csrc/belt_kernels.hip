@@ -189,6 +189,92 @@ void belt_bde_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uin
     }
 }
 
+// ------------------------------------------------- belt-dwp: polynomial MAC ---
+// T = t * r^n ^ XOR_{i=1..n} X_i * r^(n-i+1)  -- the value of `t` after absorbing n blocks
+// (belt_dwp.c:96-101: t <- (t ^ X) * r).  A wavefront owns one contiguous chunk; inside it the 64
+// lanes take interleaved blocks (coalesced 1 KiB loads) and run Horner with the single fixed
+// multiplier R = r^64 (GfMulTab); at the end lane l scales by r^(63-l) and the wavefront XOR-reduces
+// to the chunk polynomial P_w = XOR_j X_j r^(end_w-1-j).  A chunk that is not a multiple of 64 blocks
+// is treated as left-padded with zero blocks.  polyhash_finish_kernel then weights every P_w with
+// r^(n - end_w + 1) and XORs everything, plus t * r^n, into the 16-byte result.
+//
+// consts[l] = r^(63-l) for l < 64, consts[64] = r^64.
+__global__ __launch_bounds__(128)
+void polyhash_prep_kernel(BeltCtr r, uint4 *__restrict__ consts)
+{
+    const unsigned l = threadIdx.x;
+    if (l > 64) return;
+    const Gf128 rr = gf_from(make_uint4(r.c[0], r.c[1], r.c[2], r.c[3]));
+    consts[l] = gf_to(gf_pow(rr, l < 64 ? 63 - l : 64));
+}
+
+constexpr int PH_WG = 256;
+// nbytes: length of the data; the last block may be partial and counts as zero-padded (belt_dwp.c:118-119)
+__global__ __launch_bounds__(PH_WG)
+void polyhash_kernel(const uint8_t *__restrict__ data, uint64_t nbytes, uint64_t chunk,
+                     const uint4 *__restrict__ consts, uint4 *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[GfMulTab::kBytes];
+    GfMulTab::fill(smem, gf_from(consts[64]), threadIdx.x, PH_WG);
+    __syncthreads();
+    const GfMulTab M(smem);
+    const uint64_t nblocks = (nbytes + 15) / 16;
+    const unsigned lane = threadIdx.x & 63u;
+    const uint64_t w = (uint64_t)blockIdx.x * (PH_WG / 64) + (threadIdx.x >> 6);
+    const uint64_t c0 = w * chunk;
+    if (c0 >= nblocks) return;
+    const uint64_t nw = c0 + chunk <= nblocks ? chunk : nblocks - c0;      // blocks in this chunk
+    const uint64_t steps = (nw + 63) / 64;
+    const uint64_t pad = steps * 64 - nw;                                  // zero blocks in front
+    const uint4 *blk = reinterpret_cast<const uint4 *>(data);
+    Gf128 a = {0, 0};
+    for (uint64_t k = 0; k < steps; ++k) {
+        const uint64_t p = 64 * k + lane;
+        a = M.mul(a);
+        if (p >= pad) {
+            const uint64_t j = c0 + p - pad;
+            uint4 v;
+            if (16 * j + 16 <= nbytes) v = blk[j];
+            else {                                                        // the ragged last block
+                uint32_t q[4] = {0, 0, 0, 0};
+                for (uint64_t b = 16 * j; b < nbytes; ++b) q[(b & 15) >> 2] |= (uint32_t)data[b] << (8 * (b & 3));
+                v = make_uint4(q[0], q[1], q[2], q[3]);
+            }
+            a.lo ^= (uint64_t)v.x | (uint64_t)v.y << 32;
+            a.hi ^= (uint64_t)v.z | (uint64_t)v.w << 32;
+        }
+    }
+    a = gf_mul(a, gf_from(consts[lane]));                                  // * r^(63 - lane)
+    uint32_t x0 = (uint32_t)a.lo, x1 = (uint32_t)(a.lo >> 32), x2 = (uint32_t)a.hi, x3 = (uint32_t)(a.hi >> 32);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        x0 ^= __shfl_xor(x0, m, 64); x1 ^= __shfl_xor(x1, m, 64);
+        x2 ^= __shfl_xor(x2, m, 64); x3 ^= __shfl_xor(x3, m, 64);
+    }
+    if (lane == 0) partial[w] = make_uint4(x0, x1, x2, x3);
+}
+
+// out (zeroed before) ^= P_w * r^(n - end_w + 1) for every chunk, and ^= t * r^n
+__global__ __launch_bounds__(64)
+void polyhash_finish_kernel(const uint4 *__restrict__ partial, unsigned nwaves, uint64_t chunk, uint64_t nblocks,
+                            BeltCtr r, BeltCtr t_in, uint32_t *__restrict__ out)
+{
+    const unsigned w = blockIdx.x * 64 + threadIdx.x;
+    if (w > nwaves) return;
+    const Gf128 rr = gf_from(make_uint4(r.c[0], r.c[1], r.c[2], r.c[3]));
+    Gf128 v;
+    if (w < nwaves) {
+        const uint64_t c0 = (uint64_t)w * chunk;
+        if (c0 >= nblocks) return;
+        const uint64_t end = c0 + chunk <= nblocks ? c0 + chunk : nblocks;
+        v = gf_mul(gf_from(partial[w]), gf_pow(rr, nblocks - end + 1));
+    } else {
+        v = gf_mul(gf_from(make_uint4(t_in.c[0], t_in.c[1], t_in.c[2], t_in.c[3])), gf_pow(rr, nblocks));
+    }
+    atomicXor(out + 0, (uint32_t)v.lo); atomicXor(out + 1, (uint32_t)(v.lo >> 32));
+    atomicXor(out + 2, (uint32_t)v.hi); atomicXor(out + 3, (uint32_t)(v.hi >> 32));
+}
+
 // CBC encryption is a serial chain per message (belt_cbc.c:63-84): one lane per message,
 // n messages of nblk full blocks each, per-message iv, in place.  ivs[m] receives the last
 // ciphertext block (the chaining value bee2 keeps in belt_cbc_st.block).
@@ -368,6 +454,38 @@ err_t launch_belt_bde(int decr, const void *d_src, void *d_dst, size_t nblocks, 
     }
     if (d_s_out)
         B2H_TRY(hipMemcpyAsync(d_s_out, (const uint4 *)tw + nwaves, 16, hipMemcpyDeviceToDevice, st));
+    return ERR_OK;
+}
+
+// d_t_out (16 bytes, device) <- t after absorbing the nbytes at d_data as 16-byte blocks, the last
+// one zero-padded; r, t as u32 words.  nbytes == 0 gives t itself.
+err_t launch_belt_polyhash(const void *d_data, size_t nbytes, const uint32_t r[4], const uint32_t t[4],
+                           void *d_t_out, hipStream_t st)
+{
+    BeltCtr rr, tt;
+    for (int i = 0; i < 4; ++i) { rr.c[i] = r[i]; tt.c[i] = t[i]; }
+    const uint64_t nblocks = ((uint64_t)nbytes + 15) / 16;
+    // enough wavefronts to fill the chip, chunks of at least 64 x 16 blocks so that the per-chunk
+    // constants (table build, one general product per lane) stay below ~5 % of the Horner loop
+    size_t nwaves = (size_t)num_cus() * 32;
+    uint64_t chunk = (nblocks + nwaves - 1) / (nwaves ? nwaves : 1);
+    if (chunk < 1024) chunk = 1024;
+    chunk = (chunk + 63) / 64 * 64;
+    nwaves = (size_t)((nblocks + chunk - 1) / chunk);
+    void *scr = nullptr;
+    err_t code = scratch_for_stream(st, 9, (65 + nwaves + 1) * 16, &scr);
+    if (code != ERR_OK) return code;
+    uint4 *consts = (uint4 *)scr, *partial = consts + 65;
+    B2H_TRY(hipMemsetAsync(d_t_out, 0, 16, st));
+    if (nwaves) {
+        hipLaunchKernelGGL(polyhash_prep_kernel, dim3(1), dim3(128), 0, st, rr, consts);
+        const size_t wg_waves = PH_WG / 64;
+        hipLaunchKernelGGL(polyhash_kernel, dim3((unsigned)((nwaves + wg_waves - 1) / wg_waves)), dim3(PH_WG), 0, st,
+                           (const uint8_t *)d_data, (uint64_t)nbytes, chunk, (const uint4 *)consts, partial);
+    }
+    hipLaunchKernelGGL(polyhash_finish_kernel, dim3((unsigned)((nwaves + 1 + 63) / 64)), dim3(64), 0, st,
+                       (const uint4 *)partial, (unsigned)nwaves, chunk, nblocks, rr, tt, (uint32_t *)d_t_out);
+    B2H_TRY(hipGetLastError());
     return ERR_OK;
 }
 

@@ -866,6 +866,141 @@ extern "C" err_t beltECBDecr(void *dest, const void *src, size_t count, const oc
     return ecb_oneshot(dest, src, count, key, len, 1);
 }
 
+// ------------------------------------------------------------------ belt-dwp ---
+struct belt_dwp_st {          // belt_dwp.c:27-37 (own layout: no beltPolyMul stack)
+    belt_ctr_st ctr;
+    u32 r[4];
+    u32 t[4];
+    uint64_t bits_open, bits_crit;
+    octet block[16];
+    size_t filled;
+};
+extern "C" size_t beltDWP_keep(void) { return sizeof(belt_dwp_st); }
+extern "C" void beltDWPStart(void *state, const octet key[], size_t len, const octet iv[16])
+{
+    belt_dwp_st *st = (belt_dwp_st *)state;
+    beltCTRStart(&st->ctr, key, len, iv);                       // ctr = E_K(iv)
+    for (int i = 0; i < 4; ++i) st->r[i] = st->ctr.ctr[i];
+    beltBlockEncr2(st->r, st->ctr.key);                         // r = E_K(ctr)   (belt_dwp.c:52-54)
+    const octet *H = beltH();
+    for (int i = 0; i < 4; ++i) st->t[i] = load32le(H + 4 * i); // t = H[0..16)   (:59)
+    st->bits_open = st->bits_crit = 0;
+    st->filled = 0;
+}
+extern "C" void beltDWPStepE(void *buf, size_t count, void *state) { beltCTRStepE(buf, count, &((belt_dwp_st *)state)->ctr); }
+extern "C" void beltDWPStepD(void *buf, size_t count, void *state) { beltCTRStepE(buf, count, &((belt_dwp_st *)state)->ctr); }
+
+extern "C" err_t bee2hip_beltDWP_absorb_dev(const void *d_data, size_t nbytes, const u32 r[4], const u32 t[4],
+                                            void *d_t_out, void *stream)
+{
+    if ((nbytes && !d_data) || !r || !t || !d_t_out) return ERR_BAD_INPUT;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    return launch_belt_polyhash(d_data, nbytes, r, t, d_t_out, as_stream(stream));
+}
+// t_out <- t after absorbing `nbytes` of host data (zero-padded to whole blocks), on the GPU
+static err_t dwp_absorb_host(u32 t_out[4], const u32 t[4], const u32 r[4], const octet *data, size_t nbytes)
+{
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    Scratch &sc = t_scr[2];
+    const size_t off = (nbytes + 15) & ~(size_t)15;
+    code = sc.need(off + 16);
+    if (code != ERR_OK) return code;
+    octet *d = (octet *)sc.p;
+    if (nbytes) B2H_TRY(hipMemcpy(d, data, nbytes, hipMemcpyHostToDevice));
+    code = launch_belt_polyhash(d, nbytes, r, t, d + off, nullptr);
+    if (code != ERR_OK) return code;
+    octet out[16];
+    B2H_TRY(hipMemcpy(out, d + off, 16, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) t_out[i] = load32le(out + 4 * i);
+    return ERR_OK;
+}
+// buffered absorb shared by StepI / StepA (belt_dwp.c:79-106,128-154): whole blocks go to the GPU in one call
+static void dwp_feed(belt_dwp_st *st, const octet *p, size_t count, const char *who)
+{
+    if (st->filled) {
+        size_t take = 16 - st->filled;
+        if (take > count) take = count;
+        memcpy(st->block + st->filled, p, take);
+        st->filled += take; p += take; count -= take;
+        if (st->filled < 16) return;
+        die_on(dwp_absorb_host(st->t, st->t, st->r, st->block, 16), who);
+        st->filled = 0;
+    }
+    const size_t full = count & ~(size_t)15;
+    if (full) die_on(dwp_absorb_host(st->t, st->t, st->r, p, full), who);
+    if (count - full) { memcpy(st->block, p + full, count - full); st->filled = count - full; }
+}
+extern "C" void beltDWPStepI(const void *buf, size_t count, void *state)
+{
+    belt_dwp_st *st = (belt_dwp_st *)state;
+    st->bits_open += (uint64_t)count * 8;
+    dwp_feed(st, (const octet *)buf, count, "beltDWPStepI");
+}
+extern "C" void beltDWPStepA(const void *buf, size_t count, void *state)
+{
+    belt_dwp_st *st = (belt_dwp_st *)state;
+    if (count && st->bits_crit == 0 && st->filled) {            // the open data ends here: pad it (belt_dwp.c:115-122)
+        die_on(dwp_absorb_host(st->t, st->t, st->r, st->block, st->filled), "beltDWPStepA");
+        st->filled = 0;
+    }
+    st->bits_crit += (uint64_t)count * 8;
+    dwp_feed(st, (const octet *)buf, count, "beltDWPStepA");
+}
+// the tag of everything absorbed so far; the state is not disturbed (belt_dwp.c:162-189)
+static void dwp_tag(octet mac[8], const belt_dwp_st *st, const char *who)
+{
+    octet tail[32];
+    size_t n = 0;
+    if (st->filled) { memset(tail, 0, 16); memcpy(tail, st->block, st->filled); n = 16; }
+    for (int i = 0; i < 8; ++i) {
+        tail[n + i] = (octet)(st->bits_open >> (8 * i));
+        tail[n + 8 + i] = (octet)(st->bits_crit >> (8 * i));
+    }
+    u32 t1[4];
+    die_on(dwp_absorb_host(t1, st->t, st->r, tail, n + 16), who);
+    beltBlockEncr2(t1, st->ctr.key);
+    octet out[16];
+    for (int i = 0; i < 4; ++i) store32le(out + 4 * i, t1[i]);
+    memcpy(mac, out, 8);
+}
+extern "C" void beltDWPStepG(octet mac[8], void *state) { dwp_tag(mac, (const belt_dwp_st *)state, "beltDWPStepG"); }
+extern "C" bool_t beltDWPStepV(const octet mac[8], void *state)
+{
+    octet m[8];
+    dwp_tag(m, (const belt_dwp_st *)state, "beltDWPStepV");
+    return memcmp(m, mac, 8) == 0;
+}
+extern "C" err_t beltDWPWrap(void *dest, octet mac[8], const void *src1, size_t count1, const void *src2,
+                             size_t count2, const octet key[], size_t len, const octet iv[16])
+{
+    if ((len != 16 && len != 24 && len != 32) || (count1 && (!src1 || !dest)) || (count2 && !src2) || !key || !iv || !mac)
+        return ERR_BAD_INPUT;
+    belt_dwp_st st;
+    beltDWPStart(&st, key, len, iv);
+    beltDWPStepI(src2, count2, &st);                            // I before E: src2 may overlap dest (belt_dwp.c:218)
+    if (count1) memmove(dest, src1, count1);
+    beltDWPStepE(dest, count1, &st);
+    beltDWPStepA(dest, count1, &st);
+    beltDWPStepG(mac, &st);
+    return ERR_OK;
+}
+extern "C" err_t beltDWPUnwrap(void *dest, const void *src1, size_t count1, const void *src2, size_t count2,
+                               const octet mac[8], const octet key[], size_t len, const octet iv[16])
+{
+    if ((len != 16 && len != 24 && len != 32) || (count1 && (!src1 || !dest)) || (count2 && !src2) || !key || !iv || !mac)
+        return ERR_BAD_INPUT;
+    belt_dwp_st st;
+    beltDWPStart(&st, key, len, iv);
+    beltDWPStepI(src2, count2, &st);
+    beltDWPStepA(src1, count1, &st);
+    if (!beltDWPStepV(mac, &st)) return ERR_BAD_MAC;            // nothing is decrypted (belt_dwp.c:258-262)
+    if (count1) memmove(dest, src1, count1);
+    beltDWPStepD(dest, count1, &st);
+    return ERR_OK;
+}
+
 // ------------------------------------------------------------------ belt-bde ---
 struct belt_bde_st {          // belt_bde.c:26-32
     u32 key[8];

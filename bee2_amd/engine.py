@@ -55,6 +55,8 @@ DROPIN_SYMBOLS = [
     "beltECB_keep", "beltECBStart", "beltECBStepE", "beltECBStepD", "beltECBEncr", "beltECBDecr",
     "beltCBC_keep", "beltCBCStart", "beltCBCStepE", "beltCBCStepD", "beltCBCEncr", "beltCBCDecr",
     "beltBDE_keep", "beltBDEStart", "beltBDEStepE", "beltBDEStepD", "beltBDEEncr", "beltBDEDecr",
+    "beltDWP_keep", "beltDWPStart", "beltDWPStepE", "beltDWPStepI", "beltDWPStepA", "beltDWPStepD", "beltDWPStepG",
+    "beltDWPStepV", "beltDWPWrap", "beltDWPUnwrap",
     "beltMAC_keep", "beltMACStart", "beltMACStepA", "beltMACStepG", "beltMACStepG2",
     "beltMACStepV", "beltMACStepV2", "beltMAC",
     "bignParamsStd", "bignVerify", "bign128Verify", "bign192Verify", "bign256Verify",
@@ -63,7 +65,7 @@ BATCH_SYMBOLS = [
     "bee2hip_bashF_batch", "bee2hip_beltCTR_bulk", "bee2hip_bignVerify_batch",
     "bee2hip_bashHash_beltMAC_batch", "bee2hip_hash_ragged", "bee2hip_hash_ragged_dev", "bee2hip_hash_ragged_ordered_dev",
     "bee2hip_bashF_batch_dev", "bee2hip_beltCTR_blocks_dev", "bee2hip_beltBlockEncr_dev",
-    "bee2hip_beltModes_blocks_dev", "bee2hip_beltCBCEncr_batch_dev", "bee2hip_beltBDE_blocks_dev",
+    "bee2hip_beltModes_blocks_dev", "bee2hip_beltCBCEncr_batch_dev", "bee2hip_beltBDE_blocks_dev", "bee2hip_beltDWP_absorb_dev",
     "bee2hip_bign128Verify_batch_dev", "bee2hip_bignVerify_batch_dev", "bee2hip_bignVerifyL_batch_dev",
     "bee2hip_bashHash_beltMAC_batch_dev",
     "bee2hip_set_device", "bee2hip_sync", "bee2hip_last_error", "bee2hip_version",
@@ -155,6 +157,53 @@ class Engine:
         self._check(self.lib.bee2hip_beltModes_blocks_dev(int(mode), self._ptr(src), self._ptr(dst), _sz(n),
                                                           bytes(key_words), bytes(iv_words) if iv_words else None,
                                                           self._stream()), "beltModes_blocks_dev")
+
+    # ---- belt-dwp (8f-2)
+    def dwp_steps(self, key, iv, ops):
+        """ops = [("E"|"D"|"I"|"A", bytes) | ("G",) | ("V", mac)] applied to one state;
+        -> (E/D outputs concatenated, [mac per "G"], [bool per "V"])"""
+        st = ctypes.create_string_buffer(self.lib.beltDWP_keep())
+        self.lib.beltDWPStart(st, bytes(key), _sz(len(key)), bytes(iv))
+        out, macs, oks = b"", [], []
+        for op in ops:
+            if op[0] in "ED":
+                b = ctypes.create_string_buffer(bytes(op[1]), max(len(op[1]), 1))
+                getattr(self.lib, "beltDWPStep" + op[0])(b, _sz(len(op[1])), st)
+                out += b.raw[: len(op[1])]
+            elif op[0] in "IA":
+                getattr(self.lib, "beltDWPStep" + op[0])(bytes(op[1]), _sz(len(op[1])), st)
+            elif op[0] == "G":
+                m = ctypes.create_string_buffer(8)
+                self.lib.beltDWPStepG(m, st)
+                macs.append(m.raw)
+            else:
+                oks.append(bool(self.lib.beltDWPStepV(bytes(op[1]), st)))
+        return out, macs, oks
+
+    def dwp_wrap(self, crit, open_, key, iv):
+        dest, mac = ctypes.create_string_buffer(max(len(crit), 1)), ctypes.create_string_buffer(8)
+        code = self.lib.beltDWPWrap(dest, mac, bytes(crit), _sz(len(crit)), bytes(open_), _sz(len(open_)),
+                                    bytes(key), _sz(len(key)), bytes(iv))
+        return code, dest.raw[: len(crit)], mac.raw
+
+    def dwp_unwrap(self, crit, open_, mac, key, iv):
+        dest = ctypes.create_string_buffer(max(len(crit), 1))
+        code = self.lib.beltDWPUnwrap(dest, bytes(crit), _sz(len(crit)), bytes(open_), _sz(len(open_)),
+                                      bytes(mac), bytes(key), _sz(len(key)), bytes(iv))
+        return code, dest.raw[: len(crit)]
+
+    def beltDWPStart(self, key, iv):
+        """-> (expanded key, ctr0 = E_K(iv), r = E_K(ctr0), t0 = H[0..16)) as bytes of u32 words"""
+        st = ctypes.create_string_buffer(self.lib.beltDWP_keep())
+        self.lib.beltDWPStart(st, bytes(key), _sz(len(key)), bytes(iv))
+        n = self.lib.beltCTR_keep()
+        return st.raw[:32], st.raw[32:48], st.raw[n:n + 16], st.raw[n + 16:n + 32]
+
+    def beltDWP_absorb_dev(self, data, nbytes, r_words, t_words, t_out):
+        """t_out (16-byte device tensor) <- t after absorbing nbytes of the device tensor `data`"""
+        self._check(self.lib.bee2hip_beltDWP_absorb_dev(self._ptr(data) if nbytes else None, _sz(nbytes),
+                                                        bytes(r_words), bytes(t_words), self._ptr(t_out),
+                                                        self._stream()), "beltDWP_absorb_dev")
 
     def beltBDEStart(self, key, iv):
         """-> (expanded key, s = E_K(iv)) as 32 + 16 bytes of u32 words, for beltBDE_blocks_dev"""

@@ -52,6 +52,7 @@ typedef uint32_t err_t;
 #define ERR_BAD_PARAMS       ((err_t)502)   /* err.h:180 */
 #define ERR_BAD_PUBKEY       ((err_t)505)   /* err.h:186 */
 #define ERR_BAD_SIG          ((err_t)510)   /* err.h:196 */
+#define ERR_BAD_MAC          ((err_t)511)   /* err.h:198 */
 /* engine-specific: a HIP runtime call failed (no bee2 equivalent; the reference
    has no device).  bee2hip_last_error() returns the HIP message. */
 #define ERR_BEE2HIP_DEVICE   ((err_t)0x4850)
@@ -119,6 +120,24 @@ err_t beltCBCDecr(void *dest, const void *src, size_t count, const octet key[], 
    count must be a multiple of 16; the one-shots return ERR_BAD_INPUT for count < 16 or
    count % 16 != 0 (belt_bde.c:93-100).  belt-sde is NOT provided: it wraps belt-wbl, a serial
    wide-block construction over the whole sector (belt_sde.c:38-71, belt_wbl.c). */
+/* belt-dwp, authenticated encryption: CTR + polynomial MAC over GF(2^128) (belt.h, src/crypto/belt/
+   belt_dwp.c:27-274).  The state is an opaque POD of beltDWP_keep() bytes (not bee2's layout: bee2
+   appends a beltPolyMul stack).  Order of calls as in bee2: Start, StepI* (open data), then
+   StepE + StepA (protect) or StepA + StepD (unprotect) on the critical data, StepG / StepV at any
+   point.  beltDWPUnwrap returns ERR_BAD_MAC without decrypting when the tag does not match. */
+size_t beltDWP_keep(void);
+void beltDWPStart(void *state, const octet key[], size_t len, const octet iv[16]);
+void beltDWPStepE(void *buf, size_t count, void *state);
+void beltDWPStepI(const void *buf, size_t count, void *state);
+void beltDWPStepA(const void *buf, size_t count, void *state);
+void beltDWPStepD(void *buf, size_t count, void *state);
+void beltDWPStepG(octet mac[8], void *state);
+bool_t beltDWPStepV(const octet mac[8], void *state);
+err_t beltDWPWrap(void *dest, octet mac[8], const void *src1, size_t count1, const void *src2,
+                  size_t count2, const octet key[], size_t len, const octet iv[16]);
+err_t beltDWPUnwrap(void *dest, const void *src1, size_t count1, const void *src2, size_t count2,
+                    const octet mac[8], const octet key[], size_t len, const octet iv[16]);
+
 size_t beltBDE_keep(void);
 void beltBDEStart(void *state, const octet key[], size_t len, const octet iv[16]);
 void beltBDEStepE(void *buf, size_t count, void *state);
@@ -219,6 +238,12 @@ err_t bee2hip_beltCBCEncr_batch_dev(void *d_msgs, size_t nblk, size_t n, const u
    first_block + nblocks - 1 of the stream, i.e. block j uses the tweak s * x^(j+1) -- a stream can
    be cut into pieces (or sharded across GPUs) at any block boundary.  decr = 0 / 1.
    d_s_out (may be NULL) receives s * x^(first_block + nblocks), 16 bytes: the state after the piece. */
+/* belt-dwp's authenticator on device-resident data: *d_t_out (16 bytes, device) <- the value of t
+   after absorbing nbytes at d_data as 16-byte blocks, t <- (t ^ X) * r in GF(2^128), the last block
+   zero-padded (belt_dwp.c:96-101,118-119); r[4], t[4] = u32 words as in the state.  nbytes = 0
+   returns t.  Together with bee2hip_beltCTR_blocks_dev this is beltDWPWrap on resident data. */
+err_t bee2hip_beltDWP_absorb_dev(const void *d_data, size_t nbytes, const u32 r[4], const u32 t[4],
+                                 void *d_t_out, void *stream);
 err_t bee2hip_beltBDE_blocks_dev(int decr, const void *d_src, void *d_dst, size_t nblocks,
                                  const u32 key[8], const u32 s[4], uint64_t first_block,
                                  void *d_s_out, void *stream);
