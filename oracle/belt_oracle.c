@@ -573,6 +573,70 @@ uint32_t orc_beltDWPUnwrap(void *dest, const void *src1, size_t count1, const vo
     return ORC_OK;
 }
 
+/* ---- belt-che (belt_che.c:27-319): the same authenticator as belt-dwp with
+   r = E_K(iv), and the keystream gamma_i = E_K(s_i), s_0 = r, s_i = s_{i-1} * x ^ 1 in GF(2^128);
+   unused gamma bytes of a partial block are kept for the next call (belt_che.c:69-112). */
+void orc_beltCHEStart(orc_belt_che_st *st, const uint8_t *key, size_t len, const uint8_t iv[16])
+{
+    int i;
+    memset(st, 0, sizeof *st);
+    orc_beltKeyExpand2(st->mac.ctr.key, key, len);
+    blk_load(st->mac.r, iv);
+    orc_beltBlockEncr2(st->mac.r, st->mac.ctr.key);             /* r = E_K(iv), :54-56 */
+    for (i = 0; i < 4; ++i) st->s[i] = st->mac.r[i];            /* s = r */
+    blk_load(st->mac.t, orc_beltH());
+}
+void orc_beltCHEStepE(void *buf_, size_t count, orc_belt_che_st *st)
+{
+    uint8_t *buf = (uint8_t *)buf_;
+    while (count) {
+        if (st->reserved == 0) {
+            uint32_t g[4];
+            int i;
+            gf128_double(st->s);
+            st->s[0] ^= 1u;
+            for (i = 0; i < 4; ++i) g[i] = st->s[i];
+            orc_beltBlockEncr2(g, st->mac.ctr.key);
+            blk_store(st->gamma, g);
+            st->reserved = 16;
+        }
+        *buf++ ^= st->gamma[16 - st->reserved];
+        --st->reserved;
+        --count;
+    }
+}
+void orc_beltCHEStepI(const void *buf, size_t count, orc_belt_che_st *st) { orc_beltDWPStepI(buf, count, &st->mac); }
+void orc_beltCHEStepA(const void *buf, size_t count, orc_belt_che_st *st) { orc_beltDWPStepA(buf, count, &st->mac); }
+void orc_beltCHEStepG(uint8_t mac[8], const orc_belt_che_st *st) { orc_beltDWPStepG(mac, &st->mac); }
+uint32_t orc_beltCHEWrap(void *dest, uint8_t mac[8], const void *src1, size_t count1, const void *src2,
+                         size_t count2, const uint8_t *key, size_t len, const uint8_t iv[16])
+{
+    orc_belt_che_st st;
+    if (len != 16 && len != 24 && len != 32) return ORC_BAD_INPUT;
+    orc_beltCHEStart(&st, key, len, iv);
+    orc_beltCHEStepI(src2, count2, &st);
+    memmove(dest, src1, count1);
+    orc_beltCHEStepE(dest, count1, &st);
+    orc_beltCHEStepA(dest, count1, &st);
+    orc_beltCHEStepG(mac, &st);
+    return ORC_OK;
+}
+uint32_t orc_beltCHEUnwrap(void *dest, const void *src1, size_t count1, const void *src2, size_t count2,
+                           const uint8_t mac[8], const uint8_t *key, size_t len, const uint8_t iv[16])
+{
+    orc_belt_che_st st;
+    uint8_t m[8];
+    if (len != 16 && len != 24 && len != 32) return ORC_BAD_INPUT;
+    orc_beltCHEStart(&st, key, len, iv);
+    orc_beltCHEStepI(src2, count2, &st);
+    orc_beltCHEStepA(src1, count1, &st);
+    orc_beltCHEStepG(m, &st);
+    if (memcmp(m, mac, 8)) return ORC_BAD_MAC;
+    memmove(dest, src1, count1);
+    orc_beltCHEStepE(dest, count1, &st);
+    return ORC_OK;
+}
+
 /* beltCBCEncr / beltCBCDecr with ciphertext stealing (belt_cbc.c:63-193) */
 uint32_t orc_beltCBC(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
                      const uint8_t iv[16], int decr)

@@ -115,6 +115,23 @@ uint32_t orc_beltDWPWrap(void *dest, uint8_t mac[8], const void *src1, size_t co
 uint32_t orc_beltDWPUnwrap(void *dest, const void *src1, size_t count1, const void *src2, size_t count2,
                            const uint8_t mac[8], const uint8_t *key, size_t len, const uint8_t iv[16]);
 
+/* belt-che (belt_che.c:27-319): mac = the belt-dwp authenticator state (its ctr.key holds K; r = E_K(iv)) */
+typedef struct {
+    orc_belt_dwp_st mac;
+    uint32_t s[4];
+    uint8_t gamma[16];
+    size_t reserved;
+} orc_belt_che_st;
+void orc_beltCHEStart(orc_belt_che_st *st, const uint8_t *key, size_t len, const uint8_t iv[16]);
+void orc_beltCHEStepE(void *buf, size_t count, orc_belt_che_st *st);            /* = StepD */
+void orc_beltCHEStepI(const void *buf, size_t count, orc_belt_che_st *st);
+void orc_beltCHEStepA(const void *buf, size_t count, orc_belt_che_st *st);
+void orc_beltCHEStepG(uint8_t mac[8], const orc_belt_che_st *st);
+uint32_t orc_beltCHEWrap(void *dest, uint8_t mac[8], const void *src1, size_t count1, const void *src2,
+                         size_t count2, const uint8_t *key, size_t len, const uint8_t iv[16]);
+uint32_t orc_beltCHEUnwrap(void *dest, const void *src1, size_t count1, const void *src2, size_t count2,
+                           const uint8_t mac[8], const uint8_t *key, size_t len, const uint8_t iv[16]);
+
 void orc_beltCompr(uint32_t h[8], const uint32_t X[8]);        /* belt_compr.c:27-51 */
 uint32_t orc_beltHash(uint8_t hash[32], const void *src, size_t count); /* belt_hash.c:173-190 */
 

@@ -32,6 +32,8 @@ class Golden:
             self.belt_bde = json.load(f)
         with open(os.path.join(GOLD, "belt_dwp.json")) as f:
             self.belt_dwp = json.load(f)
+        with open(os.path.join(GOLD, "belt_che.json")) as f:
+            self.belt_che = json.load(f)
 
     def bign_base_arrays(self):
         hs = b"".join(t[0] for t in self.bign_base)

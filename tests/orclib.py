@@ -115,34 +115,35 @@ class Oracle:
 
     # ---- belt-dwp (8f-2): ops = list of ("E"|"D"|"I"|"A", bytes) / ("G",) applied in order to one state;
     # returns (the E/D outputs concatenated in order, [mac after every "G"])
-    def dwp_steps(self, key, iv, ops):
-        st = ctypes.create_string_buffer(256)
-        self.lib.orc_beltDWPStart(st, bytes(key), _sz(len(key)), bytes(iv))
+    def dwp_steps(self, key, iv, ops, mode="DWP"):
+        f = lambda name: getattr(self.lib, f"orc_belt{mode}{name}")      # mode "DWP" or "CHE"
+        st = ctypes.create_string_buffer(512)
+        f("Start")(st, bytes(key), _sz(len(key)), bytes(iv))
         out, macs = b"", []
         for op in ops:
             if op[0] in "ED":
                 b = ctypes.create_string_buffer(bytes(op[1]), max(len(op[1]), 1))
-                self.lib.orc_beltDWPStepE(b, _sz(len(op[1])), st)
+                f("StepE")(b, _sz(len(op[1])), st)
                 out += b.raw[: len(op[1])]
             elif op[0] == "I":
-                self.lib.orc_beltDWPStepI(bytes(op[1]), _sz(len(op[1])), st)
+                f("StepI")(bytes(op[1]), _sz(len(op[1])), st)
             elif op[0] == "A":
-                self.lib.orc_beltDWPStepA(bytes(op[1]), _sz(len(op[1])), st)
+                f("StepA")(bytes(op[1]), _sz(len(op[1])), st)
             else:
                 m = ctypes.create_string_buffer(8)
-                self.lib.orc_beltDWPStepG(m, st)
+                f("StepG")(m, st)
                 macs.append(m.raw)
         return out, macs
 
-    def dwp_wrap(self, crit, open_, key, iv):
+    def dwp_wrap(self, crit, open_, key, iv, mode="DWP"):
         dest, mac = ctypes.create_string_buffer(max(len(crit), 1)), ctypes.create_string_buffer(8)
-        code = self.lib.orc_beltDWPWrap(dest, mac, bytes(crit), _sz(len(crit)), bytes(open_), _sz(len(open_)),
+        code = getattr(self.lib, f"orc_belt{mode}Wrap")(dest, mac, bytes(crit), _sz(len(crit)), bytes(open_), _sz(len(open_)),
                                         bytes(key), _sz(len(key)), bytes(iv))
         return code, dest.raw[: len(crit)], mac.raw
 
-    def dwp_unwrap(self, crit, open_, mac, key, iv):
+    def dwp_unwrap(self, crit, open_, mac, key, iv, mode="DWP"):
         dest = ctypes.create_string_buffer(max(len(crit), 1))
-        code = self.lib.orc_beltDWPUnwrap(dest, bytes(crit), _sz(len(crit)), bytes(open_), _sz(len(open_)),
+        code = getattr(self.lib, f"orc_belt{mode}Unwrap")(dest, bytes(crit), _sz(len(crit)), bytes(open_), _sz(len(open_)),
                                           bytes(mac), bytes(key), _sz(len(key)), bytes(iv))
         return code, dest.raw[: len(crit)]
 

@@ -1,3 +1,4 @@
+import pytest
 """CPU tests: the oracle (oracle/liboracle.so) against the committed golden vectors,
 i.e. against the STB annex KATs and outputs of the reference itself
 (tools/make_golden.py).  Mirrors test/crypto/{bash,belt,bign,bign128}_test.c."""
@@ -140,31 +141,32 @@ def _dwp_ops_from_kat(k):
     return ops
 
 
-def test_belt_dwp_A19_A20_and_golden(orc, golden):
-    """belt-dwp (belt_test.c:473-543) -- STB A.19-1 / A.20-1 with the reference's incremental
-    pattern (tags taken mid-stream), the reference's outputs on short inputs, and on long seeded ones"""
-    g = golden.belt_dwp
+@pytest.mark.parametrize("mode", ["DWP", "CHE"])
+def test_belt_dwp_che_A19_A20_and_golden(orc, golden, mode):
+    """belt-dwp / belt-che (belt_test.c:473-563) -- STB A.19 / A.20 with the reference's
+    incremental pattern (tags taken mid-stream), the reference's outputs on short inputs, and on long seeded ones"""
+    g = golden.belt_dwp if mode == "DWP" else golden.belt_che
     for k in g["kat"]:
         key, iv = bytes.fromhex(k["key"]), bytes.fromhex(k["iv"])
-        out, macs = orc.dwp_steps(key, iv, _dwp_ops_from_kat(k))
+        out, macs = orc.dwp_steps(key, iv, _dwp_ops_from_kat(k), mode)
         assert out.hex() == k["out"] and macs[-1].hex() == k["mac"], k["name"]
         crit, op = bytes.fromhex(k["crit"]), bytes.fromhex(k["open"])
         if k["op"] == "wrap":
-            assert orc.dwp_wrap(crit, op, key, iv) == (0, bytes.fromhex(k["out"]), bytes.fromhex(k["mac"]))
+            assert orc.dwp_wrap(crit, op, key, iv, mode) == (0, bytes.fromhex(k["out"]), bytes.fromhex(k["mac"]))
         else:
-            assert orc.dwp_unwrap(crit, op, bytes.fromhex(k["mac"]), key, iv) == (0, bytes.fromhex(k["out"]))
+            assert orc.dwp_unwrap(crit, op, bytes.fromhex(k["mac"]), key, iv, mode) == (0, bytes.fromhex(k["out"]))
     for c in g["short"]:
         key, iv, crit, op = (bytes.fromhex(c[x]) for x in ("key", "iv", "crit", "open"))
-        assert orc.dwp_wrap(crit, op, key, iv) == (0, bytes.fromhex(c["out"]), bytes.fromhex(c["mac"]))
-        assert orc.dwp_unwrap(bytes.fromhex(c["out"]), op, bytes.fromhex(c["mac"]), key, iv) == (0, crit)
+        assert orc.dwp_wrap(crit, op, key, iv, mode) == (0, bytes.fromhex(c["out"]), bytes.fromhex(c["mac"]))
+        assert orc.dwp_unwrap(bytes.fromhex(c["out"]), op, bytes.fromhex(c["mac"]), key, iv, mode) == (0, crit)
         bad = bytes([int(c["mac"][:2], 16) ^ 0x80]) + bytes.fromhex(c["mac"])[1:]
-        assert orc.dwp_unwrap(bytes.fromhex(c["out"]), op, bad, key, iv)[0] == 511        # ERR_BAD_MAC
+        assert orc.dwp_unwrap(bytes.fromhex(c["out"]), op, bad, key, iv, mode)[0] == 511        # ERR_BAD_MAC
     for c in g["long"]:
         key, iv = bytes.fromhex(c["key"]), bytes.fromhex(c["iv"])
         crit, op = orc.fill(c["crit_len"], c["crit_seed"]), orc.fill(c["open_len"], c["open_seed"])
-        code, out, mac = orc.dwp_wrap(crit, op, key, iv)
+        code, out, mac = orc.dwp_wrap(crit, op, key, iv, mode)
         assert code == 0 and mac.hex() == c["mac"] and orc.belt_hash(out).hex() == c["out_belt_hash"], c["crit_len"]
-    assert orc.dwp_wrap(b"x", b"y", b"k" * 31, b"i" * 16)[0] == 109
+    assert orc.dwp_wrap(b"x", b"y", b"k" * 31, b"i" * 16, mode)[0] == 109
 
 
 def test_belt_bde_random_cases(orc, golden):

@@ -124,12 +124,14 @@ def test_belt_bde_random(orc):
             assert orc.bde(msg, key, iv, decr) == (0, out.raw), (fn, nb)
 
 
-def test_belt_dwp_step_sequences_with_midstream_tags(orc):
-    """8f-2 belt-dwp: the same randomly cut Step{I,E,A,G} sequence through the reference's state and the
-    oracle's -- every tag taken mid-stream and the ciphertext must agree; then Wrap / Unwrap incl. bad mac"""
+@pytest.mark.parametrize("mode", ["DWP", "CHE"])
+def test_belt_dwp_che_step_sequences_with_midstream_tags(orc, mode):
+    """8f-2 belt-dwp / belt-che: the same randomly cut Step{I,E,A,G} sequence through the reference's state and
+    the oracle's -- every tag taken mid-stream and the ciphertext must agree; then Wrap / Unwrap incl. bad mac"""
     L = refgen.ref()
-    L.beltDWP_keep.restype = _sz
+    getattr(L, f"belt{mode}_keep").restype = _sz
     rnd = random.Random(19)
+    R = lambda name: getattr(L, f"belt{mode}{name}")          # the reference's function of this mode
 
     def cut(b):
         parts = []
@@ -142,41 +144,41 @@ def test_belt_dwp_step_sequences_with_midstream_tags(orc):
         crit = rnd.randbytes(rnd.choice((0, 1, 7, 15, 16, 17, 31, 32, 33, 100, rnd.randrange(0, 600))))
         op = rnd.randbytes(rnd.choice((0, 1, 15, 16, 17, 32, 47, rnd.randrange(0, 300))))
         key, iv = rnd.randbytes(rnd.choice((16, 24, 32))), rnd.randbytes(16)
-        st = ctypes.create_string_buffer(L.beltDWP_keep())
-        L.beltDWPStart(st, key, _sz(len(key)), iv)
+        st = ctypes.create_string_buffer(getattr(L, f"belt{mode}_keep")())
+        R("Start")(st, key, _sz(len(key)), iv)
         ops, refout, refmacs = [], b"", []
 
         def tag():
             m = ctypes.create_string_buffer(8)
-            L.beltDWPStepG(m, st)
+            R("StepG")(m, st)
             refmacs.append(m.raw)
             ops.append(("G",))
         for part in cut(op):
             ops.append(("I", part))
-            L.beltDWPStepI(part, _sz(len(part)), st)
+            R("StepI")(part, _sz(len(part)), st)
             if rnd.random() < 0.3:
                 tag()
         for part in cut(crit):
             b = ctypes.create_string_buffer(part, len(part))
-            L.beltDWPStepE(b, _sz(len(part)), st)
+            R("StepE")(b, _sz(len(part)), st)
             refout += b.raw[: len(part)]
             ops.append(("E", part))
         for part in cut(refout):
             ops.append(("A", part))
-            L.beltDWPStepA(part, _sz(len(part)), st)
+            R("StepA")(part, _sz(len(part)), st)
             if rnd.random() < 0.3:
                 tag()
         tag()
-        assert orc.dwp_steps(key, iv, ops) == (refout, refmacs)
+        assert orc.dwp_steps(key, iv, ops, mode) == (refout, refmacs)
         d, m = ctypes.create_string_buffer(max(len(crit), 1)), ctypes.create_string_buffer(8)
-        assert L.beltDWPWrap(d, m, crit, _sz(len(crit)), op, _sz(len(op)), key, _sz(len(key)), iv) == 0
+        assert R("Wrap")(d, m, crit, _sz(len(crit)), op, _sz(len(op)), key, _sz(len(key)), iv) == 0
         assert (d.raw[: len(crit)], m.raw) == (refout, refmacs[-1])
-        assert orc.dwp_wrap(crit, op, key, iv) == (0, refout, m.raw)
+        assert orc.dwp_wrap(crit, op, key, iv, mode) == (0, refout, m.raw)
         bad = bytes([m.raw[0] ^ 1]) + m.raw[1:]
         d2 = ctypes.create_string_buffer(max(len(crit), 1))
         for mac in (m.raw, bad):
-            rc = L.beltDWPUnwrap(d2, refout, _sz(len(refout)), op, _sz(len(op)), mac, key, _sz(len(key)), iv)
-            oc, od = orc.dwp_unwrap(refout, op, mac, key, iv)
+            rc = R("Unwrap")(d2, refout, _sz(len(refout)), op, _sz(len(op)), mac, key, _sz(len(key)), iv)
+            oc, od = orc.dwp_unwrap(refout, op, mac, key, iv, mode)
             assert rc == oc == (0 if mac == m.raw else 511)
             if rc == 0:
                 assert od == d2.raw[: len(crit)] == crit

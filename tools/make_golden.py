@@ -267,47 +267,60 @@ def belt_random(seed=0xBE17):
     return cases
 
 
-def r_dwp_wrap(crit, open_, key, iv):
-    """beltDWPWrap of the reference (belt_dwp.c:198-232) -> (ciphertext, mac)"""
+def r_aead_wrap(mode, crit, open_, key, iv):
+    """beltDWPWrap / beltCHEWrap of the reference (belt_dwp.c:198-232, belt_che.c:243-277) -> (ciphertext, mac)"""
     d, m = ctypes.create_string_buffer(max(len(crit), 1)), ctypes.create_string_buffer(8)
-    assert L.beltDWPWrap(d, m, crit, _sz(len(crit)), open_, _sz(len(open_)), key, _sz(len(key)), iv) == 0
+    f = getattr(L, f"belt{mode}Wrap")
+    assert f(d, m, crit, _sz(len(crit)), open_, _sz(len(open_)), key, _sz(len(key)), iv) == 0
     return d.raw[: len(crit)], m.raw
 
 
-def dwp_cases(seed=0xD3B):
-    """belt-dwp of the reference.  kat: STB A.19-1 / A.20-1 with the step pattern of belt_test.c:473-543.
-    random: short (crit, open) pairs in full; long: messages given by (length, splitmix seed) with the
-    mac and the belt-hash of the ciphertext -- the lengths cross the chunk boundaries of a parallel
-    Horner evaluation (partial blocks on both inputs, empty inputs, >= 1 MiB)."""
+AEAD_KAT = {
+    # mode: (protect vector, unprotect vector) = (name, crit, open, key, iv, out hex, mac hex, step pattern);
+    # the step patterns are the reference's own (belt_test.c:473-563)
+    "DWP": (("A.19-1", H[:16], H[16:48], H[128:160], H[192:208], "52C9AF96FF50F64435FC43DEF56BD797", "3B2E0AEB2B91854B",
+             [["E", 7], ["E", 9], ["I", 14], ["G"], ["I", 18], ["G"], ["A", 12], ["G"], ["A", 4], ["G"]]),
+            ("A.20-1", H[64:80], H[80:112], H[160:192], H[208:224], "DF181ED008A20F43DCBBB93650DAD34B", "6A2C2C94C4150DC0",
+             [["I", 32], ["A", 16], ["D", 16], ["G"]])),
+    "CHE": (("A.19-2", H[:15], H[16:48], H[128:160], H[192:208], "BF3DAEAF5D18D2BCC30EA62D2E70A4", "548622B844123FF7",
+             [["E", 11], ["E", 4], ["I", 14], ["G"], ["I", 18], ["G"], ["A", 12], ["G"], ["A", 3], ["G"]]),
+            ("A.20-2", H[64:84], H[80:112], H[160:192], H[208:224], "2BABF43EB37B5398A9068F31A3C758B762F44AA9",
+             "7D9D4F59D40D197D", [["I", 32], ["A", 20], ["D", 20], ["G"]])),
+}
+
+
+def aead_cases(mode, seed):
+    """belt-dwp / belt-che of the reference.  kat: the STB vectors with the step pattern of belt_test.c.
+    short: (crit, open) pairs in full; long: messages given by (length, splitmix seed) with the mac and
+    the belt-hash of the ciphertext -- the lengths cross the chunk boundaries of a parallel Horner
+    evaluation (partial blocks on both inputs, empty inputs, >= 1 MiB)."""
     import random
     rnd = random.Random(seed)
-    y, t = r_dwp_wrap(H[:16], H[16:48], H[128:160], H[192:208])
-    check("31/A.19-1 Y", y, "52C9AF96FF50F64435FC43DEF56BD797")
-    check("31/A.19-1 T", t, "3B2E0AEB2B91854B")
-    x20 = ctypes.create_string_buffer(16)
-    assert L.beltDWPUnwrap(x20, H[64:80], _sz(16), H[80:112], _sz(32), bytes.fromhex("6A2C2C94C4150DC0"),
-                           H[160:192], _sz(32), H[208:224]) == 0
-    check("31/A.20-1 X", x20.raw, "DF181ED008A20F43DCBBB93650DAD34B")
-    kat = [{"name": "A.19-1", "op": "wrap", "crit": H[:16].hex(), "open": H[16:48].hex(), "key": H[128:160].hex(),
-            "iv": H[192:208].hex(), "out": y.hex(), "mac": t.hex(),
-            "steps": [["E", 7], ["E", 9], ["I", 14], ["G"], ["I", 18], ["G"], ["A", 12], ["G"], ["A", 4], ["G"]]},
-           {"name": "A.20-1", "op": "unwrap", "crit": H[64:80].hex(), "open": H[80:112].hex(), "key": H[160:192].hex(),
-            "iv": H[208:224].hex(), "out": x20.raw.hex(), "mac": "6a2c2c94c4150dc0",
-            "steps": [["I", 32], ["A", 16], ["D", 16], ["G"]]}]
+    (n1, c1, o1, k1, i1, y1, t1, s1), (n2, c2, o2, k2, i2, x2, t2, s2) = AEAD_KAT[mode]
+    y, t = r_aead_wrap(mode, c1, o1, k1, i1)
+    check(f"31/{n1} Y", y, y1)
+    check(f"31/{n1} T", t, t1)
+    xb = ctypes.create_string_buffer(len(c2))
+    assert getattr(L, f"belt{mode}Unwrap")(xb, c2, _sz(len(c2)), o2, _sz(len(o2)), bytes.fromhex(t2), k2, _sz(32), i2) == 0
+    check(f"31/{n2} X", xb.raw, x2)
+    kat = [{"name": n1, "op": "wrap", "crit": c1.hex(), "open": o1.hex(), "key": k1.hex(), "iv": i1.hex(),
+            "out": y.hex(), "mac": t.hex(), "steps": s1},
+           {"name": n2, "op": "unwrap", "crit": c2.hex(), "open": o2.hex(), "key": k2.hex(), "iv": i2.hex(),
+            "out": xb.raw.hex(), "mac": t2.lower(), "steps": s2}]
     short = []
     for i, (nc, no) in enumerate([(0, 0), (0, 1), (1, 0), (15, 15), (16, 16), (17, 17), (16, 0), (0, 16), (31, 33),
                                   (32, 48), (33, 47), (100, 7), (255, 256), (256, 255), (1000, 3), (4096, 4096),
                                   (4097, 1), (1023, 1025)]):
         key, iv = rnd.randbytes((16, 24, 32)[i % 3]), rnd.randbytes(16)
         crit, op = rnd.randbytes(nc), rnd.randbytes(no)
-        c, m = r_dwp_wrap(crit, op, key, iv)
+        c, m = r_aead_wrap(mode, crit, op, key, iv)
         short.append({"key": key.hex(), "iv": iv.hex(), "crit": crit.hex(), "open": op.hex(), "out": c.hex(), "mac": m.hex()})
     long_ = []
     for i, (nc, no) in enumerate([(1 << 16, 0), ((1 << 16) + 5, 1000), (16 * 8191, 16 * 4097), ((1 << 20) + 13, 3),
                                   (3, (1 << 20) - 7), (1 << 21, 1 << 18)]):
         key, iv = rnd.randbytes((32, 16, 24)[i % 3]), rnd.randbytes(16)
         crit, op = splitmix_bytes(nc, 0xC417 + i), splitmix_bytes(no, 0x09E7 + i)
-        c, m = r_dwp_wrap(crit, op, key, iv)
+        c, m = r_aead_wrap(mode, crit, op, key, iv)
         long_.append({"key": key.hex(), "iv": iv.hex(), "crit_len": nc, "crit_seed": 0xC417 + i, "open_len": no,
                       "open_seed": 0x09E7 + i, "gen": "splitmix64 LE words, x_i = mix(seed+(i+1)*golden)",
                       "out_belt_hash": r_belt_hash(c).hex(), "mac": m.hex()})
@@ -559,7 +572,9 @@ def main():
     with open(os.path.join(GOLD, "belt_bde_random.json"), "w") as f:
         json.dump(bde_random(), f, indent=1)
     with open(os.path.join(GOLD, "belt_dwp.json"), "w") as f:
-        json.dump(dwp_cases(), f, indent=1)
+        json.dump(aead_cases("DWP", 0xD3B), f, indent=1)
+    with open(os.path.join(GOLD, "belt_che.json"), "w") as f:
+        json.dump(aead_cases("CHE", 0xC4E), f, indent=1)
     base, edge = bign_sets()
     with open(os.path.join(GOLD, "bign_base.bin"), "wb") as f:      # n x (hash32 | sig48 | pub64)
         for h, s, p in base:
