@@ -189,6 +189,61 @@ void belt_bde_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uin
     }
 }
 
+// ---------------------------------------------------------------- belt-che ---
+// Keystream of belt-che (belt_che.c:86-98): S_0 = E_K(iv), S_j = S_{j-1} * x ^ 1, block i (0-based
+// from the Start of the stream) is XORed with E_K(S_{i+1}).  Closed form S_j = S_0 x^j ^ (x^j ^ 1) q
+// with q = (x + 1)^-1 = 0xFF..F82 (f(1) = 1, so q = (f + 1) / (x + 1)); for l <= 64:
+// S_{j+l} = S_j x^l ^ (2^l - 1), whose constant never reaches x^128 and needs no reduction.
+// Same shape as belt-bde: a wavefront owns a contiguous chunk, lane l starts from B x^l ^ (2^l - 1)
+// and steps 64 blocks at a time with S <- S x^64 ^ (2^64 - 1).
+//
+// states[w] = S_{first + w*chunk + 1} for w < nwaves; states[nwaves] = S_{first + nblocks}
+__global__ __launch_bounds__(64)
+void che_state_kernel(BeltCtr s0, uint64_t first, uint64_t chunk, uint64_t nblocks, unsigned nwaves,
+                      uint4 *__restrict__ states)
+{
+    const unsigned w = blockIdx.x * 64 + threadIdx.x;
+    if (w > nwaves) return;
+    const uint64_t j = w < nwaves ? first + (uint64_t)w * chunk + 1 : first + nblocks;
+    const Gf128 one = {1, 0}, q = {0xFFFFFFFFFFFFFF82ull, 0xFFFFFFFFFFFFFFFFull};
+    const Gf128 P = gf_mul_xpow(one, j);                                   // x^j
+    const Gf128 a = gf_mul(gf_from(make_uint4(s0.c[0], s0.c[1], s0.c[2], s0.c[3])), P);
+    Gf128 Pm = P;
+    Pm.lo ^= 1;
+    const Gf128 b = gf_mul(Pm, q);
+    Gf128 r;
+    r.lo = a.lo ^ b.lo; r.hi = a.hi ^ b.hi;
+    states[w] = gf_to(r);
+}
+
+__global__ __launch_bounds__(CTR_WG)
+void belt_che_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t nblocks, uint64_t chunk,
+                     BeltKey key, const uint4 *__restrict__ states)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    CtrTab::fill(smem, threadIdx.x, CTR_WG);
+    __syncthreads();
+    const CtrTab T(smem);
+    uint32_t K[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) K[i] = key.k[i];
+    const unsigned lane = threadIdx.x & 63u;
+    const uint64_t w = (uint64_t)blockIdx.x * (CTR_WG / 64) + (threadIdx.x >> 6);
+    const uint64_t c0 = w * chunk;
+    if (c0 >= nblocks) return;
+    const uint64_t end = c0 + chunk < nblocks ? c0 + chunk : nblocks;
+    Gf128 t = gf_mul_xk(gf_from(states[w]), lane);
+    t.lo ^= (1ull << lane) - 1ull;                                         // lane < 64
+    for (uint64_t i = c0 + lane; i < end; i += 64) {
+        uint32_t g[4] = {(uint32_t)t.lo, (uint32_t)(t.lo >> 32), (uint32_t)t.hi, (uint32_t)(t.hi >> 32)};
+        belt_encr(T, g, K);
+        const uint4 v = src[i];
+        dst[i] = make_uint4(v.x ^ g[0], v.y ^ g[1], v.z ^ g[2], v.w ^ g[3]);
+        t = gf_mul_x64(t);
+        t.lo = ~t.lo;                                                      // ^ (2^64 - 1)
+    }
+}
+
 // ------------------------------------------------- belt-dwp: polynomial MAC ---
 // T = t * r^n ^ XOR_{i=1..n} X_i * r^(n-i+1)  -- the value of `t` after absorbing n blocks
 // (belt_dwp.c:96-101: t <- (t ^ X) * r).  A wavefront owns one contiguous chunk; inside it the 64
@@ -454,6 +509,45 @@ err_t launch_belt_bde(int decr, const void *d_src, void *d_dst, size_t nblocks, 
     }
     if (d_s_out)
         B2H_TRY(hipMemcpyAsync(d_s_out, (const uint4 *)tw + nwaves, 16, hipMemcpyDeviceToDevice, st));
+    return ERR_OK;
+}
+
+// belt-che keystream over nblocks whole blocks that start `first` blocks after beltCHEStart
+// (s = the state's s as words); d_src may equal d_dst.  d_s_out (may be null) receives the state
+// after the piece, 16 bytes.
+err_t launch_belt_che(const void *d_src, void *d_dst, size_t nblocks, const uint32_t key[8], const uint32_t s[4],
+                      uint64_t first, void *d_s_out, hipStream_t st)
+{
+    if (nblocks == 0 && !d_s_out) return ERR_OK;
+    static bool attr[64];
+    if (!attr[cur_dev()]) {
+        B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(belt_che_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, CtrTab::kBytes));
+        attr[cur_dev()] = true;
+    }
+    BeltKey k; BeltCtr s0;
+    for (int i = 0; i < 8; ++i) k.k[i] = key[i];
+    for (int i = 0; i < 4; ++i) s0.c[i] = s[i];
+    const size_t wg_waves = CTR_WG / 64;
+    size_t grid = (nblocks + CTR_WG - 1) / CTR_WG;
+    const size_t cap = (size_t)num_cus() * (BeltTabWide::kBytes / CtrTab::kBytes);
+    if (grid > cap) grid = cap;
+    if (grid == 0) grid = 1;
+    const uint64_t nwaves = grid * wg_waves;
+    uint64_t chunk = (nblocks + nwaves - 1) / nwaves;
+    chunk = (chunk + 63) / 64 * 64;
+    if (chunk == 0) chunk = 64;
+    void *sv = nullptr;
+    err_t code = scratch_for_stream(st, 10, (nwaves + 1) * 16, &sv);
+    if (code != ERR_OK) return code;
+    hipLaunchKernelGGL(che_state_kernel, dim3((unsigned)((nwaves + 1 + 63) / 64)), dim3(64), 0, st, s0,
+                       (uint64_t)first, chunk, (uint64_t)nblocks, (unsigned)nwaves, (uint4 *)sv);
+    if (nblocks)
+        hipLaunchKernelGGL(belt_che_kernel, dim3((unsigned)grid), dim3(CTR_WG), CtrTab::kBytes, st,
+                           (const uint4 *)d_src, (uint4 *)d_dst, (uint64_t)nblocks, chunk, k, (const uint4 *)sv);
+    B2H_TRY(hipGetLastError());
+    if (d_s_out)
+        B2H_TRY(hipMemcpyAsync(d_s_out, (const uint4 *)sv + nwaves, 16, hipMemcpyDeviceToDevice, st));
     return ERR_OK;
 }
 

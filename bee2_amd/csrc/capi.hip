@@ -1001,6 +1001,115 @@ extern "C" err_t beltDWPUnwrap(void *dest, const void *src1, size_t count1, cons
     return ERR_OK;
 }
 
+// ------------------------------------------------------------------ belt-che ---
+struct belt_che_st {          // belt_che.c:27-41 (own layout).  mac.ctr.key = K, mac.r = E_K(iv); mac.ctr's
+    belt_dwp_st mac;          // counter fields are unused
+    u32 s[4];
+    octet gamma[16];
+    size_t reserved;
+};
+extern "C" size_t beltCHE_keep(void) { return sizeof(belt_che_st); }
+extern "C" void beltCHEStart(void *state, const octet key[], size_t len, const octet iv[16])
+{
+    belt_che_st *st = (belt_che_st *)state;
+    memset(st, 0, sizeof *st);
+    beltKeyExpand2(st->mac.ctr.key, key, len);
+    for (int i = 0; i < 4; ++i) st->mac.r[i] = load32le(iv + 4 * i);
+    beltBlockEncr2(st->mac.r, st->mac.ctr.key);                 // r = E_K(iv)  (belt_che.c:54-56)
+    for (int i = 0; i < 4; ++i) st->s[i] = st->mac.r[i];        // s = r
+    const octet *H = beltH();
+    for (int i = 0; i < 4; ++i) st->mac.t[i] = load32le(H + 4 * i);
+}
+extern "C" err_t bee2hip_beltCHE_blocks_dev(const void *d_src, void *d_dst, size_t nblocks, const u32 key[8],
+                                            const u32 s[4], uint64_t first_block, void *d_s_out, void *stream)
+{
+    if ((nblocks && (!d_src || !d_dst)) || !key || !s) return ERR_BAD_INPUT;
+    if (first_block + nblocks < first_block || first_block + nblocks == ~(uint64_t)0) return ERR_BAD_INPUT;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    return launch_belt_che(d_src, d_dst, nblocks, key, s, first_block, d_s_out, as_stream(stream));
+}
+static err_t che_blocks_host(octet *buf, size_t nblocks, belt_che_st *st)
+{
+    if (nblocks == 0) return ERR_OK;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    Scratch &sc = t_scr[2];
+    const size_t bytes = nblocks * 16;
+    code = sc.need(bytes + 16);
+    if (code != ERR_OK) return code;
+    octet *d = (octet *)sc.p;
+    B2H_TRY(hipMemcpy(d, buf, bytes, hipMemcpyHostToDevice));
+    code = launch_belt_che(d, d, nblocks, st->mac.ctr.key, st->s, 0, d + bytes, nullptr);
+    if (code != ERR_OK) return code;
+    octet snew[16];
+    B2H_TRY(hipMemcpy(buf, d, bytes, hipMemcpyDeviceToHost));
+    B2H_TRY(hipMemcpy(snew, d + bytes, 16, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) st->s[i] = load32le(snew + 4 * i);
+    return ERR_OK;
+}
+extern "C" void beltCHEStepE(void *buf_, size_t count, void *state)
+{
+    belt_che_st *st = (belt_che_st *)state;
+    octet *buf = (octet *)buf_;
+    if (st->reserved) {                                         // gamma left from the previous call (belt_che.c:69-83)
+        const size_t take = st->reserved < count ? st->reserved : count;
+        for (size_t i = 0; i < take; ++i) buf[i] ^= st->gamma[16 - st->reserved + i];
+        st->reserved -= take; buf += take; count -= take;
+    }
+    die_on(che_blocks_host(buf, count / 16, st), "beltCHEStepE");
+    buf += count / 16 * 16;
+    count %= 16;
+    if (count) {                                                // partial block: advance s (bookkeeping, like the CTR
+        const u32 out = st->s[3] >> 31;                         // counter increment), gamma = E_K(s) on the GPU
+        for (int i = 3; i > 0; --i) st->s[i] = (st->s[i] << 1) | (st->s[i - 1] >> 31);
+        st->s[0] = (st->s[0] << 1) ^ (out ? 0x87u : 0u) ^ 1u;
+        u32 g[4] = {st->s[0], st->s[1], st->s[2], st->s[3]};
+        beltBlockEncr2(g, st->mac.ctr.key);
+        for (int i = 0; i < 4; ++i) store32le(st->gamma + 4 * i, g[i]);
+        for (size_t i = 0; i < count; ++i) buf[i] ^= st->gamma[i];
+        st->reserved = 16 - count;
+    }
+}
+extern "C" void beltCHEStepD(void *buf, size_t count, void *state) { beltCHEStepE(buf, count, state); }
+extern "C" void beltCHEStepI(const void *buf, size_t count, void *state) { beltDWPStepI(buf, count, &((belt_che_st *)state)->mac); }
+extern "C" void beltCHEStepA(const void *buf, size_t count, void *state) { beltDWPStepA(buf, count, &((belt_che_st *)state)->mac); }
+extern "C" void beltCHEStepG(octet mac[8], void *state) { dwp_tag(mac, &((const belt_che_st *)state)->mac, "beltCHEStepG"); }
+extern "C" bool_t beltCHEStepV(const octet mac[8], void *state)
+{
+    octet m[8];
+    dwp_tag(m, &((const belt_che_st *)state)->mac, "beltCHEStepV");
+    return memcmp(m, mac, 8) == 0;
+}
+extern "C" err_t beltCHEWrap(void *dest, octet mac[8], const void *src1, size_t count1, const void *src2,
+                             size_t count2, const octet key[], size_t len, const octet iv[16])
+{
+    if ((len != 16 && len != 24 && len != 32) || (count1 && (!src1 || !dest)) || (count2 && !src2) || !key || !iv || !mac)
+        return ERR_BAD_INPUT;
+    belt_che_st st;
+    beltCHEStart(&st, key, len, iv);
+    beltCHEStepI(src2, count2, &st);
+    if (count1) memmove(dest, src1, count1);
+    beltCHEStepE(dest, count1, &st);
+    beltCHEStepA(dest, count1, &st);
+    beltCHEStepG(mac, &st);
+    return ERR_OK;
+}
+extern "C" err_t beltCHEUnwrap(void *dest, const void *src1, size_t count1, const void *src2, size_t count2,
+                               const octet mac[8], const octet key[], size_t len, const octet iv[16])
+{
+    if ((len != 16 && len != 24 && len != 32) || (count1 && (!src1 || !dest)) || (count2 && !src2) || !key || !iv || !mac)
+        return ERR_BAD_INPUT;
+    belt_che_st st;
+    beltCHEStart(&st, key, len, iv);
+    beltCHEStepI(src2, count2, &st);
+    beltCHEStepA(src1, count1, &st);
+    if (!beltCHEStepV(mac, &st)) return ERR_BAD_MAC;
+    if (count1) memmove(dest, src1, count1);
+    beltCHEStepD(dest, count1, &st);
+    return ERR_OK;
+}
+
 // ------------------------------------------------------------------ belt-bde ---
 struct belt_bde_st {          // belt_bde.c:26-32
     u32 key[8];

@@ -57,6 +57,8 @@ DROPIN_SYMBOLS = [
     "beltBDE_keep", "beltBDEStart", "beltBDEStepE", "beltBDEStepD", "beltBDEEncr", "beltBDEDecr",
     "beltDWP_keep", "beltDWPStart", "beltDWPStepE", "beltDWPStepI", "beltDWPStepA", "beltDWPStepD", "beltDWPStepG",
     "beltDWPStepV", "beltDWPWrap", "beltDWPUnwrap",
+    "beltCHE_keep", "beltCHEStart", "beltCHEStepE", "beltCHEStepI", "beltCHEStepA", "beltCHEStepD", "beltCHEStepG",
+    "beltCHEStepV", "beltCHEWrap", "beltCHEUnwrap",
     "beltMAC_keep", "beltMACStart", "beltMACStepA", "beltMACStepG", "beltMACStepG2",
     "beltMACStepV", "beltMACStepV2", "beltMAC",
     "bignParamsStd", "bignVerify", "bign128Verify", "bign192Verify", "bign256Verify",
@@ -65,7 +67,7 @@ BATCH_SYMBOLS = [
     "bee2hip_bashF_batch", "bee2hip_beltCTR_bulk", "bee2hip_bignVerify_batch",
     "bee2hip_bashHash_beltMAC_batch", "bee2hip_hash_ragged", "bee2hip_hash_ragged_dev", "bee2hip_hash_ragged_ordered_dev",
     "bee2hip_bashF_batch_dev", "bee2hip_beltCTR_blocks_dev", "bee2hip_beltBlockEncr_dev",
-    "bee2hip_beltModes_blocks_dev", "bee2hip_beltCBCEncr_batch_dev", "bee2hip_beltBDE_blocks_dev", "bee2hip_beltDWP_absorb_dev",
+    "bee2hip_beltModes_blocks_dev", "bee2hip_beltCBCEncr_batch_dev", "bee2hip_beltBDE_blocks_dev", "bee2hip_beltDWP_absorb_dev", "bee2hip_beltCHE_blocks_dev",
     "bee2hip_bign128Verify_batch_dev", "bee2hip_bignVerify_batch_dev", "bee2hip_bignVerifyL_batch_dev",
     "bee2hip_bashHash_beltMAC_batch_dev",
     "bee2hip_set_device", "bee2hip_sync", "bee2hip_last_error", "bee2hip_version",
@@ -159,36 +161,37 @@ class Engine:
                                                           self._stream()), "beltModes_blocks_dev")
 
     # ---- belt-dwp (8f-2)
-    def dwp_steps(self, key, iv, ops):
-        """ops = [("E"|"D"|"I"|"A", bytes) | ("G",) | ("V", mac)] applied to one state;
-        -> (E/D outputs concatenated, [mac per "G"], [bool per "V"])"""
-        st = ctypes.create_string_buffer(self.lib.beltDWP_keep())
-        self.lib.beltDWPStart(st, bytes(key), _sz(len(key)), bytes(iv))
+    def dwp_steps(self, key, iv, ops, mode="DWP"):
+        """ops = [("E"|"D"|"I"|"A", bytes) | ("G",) | ("V", mac)] applied to one belt-dwp (mode "DWP") or
+        belt-che ("CHE") state; -> (E/D outputs concatenated, [mac per "G"], [bool per "V"])"""
+        f = lambda name: getattr(self.lib, f"belt{mode}{name}")
+        st = ctypes.create_string_buffer(f("_keep")())
+        f("Start")(st, bytes(key), _sz(len(key)), bytes(iv))
         out, macs, oks = b"", [], []
         for op in ops:
             if op[0] in "ED":
                 b = ctypes.create_string_buffer(bytes(op[1]), max(len(op[1]), 1))
-                getattr(self.lib, "beltDWPStep" + op[0])(b, _sz(len(op[1])), st)
+                f("Step" + op[0])(b, _sz(len(op[1])), st)
                 out += b.raw[: len(op[1])]
             elif op[0] in "IA":
-                getattr(self.lib, "beltDWPStep" + op[0])(bytes(op[1]), _sz(len(op[1])), st)
+                f("Step" + op[0])(bytes(op[1]), _sz(len(op[1])), st)
             elif op[0] == "G":
                 m = ctypes.create_string_buffer(8)
-                self.lib.beltDWPStepG(m, st)
+                f("StepG")(m, st)
                 macs.append(m.raw)
             else:
-                oks.append(bool(self.lib.beltDWPStepV(bytes(op[1]), st)))
+                oks.append(bool(f("StepV")(bytes(op[1]), st)))
         return out, macs, oks
 
-    def dwp_wrap(self, crit, open_, key, iv):
+    def dwp_wrap(self, crit, open_, key, iv, mode="DWP"):
         dest, mac = ctypes.create_string_buffer(max(len(crit), 1)), ctypes.create_string_buffer(8)
-        code = self.lib.beltDWPWrap(dest, mac, bytes(crit), _sz(len(crit)), bytes(open_), _sz(len(open_)),
+        code = getattr(self.lib, f"belt{mode}Wrap")(dest, mac, bytes(crit), _sz(len(crit)), bytes(open_), _sz(len(open_)),
                                     bytes(key), _sz(len(key)), bytes(iv))
         return code, dest.raw[: len(crit)], mac.raw
 
-    def dwp_unwrap(self, crit, open_, mac, key, iv):
+    def dwp_unwrap(self, crit, open_, mac, key, iv, mode="DWP"):
         dest = ctypes.create_string_buffer(max(len(crit), 1))
-        code = self.lib.beltDWPUnwrap(dest, bytes(crit), _sz(len(crit)), bytes(open_), _sz(len(open_)),
+        code = getattr(self.lib, f"belt{mode}Unwrap")(dest, bytes(crit), _sz(len(crit)), bytes(open_), _sz(len(open_)),
                                       bytes(mac), bytes(key), _sz(len(key)), bytes(iv))
         return code, dest.raw[: len(crit)]
 
@@ -198,6 +201,22 @@ class Engine:
         self.lib.beltDWPStart(st, bytes(key), _sz(len(key)), bytes(iv))
         n = self.lib.beltCTR_keep()
         return st.raw[:32], st.raw[32:48], st.raw[n:n + 16], st.raw[n + 16:n + 32]
+
+    def beltCHEStart(self, key, iv):
+        """-> (expanded key, s0 = r = E_K(iv), t0 = H[0..16)) as bytes of u32 words"""
+        st = ctypes.create_string_buffer(self.lib.beltCHE_keep())
+        self.lib.beltCHEStart(st, bytes(key), _sz(len(key)), bytes(iv))
+        n = self.lib.beltCTR_keep()
+        return st.raw[:32], st.raw[n:n + 16], st.raw[n + 16:n + 32]
+
+    def beltCHE_blocks_dev(self, src, dst, key_words, s_words, first_block=0, s_out=None):
+        """belt-che keystream over whole blocks in HBM; the piece starts first_block blocks into the stream"""
+        n = src.numel() // 16
+        assert src.numel() == 16 * n and dst.numel() == 16 * n
+        self._check(self.lib.bee2hip_beltCHE_blocks_dev(self._ptr(src), self._ptr(dst), _sz(n), bytes(key_words),
+                                                        bytes(s_words), ctypes.c_uint64(first_block),
+                                                        self._ptr(s_out) if s_out is not None else None,
+                                                        self._stream()), "beltCHE_blocks_dev")
 
     def beltDWP_absorb_dev(self, data, nbytes, r_words, t_words, t_out):
         """t_out (16-byte device tensor) <- t after absorbing nbytes of the device tensor `data`"""

@@ -558,8 +558,15 @@ def main():
             eng.beltDWP_absorb_dev(buf, nbytes, dr, dt0, tout)
         el = timed(dist, kd, 1, wrap_dev)
         el_mac = timed(dist, kd, 1, lambda: eng.beltDWP_absorb_dev(buf, nbytes, dr, dt0, tout))
+        ckw, cs0, ct0 = eng.beltCHEStart(H[128:160], H[192:208])
+
+        def che_wrap_dev():                   # beltCHEWrap on resident data (r = s0 for belt-che)
+            eng.beltCHE_blocks_dev(buf, buf, ckw, cs0, 0)
+            eng.beltDWP_absorb_dev(buf, nbytes, cs0, ct0, tout)
+        el_che = timed(dist, kd, 1, che_wrap_dev)
         entry = {"metric": "belt-dwp wrap GiB/s", "unit": "GiB/s", "value": N * nbytes * kd / el / 2 ** 30, "steps": kd,
                  "ms_per_step": el / kd * 1e3, "mac_only": N * nbytes * kd / el_mac / 2 ** 30,
+                 "che_wrap": N * nbytes * kd / el_che / 2 ** 30,
                  "config": {"workload": f"{nbytes / 2**30:.0f} GiB message per GPU, device resident: beltCTR_blocks_dev + "
                                         "beltDWP_absorb_dev over the ciphertext (each rank its own message; SURVEY 8f-2)"}}
         if do_cpu:
@@ -587,6 +594,15 @@ def main():
                 entry["cpu_baseline"] = {"kind": "reference", "cores": nthr, "unit": "GiB/s", "value": nthr * per / dt / 2 ** 30,
                                          "sample": f"{nthr} threads, one 4 MiB beltDWPWrap each",
                                          "mac_equal": bool(code == 0 and gmac == macs[0].tobytes())}
+                cm = (ctypes.c_ubyte * 8)()
+                cb = np.ones(per, dtype=np.uint8)
+                t0 = time.perf_counter()
+                ref.beltCHEWrap(ctypes.c_void_p(cb.ctypes.data), cm, ctypes.c_void_p(cb.ctypes.data), ctypes.c_size_t(per),
+                                None, ctypes.c_size_t(0), key, ctypes.c_size_t(32), iv)
+                dt1 = time.perf_counter() - t0
+                code, _, gmac = eng.dwp_wrap(one.tobytes(), b"", key, iv, "CHE")
+                entry["cpu_baseline"]["che_wrap_single_thread"] = per / dt1 / 2 ** 30
+                entry["cpu_baseline"]["che_mac_equal"] = bool(code == 0 and gmac == bytes(cm))
         others["belt_dwp"] = entry
         del buf, tout
 

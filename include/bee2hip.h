@@ -138,6 +138,21 @@ err_t beltDWPWrap(void *dest, octet mac[8], const void *src1, size_t count1, con
 err_t beltDWPUnwrap(void *dest, const void *src1, size_t count1, const void *src2, size_t count2,
                     const octet mac[8], const octet key[], size_t len, const octet iv[16]);
 
+/* belt-che (belt_che.c:27-319): the belt-dwp authenticator with r = E_K(iv) and the keystream
+   E_K(s_i), s_0 = r, s_i = s_{i-1}*x ^ 1 in GF(2^128); same call order and error behaviour as belt-dwp */
+size_t beltCHE_keep(void);
+void beltCHEStart(void *state, const octet key[], size_t len, const octet iv[16]);
+void beltCHEStepE(void *buf, size_t count, void *state);
+void beltCHEStepI(const void *buf, size_t count, void *state);
+void beltCHEStepA(const void *buf, size_t count, void *state);
+void beltCHEStepD(void *buf, size_t count, void *state);
+void beltCHEStepG(octet mac[8], void *state);
+bool_t beltCHEStepV(const octet mac[8], void *state);
+err_t beltCHEWrap(void *dest, octet mac[8], const void *src1, size_t count1, const void *src2,
+                  size_t count2, const octet key[], size_t len, const octet iv[16]);
+err_t beltCHEUnwrap(void *dest, const void *src1, size_t count1, const void *src2, size_t count2,
+                    const octet mac[8], const octet key[], size_t len, const octet iv[16]);
+
 size_t beltBDE_keep(void);
 void beltBDEStart(void *state, const octet key[], size_t len, const octet iv[16]);
 void beltBDEStepE(void *buf, size_t count, void *state);
@@ -244,6 +259,11 @@ err_t bee2hip_beltCBCEncr_batch_dev(void *d_msgs, size_t nblk, size_t n, const u
    returns t.  Together with bee2hip_beltCTR_blocks_dev this is beltDWPWrap on resident data. */
 err_t bee2hip_beltDWP_absorb_dev(const void *d_data, size_t nbytes, const u32 r[4], const u32 t[4],
                                  void *d_t_out, void *stream);
+/* belt-che keystream on nblocks whole blocks, device resident, d_src may equal d_dst: block j of the
+   stream (first_block <= j < first_block + nblocks) is XORed with E_K(S_{j+1}), S_0 = s[4] = E_K(iv) as
+   u32 words, S_i = S_{i-1}*x ^ 1.  d_s_out (may be NULL) receives S_{first_block + nblocks}, 16 bytes. */
+err_t bee2hip_beltCHE_blocks_dev(const void *d_src, void *d_dst, size_t nblocks, const u32 key[8],
+                                 const u32 s[4], uint64_t first_block, void *d_s_out, void *stream);
 err_t bee2hip_beltBDE_blocks_dev(int decr, const void *d_src, void *d_dst, size_t nblocks,
                                  const u32 key[8], const u32 s[4], uint64_t first_block,
                                  void *d_s_out, void *stream);
