@@ -86,8 +86,10 @@ __device__ __forceinline__ void bash_s_layer(u64x2 (&a)[24], const int (&ix)[24]
 // interleaves the two classes almost one for one (290 class switches per 6 rounds; staged: 24) and
 // puts consumers right behind their producers; gfx950 issues that order 3 % slower on the whole
 // bashF kernel (profiles/r01_valu_rates_ubench.txt "class-switch cost"; A/B log profiles/r01_bashF_ab_staged.txt).
-// Costs ~40 more live VGPRs (113 in bashF_batch_kernel), so kernels that are register-bound keep
-// the compact order.
+// Costs ~40 more live VGPRs (113 in bashF_batch_kernel).  The fused hash+MAC kernel, capped at 128
+// VGPRs by its 1024-lane workgroups, spills 48-112 B per lane with it and is still 6 % faster
+// (profiles/r01_fused_ab_staged.txt: the spills are outside the round loop); with 768-lane
+// workgroups (no spills, 3 wavefronts per SIMD instead of 4) it loses 1 %.
 template <int TT> __device__ __forceinline__ uint32_t vbitop3(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t r;

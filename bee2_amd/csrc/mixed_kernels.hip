@@ -108,7 +108,7 @@ void hash_mac_fused_kernel(const uint4 *__restrict__ msgs, size_t msg_len, size_
                 a[2 * j].lo = x[j].x; a[2 * j].hi = x[j].y;
                 a[2 * j + 1].lo = x[j].z; a[2 * j + 1].hi = x[j].w;
             }
-            bash_f(a);
+            bash_f<true>(a);       // staged issue order: +6 % here even though it spills (bash_dev.hpp)
         }
     }
     // ---- tail blocks + padding (uniform across the batch: msg_len is)
@@ -152,7 +152,7 @@ void hash_mac_fused_kernel(const uint4 *__restrict__ msgs, size_t msg_len, size_
                 a[2 * j].lo = x[j].x; a[2 * j].hi = x[j].y;
                 a[2 * j + 1].lo = x[j].z; a[2 * j + 1].hi = x[j].w;
             }
-            bash_f(a);
+            bash_f<true>(a);
             const int nw = (int)(level / 32);    // digest = l/4 bytes = l/32 words
             uint64_t *d = reinterpret_cast<uint64_t *>(digests + (size_t)(level / 4) * idx);
 #pragma unroll

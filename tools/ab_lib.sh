@@ -16,6 +16,9 @@ d=json.load(sys.stdin)
 line='$1 %-9s %.4g %s' % (d['metric'][:24], d['value'], d['unit'])
 r=d.get('roofline') or {}
 if 'avg_launch_ms' in r: line+='  kernel %.4f ms' % r['avg_launch_ms']
+std={'value','n_gpus','steps','warmup','ms_per_step','vs_baseline'}
+for k,v in d.items():
+    if isinstance(v,float) and k not in std: line+='  %s %.4g' % (k, v)
 for k,v in (d.get('others') or {}).items(): line+='  | %s %.4g' % (k, v['value'])
 print(line)"; }
 for i in 1 2 3; do run A $A; run B $B; done
