@@ -315,7 +315,7 @@ def main():
                          "note": "VALU-issue bound in practice, see `valu` (DESIGN.md 2, 4.1)",
                          "valu": valu_picture(n / (ms_launch * 1e-3), BASHF_VALU)},
         }
-        if dist.rank == 0:
+        if dist.rank == 0 and N == 1:       # PCIe-inclusive rate: single-GPU runs only
             host = st.cpu().numpy()                               # pageable host copy of the same batch
             hp = ctypes.c_void_p(host.ctypes.data)
             v, ms = host_api_rate(lambda: eng._check(eng.lib.bee2hip_bashF_batch(hp, ctypes.c_size_t(n)), "bashF_batch"), n)
@@ -350,7 +350,7 @@ def main():
                                  "224 ds_read_b32 (floor 1146 GiB/s), DESIGN.md 2 and 4.2",
                          "valu": valu_picture(nb / (ms_launch * 1e-3), CTR_VALU)},
         }
-        if dist.rank == 0:
+        if dist.rank == 0 and N == 1:       # PCIe-inclusive rate: single-GPU runs only
             hn = 1 << 30                                          # 1 GiB through the drop-in one-shot beltCTR
             host = np.zeros(hn, dtype=np.uint8)
             hp = ctypes.c_void_p(host.ctypes.data)
@@ -405,7 +405,7 @@ def main():
                                  "v_mad_u64_u32 micro-benchmark (profiles/r01_valu_rates_ubench.txt); every mad is "
                                  "paired with a half-rate v_addc_co_u32, so 0.5 is the practical ceiling"},
         }
-        if dist.rank == 0:
+        if dist.rank == 0 and N == 1:       # PCIe-inclusive rate: single-GPU runs only
             hcodes = np.empty(n, dtype=np.uint32)
             prm = eng.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
             from bee2_amd.engine import OID_BELT_HASH_DER
