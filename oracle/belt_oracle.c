@@ -467,6 +467,72 @@ uint32_t orc_beltBDE(void *dest, const void *src, size_t count, const uint8_t *k
     return ORC_OK;
 }
 
+/* ---- belt-wbl on whole blocks and belt-sde (belt_wbl.c:58-152, belt_sde.c:38-121) ----
+   Wide-block cipher on n >= 2 blocks r_1..r_n.  Encryption round i = 1..2n:
+       s = r_1 ^ ... ^ r_{n-1};   (r_1, .., r_n) <- (r_2, .., r_{n-1}, r_n ^ E_K(s) ^ <i>, s)
+   with <i> the round number as a 64-bit little-endian integer in the first 8 bytes of the block.
+   Decryption runs the rounds i = 2n..1 backwards.  Written from the definition (the sum is
+   recomputed and the blocks really move every round), not in the reference's rolling-sum form. */
+static void wbl_round_word(uint32_t e[4], uint64_t i) { e[0] ^= (uint32_t)i; e[1] ^= (uint32_t)(i >> 32); }
+uint32_t orc_beltWBL(void *buf_, size_t nblocks, const uint32_t K[8], int decr)
+{
+    uint8_t *buf = (uint8_t *)buf_;
+    const size_t n = nblocks;
+    uint64_t i;
+    size_t j;
+    int k;
+    if (n < 2) return ORC_BAD_INPUT;
+    if (!decr) {
+        for (i = 1; i <= 2 * (uint64_t)n; ++i) {
+            uint32_t s[4] = {0, 0, 0, 0}, e[4], w[4];
+            uint8_t sb[16];
+            for (j = 0; j + 1 < n; ++j) { blk_load(w, buf + 16 * j); for (k = 0; k < 4; ++k) s[k] ^= w[k]; }
+            blk_store(sb, s);
+            for (k = 0; k < 4; ++k) e[k] = s[k];
+            orc_beltBlockEncr2(e, K);
+            wbl_round_word(e, i);
+            blk_load(w, buf + 16 * (n - 1));
+            for (k = 0; k < 4; ++k) w[k] ^= e[k];
+            memmove(buf, buf + 16, 16 * (n - 2));            /* r_2 .. r_{n-1} move down */
+            blk_store(buf + 16 * (n - 2), w);                  /* r_n ^ E(s) ^ <i> */
+            memcpy(buf + 16 * (n - 1), sb, 16);                /* s */
+        }
+    } else {
+        for (i = 2 * (uint64_t)n; i >= 1; --i) {
+            uint32_t s[4], e[4], w[4], r1[4];
+            blk_load(s, buf + 16 * (n - 1));                   /* s = r_n */
+            for (k = 0; k < 4; ++k) e[k] = s[k];
+            orc_beltBlockEncr2(e, K);
+            wbl_round_word(e, i);
+            blk_load(w, buf + 16 * (n - 2));                   /* old r_n = r_{n-1} ^ E(s) ^ <i> */
+            for (k = 0; k < 4; ++k) w[k] ^= e[k];
+            memmove(buf + 16, buf, 16 * (n - 2));              /* r_1 .. r_{n-2} become r_2 .. r_{n-1} */
+            blk_store(buf + 16 * (n - 1), w);
+            for (k = 0; k < 4; ++k) r1[k] = s[k];              /* old r_1 = s ^ r_2 ^ .. ^ r_{n-1} */
+            for (j = 1; j + 1 < n; ++j) { blk_load(w, buf + 16 * j); for (k = 0; k < 4; ++k) r1[k] ^= w[k]; }
+            blk_store(buf, r1);
+        }
+    }
+    return ORC_OK;
+}
+/* beltSDEEncr / beltSDEDecr: XEX around belt-wbl with the tweak E_K(iv) on the first block (belt_sde.c:47-71) */
+uint32_t orc_beltSDE(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
+                     const uint8_t iv[16], int decr)
+{
+    uint32_t K[8], s[4], w[4];
+    uint8_t *buf = (uint8_t *)dest;
+    int k;
+    if (count % 16 || count < 32 || (len != 16 && len != 24 && len != 32)) return ORC_BAD_INPUT;
+    orc_beltKeyExpand2(K, key, len);
+    blk_load(s, iv);
+    orc_beltBlockEncr2(s, K);
+    memmove(dest, src, count);
+    blk_load(w, buf); for (k = 0; k < 4; ++k) w[k] ^= s[k]; blk_store(buf, w);
+    orc_beltWBL(buf, count / 16, K, decr);
+    blk_load(w, buf); for (k = 0; k < 4; ++k) w[k] ^= s[k]; blk_store(buf, w);
+    return ORC_OK;
+}
+
 /* ---- belt-dwp: CTR encryption + polynomial MAC over GF(2^128) ------------
    State machine of belt_dwp.c:27-196.  The authenticator is t <- (t ^ X) * r for every 16-byte
    block X of the open data, then of the critical data (each zero-padded to whole blocks), then of

@@ -30,6 +30,8 @@ class Golden:
             self.bign_big = json.load(f)
         with open(os.path.join(GOLD, "belt_bde_random.json")) as f:
             self.belt_bde = json.load(f)
+        with open(os.path.join(GOLD, "belt_sde_random.json")) as f:
+            self.belt_sde = json.load(f)
         with open(os.path.join(GOLD, "belt_dwp.json")) as f:
             self.belt_dwp = json.load(f)
         with open(os.path.join(GOLD, "belt_che.json")) as f:

@@ -147,6 +147,16 @@ class Oracle:
                                           bytes(mac), bytes(key), _sz(len(key)), bytes(iv))
         return code, dest.raw[: len(crit)]
 
+    def sde(self, msg, key, iv, decr=False):
+        out = ctypes.create_string_buffer(max(len(msg), 1))
+        code = self.lib.orc_beltSDE(out, bytes(msg), _sz(len(msg)), bytes(key), _sz(len(key)), bytes(iv), int(decr))
+        return code, out.raw[: len(msg)]
+
+    def wbl(self, msg, key, decr=False):
+        buf = ctypes.create_string_buffer(bytes(msg), len(msg))
+        code = self.lib.orc_beltWBL(buf, _sz(len(msg) // 16), self.key_expand(key), int(decr))
+        return code, buf.raw[: len(msg)]
+
     def block_decr(self, block, key):
         w = (ctypes.c_uint32 * 4).from_buffer_copy(bytes(block))
         self.lib.orc_beltBlockDecr2(w, self.key_expand(key))

@@ -117,9 +117,11 @@ def test_belt_ecb_cbc_A9_A12(orc, golden):
             code, out = orc.ecb(msg, key, decr)
         elif "CBC" in k["fn"]:
             code, out = orc.cbc(msg, key, bytes.fromhex(k["iv"]), decr)
-        else:                                                # belt-bde, A.24-1 / A.25-1 (belt_test.c:628-660)
-            assert "BDE" in k["fn"]
+        elif "BDE" in k["fn"]:                               # belt-bde, A.24-1 / A.25-1 (belt_test.c:628-660)
             code, out = orc.bde(msg, key, bytes.fromhex(k["iv"]), decr)
+        else:                                                # belt-sde, A.24-2 / A.25-2 (belt_test.c:661-688)
+            assert "SDE" in k["fn"]
+            code, out = orc.sde(msg, key, bytes.fromhex(k["iv"]), decr)
         assert code == 0 and out.hex() == k["out"], k["name"]
 
 
@@ -180,6 +182,19 @@ def test_belt_bde_random_cases(orc, golden):
     for bad in (b"", b"x" * 15, b"x" * 17):                                      # whole blocks only, >= 1
         assert orc.bde(bad, b"k" * 32, b"i" * 16)[0] == 109
     assert orc.bde(b"x" * 16, b"k" * 31, b"i" * 16)[0] == 109
+
+
+def test_belt_sde_random_cases(orc, golden):
+    """belt-sde of the reference on sectors of 2..256 blocks (tools/make_golden.py sde_random)"""
+    assert len(golden.belt_sde) >= 14
+    for c in golden.belt_sde:
+        msg, key, iv = (bytes.fromhex(c[x]) for x in ("msg", "key", "iv"))
+        assert orc.sde(msg, key, iv) == (0, bytes.fromhex(c["sde_e"])), c["blocks"]
+        assert orc.sde(msg, key, iv, True) == (0, bytes.fromhex(c["sde_d"])), c["blocks"]
+        assert orc.sde(bytes.fromhex(c["sde_e"]), key, iv, True)[1] == msg
+        assert orc.wbl(orc.wbl(msg, key)[1], key, True)[1] == msg
+    for bad in (b"", b"x" * 16, b"x" * 31, b"x" * 33):                           # >= 2 whole blocks (belt_sde.c:79-80)
+        assert orc.sde(bad, b"k" * 32, b"i" * 16)[0] == 109
 
 
 def test_belt_ecb_cbc_random_cases(orc, golden):

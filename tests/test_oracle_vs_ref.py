@@ -124,6 +124,26 @@ def test_belt_bde_random(orc):
             assert orc.bde(msg, key, iv, decr) == (0, out.raw), (fn, nb)
 
 
+def test_belt_sde_wbl_random(orc):
+    """8f-1 belt-sde and the whole-block belt-wbl under it: one-shots / Step{E,D} of the reference"""
+    L = refgen.ref()
+    L.beltWBL_keep.restype = _sz
+    rnd = random.Random(31)
+    for _ in range(150):
+        nb = rnd.choice((2, 3, 4, 5, 6, 7, 8, 31, 32, 33, rnd.randrange(2, 300)))
+        msg, key, iv = rnd.randbytes(16 * nb), rnd.randbytes(rnd.choice((16, 24, 32))), rnd.randbytes(16)
+        for fn, decr in (("beltSDEEncr", False), ("beltSDEDecr", True)):
+            out = ctypes.create_string_buffer(len(msg))
+            assert getattr(L, fn)(out, msg, _sz(len(msg)), key, _sz(len(key)), iv) == 0
+            assert orc.sde(msg, key, iv, decr) == (0, out.raw), (fn, nb)
+        st = ctypes.create_string_buffer(L.beltWBL_keep())
+        L.beltWBLStart(st, key, _sz(len(key)))
+        for step, decr in ((L.beltWBLStepE, False), (L.beltWBLStepD, True)):
+            b = ctypes.create_string_buffer(msg, len(msg))
+            step(b, _sz(len(msg)), st)
+            assert orc.wbl(msg, key, decr) == (0, b.raw[: len(msg)]), (nb, decr)
+
+
 @pytest.mark.parametrize("mode", ["DWP", "CHE"])
 def test_belt_dwp_che_step_sequences_with_midstream_tags(orc, mode):
     """8f-2 belt-dwp / belt-che: the same randomly cut Step{I,E,A,G} sequence through the reference's state and

@@ -187,6 +187,11 @@ def stb_kats():
          "E9CAB32D879CC50C10378EB07C10F26307257E2DBE2B854CBC9F38282D59D6A77F952001C5D1244F53210A27C216D4BB"),
         ("A.25-1", "beltBDEDecr", H[64:112], H[160:192], H[208:224],
          "7041BC226352C706D00EA8EF23CFE46AFAE118577D037FACDC36E4ECC1F6574609F236943FB809E1BEE4A1C686C13ACC"),
+        # belt-sde (belt_test.c:661-688)
+        ("A.24-2", "beltSDEEncr", H[:48], H[128:160], H[192:208],
+         "1FCBB01852003D60B66024C508608BAA2C21AF1E884CF31154D3077D4643CF2249EB2F5A68E4BA019D90211A81D690D9"),
+        ("A.25-2", "beltSDEDecr", H[64:112], H[160:192], H[208:224],
+         "E9FDF3F788657332E6C46FCF5251B8A6D43543A93E3233837DB1571183A6EF4D7FEB5CDF999E1A3F51A5A3381BEB7FA5"),
     ]
     kat["belt_modes"] = []
     for name, fn, msg, key, iv, want in modes:
@@ -338,6 +343,20 @@ def bde_random(seed=0xBDE):
         cases.append({"blocks": nb, "key": key.hex(), "iv": iv.hex(), "msg": msg.hex(),
                       "bde_e": r_mode("beltBDEEncr", msg, key, iv).hex(),
                       "bde_d": r_mode("beltBDEDecr", msg, key, iv).hex()})
+    return cases
+
+
+def sde_random(seed=0x5DE):
+    """beltSDEEncr / beltSDEDecr of the reference (belt_sde.c:73-121) on sectors of 2..256 blocks: below and
+    above the sizes where the reference switches from its base to its rolling-sum form (belt_wbl.c:196-210)"""
+    import random
+    rnd = random.Random(seed)
+    cases = []
+    for i, nb in enumerate((2, 3, 4, 5, 6, 7, 8, 16, 31, 32, 33, 64, 100, 256)):
+        key, iv, msg = rnd.randbytes((16, 24, 32)[i % 3]), rnd.randbytes(16), rnd.randbytes(16 * nb)
+        cases.append({"blocks": nb, "key": key.hex(), "iv": iv.hex(), "msg": msg.hex(),
+                      "sde_e": r_mode("beltSDEEncr", msg, key, iv).hex(),
+                      "sde_d": r_mode("beltSDEDecr", msg, key, iv).hex()})
     return cases
 
 
@@ -571,6 +590,8 @@ def main():
         json.dump(belt_random(), f, indent=1)
     with open(os.path.join(GOLD, "belt_bde_random.json"), "w") as f:
         json.dump(bde_random(), f, indent=1)
+    with open(os.path.join(GOLD, "belt_sde_random.json"), "w") as f:
+        json.dump(sde_random(), f, indent=1)
     with open(os.path.join(GOLD, "belt_dwp.json"), "w") as f:
         json.dump(aead_cases("DWP", 0xD3B), f, indent=1)
     with open(os.path.join(GOLD, "belt_che.json"), "w") as f:
