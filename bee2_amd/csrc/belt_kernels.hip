@@ -189,6 +189,85 @@ void belt_bde_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uin
     }
 }
 
+// ---------------------------------------------------------------- belt-sde ---
+// belt-sde = XEX around belt-wbl (belt_sde.c:47-71): the first block is XORed with E_K(iv) before and
+// after the wide-block transform of the whole sector.  belt-wbl on n blocks is 2n *sequential* rounds
+// (belt_wbl.c:58-152): s = r_1 ^ .. ^ r_{n-1}; (r_1..r_n) <- (r_2, .., r_{n-1}, r_n ^ E_K(s) ^ <i>, s).
+// A sector is a serial chain, sectors are independent: one lane per sector, the sector stays in HBM.
+// Rolling form with a cyclic head h (logical r_1 lives at position h): the block a round needs as
+// "r_n" is the `s` written by the previous round, so it is carried in registers and a round costs
+// one 16-byte load (a[h]) and one store; after 2n rounds h is back at 0.  Decryption is the same
+// walk backwards.  (Derived from the definition and checked against it in tests; not the
+// reference's beltWBLStepEOpt.)
+template <int DECR>
+__global__ __launch_bounds__(CTR_WG)
+void belt_sde_kernel(uint4 *__restrict__ sectors, uint32_t n, uint64_t nsectors, BeltKey key,
+                     const uint4 *__restrict__ ivs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    CtrTab::fill(smem, threadIdx.x, CTR_WG);
+    __syncthreads();
+    const CtrTab T(smem);
+    uint32_t K[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) K[i] = key.k[i];
+    const uint64_t idx = (uint64_t)blockIdx.x * CTR_WG + threadIdx.x;
+    if (idx >= nsectors) return;
+    uint4 *a = sectors + idx * n;
+    const uint4 ivv = ivs[idx];
+    uint32_t tw[4] = {ivv.x, ivv.y, ivv.z, ivv.w};
+    belt_encr(T, tw, K);                                                  // E_K(iv)
+    auto ld = [&](uint32_t q) { return a[q]; };
+    {   // a[0] ^= E_K(iv)
+        uint4 v = a[0];
+        a[0] = make_uint4(v.x ^ tw[0], v.y ^ tw[1], v.z ^ tw[2], v.w ^ tw[3]);
+    }
+    uint32_t cur[4] = {0, 0, 0, 0};                                       // XOR of positions 0 .. n-2
+    for (uint32_t q = 0; q + 1 < n; ++q) {
+        const uint4 v = ld(q);
+        cur[0] ^= v.x; cur[1] ^= v.y; cur[2] ^= v.z; cur[3] ^= v.w;
+    }
+    const uint64_t rounds = 2ull * n;
+    if (!DECR) {
+        const uint4 l = ld(n - 1);
+        uint32_t prev[4] = {l.x, l.y, l.z, l.w};                          // logical r_n
+        uint32_t h = 0;
+        for (uint64_t i = 1; i <= rounds; ++i) {
+            uint32_t e[4] = {cur[0], cur[1], cur[2], cur[3]};
+            belt_encr(T, e, K);
+            e[0] ^= (uint32_t)i; e[1] ^= (uint32_t)(i >> 32);
+            const uint32_t x0 = prev[0] ^ e[0], x1 = prev[1] ^ e[1], x2 = prev[2] ^ e[2], x3 = prev[3] ^ e[3];
+            const uint4 ah = a[h];
+            a[h ? h - 1 : n - 1] = make_uint4(x0, x1, x2, x3);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) prev[k] = cur[k];
+            cur[0] ^= ah.x ^ x0; cur[1] ^= ah.y ^ x1; cur[2] ^= ah.z ^ x2; cur[3] ^= ah.w ^ x3;
+            h = h + 1 == n ? 0 : h + 1;
+        }
+        a[n - 1] = make_uint4(prev[0], prev[1], prev[2], prev[3]);        // h == 0 again
+    } else {
+        const uint4 l = ld(n - 1);
+        uint32_t sv[4] = {l.x, l.y, l.z, l.w};                            // s = logical r_n
+        uint32_t h = n - 1;
+        for (uint64_t i = rounds; i >= 1; --i) {
+            uint32_t e[4] = {sv[0], sv[1], sv[2], sv[3]};
+            belt_encr(T, e, K);
+            e[0] ^= (uint32_t)i; e[1] ^= (uint32_t)(i >> 32);
+            const uint4 x = a[h ? h - 1 : n - 1];
+            a[h] = make_uint4(cur[0] ^ sv[0] ^ x.x, cur[1] ^ sv[1] ^ x.y, cur[2] ^ sv[2] ^ x.z, cur[3] ^ sv[3] ^ x.w);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cur[k] = sv[k];
+            sv[0] = x.x ^ e[0]; sv[1] = x.y ^ e[1]; sv[2] = x.z ^ e[2]; sv[3] = x.w ^ e[3];
+            h = h ? h - 1 : n - 1;
+        }
+        a[h] = make_uint4(sv[0], sv[1], sv[2], sv[3]);                    // h == n - 1 again
+    }
+    {
+        uint4 v = a[0];
+        a[0] = make_uint4(v.x ^ tw[0], v.y ^ tw[1], v.z ^ tw[2], v.w ^ tw[3]);
+    }
+}
+
 // ---------------------------------------------------------------- belt-che ---
 // Keystream of belt-che (belt_che.c:86-98): S_0 = E_K(iv), S_j = S_{j-1} * x ^ 1, block i (0-based
 // from the Start of the stream) is XORed with E_K(S_{i+1}).  Closed form S_j = S_0 x^j ^ (x^j ^ 1) q
@@ -509,6 +588,32 @@ err_t launch_belt_bde(int decr, const void *d_src, void *d_dst, size_t nblocks, 
     }
     if (d_s_out)
         B2H_TRY(hipMemcpyAsync(d_s_out, (const uint4 *)tw + nwaves, 16, hipMemcpyDeviceToDevice, st));
+    return ERR_OK;
+}
+
+// nsectors sectors of nblk >= 2 whole blocks each, contiguous, transformed in place; d_ivs = nsectors x 16 bytes
+err_t launch_belt_sde(int decr, void *d_sectors, size_t nblk, size_t nsectors, const uint32_t key[8],
+                      const void *d_ivs, hipStream_t st)
+{
+    if (nsectors == 0) return ERR_OK;
+    if (nblk < 2 || nblk > 0x7fffffffull) return ERR_BAD_INPUT;
+    static bool attr[64][2];
+    const void *kern = decr ? reinterpret_cast<const void *>(belt_sde_kernel<1>)
+                            : reinterpret_cast<const void *>(belt_sde_kernel<0>);
+    if (!attr[cur_dev()][decr ? 1 : 0]) {
+        B2H_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, CtrTab::kBytes));
+        attr[cur_dev()][decr ? 1 : 0] = true;
+    }
+    BeltKey k;
+    for (int i = 0; i < 8; ++i) k.k[i] = key[i];
+    const unsigned grid = (unsigned)((nsectors + CTR_WG - 1) / CTR_WG);
+    if (decr)
+        hipLaunchKernelGGL(belt_sde_kernel<1>, dim3(grid), dim3(CTR_WG), CtrTab::kBytes, st, (uint4 *)d_sectors,
+                           (uint32_t)nblk, (uint64_t)nsectors, k, (const uint4 *)d_ivs);
+    else
+        hipLaunchKernelGGL(belt_sde_kernel<0>, dim3(grid), dim3(CTR_WG), CtrTab::kBytes, st, (uint4 *)d_sectors,
+                           (uint32_t)nblk, (uint64_t)nsectors, k, (const uint4 *)d_ivs);
+    B2H_TRY(hipGetLastError());
     return ERR_OK;
 }
 

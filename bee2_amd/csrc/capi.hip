@@ -1001,6 +1001,79 @@ extern "C" err_t beltDWPUnwrap(void *dest, const void *src1, size_t count1, cons
     return ERR_OK;
 }
 
+// ------------------------------------------------------------------ belt-sde ---
+struct belt_wbl_st {          // belt_lcl.h:143-149
+    u32 key[8];
+    octet block[16];
+    octet sum[16];
+    uint64_t round;           // `word` on this ABI
+};
+struct belt_sde_st {          // belt_sde.c:26-30
+    belt_wbl_st wbl[1];
+    octet s[16];
+};
+extern "C" size_t beltSDE_keep(void) { return sizeof(belt_sde_st); }
+extern "C" void beltSDEStart(void *state, const octet key[], size_t len)
+{
+    belt_sde_st *st = (belt_sde_st *)state;
+    beltKeyExpand2(st->wbl->key, key, len);
+    st->wbl->round = 0;
+}
+extern "C" err_t bee2hip_beltSDE_sectors_dev(int decr, void *d_sectors, size_t sector_bytes, size_t nsectors,
+                                             const u32 key[8], const void *d_ivs, void *stream)
+{
+    if ((decr != 0 && decr != 1) || !key || (nsectors && (!d_sectors || !d_ivs))) return ERR_BAD_INPUT;
+    if (sector_bytes % 16 != 0 || sector_bytes < 32) return ERR_BAD_INPUT;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    return launch_belt_sde(decr, d_sectors, sector_bytes / 16, nsectors, key, d_ivs, as_stream(stream));
+}
+static err_t sde_host(int decr, octet *buf, size_t count, const octet iv[16], belt_sde_st *st)
+{
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    Scratch &sc = t_scr[2];
+    code = sc.need(count + 16);
+    if (code != ERR_OK) return code;
+    octet *d = (octet *)sc.p;
+    B2H_TRY(hipMemcpy(d, buf, count, hipMemcpyHostToDevice));
+    B2H_TRY(hipMemcpy(d + count, iv, 16, hipMemcpyHostToDevice));
+    code = launch_belt_sde(decr, d, count / 16, 1, st->wbl->key, d + count, nullptr);
+    if (code != ERR_OK) return code;
+    B2H_TRY(hipMemcpy(buf, d, count, hipMemcpyDeviceToHost));
+    st->wbl->round = decr ? 0 : 2 * (uint64_t)(count / 16);     // where the reference's loops stop (belt_wbl.c)
+    return ERR_OK;
+}
+extern "C" void beltSDEStepE(void *buf, size_t count, const octet iv[16], void *state)
+{
+    die_on(sde_host(0, (octet *)buf, count, iv, (belt_sde_st *)state), "beltSDEStepE");
+}
+extern "C" void beltSDEStepD(void *buf, size_t count, const octet iv[16], void *state)
+{
+    die_on(sde_host(1, (octet *)buf, count, iv, (belt_sde_st *)state), "beltSDEStepD");
+}
+static err_t sde_oneshot(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                         const octet iv[16], int decr)
+{
+    // belt_sde.c:79-86
+    if (count % 16 != 0 || count < 32 || (len != 16 && len != 24 && len != 32) || !src || !dest || !key || !iv)
+        return ERR_BAD_INPUT;
+    belt_sde_st st;
+    beltSDEStart(&st, key, len);
+    memmove(dest, src, count);
+    return sde_host(decr, (octet *)dest, count, iv, &st);
+}
+extern "C" err_t beltSDEEncr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                             const octet iv[16])
+{
+    return sde_oneshot(dest, src, count, key, len, iv, 0);
+}
+extern "C" err_t beltSDEDecr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                             const octet iv[16])
+{
+    return sde_oneshot(dest, src, count, key, len, iv, 1);
+}
+
 // ------------------------------------------------------------------ belt-che ---
 struct belt_che_st {          // belt_che.c:27-41 (own layout).  mac.ctr.key = K, mac.r = E_K(iv); mac.ctr's
     belt_dwp_st mac;          // counter fields are unused

@@ -50,6 +50,8 @@ err_t launch_belt_mac(void *d_states, const void *d_data, size_t stride, size_t 
 // alg: 0 = belt-hash; 128 / 192 / 256 = bash256 / bash384 / bash512
 err_t launch_belt_bde(int decr, const void *d_src, void *d_dst, size_t nblocks, const uint32_t key[8],
                       const uint32_t s[4], uint64_t first, void *d_s_out, hipStream_t st);
+err_t launch_belt_sde(int decr, void *d_sectors, size_t nblk, size_t nsectors, const uint32_t key[8],
+                      const void *d_ivs, hipStream_t st);
 err_t launch_belt_che(const void *d_src, void *d_dst, size_t nblocks, const uint32_t key[8], const uint32_t s[4],
                       uint64_t first, void *d_s_out, hipStream_t st);
 err_t launch_belt_polyhash(const void *d_data, size_t nbytes, const uint32_t r[4], const uint32_t t[4],

@@ -55,6 +55,7 @@ DROPIN_SYMBOLS = [
     "beltECB_keep", "beltECBStart", "beltECBStepE", "beltECBStepD", "beltECBEncr", "beltECBDecr",
     "beltCBC_keep", "beltCBCStart", "beltCBCStepE", "beltCBCStepD", "beltCBCEncr", "beltCBCDecr",
     "beltBDE_keep", "beltBDEStart", "beltBDEStepE", "beltBDEStepD", "beltBDEEncr", "beltBDEDecr",
+    "beltSDE_keep", "beltSDEStart", "beltSDEStepE", "beltSDEStepD", "beltSDEEncr", "beltSDEDecr",
     "beltDWP_keep", "beltDWPStart", "beltDWPStepE", "beltDWPStepI", "beltDWPStepA", "beltDWPStepD", "beltDWPStepG",
     "beltDWPStepV", "beltDWPWrap", "beltDWPUnwrap",
     "beltCHE_keep", "beltCHEStart", "beltCHEStepE", "beltCHEStepI", "beltCHEStepA", "beltCHEStepD", "beltCHEStepG",
@@ -67,7 +68,7 @@ BATCH_SYMBOLS = [
     "bee2hip_bashF_batch", "bee2hip_beltCTR_bulk", "bee2hip_bignVerify_batch",
     "bee2hip_bashHash_beltMAC_batch", "bee2hip_hash_ragged", "bee2hip_hash_ragged_dev", "bee2hip_hash_ragged_ordered_dev",
     "bee2hip_bashF_batch_dev", "bee2hip_beltCTR_blocks_dev", "bee2hip_beltBlockEncr_dev",
-    "bee2hip_beltModes_blocks_dev", "bee2hip_beltCBCEncr_batch_dev", "bee2hip_beltBDE_blocks_dev", "bee2hip_beltDWP_absorb_dev", "bee2hip_beltCHE_blocks_dev",
+    "bee2hip_beltModes_blocks_dev", "bee2hip_beltCBCEncr_batch_dev", "bee2hip_beltBDE_blocks_dev", "bee2hip_beltSDE_sectors_dev", "bee2hip_beltDWP_absorb_dev", "bee2hip_beltCHE_blocks_dev",
     "bee2hip_bign128Verify_batch_dev", "bee2hip_bignVerify_batch_dev", "bee2hip_bignVerifyL_batch_dev",
     "bee2hip_bashHash_beltMAC_batch_dev",
     "bee2hip_set_device", "bee2hip_sync", "bee2hip_last_error", "bee2hip_version",
@@ -223,6 +224,14 @@ class Engine:
         self._check(self.lib.bee2hip_beltDWP_absorb_dev(self._ptr(data) if nbytes else None, _sz(nbytes),
                                                         bytes(r_words), bytes(t_words), self._ptr(t_out),
                                                         self._stream()), "beltDWP_absorb_dev")
+
+    def beltSDE_sectors_dev(self, decr, sectors, sector_bytes, key_words, ivs):
+        """belt-sde over contiguous sectors in HBM, in place; ivs = n x 16-byte device tensor"""
+        n = ivs.numel() // 16
+        assert sectors.numel() == n * sector_bytes
+        self._check(self.lib.bee2hip_beltSDE_sectors_dev(int(decr), self._ptr(sectors), _sz(sector_bytes), _sz(n),
+                                                         bytes(key_words), self._ptr(ivs), self._stream()),
+                    "beltSDE_sectors_dev")
 
     def beltBDEStart(self, key, iv):
         """-> (expanded key, s = E_K(iv)) as 32 + 16 bytes of u32 words, for beltBDE_blocks_dev"""
@@ -400,17 +409,21 @@ class Engine:
         return code, out.raw[: len(src)]
 
     def belt_mode_steps(self, mode, decr, src, key, iv, splits):
-        """Start / Step{E,D}* of beltECB (mode 'ECB'), beltCBC ('CBC') or beltBDE ('BDE')"""
+        """Start / Step{E,D}* of beltECB (mode 'ECB'), beltCBC ('CBC'), beltBDE ('BDE'); for 'SDE' every split
+        is one sector with the same iv (beltSDEStep{E,D}(buf, count, iv, state), belt_sde.c:47-71)"""
         st = ctypes.create_string_buffer(getattr(self.lib, f"belt{mode}_keep")())
-        if mode == "ECB":
-            self.lib.beltECBStart(st, bytes(key), _sz(len(key)))
+        if mode in ("ECB", "SDE"):
+            getattr(self.lib, f"belt{mode}Start")(st, bytes(key), _sz(len(key)))
         else:
             getattr(self.lib, f"belt{mode}Start")(st, bytes(key), _sz(len(key)), bytes(iv))
         step = getattr(self.lib, f"belt{mode}Step{'D' if decr else 'E'}")
         buf = ctypes.create_string_buffer(bytes(src), len(src))
         off = 0
         for s in splits:
-            step(ctypes.byref(buf, off), _sz(s), st)
+            if mode == "SDE":
+                step(ctypes.byref(buf, off), _sz(s), bytes(iv), st)
+            else:
+                step(ctypes.byref(buf, off), _sz(s), st)
             off += s
         return buf.raw[: len(src)]
 

@@ -616,7 +616,7 @@ def main():
         fill_seeded(src, 0xBE17 + dist.rank)
         dst = torch.empty_like(src)
         km = max(3, min(K, 10))
-        entry = {"metric": "belt ECB/CBC/BDE bulk GiB/s", "unit": "GiB/s", "steps": km,
+        entry = {"metric": "belt ECB/CBC/BDE/SDE bulk GiB/s", "unit": "GiB/s", "steps": km,
                  "config": {"workload": f"{nbytes / 2**30:.0f} GiB of full blocks per GPU, one key (SURVEY 8f-1)"}}
         for name, mode in (("ecb_encr", 0), ("ecb_decr", 1), ("cbc_decr", 2)):
             el = timed(dist, km, 1, lambda: eng.beltModes_blocks_dev(mode, src, dst, kw, c0))
@@ -627,6 +627,15 @@ def main():
             el = timed(dist, km, 1, lambda: eng.beltBDE_blocks_dev(decr, src, dst, bkw, bs0,
                                                                    first_block=dist.rank * (nbytes // 16)))
             entry[name] = N * nbytes * km / el / 2 ** 30
+        # belt-sde: independent sectors, one lane each (a sector is a serial chain of 2 E per block)
+        for sb in (512, 4096):
+            ns = (1 << 29) // sb                                   # 512 MiB of sectors per GPU
+            sec = src[: ns * sb]
+            sivs = dst[: 16 * ns]
+            fill_seeded(sivs, 0x5DE + dist.rank)
+            for name, decr in ((f"sde_encr_{sb}", 0), (f"sde_decr_{sb}", 1)):
+                el = timed(dist, km, 1, lambda: eng.beltSDE_sectors_dev(decr, sec, sb, kw, sivs))
+                entry[name] = N * ns * sb * km / el / 2 ** 30
         entry["value"] = entry["ecb_encr"]
         entry["ms_per_step"] = nbytes / 2 ** 30 / entry["ecb_encr"] * 1e3 * N
         if do_cpu:
@@ -638,10 +647,11 @@ def main():
                 hb = np.zeros(64 << 20, dtype=np.uint8)
                 ho = np.empty_like(hb)
                 cpu = {"cores": cores, "kind": "reference", "unit": "GiB/s",
-                       "sample": "64 MiB of full blocks, threads over disjoint slices"}
+                       "sample": "64 MiB of full blocks, threads over disjoint slices (belt-sde: each slice one sector)"}
                 for name, fn, iv in (("ecb_encr", "beltECBEncr", None), ("ecb_decr", "beltECBDecr", None),
                                      ("cbc_decr", "beltCBCDecr", H[192:208]), ("bde_encr", "beltBDEEncr", H[192:208]),
-                                     ("bde_decr", "beltBDEDecr", H[192:208])):
+                                     ("bde_decr", "beltBDEDecr", H[192:208]), ("sde_encr", "beltSDEEncr", H[192:208]),
+                                     ("sde_decr", "beltSDEDecr", H[192:208])):
                     fp = ctypes.cast(getattr(ref, fn), ctypes.c_void_p)
                     t0, reps = time.perf_counter(), 0
                     while time.perf_counter() - t0 < 1.5:

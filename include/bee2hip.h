@@ -118,8 +118,7 @@ err_t beltCBCDecr(void *dest, const void *src, size_t count, const octet key[], 
 /* belt-bde, block-wise disk encryption (belt.h:1360-1455, src/crypto/belt/belt_bde.c:26-133):
    s <- E_K(iv); for every 16-byte block s <- s*x in GF(2^128), Y = E_K(X ^ s) ^ s (StepD: D_K).
    count must be a multiple of 16; the one-shots return ERR_BAD_INPUT for count < 16 or
-   count % 16 != 0 (belt_bde.c:93-100).  belt-sde is NOT provided: it wraps belt-wbl, a serial
-   wide-block construction over the whole sector (belt_sde.c:38-71, belt_wbl.c). */
+   count % 16 != 0 (belt_bde.c:93-100). */
 /* belt-dwp, authenticated encryption: CTR + polynomial MAC over GF(2^128) (belt.h, src/crypto/belt/
    belt_dwp.c:27-274).  The state is an opaque POD of beltDWP_keep() bytes (not bee2's layout: bee2
    appends a beltPolyMul stack).  Order of calls as in bee2: Start, StepI* (open data), then
@@ -137,6 +136,20 @@ err_t beltDWPWrap(void *dest, octet mac[8], const void *src1, size_t count1, con
                   size_t count2, const octet key[], size_t len, const octet iv[16]);
 err_t beltDWPUnwrap(void *dest, const void *src1, size_t count1, const void *src2, size_t count2,
                     const octet mac[8], const octet key[], size_t len, const octet iv[16]);
+
+/* belt-sde, sector-wise disk encryption (belt.h, src/crypto/belt/belt_sde.c:26-121): XEX around
+   the wide-block cipher belt-wbl with the tweak E_K(iv) on the first block.  One call = one sector:
+   count a multiple of 16, >= 32 (the one-shots return ERR_BAD_INPUT otherwise, belt_sde.c:79-80).
+   A sector is a serial chain of 2*(count/16) block encryptions; the batch entry below runs many
+   sectors, one lane each. */
+size_t beltSDE_keep(void);
+void beltSDEStart(void *state, const octet key[], size_t len);
+void beltSDEStepE(void *buf, size_t count, const octet iv[16], void *state);
+void beltSDEStepD(void *buf, size_t count, const octet iv[16], void *state);
+err_t beltSDEEncr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                  const octet iv[16]);
+err_t beltSDEDecr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                  const octet iv[16]);
 
 /* belt-che (belt_che.c:27-319): the belt-dwp authenticator with r = E_K(iv) and the keystream
    E_K(s_i), s_0 = r, s_i = s_{i-1}*x ^ 1 in GF(2^128); same call order and error behaviour as belt-dwp */
@@ -259,6 +272,10 @@ err_t bee2hip_beltCBCEncr_batch_dev(void *d_msgs, size_t nblk, size_t n, const u
    returns t.  Together with bee2hip_beltCTR_blocks_dev this is beltDWPWrap on resident data. */
 err_t bee2hip_beltDWP_absorb_dev(const void *d_data, size_t nbytes, const u32 r[4], const u32 t[4],
                                  void *d_t_out, void *stream);
+/* belt-sde on nsectors contiguous sectors of sector_bytes each (a multiple of 16, >= 32), device
+   resident, in place; d_ivs = nsectors x 16 bytes, one iv per sector.  decr = 0 / 1. */
+err_t bee2hip_beltSDE_sectors_dev(int decr, void *d_sectors, size_t sector_bytes, size_t nsectors,
+                                  const u32 key[8], const void *d_ivs, void *stream);
 /* belt-che keystream on nblocks whole blocks, device resident, d_src may equal d_dst: block j of the
    stream (first_block <= j < first_block + nblocks) is XORed with E_K(S_{j+1}), S_0 = s[4] = E_K(iv) as
    u32 words, S_i = S_{i-1}*x ^ 1.  d_s_out (may be NULL) receives S_{first_block + nblocks}, 16 bytes. */
