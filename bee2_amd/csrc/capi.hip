@@ -5,6 +5,7 @@
 // error codes); every primitive evaluation is a kernel launch.  There is no CPU
 // implementation of bashF / E_K / EC arithmetic in this library.
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -65,23 +66,34 @@ err_t ensure_device()
     return ERR_OK;
 }
 
-struct PoolEntry { int dev; hipStream_t st; int slot; void *p; size_t bytes; };
+// Device scratch of the launchers (tweak tables, partial sums, the verify pipeline's SoA arrays), keyed by
+// (device, stream, slot): work queued on one stream is ordered, so one buffer per stream is enough.  The
+// NULL stream is the exception -- every thread of the host-pointer / drop-in API launches on it, and
+// thread B's first kernel may run between thread A's first and second -- so there the key also carries
+// the calling thread.  (A caller who drives one non-null stream from several threads at once has to
+// serialise them himself, as for any stream.)  Buffers live until process exit.
+struct PoolEntry { int dev; hipStream_t st; int slot; unsigned tid; void *p; size_t bytes; };
 static std::mutex g_pool_mu;
-static PoolEntry g_pool[256];
-static int g_pool_n = 0;
+static std::vector<PoolEntry> g_pool;
+static std::atomic<unsigned> g_next_tid{1};
+static thread_local unsigned t_tid = 0;
 
 err_t scratch_for_stream(hipStream_t st, int slot, size_t bytes, void **out)
 {
     int dev = 0;
     B2H_TRY(hipGetDevice(&dev));
+    unsigned tid = 0;
+    if (st == nullptr) {
+        if (t_tid == 0) t_tid = g_next_tid.fetch_add(1);
+        tid = t_tid;
+    }
     std::lock_guard<std::mutex> lk(g_pool_mu);
     PoolEntry *e = nullptr;
-    for (int i = 0; i < g_pool_n; ++i)
-        if (g_pool[i].dev == dev && g_pool[i].st == st && g_pool[i].slot == slot) { e = &g_pool[i]; break; }
+    for (PoolEntry &x : g_pool)
+        if (x.dev == dev && x.st == st && x.slot == slot && x.tid == tid) { e = &x; break; }
     if (!e) {
-        if (g_pool_n == 256) return ERR_OUTOFMEMORY;
-        e = &g_pool[g_pool_n++];
-        e->dev = dev; e->st = st; e->slot = slot; e->p = nullptr; e->bytes = 0;
+        g_pool.push_back(PoolEntry{dev, st, slot, tid, nullptr, 0});
+        e = &g_pool.back();
     }
     if (e->bytes < bytes) {
         if (e->p) {

@@ -1,0 +1,65 @@
+"""-m gpu: the drop-in entry points are re-entrant, as bee2's are (SURVEY.md 8b "Threading"): several host
+threads call a mix of them at the same time (ctypes releases the GIL for the duration of a call, so the
+calls really overlap inside the library: per-thread scratch, the per-stream pool, lazily built tables)."""
+import threading
+
+import pytest
+
+from gpulib import engine
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dropin_calls_from_eight_threads(orc, golden):
+    eng = engine()
+    H = golden.H
+    hs, ss, ps = golden.bign_base_arrays()
+    import os
+    nthreads, rounds = int(os.environ.get("BEE2_TEST_THREADS", "8")), 6
+    jobs = []                                     # per thread: list of (callable, expected)
+    for t in range(nthreads):
+        key, iv = orc.fill(32, 100 + t), orc.fill(16, 200 + t)
+        msg = orc.fill(16 * (40 + 7 * t) + (t % 5), 300 + t)          # ragged for CTR / MAC / hash
+        blocks = orc.fill(16 * (64 + t), 400 + t)                      # whole blocks for the block modes
+        i = 17 * t
+        trip = (hs[32 * i:32 * i + 32], ss[48 * i:48 * i + 48], ps[64 * i:64 * i + 64])
+        bad = (trip[0], bytes([trip[1][0] ^ 1]) + trip[1][1:], trip[2])
+        crit, op = msg[:100 + t], msg[100 + t:]
+        wrapped = orc.dwp_wrap(crit, op, key, iv)
+        che = orc.dwp_wrap(crit, op, key, iv, "CHE")
+        jobs.append([
+            (lambda m=msg, k=key, v=iv: eng.beltCTR(m, k, v), (0, orc.ctr(msg, key, iv))),
+            (lambda m=msg: eng.bashHash(128, m), orc.bashHash(128, msg)),
+            (lambda m=msg, k=key: eng.beltMAC(m, k), (0, orc.mac(msg, key))),
+            (lambda b=blocks, k=key, v=iv: eng.belt_mode("beltBDEEncr", b, k, v), orc.bde(blocks, key, iv)),
+            (lambda b=blocks, k=key, v=iv: eng.belt_mode("beltSDEDecr", b, k, v), orc.sde(blocks, key, iv, True)),
+            (lambda b=blocks, k=key, v=iv: eng.belt_mode("beltCBCDecr", b, k, v), orc.cbc(blocks, key, iv, True)),
+            (lambda c=crit, o=op, k=key, v=iv: eng.dwp_wrap(c, o, k, v), wrapped),
+            (lambda c=che[1], o=op, m=che[2], k=key, v=iv: eng.dwp_unwrap(c, o, m, k, v, "CHE"), (0, crit)),
+            (lambda x=trip: eng.bign128Verify(*x), 0),
+            (lambda x=bad: eng.bign128Verify(*x), 510),
+            (lambda m=msg: eng.hash_ragged(0, [m, m[:33], b""]),
+             (0, [orc.belt_hash(msg), orc.belt_hash(msg[:33]), orc.belt_hash(b"")])),
+        ])
+    errors = []
+    start = threading.Barrier(nthreads)
+
+    def run(t):
+        try:
+            start.wait()
+            for r in range(rounds):
+                order = jobs[t][r % len(jobs[t]):] + jobs[t][:r % len(jobs[t])]     # threads are out of phase
+                for j, (call, want) in enumerate(order):
+                    got = call()
+                    if got != want:
+                        errors.append((t, r, j))
+                        return
+        except Exception as e:                                            # noqa: BLE001
+            errors.append((t, repr(e)))
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not any(th.is_alive() for th in threads), "a thread is stuck"
+    assert not errors, errors[:5]
