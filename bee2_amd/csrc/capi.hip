@@ -133,6 +133,10 @@ static thread_local Scratch t_scr[4];
 
 using namespace bee2hip;
 
+// The kernels read blocks / states / field elements as 16-byte vectors: a misaligned device pointer
+// would be a GPU memory fault, so the _dev entry points refuse it with ERR_BAD_INPUT instead.
+static inline bool misaligned(const void *p, size_t a) { return p && ((uintptr_t)p & (a - 1)) != 0; }
+
 // ============================================================== management ===
 extern "C" err_t bee2hip_set_device(int device)
 {
@@ -150,6 +154,7 @@ extern "C" const char *bee2hip_version(void) { return "bee2hip 0.1 gfx950"; }
 // ===================================================== device-pointer batch ===
 extern "C" err_t bee2hip_bashF_batch_dev(void *d_states, size_t n, void *stream)
 {
+    if (misaligned(d_states, 16)) return ERR_BAD_INPUT;
     if (n && !d_states) return ERR_BAD_INPUT;
     return launch_bashF_batch(d_states, n, as_stream(stream));
 }
@@ -157,6 +162,7 @@ extern "C" err_t bee2hip_bashF_batch_dev(void *d_states, size_t n, void *stream)
 extern "C" err_t bee2hip_beltCTR_blocks_dev(void *d_buf, size_t nblocks, const u32 key[8],
                                             const u32 ctr0[4], uint64_t first_block, void *stream)
 {
+    if (misaligned(d_buf, 16)) return ERR_BAD_INPUT;
     if ((nblocks && !d_buf) || !key || !ctr0) return ERR_BAD_INPUT;
     err_t code = ensure_device();
     if (code != ERR_OK) return code;
@@ -165,6 +171,7 @@ extern "C" err_t bee2hip_beltCTR_blocks_dev(void *d_buf, size_t nblocks, const u
 
 extern "C" err_t bee2hip_beltBlockEncr_dev(void *d_blocks, size_t nblocks, const u32 key[8], void *stream)
 {
+    if (misaligned(d_blocks, 16)) return ERR_BAD_INPUT;
     if ((nblocks && !d_blocks) || !key) return ERR_BAD_INPUT;
     err_t code = ensure_device();
     if (code != ERR_OK) return code;
@@ -447,6 +454,7 @@ extern "C" err_t bee2hip_bignVerifyL_batch_dev(size_t l, const octet oid_der[], 
                                                const void *d_pubkeys, size_t n, void *d_codes,
                                                void *stream)
 {
+    if (misaligned(d_hashes, 16) || misaligned(d_sigs, 16) || misaligned(d_pubkeys, 16) || misaligned(d_codes, 4)) return ERR_BAD_INPUT;
     if (l != 128 && l != 192 && l != 256) return ERR_BAD_PARAMS;
     if (n && (!d_hashes || !d_sigs || !d_pubkeys || !d_codes)) return ERR_BAD_INPUT;
     if (!oid_der_valid(oid_der, oid_len)) return ERR_BAD_OID;
@@ -691,6 +699,7 @@ extern "C" err_t bee2hip_bashHash_beltMAC_batch_dev(const void *d_msgs, size_t m
                                                     const octet key[], size_t key_len,
                                                     void *d_digests, void *d_tags, void *stream)
 {
+    if (misaligned(d_msgs, 16)) return ERR_BAD_INPUT;
     const bool do_hash = d_digests != nullptr, do_mac = d_tags != nullptr;
     if (do_hash && (l == 0 || l % 16 != 0 || l > 256)) return ERR_BAD_PARAMS;      // bash_hash.c:122-123
     if (do_mac && ((key_len != 16 && key_len != 24 && key_len != 32) || !key)) return ERR_BAD_INPUT;
@@ -797,6 +806,7 @@ extern "C" void beltBlockDecr3(u32 *a, u32 *b, u32 *c, u32 *d, const u32 key[8])
 extern "C" err_t bee2hip_beltModes_blocks_dev(int mode, const void *d_src, void *d_dst, size_t nblocks,
                                               const u32 key[8], const u32 iv[4], void *stream)
 {
+    if (misaligned(d_src, 16) || misaligned(d_dst, 16)) return ERR_BAD_INPUT;
     if ((nblocks && (!d_src || !d_dst)) || !key || (mode == 2 && !iv)) return ERR_BAD_INPUT;
     err_t code = ensure_device();
     if (code != ERR_OK) return code;
@@ -806,6 +816,7 @@ extern "C" err_t bee2hip_beltModes_blocks_dev(int mode, const void *d_src, void 
 extern "C" err_t bee2hip_beltCBCEncr_batch_dev(void *d_msgs, size_t nblk, size_t n, const u32 key[8],
                                                void *d_ivs, void *stream)
 {
+    if (misaligned(d_msgs, 16) || misaligned(d_ivs, 16)) return ERR_BAD_INPUT;
     if ((n && (!d_msgs || !d_ivs)) || !key) return ERR_BAD_INPUT;
     err_t code = ensure_device();
     if (code != ERR_OK) return code;
@@ -905,6 +916,7 @@ extern "C" void beltDWPStepD(void *buf, size_t count, void *state) { beltCTRStep
 extern "C" err_t bee2hip_beltDWP_absorb_dev(const void *d_data, size_t nbytes, const u32 r[4], const u32 t[4],
                                             void *d_t_out, void *stream)
 {
+    if (misaligned(d_data, 16) || misaligned(d_t_out, 4)) return ERR_BAD_INPUT;
     if ((nbytes && !d_data) || !r || !t || !d_t_out) return ERR_BAD_INPUT;
     err_t code = ensure_device();
     if (code != ERR_OK) return code;
@@ -1034,6 +1046,7 @@ extern "C" void beltSDEStart(void *state, const octet key[], size_t len)
 extern "C" err_t bee2hip_beltSDE_sectors_dev(int decr, void *d_sectors, size_t sector_bytes, size_t nsectors,
                                              const u32 key[8], const void *d_ivs, void *stream)
 {
+    if (misaligned(d_sectors, 16) || misaligned(d_ivs, 16)) return ERR_BAD_INPUT;
     if ((decr != 0 && decr != 1) || !key || (nsectors && (!d_sectors || !d_ivs))) return ERR_BAD_INPUT;
     if (sector_bytes % 16 != 0 || sector_bytes < 32) return ERR_BAD_INPUT;
     err_t code = ensure_device();
@@ -1108,6 +1121,7 @@ extern "C" void beltCHEStart(void *state, const octet key[], size_t len, const o
 extern "C" err_t bee2hip_beltCHE_blocks_dev(const void *d_src, void *d_dst, size_t nblocks, const u32 key[8],
                                             const u32 s[4], uint64_t first_block, void *d_s_out, void *stream)
 {
+    if (misaligned(d_src, 16) || misaligned(d_dst, 16)) return ERR_BAD_INPUT;
     if ((nblocks && (!d_src || !d_dst)) || !key || !s) return ERR_BAD_INPUT;
     if (first_block + nblocks < first_block || first_block + nblocks == ~(uint64_t)0) return ERR_BAD_INPUT;
     err_t code = ensure_device();
@@ -1215,6 +1229,7 @@ extern "C" err_t bee2hip_beltBDE_blocks_dev(int decr, const void *d_src, void *d
                                             const u32 key[8], const u32 s[4], uint64_t first_block,
                                             void *d_s_out, void *stream)
 {
+    if (misaligned(d_src, 16) || misaligned(d_dst, 16)) return ERR_BAD_INPUT;
     if ((nblocks && (!d_src || !d_dst)) || !key || !s || (decr != 0 && decr != 1)) return ERR_BAD_INPUT;
     if (first_block + nblocks < first_block || first_block + nblocks == ~(uint64_t)0) return ERR_BAD_INPUT;
     err_t code = ensure_device();
@@ -1367,6 +1382,7 @@ extern "C" err_t beltCBCDecr(void *dest, const void *src, size_t count, const oc
 extern "C" err_t bee2hip_hash_ragged_ordered_dev(size_t alg, const void *d_data, const void *d_offsets,
                                                  const void *d_order, size_t n, void *d_digests, void *stream)
 {
+    if (misaligned(d_offsets, 8) || misaligned(d_order, 4)) return ERR_BAD_INPUT;
     if (alg != 0 && alg != 128 && alg != 192 && alg != 256) return ERR_BAD_PARAMS;
     if (n && (!d_offsets || !d_digests)) return ERR_BAD_INPUT;
     err_t code = ensure_device();

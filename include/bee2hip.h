@@ -245,6 +245,10 @@ err_t bee2hip_hash_ragged_ordered_dev(size_t alg, const void *d_data, const void
 
 /* ======================================================================== *
  * (3) device-pointer batch API (buffers in HBM; async on `stream`)
+ *     Device pointers to states, blocks, sectors, messages and verify records must be 16-byte
+ *     aligned (the kernels read them as 16-byte vectors), d_codes 4-byte, ragged offsets 8-byte:
+ *     a misaligned pointer is refused with ERR_BAD_INPUT.  One stream = one queue: threads that
+ *     share a stream serialise their calls themselves.
  * ======================================================================== */
 err_t bee2hip_bashF_batch_dev(void *d_states, size_t n, void *stream);
 /* full 16-byte blocks only: block i (0-based) ^= E_K(ctr0 + first_block + i + 1),

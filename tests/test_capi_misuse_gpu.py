@@ -1,0 +1,52 @@
+"""-m gpu: misuse of the device-pointer API is refused with an error code, not a GPU fault."""
+import pytest
+import torch
+
+from bee2_amd.engine import EngineError
+from gpulib import dev, engine, host
+
+pytestmark = pytest.mark.gpu
+
+
+def test_misaligned_device_pointers_are_refused(orc, golden):
+    eng = engine()
+    kw, c0 = eng.beltCTRStart(golden.H[128:160], golden.H[192:208])
+    bkw, bs0 = eng.beltBDEStart(golden.H[128:160], golden.H[192:208])
+    _, _, r, t0 = eng.beltDWPStart(golden.H[128:160], golden.H[192:208])
+    big = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    off = big[1:]                                               # data_ptr() + 1
+    a16 = big[: 16 * 64]
+    tout = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    hs, ss, ps = golden.bign_base_arrays()
+    dh, ds, dp = dev(hs[:32 * 4]), dev(ss[:48 * 4]), dev(ps[:64 * 4])
+    codes = torch.zeros(4, dtype=torch.int32, device="cuda")
+    calls = {
+        "bashF": lambda: eng.bashF_batch_dev(off[: 192 * 4]),
+        "ctr": lambda: eng.beltCTR_blocks_dev(off[: 16 * 64], kw, c0, 0),
+        "ecb src": lambda: eng.beltModes_blocks_dev(0, off[: 16 * 64], a16, kw),
+        "ecb dst": lambda: eng.beltModes_blocks_dev(0, a16, off[: 16 * 64], kw),
+        "bde": lambda: eng.beltBDE_blocks_dev(0, off[: 16 * 64], a16, bkw, bs0),
+        "che": lambda: eng.beltCHE_blocks_dev(a16, off[: 16 * 64], bkw, bs0),
+        "sde": lambda: eng.beltSDE_sectors_dev(0, off[: 512 * 2], 512, bkw, big[:32]),
+        "sde ivs": lambda: eng.beltSDE_sectors_dev(0, big[: 512 * 2], 512, bkw, off[:32]),
+        "dwp absorb": lambda: eng.beltDWP_absorb_dev(off, 1000, r, t0, tout),
+        "verify": lambda: eng.bign128Verify_batch_dev(dh.new_zeros(32 * 4 + 1)[1:], ds, dp, codes),
+        "fused": lambda: eng.bashHash_beltMAC_batch_dev(off[: 64 * 8], 64, 256, golden.H[128:160],
+                                                        torch.zeros(64 * 8, dtype=torch.uint8, device="cuda"),
+                                                        torch.zeros(8 * 8, dtype=torch.uint8, device="cuda"), n=8),
+    }
+    for name, call in calls.items():
+        with pytest.raises(EngineError) as e:
+            call()
+        assert "err 109" in str(e.value), (name, str(e.value))
+    # bad sector size / unknown flags
+    with pytest.raises(EngineError):
+        eng.beltSDE_sectors_dev(0, big[: 16 * 2], 16, bkw, big[:32])          # one block is not a sector
+    with pytest.raises(EngineError):
+        eng.beltSDE_sectors_dev(0, big[: 40 * 2], 40, bkw, big[:32])          # not whole blocks
+    # ... and the device is still healthy: a correct call right after
+    data = orc.fill(16 * 100, 1)
+    buf = dev(data)
+    eng.beltCTR_blocks_dev(buf, kw, c0, 0)
+    torch.cuda.synchronize()
+    assert host(buf) == orc.ctr(data, golden.H[128:160], golden.H[192:208])
