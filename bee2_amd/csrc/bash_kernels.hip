@@ -36,17 +36,6 @@ void bashF_batch_kernel(uint8_t *__restrict__ states, size_t n)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint8_t *wl = smem + wave * BASHF_WAVE_LDS;
-    // The 3 wavefronts that share a SIMD come from different workgroups and would otherwise
-    // march in phase (load together, permute together, store together).  A static priority
-    // derived from the block index de-phases them: +2 % measured.  Block -> CU placement is
-    // not contractual; a different placement only changes speed.
-    switch ((blockIdx.x >> 3) & 3u) {
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    case 3: __builtin_amdgcn_s_setprio(3); break;
-    default: break;
-    }
-
     const size_t first = ((size_t)blockIdx.x * (BASHF_WG / 64) + wave) * 64;   // first state of this wave
     if (first >= n) return;                                                     // whole wave idle (wave-uniform)
     const size_t left = n - first;
