@@ -1025,6 +1025,99 @@ extern "C" err_t beltDWPUnwrap(void *dest, const void *src1, size_t count1, cons
     return ERR_OK;
 }
 
+// ----------------------------------------------------------------- belt-hash ---
+struct belt_hash_st {         // belt_hash.c:28-36 (own layout: h || s contiguous for the kernel)
+    u32 hs[12];               // h[8] || s[4]
+    uint64_t bits_lo, bits_hi;
+    octet block[32];
+    size_t filled;
+};
+extern "C" size_t beltHash_keep(void) { return sizeof(belt_hash_st); }
+extern "C" void beltHashStart(void *state)
+{
+    belt_hash_st *st = (belt_hash_st *)state;
+    const octet *H = beltH();
+    for (int i = 0; i < 8; ++i) st->hs[i] = load32le(H + 4 * i);     // h = H[0..32)  (belt_hash.c:52)
+    for (int i = 8; i < 12; ++i) st->hs[i] = 0;
+    st->bits_lo = st->bits_hi = 0;
+    st->filled = 0;
+}
+// hs <- hs after nblocks 32-byte blocks of host data (+ the final length block when fin); on the GPU
+static err_t hash_stream_host(u32 hs[12], const octet *data, size_t nblocks, int fin, uint64_t lo, uint64_t hi)
+{
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    Scratch &sc = t_scr[2];
+    const size_t bytes = nblocks * 32;
+    code = sc.need(bytes + 64);
+    if (code != ERR_OK) return code;
+    octet *d = (octet *)sc.p;
+    if (bytes) B2H_TRY(hipMemcpy(d, data, bytes, hipMemcpyHostToDevice));
+    B2H_TRY(hipMemcpy(d + bytes, hs, 48, hipMemcpyHostToDevice));
+    code = launch_belt_hash_stream(d + bytes, d, nblocks, fin, lo, hi, nullptr);
+    if (code != ERR_OK) return code;
+    B2H_TRY(hipMemcpy(hs, d + bytes, 48, hipMemcpyDeviceToHost));
+    return ERR_OK;
+}
+extern "C" void beltHashStepH(const void *buf, size_t count, void *state)
+{
+    belt_hash_st *st = (belt_hash_st *)state;
+    const octet *p = (const octet *)buf;
+    const uint64_t add = (uint64_t)count << 3;                        // 128-bit bit counter (belt_lcl.c:25-51)
+    st->bits_lo += add;
+    st->bits_hi += ((uint64_t)count >> 61) + (st->bits_lo < add);
+    if (st->filled) {
+        size_t take = 32 - st->filled;
+        if (take > count) take = count;
+        memcpy(st->block + st->filled, p, take);
+        st->filled += take; p += take; count -= take;
+        if (st->filled < 32) return;
+        die_on(hash_stream_host(st->hs, st->block, 1, 0, 0, 0), "beltHashStepH");
+        st->filled = 0;
+    }
+    const size_t full = count / 32;
+    if (full) die_on(hash_stream_host(st->hs, p, full, 0, 0, 0), "beltHashStepH");
+    if (count % 32) { memcpy(st->block, p + 32 * full, count % 32); st->filled = count % 32; }
+}
+static void hash_digest(octet out[32], const belt_hash_st *st, const char *who)
+{
+    u32 hs[12];
+    memcpy(hs, st->hs, sizeof hs);                                    // the state is not disturbed (belt_hash.c:108-135)
+    octet tail[32];
+    size_t n = 0;
+    if (st->filled) { memset(tail, 0, 32); memcpy(tail, st->block, st->filled); n = 1; }
+    die_on(hash_stream_host(hs, tail, n, 1, st->bits_lo, st->bits_hi), who);
+    for (int i = 0; i < 8; ++i) store32le(out + 4 * i, hs[i]);
+}
+extern "C" void beltHashStepG(octet hash[32], void *state) { hash_digest(hash, (const belt_hash_st *)state, "beltHashStepG"); }
+extern "C" void beltHashStepG2(octet hash[], size_t hash_len, void *state)
+{
+    octet d[32];
+    hash_digest(d, (const belt_hash_st *)state, "beltHashStepG2");
+    memcpy(hash, d, hash_len < 32 ? hash_len : 32);
+}
+extern "C" bool_t beltHashStepV(const octet hash[32], void *state)
+{
+    octet d[32];
+    hash_digest(d, (const belt_hash_st *)state, "beltHashStepV");
+    return memcmp(d, hash, 32) == 0;
+}
+extern "C" bool_t beltHashStepV2(const octet hash[], size_t hash_len, void *state)
+{
+    octet d[32];
+    hash_digest(d, (const belt_hash_st *)state, "beltHashStepV2");
+    return memcmp(d, hash, hash_len < 32 ? hash_len : 32) == 0;
+}
+extern "C" err_t beltHash(octet hash[32], const void *src, size_t count)
+{
+    if (!hash || (count && !src)) return ERR_BAD_INPUT;              // belt_hash.c:177-179
+    belt_hash_st st;
+    beltHashStart(&st);
+    beltHashStepH(src, count, &st);
+    beltHashStepG(hash, &st);
+    return ERR_OK;
+}
+
 // ------------------------------------------------------------------ belt-sde ---
 struct belt_wbl_st {          // belt_lcl.h:143-149
     u32 key[8];

@@ -426,6 +426,51 @@ void belt_hash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *_
         for (int b = 0; b < 4; ++b) d[4 * k + b] = (uint8_t)(h[k] >> (8 * b));
 }
 
+// Streaming belt-hash for the drop-in beltHashStep* (belt_hash.c:43-171): one serial chain.
+// hs = h[8] || s[4] (in / out); nblocks whole 32-byte blocks at data; with fin != 0 the block
+// <bit length>_128 || s is compressed as well (belt_hash.c:120-135) and hs[0..8) is the digest.
+__global__ __launch_bounds__(64)
+void belt_hash_stream_kernel(uint32_t *__restrict__ hs, const uint8_t *__restrict__ data, size_t nblocks, int fin,
+                             uint64_t bits_lo, uint64_t bits_hi)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[BeltTabSmall::kBytes];
+    BeltTabSmall::fill(smem, threadIdx.x, 64);
+    __syncthreads();
+    const BeltTabSmall T(smem);
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t h[8], s[4], X[8], s1[4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h[k] = hs[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = hs[8 + k];
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(data);           // scratch buffer: 4-byte aligned
+#pragma unroll 1
+    for (size_t b = 0; b < nblocks; ++b) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) X[k] = w[8 * b + k];
+        belt_compress(T, s1, h, X);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] ^= s1[k];
+    }
+    if (fin) {
+        X[0] = (uint32_t)bits_lo; X[1] = (uint32_t)(bits_lo >> 32); X[2] = (uint32_t)bits_hi; X[3] = (uint32_t)(bits_hi >> 32);
+        X[4] = s[0]; X[5] = s[1]; X[6] = s[2]; X[7] = s[3];
+        belt_compress(T, s1, h, X);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hs[k] = h[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hs[8 + k] = s[k];
+}
+err_t launch_belt_hash_stream(void *d_hs, const void *d_data, size_t nblocks, int fin, uint64_t bits_lo,
+                              uint64_t bits_hi, hipStream_t st)
+{
+    hipLaunchKernelGGL(belt_hash_stream_kernel, dim3(1), dim3(64), 0, st, (uint32_t *)d_hs, (const uint8_t *)d_data,
+                       nblocks, fin, bits_lo, bits_hi);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
 // alg: 0 = belt-hash; 128 / 192 / 256 = bash256 / bash384 / bash512
 // d_order (may be null): a permutation of 0..n-1; lane k hashes message d_order[k].  Lanes of a
 // wavefront run until the longest of their 64 messages is done, so callers pass the messages

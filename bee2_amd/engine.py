@@ -56,6 +56,8 @@ DROPIN_SYMBOLS = [
     "beltCBC_keep", "beltCBCStart", "beltCBCStepE", "beltCBCStepD", "beltCBCEncr", "beltCBCDecr",
     "beltBDE_keep", "beltBDEStart", "beltBDEStepE", "beltBDEStepD", "beltBDEEncr", "beltBDEDecr",
     "beltSDE_keep", "beltSDEStart", "beltSDEStepE", "beltSDEStepD", "beltSDEEncr", "beltSDEDecr",
+    "beltHash_keep", "beltHashStart", "beltHashStepH", "beltHashStepG", "beltHashStepG2", "beltHashStepV",
+    "beltHashStepV2", "beltHash",
     "beltDWP_keep", "beltDWPStart", "beltDWPStepE", "beltDWPStepI", "beltDWPStepA", "beltDWPStepD", "beltDWPStepG",
     "beltDWPStepV", "beltDWPWrap", "beltDWPUnwrap",
     "beltCHE_keep", "beltCHEStart", "beltCHEStepE", "beltCHEStepI", "beltCHEStepA", "beltCHEStepD", "beltCHEStepG",
@@ -426,6 +428,25 @@ class Engine:
                 step(ctypes.byref(buf, off), _sz(s), st)
             off += s
         return buf.raw[: len(src)]
+
+    def beltHash(self, src):
+        out = ctypes.create_string_buffer(32)
+        code = self.lib.beltHash(out, bytes(src), _sz(len(src)))
+        return code, out.raw
+
+    def beltHash_steps(self, src, splits, hash_len=32):
+        """Start / StepH* / StepG2 with a tag taken after every piece; -> [digest prefix after each split]"""
+        st = ctypes.create_string_buffer(self.lib.beltHash_keep())
+        self.lib.beltHashStart(st)
+        outs, off = [], 0
+        for s in splits:
+            self.lib.beltHashStepH(bytes(src[off:off + s]), _sz(s), st)
+            off += s
+            d = ctypes.create_string_buffer(32)
+            self.lib.beltHashStepG2(d, _sz(hash_len), st)
+            outs.append(d.raw[:hash_len])
+            assert self.lib.beltHashStepV2(d.raw[:hash_len], _sz(hash_len), st) == 1
+        return outs
 
     def beltMAC(self, src, key):
         out = ctypes.create_string_buffer(8)

@@ -175,6 +175,18 @@ err_t beltBDEEncr(void *dest, const void *src, size_t count, const octet key[], 
 err_t beltBDEDecr(void *dest, const void *src, size_t count, const octet key[], size_t len,
                   const octet iv[16]);
 
+/* belt-hash, the default algorithm of `bee2cmd bsum` (belt.h, src/crypto/belt/belt_hash.c:28-190;
+   cmd/bsum/bsum.c:133-147 drives exactly Start / StepH* / StepG).  One message is a serial chain:
+   these calls are for drop-in use, batches go through bee2hip_hash_ragged. */
+size_t beltHash_keep(void);
+void beltHashStart(void *state);
+void beltHashStepH(const void *buf, size_t count, void *state);
+void beltHashStepG(octet hash[32], void *state);
+void beltHashStepG2(octet hash[], size_t hash_len, void *state);
+bool_t beltHashStepV(const octet hash[32], void *state);
+bool_t beltHashStepV2(const octet hash[], size_t hash_len, void *state);
+err_t beltHash(octet hash[32], const void *src, size_t count);
+
 /* belt.h:756-854, src/crypto/belt/belt_mac.c:32-203 */
 size_t beltMAC_keep(void);
 void beltMACStart(void *state, const octet key[], size_t len);

@@ -92,6 +92,34 @@ def test_ragged_hash_batches(orc, golden):
     assert eng.hash_ragged(100, [b"x"])[0] == 502
 
 
+def test_belt_hash_dropin_A23_and_streaming(orc, golden):
+    """beltHash{Start,StepH,StepG,StepG2,StepV,StepV2} / beltHash (belt_test.c:593-627, STB A.23): one-shot on
+    the STB vectors and on ragged lengths, then arbitrary splits with a digest taken after every piece"""
+    import random
+    eng = engine()
+    H = golden.H
+    for k in golden.kat["belt_hash"]:
+        assert eng.beltHash(H[: k["len"]]) == (0, bytes.fromhex(k["out"])), k["name"]
+    rnd = random.Random(41)
+    for n in (0, 1, 31, 32, 33, 63, 64, 65, 1000, 4096, 100_003):
+        msg = orc.fill(n, n + 5)
+        assert eng.beltHash(msg) == (0, orc.belt_hash(msg)), n
+        for _ in range(2):
+            splits, left = [], n
+            while left:
+                s = min(left, rnd.choice((1, 5, 31, 32, 33, 64, 100, 5000)))
+                splits.append(s)
+                left -= s
+            splits = splits or [0]
+            outs = eng.beltHash_steps(msg, splits, hash_len=rnd.choice((32, 16, 7)))
+            off = 0
+            for s_, d in zip(splits, outs):                       # the digest of every prefix, truncated
+                off += s_
+                assert d == orc.belt_hash(msg[:off])[: len(d)], (n, off)
+    for c in golden.belt_bash[:8]:
+        assert eng.beltHash(bytes.fromhex(c["msg"]))[1].hex() == c["belt_hash"]
+
+
 def test_ragged_hash_device_api_with_launch_order(orc):
     """bee2hip_hash_ragged[_ordered]_dev: digests land at the caller's index whatever the launch order
     (identity, longest-first, a random permutation); unaligned message starts included"""
