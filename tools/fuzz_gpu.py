@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Randomised differential campaign: libbee2hip (GPU) against the oracle on random sizes, keys, splits
+and corruptions, every entry point family.  TEST INFRASTRUCTURE (uses oracle/): run on the GPU box,
+   python tools/fuzz_gpu.py [seconds] [seed]
+Prints one line per family with the number of cases, and stops at the first mismatch with a
+reproducer (family, seed of the case)."""
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bee2_amd  # noqa: E402
+import goldenlib  # noqa: E402
+import orclib  # noqa: E402
+from bee2_amd.engine import LEVEL_OID  # noqa: E402
+
+eng = bee2_amd.load()
+eng.set_device(0)
+orc = orclib.load()
+G = goldenlib.Golden()
+
+
+def dev(b):
+    return torch.from_numpy(np.frombuffer(bytes(b) + bytes(16), dtype=np.uint8).copy()).cuda()[: len(b)]
+
+
+def host(t):
+    return t.cpu().numpy().tobytes()
+
+
+def size(rnd, hi, edges=()):
+    """mostly small, sometimes around a boundary, sometimes large"""
+    r = rnd.random()
+    if edges and r < 0.35:
+        return max(0, rnd.choice(edges) + rnd.randrange(-2, 3))
+    if r < 0.8:
+        return rnd.randrange(0, min(hi, 2000))
+    return rnd.randrange(0, hi)
+
+
+def splits_of(rnd, n, align=1):
+    out, left = [], n
+    while left:
+        s = min(left, align * rnd.choice((1, 2, 3, 7, 16, 33, 100, 1000)))
+        out.append(s)
+        left -= s
+    return out or [0]
+
+
+def f_bashF(rnd):
+    n = size(rnd, 300_000, (64, 256, 1024, 65536))
+    data = orc.fill(192 * n, rnd.getrandbits(32))
+    t = dev(data)
+    if n:
+        eng.bashF_batch_dev(t)
+    torch.cuda.synchronize()
+    return host(t) == orc.bashF_batch(data, nthreads=8)
+
+
+def f_ctr(rnd):
+    n = size(rnd, 1 << 22, (16, 1024 * 16, 65536 * 16))
+    key, iv = rnd.randbytes(rnd.choice((16, 24, 32))), rnd.randbytes(16)
+    msg = orc.fill(n, rnd.getrandbits(32))
+    sp = splits_of(rnd, n) if n < 20000 else [n]
+    want = orc.ctr(msg, key, iv)
+    return eng.beltCTR_steps(msg, key, iv, sp)[0] == want and eng.beltCTR(msg, key, iv) == (0, want)
+
+
+def f_mac_hash(rnd):
+    n = size(rnd, 200_000, (16, 32, 128, 192))
+    key = rnd.randbytes(rnd.choice((16, 24, 32)))
+    msg = orc.fill(n, rnd.getrandbits(32))
+    l = rnd.choice((128, 192, 256))
+    ok = eng.beltMAC(msg, key) == (0, orc.mac(msg, key)) and eng.bashHash(l, msg) == orc.bashHash(l, msg)
+    ok = ok and eng.beltHash(msg) == (0, orc.belt_hash(msg))
+    if n < 5000:
+        sp = splits_of(rnd, n)
+        ok = ok and eng.beltMAC_steps(msg, key, sp) == (orc.mac(msg, key), True)
+        ok = ok and eng.bashHash_steps(l, msg, sp) == (orc.bashHash(l, msg)[1], True)
+        ok = ok and eng.beltHash_steps(msg, sp)[-1] == orc.belt_hash(msg)
+    return ok
+
+
+def f_modes(rnd):
+    nb = max(1, size(rnd, 1 << 16, (1, 2, 64, 1024, 8192)))
+    key, iv = rnd.randbytes(rnd.choice((16, 24, 32))), rnd.randbytes(16)
+    msg = orc.fill(16 * nb + (rnd.randrange(16) if rnd.random() < 0.5 else 0), rnd.getrandbits(32))
+    blocks = msg[: 16 * nb]
+    ok = True
+    for decr in (False, True):
+        d = "Decr" if decr else "Encr"
+        ok = ok and eng.belt_mode("beltECB" + d, msg, key) == orc.ecb(msg, key, decr)
+        ok = ok and eng.belt_mode("beltCBC" + d, msg, key, iv) == orc.cbc(msg, key, iv, decr)
+        ok = ok and eng.belt_mode("beltBDE" + d, blocks, key, iv) == orc.bde(blocks, key, iv, decr)
+        if 2 <= nb <= 600:
+            ok = ok and eng.belt_mode("beltSDE" + d, blocks, key, iv) == orc.sde(blocks, key, iv, decr)
+    if nb > 1:
+        sp = splits_of(rnd, 16 * nb, align=16)
+        decr = rnd.random() < 0.5
+        ok = ok and eng.belt_mode_steps("BDE", decr, blocks, key, iv, sp) == orc.bde(blocks, key, iv, decr)[1]
+    return ok
+
+
+def f_aead(rnd):
+    mode = rnd.choice(("DWP", "CHE"))
+    nc, no = size(rnd, 1 << 20, (16, 1024 * 16, 64 * 1024 * 16)), size(rnd, 1 << 18, (16, 1024 * 16))
+    key, iv = rnd.randbytes(rnd.choice((16, 24, 32))), rnd.randbytes(16)
+    crit, op = orc.fill(nc, rnd.getrandbits(32)), orc.fill(no, rnd.getrandbits(32))
+    want = orc.dwp_wrap(crit, op, key, iv, mode)
+    ok = eng.dwp_wrap(crit, op, key, iv, mode) == want
+    mac = want[2] if rnd.random() < 0.7 else bytes([want[2][0] ^ 4]) + want[2][1:]
+    ok = ok and eng.dwp_unwrap(want[1], op, mac, key, iv, mode) == orc.dwp_unwrap(want[1], op, mac, key, iv, mode)
+    if nc + no < 6000:
+        ops = [("I", p) for p in (op[i:i + 37] for i in range(0, no, 37))] + [("G",)]
+        ops += [("E", crit[i:i + 29]) for i in range(0, nc, 29)]
+        ops += [("A", want[1][i:i + 41]) for i in range(0, nc, 41)] + [("G",)]
+        o, m, _ = eng.dwp_steps(key, iv, ops, mode)
+        ok = ok and (o, m) == orc.dwp_steps(key, iv, ops, mode)
+    return ok
+
+
+_base = {128: None, 192: None, 256: None}
+
+
+def _triples(l):
+    if _base[l] is None:
+        if l == 128:
+            hs, ss, ps = G.bign_base_arrays()
+            no = 32
+            _base[l] = [(hs[no * i:no * i + no], ss[48 * i:48 * i + 48], ps[64 * i:64 * i + 64]) for i in range(len(hs) // no)]
+        else:
+            _base[l] = [tuple(bytes.fromhex(t[k]) for k in ("hash", "sig", "pubkey")) for t in G.bign_big[str(l)]["base"]]
+    return _base[l]
+
+
+def f_verify(rnd):
+    l = rnd.choice((128, 128, 192, 256))
+    base = _triples(l)
+    n = max(1, size(rnd, 6000 if l == 128 else 800, (64, 256, 1024)))
+    no = l // 4
+    H, S, P = bytearray(), bytearray(), bytearray()
+    for _ in range(n):
+        h, s, p = (bytearray(x) for x in rnd.choice(base))
+        k = rnd.randrange(10)
+        if k == 1:
+            s[rnd.randrange(len(s))] ^= 1 << rnd.randrange(8)
+        elif k == 2:
+            h[rnd.randrange(no)] ^= 1 << rnd.randrange(8)
+        elif k == 3:
+            p[rnd.randrange(2 * no)] ^= 1 << rnd.randrange(8)
+        elif k == 4:
+            s[no // 2:] = b"\xff" * no                      # s1 >= q
+        elif k == 5:
+            p[:no] = b"\xff" * no                           # x >= p
+        elif k == 6:
+            p[no:] = b"\xff" * no                           # y >= p
+        elif k == 7:
+            s[:no // 2] = bytes(no // 2)                    # s0 = 0
+        H += h; S += s; P += p
+    oid = LEVEL_OID[l]
+    codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    eng.bignVerifyL_batch_dev(l, oid, dev(H), dev(S), dev(P), codes)
+    torch.cuda.synchronize()
+    got = [int(c) & 0xFFFFFFFF for c in codes.cpu().numpy()]
+    return got == orc.verify_batch_l(l, oid, bytes(H), bytes(S), bytes(P), nthreads=16)
+
+
+def f_ragged_mixed(rnd):
+    nm = max(1, size(rnd, 3000, (64, 65, 1024)))
+    msgs = [orc.fill(size(rnd, 20000, (0, 32, 64, 128, 192)), rnd.getrandbits(32)) for _ in range(nm)]
+    alg = rnd.choice((0, 128, 192, 256))
+    code, digs = eng.hash_ragged(alg, msgs)
+    ok = code == 0 and all(d == (orc.belt_hash(m) if alg == 0 else orc.bashHash(alg, m)[1]) for m, d in zip(msgs[:200], digs[:200]))
+    ml = 16 * rnd.randrange(1, 300)
+    n = max(1, size(rnd, 3000, (1024, 1025)))
+    key = rnd.randbytes(32)
+    data = orc.fill(ml * n, rnd.getrandbits(32))
+    dig, tag = orc.mixed_batch(data, ml, key, nthreads=16)
+    gd, gt = eng.bashHash_beltMAC_batch(data, ml, 256, key, n=n)
+    return ok and gd == dig and gt == tag
+
+
+FAMILIES = [("bashF", f_bashF), ("beltCTR", f_ctr), ("mac/hash", f_mac_hash), ("modes", f_modes), ("dwp/che", f_aead),
+            ("verify", f_verify), ("ragged/mixed", f_ragged_mixed)]
+
+
+def main(seconds, seed):
+    counts = {n: 0 for n, _ in FAMILIES}
+    t_end = time.time() + seconds
+    case = 0
+    while time.time() < t_end:
+        name, fn = FAMILIES[case % len(FAMILIES)]
+        cs = (seed << 20) + case
+        if not fn(random.Random(cs)):
+            print(f"MISMATCH family={name} case_seed={cs}  (reproduce: random.Random({cs}) into f_{name})")
+            return 1
+        counts[name] += 1
+        case += 1
+    for n, c in counts.items():
+        print(f"{n:14s} {c:6d} cases ok")
+    print(f"total {case} cases in {seconds} s, seed {seed}: no mismatch")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 1))
