@@ -443,20 +443,14 @@ static void gf128_double(uint32_t s[4])
     s[0] = (s[0] << 1) ^ (out ? 0x87u : 0u);        /* x^128 = x^7 + x^2 + x + 1 */
 }
 
-/* beltBDEEncr / beltBDEDecr (belt_bde.c:40-133): s <- E_K(iv); for every block
-   s <- s * x, Y = E_K(X ^ s) ^ s (decryption: D_K).  Whole blocks only. */
-uint32_t orc_beltBDE(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
-                     const uint8_t iv[16], int decr)
+/* the block loop of beltBDEStepE / StepD (belt_bde.c:51-85) from a given tweak state s (updated in place):
+   what one rank does with its shard once s has been advanced to the shard's first block */
+void orc_beltBDE_blocks(void *buf_, size_t nblocks, const uint32_t K[8], uint32_t s[4], int decr)
 {
-    uint32_t K[8], s[4], w[4];
-    uint8_t *buf = (uint8_t *)dest;
+    uint8_t *buf = (uint8_t *)buf_;
+    uint32_t w[4];
     int i;
-    if (count < 16 || count % 16 || (len != 16 && len != 24 && len != 32)) return ORC_BAD_INPUT;
-    orc_beltKeyExpand2(K, key, len);
-    blk_load(s, iv);
-    orc_beltBlockEncr2(s, K);
-    memmove(dest, src, count);
-    for (; count; count -= 16, buf += 16) {
+    for (; nblocks; --nblocks, buf += 16) {
         gf128_double(s);
         blk_load(w, buf);
         for (i = 0; i < 4; ++i) w[i] ^= s[i];
@@ -464,6 +458,20 @@ uint32_t orc_beltBDE(void *dest, const void *src, size_t count, const uint8_t *k
         for (i = 0; i < 4; ++i) w[i] ^= s[i];
         blk_store(buf, w);
     }
+}
+
+/* beltBDEEncr / beltBDEDecr (belt_bde.c:40-133): s <- E_K(iv); for every block
+   s <- s * x, Y = E_K(X ^ s) ^ s (decryption: D_K).  Whole blocks only. */
+uint32_t orc_beltBDE(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
+                     const uint8_t iv[16], int decr)
+{
+    uint32_t K[8], s[4];
+    if (count < 16 || count % 16 || (len != 16 && len != 24 && len != 32)) return ORC_BAD_INPUT;
+    orc_beltKeyExpand2(K, key, len);
+    blk_load(s, iv);
+    orc_beltBlockEncr2(s, K);
+    memmove(dest, src, count);
+    orc_beltBDE_blocks(dest, count / 16, K, s, decr);
     return ORC_OK;
 }
 
@@ -669,6 +677,22 @@ void orc_beltCHEStepE(void *buf_, size_t count, orc_belt_che_st *st)
         *buf++ ^= st->gamma[16 - st->reserved];
         --st->reserved;
         --count;
+    }
+}
+/* whole blocks of the belt-che keystream from a given state s (updated in place), belt_che.c:86-98 */
+void orc_beltCHE_blocks(void *buf_, size_t nblocks, const uint32_t K[8], uint32_t s[4])
+{
+    uint8_t *buf = (uint8_t *)buf_;
+    uint32_t g[4], w[4];
+    int i;
+    for (; nblocks; --nblocks, buf += 16) {
+        gf128_double(s);
+        s[0] ^= 1u;
+        for (i = 0; i < 4; ++i) g[i] = s[i];
+        orc_beltBlockEncr2(g, K);
+        blk_load(w, buf);
+        for (i = 0; i < 4; ++i) w[i] ^= g[i];
+        blk_store(buf, w);
     }
 }
 void orc_beltCHEStepI(const void *buf, size_t count, orc_belt_che_st *st) { orc_beltDWPStepI(buf, count, &st->mac); }

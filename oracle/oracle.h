@@ -96,6 +96,8 @@ uint32_t orc_beltCBC(void *dest, const void *src, size_t count, const uint8_t *k
                      const uint8_t iv[16], int decr);                        /* belt_cbc.c:63-193 */
 uint32_t orc_beltBDE(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
                      const uint8_t iv[16], int decr);                        /* belt_bde.c:40-133 */
+void orc_beltBDE_blocks(void *buf, size_t nblocks, const uint32_t key[8], uint32_t s[4], int decr); /* belt_bde.c:51-85 */
+void orc_beltCHE_blocks(void *buf, size_t nblocks, const uint32_t key[8], uint32_t s[4]);           /* belt_che.c:86-98 */
 uint32_t orc_beltWBL(void *buf, size_t nblocks, const uint32_t key[8], int decr); /* belt_wbl.c:58-152, whole blocks */
 uint32_t orc_beltSDE(void *dest, const void *src, size_t count, const uint8_t *key, size_t len,
                      const uint8_t iv[16], int decr);                        /* belt_sde.c:38-121 */

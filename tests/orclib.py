@@ -147,6 +147,19 @@ class Oracle:
                                           bytes(mac), bytes(key), _sz(len(key)), bytes(iv))
         return code, dest.raw[: len(crit)]
 
+    def bde_blocks_from(self, blocks, key, s_words, decr=False):
+        """the BDE block loop from the tweak state s (bytes of 4 u32) -> (output, state after)"""
+        buf = ctypes.create_string_buffer(bytes(blocks), max(len(blocks), 1))
+        s = (ctypes.c_uint32 * 4).from_buffer_copy(bytes(s_words))
+        self.lib.orc_beltBDE_blocks(buf, _sz(len(blocks) // 16), self.key_expand(key), s, int(decr))
+        return buf.raw[: len(blocks)], bytes(s)
+
+    def che_blocks_from(self, blocks, key, s_words):
+        buf = ctypes.create_string_buffer(bytes(blocks), max(len(blocks), 1))
+        s = (ctypes.c_uint32 * 4).from_buffer_copy(bytes(s_words))
+        self.lib.orc_beltCHE_blocks(buf, _sz(len(blocks) // 16), self.key_expand(key), s)
+        return buf.raw[: len(blocks)], bytes(s)
+
     def sde(self, msg, key, iv, decr=False):
         out = ctypes.create_string_buffer(max(len(msg), 1))
         code = self.lib.orc_beltSDE(out, bytes(msg), _sz(len(msg)), bytes(key), _sz(len(key)), bytes(iv), int(decr))

@@ -91,6 +91,84 @@ def test_sharded_ctr_and_bashF_equal_single_stream(tmp_path, orc):
     assert got_bash == want_bash
 
 
+POLY = (1 << 128) | 0x87
+Q_INV = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF82
+
+
+def _gf_mul(a, b):
+    r = 0
+    while b:
+        if b & 1:
+            r ^= a
+        a <<= 1
+        if a >> 128:
+            a ^= POLY
+        b >>= 1
+    return r
+
+
+def _x_pow(j):
+    p, b = 1, 2
+    while j:
+        if j & 1:
+            p = _gf_mul(p, b)
+        b = _gf_mul(b, b)
+        j >>= 1
+    return p
+
+
+def _stream_worker(rank, world, port, outdir):
+    """belt-bde / belt-che streams sharded by block index: rank r jumps the tweak / keystream state to its first
+    block (what `first_block` makes the kernels do) and processes [lo, hi) with no data from the other rank"""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+
+    import orclib
+    from bee2_amd import shard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = orclib.load()
+    H = orc.beltH()
+    key = H[128:160]
+    # rank 0 derives s = E_K(iv) and broadcasts it with the expanded key (the only exchange)
+    blob = (bytes(orc.key_expand(key)) + orc.block_encr(H[192:208], key)) if rank == 0 else bytes(48)
+    blob = shard.broadcast_params(dist, blob)
+    s0 = int.from_bytes(blob[32:48], "little")
+    nblocks = 1003
+    data = orc.fill(16 * nblocks, 0xBDE)
+    lo, hi = shard.shard_range(rank, world, nblocks)
+    P = _x_pow(lo)
+    s_bde = _gf_mul(s0, P)                                              # s * x^lo
+    s_che = _gf_mul(s0, P) ^ _gf_mul(P ^ 1, Q_INV)                      # S_lo of s <- s*x ^ 1
+    piece = data[16 * lo:16 * hi]
+    bde, _ = orc.bde_blocks_from(piece, key, s_bde.to_bytes(16, "little"))
+    che, _ = orc.che_blocks_from(piece, key, s_che.to_bytes(16, "little"))
+    with open(os.path.join(outdir, f"s{rank}.bin"), "wb") as f:
+        f.write(bde + che)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_bde_che_streams_equal_single_stream(tmp_path, orc):
+    world = 2
+    mp.spawn(_stream_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    H = orc.beltH()
+    key, iv = H[128:160], H[192:208]
+    data = orc.fill(16 * 1003, 0xBDE)
+    from bee2_amd import shard
+    got_bde, got_che = b"", b""
+    for r in range(world):
+        lo, hi = shard.shard_range(r, world, 1003)
+        raw = open(tmp_path / f"s{r}.bin", "rb").read()
+        n = 16 * (hi - lo)
+        got_bde += raw[:n]
+        got_che += raw[n:2 * n]
+    assert got_bde == orc.bde(data, key, iv)[1]
+    assert got_che == orc.dwp_wrap(data, b"", key, iv, "CHE")[1]
+
+
 def test_shard_ranges_cover_and_balance():
     from bee2_amd import shard
     for n in (0, 1, 7, 8, 1000, 2 ** 20 + 3):
