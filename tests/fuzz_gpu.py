@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential campaign: libbee2hip (GPU) against the oracle on random sizes, keys, splits
 and corruptions, every entry point family.  TEST INFRASTRUCTURE (uses oracle/): run on the GPU box,
-   python tools/fuzz_gpu.py [seconds] [seed]
+   python tests/fuzz_gpu.py [seconds] [seed]
 Prints one line per family with the number of cases, and stops at the first mismatch with a
 reproducer (family, seed of the case)."""
 import os

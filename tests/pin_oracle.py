@@ -8,7 +8,7 @@ import sys
 import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [HERE, os.path.join(os.path.dirname(HERE), "tests")]
+sys.path[:0] = [HERE, os.path.join(os.path.dirname(HERE), "tools")]
 import orclib  # noqa: E402
 import refgen  # noqa: E402
 

@@ -1,6 +1,6 @@
 """CPU tests, build container only: the oracle restatement against the REFERENCE itself
 (oracle/_ref/libbee2ref.so = agievich/bee2 compiled by oracle/Makefile) on seeded random
-inputs.  Skipped where _ref is absent.  tools/pin_oracle.py runs the same comparison at
+inputs.  Skipped where _ref is absent.  tests/pin_oracle.py runs the same comparison at
 >= 1e5 items per primitive."""
 import ctypes
 import random
