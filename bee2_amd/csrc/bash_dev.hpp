@@ -224,4 +224,69 @@ __device__ __forceinline__ void bash_f(u64x2 (&a)[24])
     }
 }
 
+// ---- one state across 8 lanes, one column each ------------------------------------------------
+// For a LONG message the sponge is a serial chain of permutations and one lane per state runs it at a
+// lone wavefront's issue rate.  Here lane j = lane & 7 of a group of 8 holds column j
+// (w0, w1, w2 = words j, 8 + j, 16 + j): the S-box is column-local, and the word permutation of a round
+// (bash_favx512.c:140-171) is an exchange inside the group: new w0 <- w1 of lane pi1[j], new w1 <- w2
+// of lane pi2[j], new w2 <- w0 of lane pi0[j] (six ds_bpermute_b32).  The rotation amounts differ per
+// lane; a rotation by n >= 32 is a swap of the halves followed by a rotation by n - 32, so every
+// rotation is two v_bitop3 selects with a per-lane mask and two v_alignbit with a per-lane shift
+// (no amount is a multiple of 32).  36 instructions per lane per round instead of 22: worse for
+// throughput, ~4x shorter for one message.
+struct BashCol {
+    uint32_t sh[4], mk[4];            // for m1, n1, m2, n2: alignbit shift 32 - (n & 31), all-ones if n >= 32
+    int a0, a1, a2;                   // ds_bpermute byte addresses: lanes pi0[j], pi1[j], pi2[j] of my group
+    uint32_t last;                    // all-ones in lane 7 of the group: word 23 takes the round constant
+};
+__device__ inline BashCol bash_col_setup(unsigned lane)
+{
+    // column j: (8, 53, 14, 1) * 7^j mod 64  (bash_f64.c:126-133)
+    const unsigned j = lane & 7u;
+    unsigned m = 1;
+    for (unsigned k = 0; k < j; ++k) m = (m * 7u) & 63u;
+    const unsigned par[4] = {(8u * m) & 63u, (53u * m) & 63u, (14u * m) & 63u, (1u * m) & 63u};
+    BashCol c;
+    for (int k = 0; k < 4; ++k) { c.sh[k] = 32u - (par[k] & 31u); c.mk[k] = par[k] >= 32u ? ~0u : 0u; }
+    const unsigned pi0 = (0x14725036u >> (4 * j)) & 7u;       // (6,3,0,5,2,7,4,1), digit j
+    const unsigned pi1 = (0x05634127u >> (4 * j)) & 7u;       // (7,2,1,4,3,6,5,0)
+    const unsigned pi2 = (0x67452301u >> (4 * j)) & 7u;       // (1,0,3,2,5,4,7,6)
+    const unsigned base = lane & ~7u;
+    c.a0 = (int)((base | pi0) << 2); c.a1 = (int)((base | pi1) << 2); c.a2 = (int)((base | pi2) << 2);
+    c.last = j == 7u ? ~0u : 0u;
+    return c;
+}
+constexpr int TT_SEL = 0xD8;                                   // c ? b : a
+template <int P>
+__device__ __forceinline__ u64x2 bash_col_rot(const u64x2 x, const BashCol &c)
+{
+    const uint32_t a = bitop3<TT_SEL>(x.lo, x.hi, c.mk[P]), b = bitop3<TT_SEL>(x.hi, x.lo, c.mk[P]);
+    u64x2 r;
+    r.lo = __builtin_amdgcn_alignbit(a, b, c.sh[P]);
+    r.hi = __builtin_amdgcn_alignbit(b, a, c.sh[P]);
+    return r;
+}
+__device__ __forceinline__ void bash_f_cols(u64x2 &w0, u64x2 &w1, u64x2 &w2, const BashCol &c)
+{
+    uint64_t rc = 0x3BF5080AC8BA94B1ull;
+#pragma unroll 1
+    for (int round = 0; round < 24; ++round) {
+        u64x2 u0, t, u1, u2, r, r2;
+        u0.lo = bitop3<TT_XOR3>(w0.lo, w1.lo, w2.lo); u0.hi = bitop3<TT_XOR3>(w0.hi, w1.hi, w2.hi);
+        r = bash_col_rot<1>(u0, c);  t.lo = w1.lo ^ r.lo;  t.hi = w1.hi ^ r.hi;
+        r = bash_col_rot<0>(w0, c);  u1.lo = t.lo ^ r.lo;  u1.hi = t.hi ^ r.hi;
+        r = bash_col_rot<2>(w2, c);
+        r2 = bash_col_rot<3>(t, c);
+        u2.lo = bitop3<TT_XOR3>(w2.lo, r.lo, r2.lo); u2.hi = bitop3<TT_XOR3>(w2.hi, r.hi, r2.hi);
+        const uint32_t s0l = bitop3<TT_S0>(u0.lo, u1.lo, u2.lo), s0h = bitop3<TT_S0>(u0.hi, u1.hi, u2.hi);
+        const uint32_t s1l = bitop3<TT_S1>(u0.lo, u1.lo, u2.lo), s1h = bitop3<TT_S1>(u0.hi, u1.hi, u2.hi);
+        const uint32_t s2l = bitop3<TT_S2>(u0.lo, u1.lo, u2.lo), s2h = bitop3<TT_S2>(u0.hi, u1.hi, u2.hi);
+        w0.lo = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a1, (int)s1l); w0.hi = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a1, (int)s1h);
+        w1.lo = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a2, (int)s2l); w1.hi = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a2, (int)s2h);
+        w2.lo = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a0, (int)s0l) ^ ((uint32_t)rc & c.last);
+        w2.hi = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a0, (int)s0h) ^ ((uint32_t)(rc >> 32) & c.last);
+        rc = bash_next_const(rc);
+    }
+}
+
 }  // namespace bee2hip

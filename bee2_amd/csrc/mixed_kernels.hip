@@ -332,13 +332,14 @@ template <int RW>
 __global__ __launch_bounds__(64)
 void bash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off,
                         const uint32_t *__restrict__ order, size_t n,
-                        uint32_t level, uint8_t *__restrict__ digests)
+                        uint32_t level, uint8_t *__restrict__ digests, uint64_t long_from)
 {
     const size_t slot = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (slot >= n) return;
     const size_t i = order ? order[slot] : slot;      // lane `slot` hashes message order[slot]
     const uint8_t *p = data + off[i];
     size_t left = (size_t)(off[i + 1] - off[i]);
+    if (left >= long_from) return;                    // long messages: bash_long_kernel, 8 lanes each
     constexpr int RATE = 8 * RW;
     u64x2 a[24];
 #pragma unroll
@@ -375,6 +376,66 @@ void bash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *__rest
 #pragma unroll
             for (int k = 0; k < 8; ++k) d[8 * w + k] = (uint8_t)(v >> (8 * k));
         }
+    }
+}
+
+// Long messages (>= long_from bytes): 8 lanes per message, one bash-f column each (bash_dev.hpp
+// bash_f_cols).  Launched over ALL n messages; groups whose message is short leave at once.
+// RW = rate in 64-bit words (16 / 12 / 8 for bash256 / 384 / 512): lane j absorbs words j and 8 + j.
+template <int RW>
+__global__ __launch_bounds__(64)
+void bash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off,
+                      const uint32_t *__restrict__ order, size_t n, uint32_t level,
+                      uint8_t *__restrict__ digests, uint64_t long_from)
+{
+    const size_t slot = ((size_t)blockIdx.x * 64 + threadIdx.x) >> 3;
+    const unsigned j = threadIdx.x & 7u;
+    if (slot >= n) return;
+    // a wavefront runs as long as the longest of its 8 messages: with a longest-first order the groups of
+    // a wavefront hold similar lengths (and wavefronts of short messages leave as a whole)
+    const size_t g = order ? order[slot] : slot;
+    const uint8_t *p = data + off[g];
+    size_t left = (size_t)(off[g + 1] - off[g]);
+    if (left < long_from) return;
+    constexpr int RATE = 8 * RW;
+    const BashCol C = bash_col_setup(threadIdx.x);
+    u64x2 w0 = {0, 0}, w1 = {0, 0}, w2 = {0, 0};
+    if (j == 7) w2.lo = level / 4;                     // s[184] = l / 4 (bash_hash.c:43-45): word 23
+    // the words of the next block are fetched before the permutation of the current one: a block is a
+    // step of the serial chain and its load latency would otherwise sit on it
+    const bool row1 = 8 + j < (unsigned)RW;            // row 0 is always inside the rate (RW >= 8)
+    uint64_t n0 = 0, n1 = 0;
+    if (left >= (size_t)RATE) { n0 = load64_any(p + 8 * j); if (row1) n1 = load64_any(p + 8 * (8 + j)); }
+    while (left >= (size_t)RATE) {
+        w0.lo = (uint32_t)n0; w0.hi = (uint32_t)(n0 >> 32);
+        if (row1) { w1.lo = (uint32_t)n1; w1.hi = (uint32_t)(n1 >> 32); }
+        p += RATE; left -= RATE;
+        if (left >= (size_t)RATE) { n0 = load64_any(p + 8 * j); if (row1) n1 = load64_any(p + 8 * (8 + j)); }
+        bash_f_cols(w0, w1, w2, C);
+    }
+    // last block: tail || 0x40 || 0..  (bash_hash.c:81-102)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const unsigned k = 8u * r + j;
+        if (k < (unsigned)RW) {
+            uint64_t v = 0;
+#pragma unroll
+            for (int b = 7; b >= 0; --b) {
+                const size_t pos = (size_t)(8 * k + b);
+                const uint32_t x = pos < left ? p[pos] : (pos == left ? 0x40u : 0u);
+                v = (v << 8) | x;
+            }
+            if (r == 0) { w0.lo = (uint32_t)v; w0.hi = (uint32_t)(v >> 32); }
+            else        { w1.lo = (uint32_t)v; w1.hi = (uint32_t)(v >> 32); }
+        }
+    }
+    bash_f_cols(w0, w1, w2, C);
+    const unsigned nw = level / 32;                    // digest = l / 4 bytes = l / 32 words, all in row 0
+    if (j < nw) {
+        uint8_t *d = digests + (size_t)(level / 4) * g + 8 * j;
+        const uint64_t v = ((uint64_t)w0.hi << 32) | w0.lo;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) d[b] = (uint8_t)(v >> (8 * b));
     }
 }
 
@@ -475,6 +536,7 @@ err_t launch_belt_hash_stream(void *d_hs, const void *d_data, size_t nblocks, in
 // d_order (may be null): a permutation of 0..n-1; lane k hashes message d_order[k].  Lanes of a
 // wavefront run until the longest of their 64 messages is done, so callers pass the messages
 // sorted by decreasing length (the host entry point does) -- digests still land at index i.
+constexpr uint64_t RAGGED_LONG = 4096;     // bytes; see bench.py --only ragged and DESIGN.md 4.7
 err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, const void *d_order, size_t n,
                          void *d_digests, hipStream_t st)
 {
@@ -485,10 +547,20 @@ err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, cons
     const uint8_t *data = (const uint8_t *)d_data;
     const uint64_t *off = (const uint64_t *)d_off;
     uint8_t *dig = (uint8_t *)d_digests;
+    // bash: messages of >= RAGGED_LONG bytes go to the 8-lanes-per-message kernel (a 4x shorter serial chain),
+    // the rest stay one lane each; both launches cover all n messages and each skips what is not its own
+    const dim3 gl((unsigned)((n * 8 + 63) / 64));
     if (alg == 0) hipLaunchKernelGGL(belt_hash_ragged_kernel, g, t, 0, st, data, off, ord, n, dig);
-    else if (alg == 256) hipLaunchKernelGGL(bash_ragged_kernel<8>, g, t, 0, st, data, off, ord, n, 256u, dig);
-    else if (alg == 192) hipLaunchKernelGGL(bash_ragged_kernel<12>, g, t, 0, st, data, off, ord, n, 192u, dig);
-    else if (alg == 128) hipLaunchKernelGGL(bash_ragged_kernel<16>, g, t, 0, st, data, off, ord, n, 128u, dig);
+    else if (alg == 256) {
+        hipLaunchKernelGGL(bash_long_kernel<8>, gl, t, 0, st, data, off, ord, n, 256u, dig, RAGGED_LONG);
+        hipLaunchKernelGGL(bash_ragged_kernel<8>, g, t, 0, st, data, off, ord, n, 256u, dig, RAGGED_LONG);
+    } else if (alg == 192) {
+        hipLaunchKernelGGL(bash_long_kernel<12>, gl, t, 0, st, data, off, ord, n, 192u, dig, RAGGED_LONG);
+        hipLaunchKernelGGL(bash_ragged_kernel<12>, g, t, 0, st, data, off, ord, n, 192u, dig, RAGGED_LONG);
+    } else if (alg == 128) {
+        hipLaunchKernelGGL(bash_long_kernel<16>, gl, t, 0, st, data, off, ord, n, 128u, dig, RAGGED_LONG);
+        hipLaunchKernelGGL(bash_ragged_kernel<16>, g, t, 0, st, data, off, ord, n, 128u, dig, RAGGED_LONG);
+    }
     else return ERR_NOT_IMPLEMENTED;
     B2H_TRY(hipGetLastError());
     return ERR_OK;

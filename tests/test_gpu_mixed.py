@@ -80,6 +80,9 @@ def test_ragged_hash_batches(orc, golden):
     rnd = random.Random(21)
     msgs = [bytes.fromhex(c["msg"]) for c in golden.belt_bash]
     msgs += [orc.fill(n, n) for n in (0, 1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 192, 193, 5000)]
+    # around the switch to 8 lanes per message (4096 bytes) and around its rate blocks (64 / 96 / 128 bytes)
+    msgs += [orc.fill(n, n) for n in (4095, 4096, 4097, 4096 + 63, 4096 + 64, 4096 + 95, 4096 + 96, 4096 + 127,
+                                      4096 + 128, 4096 + 129, 8192, 65536 + 5, 300_000)]
     msgs += [rnd.randbytes(rnd.randrange(0, 3000)) for _ in range(200)]
     for alg in (0, 128, 192, 256):
         code, digs = eng.hash_ragged(alg, msgs)
