@@ -570,8 +570,20 @@ static err_t sponge_host(bash_hash_st *st, const octet *buf, size_t count)
     octet *d = (octet *)s.p;
     B2H_TRY(hipMemcpy(d, st, sizeof *st, hipMemcpyHostToDevice));
     B2H_TRY(hipMemcpy(d + sizeof *st, buf, count, hipMemcpyHostToDevice));
-    code = launch_bash_sponge(d, d + sizeof *st, 0, count, 1, 0, nullptr);
-    if (code != ERR_OK) return code;
+    const octet *dd = d + sizeof *st;
+    // large chunk: byte-wise up to the next block boundary, whole rate blocks with 8 lanes (a 3x shorter chain,
+    // DESIGN.md 4.7), the remainder byte-wise again
+    const size_t head = st->pos ? st->buf_len - st->pos : 0;
+    if (count >= 4096 + head) {
+        const size_t blocks = (count - head) / st->buf_len, tail = count - head - blocks * st->buf_len;
+        if (head) { code = launch_bash_sponge(d, dd, 0, head, 1, 0, nullptr); if (code != ERR_OK) return code; }
+        code = launch_bash_sponge_cols(d, dd + head, blocks, nullptr);
+        if (code != ERR_OK) return code;
+        if (tail) { code = launch_bash_sponge(d, dd + head + blocks * st->buf_len, 0, tail, 1, 0, nullptr); if (code != ERR_OK) return code; }
+    } else {
+        code = launch_bash_sponge(d, dd, 0, count, 1, 0, nullptr);
+        if (code != ERR_OK) return code;
+    }
     B2H_TRY(hipMemcpy(st, d, sizeof *st, hipMemcpyDeviceToHost));
     return ERR_OK;
 }

@@ -56,6 +56,7 @@ err_t launch_belt_che(const void *d_src, void *d_dst, size_t nblocks, const uint
                       uint64_t first, void *d_s_out, hipStream_t st);
 err_t launch_belt_polyhash(const void *d_data, size_t nbytes, const uint32_t r[4], const uint32_t t[4],
                            void *d_t_out, hipStream_t st);
+err_t launch_bash_sponge_cols(void *d_state, const void *d_data, size_t nblocks, hipStream_t st);
 err_t launch_belt_hash_stream(void *d_hs, const void *d_data, size_t nblocks, int fin, uint64_t bits_lo,
                               uint64_t bits_hi, hipStream_t st);
 err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, const void *d_order, size_t n,

@@ -209,6 +209,65 @@ void bash_sponge_kernel(bash_hash_st *__restrict__ states, const uint8_t *__rest
     }
 }
 
+// 64-bit little-endian load from any address (message starts are not aligned)
+__device__ __forceinline__ uint64_t load64_any(const uint8_t *p)
+{
+    if (((uintptr_t)p & 3) == 0) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+        return ((uint64_t)w[1] << 32) | w[0];
+    }
+    uint64_t v = 0;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) v = (v << 8) | p[k];
+    return v;
+}
+
+// Whole rate blocks of ONE state with 8 lanes, one bash-f column each (bash_dev.hpp bash_f_cols): the bulk
+// of a large bashHashStepH.  Precondition: st->pos == 0 (the host aligns to a block boundary with the
+// byte-wise kernel first).  rate = st->buf_len bytes = RW words, RW <= 23; lane j absorbs words j, 8 + j
+// and 16 + j that lie inside the rate.
+__global__ __launch_bounds__(64)
+void bash_sponge_cols_kernel(bash_hash_st *__restrict__ st, const uint8_t *__restrict__ data, size_t nblocks)
+{
+    if (threadIdx.x >= 8) return;
+    const unsigned j = threadIdx.x;
+    const unsigned rate = (unsigned)st->buf_len, rw = rate / 8;
+    const BashCol C = bash_col_setup(threadIdx.x);
+    u64x2 w[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const uint64_t v = load64_any(st->s + 8 * (8 * r + j));
+        w[r].lo = (uint32_t)v; w[r].hi = (uint32_t)(v >> 32);
+    }
+    const uint8_t *p = data;
+    for (size_t b = 0; b < nblocks; ++b, p += rate) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const unsigned k = 8u * r + j;
+            if (k < rw) {
+                const uint64_t v = load64_any(p + 8 * k);
+                w[r].lo = (uint32_t)v; w[r].hi = (uint32_t)(v >> 32);
+            }
+        }
+        bash_f_cols(w[0], w[1], w[2], C);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        uint8_t *d = st->s + 8 * (8 * r + j);
+        const uint64_t v = ((uint64_t)w[r].hi << 32) | w[r].lo;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = (uint8_t)(v >> (8 * k));
+    }
+}
+err_t launch_bash_sponge_cols(void *d_state, const void *d_data, size_t nblocks, hipStream_t st)
+{
+    if (nblocks == 0) return ERR_OK;
+    hipLaunchKernelGGL(bash_sponge_cols_kernel, dim3(1), dim3(64), 0, st, (bash_hash_st *)d_state,
+                       (const uint8_t *)d_data, nblocks);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
 // belt MAC state in bee2's layout (belt_mac.c:32-40)
 struct belt_mac_st {
     uint32_t key[8];
@@ -315,17 +374,6 @@ __global__ void init_states_kernel(bash_hash_st *hs, belt_mac_st *ms, size_t n, 
 // One lane per message (lanes of a wavefront finish at different times; that is the nature of
 // ragged input).  This is the device side of a `bee2cmd bsum`-style front-end that hashes many
 // files per launch instead of one file per bashHashStepH loop (cmd/bsum/bsum.c:133-221).
-__device__ __forceinline__ uint64_t load64_any(const uint8_t *p)
-{
-    if (((uintptr_t)p & 3) == 0) {
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
-        return ((uint64_t)w[1] << 32) | w[0];
-    }
-    uint64_t v = 0;
-#pragma unroll
-    for (int k = 7; k >= 0; --k) v = (v << 8) | p[k];
-    return v;
-}
 
 // ALG = 8 / 12 / 16: bash512 / bash384 / bash256 (rate in u64 words); digests are l/4 bytes each
 template <int RW>

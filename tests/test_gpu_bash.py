@@ -75,6 +75,22 @@ def test_bash_hash_levels_and_splits_vs_oracle(orc):
     assert d == orc.bashHash(256, msg)[1] and ok
 
 
+def test_bash_hash_large_chunks_all_levels(orc):
+    """chunks of >= 4 KiB take the 8-lanes-per-state kernel (rates of 8 .. 23 words: the rate reaches into
+    rows 1 and 2 of the state for the small levels); one-shot, and split so that a partial block precedes
+    a large chunk (byte-wise head, 8-lane bulk, byte-wise tail)"""
+    eng = engine()
+    msg = orc.fill(40_001, 7)
+    for l in (16, 32, 64, 128, 144, 192, 256):
+        want = orc.bashHash(l, msg)
+        assert eng.bashHash(l, msg) == want, l
+        assert eng.bashHash(l, msg[:4096]) == orc.bashHash(l, msg[:4096]), l
+        for splits in ([40_001], [37, 9000, 30_964], [1, 4096 + 191, 35_713], [20_000, 20_001], [5000, 3, 34_998]):
+            assert sum(splits) == len(msg)
+            d, ok = eng.bashHash_steps(l, msg, splits)
+            assert d == want[1] and ok, (l, splits)
+
+
 def test_config0_bash256_1MiB_dropin(orc, golden):
     """BASELINE.json configs[0] shape through the drop-in bash256Hash path"""
     eng = engine()
