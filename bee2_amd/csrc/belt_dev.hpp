@@ -342,6 +342,35 @@ __device__ __forceinline__ void belt_compress(const Tab &T, uint32_t (&s1)[4], u
     for (int i = 0; i < 4; ++i) { h[i] = y0[i] ^ X[i]; h[4 + i] = y1[i] ^ X[4 + i]; }
 }
 
+// The same compression by a PAIR of lanes (even / odd) that both hold h and X: the first encryption is
+// done by both, then the two remaining ones -- which do not depend on each other -- one each, and the
+// halves are swapped with a one-lane shuffle.  The chain step of a long belt-hash is 2 E instead of 3.
+template <class Tab>
+__device__ __forceinline__ void belt_compress_pair(const Tab &T, uint32_t (&s1)[4], uint32_t (&h)[8],
+                                                   const uint32_t (&X)[8], uint32_t odd /* all-ones in the odd lane */)
+{
+    uint32_t u[4], key[8], y[4], xs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { u[i] = h[i] ^ h[4 + i]; s1[i] = u[i]; }
+    belt_encr(T, s1, X);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s1[i] ^= u[i];
+        key[i] = s1[i] ^ odd;                                   // s1 | ~s1
+        key[4 + i] = (h[4 + i] & ~odd) | (h[i] & odd);          // h1 | h0
+        xs[i] = (X[i] & ~odd) | (X[4 + i] & odd);               // X0 | X1
+        y[i] = xs[i];
+    }
+    belt_encr(T, y, key);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t mine = y[i] ^ xs[i];                     // h0' in the even lane, h1' in the odd one
+        const uint32_t other = (uint32_t)__shfl_xor((int)mine, 1, 64);
+        h[i] = (mine & ~odd) | (other & odd);
+        h[4 + i] = (other & ~odd) | (mine & odd);
+    }
+}
+
 // ---------------------------------------------------------------- GF(2^128) ---
 // belt-bde tweaks (belt_bde.c:58, belt_lcl.c:99-108): elements of GF(2)[x] / (x^128 + x^7 + x^2 + x + 1),
 // bit i of the 128-bit little-endian block = coefficient of x^i.  Only multiplications by powers

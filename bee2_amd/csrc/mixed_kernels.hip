@@ -490,7 +490,8 @@ void bash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__restri
 // belt-hash of ragged messages (src/crypto/belt/belt_hash.c:43-171): 32-byte digests
 __global__ __launch_bounds__(64)
 void belt_hash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off,
-                             const uint32_t *__restrict__ order, size_t n, uint8_t *__restrict__ digests)
+                             const uint32_t *__restrict__ order, size_t n, uint8_t *__restrict__ digests,
+                             uint64_t long_from)
 {
     __shared__ __attribute__((aligned(16))) uint8_t smem[BeltTabSmall::kBytes];
     BeltTabSmall::fill(smem, threadIdx.x, 64);
@@ -501,6 +502,7 @@ void belt_hash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *_
     const size_t i = order ? order[slot] : slot;
     const uint8_t *p = data + off[i];
     const size_t len = (size_t)(off[i + 1] - off[i]);
+    if (len >= long_from) return;                      // long messages: belt_hash_long_kernel, 2 lanes each
     size_t left = len;
     uint32_t h[8], s[4] = {0, 0, 0, 0}, X[8], s1[4];
 #pragma unroll
@@ -535,7 +537,8 @@ void belt_hash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *_
         for (int b = 0; b < 4; ++b) d[4 * k + b] = (uint8_t)(h[k] >> (8 * b));
 }
 
-// Streaming belt-hash for the drop-in beltHashStep* (belt_hash.c:43-171): one serial chain.
+// Streaming belt-hash for the drop-in beltHashStep* (belt_hash.c:43-171): one serial chain, run by a pair of
+// lanes (belt_compress_pair: 2 E per block on the chain instead of 3).
 // hs = h[8] || s[4] (in / out); nblocks whole 32-byte blocks at data; with fin != 0 the block
 // <bit length>_128 || s is compressed as well (belt_hash.c:120-135) and hs[0..8) is the digest.
 __global__ __launch_bounds__(64)
@@ -546,7 +549,8 @@ void belt_hash_stream_kernel(uint32_t *__restrict__ hs, const uint8_t *__restric
     BeltTabSmall::fill(smem, threadIdx.x, 64);
     __syncthreads();
     const BeltTabSmall T(smem);
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x >= 2 || blockIdx.x != 0) return;                    // a pair of lanes: belt_compress_pair
+    const uint32_t odd = threadIdx.x ? ~0u : 0u;
     uint32_t h[8], s[4], X[8], s1[4];
 #pragma unroll
     for (int k = 0; k < 8; ++k) h[k] = hs[k];
@@ -557,15 +561,16 @@ void belt_hash_stream_kernel(uint32_t *__restrict__ hs, const uint8_t *__restric
     for (size_t b = 0; b < nblocks; ++b) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) X[k] = w[8 * b + k];
-        belt_compress(T, s1, h, X);
+        belt_compress_pair(T, s1, h, X, odd);
 #pragma unroll
         for (int k = 0; k < 4; ++k) s[k] ^= s1[k];
     }
     if (fin) {
         X[0] = (uint32_t)bits_lo; X[1] = (uint32_t)(bits_lo >> 32); X[2] = (uint32_t)bits_hi; X[3] = (uint32_t)(bits_hi >> 32);
         X[4] = s[0]; X[5] = s[1]; X[6] = s[2]; X[7] = s[3];
-        belt_compress(T, s1, h, X);
+        belt_compress_pair(T, s1, h, X, odd);
     }
+    if (odd) return;                                                    // both lanes hold the result; lane 0 stores it
 #pragma unroll
     for (int k = 0; k < 8; ++k) hs[k] = h[k];
 #pragma unroll
@@ -584,6 +589,72 @@ err_t launch_belt_hash_stream(void *d_hs, const void *d_data, size_t nblocks, in
 // d_order (may be null): a permutation of 0..n-1; lane k hashes message d_order[k].  Lanes of a
 // wavefront run until the longest of their 64 messages is done, so callers pass the messages
 // sorted by decreasing length (the host entry point does) -- digests still land at index i.
+__device__ __forceinline__ uint32_t load32_any(const uint8_t *p)
+{
+    if (((uintptr_t)p & 3) == 0) return *reinterpret_cast<const uint32_t *>(p);
+    return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+}
+// Long belt-hash messages (>= long_from bytes): a PAIR of lanes per message (belt_compress_pair): of the
+// three encryptions of a block the last two are independent, so the chain step is 2 E instead of 3.
+// Launched over all n messages (2 lanes each); pairs whose message is short leave at once.
+__global__ __launch_bounds__(64)
+void belt_hash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off,
+                           const uint32_t *__restrict__ order, size_t n, uint8_t *__restrict__ digests,
+                           uint64_t long_from)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[BeltTabSmall::kBytes];
+    BeltTabSmall::fill(smem, threadIdx.x, 64);
+    __syncthreads();
+    const BeltTabSmall T(smem);
+    const size_t slot = ((size_t)blockIdx.x * 64 + threadIdx.x) >> 1;
+    const uint32_t odd = (threadIdx.x & 1u) ? ~0u : 0u;
+    if (slot >= n) return;
+    const size_t i = order ? order[slot] : slot;
+    const uint8_t *p = data + off[i];
+    const size_t len = (size_t)(off[i + 1] - off[i]);
+    if (len < long_from) return;
+    size_t left = len;
+    uint32_t h[8], s[4] = {0, 0, 0, 0}, X[8], s1[4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        h[k] = (uint32_t)c_beltH[4 * k] | (uint32_t)c_beltH[4 * k + 1] << 8 |
+               (uint32_t)c_beltH[4 * k + 2] << 16 | (uint32_t)c_beltH[4 * k + 3] << 24;
+    while (left >= 32) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) X[k] = load32_any(p + 4 * k);
+        belt_compress_pair(T, s1, h, X, odd);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] ^= s1[k];
+        p += 32; left -= 32;
+    }
+    if (left) {                                        // the last, zero-padded block (belt_hash.c:115-119)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 3; b >= 0; --b) {
+                const size_t pos = (size_t)(4 * k + b);
+                v = (v << 8) | (pos < left ? p[pos] : 0u);
+            }
+            X[k] = v;
+        }
+        belt_compress_pair(T, s1, h, X, odd);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] ^= s1[k];
+    }
+    const uint64_t bits_lo = (uint64_t)len << 3, bits_hi = (uint64_t)len >> 61;
+    X[0] = (uint32_t)bits_lo; X[1] = (uint32_t)(bits_lo >> 32); X[2] = (uint32_t)bits_hi; X[3] = 0;
+    X[4] = s[0]; X[5] = s[1]; X[6] = s[2]; X[7] = s[3];
+    belt_compress_pair(T, s1, h, X, odd);
+    if (!odd) {
+        uint8_t *d = digests + 32 * i;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) d[4 * k + b] = (uint8_t)(h[k] >> (8 * b));
+    }
+}
+
 constexpr uint64_t RAGGED_LONG = 4096;     // bytes; see bench.py --only ragged and DESIGN.md 4.7
 err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, const void *d_order, size_t n,
                          void *d_digests, hipStream_t st)
@@ -598,7 +669,11 @@ err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, cons
     // bash: messages of >= RAGGED_LONG bytes go to the 8-lanes-per-message kernel (a 4x shorter serial chain),
     // the rest stay one lane each; both launches cover all n messages and each skips what is not its own
     const dim3 gl((unsigned)((n * 8 + 63) / 64));
-    if (alg == 0) hipLaunchKernelGGL(belt_hash_ragged_kernel, g, t, 0, st, data, off, ord, n, dig);
+    if (alg == 0) {
+        hipLaunchKernelGGL(belt_hash_long_kernel, dim3((unsigned)((n * 2 + 63) / 64)), t, 0, st, data, off, ord, n, dig,
+                           RAGGED_LONG);
+        hipLaunchKernelGGL(belt_hash_ragged_kernel, g, t, 0, st, data, off, ord, n, dig, RAGGED_LONG);
+    }
     else if (alg == 256) {
         hipLaunchKernelGGL(bash_long_kernel<8>, gl, t, 0, st, data, off, ord, n, 256u, dig, RAGGED_LONG);
         hipLaunchKernelGGL(bash_ragged_kernel<8>, g, t, 0, st, data, off, ord, n, 256u, dig, RAGGED_LONG);
