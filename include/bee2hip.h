@@ -1,14 +1,20 @@
 /*
  * bee2hip.h -- C ABI of libbee2hip.so, the MI355X (gfx950) batch-primitive engine
- * for bee2's three data-parallel hot paths.
+ * for bee2's data-parallel hot paths: bash-f / bashHash, belt (block, CTR, MAC, hash,
+ * ECB, CBC, BDE, SDE, DWP, CHE) and bign signature verification on the three standard
+ * curves.
  *
  * Three groups of entry points, all `extern "C"`, plain pointers and sizes:
  *
- *  (1) bee2 DROP-IN symbols: same names, signatures, state layouts and error
- *      behaviour as the bee2 functions they replace, so a bee2 caller can link
- *      this library instead of those objects.  Every primitive evaluation
- *      (bashF, E_K, the double-scalar multiplication) runs on the GPU; there is
- *      no CPU fallback.  Each declaration cites the bee2 interface it replaces.
+ *  (1) bee2 DROP-IN symbols: same names, signatures and error behaviour as the
+ *      bee2 functions they replace, so a bee2 caller can link this library instead
+ *      of those objects.  States are caller-owned PODs of X_keep() bytes that may be
+ *      memcpy-cloned, as in bee2; belt_ctr_st, belt_mac_st and bash_hash_st have
+ *      bee2's exact layout, the other states are opaque.  Every primitive evaluation
+ *      (bashF, E_K / D_K, GF(2^128) products, the double-scalar multiplication) runs
+ *      on the GPU; there is no CPU fallback, and a device failure inside a `void`
+ *      function aborts with a message.  Each declaration cites the bee2 interface it
+ *      replaces.  All of them may be called from several threads at once.
  *
  *  (2) bee2hip_*  host-pointer batch API: the caller hands host buffers; the
  *      library stages H2D, launches, stages D2H.
@@ -119,6 +125,29 @@ err_t beltCBCDecr(void *dest, const void *src, size_t count, const octet key[], 
    s <- E_K(iv); for every 16-byte block s <- s*x in GF(2^128), Y = E_K(X ^ s) ^ s (StepD: D_K).
    count must be a multiple of 16; the one-shots return ERR_BAD_INPUT for count < 16 or
    count % 16 != 0 (belt_bde.c:93-100). */
+size_t beltBDE_keep(void);
+void beltBDEStart(void *state, const octet key[], size_t len, const octet iv[16]);
+void beltBDEStepE(void *buf, size_t count, void *state);
+void beltBDEStepD(void *buf, size_t count, void *state);
+err_t beltBDEEncr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                  const octet iv[16]);
+err_t beltBDEDecr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                  const octet iv[16]);
+
+/* belt-sde, sector-wise disk encryption (belt.h, src/crypto/belt/belt_sde.c:26-121): XEX around
+   the wide-block cipher belt-wbl with the tweak E_K(iv) on the first block.  One call = one sector:
+   count a multiple of 16, >= 32 (the one-shots return ERR_BAD_INPUT otherwise, belt_sde.c:79-80).
+   A sector is a serial chain of 2*(count/16) block encryptions; the batch entry below runs many
+   sectors, one lane each. */
+size_t beltSDE_keep(void);
+void beltSDEStart(void *state, const octet key[], size_t len);
+void beltSDEStepE(void *buf, size_t count, const octet iv[16], void *state);
+void beltSDEStepD(void *buf, size_t count, const octet iv[16], void *state);
+err_t beltSDEEncr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                  const octet iv[16]);
+err_t beltSDEDecr(void *dest, const void *src, size_t count, const octet key[], size_t len,
+                  const octet iv[16]);
+
 /* belt-dwp, authenticated encryption: CTR + polynomial MAC over GF(2^128) (belt.h, src/crypto/belt/
    belt_dwp.c:27-274).  The state is an opaque POD of beltDWP_keep() bytes (not bee2's layout: bee2
    appends a beltPolyMul stack).  Order of calls as in bee2: Start, StepI* (open data), then
@@ -137,20 +166,6 @@ err_t beltDWPWrap(void *dest, octet mac[8], const void *src1, size_t count1, con
 err_t beltDWPUnwrap(void *dest, const void *src1, size_t count1, const void *src2, size_t count2,
                     const octet mac[8], const octet key[], size_t len, const octet iv[16]);
 
-/* belt-sde, sector-wise disk encryption (belt.h, src/crypto/belt/belt_sde.c:26-121): XEX around
-   the wide-block cipher belt-wbl with the tweak E_K(iv) on the first block.  One call = one sector:
-   count a multiple of 16, >= 32 (the one-shots return ERR_BAD_INPUT otherwise, belt_sde.c:79-80).
-   A sector is a serial chain of 2*(count/16) block encryptions; the batch entry below runs many
-   sectors, one lane each. */
-size_t beltSDE_keep(void);
-void beltSDEStart(void *state, const octet key[], size_t len);
-void beltSDEStepE(void *buf, size_t count, const octet iv[16], void *state);
-void beltSDEStepD(void *buf, size_t count, const octet iv[16], void *state);
-err_t beltSDEEncr(void *dest, const void *src, size_t count, const octet key[], size_t len,
-                  const octet iv[16]);
-err_t beltSDEDecr(void *dest, const void *src, size_t count, const octet key[], size_t len,
-                  const octet iv[16]);
-
 /* belt-che (belt_che.c:27-319): the belt-dwp authenticator with r = E_K(iv) and the keystream
    E_K(s_i), s_0 = r, s_i = s_{i-1}*x ^ 1 in GF(2^128); same call order and error behaviour as belt-dwp */
 size_t beltCHE_keep(void);
@@ -165,15 +180,6 @@ err_t beltCHEWrap(void *dest, octet mac[8], const void *src1, size_t count1, con
                   size_t count2, const octet key[], size_t len, const octet iv[16]);
 err_t beltCHEUnwrap(void *dest, const void *src1, size_t count1, const void *src2, size_t count2,
                     const octet mac[8], const octet key[], size_t len, const octet iv[16]);
-
-size_t beltBDE_keep(void);
-void beltBDEStart(void *state, const octet key[], size_t len, const octet iv[16]);
-void beltBDEStepE(void *buf, size_t count, void *state);
-void beltBDEStepD(void *buf, size_t count, void *state);
-err_t beltBDEEncr(void *dest, const void *src, size_t count, const octet key[], size_t len,
-                  const octet iv[16]);
-err_t beltBDEDecr(void *dest, const void *src, size_t count, const octet key[], size_t len,
-                  const octet iv[16]);
 
 /* belt-hash, the default algorithm of `bee2cmd bsum` (belt.h, src/crypto/belt/belt_hash.c:28-190;
    cmd/bsum/bsum.c:133-147 drives exactly Start / StepH* / StepG).  One message is a serial chain:
