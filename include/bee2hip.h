@@ -255,9 +255,11 @@ err_t bee2hip_hash_ragged(size_t alg, const octet *data, const uint64_t *offsets
 err_t bee2hip_hash_ragged_dev(size_t alg, const void *d_data, const void *d_offsets, size_t n,
                               void *d_digests, void *stream);
 /* same with a launch order: d_order = n x uint32, a permutation of 0..n-1 (or NULL = identity);
-   wavefront lane k hashes message d_order[k], digest i still lands at d_digests + i*dlen.  A
-   wavefront runs until the longest of its 64 messages is done: pass the messages sorted by
-   decreasing length (bee2hip_hash_ragged does so itself). */
+   slot k hashes message d_order[k], digest i still lands at d_digests + i*dlen.  A slot is one lane,
+   or for messages of 4 KiB and more a group of 8 lanes (bash: one column of the state each) or a
+   pair (belt-hash: the two independent encryptions of a compression).  A wavefront runs until the
+   longest of its messages is done: pass the messages sorted by decreasing length
+   (bee2hip_hash_ragged does so itself). */
 err_t bee2hip_hash_ragged_ordered_dev(size_t alg, const void *d_data, const void *d_offsets,
                                       const void *d_order, size_t n, void *d_digests, void *stream);
 
