@@ -507,11 +507,11 @@ static err_t bign_table(uint4 **out, hipStream_t st)
     if (!slot) {
         const size_t pt = 8 * N;                                      // bytes per affine point
         uint4 *t8 = nullptr;
-        if (hipMalloc((void **)&t8, (size_t)4 * N * GT8_ENTRIES * pt) != hipSuccess) return ERR_OUTOFMEMORY;
+        if (hipMalloc((void **)&t8, (size_t)4 * N * GT8_ENTRIES * pt) != hipSuccess) { (void)hipGetLastError(); return ERR_OUTOFMEMORY; }
         hipLaunchKernelGGL(bign_gtable_kernel<N>, dim3(4 * N * GT8_ENTRIES / 64), dim3(64), 0, st, t8);
         if (Comb<N>::W == 16) {
             uint4 *t16 = nullptr;
-            if (hipMalloc((void **)&t16, (size_t)2 * N * 65536 * pt) != hipSuccess) { (void)hipFree(t8); return ERR_OUTOFMEMORY; }
+            if (hipMalloc((void **)&t16, (size_t)2 * N * 65536 * pt) != hipSuccess) { (void)hipFree(t8); (void)hipGetLastError(); return ERR_OUTOFMEMORY; }
             hipLaunchKernelGGL(bign_gtable16_kernel<N>, dim3(2 * N * 65536 / 256), dim3(256), 0, st,
                                (const uint4 *)t8, t16);
             B2H_TRY(hipGetLastError());

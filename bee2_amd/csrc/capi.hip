@@ -23,7 +23,16 @@ static thread_local char t_err[256] = "";
 err_t hip_fail(hipError_t e, const char *what)
 {
     snprintf(t_err, sizeof t_err, "%s: %s", what, hipGetErrorString(e));
+    // HIP keeps the failure as this thread's "last error"; a later hipGetLastError() (the launchers check
+    // it after every kernel launch) would blame an unrelated call for it.  The error has been reported: clear it.
+    (void)hipGetLastError();
     return ERR_BEE2HIP_DEVICE;
+}
+// the same for failures the library maps to a bee2 error code itself (a refused allocation)
+static inline err_t out_of_memory()
+{
+    (void)hipGetLastError();
+    return ERR_OUTOFMEMORY;
 }
 
 // ---------------------------------------------------------- per-device init ---
@@ -101,7 +110,7 @@ err_t scratch_for_stream(hipStream_t st, int slot, size_t bytes, void **out)
             (void)hipFree(e->p);
             e->p = nullptr; e->bytes = 0;
         }
-        if (hipMalloc(&e->p, bytes) != hipSuccess) { e->p = nullptr; return ERR_OUTOFMEMORY; }
+        if (hipMalloc(&e->p, bytes) != hipSuccess) { e->p = nullptr; return out_of_memory(); }
         e->bytes = bytes;
     }
     *out = e->p;
@@ -120,7 +129,7 @@ struct Scratch {
         if (p && (cur != dev || cap < n)) { (void)hipFree(p); p = nullptr; cap = 0; }
         if (!p) {
             size_t want = n < 4096 ? 4096 : n;
-            if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return ERR_OUTOFMEMORY; }
+            if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return out_of_memory(); }
             cap = want; dev = cur;
         }
         return ERR_OK;

@@ -50,3 +50,18 @@ def test_misaligned_device_pointers_are_refused(orc, golden):
     eng.beltCTR_blocks_dev(buf, kw, c0, 0)
     torch.cuda.synchronize()
     assert host(buf) == orc.ctr(data, golden.H[128:160], golden.H[192:208])
+
+
+def test_absurd_sizes_fail_with_out_of_memory_not_a_crash():
+    """the device buffer is allocated before the host pointer is read: a size no GPU has is ERR_OUTOFMEMORY"""
+    import ctypes
+    eng = engine()
+    buf = ctypes.create_string_buffer(192)
+    huge = ctypes.c_size_t(1 << 42)                                   # 2^42 states = 768 TiB
+    assert eng.lib.bee2hip_bashF_batch(buf, huge) == 110
+    st = ctypes.create_string_buffer(eng.lib.beltCTR_keep())
+    eng.lib.beltCTRStart(st, bytes(32), ctypes.c_size_t(32), bytes(16))
+    assert eng.lib.bee2hip_beltCTR_bulk(buf, ctypes.c_size_t(1 << 50), st) in (110, 109)
+    # and the library still works afterwards
+    code, out = eng.beltCTR(b"abc", bytes(32), bytes(16))
+    assert code == 0 and len(out) == 3
