@@ -65,3 +65,80 @@ def test_absurd_sizes_fail_with_out_of_memory_not_a_crash():
     # and the library still works afterwards
     code, out = eng.beltCTR(b"abc", bytes(32), bytes(16))
     assert code == 0 and len(out) == 3
+
+
+def test_states_can_be_cloned_mid_stream(orc, golden):
+    """bee2: "states are flat PODs of X_keep() bytes that may be memcpy-cloned" (SURVEY.md 8b Ownership).
+    Feed a common prefix, copy the state bytes, continue the two copies with different data."""
+    import ctypes
+    eng = engine()
+    L = eng.lib
+    sz = ctypes.c_size_t
+    key, iv = golden.H[128:160], golden.H[192:208]
+    pre, a, b = orc.fill(1000 + 7, 1), orc.fill(5000 + 3, 2), orc.fill(333, 3)
+
+    def clone(st):
+        return ctypes.create_string_buffer(st.raw, len(st.raw))
+    # beltCTR
+    st = ctypes.create_string_buffer(L.beltCTR_keep())
+    L.beltCTRStart(st, key, sz(32), iv)
+    p = ctypes.create_string_buffer(pre, len(pre))
+    L.beltCTRStepE(p, sz(len(pre)), st)
+    for tail in (a, b):
+        c = clone(st)
+        t = ctypes.create_string_buffer(tail, len(tail))
+        L.beltCTRStepE(t, sz(len(tail)), c)
+        assert p.raw[: len(pre)] + t.raw[: len(tail)] == orc.ctr(pre + tail, key, iv)
+    # beltMAC, bashHash, beltHash: digest of prefix || tail from a cloned state
+    st = ctypes.create_string_buffer(L.beltMAC_keep())
+    L.beltMACStart(st, key, sz(32))
+    L.beltMACStepA(pre, sz(len(pre)), st)
+    for tail in (a, b):
+        c = clone(st)
+        L.beltMACStepA(tail, sz(len(tail)), c)
+        m = ctypes.create_string_buffer(8)
+        L.beltMACStepG(m, c)
+        assert m.raw == orc.mac(pre + tail, key)
+    st = ctypes.create_string_buffer(L.bashHash_keep())
+    L.bashHashStart(st, sz(128))
+    L.bashHashStepH(pre, sz(len(pre)), st)
+    for tail in (a, b):
+        c = clone(st)
+        L.bashHashStepH(tail, sz(len(tail)), c)
+        d = ctypes.create_string_buffer(32)
+        L.bashHashStepG(d, sz(32), c)
+        assert d.raw == orc.bashHash(128, pre + tail)[1]
+    st = ctypes.create_string_buffer(L.beltHash_keep())
+    L.beltHashStart(st)
+    L.beltHashStepH(pre, sz(len(pre)), st)
+    for tail in (a, b):
+        c = clone(st)
+        L.beltHashStepH(tail, sz(len(tail)), c)
+        d = ctypes.create_string_buffer(32)
+        L.beltHashStepG(d, c)
+        assert d.raw == orc.belt_hash(pre + tail)
+    # belt-dwp / belt-che: open data in the common prefix, different critical data afterwards
+    for mode in ("DWP", "CHE"):
+        f = lambda n: getattr(L, f"belt{mode}{n}")
+        st = ctypes.create_string_buffer(f("_keep")())
+        f("Start")(st, key, sz(32), iv)
+        f("StepI")(pre, sz(len(pre)), st)
+        for tail in (a, b):
+            c = clone(st)
+            t = ctypes.create_string_buffer(tail, len(tail))
+            f("StepE")(t, sz(len(tail)), c)
+            f("StepA")(t, sz(len(tail)), c)
+            m = ctypes.create_string_buffer(8)
+            f("StepG")(m, c)
+            assert (0, t.raw[: len(tail)], m.raw) == orc.dwp_wrap(tail, pre, key, iv, mode), mode
+    # belt-bde: whole blocks
+    pre16, a16, b16 = pre[:992], a[:4992], b[:320]
+    st = ctypes.create_string_buffer(L.beltBDE_keep())
+    L.beltBDEStart(st, key, sz(32), iv)
+    p = ctypes.create_string_buffer(pre16, len(pre16))
+    L.beltBDEStepE(p, sz(len(pre16)), st)
+    for tail in (a16, b16):
+        c = clone(st)
+        t = ctypes.create_string_buffer(tail, len(tail))
+        L.beltBDEStepE(t, sz(len(tail)), c)
+        assert p.raw[: len(pre16)] + t.raw[: len(tail)] == orc.bde(pre16 + tail, key, iv)[1]
