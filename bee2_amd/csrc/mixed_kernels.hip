@@ -655,6 +655,32 @@ void belt_hash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__r
     }
 }
 
+// Launch order for a ragged batch when the caller gives none: messages bucketed by the power of two of
+// their length, buckets in descending order (a counting sort: histogram, prefix, scatter).  Inside a
+// wavefront lengths then differ by less than 2x; the order inside a bucket is whatever the atomics
+// give -- it only decides which lane hashes which message, every digest lands at its own index.
+// work[0..63] = histogram, work[64..127] = bucket start, work[128..191] = cursor
+__device__ __forceinline__ unsigned ragged_bucket(uint64_t len) { return len ? 63u - (unsigned)__builtin_clzll(len) + 1u : 0u; }
+__global__ void ragged_hist_kernel(const uint64_t *__restrict__ off, size_t n, unsigned *__restrict__ work)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&work[ragged_bucket(off[i + 1] - off[i])], 1u);
+}
+__global__ void ragged_scan_kernel(unsigned *__restrict__ work)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    unsigned acc = 0;
+    for (int b = 63; b >= 0; --b) { work[64 + b] = acc; work[128 + b] = 0; acc += work[b]; }
+}
+__global__ void ragged_scatter_kernel(const uint64_t *__restrict__ off, size_t n, unsigned *__restrict__ work,
+                                      uint32_t *__restrict__ order)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned b = ragged_bucket(off[i + 1] - off[i]);
+    order[work[64 + b] + atomicAdd(&work[128 + b], 1u)] = (uint32_t)i;
+}
+
 constexpr uint64_t RAGGED_LONG = 4096;     // bytes; see bench.py --only ragged and DESIGN.md 4.7
 err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, const void *d_order, size_t n,
                          void *d_digests, hipStream_t st)
@@ -665,6 +691,19 @@ err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, cons
     const dim3 g((unsigned)((n + 63) / 64)), t(64);
     const uint8_t *data = (const uint8_t *)d_data;
     const uint64_t *off = (const uint64_t *)d_off;
+    if (!ord && n >= 128) {                          // no order given: bucket the lengths on the device
+        void *scr = nullptr;
+        err_t code = scratch_for_stream(st, 11, 192 * 4 + n * 4, &scr);
+        if (code != ERR_OK) return code;
+        unsigned *work = (unsigned *)scr;
+        uint32_t *order = (uint32_t *)(work + 192);
+        B2H_TRY(hipMemsetAsync(work, 0, 192 * 4, st));
+        const dim3 gn((unsigned)((n + 255) / 256)), tn(256);
+        hipLaunchKernelGGL(ragged_hist_kernel, gn, tn, 0, st, off, n, work);
+        hipLaunchKernelGGL(ragged_scan_kernel, dim3(1), dim3(64), 0, st, work);
+        hipLaunchKernelGGL(ragged_scatter_kernel, gn, tn, 0, st, off, n, work, order);
+        ord = order;
+    }
     uint8_t *dig = (uint8_t *)d_digests;
     // bash: messages of >= RAGGED_LONG bytes go to the 8-lanes-per-message kernel (a 4x shorter serial chain),
     // the rest stay one lane each; both launches cover all n messages and each skips what is not its own

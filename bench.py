@@ -494,7 +494,8 @@ def main():
         data = torch.empty(max(total, 8) // 8 * 8 + 8, dtype=torch.uint8, device="cuda")
         fill_seeded(data, 0x4D1C + dist.rank)
         doff = torch.from_numpy(offs).cuda()
-        # launch order: longest message first (what the host entry point bee2hip_hash_ragged does itself)
+        # "caller_order": no order passed, the library buckets the lengths on the device (powers of two, longest
+        # bucket first); "longest_first": an exact descending sort passed in (what the host entry point does itself)
         dord = torch.from_numpy(np.argsort(-lens, kind="stable").astype(np.int32)).cuda()
         for name, alg, dl in (("belt_hash", 0, 32), ("bash256", 128, 32)):
             dig = torch.empty(nm * dl, dtype=torch.uint8, device="cuda")

@@ -254,7 +254,9 @@ err_t bee2hip_hash_ragged(size_t alg, const octet *data, const uint64_t *offsets
                           octet *digests);
 err_t bee2hip_hash_ragged_dev(size_t alg, const void *d_data, const void *d_offsets, size_t n,
                               void *d_digests, void *stream);
-/* same with a launch order: d_order = n x uint32, a permutation of 0..n-1 (or NULL = identity);
+/* (without an order the library buckets the messages by the power of two of their length on the device
+   and launches the buckets longest first)
+   same with an explicit launch order: d_order = n x uint32, a permutation of 0..n-1 (NULL = as above);
    slot k hashes message d_order[k], digest i still lands at d_digests + i*dlen.  A slot is one lane,
    or for messages of 4 KiB and more a group of 8 lanes (bash: one column of the state each) or a
    pair (belt-hash: the two independent encryptions of a compression).  A wavefront runs until the
