@@ -176,3 +176,40 @@ def test_bsum_front_end_example(orc, golden, tmp_path):
             data = open(name, "rb").read()
             want = orc.belt_hash(data) if alg == 0 else orc.bashHash(alg, data)[1]
             assert line == f"{want.hex().upper()}  {name}"
+
+
+def test_c_selftest_example_runs_the_stb_vectors(golden, tmp_path):
+    """examples/selftest.c: the drop-in functions from plain C (what a bee2 maintainer would try first), on the
+    STB vectors of the fixtures: bash A.2 / A.3, belt A.9-A.12, A.15-A.17, A.19-A.20, A.23-A.25, bign G.2 / G.3"""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("cc") is None:
+        pytest.skip("no C compiler on this box")
+    exe = tmp_path / "selftest"
+    lib = os.path.join(root, "bee2_amd", "lib")
+    subprocess.check_call(["cc", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "selftest.c"),
+                           "-L" + lib, "-lbee2hip", "-Wl,-rpath," + lib, "-o", str(exe)])
+    k, H = golden.kat, golden.H
+    hx = lambda b: b.hex() if len(b) else "-"
+    lines = [f"bashF A.2 {k['bashF_A2']['in']} {k['bashF_A2']['out']}"]
+    lines += [f"bashhash {v['name']} {v['l']} {hx(H[:v['len']])} {v['out']}" for v in k["bash_hash"]]
+    lines += [f"belthash {v['name']} {hx(H[:v['len']])} {v['out']}" for v in k["belt_hash"]]
+    lines += [f"ctr {v['name']} {v['in']} {v['key']} {v['iv']} {v['out']}" for v in k["belt_ctr"]]
+    lines += [f"mac {v['name']} {v['in']} {v['key']} {v['out']}" for v in k["belt_mac"]]
+    lines += [f"mode {v['name']} {v['fn']} {v['in']} {v['key']} {v['iv'] or '-'} {v['out']}" for v in k["belt_modes"]]
+    for mode, g in (("DWP", golden.belt_dwp), ("CHE", golden.belt_che)):
+        v = g["kat"][0]
+        assert v["op"] == "wrap"
+        lines.append(f"wrap {v['name']} {mode} {v['crit']} {v['open']} {v['key']} {v['iv']} {v['out']} {v['mac']}")
+        for i, c in enumerate(g["short"][:6]):
+            lines.append(f"wrap short{i} {mode} {c['crit'] or '-'} {c['open'] or '-'} {c['key']} {c['iv']} {c['out'] or '-'} {c['mac']}")
+    lines += [f"verify {v['name']} {v['hash']} {v['sig']} {v['pubkey']} {v['code']}" for v in k["bign_verify"]]
+    vec = tmp_path / "vectors.txt"
+    vec.write_text("\n".join(lines) + "\n")
+    r = subprocess.run([str(exe), str(vec)], capture_output=True, text=True, timeout=300)
+    out = r.stdout.strip().splitlines()
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
+    assert not [l for l in out if l.startswith(("FAIL", "SKIP"))]
+    assert out[-1].startswith(f"{len(lines)} vectors, 0 failed"), out[-1]
