@@ -630,7 +630,8 @@ def main():
             entry[name] = N * nbytes * km / el / 2 ** 30
         # belt-sde: independent sectors, one lane each (a sector is a serial chain of 2 E per block)
         for sb in (512, 4096):
-            ns = (1 << 29) // sb                                   # 512 MiB of sectors per GPU
+            ns = (1 << 20) if sb == 512 else (1 << 19)             # 512 MiB / 2 GiB of sectors: >= 8 wavefronts per SIMD
+            ns = min(ns, nbytes // sb, dst.numel() // 16)
             sec = src[: ns * sb]
             sivs = dst[: 16 * ns]
             fill_seeded(sivs, 0x5DE + dist.rank)

@@ -37,7 +37,7 @@ def main(path):
     bc = b.get("cpu_baseline", {})
     rows.append(("belt ECB / CBC-decrypt / BDE, 4 GiB", f"**{b['ecb_encr']:.0f} / {b['cbc_decr']:.0f} / {b['bde_encr']:.0f} GiB/s**",
                  f"{bc.get('ecb_encr', 0):.2f} / {bc.get('cbc_decr', 0):.2f} / {bc.get('bde_encr', 0):.2f} GiB/s"))
-    rows.append(("belt-sde, 512 B / 4 KiB sectors", f"**{b['sde_encr_512']:.0f} / {b['sde_encr_4096']:.0f} GiB/s** (§4.5: 2 E per block, serial per sector)",
+    rows.append(("belt-sde, 512 B / 4 KiB sectors", f"**{b['sde_encr_512']:.0f} / {b['sde_encr_4096']:.0f} GiB/s** (§4.5: 2 E per block = half of ECB at best)",
                  f"{bc.get('sde_encr', 0):.2f} GiB/s"))
     w = o["belt_dwp"]
     rows.append(("belt-dwp / belt-che wrap, 4 GiB", f"**{w['value']:.0f} / {w['che_wrap']:.0f} GiB/s** (MAC alone {w['mac_only']/1024:.2f} TiB/s)",
