@@ -536,14 +536,14 @@ void polyhash_finish_kernel(const uint4 *__restrict__ partial, unsigned nwaves, 
 // CBC encryption is a serial chain per message (belt_cbc.c:63-84): one lane per message,
 // n messages of nblk full blocks each, per-message iv, in place.  ivs[m] receives the last
 // ciphertext block (the chaining value bee2 keeps in belt_cbc_st.block).
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(CTR_WG)
 void belt_cbc_encr_kernel(uint4 *__restrict__ msgs, size_t nblk, size_t n, BeltKey key, uint4 *__restrict__ ivs)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[BeltTabSmall::kBytes];
-    BeltTabSmall::fill(smem, threadIdx.x, 64);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    CtrTab::fill(smem, threadIdx.x, CTR_WG);
     __syncthreads();
-    const BeltTabSmall T(smem);
-    const size_t m = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const CtrTab T(smem);
+    const size_t m = (size_t)blockIdx.x * CTR_WG + threadIdx.x;
     if (m >= n) return;
     uint32_t K[8];
 #pragma unroll
@@ -551,7 +551,23 @@ void belt_cbc_encr_kernel(uint4 *__restrict__ msgs, size_t nblk, size_t n, BeltK
     uint4 c = ivs[m];
     uint32_t x[4] = {c.x, c.y, c.z, c.w};
     uint4 *p = msgs + m * nblk;
-    for (size_t i = 0; i < nblk; ++i) {
+    // 8 blocks = one 128-byte line per lane and memory instruction: the lanes of a wavefront sit in 64 different
+    // messages, a 16-byte access would move a whole line for a quarter of it (cf. belt_sde_lines_kernel)
+    size_t i = 0;
+    for (; i + 8 <= nblk; i += 8) {
+        uint4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[i + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x[0] ^= v[j].x; x[1] ^= v[j].y; x[2] ^= v[j].z; x[3] ^= v[j].w;
+            belt_encr(T, x, K);
+            v[j] = make_uint4(x[0], x[1], x[2], x[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[i + j] = v[j];
+    }
+    for (; i < nblk; ++i) {
         const uint4 v = p[i];
         x[0] ^= v.x; x[1] ^= v.y; x[2] ^= v.z; x[3] ^= v.w;
         belt_encr(T, x, K);
@@ -832,8 +848,14 @@ err_t launch_belt_cbc_encr(void *d_msgs, size_t nblk, size_t n, const uint32_t k
     if (n == 0) return ERR_OK;
     BeltKey k;
     for (int i = 0; i < 8; ++i) k.k[i] = key[i];
-    hipLaunchKernelGGL(belt_cbc_encr_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (uint4 *)d_msgs,
-                       nblk, n, k, (uint4 *)d_ivs);
+    static bool cattr[64];
+    if (!cattr[cur_dev()]) {
+        B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(belt_cbc_encr_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, CtrTab::kBytes));
+        cattr[cur_dev()] = true;
+    }
+    hipLaunchKernelGGL(belt_cbc_encr_kernel, dim3((unsigned)((n + CTR_WG - 1) / CTR_WG)), dim3(CTR_WG), CtrTab::kBytes, st,
+                       (uint4 *)d_msgs, nblk, n, k, (uint4 *)d_ivs);
     B2H_TRY(hipGetLastError());
     return ERR_OK;
 }

@@ -638,6 +638,13 @@ def main():
             for name, decr in ((f"sde_encr_{sb}", 0), (f"sde_decr_{sb}", 1)):
                 el = timed(dist, km, 1, lambda: eng.beltSDE_sectors_dev(decr, sec, sb, kw, sivs))
                 entry[name] = N * ns * sb * km / el / 2 ** 30
+        # CBC encryption is a serial chain per message: a batch of independent 512-byte messages, one lane each
+        nm, mb = 1 << 20, 512
+        cmsgs = src[: nm * mb]
+        civs = dst[: 16 * nm]
+        fill_seeded(civs, 0xCBC + dist.rank)
+        el = timed(dist, km, 1, lambda: eng.beltCBCEncr_batch_dev(cmsgs, mb // 16, kw, civs))
+        entry["cbc_encr_batch_512"] = N * nm * mb * km / el / 2 ** 30
         entry["value"] = entry["ecb_encr"]
         entry["ms_per_step"] = nbytes / 2 ** 30 / entry["ecb_encr"] * 1e3 * N
         if do_cpu:
