@@ -661,10 +661,18 @@ void belt_hash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__r
 // give -- it only decides which lane hashes which message, every digest lands at its own index.
 // work[0..63] = histogram, work[64..127] = bucket start, work[128..191] = cursor
 __device__ __forceinline__ unsigned ragged_bucket(uint64_t len) { return len ? 63u - (unsigned)__builtin_clzll(len) + 1u : 0u; }
-__global__ void ragged_hist_kernel(const uint64_t *__restrict__ off, size_t n, unsigned *__restrict__ work)
+// (global atomics of 65 536 threads on ~19 addresses serialise -- 160 us per kernel; a workgroup therefore
+// counts in LDS first and touches each global bucket once)
+__global__ __launch_bounds__(256)
+void ragged_hist_kernel(const uint64_t *__restrict__ off, size_t n, unsigned *__restrict__ work)
 {
+    __shared__ unsigned h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&work[ragged_bucket(off[i + 1] - off[i])], 1u);
+    if (i < n) atomicAdd(&h[ragged_bucket(off[i + 1] - off[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64 && h[threadIdx.x]) atomicAdd(&work[threadIdx.x], h[threadIdx.x]);
 }
 __global__ void ragged_scan_kernel(unsigned *__restrict__ work)
 {
@@ -672,13 +680,21 @@ __global__ void ragged_scan_kernel(unsigned *__restrict__ work)
     unsigned acc = 0;
     for (int b = 63; b >= 0; --b) { work[64 + b] = acc; work[128 + b] = 0; acc += work[b]; }
 }
-__global__ void ragged_scatter_kernel(const uint64_t *__restrict__ off, size_t n, unsigned *__restrict__ work,
-                                      uint32_t *__restrict__ order)
+__global__ __launch_bounds__(256)
+void ragged_scatter_kernel(const uint64_t *__restrict__ off, size_t n, unsigned *__restrict__ work,
+                           uint32_t *__restrict__ order)
 {
+    __shared__ unsigned cnt[64], base[64];
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned b = ragged_bucket(off[i + 1] - off[i]);
-    order[work[64 + b] + atomicAdd(&work[128 + b], 1u)] = (uint32_t)i;
+    unsigned b = 0, rank = 0;
+    if (i < n) { b = ragged_bucket(off[i + 1] - off[i]); rank = atomicAdd(&cnt[b], 1u); }
+    __syncthreads();
+    if (threadIdx.x < 64 && cnt[threadIdx.x])                         // this workgroup's slice of every bucket
+        base[threadIdx.x] = work[64 + threadIdx.x] + atomicAdd(&work[128 + threadIdx.x], cnt[threadIdx.x]);
+    __syncthreads();
+    if (i < n) order[base[b] + rank] = (uint32_t)i;
 }
 
 constexpr uint64_t RAGGED_LONG = 4096;     // bytes; see bench.py --only ragged and DESIGN.md 4.7
