@@ -48,6 +48,10 @@ __constant__ uint32_t c_q12[12] = BIGN192_Q_LIMBS;
 __constant__ uint32_t c_yG12[12] = BIGN192_YG_LIMBS;
 __constant__ uint32_t c_q16[16] = BIGN256_Q_LIMBS;
 __constant__ uint32_t c_yG16[16] = BIGN256_YG_LIMBS;
+__constant__ uint32_t c_b8[8] = BIGN128_B_LIMBS;
+__constant__ uint32_t c_b12[12] = BIGN192_B_LIMBS;
+__constant__ uint32_t c_b16[16] = BIGN256_B_LIMBS;
+template <int N> __device__ __forceinline__ const uint32_t *curve_b() { return N == 8 ? c_b8 : N == 12 ? c_b12 : c_b16; }
 template <int N> __device__ __forceinline__ const uint32_t *curve_q() { return N == 8 ? c_q8 : N == 12 ? c_q12 : c_q16; }
 template <int N> __device__ __forceinline__ const uint32_t *curve_yG() { return N == 8 ? c_yG8 : N == 12 ? c_yG12 : c_yG16; }
 
@@ -453,6 +457,36 @@ void bign_gtable16_kernel(const uint4 *__restrict__ gtab8, uint4 *__restrict__ g
     store_aff(e, x, y);
 }
 
+// -------------------------------------------------------------- pubkey val ---
+// bignPubkeyValEc (bign_misc.c:319-352): both coordinates < p (qrFrom) and the point on the curve,
+// ecpIsOnA (src/math/ecp/ecp_a.c:36-60): (x^2 + a) x + b == y^2 with a = p - 3 on all three
+// standard curves.  One lane per key; 8N octets in, one err_t out -- HBM-bound.
+template <int N>
+__global__ __launch_bounds__(256)
+void bign_pubkey_val_kernel(const uint8_t *__restrict__ pubkeys, size_t n, uint32_t *__restrict__ codes)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    constexpr int NO = 4 * N;
+    feT<N> x, y, t, b, three;
+    load_fe_bytes(x, pubkeys + 2 * NO * idx);
+    load_fe_bytes(y, pubkeys + 2 * NO * idx + NO);
+    uint32_t P[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { P[i] = 0xFFFFFFFFu; b.v[i] = curve_b<N>()[i]; three.v[i] = 0; }
+    P[0] = 0u - CurveC<N>::C;
+    three.v[0] = 3u;
+    bool ok = !limbs_ge(x.v, P) && !limbs_ge(y.v, P);
+    fe_sqr(t, x);
+    fe_sub(t, t, three);
+    fe_mul(t, t, x);
+    fe_add(t, t, b);
+    fe_sqr(y, y);
+    fe_sub(t, t, y);
+    ok = ok && fe_is_zero(t);
+    codes[idx] = ok ? ERR_OK : ERR_BAD_PUBKEY;
+}
+
 // --------------------------------------------------------- debug / self-test ---
 // element-wise field ops over arrays of N-limb values, used by tests/test_gpu_bign.py
 // to check the GF(p) layer against Python big integers.  op: 0 mul, 1 sqr, 2 add, 3 sub,
@@ -588,6 +622,19 @@ err_t launch_bign_verify(size_t l, const uint8_t *oid_der, size_t oid_len, const
     if (l == 192) return launch_bign_verify_t<12>(oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, st);
     if (l == 256) return launch_bign_verify_t<16>(oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, st);
     return ERR_BAD_PARAMS;
+}
+
+// pubkeys n*(l/2) octets (16-byte aligned), codes n err_t
+err_t launch_bign_pubkey_val(size_t l, const void *d_pubkeys, size_t n, void *d_codes, hipStream_t st)
+{
+    if (n == 0) return ERR_OK;
+    const dim3 g((unsigned)((n + 255) / 256)), t(256);
+    if (l == 128) hipLaunchKernelGGL(bign_pubkey_val_kernel<8>, g, t, 0, st, (const uint8_t *)d_pubkeys, n, (uint32_t *)d_codes);
+    else if (l == 192) hipLaunchKernelGGL(bign_pubkey_val_kernel<12>, g, t, 0, st, (const uint8_t *)d_pubkeys, n, (uint32_t *)d_codes);
+    else if (l == 256) hipLaunchKernelGGL(bign_pubkey_val_kernel<16>, g, t, 0, st, (const uint8_t *)d_pubkeys, n, (uint32_t *)d_codes);
+    else return ERR_BAD_PARAMS;
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
 }
 
 err_t launch_bign_debug_fe(size_t l, int op, const void *a, const void *b, void *out, size_t n, hipStream_t st)

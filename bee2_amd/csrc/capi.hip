@@ -547,6 +547,60 @@ extern "C" err_t bign256Verify(const octet hash[64], const octet sig[96], const 
     return level_verify(2, k_oid_bash512, hash, sig, pubkey);
 }
 
+// ---- public-key validation (bign_misc.c:319-365) ----
+extern "C" err_t bee2hip_bignPubkeyValL_batch_dev(size_t l, const void *d_pubkeys, size_t n, void *d_codes,
+                                                  void *stream)
+{
+    if (misaligned(d_pubkeys, 16) || misaligned(d_codes, 4)) return ERR_BAD_INPUT;
+    if (l != 128 && l != 192 && l != 256) return ERR_BAD_PARAMS;
+    if (n && (!d_pubkeys || !d_codes)) return ERR_BAD_INPUT;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    return launch_bign_pubkey_val(l, d_pubkeys, n, d_codes, as_stream(stream));
+}
+
+extern "C" err_t bee2hip_bignPubkeyVal_batch(const bign_params *params, const octet *pubkeys, size_t n,
+                                             err_t *codes)
+{
+    // bignPubkeyVal: params first (bign_misc.c:358-359), then the key
+    err_t code = params_check(params);
+    if (code != ERR_OK) return code;
+    if (n && (!pubkeys || !codes)) return ERR_BAD_INPUT;
+    if (n == 0) return ERR_OK;
+    code = ensure_device();
+    if (code != ERR_OK) return code;
+    const size_t pb = params->l / 2 * n, co = (pb + 15) & ~(size_t)15;
+    Scratch &s = t_scr[3];
+    code = s.need(co + n * 4);
+    if (code != ERR_OK) return code;
+    octet *d = (octet *)s.p;
+    B2H_TRY(hipMemcpy(d, pubkeys, pb, hipMemcpyHostToDevice));
+    code = launch_bign_pubkey_val(params->l, d, n, d + co, nullptr);
+    if (code != ERR_OK) return code;
+    B2H_TRY(hipMemcpy(codes, d + co, 4 * n, hipMemcpyDeviceToHost));
+    return ERR_OK;
+}
+
+extern "C" err_t bignPubkeyVal(const bign_params *params, const octet pubkey[])
+{
+    err_t one = ERR_BAD_PUBKEY;
+    if (!pubkey) {
+        const err_t pc = params_check(params);
+        return pc != ERR_OK ? pc : ERR_BAD_INPUT;
+    }
+    const err_t code = bee2hip_bignPubkeyVal_batch(params, pubkey, 1, &one);
+    return code != ERR_OK ? code : one;
+}
+static err_t level_pubkey_val(int which, const octet *pubkey)
+{
+    bign_params params;
+    bignParamsStd(&params, k_curves[which].name);
+    return bignPubkeyVal(&params, pubkey);
+}
+extern "C" err_t bign128PubkeyVal(const octet pubkey[64]) { return level_pubkey_val(0, pubkey); }
+extern "C" err_t bign192PubkeyVal(const octet pubkey[96]) { return level_pubkey_val(1, pubkey); }
+extern "C" err_t bign256PubkeyVal(const octet pubkey[128]) { return level_pubkey_val(2, pubkey); }
+
 extern "C" err_t bee2hip_debug_fe(int op, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream)
 {
     return launch_bign_debug_fe(128, op, d_a, d_b, d_out, n, as_stream(stream));

@@ -61,6 +61,7 @@ err_t launch_belt_hash_stream(void *d_hs, const void *d_data, size_t nblocks, in
                               uint64_t bits_hi, hipStream_t st);
 err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, const void *d_order, size_t n,
                          void *d_digests, hipStream_t st);
+err_t launch_bign_pubkey_val(size_t l, const void *d_pubkeys, size_t n, void *d_codes, hipStream_t st);
 err_t launch_bign_debug_fe(size_t l, int op, const void *a, const void *b, void *out, size_t n, hipStream_t st);
 
 }  // namespace bee2hip

@@ -65,6 +65,7 @@ DROPIN_SYMBOLS = [
     "beltMAC_keep", "beltMACStart", "beltMACStepA", "beltMACStepG", "beltMACStepG2",
     "beltMACStepV", "beltMACStepV2", "beltMAC",
     "bignParamsStd", "bignVerify", "bign128Verify", "bign192Verify", "bign256Verify",
+    "bignPubkeyVal", "bign128PubkeyVal", "bign192PubkeyVal", "bign256PubkeyVal",
 ]
 BATCH_SYMBOLS = [
     "bee2hip_bashF_batch", "bee2hip_beltCTR_bulk", "bee2hip_bignVerify_batch",
@@ -72,6 +73,7 @@ BATCH_SYMBOLS = [
     "bee2hip_bashF_batch_dev", "bee2hip_beltCTR_blocks_dev", "bee2hip_beltBlockEncr_dev",
     "bee2hip_beltModes_blocks_dev", "bee2hip_beltCBCEncr_batch_dev", "bee2hip_beltBDE_blocks_dev", "bee2hip_beltSDE_sectors_dev", "bee2hip_beltDWP_absorb_dev", "bee2hip_beltCHE_blocks_dev",
     "bee2hip_bign128Verify_batch_dev", "bee2hip_bignVerify_batch_dev", "bee2hip_bignVerifyL_batch_dev",
+    "bee2hip_bignPubkeyVal_batch", "bee2hip_bignPubkeyValL_batch_dev",
     "bee2hip_bashHash_beltMAC_batch_dev",
     "bee2hip_set_device", "bee2hip_sync", "bee2hip_last_error", "bee2hip_version",
     "bee2hip_time_kernel",
@@ -272,6 +274,12 @@ class Engine:
             _sz(l), bytes(oid_der), _sz(len(oid_der)), self._ptr(hashes), self._ptr(sigs), self._ptr(pubkeys),
             _sz(n), self._ptr(codes), self._stream()), "bignVerifyL_batch_dev")
 
+    def bignPubkeyValL_batch_dev(self, l, pubkeys, codes):
+        n = pubkeys.numel() // (l // 2)
+        assert codes.numel() >= n
+        self._check(self.lib.bee2hip_bignPubkeyValL_batch_dev(_sz(l), self._ptr(pubkeys), _sz(n), self._ptr(codes),
+                                                              self._stream()), "bignPubkeyValL_batch_dev")
+
     def bashHash_beltMAC_batch_dev(self, msgs, msg_len, l, key, digests, tags, n=None):
         if n is None:
             n = msgs.numel() // msg_len if msg_len else 0
@@ -312,6 +320,12 @@ class Engine:
         code = self.lib.bee2hip_bignVerify_batch(ctypes.byref(params), bytes(oid_der),
                                                  _sz(len(oid_der)), bytes(hashes), bytes(sigs),
                                                  bytes(pubkeys), _sz(n), codes)
+        return code, list(codes)[:n]
+
+    def bignPubkeyVal_batch(self, pubkeys, params):
+        n = len(pubkeys) // (params.l // 2)
+        codes = (_u32 * max(n, 1))()
+        code = self.lib.bee2hip_bignPubkeyVal_batch(ctypes.byref(params), bytes(pubkeys), _sz(n), codes)
         return code, list(codes)[:n]
 
     def bashHash_beltMAC_batch(self, msgs, msg_len, l, key, want_hash=True, want_mac=True, n=None):
@@ -481,6 +495,13 @@ class Engine:
 
     def bign128Verify(self, hash_, sig, pubkey):
         return self.lib.bign128Verify(bytes(hash_), bytes(sig), bytes(pubkey))
+
+    def bignPubkeyVal(self, params, pubkey):
+        return self.lib.bignPubkeyVal(ctypes.byref(params), bytes(pubkey))
+
+    def bignLPubkeyVal(self, l, pubkey):
+        """bign128PubkeyVal / bign192PubkeyVal / bign256PubkeyVal"""
+        return getattr(self.lib, f"bign{l}PubkeyVal")(bytes(pubkey))
 
     def bignLVerify(self, l, hash_, sig, pubkey):
         """bign128Verify / bign192Verify / bign256Verify"""

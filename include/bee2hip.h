@@ -225,6 +225,14 @@ err_t bign128Verify(const octet hash[32], const octet sig[48], const octet pubke
    include/bee2/crypto/bign192.h, bign256.h; src/crypto/bign/bign192.c:177-185, bign256.c:177-185 */
 err_t bign192Verify(const octet hash[48], const octet sig[72], const octet pubkey[96]);
 err_t bign256Verify(const octet hash[64], const octet sig[96], const octet pubkey[128]);
+/* public-key validation, the step `bee2cmd sig vfy` runs before each verification
+   (cmd/core/cmd_sig.c:463-478): bign.h:278-281, src/crypto/bign/bign_misc.c:319-365 (coordinates < p and
+   the point on the curve, src/math/ecp/ecp_a.c:36-60); bign128.h:87, bign192.h, bign256.h facades
+   (bign128.c:115-122).  ERR_OK or ERR_BAD_PUBKEY. */
+err_t bignPubkeyVal(const bign_params *params, const octet pubkey[]);
+err_t bign128PubkeyVal(const octet pubkey[64]);
+err_t bign192PubkeyVal(const octet pubkey[96]);
+err_t bign256PubkeyVal(const octet pubkey[128]);
 
 /* ======================================================================== *
  * (2) host-pointer batch API (new; SURVEY.md 8b "batch extension")
@@ -240,6 +248,9 @@ err_t bee2hip_beltCTR_bulk(void *buf, size_t count, void *ctr_state);
 err_t bee2hip_bignVerify_batch(const bign_params *params, const octet oid_der[], size_t oid_len,
                                const octet *hashes, const octet *sigs, const octet *pubkeys,
                                size_t n, err_t *codes);
+/* n public keys of params->l/2 octets each -> codes[n] = what bignPubkeyVal(params, key) returns */
+err_t bee2hip_bignPubkeyVal_batch(const bign_params *params, const octet *pubkeys, size_t n,
+                                  err_t *codes);
 /* n messages of msg_len bytes each (contiguous): bashHash(l) digest (l/4 bytes each,
    digests may be NULL) and beltMAC tag (8 bytes each, tags may be NULL) per message */
 err_t bee2hip_bashHash_beltMAC_batch(const octet *msgs, size_t msg_len, size_t n, size_t l,
@@ -321,6 +332,9 @@ err_t bee2hip_bignVerify_batch_dev(const octet oid_der[], size_t oid_len,
 err_t bee2hip_bignVerifyL_batch_dev(size_t l, const octet oid_der[], size_t oid_len,
                                     const void *d_hashes, const void *d_sigs,
                                     const void *d_pubkeys, size_t n, void *d_codes, void *stream);
+/* n public keys of l/2 octets, l in {128, 192, 256}; d_pubkeys 16-byte aligned, d_codes n x err_t */
+err_t bee2hip_bignPubkeyValL_batch_dev(size_t l, const void *d_pubkeys, size_t n, void *d_codes,
+                                       void *stream);
 err_t bee2hip_bashHash_beltMAC_batch_dev(const void *d_msgs, size_t msg_len, size_t n, size_t l,
                                          const octet key[], size_t key_len,
                                          void *d_digests, void *d_tags, void *stream);

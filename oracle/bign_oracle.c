@@ -62,6 +62,20 @@ static const uint8_t YG256[64] = {
     0xDA, 0xCA, 0xCC, 0x00, 0x1B, 0xF8, 0xED, 0xD2, 0xE2, 0xBC, 0x61, 0xB3, 0xB3, 0x41, 0xAB, 0xB0,
     0xAB, 0x8F, 0xD1, 0xA0, 0xF7, 0xE6, 0x82, 0xB1, 0x81, 0x76, 0x03, 0xE4, 0x7A, 0xFF, 0x26, 0xA8};
 
+/* curve coefficient b (a = p - 3 on all three curves), bign_params.c:43-56,87-104,142-165 */
+static const uint8_t B128[32] = {
+    0xF1, 0x03, 0x9C, 0xD6, 0x6B, 0x7D, 0x2E, 0xB2, 0x53, 0x92, 0x8B, 0x97, 0x69, 0x50, 0xF5, 0x4C,
+    0xBE, 0xFB, 0xD8, 0xE4, 0xAB, 0x3A, 0xC1, 0xD2, 0xED, 0xA8, 0xF3, 0x15, 0x15, 0x6C, 0xCE, 0x77};
+static const uint8_t B192[48] = {
+    0x64, 0xBF, 0x73, 0x68, 0x23, 0xFC, 0xA7, 0xBC, 0x7C, 0xBD, 0xCE, 0xF3, 0xF0, 0xE2, 0xBD, 0x14,
+    0x3A, 0x2E, 0x71, 0xE9, 0xF9, 0x6A, 0x21, 0xA6, 0x96, 0xB1, 0xFB, 0x0F, 0xBB, 0x48, 0x27, 0x71,
+    0xD2, 0x34, 0x5D, 0x65, 0xAB, 0x5A, 0x07, 0x33, 0x20, 0xEF, 0x9C, 0x95, 0xE1, 0xDF, 0x75, 0x3C};
+static const uint8_t B256[64] = {
+    0x90, 0x9C, 0x13, 0xD6, 0x98, 0x69, 0x34, 0x09, 0x7A, 0xA2, 0x49, 0x3A, 0x27, 0x22, 0x86, 0xEA,
+    0x43, 0xA2, 0xAC, 0x87, 0x8C, 0x00, 0x33, 0x29, 0x95, 0x5E, 0x24, 0xC4, 0xB5, 0xDC, 0x11, 0x27,
+    0x88, 0xB0, 0xAD, 0xDA, 0xE3, 0x13, 0xCE, 0x17, 0x51, 0x25, 0x5D, 0xDD, 0xEE, 0xA9, 0xC6, 0x5B,
+    0x89, 0x58, 0xFD, 0x60, 0x6A, 0x5D, 0x8C, 0xD8, 0x43, 0x8C, 0x3B, 0x93, 0x44, 0x59, 0xB4, 0x6C};
+
 /* DER of the pre-hash OIDs of the level-fixed facades: belt-hash, bash384, bash512 */
 static const uint8_t OID_BELT_HASH[11] = {0x06, 0x09, 0x2A, 0x70, 0x00, 0x02, 0x00, 0x22, 0x65, 0x1F, 0x51};
 static const uint8_t OID_BASH384[11] = {0x06, 0x09, 0x2A, 0x70, 0x00, 0x02, 0x00, 0x22, 0x65, 0x4D, 0x0C};
@@ -393,6 +407,34 @@ uint32_t orc_bignVerify_ex(size_t l, const uint8_t *oid_der, size_t oid_len, con
     if (rx_out) memcpy(rx_out, msg + oid_len, no);
     orc_beltHash(t, msg, oid_len + 2 * no);
     return memcmp(t, sig, no / 2) == 0 ? ORC_OK : ORC_BAD_SIG;
+}
+
+/* bignPubkeyVal: src/crypto/bign/bign_misc.c:319-365 -- both coordinates < p (qrFrom), then
+   ecpIsOnA, src/math/ecp/ecp_a.c:36-60: (x^2 + a) x + b == y^2 */
+uint32_t orc_bignPubkeyVal(size_t l, const uint8_t *pubkey)
+{
+    curve E;
+    fe x, y, t, a, b;
+    if (l != 128 && l != 192 && l != 256) return ORC_BAD_PARAMS;
+    curve_init(&E, (int)l);
+    const int n = E.n, no = (int)l / 4;
+    memset(&x, 0, sizeof x); memset(&y, 0, sizeof y); memset(&a, 0, sizeof a); memset(&b, 0, sizeof b);
+    words_from_le(x.v, pubkey, n);
+    words_from_le(y.v, pubkey + no, n);
+    if (words_cmp(x.v, E.p, n) >= 0 || words_cmp(y.v, E.p, n) >= 0) return ORC_BAD_PUBKEY;
+    memcpy(a.v, E.p, sizeof E.p);
+    a.v[0] -= 3;                                        /* a = p - 3, no borrow: p[0] = -c */
+    words_from_le(b.v, l == 128 ? B128 : l == 192 ? B192 : B256, n);
+    fe_sqr(&E, &t, &x);
+    fe_add(&E, &t, &t, &a);
+    fe_mul(&E, &t, &t, &x);
+    fe_add(&E, &t, &t, &b);
+    fe_sqr(&E, &y, &y);
+    return fe_eq(&E, &t, &y) ? ORC_OK : ORC_BAD_PUBKEY;
+}
+void orc_bignPubkeyVal_batch(size_t l, const uint8_t *pubkeys, size_t n, uint32_t *codes)
+{
+    for (size_t i = 0; i < n; ++i) codes[i] = orc_bignPubkeyVal(l, pubkeys + i * (l / 2));
 }
 
 uint32_t orc_bign128Verify_ex(const uint8_t hash[32], const uint8_t sig[48], const uint8_t pubkey[64], uint8_t rx[32])

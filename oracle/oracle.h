@@ -155,6 +155,9 @@ void orc_bign128Verify_batch(const uint8_t *hashes, const uint8_t *sigs,
    pubkey l/2 octets.  bignVerify: src/crypto/bign/bign_sign.c:349-361 */
 uint32_t orc_bignVerify_ex(size_t l, const uint8_t *oid_der, size_t oid_len, const uint8_t *hash,
                            const uint8_t *sig, const uint8_t *pubkey, uint8_t *rx);
+/* bignPubkeyVal (bign_misc.c:319-365): pubkey l/2 octets -> ORC_OK / ORC_BAD_PUBKEY */
+uint32_t orc_bignPubkeyVal(size_t l, const uint8_t *pubkey);
+void orc_bignPubkeyVal_batch(size_t l, const uint8_t *pubkeys, size_t n, uint32_t *codes);
 uint32_t orc_bign192Verify(const uint8_t hash[48], const uint8_t sig[72], const uint8_t pubkey[96]);
 uint32_t orc_bign256Verify(const uint8_t hash[64], const uint8_t sig[96], const uint8_t pubkey[128]);
 void orc_bignVerify_batch(size_t l, const uint8_t *oid_der, size_t oid_len, const uint8_t *hashes,

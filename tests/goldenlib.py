@@ -28,6 +28,8 @@ class Golden:
         self.H = bytes.fromhex(self.kat["beltH"])
         with open(os.path.join(GOLD, "bign_big_curves.json")) as f:
             self.bign_big = json.load(f)
+        with open(os.path.join(GOLD, "bign_pubkey_val.json")) as f:
+            self.bign_pubkey_val = json.load(f)
         with open(os.path.join(GOLD, "belt_bde_random.json")) as f:
             self.belt_bde = json.load(f)
         with open(os.path.join(GOLD, "belt_sde_random.json")) as f:

@@ -217,6 +217,16 @@ class Oracle:
                                       _sz(n), codes, ctypes.c_int(nthreads))
         return list(codes)[:n]
 
+    def pubkey_val(self, l, pub):
+        self.lib.orc_bignPubkeyVal.restype = ctypes.c_uint32
+        return self.lib.orc_bignPubkeyVal(_sz(l), bytes(pub))
+
+    def pubkey_val_batch(self, l, pubs):
+        n = len(pubs) // (l // 2)
+        codes = (ctypes.c_uint32 * max(n, 1))()
+        self.lib.orc_bignPubkeyVal_batch(_sz(l), bytes(pubs), _sz(n), codes)
+        return list(codes)[:n]
+
     def verify_batch(self, hashes, sigs, pubs, nthreads=1):
         n = len(hashes) // 32
         codes = (ctypes.c_uint32 * n)()

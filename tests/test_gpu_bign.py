@@ -288,3 +288,42 @@ def test_bign_big_curves_batch_and_dropin(orc, golden, l):
     code, host_codes = eng.bignVerify_batch(hs, ss, ps, oid_der=oid, params=params)
     assert code == 0 and host_codes == [c["code"] for c in cases]
     assert got == orc.verify_batch_l(l, oid, hs, ss, ps, nthreads=8)
+
+
+@pytest.mark.parametrize("l", [128, 192, 256])
+def test_bign_pubkey_val_batch_and_dropin(orc, golden, l):
+    """bignPubkeyVal (bign_misc.c:319-365), the step before each verification in `sig vfy` (cmd_sig.c:463-478)"""
+    eng = engine()
+    cases = golden.bign_pubkey_val[str(l)]
+    want = [c["code"] for c in cases]
+    ps = b"".join(bytes.fromhex(c["pubkey"]) for c in cases)
+    codes = torch.full((len(cases),), -1, dtype=torch.int32, device="cuda")
+    eng.bignPubkeyValL_batch_dev(l, dev(ps), codes)
+    torch.cuda.synchronize()
+    got = [int(c) & 0xFFFFFFFF for c in codes.cpu().numpy()]
+    bad = [(c["name"], g, c["code"]) for c, g in zip(cases, got) if g != c["code"]]
+    assert not bad, bad[:10]
+    assert set(got) == {0, 505}
+    params = eng.bignParamsStd(E.CURVE_NAME[l])
+    code, host = eng.bignPubkeyVal_batch(ps, params)
+    assert code == 0 and host == want
+    for c in cases[:4] + cases[92:110]:
+        pk = bytes.fromhex(c["pubkey"])
+        assert eng.bignLPubkeyVal(l, pk) == c["code"], c["name"]
+        assert eng.bignPubkeyVal(params, pk) == c["code"], c["name"]
+    # a larger seeded batch against the oracle: the golden keys tiled, every third one corrupted
+    rnd = random.Random(l)
+    big = bytearray(ps * 40)
+    n = len(big) // (l // 2)
+    for i in range(0, n, 3):
+        big[i * (l // 2) + rnd.randrange(l // 2)] ^= 1 << rnd.randrange(8)
+    codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    eng.bignPubkeyValL_batch_dev(l, dev(bytes(big)), codes)
+    torch.cuda.synchronize()
+    assert [int(c) & 0xFFFFFFFF for c in codes.cpu().numpy()] == orc.pubkey_val_batch(l, bytes(big))
+    # errors: wrong level, empty batch, bad parameters
+    assert eng.lib.bee2hip_bignPubkeyValL_batch_dev(E._sz(100), None, E._sz(0), None, None) == 502
+    assert eng.lib.bee2hip_bignPubkeyValL_batch_dev(E._sz(l), None, E._sz(0), None, None) == 0
+    bad_params = eng.bignParamsStd(E.CURVE_NAME[l])
+    bad_params.b[0] ^= 1
+    assert eng.bignPubkeyVal(bad_params, bytes.fromhex(cases[0]["pubkey"])) == 119    # not one of the three standard curves

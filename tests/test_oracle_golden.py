@@ -221,3 +221,14 @@ def test_bign_big_curves_oracle_vs_golden(orc, golden):
         for e in d["edge"]:
             got = orc.verify_l(l, LEVEL_OID[l], *(bytes.fromhex(e[x]) for x in ("hash", "sig", "pubkey")))
             assert got == e["code"], (l, e["name"])
+
+
+def test_bign_pubkey_val_oracle_vs_golden(orc, golden):
+    """bignPubkeyVal (bign_misc.c:319-365) on the reference-generated cases, all three curves"""
+    for l in (128, 192, 256):
+        cases = golden.bign_pubkey_val[str(l)]
+        bad = [(c["name"], c["code"]) for c in cases if orc.pubkey_val(l, bytes.fromhex(c["pubkey"])) != c["code"]]
+        assert not bad, (l, bad[:5])
+        pubs = b"".join(bytes.fromhex(c["pubkey"]) for c in cases)
+        assert orc.pubkey_val_batch(l, pubs) == [c["code"] for c in cases]
+    assert orc.pubkey_val(100, bytes(50)) == 502

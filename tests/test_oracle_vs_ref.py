@@ -111,6 +111,28 @@ def test_verify_big_curves_random_and_corrupted(orc):
         assert seen >= {0, 510}
 
 
+def test_pubkey_val_random_and_corrupted(orc):
+    rnd = random.Random(11)
+    L = refgen.ref()
+    for l in (128, 192, 256):
+        no = l // 4
+        fn = getattr(L, f"bign{l}PubkeyVal")
+        seen = set()
+        for i in range(300):
+            pub = bytearray(refgen.pubkey_calc_l(l, rnd.randbytes(no - 1) + b"\x00"))
+            kind = i % 4
+            if kind == 1:
+                pub[rnd.randrange(2 * no)] ^= 1 << rnd.randrange(8)
+            elif kind == 2:
+                pub[1:no] = b"\xff" * (no - 1)                    # x in [p - 255, 2^(8 no))
+            elif kind == 3:
+                pub = bytearray(rnd.randbytes(2 * no))
+            want = fn(bytes(pub))
+            assert orc.pubkey_val(l, pub) == want, (l, i, kind)
+            seen.add(want)
+        assert seen == {0, 505}
+
+
 def test_belt_bde_random(orc):
     """8f-1 belt-bde: one-shots of the reference on whole-block messages of every key size"""
     L = refgen.ref()

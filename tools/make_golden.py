@@ -527,6 +527,56 @@ def bign_big_curves(seed=0xB192):
     return out
 
 
+def pubkey_val_cases(seed=0x9B7A):
+    """bignPubkeyVal (bign_misc.c:319-365; bign128_test.c:112, bign_test.c:318): per level genuine keys,
+    their negatives, G, range violations, bit flips and random pairs, with the reference's return code."""
+    import random
+    out = {}
+    L = refgen.ref()
+    for l in (128, 192, 256):
+        rnd = random.Random(seed + l)
+        no = l // 4
+        p = 2 ** (8 * no) - {128: 189, 192: 317, 256: 569}[l]
+        prm = refparams(l)
+        q = int.from_bytes(bytes(prm.q)[:no], "little")
+        yG = bytes(prm.yG)[:no]
+        fn = getattr(L, f"bign{l}PubkeyVal")
+        cases = []
+
+        def add(name, pk):
+            assert len(pk) == 2 * no
+            cases.append({"name": name, "pubkey": pk.hex(), "code": fn(pk)})
+
+        keys = []
+        for d in [1, 2, 3, q - 1, q - 2, 2 ** l] + [rnd.randrange(1, q) for _ in range(40)]:
+            pub = refgen.pubkey_calc_l(l, int_le(d, no))
+            keys.append(pub)
+            add("valid", pub)
+            y = int.from_bytes(pub[no:], "little")
+            add("negated", pub[:no] + int_le((p - y) % p, no))
+        add("G", bytes(no) + yG)
+        add("-G", bytes(no) + int_le(p - int.from_bytes(yG, "little"), no))
+        add("(0,0)", bytes(2 * no))
+        add("(1,0)", int_le(1, no) + bytes(no))
+        k = keys[7]
+        add("x=p", int_le(p, no) + k[no:])
+        add("y=p", k[:no] + int_le(p, no))
+        add("x=p-1", int_le(p - 1, no) + k[no:])
+        add("x+p wraps", int_le((int.from_bytes(k[:no], "little") + p) % 2 ** (8 * no), no) + k[no:])
+        add("x=max", b"\xff" * no + k[no:])
+        add("y=max", k[:no] + b"\xff" * no)
+        add("G with y+p", bytes(no) + int_le((int.from_bytes(yG, "little") + p) % 2 ** (8 * no), no))
+        for i in range(64):
+            pk = bytearray(keys[i % len(keys)])
+            pk[rnd.randrange(2 * no)] ^= 1 << rnd.randrange(8)
+            add(f"flip{i}", bytes(pk))
+        for i in range(32):
+            add(f"random{i}", rnd.randbytes(2 * no))
+        assert cases[0]["code"] == 0 and {c["code"] for c in cases} == {0, 505}
+        out[str(l)] = cases
+    return out
+
+
 def refparams(l):
     class Params(ctypes.Structure):
         _fields_ = [("l", _sz), ("p", ctypes.c_ubyte * 64), ("a", ctypes.c_ubyte * 64), ("b", ctypes.c_ubyte * 64),
@@ -581,6 +631,8 @@ def main():
         from collections import Counter
         for l, d in big.items():
             print(f"bign l={l}: {len(d['base'])} base, edge codes {dict(Counter(e['code'] for e in d['edge']))}")
+    with open(os.path.join(GOLD, "bign_pubkey_val.json"), "w") as f:
+        json.dump(pubkey_val_cases(), f)
     with open(os.path.join(GOLD, "stb_kat.json"), "w") as f:
         json.dump(stb_kats(), f, indent=1)
     inp, out = bashf_random()
