@@ -38,7 +38,7 @@ from bee2_amd import shard  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BASHF_BYTES = 384                # algorithmic bytes per permutation (192 read + 192 written)
 CTR_BYTES_PER_BLOCK = 32         # 16 read + 16 written per 16-byte block
-MADS_PER_VERIFY = 1025 * 72 + 939 * 52 + 3000   # v_mad_u64_u32 per signature
+MADS_PER_VERIFY = 1019 * 72 + 717 * 52 + 3000   # v_mad_u64_u32 per signature, inversion shared by 8
 MAD_PEAK_T = 30.0                # measured: 256 CU x 4 SIMD x 64 lanes x 2.31 GHz / 5.05 cycles
 
 
@@ -396,7 +396,7 @@ def main():
             "config": {"workload": "bignVerify batch: 2^18 signatures per GPU on bign-curve256v1 (BASELINE configs[3]); "
                                    "2048 genuine triples tiled 128x, seeded 1/16 corrupted"},
             "roofline": {"kernels": "bign_prep+main+slow+tail", "bound": "valu-int", "avg_batch_ms": ms_launch,
-                         # 32x32+64 multiply-adds per verify: 1025 M x 72 + 939 S x 52 + scaled folds
+                         # 32x32+64 multiply-adds per verify: 1019 M x 72 + 717 S x 52 + scaled folds
                          "mads_per_verify": MADS_PER_VERIFY,
                          "achieved": MADS_PER_VERIFY * n / (ms_launch * 1e-3) / 1e12,
                          "peak": MAD_PEAK_T, "unit": "T v_mad_u64_u32 lane-ops/s",
@@ -439,7 +439,7 @@ def main():
         from bee2_amd.engine import LEVEL_OID
         for l in (192, 256):
             base = G.bign_big[str(l)]["base"]
-            reps_l = (1 << 16) // len(base)
+            reps_l = (1 << 18) // len(base)
             hs_l = b"".join(bytes.fromhex(t["hash"]) for t in base) * reps_l
             ss_l = b"".join(bytes.fromhex(t["sig"]) for t in base) * reps_l
             ps_l = b"".join(bytes.fromhex(t["pubkey"]) for t in base) * reps_l
@@ -451,7 +451,7 @@ def main():
             others[f"bignVerify_l{l}"] = {
                 "metric": f"bign-curve{2 * l}v1 verifies/s", "value": N * nl * kl / el, "unit": "verifies/s",
                 "steps": kl, "ms_per_step": el / kl * 1e3, "all_valid": bool((tc == 0).all()),
-                "config": {"workload": f"{nl} signatures per GPU on the {2 * l}-bit curve (SURVEY 8f-4), "
+                "config": {"workload": f"{nl} signatures per GPU on the {2 * l}-bit curve (SURVEY 8f-4; 2^18 as configs[3]: 2^16 leaves one wavefront per SIMD), "
                                        f"{len(base)} genuine triples tiled"}}
             if do_cpu:
                 import refgen

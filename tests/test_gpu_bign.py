@@ -327,3 +327,34 @@ def test_bign_pubkey_val_batch_and_dropin(orc, golden, l):
     bad_params = eng.bignParamsStd(E.CURVE_NAME[l])
     bad_params.b[0] ^= 1
     assert eng.bignPubkeyVal(bad_params, bytes.fromhex(cases[0]["pubkey"])) == 119    # not one of the three standard curves
+
+
+@pytest.mark.parametrize("l,n", [(128, 2 * 32768 + 37), (128, 9 * 32768 - 5), (192, 2 * 65536 + 37), (256, 2 * 65536 + 3)])
+def test_bign_shared_inversion_groups_with_mixed_statuses(golden, l, n):
+    """bign_inv_kernel shares one inversion between K signatures (K = n / 32768 resp. n / 65536, here 2 and 8).
+    Batches whose groups mix genuine signatures with every edge case of the reference-generated fixtures
+    (range errors that never reach the inversion, R = O, slow-path lanes, wrong signatures), sizes that
+    are not multiples of K: each code must be the reference's."""
+    eng = engine()
+    if l == 128:
+        hs, ss, ps = golden.bign_base_arrays()
+        cases = [(hs[32 * i:32 * i + 32], ss[48 * i:48 * i + 48], ps[64 * i:64 * i + 64], 0) for i in range(len(hs) // 32)]
+        cases += [(bytes.fromhex(e["hash"]), bytes.fromhex(e["sig"]), bytes.fromhex(e["pubkey"]), e["code"])
+                  for e in golden.bign_edge]
+    else:
+        d = golden.bign_big[str(l)]
+        cases = [(bytes.fromhex(t["hash"]), bytes.fromhex(t["sig"]), bytes.fromhex(t["pubkey"]), t.get("code", 0))
+                 for t in d["base"] + d["edge"] * 3]
+    rnd = random.Random(n)
+    pick = [rnd.randrange(len(cases)) for _ in range(n)]
+    H = b"".join(cases[i][0] for i in pick)
+    S = b"".join(cases[i][1] for i in pick)
+    P = b"".join(cases[i][2] for i in pick)
+    want = np.array([cases[i][3] for i in pick], dtype=np.int64)
+    codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    eng.bignVerifyL_batch_dev(l, E.LEVEL_OID[l], dev(H), dev(S), dev(P), codes)
+    torch.cuda.synchronize()
+    got = codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (l, n, bad[:5], got[bad[:5]], want[bad[:5]])
+    assert {0, 505, 510} <= set(int(x) for x in np.unique(got))
