@@ -394,9 +394,10 @@ void bign_tail_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
                       size_t n, VerifyScratch S, OidArg oid, uint32_t *__restrict__ codes)
 {
     constexpr int NO = 4 * N;
-    constexpr int STRIDE = OID_MAX + 2 * NO + 32;          // per-lane message area, zero padded
+    constexpr int DW = 2 * N;                              // words of <x_R> || H
+    constexpr int LSTR = DW + 1;                           // odd word stride: conflict-free per-lane rows
     __shared__ __attribute__((aligned(16))) uint8_t s_tab[BeltTabSmall::kBytes];
-    __shared__ __attribute__((aligned(16))) uint8_t s_msg[64 * STRIDE];
+    __shared__ uint32_t s_dat[64 * LSTR];
     BeltTabSmall::fill(s_tab, threadIdx.x, 64);
     __syncthreads();
     const BeltTabSmall T(s_tab);
@@ -406,16 +407,33 @@ void bign_tail_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
     const uint32_t st = S.status[idx];
     if (st != ST_PENDING) { codes[idx] = st; return; }
 
-    // message = oid_der || <x_R> || H  (bign_sign.c:339-342), staged per lane in LDS
-    uint8_t *m = s_msg + threadIdx.x * STRIDE;
-    const uint32_t L = oid.len + 2 * NO;
-    for (uint32_t i = 0; i < STRIDE; i += 4) *reinterpret_cast<uint32_t *>(m + i) = 0;
-    for (uint32_t i = 0; i < oid.len; ++i) m[i] = oid.der[i];
-    for (int l = 0; l < N; ++l) {
-        const uint32_t x = S.rx[(size_t)l * S.n_pad + idx];
-        for (int b = 0; b < 4; ++b) m[oid.len + 4 * l + b] = (uint8_t)(x >> (8 * b));
+    // message = oid_der || <x_R> || H  (bign_sign.c:339-342).  <x_R> || H sits in LDS as whole words, one
+    // row per lane; the OID is wavefront-uniform, so word k of the message is either an OID word or two
+    // neighbouring data words funnel-shifted by the OID length mod 4 -- no byte traffic.
+    uint32_t *d = s_dat + threadIdx.x * LSTR;
+#pragma unroll
+    for (int l = 0; l < N; ++l) d[l] = S.rx[(size_t)l * S.n_pad + idx];
+#pragma unroll
+    for (int k = 0; k < N / 4; ++k) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(hashes + NO * idx + 16 * k);
+        d[N + 4 * k] = a.x; d[N + 4 * k + 1] = a.y; d[N + 4 * k + 2] = a.z; d[N + 4 * k + 3] = a.w;
     }
-    for (int i = 0; i < NO; ++i) m[oid.len + NO + i] = hashes[NO * idx + i];
+    const uint32_t L = oid.len + 2 * NO;
+    const uint32_t q = oid.len >> 2, r8 = (oid.len & 3u) * 8u;
+    auto oid_word = [&](uint32_t k) -> uint32_t {          // bytes 4k .. 4k+3 of the OID, zero past its end
+        uint32_t w = 0;
+        for (uint32_t b = 0; b < 4; ++b)
+            if (4 * k + b < oid.len) w |= (uint32_t)oid.der[4 * k + b] << (8 * b);
+        return w;
+    };
+    const uint32_t oid_tail = r8 ? oid_word(q) << (32 - r8) : 0u;   // the OID's last 1..3 bytes, top-aligned
+    auto msg_word = [&](uint32_t k) -> uint32_t {
+        if (k < q) return oid_word(k);
+        const uint32_t t = k - q;
+        const uint32_t hi = t < (uint32_t)DW ? d[t] : 0u;
+        const uint32_t lo = t == 0 ? oid_tail : (t - 1 < (uint32_t)DW ? d[t - 1] : 0u);
+        return (uint32_t)((((uint64_t)hi << 32) | lo) >> (32 - r8));
+    };
 
     // belt-hash (src/crypto/belt/belt_hash.c:43-171)
     uint32_t h[8], s[4] = {0, 0, 0, 0}, X[8], s1[4];
@@ -427,7 +445,7 @@ void bign_tail_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
 #pragma unroll 1
     for (uint32_t b = 0; b < nblk; ++b) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) X[i] = *reinterpret_cast<const uint32_t *>(m + 32 * b + 4 * i);
+        for (int i = 0; i < 8; ++i) X[i] = msg_word(8 * b + i);
         belt_compress(T, s1, h, X);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i] ^= s1[i];

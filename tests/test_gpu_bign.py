@@ -358,3 +358,29 @@ def test_bign_shared_inversion_groups_with_mixed_statuses(golden, l, n):
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, (l, n, bad[:5], got[bad[:5]], want[bad[:5]])
     assert {0, 505, 510} <= set(int(x) for x in np.unique(got))
+
+
+def test_bign_oid_lengths_every_alignment(golden):
+    """The tail hashes oid || <x_R> || H with the OID's length shifting every later byte: genuine signatures
+    under OIDs of 3..128 DER octets (all alignments mod 4, up to the staging limit), the reference as signer.
+    Device batches per (curve, OID) and the generic drop-in."""
+    eng = engine()
+    groups = {}
+    for c in golden.bign_oid_lengths:
+        groups.setdefault((c["l"], c["oid"]), []).append(c)
+    assert len(groups) >= 90
+    for (l, oid_hex), cs in groups.items():
+        oid = bytes.fromhex(oid_hex)
+        cs = cs * 40                                        # several wavefronts
+        hs = b"".join(bytes.fromhex(c["hash"]) for c in cs)
+        ss = b"".join(bytes.fromhex(c["sig"]) for c in cs)
+        ps = b"".join(bytes.fromhex(c["pubkey"]) for c in cs)
+        codes = torch.full((len(cs),), -1, dtype=torch.int32, device="cuda")
+        eng.bignVerifyL_batch_dev(l, oid, dev(hs), dev(ss), dev(ps), codes)
+        torch.cuda.synchronize()
+        got = [int(x) & 0xFFFFFFFF for x in codes.cpu().numpy()]
+        assert got == [c["code"] for c in cs], (l, len(oid))
+    params = eng.bignParamsStd(E.CURVE_NAME[128])
+    for c in [c for c in golden.bign_oid_lengths if c["l"] == 128][:12]:
+        assert eng.bignVerify(params, bytes.fromhex(c["oid"]), bytes.fromhex(c["hash"]), bytes.fromhex(c["sig"]),
+                              bytes.fromhex(c["pubkey"])) == c["code"]

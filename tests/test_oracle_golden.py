@@ -232,3 +232,11 @@ def test_bign_pubkey_val_oracle_vs_golden(orc, golden):
         pubs = b"".join(bytes.fromhex(c["pubkey"]) for c in cases)
         assert orc.pubkey_val_batch(l, pubs) == [c["code"] for c in cases]
     assert orc.pubkey_val(100, bytes(50)) == 502
+
+
+def test_bign_oid_lengths_oracle_vs_golden(orc, golden):
+    """genuine signatures under OIDs of 3..128 DER octets (reference as signer), all three curves"""
+    for c in golden.bign_oid_lengths:
+        got = orc.verify_l(c["l"], bytes.fromhex(c["oid"]), bytes.fromhex(c["hash"]), bytes.fromhex(c["sig"]),
+                           bytes.fromhex(c["pubkey"]))
+        assert got == c["code"], (c["l"], len(c["oid"]) // 2)

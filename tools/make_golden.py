@@ -577,6 +577,43 @@ def pubkey_val_cases(seed=0x9B7A):
     return out
 
 
+def oid_len_cases(seed=0x01DA):
+    """Genuine signatures under pre-hash OIDs of many DER lengths (every alignment mod 4, up to 128 octets,
+    the kernel's staging limit): bignSign2 / bignVerify of the reference with an explicit oid_der
+    (bign_sign.c:140-245, 349-361).  The message hashed at the end is oid || <x_R> || H, so the OID length
+    moves every later byte."""
+    import random
+    L = refgen.ref()
+    out = []
+    rnd = random.Random(seed)
+
+    def der(body_len):
+        body = bytes([0x2A]) + bytes(rnd.randrange(1, 128) for _ in range(body_len - 1))
+        return bytes([0x06, body_len]) + body if body_len < 128 else bytes([0x06, 0x81, body_len]) + body
+
+    for l in (128, 192, 256):
+        prm = refparams(l)
+        no = l // 4
+        for body_len in list(range(1, 24)) + [37, 62, 63, 64, 65, 100, 124, 125, 126]:
+            oid = der(body_len)
+            if len(oid) > 128:
+                continue
+            priv = int_le(rnd.randrange(1, 2 ** (l - 1)), no)
+            pub = refgen.pubkey_calc_l(l, priv)
+            h = rnd.randbytes(no)
+            sig = ctypes.create_string_buffer(no + no // 2)
+            assert L.bignSign2(sig, ctypes.byref(prm), oid, _sz(len(oid)), h, priv, None, _sz(0)) == 0
+            for kind in ("valid", "flip"):
+                sg = bytearray(sig.raw)
+                if kind == "flip":
+                    sg[rnd.randrange(len(sg))] ^= 1 << rnd.randrange(8)
+                code = L.bignVerify(ctypes.byref(prm), oid, _sz(len(oid)), h, bytes(sg), pub)
+                assert code == (0 if kind == "valid" else 510)
+                out.append({"l": l, "oid": oid.hex(), "hash": h.hex(), "sig": bytes(sg).hex(), "pubkey": pub.hex(),
+                            "code": code})
+    return out
+
+
 def refparams(l):
     class Params(ctypes.Structure):
         _fields_ = [("l", _sz), ("p", ctypes.c_ubyte * 64), ("a", ctypes.c_ubyte * 64), ("b", ctypes.c_ubyte * 64),
@@ -633,6 +670,8 @@ def main():
             print(f"bign l={l}: {len(d['base'])} base, edge codes {dict(Counter(e['code'] for e in d['edge']))}")
     with open(os.path.join(GOLD, "bign_pubkey_val.json"), "w") as f:
         json.dump(pubkey_val_cases(), f)
+    with open(os.path.join(GOLD, "bign_oid_lengths.json"), "w") as f:
+        json.dump(oid_len_cases(), f)
     with open(os.path.join(GOLD, "stb_kat.json"), "w") as f:
         json.dump(stb_kats(), f, indent=1)
     inp, out = bashf_random()
