@@ -332,6 +332,160 @@ __device__ __noinline__ feT<N> fe_inv(feT<N> x)
     return r;
 }
 
+// ------------------------------------------------- inversion by division steps ---
+// a^-1 mod p with the Bernstein-Yang "safegcd" recurrence (half-delta variant) instead of a^(p-2): about
+// 2.3 * 32N division steps of a dozen full-rate VALU ops each, applied to the full-width numbers in batches
+// of 30 through a 2x2 transition matrix -- ~11 k instructions on the 256-bit curve against ~62 k for the
+// Fermat chain (268 dependent field multiplications).  Numbers are L signed limbs of 30 bits
+// (f, g in (-p, p); d, e in (-2p, p)).  Branch-free inside an iteration; the loop ends when g = 0 in every
+// lane of the wavefront (further steps leave f and d untouched).  bee2 itself inverts by a^(p-2)
+// (gfpInv, gfp.c:33-44): the result is the same canonical residue either way, and fe_inv_checked below
+// verifies a * r = 1 and falls back to the Fermat chain otherwise.
+template <int N> struct SafeGcd {
+    static constexpr int L = (32 * N + 2 + 29) / 30;           // 9, 13, 18
+    static constexpr int FULL = 32 * N / 30, REM = 32 * N % 30; // p = 2^(30 FULL + REM) - c
+    static_assert(REM != 0 && L == FULL + 1, "limb layout of p");
+    static constexpr int32_t M30 = 0x3FFFFFFF;
+    static constexpr int32_t mod_limb(int i)
+    {
+        return i == 0 ? (int32_t)((1u << 30) - CurveC<N>::C) : i < FULL ? M30 : (int32_t)((1u << REM) - 1u);
+    }
+    static constexpr uint32_t inv30()                           // p^-1 mod 2^30 (Newton iteration mod 2^32)
+    {
+        const uint32_t a = 0u - CurveC<N>::C;                   // p mod 2^32
+        uint32_t x = 1;
+        for (int i = 0; i < 6; ++i) x *= 2u - a * x;
+        return x & 0x3FFFFFFFu;
+    }
+    static constexpr int MAX_ITER = (32 * N * 24 / 10 + 60) / 30;   // generous; the g == 0 test ends the loop
+};
+
+// 30 division steps on the low limbs; returns the new zeta = -(delta + 1/2), matrix t = (u v; q r) with
+// 2^30 (f', g') = t (f, g).  Entries are signed, |.| <= 2^30, carried as uint32 mod 2^32.
+__device__ __forceinline__ int32_t sg_divsteps_30(int32_t zeta, uint32_t f, uint32_t g, uint32_t &u, uint32_t &v,
+                                                  uint32_t &q, uint32_t &r)
+{
+    u = 1; v = 0; q = 0; r = 1;
+#pragma unroll 1
+    for (int i = 0; i < 30; ++i) {
+        uint32_t m1 = (uint32_t)(zeta >> 31);                   // delta > 0
+        const uint32_t m2 = 0u - (g & 1u);                      // g odd
+        const uint32_t x = (f ^ m1) - m1, y = (u ^ m1) - m1, z = (v ^ m1) - m1;
+        g += x & m2; q += y & m2; r += z & m2;
+        m1 &= m2;                                               // swap step
+        zeta = (int32_t)((uint32_t)zeta ^ m1) - 1;
+        f += g & m1; u += q & m1; v += r & m1;
+        g >>= 1; u <<= 1; v <<= 1;
+    }
+    return zeta;
+}
+
+// a^-1 mod p for canonical a (0 -> 0); no fallback
+template <int N>
+__device__ __noinline__ feT<N> fe_inv_safegcd(feT<N> a)
+{
+    using SG = SafeGcd<N>;
+    constexpr int L = SG::L;
+    constexpr int32_t M30 = SG::M30;
+    int32_t d[L], e[L], f[L], g[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const int bit = 30 * i, w = bit >> 5, sh = bit & 31;
+        uint32_t lo = w < N ? a.v[w] : 0u, hi = w + 1 < N ? a.v[w + 1] : 0u;
+        g[i] = (int32_t)((uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & (uint32_t)M30);
+        f[i] = SG::mod_limb(i);
+        d[i] = 0; e[i] = i == 0 ? 1 : 0;
+    }
+    int32_t zeta = -1;
+#pragma unroll 1
+    for (int it = 0; it < SG::MAX_ITER; ++it) {
+        int32_t nz = 0;
+#pragma unroll
+        for (int i = 0; i < L; ++i) nz |= g[i];
+        if (!__any(nz != 0)) break;
+        uint32_t uu, vv, qq, rr;
+        zeta = sg_divsteps_30(zeta, (uint32_t)f[0], (uint32_t)g[0], uu, vv, qq, rr);
+        const int32_t u = (int32_t)uu, v = (int32_t)vv, q = (int32_t)qq, r = (int32_t)rr;
+        // (d, e) <- t (d, e) / 2^30 mod p: multiples md, me of p make the low 30 bits vanish
+        {
+            const int32_t sd = d[L - 1] >> 31, se = e[L - 1] >> 31;
+            int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+            int64_t cd = (int64_t)u * d[0] + (int64_t)v * e[0];
+            int64_t ce = (int64_t)q * d[0] + (int64_t)r * e[0];
+            md -= (int32_t)((SG::inv30() * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
+            me -= (int32_t)((SG::inv30() * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
+            cd += (int64_t)SG::mod_limb(0) * md;
+            ce += (int64_t)SG::mod_limb(0) * me;
+            cd >>= 30; ce >>= 30;
+#pragma unroll
+            for (int i = 1; i < L; ++i) {
+                cd += (int64_t)u * d[i] + (int64_t)v * e[i] + (int64_t)SG::mod_limb(i) * md;
+                ce += (int64_t)q * d[i] + (int64_t)r * e[i] + (int64_t)SG::mod_limb(i) * me;
+                d[i - 1] = (int32_t)cd & M30; cd >>= 30;
+                e[i - 1] = (int32_t)ce & M30; ce >>= 30;
+            }
+            d[L - 1] = (int32_t)cd; e[L - 1] = (int32_t)ce;
+        }
+        // (f, g) <- t (f, g) / 2^30 (exact)
+        {
+            int64_t cf = (int64_t)u * f[0] + (int64_t)v * g[0];
+            int64_t cg = (int64_t)q * f[0] + (int64_t)r * g[0];
+            cf >>= 30; cg >>= 30;
+#pragma unroll
+            for (int i = 1; i < L; ++i) {
+                cf += (int64_t)u * f[i] + (int64_t)v * g[i];
+                cg += (int64_t)q * f[i] + (int64_t)r * g[i];
+                f[i - 1] = (int32_t)cf & M30; cf >>= 30;
+                g[i - 1] = (int32_t)cg & M30; cg >>= 30;
+            }
+            f[L - 1] = (int32_t)cf; g[L - 1] = (int32_t)cg;
+        }
+    }
+    // f = +-1 and d = +-a^-1 with the same sign: bring d from (-2p, p) to [0, p)
+    {
+        int32_t ca = d[L - 1] >> 31;
+#pragma unroll
+        for (int i = 0; i < L; ++i) d[i] += SG::mod_limb(i) & ca;
+        const int32_t cn = f[L - 1] >> 31;
+#pragma unroll
+        for (int i = 0; i < L; ++i) d[i] = (d[i] ^ cn) - cn;
+#pragma unroll
+        for (int i = 0; i < L - 1; ++i) { d[i + 1] += d[i] >> 30; d[i] &= M30; }
+        ca = d[L - 1] >> 31;
+#pragma unroll
+        for (int i = 0; i < L; ++i) d[i] += SG::mod_limb(i) & ca;
+#pragma unroll
+        for (int i = 0; i < L - 1; ++i) { d[i + 1] += d[i] >> 30; d[i] &= M30; }
+    }
+    feT<N> out;
+#pragma unroll
+    for (int w = 0; w < N; ++w) {                               // 32-bit word w = bits [32w, 32w+32)
+        const int lo = 32 * w / 30, sh = 32 * w % 30;           // starts in limb lo at bit sh
+        uint64_t acc = (uint64_t)(uint32_t)d[lo] >> sh;
+        if (lo + 1 < L) acc |= (uint64_t)(uint32_t)d[lo + 1] << (30 - sh);
+        if (lo + 2 < L && 60 - sh < 32) acc |= (uint64_t)(uint32_t)d[lo + 2] << (60 - sh);
+        out.v[w] = (uint32_t)acc;
+    }
+    return out;
+}
+
+// the inversion the kernels call: division steps, verified, Fermat chain if the check ever fails
+template <int N>
+__device__ __forceinline__ feT<N> fe_inv_checked(const feT<N> &x)
+{
+    feT<N> a, r, t, one;
+    fe_canon(a, x);
+    r = fe_inv_safegcd(a);
+    fe_mul(t, a, r);
+    fe_canon(t, t);
+    fe_set_one(one);
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) ok = ok && (t.v[i] == one.v[i]);
+    if (!ok) r = fe_inv(a);                                     // also the a = 0 case: 0^(p-2) = 0
+    return r;
+}
+
 // ----------------------------------------------------------------- points ---
 // T <- 2T, a = -3.  4M + 4S + 6 add/sub.  Z3 = 2YZ, so Y = 0 or Z = 0 gives O as in
 // ecp_j.c:258-263.  (dbl-2001-b with the small multiples moved into the reductions.)

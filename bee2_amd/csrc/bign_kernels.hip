@@ -364,7 +364,7 @@ void bign_inv_kernel(size_t n, size_t lanes, int K, VerifyScratch S)
         }
         store_soa(PZ, S.n_pad, idx, acc);             // product of the pending Z up to and including t
     }
-    feT<N> inv = fe_inv(acc);
+    feT<N> inv = fe_inv_checked(acc);
 #pragma unroll 1
     for (int t = K - 1; t >= 0; --t) {
         const size_t idx = (size_t)t * lanes + j;
@@ -568,6 +568,8 @@ __global__ void bign_debug_fe_kernel(int op, const uint32_t *a, const uint32_t *
     case 2: fe_add(r, x, y); break;
     case 3: fe_sub(r, x, y); break;
     case 4: r = fe_inv(x); break;
+    case 11: fe_canon(x, x); r = fe_inv_safegcd(x); break;      // division steps alone, no fallback
+    case 12: r = fe_inv_checked(x); break;
     case 5: fe_mul<3>(r, x, y); break;
     case 6: fe_sqr<8>(r, x); break;
     case 7: r = x; break;

@@ -38,7 +38,11 @@ def test_field_ops_vs_python_ints():
     B = [b for b in special for _ in special] + [rnd.choice(pool) for _ in range(4096)]
     ops = {0: lambda a, b: a * b % P, 1: lambda a, b: a * a % P, 2: lambda a, b: (a + b) % P,
            3: lambda a, b: (a - b) % P, 4: lambda a, b: pow(a, P - 2, P), 5: lambda a, b: 3 * a * b % P,
-           6: lambda a, b: 8 * a * a % P, 7: lambda a, b: a % P}
+           6: lambda a, b: 8 * a * a % P, 7: lambda a, b: a % P,
+           # 11: inversion by division steps alone, 12: the checked inversion the kernels call
+           11: lambda a, b: pow(a, P - 2, P), 12: lambda a, b: pow(a, P - 2, P)}
+    A += [2 ** k for k in range(256)] + [P - 2 ** k for k in range(255)] + [2 ** k - 1 for k in range(1, 256)]
+    B += [0] * (len(A) - len(B))
     for op, f in ops.items():
         got = _fe_run(eng, op, A, B)
         want = [f(a, b) for a, b in zip(A, B)]
@@ -201,12 +205,15 @@ def test_field_ops_big_curves(l):
     pool = special + [rnd.getrandbits(2 * l) for _ in range(100)]
     A = special * len(special) + [rnd.choice(pool) for _ in range(1024)]
     B = [b for b in special for _ in special] + [rnd.choice(pool) for _ in range(1024)]
+    A += [2 ** k for k in range(2 * l)] + [P - 2 ** k for k in range(2 * l - 1)] + [2 ** k - 1 for k in range(1, 2 * l)]
+    B += [0] * (len(A) - len(B))
     ta = dev(b"".join(x.to_bytes(nb, "little") for x in A))
     tb = dev(b"".join(x.to_bytes(nb, "little") for x in B))
     out = torch.empty_like(ta)
     ops = {0: lambda a, b: a * b % P, 1: lambda a, b: a * a % P, 2: lambda a, b: (a + b) % P,
            3: lambda a, b: (a - b) % P, 4: lambda a, b: pow(a, P - 2, P), 5: lambda a, b: 3 * a * b % P,
-           6: lambda a, b: 8 * a * a % P, 7: lambda a, b: a % P}
+           6: lambda a, b: 8 * a * a % P, 7: lambda a, b: a % P,
+           11: lambda a, b: pow(a, P - 2, P), 12: lambda a, b: pow(a, P - 2, P)}
     for op, f in ops.items():
         code = eng.lib.bee2hip_debug_feL(ctypes.c_size_t(l), op, ctypes.c_void_p(ta.data_ptr()),
                                          ctypes.c_void_p(tb.data_ptr()), ctypes.c_void_p(out.data_ptr()),
