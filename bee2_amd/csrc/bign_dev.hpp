@@ -482,7 +482,7 @@ __device__ __forceinline__ feT<N> fe_inv_checked(const feT<N> &x)
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < N; ++i) ok = ok && (t.v[i] == one.v[i]);
-    if (!ok) r = fe_inv(a);                                     // also the a = 0 case: 0^(p-2) = 0
+    if (!ok && !fe_is_zero(a)) r = fe_inv(a);                   // a = 0 gives 0 either way, as 0^(p-2)
     return r;
 }
 

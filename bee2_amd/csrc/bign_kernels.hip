@@ -64,7 +64,8 @@ struct VerifyScratch {          // all arrays are [..][n_pad] (signature index f
     uint32_t *status;           // [n_pad]
     uint32_t *u;                // [N][n_pad]      scalar of G; after main / slow: Z of R
     uint32_t *w;                // [N/2+1][n_pad]  v + 0x888..8 (4N+1 nibbles): digit_i = nib_i - 8
-    uint32_t *qtab;             // [8][3N][n_pad]  Jacobian 1Q..8Q
+    uint32_t *qtab;             // [8][2N][n_pad]  1Q..8Q, affine once bign_prep_kernel is through
+    uint32_t *qz;               // [13][N][n_pad]  prep: Z of 2Q..8Q and their running products; inv: prefixes
     uint32_t *rx;               // [N][n_pad]      X of R, then (bign_inv_kernel) canonical x_R
     size_t n_pad;
 };
@@ -101,20 +102,18 @@ __device__ __forceinline__ void load_soa(feT<N> &a, const uint32_t *base, size_t
     for (int l = 0; l < N; ++l) a.v[l] = base[(size_t)l * n_pad + idx];
 }
 template <int N>
-__device__ __forceinline__ void store_jac(const VerifyScratch &S, int e, size_t idx, const jacT<N> &P)
+__device__ __forceinline__ void store_qxy(const VerifyScratch &S, int e, size_t idx, const feT<N> &x, const feT<N> &y)
 {
-    uint32_t *b = S.qtab + (size_t)e * 3 * N * S.n_pad;
-    store_soa(b, S.n_pad, idx, P.X);
-    store_soa(b + (size_t)N * S.n_pad, S.n_pad, idx, P.Y);
-    store_soa(b + (size_t)2 * N * S.n_pad, S.n_pad, idx, P.Z);
+    uint32_t *b = S.qtab + (size_t)e * 2 * N * S.n_pad;
+    store_soa(b, S.n_pad, idx, x);
+    store_soa(b + (size_t)N * S.n_pad, S.n_pad, idx, y);
 }
 template <int N>
-__device__ __forceinline__ void load_jac(jacT<N> &P, const VerifyScratch &S, int e, size_t idx)
+__device__ __forceinline__ void load_qaff(affT<N> &P, const VerifyScratch &S, int e, size_t idx)
 {
-    const uint32_t *b = S.qtab + (size_t)e * 3 * N * S.n_pad;
-    load_soa(P.X, b, S.n_pad, idx);
-    load_soa(P.Y, b + (size_t)N * S.n_pad, S.n_pad, idx);
-    load_soa(P.Z, b + (size_t)2 * N * S.n_pad, S.n_pad, idx);
+    const uint32_t *b = S.qtab + (size_t)e * 2 * N * S.n_pad;
+    load_soa(P.x, b, S.n_pad, idx);
+    load_soa(P.y, b + (size_t)N * S.n_pad, S.n_pad, idx);
 }
 template <int N>
 __device__ __forceinline__ void load_aff(affT<N> &E, const uint4 *e)
@@ -216,27 +215,66 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
             c >>= 32;
         }
     }
-    // table 1Q..8Q (Jacobian).  Any exceptional case -> slow path.
+    // table 1Q..8Q, made AFFINE so that the main loop adds with the mixed formula (8M + 3S instead of
+    // 12M + 4S, 31 times per signature): the seven Jacobian points 2Q..8Q are normalised with one shared
+    // inversion (Montgomery's trick over their Z, inversion by division steps) -- 39 M + 7 S + one
+    // inversion (~35 M) spent here, 124 M + 31 S saved in bign_main_kernel.  Any exceptional case -> slow path.
     bool ok = true;
-    jacT<N> P1, P2, P3, P4, T;
-    P1.X = Q.x; P1.Y = Q.y; fe_set_one(P1.Z);
-    store_jac(S, 0, idx, P1);
-    P2 = P1; jac_dbl(P2);                 store_jac(S, 1, idx, P2);
-    P3 = P2; ok &= jac_madd(P3, Q);       store_jac(S, 2, idx, P3);
-    P4 = P2; jac_dbl(P4);                 store_jac(S, 3, idx, P4);
-    T = P4;  ok &= jac_madd(T, Q);        store_jac(S, 4, idx, T);      // 5Q
-    T = P3;  jac_dbl(T);                  store_jac(S, 5, idx, T);      // 6Q
-    ok &= !fe_is_zero(T.Z);
-    ok &= jac_madd(T, Q);                 store_jac(S, 6, idx, T);      // 7Q
-    ok &= !fe_is_zero(T.Z);
-    T = P4;  jac_dbl(T);                  store_jac(S, 7, idx, T);      // 8Q
-    ok &= !fe_is_zero(T.Z) && !fe_is_zero(P2.Z) && !fe_is_zero(P3.Z) && !fe_is_zero(P4.Z);
+    const auto put = [&](int e, const jacT<N> &P) {      // entry e = (e+1) Q: X, Y in place, Z aside
+        store_qxy(S, e, idx, P.X, P.Y);
+        store_soa(S.qz + (size_t)(e - 1) * N * S.n_pad, S.n_pad, idx, P.Z);
+        ok &= !fe_is_zero(P.Z);
+    };
+    jacT<N> P2, P3, P4, T;
+    store_qxy(S, 0, idx, Q.x, Q.y);
+    P2.X = Q.x; P2.Y = Q.y; fe_set_one(P2.Z);
+    jac_dbl(P2);                          put(1, P2);
+    P3 = P2; ok &= jac_madd(P3, Q);       put(2, P3);
+    P4 = P2; jac_dbl(P4);                 put(3, P4);
+    T = P4;  ok &= jac_madd(T, Q);        put(4, T);      // 5Q
+    T = P3;  jac_dbl(T);                  put(5, T);      // 6Q
+    ok &= jac_madd(T, Q);                 put(6, T);      // 7Q
+    T = P4;  jac_dbl(T);                  put(7, T);      // 8Q
+    {
+        // c_k = Z_0 ... Z_k (Z_k = Z of (k+2) Q); c_0..c_5 parked behind the Z, c_6 inverted
+        uint32_t *Zs = S.qz, *Cs = S.qz + (size_t)7 * N * S.n_pad;
+        feT<N> acc, z, zi, zi2, v;
+        load_soa(acc, Zs, S.n_pad, idx);
+#pragma unroll 1
+        for (int k = 1; k < 7; ++k) {
+            store_soa(Cs + (size_t)(k - 1) * N * S.n_pad, S.n_pad, idx, acc);
+            load_soa(z, Zs + (size_t)k * N * S.n_pad, S.n_pad, idx);
+            fe_mul(acc, acc, z);
+        }
+        feT<N> inv = fe_inv_checked(acc);                 // product 0 (flagged above) gives 0: harmless
+#pragma unroll 1
+        for (int k = 6; k >= 0; --k) {
+            zi = inv;
+            if (k > 0) {
+                load_soa(v, Cs + (size_t)(k - 1) * N * S.n_pad, S.n_pad, idx);
+                fe_mul(zi, inv, v);                       // 1 / Z_k
+                load_soa(z, Zs + (size_t)k * N * S.n_pad, S.n_pad, idx);
+                fe_mul(inv, inv, z);                      // 1 / c_{k-1}
+            }
+            uint32_t *b = S.qtab + (size_t)(k + 1) * 2 * N * S.n_pad;
+            fe_sqr(zi2, zi);
+            load_soa(v, b, S.n_pad, idx);
+            fe_mul(v, v, zi2);
+            store_soa(b, S.n_pad, idx, v);                // x = X / Z^2
+            fe_mul(zi2, zi2, zi);
+            load_soa(v, b + (size_t)N * S.n_pad, S.n_pad, idx);
+            fe_mul(v, v, zi2);
+            store_soa(b + (size_t)N * S.n_pad, S.n_pad, idx, v);   // y = Y / Z^3
+        }
+    }
     S.status[idx] = ok ? ST_PENDING : ST_SLOW;
 }
 
 // --------------------------------------------------------------------- main ---
+// (second bound: wavefronts per SIMD the register allocation must leave room for -- the 256-bit kernel sits
+// a few registers above the 128 that four wavefronts allow unless told so)
 template <int N>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, (N == 8 ? 4 : 1))
 void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -252,7 +290,11 @@ void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
 
     // top digit d_{4N} = nibble_{4N}(w) - 8 is 1 or 2
     jacT<N> T;
-    load_jac(T, S, (int)(w[NW - 1] & 15u) - 9, idx);
+    {
+        affT<N> E;
+        load_qaff(E, S, (int)(w[NW - 1] & 15u) - 9, idx);
+        T.X = E.x; T.Y = E.y; fe_set_one(T.Z);
+    }
 
 #pragma unroll 1
     for (int i = 4 * N - 1; i >= 0; --i) {
@@ -263,10 +305,10 @@ void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
         for (int l = NW - 2; l > 0; --l) w[l] = (w[l] << 4) | (w[l - 1] >> 28);
         w[0] <<= 4;
         if (d != 0) {
-            jacT<N> E;
-            load_jac(E, S, (d < 0 ? -d : d) - 1, idx);
-            if (d < 0) fe_neg(E.Y, E.Y);
-            ok &= jac_add(T, E);
+            affT<N> E;
+            load_qaff(E, S, (d < 0 ? -d : d) - 1, idx);
+            if (d < 0) fe_neg(E.y, E.y);
+            ok &= jac_madd(T, E);
         }
     }
     // + u G : comb over the W-bit windows of u (mixed additions only)
@@ -341,7 +383,7 @@ void bign_slow_kernel(const uint8_t *__restrict__ sigs, const uint8_t *__restric
 // ---------------------------------------------------------------- inversion ---
 // x_R = X / Z^2 for all pending signatures with Montgomery's simultaneous inversion: lane j owns the K
 // signatures j, j + lanes, j + 2 lanes, ... (coalesced in the limb-major scratch), multiplies their Z
-// (prefix products parked in the dead qtab rows), inverts the product once (255 S + 13 M on the
+// (prefix products parked in the dead qz rows), inverts the product once (255 S + 13 M on the
 // 256-bit curve, as much as 1/7 of a whole verification when done per signature) and peels the
 // individual inverses off with two multiplications each.  Z != 0 for every pending lane (main / slow
 // send R = O elsewhere), so the product is invertible.  Same x_R as ecpToAJ: the canonical residue.
@@ -351,7 +393,7 @@ void bign_inv_kernel(size_t n, size_t lanes, int K, VerifyScratch S)
 {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= lanes) return;
-    uint32_t *Z = S.u, *PZ = S.qtab;
+    uint32_t *Z = S.u, *PZ = S.qz;
     feT<N> acc, z;
     fe_set_one(acc);
 #pragma unroll 1
@@ -632,7 +674,7 @@ template <int N>
 static err_t bign_scratch(hipStream_t st, size_t n, VerifyScratch &S)
 {
     const size_t n_pad = (n + 63) & ~(size_t)63;
-    const size_t words = n_pad * (1 + N + (N / 2 + 1) + 8 * 3 * N + N);
+    const size_t words = n_pad * (1 + N + (N / 2 + 1) + 8 * 2 * N + 13 * N + N);
     void *base = nullptr;
     err_t code = scratch_for_stream(st, N / 4 - 2 + 4, words * 4, &base);
     if (code != ERR_OK) return code;
@@ -641,7 +683,8 @@ static err_t bign_scratch(hipStream_t st, size_t n, VerifyScratch &S)
     S.status = p; p += n_pad;
     S.u = p; p += (size_t)N * n_pad;
     S.w = p; p += (size_t)(N / 2 + 1) * n_pad;
-    S.qtab = p; p += (size_t)8 * 3 * N * n_pad;
+    S.qtab = p; p += (size_t)8 * 2 * N * n_pad;
+    S.qz = p; p += (size_t)13 * N * n_pad;
     S.rx = p;
     return ERR_OK;
 }
@@ -671,10 +714,10 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
     hipLaunchKernelGGL(bign_main_kernel<N>, dim3(g256), dim3(256), 0, st, n, S, (const uint4 *)gtab);
     hipLaunchKernelGGL(bign_slow_kernel<N>, dim3(g64), dim3(64), 0, st, (const uint8_t *)d_sigs,
                        (const uint8_t *)d_pubkeys, n, S);
-    // signatures per inversion.  The kernel is one chain of dependent multiplications per lane and a lone
-    // wavefront issues at a third of a SIMD's rate, so fewer, longer lanes cost nothing until the lanes no
-    // longer cover the SIMDs: measured best at 2^18 signatures K = 8 (256-bit: +4.8 %; K = 2 / 4 / 16:
-    // +1.8 / +3.5 / +2.2 %) and K = 4 on the wider curves (profiles/r01_bign_ab_inv.txt)
+    // signatures per inversion.  Each lane runs one chain (division steps, then 5 multiplications per
+    // signature) and a lone wavefront issues at about a third of a SIMD's rate, so fewer, longer lanes cost
+    // little until the lanes no longer cover the SIMDs: measured best at 2^18 signatures K = 8 on the 256-bit
+    // curve (72 us; K = 2: 105 us) and K = 4 on the wider ones (profiles/r01_bign_ab_inv.txt)
     constexpr size_t inv_lanes = N == 8 ? 32768 : 65536;
     const size_t k_inv = std::min<size_t>(16, std::max<size_t>(1, n / inv_lanes));
     const size_t lanes = (n + k_inv - 1) / k_inv;

@@ -38,7 +38,7 @@ from bee2_amd import shard  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BASHF_BYTES = 384                # algorithmic bytes per permutation (192 read + 192 written)
 CTR_BYTES_PER_BLOCK = 32         # 16 read + 16 written per 16-byte block
-MADS_PER_VERIFY = 1019 * 72 + 717 * 52 + 3000   # v_mad_u64_u32 per signature, inversion shared by 8
+MADS_PER_VERIFY = 976 * 72 + 685 * 52 + 3000   # v_mad_u64_u32 per signature: affine table, shared inversion
 MAD_PEAK_T = 30.0                # measured: 256 CU x 4 SIMD x 64 lanes x 2.31 GHz / 5.05 cycles
 
 
@@ -396,7 +396,7 @@ def main():
             "config": {"workload": "bignVerify batch: 2^18 signatures per GPU on bign-curve256v1 (BASELINE configs[3]); "
                                    "2048 genuine triples tiled 128x, seeded 1/16 corrupted"},
             "roofline": {"kernels": "bign_prep+main+slow+tail", "bound": "valu-int", "avg_batch_ms": ms_launch,
-                         # 32x32+64 multiply-adds per verify: 1019 M x 72 + 717 S x 52 + scaled folds
+                         # 32x32+64 multiply-adds per verify: 976 M x 72 + 685 S x 52 + scaled folds; inversions are division steps (no mads)
                          "mads_per_verify": MADS_PER_VERIFY,
                          "achieved": MADS_PER_VERIFY * n / (ms_launch * 1e-3) / 1e12,
                          "peak": MAD_PEAK_T, "unit": "T v_mad_u64_u32 lane-ops/s",
