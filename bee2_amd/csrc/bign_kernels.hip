@@ -65,7 +65,7 @@ struct VerifyScratch {          // all arrays are [..][n_pad] (signature index f
     uint32_t *u;                // [N][n_pad]      scalar of G; after main / slow: Z of R
     uint32_t *w;                // [N/2+1][n_pad]  v + 0x888..8 (4N+1 nibbles): digit_i = nib_i - 8
     uint32_t *qtab;             // [8][2N][n_pad]  1Q..8Q, affine once bign_prep_kernel is through
-    uint32_t *qz;               // [13][N][n_pad]  prep: Z of 2Q..8Q and their running products; inv: prefixes
+    uint32_t *qz;               // [14][N][n_pad]  prep: Z of 2Q..8Q and the running products; inv: prefixes
     uint32_t *rx;               // [N][n_pad]      X of R, then (bign_inv_kernel) canonical x_R
     size_t n_pad;
 };
@@ -148,13 +148,12 @@ __device__ __forceinline__ void to_affine(feT<N> &x, feT<N> &y, const jacT<N> &T
 }
 
 // --------------------------------------------------------------------- prep ---
+// one signature: range checks, the scalars u and w, and 1Q..8Q (1Q affine, 2Q..8Q Jacobian: X, Y in the table
+// rows, Z aside).  Sets the status; returns true when the table is to be normalised (no exceptional case).
 template <int N>
-__global__ __launch_bounds__(256)
-void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
-                      const uint8_t *__restrict__ pubkeys, size_t n, VerifyScratch S)
+__device__ __forceinline__ bool prep_points(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
+                                            const uint8_t *__restrict__ pubkeys, size_t idx, const VerifyScratch &S)
 {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
     constexpr int NO = 4 * N;                       // octets per field element
 
     affT<N> Q;
@@ -172,9 +171,9 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
     P[0] = 0u - CurveC<N>::C;
 
     // qrFrom rejects coordinates >= p (bign_sign.c:306-311); there is no on-curve check
-    if (limbs_ge(Q.x.v, P) || limbs_ge(Q.y.v, P)) { S.status[idx] = ERR_BAD_PUBKEY; return; }
+    if (limbs_ge(Q.x.v, P) || limbs_ge(Q.y.v, P)) { S.status[idx] = ERR_BAD_PUBKEY; return false; }
     // s1 >= q (bign_sign.c:313-318)
-    if (limbs_ge(s1.v, q)) { S.status[idx] = ERR_BAD_SIG; return; }
+    if (limbs_ge(s1.v, q)) { S.status[idx] = ERR_BAD_SIG; return false; }
 
     // H <- H - q if H >= q ; u <- (s1 + H) mod q   (bign_sign.c:320-327)
     {
@@ -215,10 +214,8 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
             c >>= 32;
         }
     }
-    // table 1Q..8Q, made AFFINE so that the main loop adds with the mixed formula (8M + 3S instead of
-    // 12M + 4S, 31 times per signature): the seven Jacobian points 2Q..8Q are normalised with one shared
-    // inversion (Montgomery's trick over their Z, inversion by division steps) -- 39 M + 7 S + one
-    // inversion (~35 M) spent here, 124 M + 31 S saved in bign_main_kernel.  Any exceptional case -> slow path.
+    // table 1Q..8Q: 1Q as given, 2Q..8Q Jacobian for now (bign_prep_kernel normalises them).  Any exceptional
+    // case -> slow path.
     bool ok = true;
     const auto put = [&](int e, const jacT<N> &P) {      // entry e = (e+1) Q: X, Y in place, Z aside
         store_qxy(S, e, idx, P.X, P.Y);
@@ -235,27 +232,52 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
     T = P3;  jac_dbl(T);                  put(5, T);      // 6Q
     ok &= jac_madd(T, Q);                 put(6, T);      // 7Q
     T = P4;  jac_dbl(T);                  put(7, T);      // 8Q
-    {
-        // c_k = Z_0 ... Z_k (Z_k = Z of (k+2) Q); c_0..c_5 parked behind the Z, c_6 inverted
-        uint32_t *Zs = S.qz, *Cs = S.qz + (size_t)7 * N * S.n_pad;
-        feT<N> acc, z, zi, zi2, v;
-        load_soa(acc, Zs, S.n_pad, idx);
+    S.status[idx] = ok ? ST_PENDING : ST_SLOW;
+    return ok;
+}
+
+// The table is made AFFINE so that the main loop adds with the mixed formula (8M + 3S instead of 12M + 4S, 31
+// times per signature): the Jacobian points 2Q..8Q are normalised with a shared inversion (Montgomery's trick
+// over their Z, inversion by division steps).  A lane takes SP signatures (j, j + lanes, ...) and inverts once
+// for all of them: at 2 wavefronts per SIMD (196 VGPRs) 2^18 signatures are two rounds of wavefronts anyway, so
+// SP = 2 halves the inversions at no loss of parallelism.  Signatures whose table hit an exceptional case go to
+// the slow path and stay out of the product.
+template <int N>
+__global__ __launch_bounds__(256)
+void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
+                      const uint8_t *__restrict__ pubkeys, size_t n, size_t lanes, int SP, VerifyScratch S)
+{
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= lanes) return;
+    uint32_t *Zs = S.qz, *Cs = S.qz + (size_t)7 * N * S.n_pad;     // Z of 2Q..8Q; product of all Z before it
+    feT<N> acc, z, zi, zi2, v;
+    fe_set_one(acc);
+    unsigned todo = 0;
 #pragma unroll 1
-        for (int k = 1; k < 7; ++k) {
-            store_soa(Cs + (size_t)(k - 1) * N * S.n_pad, S.n_pad, idx, acc);
+    for (int sp = 0; sp < SP; ++sp) {
+        const size_t idx = (size_t)sp * lanes + j;
+        if (idx >= n) break;
+        if (!prep_points<N>(hashes, sigs, pubkeys, idx, S)) continue;
+        todo |= 1u << sp;
+#pragma unroll 1
+        for (int k = 0; k < 7; ++k) {
+            store_soa(Cs + (size_t)k * N * S.n_pad, S.n_pad, idx, acc);
             load_soa(z, Zs + (size_t)k * N * S.n_pad, S.n_pad, idx);
             fe_mul(acc, acc, z);
         }
-        feT<N> inv = fe_inv_checked(acc);                 // product 0 (flagged above) gives 0: harmless
+    }
+    if (!todo) return;
+    feT<N> inv = fe_inv_checked(acc);
+#pragma unroll 1
+    for (int sp = SP - 1; sp >= 0; --sp) {
+        if (!((todo >> sp) & 1u)) continue;
+        const size_t idx = (size_t)sp * lanes + j;
 #pragma unroll 1
         for (int k = 6; k >= 0; --k) {
-            zi = inv;
-            if (k > 0) {
-                load_soa(v, Cs + (size_t)(k - 1) * N * S.n_pad, S.n_pad, idx);
-                fe_mul(zi, inv, v);                       // 1 / Z_k
-                load_soa(z, Zs + (size_t)k * N * S.n_pad, S.n_pad, idx);
-                fe_mul(inv, inv, z);                      // 1 / c_{k-1}
-            }
+            load_soa(v, Cs + (size_t)k * N * S.n_pad, S.n_pad, idx);
+            fe_mul(zi, inv, v);                           // 1 / Z_k
+            load_soa(z, Zs + (size_t)k * N * S.n_pad, S.n_pad, idx);
+            fe_mul(inv, inv, z);                          // 1 / (product before Z_k)
             uint32_t *b = S.qtab + (size_t)(k + 1) * 2 * N * S.n_pad;
             fe_sqr(zi2, zi);
             load_soa(v, b, S.n_pad, idx);
@@ -267,8 +289,8 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
             store_soa(b + (size_t)N * S.n_pad, S.n_pad, idx, v);   // y = Y / Z^3
         }
     }
-    S.status[idx] = ok ? ST_PENDING : ST_SLOW;
 }
+
 
 // --------------------------------------------------------------------- main ---
 // (second bound: wavefronts per SIMD the register allocation must leave room for -- the 256-bit kernel sits
@@ -674,7 +696,7 @@ template <int N>
 static err_t bign_scratch(hipStream_t st, size_t n, VerifyScratch &S)
 {
     const size_t n_pad = (n + 63) & ~(size_t)63;
-    const size_t words = n_pad * (1 + N + (N / 2 + 1) + 8 * 2 * N + 13 * N + N);
+    const size_t words = n_pad * (1 + N + (N / 2 + 1) + 8 * 2 * N + 14 * N + N);
     void *base = nullptr;
     err_t code = scratch_for_stream(st, N / 4 - 2 + 4, words * 4, &base);
     if (code != ERR_OK) return code;
@@ -684,7 +706,7 @@ static err_t bign_scratch(hipStream_t st, size_t n, VerifyScratch &S)
     S.u = p; p += (size_t)N * n_pad;
     S.w = p; p += (size_t)(N / 2 + 1) * n_pad;
     S.qtab = p; p += (size_t)8 * 2 * N * n_pad;
-    S.qz = p; p += (size_t)13 * N * n_pad;
+    S.qz = p; p += (size_t)14 * N * n_pad;
     S.rx = p;
     return ERR_OK;
 }
@@ -709,8 +731,11 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
     oid.len = (uint32_t)oid_len;
     memcpy(oid.der, oid_der, oid_len);
     const unsigned g256 = (unsigned)((n + 255) / 256), g64 = (unsigned)((n + 63) / 64);
-    hipLaunchKernelGGL(bign_prep_kernel<N>, dim3(g256), dim3(256), 0, st, (const uint8_t *)d_hashes,
-                       (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S);
+    const size_t sp = n >= ((size_t)1 << 18) ? 2 : 1;     // signatures per lane in prep (shared inversion)
+    const size_t plan = (n + sp - 1) / sp;
+    hipLaunchKernelGGL(bign_prep_kernel<N>, dim3((unsigned)((plan + 255) / 256)), dim3(256), 0, st,
+                       (const uint8_t *)d_hashes, (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, plan,
+                       (int)sp, S);
     hipLaunchKernelGGL(bign_main_kernel<N>, dim3(g256), dim3(256), 0, st, n, S, (const uint4 *)gtab);
     hipLaunchKernelGGL(bign_slow_kernel<N>, dim3(g64), dim3(64), 0, st, (const uint8_t *)d_sigs,
                        (const uint8_t *)d_pubkeys, n, S);

@@ -163,11 +163,19 @@ def f_verify(rnd):
             s[:no // 2] = bytes(no // 2)                    # s0 = 0
         H += h; S += s; P += p
     oid = LEVEL_OID[l]
+    if rnd.randrange(4) == 0:                               # another OID length: every byte of the tail message moves
+        k = rnd.choice((1, 2, 3, 4, 5, 8, 13, 20, 61, 126))
+        oid = bytes([0x06, k] if k < 128 else [0x06, 0x81, k]) + bytes([0x2A] + [rnd.randrange(1, 128) for _ in range(k - 1)])
     codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
     eng.bignVerifyL_batch_dev(l, oid, dev(H), dev(S), dev(P), codes)
     torch.cuda.synchronize()
     got = [int(c) & 0xFFFFFFFF for c in codes.cpu().numpy()]
-    return got == orc.verify_batch_l(l, oid, bytes(H), bytes(S), bytes(P), nthreads=16)
+    if got != orc.verify_batch_l(l, oid, bytes(H), bytes(S), bytes(P), nthreads=16):
+        return False
+    # public-key validation over the same (partly damaged) keys
+    eng.bignPubkeyValL_batch_dev(l, dev(P), codes)
+    torch.cuda.synchronize()
+    return [int(c) & 0xFFFFFFFF for c in codes.cpu().numpy()] == orc.pubkey_val_batch(l, bytes(P))
 
 
 def f_ragged_mixed(rnd):
