@@ -242,8 +242,10 @@ __device__ __forceinline__ bool prep_points(const uint8_t *__restrict__ hashes, 
 // for all of them: at 2 wavefronts per SIMD (196 VGPRs) 2^18 signatures are two rounds of wavefronts anyway, so
 // SP = 2 halves the inversions at no loss of parallelism.  Signatures whose table hit an exceptional case go to
 // the slow path and stay out of the product.
+// (two wavefronts per SIMD on every curve: 196 VGPRs on the 256-bit one as it comes; the wider ones, 311 / 409
+// VGPRs unbounded, are held to 256 -- +3 % on their whole pipelines)
 template <int N>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, (N == 8 ? 1 : 2))
 void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
                       const uint8_t *__restrict__ pubkeys, size_t n, size_t lanes, int SP, VerifyScratch S)
 {
@@ -293,10 +295,12 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
 
 
 // --------------------------------------------------------------------- main ---
-// (second bound: wavefronts per SIMD the register allocation must leave room for -- the 256-bit kernel sits
-// a few registers above the 128 that four wavefronts allow unless told so)
+// (second bound: wavefronts per SIMD the register allocation must leave room for.  The 256-bit kernel sits a few
+// registers above the 128 that four wavefronts allow unless told so; the 512-bit one took 292 VGPRs, i.e. ONE
+// wavefront per SIMD, which issues at under half a SIMD's rate -- held to 256 (36 spills) it runs 1.5x as fast.
+// The 384-bit kernel has two wavefronts at 224 VGPRs; forcing three costs 92 spills and 12 %.)
 template <int N>
-__global__ __launch_bounds__(256, (N == 8 ? 4 : 1))
+__global__ __launch_bounds__(256, (N == 8 ? 4 : N == 12 ? 1 : 2))
 void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
