@@ -456,19 +456,24 @@ void bign_inv_kernel(size_t n, size_t lanes, int K, VerifyScratch S)
 constexpr int OID_MAX = 128;                      // longest DER OID the kernel stages
 struct OidArg { uint32_t len; uint8_t der[OID_MAX]; };
 
-template <int N>
-__global__ __launch_bounds__(64)
+// Tab = BeltTabSmall: 64-thread workgroups, 4 KiB table with bank conflicts (any curve, any batch size);
+// Tab = BeltTabTwo: 1024-thread workgroups around the conflict-free 64 KiB table of the CTR kernel -- worth its
+// fill for big batches on the 256-bit curve (the rows of the wider curves do not fit beside the table).
+// Dynamic LDS: table first (BeltTabTwo composes addresses with OR and needs its 64 KiB alignment), rows behind.
+template <int N, class Tab, int WG>
+__global__ __launch_bounds__(WG)
 void bign_tail_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
                       size_t n, VerifyScratch S, OidArg oid, uint32_t *__restrict__ codes)
 {
     constexpr int NO = 4 * N;
     constexpr int DW = 2 * N;                              // words of <x_R> || H
     constexpr int LSTR = DW + 1;                           // odd word stride: conflict-free per-lane rows
-    __shared__ __attribute__((aligned(16))) uint8_t s_tab[BeltTabSmall::kBytes];
-    __shared__ uint32_t s_dat[64 * LSTR];
-    BeltTabSmall::fill(s_tab, threadIdx.x, 64);
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    uint8_t *s_tab = s_dyn;
+    uint32_t *s_dat = reinterpret_cast<uint32_t *>(s_dyn + Tab::kBytes);
+    Tab::fill(s_tab, threadIdx.x, WG);
     __syncthreads();
-    const BeltTabSmall T(s_tab);
+    const Tab T(s_tab);
 
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
@@ -752,8 +757,23 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
     const size_t lanes = (n + k_inv - 1) / k_inv;
     hipLaunchKernelGGL(bign_inv_kernel<N>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, n, lanes,
                        (int)k_inv, S);
-    hipLaunchKernelGGL(bign_tail_kernel<N>, dim3(g64), dim3(64), 0, st, (const uint8_t *)d_hashes,
-                       (const uint8_t *)d_sigs, n, S, oid, (uint32_t *)d_codes);
+    constexpr size_t row_bytes = (2 * N + 1) * 4;
+    if (N == 8 && n >= 65536) {
+        auto kern = bign_tail_kernel<N, BeltTabTwo, 1024>;
+        const size_t lds = BeltTabTwo::kBytes + 1024 * row_bytes;
+        static bool attr_set[64];
+        if (!attr_set[cur_dev()]) {
+            B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set[cur_dev()] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), lds, st, (const uint8_t *)d_hashes,
+                           (const uint8_t *)d_sigs, n, S, oid, (uint32_t *)d_codes);
+    } else {
+        hipLaunchKernelGGL((bign_tail_kernel<N, BeltTabSmall, 64>), dim3(g64), dim3(64),
+                           BeltTabSmall::kBytes + 64 * row_bytes, st, (const uint8_t *)d_hashes,
+                           (const uint8_t *)d_sigs, n, S, oid, (uint32_t *)d_codes);
+    }
     B2H_TRY(hipGetLastError());
     return ERR_OK;
 }
