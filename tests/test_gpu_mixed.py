@@ -213,3 +213,34 @@ def test_c_selftest_example_runs_the_stb_vectors(golden, tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
     assert not [l for l in out if l.startswith(("FAIL", "SKIP"))]
     assert out[-1].startswith(f"{len(lines)} vectors, 0 failed"), out[-1]
+
+
+@pytest.mark.parametrize("l", [128, 192, 256])
+def test_sigvfy_pipeline_on_one_stream(golden, l):
+    """`bee2cmd sig vfy` as a batch (cmd/core/cmd_sig.c:461-490: hash the file, bignPubkeyVal, bignVerify): the
+    ragged hash writes its digests where the verification reads its hashes, everything queued on one stream with
+    no host round trip in between; verdicts are the reference's (tests/golden/sigvfy_pipeline.json)."""
+    import numpy as np
+    from bee2_amd import engine as E
+    eng = engine()
+    items = golden.sigvfy_pipeline[str(l)] * 30                      # ~2 000 messages, several wavefronts
+    msgs = [bytes.fromhex(it["msg"]) for it in items]
+    offs = np.zeros(len(msgs) + 1, dtype=np.int64)
+    np.cumsum([len(m) for m in msgs], out=offs[1:])
+    data = dev(b"".join(msgs) + bytes(16))
+    doff = torch.from_numpy(offs).cuda()
+    sigs = dev(b"".join(bytes.fromhex(it["sig"]) for it in items))
+    pubs = dev(b"".join(bytes.fromhex(it["pubkey"]) for it in items))
+    n = len(items)
+    digests = torch.zeros(n * (l // 4), dtype=torch.uint8, device="cuda")
+    kcodes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    vcodes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        eng.hash_ragged_dev(0 if l == 128 else l, data, doff, digests, n)
+        eng.bignPubkeyValL_batch_dev(l, pubs, kcodes)
+        eng.bignVerifyL_batch_dev(l, E.LEVEL_OID[l], digests, sigs, pubs, vcodes)
+    st.synchronize()
+    assert host(digests) == b"".join(bytes.fromhex(it["digest"]) for it in items)
+    assert [int(c) & 0xFFFFFFFF for c in kcodes.cpu().numpy()] == [it["pubkey_val"] for it in items]
+    assert [int(c) & 0xFFFFFFFF for c in vcodes.cpu().numpy()] == [it["verify"] for it in items]

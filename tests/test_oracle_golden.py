@@ -240,3 +240,15 @@ def test_bign_oid_lengths_oracle_vs_golden(orc, golden):
         got = orc.verify_l(c["l"], bytes.fromhex(c["oid"]), bytes.fromhex(c["hash"]), bytes.fromhex(c["sig"]),
                            bytes.fromhex(c["pubkey"]))
         assert got == c["code"], (c["l"], len(c["oid"]) // 2)
+
+
+def test_sigvfy_pipeline_oracle_vs_golden(orc, golden):
+    """hash -> bignPubkeyVal -> bignVerify as `bee2cmd sig vfy` chains them (cmd_sig.c:461-490), reference verdicts"""
+    from bee2_amd.engine import LEVEL_OID
+    for l in (128, 192, 256):
+        for it in golden.sigvfy_pipeline[str(l)]:
+            msg, pub, sig = (bytes.fromhex(it[k]) for k in ("msg", "pubkey", "sig"))
+            dig = orc.belt_hash(msg) if l == 128 else orc.bashHash(l, msg)[1]
+            assert dig == bytes.fromhex(it["digest"])
+            assert orc.pubkey_val(l, pub) == it["pubkey_val"]
+            assert orc.verify_l(l, LEVEL_OID[l], dig, sig, pub) == it["verify"]

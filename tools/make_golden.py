@@ -614,6 +614,48 @@ def oid_len_cases(seed=0x01DA):
     return out
 
 
+def sigvfy_pipeline(seed=0x51F7):
+    """`bee2cmd sig vfy`-shaped batch (cmd/core/cmd_sig.c:461-490): messages of ragged lengths, their belt-hash
+    (level 128) or bash384 / bash512 digest as pre-hash, a public key and a signature per message (reference as
+    hasher and signer), plus a few damaged entries with the reference's verdicts."""
+    import random
+    L = refgen.ref()
+    out = {}
+    for l in (128, 192, 256):
+        rnd = random.Random(seed + l)
+        no = l // 4
+        items = []
+        for i in range(72):
+            ln = rnd.choice((0, 1, 31, 32, 33, 64, 95, 127, 128, 129, 200)) if i < 22 else rnd.randrange(0, 1200)
+            msg = rnd.randbytes(ln)
+            dig = ctypes.create_string_buffer(no)
+            if l == 128:
+                assert L.beltHash(dig, msg, _sz(ln)) == 0
+            else:
+                assert L.bashHash(dig, _sz(l), msg, _sz(ln)) == 0
+            priv = int_le(rnd.randrange(1, 2 ** (l - 1)), no)
+            pub = bytearray(refgen.pubkey_calc_l(l, priv))
+            sig = bytearray(refgen.sign2_l(l, dig.raw, priv))
+            kind = i % 8
+            if kind == 5:
+                sig[rnd.randrange(len(sig))] ^= 1 << rnd.randrange(8)
+            elif kind == 6:
+                pub[rnd.randrange(len(pub))] ^= 1 << rnd.randrange(8)
+            elif kind == 7 and ln:
+                msg = bytearray(msg); msg[rnd.randrange(ln)] ^= 1; msg = bytes(msg)
+                if l == 128:
+                    L.beltHash(dig, msg, _sz(ln))
+                else:
+                    L.bashHash(dig, _sz(l), msg, _sz(ln))
+            items.append({"msg": bytes(msg).hex(), "digest": dig.raw.hex(), "sig": bytes(sig).hex(),
+                          "pubkey": bytes(pub).hex(),
+                          "pubkey_val": getattr(L, f"bign{l}PubkeyVal")(bytes(pub)),
+                          "verify": refgen.verify_l(l, dig.raw, bytes(sig), bytes(pub))})
+        assert {it["verify"] for it in items} >= {0, 510} and {it["pubkey_val"] for it in items} == {0, 505}
+        out[str(l)] = items
+    return out
+
+
 def refparams(l):
     class Params(ctypes.Structure):
         _fields_ = [("l", _sz), ("p", ctypes.c_ubyte * 64), ("a", ctypes.c_ubyte * 64), ("b", ctypes.c_ubyte * 64),
@@ -672,6 +714,8 @@ def main():
         json.dump(pubkey_val_cases(), f)
     with open(os.path.join(GOLD, "bign_oid_lengths.json"), "w") as f:
         json.dump(oid_len_cases(), f)
+    with open(os.path.join(GOLD, "sigvfy_pipeline.json"), "w") as f:
+        json.dump(sigvfy_pipeline(), f)
     with open(os.path.join(GOLD, "stb_kat.json"), "w") as f:
         json.dump(stb_kats(), f, indent=1)
     inp, out = bashf_random()
