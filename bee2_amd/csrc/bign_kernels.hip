@@ -14,17 +14,20 @@
 //     table by double-and-add, bign_gtable16_kernel combines it) -> 16 mixed additions.
 //     l = 192 / 256: the 8-bit table itself (4N windows) -> 48 / 64 mixed additions.
 //   * Q part: signed radix-16 digits of the (l+1)-bit scalar (uniform 4 doublings + 1
-//     addition per digit, 4N+1 digits), per-signature table 1Q..8Q kept in an HBM scratch
-//     laid out [entry][limb][signature] so table reads coalesce across the wavefront.
+//     mixed addition per digit, 4N+1 digits), per-signature AFFINE table 1Q..8Q kept in an HBM
+//     scratch laid out [entry][limb][signature] so table reads coalesce across the wavefront.
+//   * inversions (table normalisation, x_R = X / Z^2) by division steps (bign_dev.hpp,
+//     fe_inv_safegcd) and shared between signatures (Montgomery's trick).
 // Exceptional cases of the addition law (operand O, P = +-Q) cannot occur for honest
 // inputs; lanes that hit one are flagged and recomputed by bign_slow_kernel with the
 // complete (branchy) formulas, so verdicts are exact for every input.
 //
-// Kernels per batch (same stream): prep -> main -> slow -> tail.
+// Kernels per batch (same stream): prep -> main -> slow -> inv -> tail.
 //   prep : range checks (bign_sign.c:306-318), u = s1 + H mod q (:320-327),
-//          v = s0 + 2^l (:329-330), Q table
-//   main : the double-scalar multiplication and x_R = X / Z^2 (one Fermat inversion)
-//   slow : flagged lanes only
+//          v = s0 + 2^l (:329-330), affine Q table
+//   main : the double-scalar multiplication, leaves R as (X, Z)
+//   slow : flagged lanes only (complete formulas, own inversion)
+//   inv  : x_R = X / Z^2, one inversion per K signatures
 //   tail : belt-hash(oid || x_R || H) == s0 ? (bign_sign.c:337-343)
 // HBM traffic is irrelevant here (148 B of input per ~5e5 VALU ops at l = 128): the bound is
 // the integer multiplier rate.
