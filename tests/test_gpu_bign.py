@@ -393,3 +393,34 @@ def test_bign_oid_lengths_every_alignment(golden):
     for c in [c for c in golden.bign_oid_lengths if c["l"] == 128][:12]:
         assert eng.bignVerify(params, bytes.fromhex(c["oid"]), bytes.fromhex(c["hash"]), bytes.fromhex(c["sig"]),
                               bytes.fromhex(c["pubkey"])) == c["code"]
+
+
+def test_bign_big_batch_every_entry_against_the_oracle(orc, golden):
+    """2^18 + 17 signatures on the 256-bit curve (shared inversions in prep and inv, big-table tail), HALF of them
+    damaged by a random bit flip in the hash, s0, s1 or the public key -- each damaged key gives a table of its
+    own -- and every single verdict compared with the oracle's."""
+    eng = engine()
+    hs, ss, ps = golden.bign_base_arrays()
+    nb = len(hs) // 32
+    n = (1 << 18) + 17
+    reps = -(-n // nb)
+    H = np.tile(np.frombuffer(hs, dtype=np.uint8), reps).reshape(-1, 32)[:n].copy()
+    S = np.tile(np.frombuffer(ss, dtype=np.uint8), reps).reshape(-1, 48)[:n].copy()
+    K = np.tile(np.frombuffer(ps, dtype=np.uint8), reps).reshape(-1, 64)[:n].copy()
+    rng = np.random.default_rng(0x2B18)
+    bad = rng.choice(n, n // 2, replace=False)
+    kind = rng.integers(0, 4, bad.size)
+    bit = (1 << rng.integers(0, 8, bad.size)).astype(np.uint8)
+    for arr, k, width in ((H, 0, 32), (S, 1, 48), (K, 2, 64), (K, 3, 64)):
+        sel = bad[kind == k]
+        arr[sel, rng.integers(0, width, sel.size)] ^= bit[kind == k]
+    K[rng.choice(n, 64, replace=False), :32] = 0xFF                  # x_Q >= p: never reaches the inversions
+    S[rng.choice(n, 64, replace=False), 16:] = 0xFF                  # s1 >= q
+    codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    eng.bign128Verify_batch_dev(dev(H.reshape(-1)), dev(S.reshape(-1)), dev(K.reshape(-1)), codes)
+    torch.cuda.synchronize()
+    got = codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    want = np.array(orc.verify_batch(H.tobytes(), S.tobytes(), K.tobytes(), nthreads=64), dtype=np.int64)
+    diff = np.nonzero(got != want)[0]
+    assert diff.size == 0, (diff[:5], got[diff[:5]], want[diff[:5]])
+    assert int((want == 0).sum()) >= n // 2 - 128 and {505, 510} <= set(np.unique(want).tolist())
