@@ -1550,7 +1550,7 @@ extern "C" err_t beltCBCDecr(void *dest, const void *src, size_t count, const oc
 extern "C" err_t bee2hip_hash_ragged_ordered_dev(size_t alg, const void *d_data, const void *d_offsets,
                                                  const void *d_order, size_t n, void *d_digests, void *stream)
 {
-    if (misaligned(d_offsets, 8) || misaligned(d_order, 4)) return ERR_BAD_INPUT;
+    if (misaligned(d_offsets, 8) || misaligned(d_order, 4) || misaligned(d_digests, 4)) return ERR_BAD_INPUT;
     if (alg != 0 && alg != 128 && alg != 192 && alg != 256) return ERR_BAD_PARAMS;
     if (n && (!d_offsets || !d_digests)) return ERR_BAD_INPUT;
     err_t code = ensure_device();

@@ -209,17 +209,32 @@ void bash_sponge_kernel(bash_hash_st *__restrict__ states, const uint8_t *__rest
     }
 }
 
-// 64-bit little-endian load from any address (message starts are not aligned)
+// Little-endian loads from any address (message starts are not aligned): aligned words and a funnel shift by
+// the misalignment.  The extra word is read only when the address is misaligned, and then it holds at least
+// one of the requested bytes -- an aligned word with a valid byte in it cannot fault.  Branch-free on purpose:
+// the lanes of a wavefront hold messages of every alignment, and a wavefront that splits into an aligned and a
+// misaligned path pays for both (ragged belt-hash 33 -> 23 GiB/s when tried).
+__device__ __forceinline__ uint32_t load32_any(const uint8_t *p)
+{
+    const uint32_t *b = reinterpret_cast<const uint32_t *>((uintptr_t)p & ~(uintptr_t)3);
+    const uint32_t sh = ((uint32_t)(uintptr_t)p & 3u) * 8u;
+    const uint32_t lo = b[0], hi = sh ? b[1] : 0u;
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
 __device__ __forceinline__ uint64_t load64_any(const uint8_t *p)
 {
-    if (((uintptr_t)p & 3) == 0) {
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
-        return ((uint64_t)w[1] << 32) | w[0];
-    }
-    uint64_t v = 0;
-#pragma unroll
-    for (int k = 7; k >= 0; --k) v = (v << 8) | p[k];
-    return v;
+    const uint32_t *b = reinterpret_cast<const uint32_t *>((uintptr_t)p & ~(uintptr_t)3);
+    const uint32_t sh = ((uint32_t)(uintptr_t)p & 3u) * 8u;
+    const uint32_t w0 = b[0], w1 = b[1], w2 = sh ? b[2] : 0u;
+    return ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32) | __builtin_amdgcn_alignbit(w1, w0, sh);
+}
+// the first `valid` (1..3) bytes at p, zero above; never touches a word without a valid byte
+__device__ __forceinline__ uint32_t load32_head(const uint8_t *p, uint32_t valid)
+{
+    const uint32_t *b = reinterpret_cast<const uint32_t *>((uintptr_t)p & ~(uintptr_t)3);
+    const uint32_t mis = (uint32_t)(uintptr_t)p & 3u, sh = mis * 8u;
+    const uint32_t lo = b[0], hi = (mis + valid > 4u) ? b[1] : 0u;
+    return __builtin_amdgcn_alignbit(hi, lo, sh) & ((1u << (8u * valid)) - 1u);
 }
 
 // Whole rate blocks of ONE state with 8 lanes, one bash-f column each (bash_dev.hpp bash_f_cols): the bulk
@@ -487,17 +502,20 @@ void bash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__restri
     }
 }
 
-// belt-hash of ragged messages (src/crypto/belt/belt_hash.c:43-171): 32-byte digests
-__global__ __launch_bounds__(64)
+// belt-hash of ragged messages (src/crypto/belt/belt_hash.c:43-171): 32-byte digests, one lane per message.
+// Tab / WG: BeltTabSmall in 64-thread workgroups (4 KiB table, data-dependent bank conflicts) for small batches,
+// BeltTabTwo in 1024-thread workgroups (the CTR kernel's conflict-free 64 KiB table) once its fill pays.
+template <class Tab, int WG>
+__global__ __launch_bounds__(WG)
 void belt_hash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off,
                              const uint32_t *__restrict__ order, size_t n, uint8_t *__restrict__ digests,
                              uint64_t long_from)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[BeltTabSmall::kBytes];
-    BeltTabSmall::fill(smem, threadIdx.x, 64);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Tab::fill(smem, threadIdx.x, WG);
     __syncthreads();
-    const BeltTabSmall T(smem);
-    const size_t slot = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const Tab T(smem);
+    const size_t slot = (size_t)blockIdx.x * WG + threadIdx.x;
     if (slot >= n) return;
     const size_t i = order ? order[slot] : slot;
     const uint8_t *p = data + off[i];
@@ -509,32 +527,31 @@ void belt_hash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *_
     for (int k = 0; k < 8; ++k)
         h[k] = (uint32_t)c_beltH[4 * k] | (uint32_t)c_beltH[4 * k + 1] << 8 |
                (uint32_t)c_beltH[4 * k + 2] << 16 | (uint32_t)c_beltH[4 * k + 3] << 24;
-    while (left) {
-        const size_t take = left < 32 ? left : 32;
+    while (left >= 32) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) X[k] = load32_any(p + 4 * k);
+        belt_compress(T, s1, h, X);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] ^= s1[k];
+        p += 32; left -= 32;
+    }
+    if (left) {                                        // last, partial block: zero padded
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            uint32_t v = 0;
-#pragma unroll
-            for (int b = 3; b >= 0; --b) {
-                const size_t pos = (size_t)(4 * k + b);
-                v = (v << 8) | (pos < take ? p[pos] : 0u);
-            }
-            X[k] = v;
+            const uint32_t have = left > (size_t)(4 * k) ? (uint32_t)(left - 4 * k) : 0u;
+            X[k] = have >= 4 ? load32_any(p + 4 * k) : have ? load32_head(p + 4 * k, have) : 0u;
         }
         belt_compress(T, s1, h, X);
 #pragma unroll
         for (int k = 0; k < 4; ++k) s[k] ^= s1[k];
-        p += take; left -= take;
     }
     const uint64_t bits_lo = (uint64_t)len << 3, bits_hi = (uint64_t)len >> 61;
     X[0] = (uint32_t)bits_lo; X[1] = (uint32_t)(bits_lo >> 32); X[2] = (uint32_t)bits_hi; X[3] = 0;
     X[4] = s[0]; X[5] = s[1]; X[6] = s[2]; X[7] = s[3];
     belt_compress(T, s1, h, X);
-    uint8_t *d = digests + 32 * i;
+    uint32_t *d = reinterpret_cast<uint32_t *>(digests + 32 * i);      // 32-byte slots of an aligned buffer
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) d[4 * k + b] = (uint8_t)(h[k] >> (8 * b));
+    for (int k = 0; k < 8; ++k) d[k] = h[k];
 }
 
 // Streaming belt-hash for the drop-in beltHashStep* (belt_hash.c:43-171): one serial chain, run by a pair of
@@ -589,11 +606,6 @@ err_t launch_belt_hash_stream(void *d_hs, const void *d_data, size_t nblocks, in
 // d_order (may be null): a permutation of 0..n-1; lane k hashes message d_order[k].  Lanes of a
 // wavefront run until the longest of their 64 messages is done, so callers pass the messages
 // sorted by decreasing length (the host entry point does) -- digests still land at index i.
-__device__ __forceinline__ uint32_t load32_any(const uint8_t *p)
-{
-    if (((uintptr_t)p & 3) == 0) return *reinterpret_cast<const uint32_t *>(p);
-    return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
-}
 // Long belt-hash messages (>= long_from bytes): a PAIR of lanes per message (belt_compress_pair): of the
 // three encryptions of a block the last two are independent, so the chain step is 2 E instead of 3.
 // Launched over all n messages (2 lanes each); pairs whose message is short leave at once.
@@ -727,7 +739,28 @@ err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, cons
     if (alg == 0) {
         hipLaunchKernelGGL(belt_hash_long_kernel, dim3((unsigned)((n * 2 + 63) / 64)), t, 0, st, data, off, ord, n, dig,
                            RAGGED_LONG);
-        hipLaunchKernelGGL(belt_hash_ragged_kernel, g, t, 0, st, data, off, ord, n, dig, RAGGED_LONG);
+        if (n >= 32768) {
+            // big table; 256-thread workgroups until there are enough messages to fill 1024-thread ones on every CU
+            const bool wide = n >= (size_t)num_cus() * 1024;
+            const void *kern = wide ? reinterpret_cast<const void *>(belt_hash_ragged_kernel<BeltTabTwo, 1024>)
+                                    : reinterpret_cast<const void *>(belt_hash_ragged_kernel<BeltTabTwo, 256>);
+            static bool attr_set[2][64];
+            int dev_id = 0;
+            B2H_TRY(hipGetDevice(&dev_id));
+            if (!attr_set[wide][dev_id & 63]) {
+                B2H_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, BeltTabTwo::kBytes));
+                attr_set[wide][dev_id & 63] = true;
+            }
+            if (wide)
+                hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabTwo, 1024>), dim3((unsigned)((n + 1023) / 1024)),
+                                   dim3(1024), BeltTabTwo::kBytes, st, data, off, ord, n, dig, RAGGED_LONG);
+            else
+                hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabTwo, 256>), dim3((unsigned)((n + 255) / 256)),
+                                   dim3(256), BeltTabTwo::kBytes, st, data, off, ord, n, dig, RAGGED_LONG);
+        } else {
+            hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabSmall, 64>), g, t, BeltTabSmall::kBytes, st, data, off,
+                               ord, n, dig, RAGGED_LONG);
+        }
     }
     else if (alg == 256) {
         hipLaunchKernelGGL(bash_long_kernel<8>, gl, t, 0, st, data, off, ord, n, 256u, dig, RAGGED_LONG);

@@ -279,7 +279,7 @@ err_t bee2hip_hash_ragged_ordered_dev(size_t alg, const void *d_data, const void
 /* ======================================================================== *
  * (3) device-pointer batch API (buffers in HBM; async on `stream`)
  *     Device pointers to states, blocks, sectors, messages and verify records must be 16-byte
- *     aligned (the kernels read them as 16-byte vectors), d_codes 4-byte, ragged offsets 8-byte:
+ *     aligned (the kernels read them as 16-byte vectors), d_codes 4-byte, ragged offsets 8-byte and digests 4-byte:
  *     a misaligned pointer is refused with ERR_BAD_INPUT.  One stream = one queue: threads that
  *     share a stream serialise their calls themselves.
  * ======================================================================== */
