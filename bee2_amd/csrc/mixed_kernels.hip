@@ -391,8 +391,10 @@ __global__ void init_states_kernel(bash_hash_st *hs, belt_mac_st *ms, size_t n, 
 // files per launch instead of one file per bashHashStepH loop (cmd/bsum/bsum.c:133-221).
 
 // ALG = 8 / 12 / 16: bash512 / bash384 / bash256 (rate in u64 words); digests are l/4 bytes each
+// (bash256 compiled to 276 VGPRs = one wavefront per SIMD; held to 256 it keeps two, which many-message batches
+// need: 2^18 x 1000 B 558 -> 662 GiB/s, 2^20 x 256 B 373 -> 447; bash384 / bash512 have two / three as they come)
 template <int RW>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64, (RW == 16 ? 2 : 1))
 void bash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off,
                         const uint32_t *__restrict__ order, size_t n,
                         uint32_t level, uint8_t *__restrict__ digests, uint64_t long_from)
