@@ -553,6 +553,16 @@ def main():
                         entry["cpu_baseline"]["value"] = entry["cpu_baseline"][name]
             del dig
         del data, doff, dord
+        # the many-small-files shape of bsum: 2^18 messages of 1000 bytes (packed, so three in four start misaligned)
+        nu, lu = 1 << 18, 1000
+        udata = torch.empty(nu * lu + 16, dtype=torch.uint8, device="cuda")
+        fill_seeded(udata[: (nu * lu) // 8 * 8], 0x4D1C + 7 + dist.rank)
+        uoff = torch.arange(nu + 1, dtype=torch.int64, device="cuda") * lu
+        udig = torch.empty(nu * 32, dtype=torch.uint8, device="cuda")
+        for name, alg in (("belt_hash", 0), ("bash256", 128)):
+            el = timed(dist, kr, 1, lambda: eng.hash_ragged_dev(alg, udata, uoff, udig, nu))
+            entry[f"{name}_uniform_1000B"] = N * nu * lu * kr / el / 2 ** 30
+        del udata, uoff, udig
         others["hash_ragged"] = entry
 
     # ------------------------------------------------- 8f-2: belt-dwp (CTR + polynomial MAC)

@@ -45,6 +45,8 @@ def main(path):
     rows.append(("belt-dwp / belt-che wrap, 4 GiB", f"**{w['value']:.0f} / {w['che_wrap']:.0f} GiB/s** (MAC alone {w['mac_only']/1024:.2f} TiB/s)",
                  f"{g(w,'cpu_baseline','value') or 0:.2f} GiB/s (64 threads)"))
     r = o["hash_ragged"]
+    if "belt_hash_uniform_1000B" in r:
+        rows.append(("belt-hash / bash256, 2^18 msgs x 1000 B", f"**{r['belt_hash_uniform_1000B']:.0f} / {r['bash256_uniform_1000B']:.0f} GiB/s**", "—"))
     rows.append(("ragged belt-hash / bash256, 2^16 msgs", f"**{r['belt_hash_longest_first']:.1f} / {r['bash256_longest_first']:.1f} GiB/s** (§4.7: serial-chain bound)",
                  f"{g(r,'cpu_baseline','belt_hash') or 0:.1f} / {g(r,'cpu_baseline','bash256') or 0:.1f} GiB/s (64 threads)"))
     print("| " + " | ".join(rows[0]) + " |")
