@@ -9,10 +9,10 @@
 // (ecAddMulA, src/math/ec.c:1183-1273): data-dependent branching, 2l+1 doublings.  Any
 // correct algorithm yields the same affine R, so the GPU uses a wavefront-friendly
 // schedule instead (N = number of 32-bit limbs = l/16):
-//   * G part: fixed-base comb, no doublings.  l = 128: 16 windows x 16 bits, 16 x 65535
-//     affine points (64 MiB, built once per device: bign_gtable_kernel makes an 8-bit seed
-//     table by double-and-add, bign_gtable16_kernel combines it) -> 16 mixed additions.
-//     l = 192 / 256: the 8-bit table itself (4N windows) -> 48 / 64 mixed additions.
+//   * G part: fixed-base comb, no doublings: 2N windows x 16 bits, 2N x 65535 affine points
+//     (64 / 144 / 256 MiB for l = 128 / 192 / 256, built once per device and curve in 3 / 10 /
+//     22 ms: bign_gtable_kernel makes an 8-bit seed table by double-and-add, bign_gtable16_kernel
+//     combines it) -> 16 / 24 / 32 mixed additions.
 //   * Q part: signed radix-16 digits of the (l+1)-bit scalar (uniform 4 doublings + 1
 //     mixed addition per digit, 4N+1 digits), per-signature AFFINE table 1Q..8Q kept in an HBM
 //     scratch laid out [entry][limb][signature] so table reads coalesce across the wavefront.
@@ -59,8 +59,9 @@ template <int N> __device__ __forceinline__ const uint32_t *curve_q() { return N
 template <int N> __device__ __forceinline__ const uint32_t *curve_yG() { return N == 8 ? c_yG8 : N == 12 ? c_yG12 : c_yG16; }
 
 // comb geometry: window width W bits, 32N/W windows, 2^W entries (entry 0 = neutral, unused),
-// each entry an affine point of 2N limbs
-template <int N> struct Comb { static constexpr int W = (N == 8) ? 16 : 8; };
+// each entry an affine point of 2N limbs.  16 bits on every curve: the wider curves ran the 8-bit seed table
+// directly at first (48 / 64 additions instead of 24 / 32, a fifth of their work) -- +10 % / +11 % with the big one.
+template <int N> struct Comb { static constexpr int W = 16; };
 constexpr int GT8_ENTRIES = 256;
 
 struct VerifyScratch {          // all arrays are [..][n_pad] (signature index fastest)
@@ -141,7 +142,7 @@ __device__ __forceinline__ void store_aff(uint4 *e, const feT<N> &x, const feT<N
 template <int N>
 __device__ __forceinline__ void to_affine(feT<N> &x, feT<N> &y, const jacT<N> &T)
 {
-    feT<N> zi = fe_inv(T.Z), zi2;
+    feT<N> zi = fe_inv_checked(T.Z), zi2;
     fe_sqr(zi2, zi);
     fe_mul(x, T.X, zi2);
     fe_mul(zi2, zi2, zi);
