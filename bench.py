@@ -395,7 +395,7 @@ def main():
             "ms_per_step": el / kv * 1e3, "verdicts_as_expected": sane,
             "config": {"workload": "bignVerify batch: 2^18 signatures per GPU on bign-curve256v1 (BASELINE configs[3]); "
                                    "2048 genuine triples tiled 128x, seeded 1/16 corrupted"},
-            "roofline": {"kernels": "bign_prep+main+slow+tail", "bound": "valu-int", "avg_batch_ms": ms_launch,
+            "roofline": {"kernels": "bign_prep+main+slow+inv+tail", "bound": "valu-int", "avg_batch_ms": ms_launch,
                          # 32x32+64 multiply-adds per verify: 976 M x 72 + 685 S x 52 + scaled folds; inversions are division steps (no mads)
                          "mads_per_verify": MADS_PER_VERIFY,
                          "achieved": MADS_PER_VERIFY * n / (ms_launch * 1e-3) / 1e12,
