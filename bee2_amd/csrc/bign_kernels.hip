@@ -226,16 +226,17 @@ __device__ __forceinline__ bool prep_points(const uint8_t *__restrict__ hashes, 
         store_soa(S.qz + (size_t)(e - 1) * N * S.n_pad, S.n_pad, idx, P.Z);
         ok &= !fe_is_zero(P.Z);
     };
-    jacT<N> P2, P3, P4, T;
+    // Two chains, two points in registers: A = 2Q -> 4Q -> 8Q and T = 3Q -> 6Q -> 7Q, then 5Q = 4Q + Q from A.
+    jacT<N> A, T;
     store_qxy(S, 0, idx, Q.x, Q.y);
-    P2.X = Q.x; P2.Y = Q.y; fe_set_one(P2.Z);
-    jac_dbl(P2);                          put(1, P2);
-    P3 = P2; ok &= jac_madd(P3, Q);       put(2, P3);
-    P4 = P2; jac_dbl(P4);                 put(3, P4);
-    T = P4;  ok &= jac_madd(T, Q);        put(4, T);      // 5Q
-    T = P3;  jac_dbl(T);                  put(5, T);      // 6Q
+    A.X = Q.x; A.Y = Q.y; fe_set_one(A.Z);
+    jac_dbl(A);                           put(1, A);      // 2Q
+    T = A;   ok &= jac_madd(T, Q);        put(2, T);      // 3Q
+    jac_dbl(A);                           put(3, A);      // 4Q
+    jac_dbl(T);                           put(5, T);      // 6Q
     ok &= jac_madd(T, Q);                 put(6, T);      // 7Q
-    T = P4;  jac_dbl(T);                  put(7, T);      // 8Q
+    T = A;   ok &= jac_madd(T, Q);        put(4, T);      // 5Q
+    jac_dbl(A);                           put(7, A);      // 8Q
     S.status[idx] = ok ? ST_PENDING : ST_SLOW;
     return ok;
 }
