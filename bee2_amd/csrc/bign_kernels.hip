@@ -241,6 +241,15 @@ __device__ __forceinline__ bool prep_points(const uint8_t *__restrict__ hashes, 
     return ok;
 }
 
+template <int N>
+__global__ __launch_bounds__(256, 2)
+void bign_points_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
+                        const uint8_t *__restrict__ pubkeys, size_t n, VerifyScratch S)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) prep_points<N>(hashes, sigs, pubkeys, idx, S);
+}
+
 // The table is made AFFINE so that the main loop adds with the mixed formula (8M + 3S instead of 12M + 4S, 31
 // times per signature): the Jacobian points 2Q..8Q are normalised with a shared inversion (Montgomery's trick
 // over their Z, inversion by division steps).  A lane takes SP signatures (j, j + lanes, ...) and inverts once
@@ -254,6 +263,10 @@ __global__ __launch_bounds__(256, (N == 8 ? 1 : 2))
 void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
                       const uint8_t *__restrict__ pubkeys, size_t n, size_t lanes, int SP, VerifyScratch S)
 {
+    // wider curves: the points come from bign_points_kernel -- together the two halves need 311 / 409 VGPRs,
+    // apart the normalising half fits 120 / 153 without spills (split: 970 -> 625 us and 1670 -> 1170 us at
+    // 2^18 signatures; on the 256-bit curve, 173 VGPRs in one piece, splitting costs 2 %)
+    constexpr bool SPLIT = N != 8;
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= lanes) return;
     uint32_t *Zs = S.qz, *Cs = S.qz + (size_t)7 * N * S.n_pad;     // Z of 2Q..8Q; product of all Z before it
@@ -264,7 +277,8 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
     for (int sp = 0; sp < SP; ++sp) {
         const size_t idx = (size_t)sp * lanes + j;
         if (idx >= n) break;
-        if (!prep_points<N>(hashes, sigs, pubkeys, idx, S)) continue;
+        if (SPLIT) { if (S.status[idx] != ST_PENDING) continue; }
+        else if (!prep_points<N>(hashes, sigs, pubkeys, idx, S)) continue;
         todo |= 1u << sp;
 #pragma unroll 1
         for (int k = 0; k < 7; ++k) {
@@ -747,6 +761,9 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
     const unsigned g256 = (unsigned)((n + 255) / 256), g64 = (unsigned)((n + 63) / 64);
     const size_t sp = n >= ((size_t)1 << 18) ? 2 : 1;     // signatures per lane in prep (shared inversion)
     const size_t plan = (n + sp - 1) / sp;
+    if (N != 8)
+        hipLaunchKernelGGL(bign_points_kernel<N>, dim3(g256), dim3(256), 0, st, (const uint8_t *)d_hashes,
+                           (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S);
     hipLaunchKernelGGL(bign_prep_kernel<N>, dim3((unsigned)((plan + 255) / 256)), dim3(256), 0, st,
                        (const uint8_t *)d_hashes, (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, plan,
                        (int)sp, S);
