@@ -22,9 +22,10 @@
 // inputs; lanes that hit one are flagged and recomputed by bign_slow_kernel with the
 // complete (branchy) formulas, so verdicts are exact for every input.
 //
-// Kernels per batch (same stream): prep -> main -> slow -> inv -> tail.
+// Kernels per batch (same stream): [points ->] prep -> main -> slow -> inv -> tail.
 //   prep : range checks (bign_sign.c:306-318), u = s1 + H mod q (:320-327),
-//          v = s0 + 2^l (:329-330), affine Q table
+//          v = s0 + 2^l (:329-330), affine Q table (on the wider curves the first half of this,
+//          everything up to the Jacobian table points, is a kernel of its own: points)
 //   main : the double-scalar multiplication, leaves R as (X, Z)
 //   slow : flagged lanes only (complete formulas, own inversion)
 //   inv  : x_R = X / Z^2, one inversion per K signatures
