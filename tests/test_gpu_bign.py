@@ -337,7 +337,8 @@ def test_bign_pubkey_val_batch_and_dropin(orc, golden, l):
 
 
 @pytest.mark.parametrize("l,n", [(128, 2 * 32768 + 37), (128, 9 * 32768 - 5), (192, 2 * 65536 + 37), (256, 2 * 65536 + 3),
-                                 (128, 2 ** 18 + 1), (192, 2 ** 18 + 3), (256, 2 ** 18 + 1)])
+                                 (128, 2 ** 18 + 1), (192, 2 ** 18 + 3), (256, 2 ** 18 + 1),
+                                 (128, 32767), (128, 32768), (128, 65535), (128, 65536), (128, 2 ** 18 - 1), (128, 2 ** 18)])
 def test_bign_shared_inversion_groups_with_mixed_statuses(golden, l, n):
     """bign_inv_kernel shares one inversion between K signatures (K = n / 32768 resp. n / 65536, here 2, 4 and 8)
     and from 2^18 signatures on bign_prep_kernel normalises the tables of two signatures with one inversion.
