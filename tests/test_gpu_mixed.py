@@ -244,3 +244,30 @@ def test_sigvfy_pipeline_on_one_stream(golden, l):
     assert host(digests) == b"".join(bytes.fromhex(it["digest"]) for it in items)
     assert [int(c) & 0xFFFFFFFF for c in kcodes.cpu().numpy()] == [it["pubkey_val"] for it in items]
     assert [int(c) & 0xFFFFFFFF for c in vcodes.cpu().numpy()] == [it["verify"] for it in items]
+
+
+@pytest.mark.parametrize("n", [32767, 32768 + 3, 256 * 1024 + 5])
+def test_ragged_belt_hash_many_short_messages_every_table_variant(orc, n):
+    """The short-message belt-hash kernel switches table and workgroup shape with the batch size (4 KiB table /
+    64 threads below 2^15 messages, 64 KiB table / 256 threads, 64 KiB / 1024 threads once every CU gets one):
+    batches on each side, lengths 0..199 so every alignment and every partial-block length occurs, every
+    digest against the oracle (sampled for the largest batch); bash256 on the same batch as well."""
+    import random
+    eng = engine()
+    rnd = random.Random(n)
+    lens = np.array([rnd.randrange(0, 200) for _ in range(n)], dtype=np.int64)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    blob = rnd.randbytes(int(offs[-1]))
+    data = dev(blob + bytes(16))
+    doff = torch.from_numpy(offs).cuda()
+    step = 1 if n < 100000 else 7
+    for alg, dl in ((0, 32), (128, 32)):
+        dig = torch.zeros(n * dl, dtype=torch.uint8, device="cuda")
+        eng.hash_ragged_dev(alg, data, doff, dig, n)
+        torch.cuda.synchronize()
+        got = host(dig)
+        for i in range(0, n, step):
+            m = blob[offs[i]:offs[i + 1]]
+            want = orc.belt_hash(m) if alg == 0 else orc.bashHash(alg, m)[1]
+            assert got[dl * i: dl * i + dl] == want, (alg, n, i, len(m))
