@@ -432,6 +432,19 @@ def main():
             "roofline": {"kernel": "bign_pubkey_val_kernel<8>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                          "note": "68 B per key (64 in + 4 out), 2 squarings + 1 multiplication; wall time per launch"}}
+        if do_cpu:
+            import refgen
+            if refgen.have_ref():
+                ref = ctypes.CDLL(refgen.REF_SO)
+                ref.bign128PubkeyVal.restype = ctypes.c_uint32
+                t0, cnt = time.perf_counter(), 0
+                while time.perf_counter() - t0 < 1.0:
+                    i = cnt % nbase
+                    ref.bign128PubkeyVal(ps[64 * i: 64 * i + 64])
+                    cnt += 1
+                others["bignPubkeyVal"]["cpu_baseline"] = {
+                    "value": cnt / (time.perf_counter() - t0), "unit": "keys/s", "cores": 1, "kind": "reference",
+                    "sample": "1 s of bign128PubkeyVal calls, one thread"}
         del dh, ds, dk, codes, kk, kcodes
 
     # ------------------------------------------------- 8f-4: the 384- and 512-bit curves

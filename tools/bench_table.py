@@ -30,7 +30,9 @@ def main(path):
                  f"{(g(v,'cpu_baseline','value') or 0)/1e3:.0f} k/s (bee2's process-global curve mutex serialises threads) / "
                  f"{(g(v,'cpu_baseline','single_thread') or 0)/1e3:.1f} k/s"))
     if "bignPubkeyVal" in o:
-        rows.append(("bign public-key validation, 2^24 keys", f"**{o['bignPubkeyVal']['value']/1e9:.1f} G keys/s** ({o['bignPubkeyVal']['roofline']['achieved']/1e3:.2f} TB/s = {o['bignPubkeyVal']['roofline']['frac']:.2f} of HBM peak)", "—"))
+        rows.append(("bign public-key validation, 2^24 keys", f"**{o['bignPubkeyVal']['value']/1e9:.1f} G keys/s** ({o['bignPubkeyVal']['roofline']['achieved']/1e3:.2f} TB/s = {o['bignPubkeyVal']['roofline']['frac']:.2f} of HBM peak)",
+                     (f"{g(o['bignPubkeyVal'],'cpu_baseline','value')/1e6:.1f} M keys/s per thread"
+                      if g(o['bignPubkeyVal'], 'cpu_baseline', 'value') else "—")))
     rows.append(("bign-curve384v1 / 512v1 verify, 2^18", f"**{o['bignVerify_l192']['value']/1e6:.1f} / {o['bignVerify_l256']['value']/1e6:.2f} M/s**",
                  f"{(g(o['bignVerify_l192'],'cpu_baseline','value') or 0)/1e3:.1f} / {(g(o['bignVerify_l256'],'cpu_baseline','value') or 0)/1e3:.1f} k/s per thread"))
     m = o["bash512_beltMAC"]
