@@ -182,3 +182,51 @@ def test_shard_ranges_cover_and_balance():
         shard.shard_range(2, 2, 10)
     lo, hi, first = shard.ctr_shard(1, 2, 16 * 10 + 3)
     assert (lo, hi, first) == (80, 163, 5)
+
+
+def _sigvfy_worker(rank, world, port, outdir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import json
+    import torch
+    import torch.distributed as dist
+
+    import goldenlib
+    import orclib
+    from bee2_amd import shard
+    from bee2_amd.engine import LEVEL_OID
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = orclib.load()
+    items = goldenlib.Golden().sigvfy_pipeline["128"]
+    lo, hi = shard.shard_range(rank, world, len(items))
+    out = []
+    for it in items[lo:hi]:                       # this rank's files: hash, validate the key, verify
+        msg, pub, sig = (bytes.fromhex(it[k]) for k in ("msg", "pubkey", "sig"))
+        dig = orc.belt_hash(msg)
+        out.append((dig.hex(), orc.pubkey_val(128, pub), orc.verify_l(128, LEVEL_OID[128], dig, sig, pub)))
+    bad = torch.tensor([sum(1 for _, k, v in out if k or v)])
+    dist.all_reduce(bad)                          # the only cross-rank traffic such a job needs: a count
+    with open(os.path.join(outdir, f"v{rank}.json"), "w") as f:
+        json.dump({"lo": lo, "hi": hi, "out": out, "bad_total": int(bad[0])}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_sigvfy_pipeline_equals_fixture(tmp_path, golden):
+    """hash -> key validation -> verification over index shards: no exchange step, the
+    concatenated verdicts are the reference's and the all-reduced failure count is the global one"""
+    import json
+    world = 2
+    mp.spawn(_sigvfy_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    items = golden.sigvfy_pipeline["128"]
+    got, pos = [], 0
+    for r in range(world):
+        d = json.load(open(tmp_path / f"v{r}.json"))
+        assert d["lo"] == pos
+        pos = d["hi"]
+        got += d["out"]
+        assert d["bad_total"] == sum(1 for it in items if it["pubkey_val"] or it["verify"])
+    assert pos == len(items)
+    assert [tuple(g) for g in got] == [(it["digest"], it["pubkey_val"], it["verify"]) for it in items]
