@@ -126,6 +126,17 @@ template <> struct BashRotC<5> { static constexpr int m1 = 56, n1 = 19, m2 = 34,
 template <> struct BashRotC<6> { static constexpr int m1 =  8, n1 =  5, m2 = 46, n2 = 17; };
 template <> struct BashRotC<7> { static constexpr int m1 = 56, n1 = 35, m2 =  2, n2 = 55; };
 
+// ---- issue priority follows the instruction class (r02) ---------------------------------------------
+// gfx950 arbitrates VALU issue oldest-wavefront-first.  A half-rate op (v_alignbit_b32) holds its unit for 4
+// cycles but needs one issue slot; full-rate ops of OTHER wavefronts can issue while it runs -- if the half-rate
+// op gets its slot in time.  With every wavefront at the same priority the older wavefronts' full-rate runs
+// take the slots, the half-rate unit idles, and mixed code runs 15 % slower than the two classes one after the
+// other.  s_setprio 3 for the half-rate runs and 0 for the full-rate runs: the bash round pattern
+// F80 H48 F32 H16 goes from 3.63 to 2.18 cycles per instruction per SIMD (tools/ubench/valu_overlap.hip,
+// profiles/r02_valu_overlap.txt; raising the priority of the FULL-rate runs instead: 3.69).
+__device__ __forceinline__ void bash_prio_half() { __builtin_amdgcn_s_setprio(3); }
+__device__ __forceinline__ void bash_prio_full() { __builtin_amdgcn_s_setprio(0); }
+
 struct BashStage { u64x2 u0[8], ra[8], rb[8], rc[8], t[8], u1[8], r2[8]; };
 template <int C> __device__ __forceinline__ void st_rot3(BashStage &q, u64x2 (&a)[24], const int (&ix)[24])
 {
@@ -135,6 +146,8 @@ template <int C> __device__ __forceinline__ void st_rot3(BashStage &q, u64x2 (&a
 }
 template <int C> __device__ __forceinline__ void st_rot1(BashStage &q) { q.r2[C] = vrotl64<BashRotC<C>::n2>(q.t[C]); }
 
+// PRIO: raise the wavefront's issue priority for the half-rate runs (see bash_prio_half / bash_prio_full below)
+template <bool PRIO = false>
 __device__ __forceinline__ void bash_s_layer_staged(u64x2 (&a)[24], const int (&ix)[24])
 {
     BashStage q;
@@ -143,14 +156,18 @@ __device__ __forceinline__ void bash_s_layer_staged(u64x2 (&a)[24], const int (&
         q.u0[c].lo = vbitop3<TT_XOR3>(a[ix[c]].lo, a[ix[8 + c]].lo, a[ix[16 + c]].lo);
         q.u0[c].hi = vbitop3<TT_XOR3>(a[ix[c]].hi, a[ix[8 + c]].hi, a[ix[16 + c]].hi);
     }
+    if constexpr (PRIO) bash_prio_half();
     st_rot3<0>(q, a, ix); st_rot3<1>(q, a, ix); st_rot3<2>(q, a, ix); st_rot3<3>(q, a, ix);
     st_rot3<4>(q, a, ix); st_rot3<5>(q, a, ix); st_rot3<6>(q, a, ix); st_rot3<7>(q, a, ix);
+    if constexpr (PRIO) bash_prio_full();
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         q.t[c].lo = vxor(a[ix[8 + c]].lo, q.ra[c].lo);  q.t[c].hi = vxor(a[ix[8 + c]].hi, q.ra[c].hi);
         q.u1[c].lo = vxor(q.t[c].lo, q.rb[c].lo);       q.u1[c].hi = vxor(q.t[c].hi, q.rb[c].hi);
     }
+    if constexpr (PRIO) bash_prio_half();
     st_rot1<0>(q); st_rot1<1>(q); st_rot1<2>(q); st_rot1<3>(q); st_rot1<4>(q); st_rot1<5>(q); st_rot1<6>(q); st_rot1<7>(q);
+    if constexpr (PRIO) bash_prio_full();
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         u64x2 u2;
@@ -160,6 +177,72 @@ __device__ __forceinline__ void bash_s_layer_staged(u64x2 (&a)[24], const int (&
         a[ix[8 + c]].lo = vbitop3<TT_S1>(q.u0[c].lo, q.u1[c].lo, u2.lo);   a[ix[8 + c]].hi = vbitop3<TT_S1>(q.u0[c].hi, q.u1[c].hi, u2.hi);
         a[ix[16 + c]].lo = vbitop3<TT_S2>(q.u0[c].lo, q.u1[c].lo, u2.lo);  a[ix[16 + c]].hi = vbitop3<TT_S2>(q.u0[c].hi, q.u1[c].hi, u2.hi);
     }
+}
+
+// ---- staged S-layer, second form (r02) ----------------------------------------------------------
+// Same stages, but (i) inside a stage no instruction reads the result of its predecessor (the first form
+// computed t and u1 = t ^ rb back to back, and u2 right before the three S-box outputs that need it: hipcc
+// pads every such asm -> asm dependency with an s_nop, 81 of them per 6 rounds, and the wavefront stalls on
+// the VALU latency anyway), and (ii) the stage width W is a parameter: W = 8 is one pass over all columns
+// (temporaries for 8 columns live), W = 4 two passes over 4 columns each (half the temporaries, shorter
+// runs of one instruction class).
+template <int C0, int W, int K = 0>
+__device__ __forceinline__ void st2_rot3(u64x2 (&ra)[8], u64x2 (&rb)[8], u64x2 (&rc)[8], const u64x2 (&u0)[8],
+                                         u64x2 (&a)[24], const int (&ix)[24])
+{
+    if constexpr (K < W) {
+        constexpr int C = C0 + K;
+        ra[C] = vrotl64<BashRotC<C>::n1>(u0[C]);
+        rb[C] = vrotl64<BashRotC<C>::m1>(a[ix[C]]);
+        rc[C] = vrotl64<BashRotC<C>::m2>(a[ix[16 + C]]);
+        st2_rot3<C0, W, K + 1>(ra, rb, rc, u0, a, ix);
+    }
+}
+template <int C0, int W, int K = 0>
+__device__ __forceinline__ void st2_rot1(u64x2 (&r2)[8], const u64x2 (&t)[8])
+{
+    if constexpr (K < W) {
+        r2[C0 + K] = vrotl64<BashRotC<C0 + K>::n2>(t[C0 + K]);
+        st2_rot1<C0, W, K + 1>(r2, t);
+    }
+}
+template <int C0, int W, bool PRIO>
+__device__ __forceinline__ void bash_s_cols_staged2(u64x2 (&a)[24], const int (&ix)[24])
+{
+    u64x2 u0[8], ra[8], rb[8], rc[8], t[8], u1[8], r2[8], u2[8];
+#pragma unroll
+    for (int c = C0; c < C0 + W; ++c) {
+        u0[c].lo = vbitop3<TT_XOR3>(a[ix[c]].lo, a[ix[8 + c]].lo, a[ix[16 + c]].lo);
+        u0[c].hi = vbitop3<TT_XOR3>(a[ix[c]].hi, a[ix[8 + c]].hi, a[ix[16 + c]].hi);
+    }
+    if constexpr (PRIO) bash_prio_half();
+    st2_rot3<C0, W>(ra, rb, rc, u0, a, ix);
+    if constexpr (PRIO) bash_prio_full();
+#pragma unroll
+    for (int c = C0; c < C0 + W; ++c) { t[c].lo = vxor(a[ix[8 + c]].lo, ra[c].lo); t[c].hi = vxor(a[ix[8 + c]].hi, ra[c].hi); }
+#pragma unroll
+    for (int c = C0; c < C0 + W; ++c) { u1[c].lo = vxor(t[c].lo, rb[c].lo); u1[c].hi = vxor(t[c].hi, rb[c].hi); }
+    if constexpr (PRIO) bash_prio_half();
+    st2_rot1<C0, W>(r2, t);
+    if constexpr (PRIO) bash_prio_full();
+#pragma unroll
+    for (int c = C0; c < C0 + W; ++c) {
+        u2[c].lo = vbitop3<TT_XOR3>(a[ix[16 + c]].lo, rc[c].lo, r2[c].lo);
+        u2[c].hi = vbitop3<TT_XOR3>(a[ix[16 + c]].hi, rc[c].hi, r2[c].hi);
+    }
+#pragma unroll
+    for (int c = C0; c < C0 + W; ++c) {
+        a[ix[c]].lo = vbitop3<TT_S0>(u0[c].lo, u1[c].lo, u2[c].lo);       a[ix[c]].hi = vbitop3<TT_S0>(u0[c].hi, u1[c].hi, u2[c].hi);
+        a[ix[8 + c]].lo = vbitop3<TT_S1>(u0[c].lo, u1[c].lo, u2[c].lo);   a[ix[8 + c]].hi = vbitop3<TT_S1>(u0[c].hi, u1[c].hi, u2[c].hi);
+        a[ix[16 + c]].lo = vbitop3<TT_S2>(u0[c].lo, u1[c].lo, u2[c].lo);  a[ix[16 + c]].hi = vbitop3<TT_S2>(u0[c].hi, u1[c].hi, u2[c].hi);
+    }
+}
+template <int W, bool PRIO = false>
+__device__ __forceinline__ void bash_s_layer_staged2(u64x2 (&a)[24], const int (&ix)[24])
+{
+    if constexpr (W == 8) bash_s_cols_staged2<0, 8, PRIO>(a, ix);
+    else if constexpr (W == 4) { bash_s_cols_staged2<0, 4, PRIO>(a, ix); bash_s_cols_staged2<4, 4, PRIO>(a, ix); }
+    else { bash_s_cols_staged2<0, 2, PRIO>(a, ix); bash_s_cols_staged2<2, 2, PRIO>(a, ix); bash_s_cols_staged2<4, 2, PRIO>(a, ix); bash_s_cols_staged2<6, 2, PRIO>(a, ix); }
 }
 
 // logical word k of the next round = logical word BASH_PERM[k] of this round:
@@ -195,12 +278,21 @@ __device__ __forceinline__ uint64_t bash_next_const(uint64_t c)
     return (c >> 1) ^ (0xDC2BE1997FE0D8AEull & (0ull - (c & 1ull)));
 }
 
-template <int R, bool STAGED>
+// ORDER: 0 = compiler's order ("compact"), 1 = staged (r01), 28 / 24 / 22 = staged, second form, W = 8 / 4 / 2;
+// +100: issue priority follows the instruction class
+template <int R, int ORDER>
 __device__ __forceinline__ void bash_round(u64x2 (&a)[24], uint64_t &c)
 {
     constexpr BashSlots S{};
-    if constexpr (STAGED) bash_s_layer_staged(a, S.m[R]);
-    else                  bash_s_layer(a, S.m[R]);
+    if constexpr (ORDER == 1)        bash_s_layer_staged<false>(a, S.m[R]);
+    else if constexpr (ORDER == 101) bash_s_layer_staged<true>(a, S.m[R]);
+    else if constexpr (ORDER == 28)  bash_s_layer_staged2<8>(a, S.m[R]);
+    else if constexpr (ORDER == 24)  bash_s_layer_staged2<4>(a, S.m[R]);
+    else if constexpr (ORDER == 22)  bash_s_layer_staged2<2>(a, S.m[R]);
+    else if constexpr (ORDER == 128) bash_s_layer_staged2<8, true>(a, S.m[R]);
+    else if constexpr (ORDER == 124) bash_s_layer_staged2<4, true>(a, S.m[R]);
+    else if constexpr (ORDER == 122) bash_s_layer_staged2<2, true>(a, S.m[R]);
+    else                            bash_s_layer(a, S.m[R]);
     // after the word permutation the constant lands on logical word 23 of the next round
     constexpr int slot = S.m[R + 1][23];
     a[slot].lo ^= (uint32_t)c;
@@ -209,7 +301,7 @@ __device__ __forceinline__ void bash_round(u64x2 (&a)[24], uint64_t &c)
 }
 
 // the permutation: 4 x 6 rounds.  STAGED picks the issue order of the S-layer (see above).
-template <bool STAGED = false>
+template <int STAGED = 0>
 __device__ __forceinline__ void bash_f(u64x2 (&a)[24])
 {
     uint64_t c = 0x3BF5080AC8BA94B1ull;

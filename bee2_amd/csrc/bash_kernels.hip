@@ -106,17 +106,286 @@ void bashF_batch_kernel(uint8_t *__restrict__ states, size_t n)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// r02 variants of the batch kernel (profiles/r02_bashF_variants.txt has the A/B numbers).
+//
+// LDS-DMA load: global_load_lds_dwordx4 writes lane i's 16 bytes to <wave-uniform base> + 16 i, so the
+// LDS image of one instruction is 64 consecutive 16-byte slots and the record stride cannot be padded
+// by the *destination*.  The padded layout (13 slots per record, slot 12 unused) is produced by the
+// *source* instead: 13 instructions cover the 832 slots, lane i of instruction k fills slot
+// s = 64 k + i with chunk min(s mod 13, 11) of record s div 13 (the pad slot re-reads chunk 11 of the
+// same record: same memory line, no extra traffic).  No VGPR round trip, no ds_write_b128.
+__device__ __forceinline__ void bashF_dma_tile(const uint8_t *g, uint8_t *wl, int lane, int cnt)
+{
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        const unsigned s = 64u * k + lane;
+        unsigned r = (s * 5042u) >> 16;                    // s div 13 for s < 832
+        unsigned j = s - 13u * r;
+        j = j > 11u ? 11u : j;
+        r = r < (unsigned)cnt ? r : (unsigned)cnt - 1u;    // ragged tile: stay inside the batch
+        const uint8_t *src = g + r * BASHF_REC + j * 16u;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(wl + 1024 * k), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void bashF_read_slab(u64x2 (&a)[24], const uint8_t *wl, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(wl + lane * BASHF_PAD + 16 * j);
+        a[2 * j].lo = v.x; a[2 * j].hi = v.y; a[2 * j + 1].lo = v.z; a[2 * j + 1].hi = v.w;
+    }
+}
+// Ordering of one wavefront's own LDS traffic.  A workgroup-scope release fence also waits for the
+// wavefront's outstanding *global* stores (vmcnt(0)) -- in a walking wavefront that exposed the store
+// latency of every tile (r02: 171 us instead of 118), and at the end of a one-tile kernel it keeps the
+// slab allocated until the stores are acknowledged.  DS operations of one wavefront execute in order,
+// so all that is needed is that the compiler keeps the order and that returned data has arrived.
+__device__ __forceinline__ void bashF_wave_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+// registers -> slab (transposed) -> coalesced 1 KiB global stores
+__device__ __forceinline__ void bashF_store_via_slab(const u64x2 (&a)[24], uint8_t *g, uint8_t *wl, int lane, int cnt)
+{
+    if (lane < cnt) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            uint4 v;
+            v.x = a[2 * j].lo; v.y = a[2 * j].hi; v.z = a[2 * j + 1].lo; v.w = a[2 * j + 1].hi;
+            *reinterpret_cast<uint4 *>(wl + lane * BASHF_PAD + 16 * j) = v;
+        }
+    }
+    bashF_wave_sync();
+    const int bytes = cnt * BASHF_REC;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const int o = k * 1024 + lane * 16;
+        if (o < bytes) {
+            const int rec = o / BASHF_REC, off = o % BASHF_REC;
+            const uint4 v = *reinterpret_cast<const uint4 *>(wl + rec * BASHF_PAD + off);
+            *reinterpret_cast<uint4 *>(g + o) = v;
+        }
+    }
+}
+// registers -> global, every lane its own record (16-byte pieces at stride 192)
+__device__ __forceinline__ void bashF_store_direct(const u64x2 (&a)[24], uint8_t *g, int lane, int cnt)
+{
+    if (lane < cnt) {
+        uint4 *p = reinterpret_cast<uint4 *>(g + lane * BASHF_REC);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            uint4 v;
+            v.x = a[2 * j].lo; v.y = a[2 * j].hi; v.z = a[2 * j + 1].lo; v.w = a[2 * j + 1].hi;
+            p[j] = v;
+        }
+    }
+}
+
+// Generic one-tile-per-wavefront kernel.  LOAD / STORE: 0 = direct (every lane its own record, 16-byte
+// pieces at stride 192), 1 = through a 64-record slab (13 KiB per wavefront; load by LDS-DMA), 2 = through a
+// 32-record half slab in two passes (7 KiB per wavefront).  ORDER: issue order of the S-layer (bash_dev.hpp).
+template <int LOAD, int STORE>
+constexpr int bashF_tile_lds()
+{
+    return (LOAD == 1 || STORE == 1) ? 64 * BASHF_PAD : (LOAD == 2 || STORE == 2) ? 7168 : 0;
+}
+template <int LOAD, int STORE, int ORDER, int MINW>
+__global__ __launch_bounds__(BASHF_WG, MINW)
+void bashF_tile_kernel(uint8_t *__restrict__ states, size_t n)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *wl = smem + wave * bashF_tile_lds<LOAD, STORE>();
+    const size_t first = ((size_t)blockIdx.x * (BASHF_WG / 64) + wave) * 64;
+    if (first >= n) return;
+    const size_t left = n - first;
+    const int cnt = left < 64 ? (int)left : 64;
+    uint8_t *g = states + first * BASHF_REC;
+    u64x2 a[24];
+    if constexpr (LOAD == 0) {
+        const int r = lane < cnt ? lane : cnt - 1;
+        const uint4 *p = reinterpret_cast<const uint4 *>(g + r * BASHF_REC);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const uint4 v = p[j];
+            a[2 * j].lo = v.x; a[2 * j].hi = v.y; a[2 * j + 1].lo = v.z; a[2 * j + 1].hi = v.w;
+        }
+    } else if constexpr (LOAD == 1) {
+        bashF_dma_tile(g, wl, lane, cnt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bashF_read_slab(a, wl, lane);
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // records [32h, 32h + 32): 416 slots of the padded layout, 7 instructions (the last 32 lanes of
+            // the seventh land in the spare KiB of the 7 KiB half slab)
+            if (h) bashF_wave_sync();
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const unsigned s = 64u * k + lane;
+                unsigned r = (s * 5042u) >> 16;
+                unsigned j = s - 13u * r;
+                j = j > 11u ? 11u : j;
+                r += 32u * h;
+                r = r < (unsigned)cnt ? r : (unsigned)cnt - 1u;
+                const uint8_t *src = g + r * BASHF_REC + j * 16u;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(wl + 1024 * k), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((lane >> 5) == h) bashF_read_slab(a, wl, lane & 31);
+        }
+    }
+
+    bash_f<ORDER>(a);
+
+    if constexpr (STORE == 0) bashF_store_direct(a, g, lane, cnt);
+    else if constexpr (STORE == 1) { bashF_wave_sync(); bashF_store_via_slab(a, g, wl, lane, cnt); }
+    else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bashF_wave_sync();
+            if ((lane >> 5) == h && lane < cnt) {
+#pragma unroll
+                for (int j = 0; j < 12; ++j) {
+                    uint4 v;
+                    v.x = a[2 * j].lo; v.y = a[2 * j].hi; v.z = a[2 * j + 1].lo; v.w = a[2 * j + 1].hi;
+                    *reinterpret_cast<uint4 *>(wl + (lane & 31) * BASHF_PAD + 16 * j) = v;
+                }
+            }
+            bashF_wave_sync();
+            const int bytes = cnt * BASHF_REC - h * 6144;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int o = k * 1024 + lane * 16;
+                if (o < bytes) {
+                    const int rec = o / BASHF_REC, off = o % BASHF_REC;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(wl + rec * BASHF_PAD + off);
+                    *reinterpret_cast<uint4 *>(g + h * 6144 + o) = v;
+                }
+            }
+        }
+    }
+}
+
+// V4 / V5: persistent wavefronts.  A wavefront walks tiles t, t + nwaves, ...; the LDS-DMA of the next
+// tile is in flight during the 24 rounds of the current one (it costs LDS, not VGPRs), so the memory
+// phase of a wavefront overlaps its own arithmetic.  V4 stores through the slab: after the rounds the
+// next tile moves slab -> second register set, the results go registers -> slab -> memory, and only
+// then is the slab handed to the DMA of the tile after next.  V5 stores directly (slab is free as soon
+// as it has been read).
+template <bool DIRECT_STORE, int STAGED>
+__global__ __launch_bounds__(BASHF_WG, 3)
+void bashF_walk_kernel(uint8_t *__restrict__ states, size_t n, unsigned nwaves)
+{
+    // 256-lane workgroups only so that the four wavefronts land on the four SIMDs (one-wavefront
+    // workgroups were placed unevenly: 172 us); the wavefronts never synchronise with each other.
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *wl = smem + wave * (64 * BASHF_PAD);
+    const int lane = threadIdx.x & 63;
+    const size_t ntiles = (n + 63) / 64;
+    size_t tile = (size_t)blockIdx.x * (BASHF_WG / 64) + wave;
+    if (tile >= ntiles) return;
+    auto count = [&](size_t t) { const size_t left = n - t * 64; return left < 64 ? (int)left : 64; };
+    u64x2 a[24];
+    bashF_dma_tile(states + tile * 64 * BASHF_REC, wl, lane, count(tile));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bashF_read_slab(a, wl, lane);
+    for (;;) {
+        const size_t next = tile + nwaves;
+        const bool more = next < ntiles;
+        uint8_t *g = states + tile * 64 * BASHF_REC;
+        const int cnt = count(tile);
+        bashF_wave_sync();                                  // slab reads done before the DMA may overwrite it
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                        // keep the 13 source offsets out of the loop-invariant set
+        if (more) bashF_dma_tile(states + next * 64 * BASHF_REC, wl, ln, count(next));
+        bash_f<STAGED>(a);
+        if constexpr (DIRECT_STORE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the DMA landed long ago; waiting *before* the
+            bashF_store_direct(a, g, ln, cnt);                   // stores keeps their latency off this wavefront
+            if (!more) break;
+            bashF_read_slab(a, wl, ln);
+        } else {
+            u64x2 b[24];
+            int l2 = lane;
+            asm volatile("" : "+v"(l2));
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bashF_read_slab(b, wl, l2);
+            }
+            bashF_wave_sync();
+            bashF_store_via_slab(a, g, wl, l2, cnt);
+            if (!more) break;
+#pragma unroll
+            for (int j = 0; j < 24; ++j) a[j] = b[j];
+        }
+        tile = next;
+    }
+}
+
+template <int LOAD, int STORE, int ORDER, int MINW>
+static void launch_bashF_tile(unsigned grid, uint8_t *p, size_t n, hipStream_t st)
+{
+    constexpr int lds = 4 * bashF_tile_lds<LOAD, STORE>();
+    auto k = bashF_tile_kernel<LOAD, STORE, ORDER, MINW>;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(BASHF_WG), lds, st, p, n);
+}
+
+static int g_bashF_variant = 0;
+void set_bashF_variant(int v) { g_bashF_variant = v; }
+
 err_t launch_bashF_batch(void *d_states, size_t n, hipStream_t st)
 {
     if (n == 0) return ERR_OK;
     const size_t per_wg = BASHF_WG;           // one state per lane
     const size_t grid = (n + per_wg - 1) / per_wg;
     if (grid > 0x7fffffffull) return ERR_BAD_INPUT;
-    // PASSES = 1: 64 records staged at once (13 KiB LDS per wavefront, 3 wavefronts/SIMD).
-    // PASSES = 2 (6.5 KiB, 5-6 wavefronts/SIMD) measured the same within noise on MI355X:
-    // the kernel is VALU-issue bound, not latency bound.
-    hipLaunchKernelGGL(bashF_batch_kernel<1>, dim3((unsigned)grid), dim3(BASHF_WG),
-                       (BASHF_WG / 64) * 64 * BASHF_PAD, st, (uint8_t *)d_states, n);
+    uint8_t *p = (uint8_t *)d_states;
+    const size_t lds4 = (BASHF_WG / 64) * 64 * BASHF_PAD;
+    const int v = g_bashF_variant;
+    const size_t ntiles = (n + 63) / 64;
+    const unsigned nwg = (unsigned)((ntiles + 3) / 4 < 768 ? (ntiles + 3) / 4 : 768);   // 256 CUs x 3 workgroups (12 slabs of 13 KiB)
+    const unsigned nwaves = nwg * 4;
+#define TILE(L, S, O, W) launch_bashF_tile<L, S, O, W>((unsigned)grid, p, n, st)
+    switch (v) {
+    case 1: TILE(1, 1, 1, 3); break;        // LDS-DMA load, slab store, r01 staged order
+    case 2: TILE(1, 0, 1, 3); break;        // LDS-DMA load, direct store
+    case 3: TILE(0, 0, 1, 4); break;        // no LDS, r01 staged order
+    case 4: hipLaunchKernelGGL((bashF_walk_kernel<false, 1>), dim3(nwg), dim3(BASHF_WG), lds4, st, p, n, nwaves); break;
+    case 5: hipLaunchKernelGGL((bashF_walk_kernel<true, 1>), dim3(nwg), dim3(BASHF_WG), lds4, st, p, n, nwaves); break;
+    case 6: TILE(0, 0, 0, 6); break;        // no LDS, compiler's order
+    case 7: TILE(0, 0, 0, 8); break;
+    case 10: TILE(0, 0, 28, 4); break;      // no LDS, staged second form W = 8
+    case 11: TILE(0, 0, 24, 4); break;      // W = 4
+    case 12: TILE(0, 0, 24, 5); break;
+    case 13: TILE(0, 0, 24, 6); break;
+    case 14: TILE(0, 0, 22, 6); break;      // W = 2
+    case 15: TILE(0, 0, 22, 8); break;
+    case 16: TILE(0, 2, 28, 4); break;      // direct load, half-slab store
+    case 17: TILE(2, 2, 28, 4); break;      // half-slab DMA load, half-slab store
+    case 18: TILE(0, 2, 24, 5); break;
+    case 19: TILE(1, 1, 28, 3); break;      // LDS-DMA load, slab store, second form
+    case 20: TILE(0, 0, 1, 5); break;       // no LDS, r01 staged order, 5 wavefronts/SIMD
+    case 30: TILE(0, 0, 101, 4); break;     // class-following priority: no LDS, r01 staged
+    case 31: TILE(0, 0, 128, 4); break;     // no LDS, staged2 W = 8
+    case 32: TILE(0, 0, 124, 6); break;     // no LDS, staged2 W = 4
+    case 33: TILE(0, 0, 122, 8); break;     // no LDS, staged2 W = 2
+    case 34: TILE(0, 2, 124, 5); break;     // direct load, half-slab store, W = 4
+    case 35: TILE(1, 1, 101, 3); break;     // LDS-DMA load, slab store, r01 staged
+    case 36: TILE(0, 2, 128, 4); break;     // direct load, half-slab store, W = 8
+    case 37: TILE(2, 2, 124, 5); break;     // half-slab DMA load + half-slab store, W = 4
+    default:
+        // PASSES = 1: 64 records staged at once (13 KiB LDS per wavefront, 3 wavefronts/SIMD).
+        hipLaunchKernelGGL(bashF_batch_kernel<1>, dim3((unsigned)grid), dim3(BASHF_WG), lds4, st, p, n);
+    }
+#undef TILE
     B2H_TRY(hipGetLastError());
     return ERR_OK;
 }

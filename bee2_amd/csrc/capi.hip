@@ -810,6 +810,17 @@ extern "C" err_t bee2hip_bashHash_beltMAC_batch(const octet *msgs, size_t msg_le
     return ERR_OK;
 }
 
+// ============================================================ internal tuning hook ===
+// A/B switch for experiment builds (tools/bashf_ab.py); not part of the product ABI (BEE2HIP_INTERNAL).
+namespace bee2hip { void set_bashF_variant(int v); }
+extern "C" err_t bee2hip_internal_tune(int key, int value)
+{
+    switch (key) {
+    case 0: bee2hip::set_bashF_variant(value); return ERR_OK;
+    default: return ERR_BAD_INPUT;
+    }
+}
+
 // ============================================================ kernel timing ===
 extern "C" err_t bee2hip_time_kernel(int which, int reps, void *d_a, void *d_b, void *d_c, void *d_d,
                                      size_t n, size_t aux, void *stream, float *ms)

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <string.h>
 #include "../../include/bee2hip.h"
+#include "../../include/bee2hip_internal.h"
 
 namespace bee2hip {
 

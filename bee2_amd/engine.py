@@ -76,8 +76,9 @@ BATCH_SYMBOLS = [
     "bee2hip_bignPubkeyVal_batch", "bee2hip_bignPubkeyValL_batch_dev",
     "bee2hip_bashHash_beltMAC_batch_dev",
     "bee2hip_set_device", "bee2hip_sync", "bee2hip_last_error", "bee2hip_version",
-    "bee2hip_time_kernel",
 ]
+# include/bee2hip_internal.h: test / bench hooks, not product ABI
+INTERNAL_SYMBOLS = ["bee2hip_time_kernel", "bee2hip_debug_fe", "bee2hip_debug_feL", "bee2hip_internal_tune"]
 
 
 def lib_exports(path=LIB_PATH):
@@ -103,7 +104,7 @@ class Engine:
         for name in ("bashF_deep", "bashHash_keep", "beltCTR_keep", "beltMAC_keep", "beltECB_keep", "beltCBC_keep"):
             if hasattr(L, name):
                 getattr(L, name).restype = _sz
-        for name in DROPIN_SYMBOLS + BATCH_SYMBOLS:
+        for name in DROPIN_SYMBOLS + BATCH_SYMBOLS + INTERNAL_SYMBOLS:
             f = getattr(L, name, None)
             if f is not None and name.startswith(("bee2hip_", "bash", "belt", "bign")) and \
                     name not in ("bee2hip_last_error", "bee2hip_version", "beltH", "bashF_deep",

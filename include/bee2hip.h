@@ -348,19 +348,6 @@ err_t bee2hip_sync(void *stream);
 const char *bee2hip_last_error(void);
 /* "bee2hip <ver> gfx950" */
 const char *bee2hip_version(void);
-/* time `reps` launches of one kernel with hipEvents on `stream`; returns the
-   average milliseconds per launch in *ms (used by bench.py's roofline object).
-   which: 0 bashF_batch, 1 beltCTR_blocks, 2 bign128Verify_batch, 3 bashHash_beltMAC */
-err_t bee2hip_time_kernel(int which, int reps, void *d_a, void *d_b, void *d_c, void *d_d,
-                          size_t n, size_t aux, void *stream, float *ms);
-
-/* self-test hook: element-wise GF(2^256-189) ops on device arrays of 8 x u32 limbs
-   (op: 0 mul, 1 sqr, 2 add, 3 sub, 4 inv, 5 3*mul, 6 8*sqr, 7 canon, 8 x(2P)) */
-err_t bee2hip_debug_fe(int op, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
-/* same over GF(2^(2l) - c) for l in {128, 192, 256} (8 / 12 / 16 limbs per element) */
-err_t bee2hip_debug_feL(size_t l, int op, const void *d_a, const void *d_b, void *d_out, size_t n,
-                        void *stream);
-
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

@@ -1,0 +1,24 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/bashf_pmc
+rm -rf $O; mkdir -p $O
+rocprofv3 -L > $O/counters.txt 2>&1
+for v in 0 3 18; do
+  i=0
+  for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM" "GRBM_GUI_ACTIVE GRBM_COUNT" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+    rocprofv3 --pmc $set --output-format csv -d $O/v${v}_s$i -o b -- python $R/tools/bashf_run.py $v 20 12 > $O/v${v}_s$i.log 2>&1
+    i=$((i+1))
+  done
+done
+cd $R
+python - <<PY
+import csv, collections, glob
+for f in sorted(glob.glob("gpurun_out/bashf_pmc/v*/b_counter_collection.csv")):
+    d=collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k=r["Kernel_Name"].split("(")[0][-40:]
+        if "bashF" not in k: continue
+        d[k][r["Counter_Name"]].append(float(r["Counter_Value"])); d[k]["dur_ns"].append(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))
+    for k,v in d.items():
+        print(f.split("/")[2], k, {c: round(sum(x[2:])/len(x[2:]),1) for c,x in v.items()})
+PY
