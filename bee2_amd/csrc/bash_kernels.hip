@@ -191,12 +191,16 @@ __device__ __forceinline__ void bashF_store_direct(const u64x2 (&a)[24], uint8_t
 template <int LOAD, int STORE>
 constexpr int bashF_tile_lds()
 {
-    return (LOAD == 1 || STORE == 1) ? 64 * BASHF_PAD : (LOAD == 2 || STORE == 2) ? 7168 : 0;
+    // STORE = P in {2, 4, 8}: P passes of 64 / P records through a slab of that many padded records
+    return (LOAD == 1 || STORE == 1) ? 64 * BASHF_PAD : LOAD == 2 ? 7168 : (STORE == 2 || STORE == 4 || STORE == 8) ? (64 / STORE) * BASHF_PAD : 0;
 }
-template <int LOAD, int STORE, int ORDER, int MINW>
+template <int LOAD, int STORE, int ORDER, int MINW, int FLAGS = 0>
 __global__ __launch_bounds__(BASHF_WG, MINW)
 void bashF_tile_kernel(uint8_t *__restrict__ states, size_t n)
 {
+    // FLAGS & 1: the new wavefront is the youngest on its SIMD; without help its address arithmetic and load issue
+    // wait behind every older wavefront's VALU work.  Priority 3 until the loads are out.
+    if constexpr (FLAGS & 1) __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -207,7 +211,10 @@ void bashF_tile_kernel(uint8_t *__restrict__ states, size_t n)
     const int cnt = left < 64 ? (int)left : 64;
     uint8_t *g = states + first * BASHF_REC;
     u64x2 a[24];
-    if constexpr (LOAD == 0) {
+    if constexpr (LOAD == 9) {                     // ablation: no memory phase
+#pragma unroll
+        for (int j = 0; j < 24; ++j) { a[j].lo = lane * (2 * j + 1) + (uint32_t)first; a[j].hi = lane ^ (j * 0x9E3779B9u); }
+    } else if constexpr (LOAD == 0) {
         const int r = lane < cnt ? lane : cnt - 1;
         const uint4 *p = reinterpret_cast<const uint4 *>(g + r * BASHF_REC);
 #pragma unroll
@@ -242,31 +249,39 @@ void bashF_tile_kernel(uint8_t *__restrict__ states, size_t n)
         }
     }
 
-    bash_f<ORDER>(a);
+    if constexpr (FLAGS & 1) __builtin_amdgcn_s_setprio(0);
+    if constexpr (ORDER >= 0) bash_f<ORDER>(a);
+    if constexpr (FLAGS & 2) __builtin_amdgcn_s_setprio(3);          // drain the store phase ahead of others' arithmetic
 
-    if constexpr (STORE == 0) bashF_store_direct(a, g, lane, cnt);
+    if constexpr (STORE == 9) {                    // ablation: keep the result alive with one dword per lane
+        uint32_t x = 0;
+#pragma unroll
+        for (int j = 0; j < 24; ++j) x ^= a[j].lo ^ a[j].hi;
+        if (x == 0x12345678u) *reinterpret_cast<uint32_t *>(g + lane * 4) = x;
+    } else if constexpr (STORE == 0) bashF_store_direct(a, g, lane, cnt);
     else if constexpr (STORE == 1) { bashF_wave_sync(); bashF_store_via_slab(a, g, wl, lane, cnt); }
     else {
+        constexpr int P = STORE, RECS = 64 / P, SLAB = RECS * BASHF_REC;      // SLAB bytes of states per pass
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < P; ++h) {
             bashF_wave_sync();
-            if ((lane >> 5) == h && lane < cnt) {
+            if (lane / RECS == h && lane < cnt) {
 #pragma unroll
                 for (int j = 0; j < 12; ++j) {
                     uint4 v;
                     v.x = a[2 * j].lo; v.y = a[2 * j].hi; v.z = a[2 * j + 1].lo; v.w = a[2 * j + 1].hi;
-                    *reinterpret_cast<uint4 *>(wl + (lane & 31) * BASHF_PAD + 16 * j) = v;
+                    *reinterpret_cast<uint4 *>(wl + (lane % RECS) * BASHF_PAD + 16 * j) = v;
                 }
             }
             bashF_wave_sync();
-            const int bytes = cnt * BASHF_REC - h * 6144;
+            const int bytes = cnt * BASHF_REC - h * SLAB;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
+            for (int k = 0; k < SLAB / 1024; ++k) {
                 const int o = k * 1024 + lane * 16;
                 if (o < bytes) {
                     const int rec = o / BASHF_REC, off = o % BASHF_REC;
                     const uint4 v = *reinterpret_cast<const uint4 *>(wl + rec * BASHF_PAD + off);
-                    *reinterpret_cast<uint4 *>(g + h * 6144 + o) = v;
+                    *reinterpret_cast<uint4 *>(g + h * SLAB + o) = v;
                 }
             }
         }
@@ -330,11 +345,11 @@ void bashF_walk_kernel(uint8_t *__restrict__ states, size_t n, unsigned nwaves)
     }
 }
 
-template <int LOAD, int STORE, int ORDER, int MINW>
+template <int LOAD, int STORE, int ORDER, int MINW, int FLAGS = 0>
 static void launch_bashF_tile(unsigned grid, uint8_t *p, size_t n, hipStream_t st)
 {
     constexpr int lds = 4 * bashF_tile_lds<LOAD, STORE>();
-    auto k = bashF_tile_kernel<LOAD, STORE, ORDER, MINW>;
+    auto k = bashF_tile_kernel<LOAD, STORE, ORDER, MINW, FLAGS>;
     hipLaunchKernelGGL(k, dim3(grid), dim3(BASHF_WG), lds, st, p, n);
 }
 
@@ -354,6 +369,7 @@ err_t launch_bashF_batch(void *d_states, size_t n, hipStream_t st)
     const unsigned nwg = (unsigned)((ntiles + 3) / 4 < 768 ? (ntiles + 3) / 4 : 768);   // 256 CUs x 3 workgroups (12 slabs of 13 KiB)
     const unsigned nwaves = nwg * 4;
 #define TILE(L, S, O, W) launch_bashF_tile<L, S, O, W>((unsigned)grid, p, n, st)
+#define TILEF(L, S, O, W, F) launch_bashF_tile<L, S, O, W, F>((unsigned)grid, p, n, st)
     switch (v) {
     case 1: TILE(1, 1, 1, 3); break;        // LDS-DMA load, slab store, r01 staged order
     case 2: TILE(1, 0, 1, 3); break;        // LDS-DMA load, direct store
@@ -381,11 +397,29 @@ err_t launch_bashF_batch(void *d_states, size_t n, hipStream_t st)
     case 35: TILE(1, 1, 101, 3); break;     // LDS-DMA load, slab store, r01 staged
     case 36: TILE(0, 2, 128, 4); break;     // direct load, half-slab store, W = 8
     case 37: TILE(2, 2, 124, 5); break;     // half-slab DMA load + half-slab store, W = 4
+    case 50: TILEF(0, 2, 128, 4, 1); break;  // v36 + priority 3 until the loads are issued
+    case 51: TILEF(0, 2, 128, 4, 3); break;  //     + priority 3 for the store phase too
+    case 52: TILE(0, 4, 122, 8); break;      // quarter-slab store, W = 2, 8 wavefronts/SIMD
+    case 53: TILEF(0, 4, 122, 8, 1); break;
+    case 54: TILE(0, 2, 124, 6); break;      // half-slab (6.5 KiB) store, W = 4, 6 wavefronts/SIMD
+    case 55: TILEF(0, 2, 124, 6, 1); break;
+    case 56: TILEF(0, 4, 124, 6, 1); break;  // quarter-slab, W = 4
+    case 57: TILEF(0, 8, 122, 8, 1); break;  // eighth-slab, W = 2
+    case 58: TILEF(0, 0, 122, 8, 1); break;  // direct store, W = 2, 8 wavefronts
+    case 59: TILEF(0, 4, 101, 4, 1); break;  // quarter-slab, r01 staged
+    case 40: TILE(9, 9, 128, 4); break;     // ablation: rounds only, W = 8, priority
+    case 41: TILE(9, 9, 28, 4); break;      //           rounds only, W = 8, no priority
+    case 42: TILE(0, 2, -1, 4); break;      //           memory only: direct load, half-slab store
+    case 43: TILE(0, 0, -1, 4); break;      //           memory only: direct load, direct store
+    case 44: TILE(9, 9, 124, 6); break;     //           rounds only, W = 4, priority
+    case 45: TILE(9, 9, 122, 8); break;     //           rounds only, W = 2, priority
+    case 46: TILE(9, 9, 101, 4); break;     //           rounds only, r01 staged, priority
     default:
         // PASSES = 1: 64 records staged at once (13 KiB LDS per wavefront, 3 wavefronts/SIMD).
         hipLaunchKernelGGL(bashF_batch_kernel<1>, dim3((unsigned)grid), dim3(BASHF_WG), lds4, st, p, n);
     }
 #undef TILE
+#undef TILEF
     B2H_TRY(hipGetLastError());
     return ERR_OK;
 }

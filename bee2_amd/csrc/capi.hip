@@ -821,6 +821,27 @@ extern "C" err_t bee2hip_internal_tune(int key, int value)
     }
 }
 
+// shader-clock probe: one wavefront spins for `us` microseconds of s_memrealtime (100 MHz) and reports how many
+// shader cycles (s_memtime) went by -- launched on a second stream beside the kernels under test, it gives the
+// clock the chip actually sustained under that load (DVFS: MI355X_MICROARCH.md "DVFS give-back")
+__global__ void clock_probe_kernel(unsigned long long *out, unsigned long long ticks)
+{
+    unsigned long long t0, r0, t1, r1;
+    asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
+    do {
+        __builtin_amdgcn_s_sleep(32);
+        asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+    } while (r1 - r0 < ticks);
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+}
+extern "C" err_t bee2hip_internal_clock_probe(void *d_out16, unsigned us, void *stream)
+{
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, as_stream(stream), (unsigned long long *)d_out16,
+                       (unsigned long long)us * 100ull);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
 // ============================================================ kernel timing ===
 extern "C" err_t bee2hip_time_kernel(int which, int reps, void *d_a, void *d_b, void *d_c, void *d_d,
                                      size_t n, size_t aux, void *stream, float *ms)

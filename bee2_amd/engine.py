@@ -78,7 +78,8 @@ BATCH_SYMBOLS = [
     "bee2hip_set_device", "bee2hip_sync", "bee2hip_last_error", "bee2hip_version",
 ]
 # include/bee2hip_internal.h: test / bench hooks, not product ABI
-INTERNAL_SYMBOLS = ["bee2hip_time_kernel", "bee2hip_debug_fe", "bee2hip_debug_feL", "bee2hip_internal_tune"]
+INTERNAL_SYMBOLS = ["bee2hip_time_kernel", "bee2hip_debug_fe", "bee2hip_debug_feL", "bee2hip_internal_tune",
+                    "bee2hip_internal_clock_probe"]
 
 
 def lib_exports(path=LIB_PATH):

@@ -29,6 +29,9 @@ err_t bee2hip_debug_fe(int op, const void *d_a, const void *d_b, void *d_out, si
 err_t bee2hip_debug_feL(size_t l, int op, const void *d_a, const void *d_b, void *d_out, size_t n,
                         void *stream);
 
+/* one wavefront spins for `us` microseconds on `stream` and writes {shader cycles, 100 MHz ticks} to d_out16:
+   the clock the chip sustains under whatever runs beside it */
+err_t bee2hip_internal_clock_probe(void *d_out16, unsigned us, void *stream);
 /* experiment switch: key 0 = bashF batch kernel variant (tools/bashf_ab.py) */
 err_t bee2hip_internal_tune(int key, int value);
 

@@ -26,7 +26,17 @@ NAMES = {0: "r01 product: VGPR-staged load, slab store, staged order",
          30: "PRIO: no LDS, staged r01", 31: "PRIO: no LDS, staged2 W=8", 32: "PRIO: no LDS, staged2 W=4",
          33: "PRIO: no LDS, staged2 W=2", 34: "PRIO: direct load, half-slab store, W=4",
          35: "PRIO: LDS-DMA load, slab store, staged r01", 36: "PRIO: direct load, half-slab store, W=8",
-         37: "PRIO: half-slab DMA load + store, W=4"}
+         37: "PRIO: half-slab DMA load + store, W=4",
+         50: "v36 + prio 3 until loads issued", 51: "v36 + prio 3 for load issue and store phase",
+         52: "PRIO W=2 (8 w/SIMD), quarter-slab store", 53: "  + prio 3 until loads issued",
+         54: "PRIO W=4 (6 w/SIMD), half-slab 6.5 KiB store", 55: "  + prio 3 until loads issued",
+         56: "PRIO W=4, quarter-slab store, load prio", 57: "PRIO W=2, eighth-slab store, load prio",
+         58: "PRIO W=2, direct store, load prio", 59: "PRIO r01 staged, quarter-slab store, load prio",
+         40: "ablation: rounds only, W=8, PRIO", 41: "ablation: rounds only, W=8, no priority",
+         42: "ablation: memory only (direct load, half-slab store)", 43: "ablation: memory only (direct load + store)",
+         44: "ablation: rounds only, W=4, PRIO (6 w/SIMD)", 45: "ablation: rounds only, W=2, PRIO (8 w/SIMD)",
+         46: "ablation: rounds only, r01 staged, PRIO"}
+ABLATION = {40, 41, 42, 43, 44, 45, 46}
 
 
 def main():
@@ -43,6 +53,9 @@ def main():
     ok = {}
     for v in variants:
         assert tune(0, v) == 0
+        if v in ABLATION:
+            ok[v] = True
+            continue
         for n in (n_par, 1, 63, 64, 65, 4097):
             t = src[: 192 * n].clone()
             eng.bashF_batch_dev(t)
@@ -55,16 +68,26 @@ def main():
         st = torch.empty(192 * n, dtype=torch.uint8, device="cuda")
         st.random_(0, 256)
         res = {v: [] for v in variants}
+        ghz = {v: [] for v in variants}
+        side = torch.cuda.Stream()
+        probe = torch.zeros(2, dtype=torch.int64, device="cuda")
         for rnd in range(4):
             for v in variants:
                 tune(0, v)
-                eng.time_kernel(0, 10, st, n=n)
+                us = eng.time_kernel(0, 10, st, n=n) * 1e3
+                # clock probe beside the timed launches: spins for ~80 % of their expected duration
+                torch.cuda.synchronize()
+                eng.lib.bee2hip_internal_clock_probe(ctypes.c_void_p(probe.data_ptr()), ctypes.c_uint(int(us * 60 * 0.8)),
+                                                     ctypes.c_void_p(side.cuda_stream))
                 res[v].append(eng.time_kernel(0, 60, st, n=n) * 1e3)
+                torch.cuda.synchronize()
+                c = probe.cpu().numpy()
+                ghz[v].append(c[0] / (c[1] * 10.0))
         print(f"--- n = 2^{logn} states, us per launch (4 alternating rounds of 60 launches), G perm/s from the best")
         for v in variants:
             us = res[v]
             print(f"v{v} {NAMES[v]:<52s} " + " ".join(f"{x:7.1f}" for x in us) +
-                  f"   {n / min(us) / 1e3:6.2f} G/s  {'ok' if ok[v] else 'WRONG'}")
+                  f"   {n / min(us) / 1e3:6.2f} G/s  {sum(ghz[v]) / len(ghz[v]):.3f} GHz  {'ok' if ok[v] else 'WRONG'}")
     tune(0, 0)
 
 

@@ -1,12 +1,14 @@
+#!/bin/bash
+# PMC counters of bashF kernel variants: bash tools/prof_bashf.sh "<variants>" <log2 n>   (on the GPU box)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/bashf_pmc
 rm -rf $O; mkdir -p $O
-rocprofv3 -L > $O/counters.txt 2>&1
-for v in 0 3 18; do
+VARS=${1:-"0 36"}; LOGN=${2:-20}
+for v in $VARS; do
   i=0
-  for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM" "GRBM_GUI_ACTIVE GRBM_COUNT" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
-    rocprofv3 --pmc $set --output-format csv -d $O/v${v}_s$i -o b -- python $R/tools/bashf_run.py $v 20 12 > $O/v${v}_s$i.log 2>&1
+  for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INST_LEVEL_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM" "GRBM_GUI_ACTIVE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_STALL_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+    rocprofv3 --pmc $set --output-format csv -d $O/v${v}_s$i -o b -- python $R/tools/bashf_run.py $v $LOGN 12 > $O/v${v}_s$i.log 2>&1
     i=$((i+1))
   done
 done
