@@ -353,7 +353,7 @@ static void launch_bashF_tile(unsigned grid, uint8_t *p, size_t n, hipStream_t s
     hipLaunchKernelGGL(k, dim3(grid), dim3(BASHF_WG), lds, st, p, n);
 }
 
-static int g_bashF_variant = 0;
+static int g_bashF_variant = -1;
 void set_bashF_variant(int v) { g_bashF_variant = v; }
 
 err_t launch_bashF_batch(void *d_states, size_t n, hipStream_t st)
@@ -370,53 +370,21 @@ err_t launch_bashF_batch(void *d_states, size_t n, hipStream_t st)
     const unsigned nwaves = nwg * 4;
 #define TILE(L, S, O, W) launch_bashF_tile<L, S, O, W>((unsigned)grid, p, n, st)
 #define TILEF(L, S, O, W, F) launch_bashF_tile<L, S, O, W, F>((unsigned)grid, p, n, st)
+    // Variants kept for the A/B record (profiles/r02_bashF_variants.txt lists every one that was measured; the
+    // numbers there name them as below).  Product = default.
     switch (v) {
-    case 1: TILE(1, 1, 1, 3); break;        // LDS-DMA load, slab store, r01 staged order
-    case 2: TILE(1, 0, 1, 3); break;        // LDS-DMA load, direct store
-    case 3: TILE(0, 0, 1, 4); break;        // no LDS, r01 staged order
+    case 0: hipLaunchKernelGGL(bashF_batch_kernel<1>, dim3((unsigned)grid), dim3(BASHF_WG), lds4, st, p, n); break;   // r01 product
+    case 1: TILE(1, 1, 1, 3); break;         // LDS-DMA load, slab store, r01 staged order
+    case 3: TILE(0, 0, 1, 4); break;         // no LDS, r01 staged order
     case 4: hipLaunchKernelGGL((bashF_walk_kernel<false, 1>), dim3(nwg), dim3(BASHF_WG), lds4, st, p, n, nwaves); break;
-    case 5: hipLaunchKernelGGL((bashF_walk_kernel<true, 1>), dim3(nwg), dim3(BASHF_WG), lds4, st, p, n, nwaves); break;
-    case 6: TILE(0, 0, 0, 6); break;        // no LDS, compiler's order
-    case 7: TILE(0, 0, 0, 8); break;
-    case 10: TILE(0, 0, 28, 4); break;      // no LDS, staged second form W = 8
-    case 11: TILE(0, 0, 24, 4); break;      // W = 4
-    case 12: TILE(0, 0, 24, 5); break;
-    case 13: TILE(0, 0, 24, 6); break;
-    case 14: TILE(0, 0, 22, 6); break;      // W = 2
-    case 15: TILE(0, 0, 22, 8); break;
-    case 16: TILE(0, 2, 28, 4); break;      // direct load, half-slab store
-    case 17: TILE(2, 2, 28, 4); break;      // half-slab DMA load, half-slab store
-    case 18: TILE(0, 2, 24, 5); break;
-    case 19: TILE(1, 1, 28, 3); break;      // LDS-DMA load, slab store, second form
-    case 20: TILE(0, 0, 1, 5); break;       // no LDS, r01 staged order, 5 wavefronts/SIMD
-    case 30: TILE(0, 0, 101, 4); break;     // class-following priority: no LDS, r01 staged
-    case 31: TILE(0, 0, 128, 4); break;     // no LDS, staged2 W = 8
-    case 32: TILE(0, 0, 124, 6); break;     // no LDS, staged2 W = 4
-    case 33: TILE(0, 0, 122, 8); break;     // no LDS, staged2 W = 2
-    case 34: TILE(0, 2, 124, 5); break;     // direct load, half-slab store, W = 4
-    case 35: TILE(1, 1, 101, 3); break;     // LDS-DMA load, slab store, r01 staged
-    case 36: TILE(0, 2, 128, 4); break;     // direct load, half-slab store, W = 8
-    case 37: TILE(2, 2, 124, 5); break;     // half-slab DMA load + half-slab store, W = 4
-    case 50: TILEF(0, 2, 128, 4, 1); break;  // v36 + priority 3 until the loads are issued
-    case 51: TILEF(0, 2, 128, 4, 3); break;  //     + priority 3 for the store phase too
-    case 52: TILE(0, 4, 122, 8); break;      // quarter-slab store, W = 2, 8 wavefronts/SIMD
-    case 53: TILEF(0, 4, 122, 8, 1); break;
-    case 54: TILE(0, 2, 124, 6); break;      // half-slab (6.5 KiB) store, W = 4, 6 wavefronts/SIMD
-    case 55: TILEF(0, 2, 124, 6, 1); break;
-    case 56: TILEF(0, 4, 124, 6, 1); break;  // quarter-slab, W = 4
-    case 57: TILEF(0, 8, 122, 8, 1); break;  // eighth-slab, W = 2
-    case 58: TILEF(0, 0, 122, 8, 1); break;  // direct store, W = 2, 8 wavefronts
-    case 59: TILEF(0, 4, 101, 4, 1); break;  // quarter-slab, r01 staged
-    case 40: TILE(9, 9, 128, 4); break;     // ablation: rounds only, W = 8, priority
-    case 41: TILE(9, 9, 28, 4); break;      //           rounds only, W = 8, no priority
-    case 42: TILE(0, 2, -1, 4); break;      //           memory only: direct load, half-slab store
-    case 43: TILE(0, 0, -1, 4); break;      //           memory only: direct load, direct store
-    case 44: TILE(9, 9, 124, 6); break;     //           rounds only, W = 4, priority
-    case 45: TILE(9, 9, 122, 8); break;     //           rounds only, W = 2, priority
-    case 46: TILE(9, 9, 101, 4); break;     //           rounds only, r01 staged, priority
-    default:
-        // PASSES = 1: 64 records staged at once (13 KiB LDS per wavefront, 3 wavefronts/SIMD).
-        hipLaunchKernelGGL(bashF_batch_kernel<1>, dim3((unsigned)grid), dim3(BASHF_WG), lds4, st, p, n);
+    case 11: TILE(0, 0, 24, 6); break;       // no LDS, staged2 W = 4, no priority
+    case 31: TILE(0, 0, 128, 4); break;      // class-following priority: no LDS, staged2 W = 8
+    case 36: TILE(0, 2, 128, 4); break;      // direct load, half-slab store, W = 8
+    case 53: TILEF(0, 4, 122, 8, 1); break;  // W = 2, quarter-slab store, 8 wavefronts/SIMD, load priority
+    case 40: TILE(9, 9, 128, 4); break;      // ablation: rounds only, priority
+    case 41: TILE(9, 9, 28, 4); break;       //           rounds only, no priority
+    case 42: TILE(0, 2, -1, 4); break;       //           memory only: direct load, half-slab store
+    default: TILEF(0, 2, 124, 6, 3);         // product (v61): W = 4, priority, direct load, half-slab store
     }
 #undef TILE
 #undef TILEF

@@ -39,6 +39,10 @@ __device__ __forceinline__ void mac_phi2(uint32_t (&m)[4], const uint32_t (&r)[4
 }
 
 constexpr int FUSED_WG = 1024;
+// issue order of bash-f inside the fused kernel (bash_dev.hpp bash_round): A/B builds override it
+#ifndef BASH_FUSED_ORDER
+#define BASH_FUSED_ORDER 101
+#endif
 
 template <int RW, bool HASH, bool MAC>
 __global__ __launch_bounds__(FUSED_WG)
@@ -108,7 +112,7 @@ void hash_mac_fused_kernel(const uint4 *__restrict__ msgs, size_t msg_len, size_
                 a[2 * j].lo = x[j].x; a[2 * j].hi = x[j].y;
                 a[2 * j + 1].lo = x[j].z; a[2 * j + 1].hi = x[j].w;
             }
-            bash_f<true>(a);       // staged issue order: +6 % here even though it spills (bash_dev.hpp)
+            bash_f<BASH_FUSED_ORDER>(a);   // staged order + class-following priority (bash_dev.hpp)
         }
     }
     // ---- tail blocks + padding (uniform across the batch: msg_len is)
@@ -152,7 +156,7 @@ void hash_mac_fused_kernel(const uint4 *__restrict__ msgs, size_t msg_len, size_
                 a[2 * j].lo = x[j].x; a[2 * j].hi = x[j].y;
                 a[2 * j + 1].lo = x[j].z; a[2 * j + 1].hi = x[j].w;
             }
-            bash_f<true>(a);
+            bash_f<BASH_FUSED_ORDER>(a);
             const int nw = (int)(level / 32);    // digest = l/4 bytes = l/32 words
             uint64_t *d = reinterpret_cast<uint64_t *>(digests + (size_t)(level / 4) * idx);
 #pragma unroll

@@ -32,6 +32,8 @@ NAMES = {0: "r01 product: VGPR-staged load, slab store, staged order",
          54: "PRIO W=4 (6 w/SIMD), half-slab 6.5 KiB store", 55: "  + prio 3 until loads issued",
          56: "PRIO W=4, quarter-slab store, load prio", 57: "PRIO W=2, eighth-slab store, load prio",
          58: "PRIO W=2, direct store, load prio", 59: "PRIO r01 staged, quarter-slab store, load prio",
+         60: "PRIO W=2, quarter-slab, load+store prio", 61: "PRIO W=4, half-slab, load+store prio",
+         62: "PRIO W=8, quarter-slab, load+store prio", 63: "PRIO W=4, quarter-slab, load+store prio",
          40: "ablation: rounds only, W=8, PRIO", 41: "ablation: rounds only, W=8, no priority",
          42: "ablation: memory only (direct load, half-slab store)", 43: "ablation: memory only (direct load + store)",
          44: "ablation: rounds only, W=4, PRIO (6 w/SIMD)", 45: "ablation: rounds only, W=2, PRIO (8 w/SIMD)",
@@ -40,7 +42,7 @@ ABLATION = {40, 41, 42, 43, 44, 45, 46}
 
 
 def main():
-    variants = [int(x) for x in sys.argv[1:]] or sorted(NAMES)
+    variants = [int(x) for x in sys.argv[1:]] or [0, 1, 3, 4, 11, 31, 36, 53, 61, 40, 41, 42]
     eng = bee2_amd.load()
     eng.set_device(0)
     orc = orclib.load()
@@ -71,7 +73,7 @@ def main():
         ghz = {v: [] for v in variants}
         side = torch.cuda.Stream()
         probe = torch.zeros(2, dtype=torch.int64, device="cuda")
-        for rnd in range(4):
+        for rnd in range(int(os.environ.get('AB_ROUNDS', '4'))):
             for v in variants:
                 tune(0, v)
                 us = eng.time_kernel(0, 10, st, n=n) * 1e3
@@ -86,9 +88,10 @@ def main():
         print(f"--- n = 2^{logn} states, us per launch (4 alternating rounds of 60 launches), G perm/s from the best")
         for v in variants:
             us = res[v]
+            med = sorted(us)[len(us) // 2]
             print(f"v{v} {NAMES[v]:<52s} " + " ".join(f"{x:7.1f}" for x in us) +
-                  f"   {n / min(us) / 1e3:6.2f} G/s  {sum(ghz[v]) / len(ghz[v]):.3f} GHz  {'ok' if ok[v] else 'WRONG'}")
-    tune(0, 0)
+                  f"   median {med:6.1f}  best {n / min(us) / 1e3:6.2f} G/s  {sum(ghz[v]) / len(ghz[v]):.3f} GHz  {'ok' if ok[v] else 'WRONG'}")
+    tune(0, -1)
 
 
 if __name__ == "__main__":
