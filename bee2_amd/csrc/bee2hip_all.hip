@@ -4,5 +4,6 @@
 #include "bash_kernels.hip"
 #include "belt_kernels.hip"
 #include "bign_kernels.hip"
+#include "bign_sign_kernels.hip"
 #include "mixed_kernels.hip"
 #include "capi.hip"

@@ -61,6 +61,15 @@ __device__ __forceinline__ uint32_t shr_c(uint32_t x)
 // the four table values of one G-box; the consumer folds them with v_bitop3 (xor3)
 struct GParts { uint32_t p, q; };          // G = p ^ q, p already = t0 ^ t1 ^ t2
 
+// experiment hook (r02): raise the wavefront's priority while it issues the four table reads of a G-box
+#ifdef BELT_LDS_PRIO
+__device__ __forceinline__ void belt_prio_lds() { __builtin_amdgcn_s_setprio(BELT_LDS_PRIO); }
+__device__ __forceinline__ void belt_prio_valu() { __builtin_amdgcn_s_setprio(0); }
+#else
+__device__ __forceinline__ void belt_prio_lds() {}
+__device__ __forceinline__ void belt_prio_valu() {}
+#endif
+
 struct BeltTabWide {
     // dword index = byte*128 + R*32 + bank: the table selector R sits in the instruction's
     // immediate offset (R*128 bytes), the byte in address bits [16:9], the bank-private copy
@@ -92,10 +101,12 @@ struct BeltTabWide {
         constexpr uint32_t M = 0x1FE00u;
         const uint32_t a0 = and_or(shl_c<9>(x), M, base), a1 = and_or(shl_c<1>(x), M, base);
         const uint32_t a2 = and_or(shr_c<7>(x), M, base), a3 = and_or(shr_c<15>(x), M, base);
+        belt_prio_lds();
         const uint32_t t0 = *(lds_u32 *)(uintptr_t)(a0 + ((R0 + 0) & 3) * 128);
         const uint32_t t1 = *(lds_u32 *)(uintptr_t)(a1 + ((R0 + 1) & 3) * 128);
         const uint32_t t2 = *(lds_u32 *)(uintptr_t)(a2 + ((R0 + 2) & 3) * 128);
         const uint32_t t3 = *(lds_u32 *)(uintptr_t)(a3 + ((R0 + 3) & 3) * 128);
+        belt_prio_valu();
         GParts r;
         r.p = xor3(t0, t1, t2);
         r.q = t3;
@@ -142,10 +153,12 @@ struct BeltTabTwo {
         const uint32_t a2 = and_or(shr_c<8>(x), M, base), a3 = and_or(shr_c<16>(x), M, base);
         // byte k gets rotation 5 + 8*((R0 + k) & 3): 29 -> wrapped table, else T5 << 8*((R0+k)&3)
         constexpr int r0 = (R0 + 0) & 3, r1 = (R0 + 1) & 3, r2 = (R0 + 2) & 3, r3 = (R0 + 3) & 3;
+        belt_prio_lds();
         uint32_t t0 = *(lds_u32 *)(uintptr_t)(a0 + (r0 == 3 ? 128 : 0));
         uint32_t t1 = *(lds_u32 *)(uintptr_t)(a1 + (r1 == 3 ? 128 : 0));
         uint32_t t2 = *(lds_u32 *)(uintptr_t)(a2 + (r2 == 3 ? 128 : 0));
         uint32_t t3 = *(lds_u32 *)(uintptr_t)(a3 + (r3 == 3 ? 128 : 0));
+        belt_prio_valu();
         if (r0 == 1 || r0 == 2) t0 <<= 8 * r0;
         if (r1 == 1 || r1 == 2) t1 <<= 8 * r1;
         if (r2 == 1 || r2 == 2) t2 <<= 8 * r2;

@@ -685,10 +685,42 @@ __global__ void bign_debug_fe_kernel(int op, const uint32_t *a, const uint32_t *
 
 // ------------------------------------------------------------------ host side ---
 struct BignDevice {
-    uint4 *gtab[3] = {nullptr, nullptr, nullptr};      // comb table per curve (index N/4 - 2)
+    uint4 *gtab8[3] = {nullptr, nullptr, nullptr};     // 8-bit seed table per curve (index N/4 - 2): 4N x 256 affine points
+    uint4 *gtab[3] = {nullptr, nullptr, nullptr};      // 16-bit comb table per curve, built from the seed table
 };
 static BignDevice g_bign[64];
 static std::mutex g_bign_mu;          // table construction is per device, shared by threads
+
+// the seed table alone (0.5 / 1.7 / 4 MiB): all the signing / key generation path needs (bign_sign_kernels.hip).
+// Caller holds g_bign_mu.
+template <int N>
+static err_t bign_table8_locked(uint4 **out, hipStream_t st)
+{
+    int dev = 0;
+    B2H_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return ERR_BAD_INPUT;
+    uint4 *&slot = g_bign[dev].gtab8[N / 4 - 2];
+    if (!slot) {
+        const size_t pt = 8 * N;                                      // bytes per affine point
+        uint4 *t8 = nullptr;
+        if (hipMalloc((void **)&t8, (size_t)4 * N * GT8_ENTRIES * pt) != hipSuccess) { (void)hipGetLastError(); return ERR_OUTOFMEMORY; }
+        hipLaunchKernelGGL(bign_gtable_kernel<N>, dim3(4 * N * GT8_ENTRIES / 64), dim3(64), 0, st, t8);
+        B2H_TRY(hipGetLastError());
+        B2H_TRY(hipStreamSynchronize(st));
+        slot = t8;
+    }
+    *out = slot;
+    return ERR_OK;
+}
+template <int N>
+static err_t bign_table8(const uint32_t **out, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_bign_mu);
+    uint4 *t = nullptr;
+    const err_t code = bign_table8_locked<N>(&t, st);
+    *out = reinterpret_cast<const uint32_t *>(t);
+    return code;
+}
 
 template <int N>
 static err_t bign_table(uint4 **out, hipStream_t st)
@@ -698,24 +730,16 @@ static err_t bign_table(uint4 **out, hipStream_t st)
     if (dev < 0 || dev >= 64) return ERR_BAD_INPUT;
     uint4 *&slot = g_bign[dev].gtab[N / 4 - 2];
     if (!slot) {
-        const size_t pt = 8 * N;                                      // bytes per affine point
+        const size_t pt = 8 * N;
         uint4 *t8 = nullptr;
-        if (hipMalloc((void **)&t8, (size_t)4 * N * GT8_ENTRIES * pt) != hipSuccess) { (void)hipGetLastError(); return ERR_OUTOFMEMORY; }
-        hipLaunchKernelGGL(bign_gtable_kernel<N>, dim3(4 * N * GT8_ENTRIES / 64), dim3(64), 0, st, t8);
-        if (Comb<N>::W == 16) {
-            uint4 *t16 = nullptr;
-            if (hipMalloc((void **)&t16, (size_t)2 * N * 65536 * pt) != hipSuccess) { (void)hipFree(t8); (void)hipGetLastError(); return ERR_OUTOFMEMORY; }
-            hipLaunchKernelGGL(bign_gtable16_kernel<N>, dim3(2 * N * 65536 / 256), dim3(256), 0, st,
-                               (const uint4 *)t8, t16);
-            B2H_TRY(hipGetLastError());
-            B2H_TRY(hipStreamSynchronize(st));
-            (void)hipFree(t8);
-            slot = t16;
-        } else {
-            B2H_TRY(hipGetLastError());
-            B2H_TRY(hipStreamSynchronize(st));
-            slot = t8;
-        }
+        const err_t code = bign_table8_locked<N>(&t8, st);
+        if (code != ERR_OK) return code;
+        uint4 *t16 = nullptr;
+        if (hipMalloc((void **)&t16, (size_t)2 * N * 65536 * pt) != hipSuccess) { (void)hipGetLastError(); return ERR_OUTOFMEMORY; }
+        hipLaunchKernelGGL(bign_gtable16_kernel<N>, dim3(2 * N * 65536 / 256), dim3(256), 0, st, (const uint4 *)t8, t16);
+        B2H_TRY(hipGetLastError());
+        B2H_TRY(hipStreamSynchronize(st));
+        slot = t16;
     }
     *out = slot;
     return ERR_OK;

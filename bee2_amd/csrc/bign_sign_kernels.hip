@@ -1,0 +1,670 @@
+// bign_sign_kernels.hip -- batched public-key calculation, key generation and signing on the three standard
+// bign curves (gfx950).  SURVEY.md 8f-4, second half.  Replaces n calls of
+//   bignPubkeyCalc  src/crypto/bign/bign_misc.c:373-417   (0 < d < q, Q = d G)
+//   bignKeypairGen  src/crypto/bign/bign_misc.c:182-229   (d from the caller's rng on the host, Q = d G here)
+//   bignSign        src/crypto/bign/bign_sign.c:32-112    (k from the caller's rng on the host)
+//   bignSign2       src/crypto/bign/bign_sign.c:140-245   (k by STB 34.101.45 algorithm 6.3.3, on the device)
+// and the bign128 / bign192 / bign256 facades of each.  One lane per key / signature.
+//
+// Everything below handles SECRETS (d, k) and is written to be constant-time at the instruction level:
+//   * no branch condition and no global / scalar memory address depends on a secret.  Loops run over public
+//     counts; selections are masks (v_bitop3 / v_cndmask), never control flow.  The one exception is the
+//     rejection loop "k <- belt-wbl(k) until 0 < k < q" of algorithm 6.3.3 (bign_sign.c:206-216), which the
+//     reference has too and which repeats with probability (2^2l - q) / 2^2l < 2^-126 per signature;
+//   * the reference's bignMulBase (src/crypto/bign/bign_lcl.c, tables under src/crypto/bign/pre) reads a
+//     precomputed table at secret indices with a regular recoding.  Here k G is a fixed-base comb over 4-bit
+//     windows (8N windows, no doublings) whose table row -- 15 affine multiples of 16^w G -- is read IN FULL
+//     for every window with wavefront-uniform scalar loads (s_load_dwordx16: the addresses depend on the
+//     window number only) and the wanted entry is picked with masks;
+//   * the additions use the COMPLETE projective formulas of Renes, Costello and Batina (algorithm 5: a = -3,
+//     mixed, 11 M + 2 m_b), so there is no exceptional case to branch on: k = q - 2 d_0, acc = O, digit = 0
+//     all go through the same instructions (a zero digit adds a dummy point and keeps the old accumulator);
+//   * the inversion for the affine result is a^(p-2) (fe_inv: fixed chain of squarings and multiplications),
+//     not the division-step inversion of the verify path, whose trip count depends on the operand;
+//   * belt (theta = belt-hash(oid || d || t), k = belt-wbl_theta(H)) looks its S-box up in LDS at secret
+//     indices, as every table-driven belt does.  The table used here is BeltTabTwo, whose copies are
+//     bank-private (lane l only ever touches bank l mod 32, belt_dev.hpp): an access takes the same LDS
+//     cycles whatever the index (SQ_LDS_BANK_CONFLICT = 0), so the lookups leak nothing through timing;
+//   * s1 = (k - (s0 + 2^l) d - H) mod q: schoolbook product, Crandall-style folds by 2^2l - q and masked
+//     conditional subtractions.
+// profiles/r02_sign_ct_audit.txt lists every conditional branch of these kernels with what it tests.
+//
+// Kernels: pubkey calc = mulbase<CHECK_D>;  sign2 = nonce -> mulbase -> tail;  sign with given k = kcheck -> mulbase -> tail.
+#include "belt_dev.hpp"
+#include "bign_dev.hpp"
+#include "common.hpp"
+
+namespace bee2hip {
+
+constexpr uint32_t ERR_BAD_PRIVKEY_V = 504;          // err.h:184
+constexpr uint32_t ERR_BAD_RNG_V = 304;              // err.h:138
+
+__constant__ uint32_t c_cq8[5] = BIGN128_CQ_LIMBS;   // 2^2l - q, N/2 + 1 limbs
+__constant__ uint32_t c_cq12[7] = BIGN192_CQ_LIMBS;
+__constant__ uint32_t c_cq16[9] = BIGN256_CQ_LIMBS;
+template <int N> __device__ __forceinline__ const uint32_t *curve_cq() { return N == 8 ? c_cq8 : N == 12 ? c_cq12 : c_cq16; }
+
+// ------------------------------------------------------------ mask helpers ---
+// all-ones iff a == b, for values below 2^31
+__device__ __forceinline__ uint32_t ct_eq_small(uint32_t a, uint32_t b) { return (uint32_t)((int32_t)((a ^ b) - 1u) >> 31); }
+// all-ones iff x == 0 (any 32-bit x)
+__device__ __forceinline__ uint32_t ct_is_zero32(uint32_t x) { return (uint32_t)((int32_t)(~x & (x - 1u)) >> 31); }
+// r = m ? a : b, m all-ones or zero
+__device__ __forceinline__ uint32_t ct_sel(uint32_t m, uint32_t a, uint32_t b) { return bitop3<0xCA>(m, a, b); }   // (m & a) | (~m & b)
+template <int N>
+__device__ __forceinline__ uint32_t ct_is_zero(const uint32_t (&a)[N])
+{
+    uint32_t z = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) z |= a[i];
+    return ct_is_zero32(z);
+}
+// all-ones iff a < b (multi-limb, raw values)
+template <int N>
+__device__ __forceinline__ uint32_t ct_lt(const uint32_t (&a)[N], const uint32_t (&b)[N])
+{
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint64_t d = (uint64_t)a[i] - b[i] - borrow;
+        borrow = (uint32_t)(d >> 32) & 1u;
+    }
+    return 0u - borrow;
+}
+// all-ones iff 0 < x < q
+template <int N>
+__device__ __forceinline__ uint32_t ct_in_range_q(const uint32_t (&x)[N])
+{
+    uint32_t q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = curve_q<N>()[i];
+    return ~ct_is_zero(x) & ct_lt(x, q);
+}
+
+// ------------------------------------------------- complete mixed addition ---
+// P <- P + Q on y^2 = x^3 - 3x + b, P = (X : Y : Z) homogeneous projective (x = X / Z, O = (0 : 1 : 0)),
+// Q = (x2, y2) affine and on the curve.  Renes-Costello-Batina, "Complete addition formulas for prime order
+// elliptic curves", algorithm 5: valid for EVERY P including O, P = Q and P = -Q (the group order is odd).
+// Checked against affine arithmetic incl. those cases before it was written (tools/model_sign.py).
+template <int N> struct projT { feT<N> X, Y, Z; };
+template <int N>
+__device__ __forceinline__ void proj_madd_complete(projT<N> &P, const affT<N> &Q, const feT<N> &b)
+{
+    feT<N> t0, t1, t2, t3, t4, X3, Y3, Z3;
+    fe_mul(t0, P.X, Q.x);
+    fe_mul(t1, P.Y, Q.y);
+    fe_add(t3, Q.x, Q.y);
+    fe_add(t4, P.X, P.Y);
+    fe_mul(t3, t3, t4);
+    fe_add(t4, t0, t1);
+    fe_sub(t3, t3, t4);
+    fe_mul(t4, Q.y, P.Z);
+    fe_add(t4, t4, P.Y);
+    fe_mul(Y3, Q.x, P.Z);
+    fe_add(Y3, Y3, P.X);
+    fe_mul(Z3, b, P.Z);
+    fe_sub(X3, Y3, Z3);
+    fe_add(Z3, X3, X3);
+    fe_add(X3, X3, Z3);
+    fe_sub(Z3, t1, X3);
+    fe_add(X3, t1, X3);
+    fe_mul(Y3, b, Y3);
+    fe_add(t1, P.Z, P.Z);
+    fe_add(t2, t1, P.Z);
+    fe_sub(Y3, Y3, t2);
+    fe_sub(Y3, Y3, t0);
+    fe_add(t1, Y3, Y3);
+    fe_add(Y3, t1, Y3);
+    fe_add(t1, t0, t0);
+    fe_add(t0, t1, t0);
+    fe_sub(t0, t0, t2);
+    fe_mul(t1, t4, Y3);
+    fe_mul(t2, t0, Y3);
+    fe_mul(Y3, X3, Z3);
+    fe_add(Y3, Y3, t2);
+    fe_mul(X3, t3, X3);
+    fe_sub(P.X, X3, t1);
+    fe_mul(Z3, t4, Z3);
+    fe_mul(t1, t3, t0);
+    fe_add(P.Z, Z3, t1);
+    P.Y = Y3;
+}
+
+// -------------------------------------------------------------- k G, affine ---
+// R = k G for a secret k (any N-limb value; the callers have k in {1 .. q - 1}).  gtab8 is the verify path's 8-bit
+// seed table: entry (win, b) = b 2^(8 win) G affine, 2N words, at index win * 256 + b; window w of 4 bits reads
+// its 15 entries j 16^w G = entry (w / 2, j << 4 (w & 1)).
+template <int N>
+__device__ __forceinline__ uint32_t mul_base_ct(feT<N> &x, feT<N> &y, const uint32_t (&k)[N], const uint32_t *__restrict__ gtab8)
+{
+    uint32_t kk[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) kk[i] = k[i];
+    feT<N> b;
+#pragma unroll
+    for (int i = 0; i < N; ++i) b.v[i] = curve_b<N>()[i];
+    projT<N> acc;
+    fe_set_zero(acc.X); fe_set_one(acc.Y); fe_set_zero(acc.Z);          // O
+#pragma unroll 1
+    for (int w = 0; w < 8 * N; ++w) {
+        const uint32_t dg = kk[0] & 15u;
+        // k >>= 4
+#pragma unroll
+        for (int i = 0; i < N - 1; ++i) kk[i] = __builtin_amdgcn_alignbit(kk[i + 1], kk[i], 4);
+        kk[N - 1] >>= 4;
+        // scan the whole row of the table; addresses depend on w only (scalar loads)
+        const uint32_t *row = gtab8 + ((size_t)(w >> 1) * GT8_ENTRIES) * (2 * N);
+        const int sh = 4 * (w & 1);
+        affT<N> E;
+        fe_set_zero(E.x); fe_set_zero(E.y);
+#pragma unroll
+        for (int j = 1; j < 16; ++j) {
+            const uint32_t m = ct_eq_small(dg, (uint32_t)j);
+            const uint32_t *e = row + (size_t)(j << sh) * (2 * N);
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                E.x.v[l] = bitop3<0xF8>(E.x.v[l], e[l], m);             // a | (b & c)
+                E.y.v[l] = bitop3<0xF8>(E.y.v[l], e[N + l], m);
+            }
+        }
+        // digit 0: E = (0, 0), not a point -- add it all the same and keep the old accumulator
+        projT<N> sum = acc;
+        proj_madd_complete(sum, E, b);
+        const uint32_t keep = ct_eq_small(dg, 0u);
+#pragma unroll
+        for (int l = 0; l < N; ++l) {
+            acc.X.v[l] = ct_sel(keep, acc.X.v[l], sum.X.v[l]);
+            acc.Y.v[l] = ct_sel(keep, acc.Y.v[l], sum.Y.v[l]);
+            acc.Z.v[l] = ct_sel(keep, acc.Z.v[l], sum.Z.v[l]);
+        }
+    }
+    // affine: x = X / Z, y = Y / Z with the fixed exponentiation chain (Z = 0 only for k = 0 mod q: gives 0)
+    feT<N> zc;
+    fe_canon(zc, acc.Z);
+    const feT<N> zi = fe_inv(zc);
+    fe_mul(x, acc.X, zi);
+    fe_mul(y, acc.Y, zi);
+    fe_canon(x, x);
+    fe_canon(y, y);
+    return ct_is_zero(zc.v);                       // all-ones iff k G = O
+}
+
+template <int N>
+__device__ __forceinline__ void load_words_bytes(uint32_t (&r)[N], const uint8_t *p)
+{
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = w[i];
+}
+
+// scalars: n x 4N octets (LE).
+// MODE 1 (bignPubkeyCalc): the scalars are private keys d -- codes[i] = ERR_OK / ERR_BAD_PRIVKEY
+//         (bign_misc.c:399-403); an invalid key leaves an all-zero public key behind.
+// MODE 2 (bignKeypairGen): any d below 2^(2l) is multiplied, as the reference does with its draw below p
+//         (bign_misc.c:209-218); codes[i] = ERR_BAD_PARAMS when d G = O (d = q), else ERR_OK.
+// MODE 0 (signing): no codes; every lane computes.
+// xy_out: n x 8N octets (x || y), or with X_ONLY n x 4N octets.
+template <int N, int MODE, bool X_ONLY>
+__global__ __launch_bounds__(256, (N == 8 ? 2 : 1))
+void bign_mulbase_ct_kernel(const uint8_t *__restrict__ scalars, size_t n, uint32_t *__restrict__ codes,
+                            uint8_t *__restrict__ xy_out, const uint32_t *__restrict__ gtab8)
+{
+    constexpr int NO = 4 * N;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    uint32_t k[N];
+    load_words_bytes(k, scalars + NO * idx);
+    uint32_t valid = ~0u;
+    if constexpr (MODE == 1) {
+        valid = ct_in_range_q(k);
+        codes[idx] = ct_sel(valid, (uint32_t)ERR_OK, ERR_BAD_PRIVKEY_V);
+    }
+    feT<N> x, y;
+    const uint32_t inf = mul_base_ct(x, y, k, gtab8);
+    if constexpr (MODE == 2) {
+        valid = ~inf;
+        codes[idx] = ct_sel(inf, (uint32_t)ERR_BAD_PARAMS, (uint32_t)ERR_OK);
+    }
+    uint32_t *o = reinterpret_cast<uint32_t *>(xy_out + (X_ONLY ? NO : 2 * NO) * idx);
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = x.v[i] & valid;
+    if constexpr (!X_ONLY) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[N + i] = y.v[i] & valid;
+    }
+}
+
+// ------------------------------------------------ belt-hash of a short message ---
+// words of the message live in an LDS row per lane (secret data: the row is lane-private); nw = number of
+// 32-bit words that hold message bytes, len = message length in octets (wavefront-uniform).
+template <class Tab>
+__device__ __forceinline__ void belt_hash_row(const Tab &T, uint32_t (&h)[8], const uint32_t *row, uint32_t len)
+{
+    uint32_t s[4] = {0, 0, 0, 0}, X[8], s1[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        h[i] = (uint32_t)c_beltH[4 * i] | (uint32_t)c_beltH[4 * i + 1] << 8 |
+               (uint32_t)c_beltH[4 * i + 2] << 16 | (uint32_t)c_beltH[4 * i + 3] << 24;
+    const uint32_t nblk = (len + 31) / 32;
+#pragma unroll 1
+    for (uint32_t b = 0; b < nblk; ++b) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) X[i] = row[8 * b + i];          // the row is zero-padded to whole blocks
+        belt_compress(T, s1, h, X);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] ^= s1[i];
+    }
+    X[0] = len << 3; X[1] = 0; X[2] = 0; X[3] = 0;                  // <bit length>_128 || s (belt_hash.c:120-135)
+    X[4] = s[0]; X[5] = s[1]; X[6] = s[2]; X[7] = s[3];
+    belt_compress(T, s1, h, X);
+}
+
+// message = oid || a || b assembled into the lane's row: a_words words of a, b_len octets of b (b may be null).
+// The OID is wavefront-uniform; data words are funnel-shifted by the OID length mod 4 (as bign_tail_kernel does).
+__device__ __forceinline__ void row_put_bytes(uint32_t *row, uint32_t pos, uint32_t byte)
+{
+    row[pos >> 2] |= byte << (8 * (pos & 3u));
+}
+
+constexpr int SIGN_WG = 256;
+constexpr int SIGN_T_MAX = 64;                       // longest additional input t (octets) the device path takes
+
+// algorithm 6.3.3 (bign_sign.c:192-216): theta = belt-hash(oid || d || t), k = H, repeat k <- belt-wbl_theta(k) until
+// 0 < k < q.  Also range-checks d (:185-189).  Writes k (4N octets per signature) and status.
+// t: n x t_len octets (t_stride = t_len) or one shared string (t_stride = 0); may be null with t_len = 0.
+template <int N>
+__global__ __launch_bounds__(SIGN_WG)
+void bign_sign_nonce_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ privkeys,
+                            const uint8_t *__restrict__ t, uint32_t t_len, uint32_t t_stride,
+                            const uint8_t *__restrict__ theta_in, size_t n, OidArg oid,
+                            uint32_t *__restrict__ status, uint8_t *__restrict__ k_out)
+{
+    constexpr int NO = 4 * N;
+    constexpr int ROW = (OID_MAX + 64 + SIGN_T_MAX + 31) / 32 * 8 + 1;     // words, odd stride
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    uint8_t *s_tab = s_dyn;
+    uint32_t *s_rows = reinterpret_cast<uint32_t *>(s_dyn + BeltTabTwo::kBytes);
+    BeltTabTwo::fill(s_tab, threadIdx.x, SIGN_WG);
+    __syncthreads();
+    const BeltTabTwo T(s_tab);
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+
+    uint32_t d[N];
+    load_words_bytes(d, privkeys + NO * idx);
+    const uint32_t d_ok = ct_in_range_q(d);
+    status[idx] = ct_sel(d_ok, ST_PENDING, ERR_BAD_PRIVKEY_V);
+
+    // ---- theta = belt-hash(oid || d || t) (or taken from the caller: additional input longer than SIGN_T_MAX is
+    // hashed by the streaming belt-hash of the library, capi.hip)
+    uint32_t theta[8];
+    if (theta_in) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) theta[i] = reinterpret_cast<const uint32_t *>(theta_in + 32 * idx)[i];
+    } else {
+    uint32_t *row = s_rows + threadIdx.x * ROW;
+    const uint32_t len = oid.len + NO + t_len;
+    const uint32_t nwords = (len + 31) / 32 * 8;
+    for (uint32_t i = 0; i < nwords; ++i) row[i] = 0;
+    for (uint32_t i = 0; i < oid.len; ++i) row_put_bytes(row, i, oid.der[i]);
+    {
+        const uint32_t sh = (oid.len & 3u) * 8u, w0 = oid.len >> 2;          // uniform
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            row[w0 + i] |= d[i] << sh;
+            if (sh) row[w0 + i + 1] |= d[i] >> (32 - sh);
+        }
+    }
+    if (t_len) {
+        const uint8_t *tp = t + (size_t)t_stride * idx;
+        for (uint32_t i = 0; i < t_len; ++i) row_put_bytes(row, oid.len + NO + i, tp[i]);
+    }
+    belt_hash_row(T, theta, row, len);
+    for (uint32_t i = 0; i < nwords; ++i) row[i] = 0;                        // wipe d from LDS
+    }
+
+    // ---- k = belt-wbl_theta(H), repeated until 0 < k < q.  belt-wbl on NB = N / 4 blocks (belt_wbl.c:58-152):
+    // 2 NB rounds  s = r_1 ^ .. ^ r_{NB-1};  (r_1 .. r_NB) <- (r_2, .., r_{NB-1}, r_NB ^ E(s) ^ <i>, s)
+    constexpr int NB = N / 4;
+    uint32_t r[NB][4];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(hashes + NO * idx + 16 * j);
+        r[j][0] = a.x; r[j][1] = a.y; r[j][2] = a.z; r[j][3] = a.w;
+    }
+    uint32_t kk[N];
+    uint32_t done = 0;
+#pragma unroll 1
+    for (;;) {
+        uint32_t c[NB][4];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[j][i] = r[j][i];
+#pragma unroll
+        for (int round = 1; round <= 2 * NB; ++round) {
+            uint32_t s[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s[i] = c[0][i];
+#pragma unroll
+                for (int j = 1; j < NB - 1; ++j) s[i] ^= c[j][i];
+            }
+            uint32_t e[4] = {s[0], s[1], s[2], s[3]};
+            belt_encr(T, e, theta);
+            e[0] ^= (uint32_t)round;
+            uint32_t last[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) last[i] = c[NB - 1][i] ^ e[i];
+#pragma unroll
+            for (int j = 0; j + 2 < NB; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[j][i] = c[j + 1][i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { c[NB - 2][i] = last[i]; c[NB - 1][i] = s[i]; }
+        }
+        // lanes that already have their k keep it; the others take the new value
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[j][i] = ct_sel(done, r[j][i], c[j][i]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kk[4 * j + i] = r[j][i];
+        done |= ct_in_range_q(kk);
+        if (__all(done != 0)) break;          // fails with probability < 2^-126 per signature (see the header)
+    }
+    uint32_t *ko = reinterpret_cast<uint32_t *>(k_out + NO * idx);
+#pragma unroll
+    for (int i = 0; i < N; ++i) ko[i] = kk[i];
+}
+
+// bignSign with the one-time key supplied (bign_sign.c:71-82 after the rng): d and k range checks only
+template <int N>
+__global__ __launch_bounds__(256)
+void bign_sign_kcheck_kernel(const uint8_t *__restrict__ privkeys, const uint8_t *__restrict__ ks, size_t n,
+                             uint32_t *__restrict__ status)
+{
+    constexpr int NO = 4 * N;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    uint32_t d[N], k[N];
+    load_words_bytes(d, privkeys + NO * idx);
+    load_words_bytes(k, ks + NO * idx);
+    const uint32_t d_ok = ct_in_range_q(d), k_ok = ct_in_range_q(k);
+    status[idx] = ct_sel(d_ok, ct_sel(k_ok, ST_PENDING, ERR_BAD_RNG_V), ERR_BAD_PRIVKEY_V);
+}
+
+// x mod q for x of NX limbs (NX <= 3N/2 + 1), result N limbs in [0, q).  2^(32N) = cq (mod q), cq of N/2 + 1 limbs.
+template <int N, int NX>
+__device__ __forceinline__ void mod_q_ct(uint32_t (&r)[N], const uint32_t (&x)[NX])
+{
+    constexpr int NC = N / 2 + 1, NH = NX - N;         // limbs of cq, of the high part
+    static_assert(NH >= 1 && NH <= N / 2 + 1, "operand size");
+    uint32_t cq[NC], q[N];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) cq[i] = curve_cq<N>()[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = curve_q<N>()[i];
+    // v = lo + hi * cq : up to N + 1 limbs (hi * cq < 2^(32N + 2))
+    uint32_t v[N + 2];
+#pragma unroll
+    for (int i = 0; i < N + 2; ++i) v[i] = i < N ? x[i] : 0u;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            if (i + j < N + 2) {
+                c += (uint64_t)x[N + i] * cq[j] + v[i + j];
+                v[i + j] = (uint32_t)c; c >>= 32;
+            }
+        }
+#pragma unroll
+        for (int j = i + NC; j < N + 2; ++j) { c += v[j]; v[j] = (uint32_t)c; c >>= 32; }
+    }
+    // fold the top (v[N], v[N+1] small) twice more: t * cq + lo
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const uint32_t t = v[N];                       // < 8 after the first pass, 0 or 1 after the second
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < N + 1; ++j) {
+            c += (uint64_t)(j < N ? v[j] : 0u) + (j < NC ? (uint64_t)t * cq[j] : 0u);
+            v[j] = (uint32_t)c; c >>= 32;
+        }
+    }
+    // v < 2^(32N) = q + cq now (v[N] == 0): one masked subtraction of q
+    uint32_t s[N];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint64_t dd = (uint64_t)v[i] - q[i] - borrow;
+        s[i] = (uint32_t)dd; borrow = (uint32_t)(dd >> 32) & 1u;
+    }
+    const uint32_t lt = 0u - borrow;                   // v < q: keep v
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = ct_sel(lt, v[i], s[i]);
+}
+// zzSubMod (zz_mod.c:120-132): c = a - b, + q when the subtraction borrowed.  b need not be below q.
+template <int N>
+__device__ __forceinline__ void sub_mod_q_ct(uint32_t (&c)[N], const uint32_t (&a)[N], const uint32_t (&b)[N])
+{
+    uint32_t t[N];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint64_t d = (uint64_t)a[i] - b[i] - borrow;
+        t[i] = (uint32_t)d; borrow = (uint32_t)(d >> 32) & 1u;
+    }
+    const uint32_t m = 0u - borrow;
+    uint64_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        cy += (uint64_t)t[i] + (curve_q<N>()[i] & m);
+        c[i] = (uint32_t)cy; cy >>= 32;
+    }
+}
+
+// s0 = belt-hash(oid || <x_R> || H)[0 .. l bits), s1 = (k - (s0 + 2^l) d - H) mod q (bign_sign.c:221-238);
+// wipes k.  x_R and H are public, so this hash could use any table; it shares BeltTabTwo with the nonce kernel.
+template <int N>
+__global__ __launch_bounds__(SIGN_WG)
+void bign_sign_tail_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ privkeys,
+                           const uint8_t *__restrict__ rx, uint8_t *__restrict__ ks, size_t n, OidArg oid,
+                           const uint32_t *__restrict__ status, uint8_t *__restrict__ sigs, uint32_t *__restrict__ codes)
+{
+    constexpr int NO = 4 * N;
+    constexpr int ROW = (OID_MAX + 2 * 64 + 31) / 32 * 8 + 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    uint8_t *s_tab = s_dyn;
+    uint32_t *s_rows = reinterpret_cast<uint32_t *>(s_dyn + BeltTabTwo::kBytes);
+    BeltTabTwo::fill(s_tab, threadIdx.x, SIGN_WG);
+    __syncthreads();
+    const BeltTabTwo T(s_tab);
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const uint32_t st = status[idx];
+    const uint32_t ok = ct_eq_small(st >> 1, ST_PENDING >> 1);      // status is public (an error code the caller sees)
+
+    uint32_t xr[N], H[N], d[N], k[N];
+    load_words_bytes(xr, rx + NO * idx);
+    load_words_bytes(H, hashes + NO * idx);
+    load_words_bytes(d, privkeys + NO * idx);
+    load_words_bytes(k, ks + NO * idx);
+    uint32_t *kz = reinterpret_cast<uint32_t *>(ks + NO * idx);
+#pragma unroll
+    for (int i = 0; i < N; ++i) kz[i] = 0;                           // the one-time key does not outlive the call
+
+    uint32_t *row = s_rows + threadIdx.x * ROW;
+    const uint32_t len = oid.len + 2 * NO;
+    const uint32_t nwords = (len + 31) / 32 * 8;
+    for (uint32_t i = 0; i < nwords; ++i) row[i] = 0;
+    for (uint32_t i = 0; i < oid.len; ++i) row_put_bytes(row, i, oid.der[i]);
+    {
+        const uint32_t sh = (oid.len & 3u) * 8u, w0 = oid.len >> 2;
+#pragma unroll
+        for (int i = 0; i < 2 * N; ++i) {
+            const uint32_t v = i < N ? xr[i] : H[i - N];
+            row[w0 + i] |= v << sh;
+            if (sh) row[w0 + i + 1] |= v >> (32 - sh);
+        }
+    }
+    uint32_t h[8];
+    belt_hash_row(T, h, row, len);
+
+    // (s0 + 2^l) d : (N/2 + 1) x N limbs
+    uint32_t s0[N / 2 + 1];
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) s0[i] = h[i];
+    s0[N / 2] = 1u;
+    uint32_t prod[N + N / 2 + 1];
+#pragma unroll
+    for (int i = 0; i < N + N / 2 + 1; ++i) prod[i] = 0;
+#pragma unroll
+    for (int i = 0; i <= N / 2; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            c += (uint64_t)s0[i] * d[j] + prod[i + j];
+            prod[i + j] = (uint32_t)c; c >>= 32;
+        }
+        prod[i + N] += (uint32_t)c;
+    }
+    uint32_t s1[N];
+    mod_q_ct<N, N + N / 2 + 1>(s1, prod);
+    sub_mod_q_ct<N>(s1, k, s1);
+    sub_mod_q_ct<N>(s1, s1, H);
+
+    uint32_t *so = reinterpret_cast<uint32_t *>(sigs + (NO + NO / 2) * idx);
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) so[i] = h[i] & ok;
+#pragma unroll
+    for (int i = 0; i < N; ++i) so[N / 2 + i] = s1[i] & ok;
+    codes[idx] = ct_sel(ok, (uint32_t)ERR_OK, st);
+}
+
+// ------------------------------------------------------------------ host side ---
+struct SignScratch { uint32_t *status; uint8_t *k; uint8_t *rx; };
+template <int N>
+static err_t sign_scratch(hipStream_t st, size_t n, SignScratch &S)
+{
+    const size_t n_pad = (n + 63) & ~(size_t)63;
+    void *base = nullptr;
+    err_t code = scratch_for_stream(st, 8 + N / 4 - 2, n_pad * (4 + 4 * N + 4 * N), &base);
+    if (code != ERR_OK) return code;
+    S.status = (uint32_t *)base;
+    S.k = (uint8_t *)base + 4 * n_pad;
+    S.rx = S.k + 4 * N * n_pad;
+    return ERR_OK;
+}
+
+static err_t make_oid_arg(OidArg &oa, const uint8_t *oid_der, size_t oid_len)
+{
+    if (oid_len > OID_MAX) return ERR_NOT_IMPLEMENTED;
+    oa.len = (uint32_t)oid_len;
+    memset(oa.der, 0, sizeof oa.der);
+    memcpy(oa.der, oid_der, oid_len);
+    return ERR_OK;
+}
+
+template <int N>
+static err_t launch_bign_pubkey_calc_t(bool keygen, const void *d_privkeys, size_t n, void *d_pubkeys, void *d_codes, hipStream_t st)
+{
+    const uint32_t *tab = nullptr;
+    err_t code = bign_table8<N>(&tab, st);
+    if (code != ERR_OK) return code;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (!keygen)
+        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 1, false>), dim3(grid), dim3(256), 0, st, (const uint8_t *)d_privkeys, n,
+                           (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab);
+    else
+        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 2, false>), dim3(grid), dim3(256), 0, st, (const uint8_t *)d_privkeys, n,
+                           (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
+// mode 0: deterministic (bignSign2): d_aux = t (n x t_len, or shared when t_shared), may be null
+// mode 1: one-time keys supplied (bignSign after its rng): d_aux = k, n x 4N octets
+// mode 2: deterministic with theta = belt-hash(oid || d || t) supplied: d_aux = n x 32 octets
+template <int N>
+static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len, const void *d_hashes, const void *d_privkeys,
+                                const void *d_aux, size_t t_len, int t_shared, size_t n, void *d_sigs, void *d_codes,
+                                hipStream_t st)
+{
+    // mode 2: d_aux = theta (n x 32 octets), computed by the caller
+    if (n == 0) return ERR_OK;
+    if (mode == 0 && d_aux && t_len > (size_t)SIGN_T_MAX) return ERR_NOT_IMPLEMENTED;
+    OidArg oa;
+    err_t code = make_oid_arg(oa, oid_der, oid_len);
+    if (code != ERR_OK) return code;
+    const uint32_t *tab = nullptr;
+    code = bign_table8<N>(&tab, st);
+    if (code != ERR_OK) return code;
+    SignScratch S;
+    code = sign_scratch<N>(st, n, S);
+    if (code != ERR_OK) return code;
+    const unsigned grid = (unsigned)((n + SIGN_WG - 1) / SIGN_WG);
+    const uint8_t *kptr;
+    if (mode == 0 || mode == 2) {
+        constexpr int ROW = (OID_MAX + 64 + SIGN_T_MAX + 31) / 32 * 8 + 1;
+        const size_t lds = BeltTabTwo::kBytes + (size_t)SIGN_WG * ROW * 4;
+        static bool attr_done[64];
+        if (!attr_done[cur_dev()]) {
+            B2H_TRY(hipFuncSetAttribute((const void *)bign_sign_nonce_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done[cur_dev()] = true;
+        }
+        const uint8_t *tp = mode == 0 ? (const uint8_t *)d_aux : nullptr;
+        hipLaunchKernelGGL(bign_sign_nonce_kernel<N>, dim3(grid), dim3(SIGN_WG), lds, st, (const uint8_t *)d_hashes,
+                           (const uint8_t *)d_privkeys, tp, (uint32_t)(tp ? t_len : 0),
+                           (uint32_t)(t_shared ? 0 : t_len), mode == 2 ? (const uint8_t *)d_aux : nullptr, n, oa, S.status, S.k);
+        kptr = S.k;
+    } else {
+        hipLaunchKernelGGL(bign_sign_kcheck_kernel<N>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           (const uint8_t *)d_privkeys, (const uint8_t *)d_aux, n, S.status);
+        B2H_TRY(hipMemcpyAsync(S.k, d_aux, n * 4 * N, hipMemcpyDeviceToDevice, st));
+        kptr = S.k;
+    }
+    hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 0, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, kptr, n,
+                       (uint32_t *)nullptr, S.rx, tab);
+    {
+        constexpr int ROW = (OID_MAX + 2 * 64 + 31) / 32 * 8 + 1;
+        const size_t lds = BeltTabTwo::kBytes + (size_t)SIGN_WG * ROW * 4;
+        static bool attr_done[64];
+        if (!attr_done[cur_dev()]) {
+            B2H_TRY(hipFuncSetAttribute((const void *)bign_sign_tail_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done[cur_dev()] = true;
+        }
+        hipLaunchKernelGGL(bign_sign_tail_kernel<N>, dim3(grid), dim3(SIGN_WG), lds, st, (const uint8_t *)d_hashes,
+                           (const uint8_t *)d_privkeys, (const uint8_t *)S.rx, S.k, n, oa, (const uint32_t *)S.status,
+                           (uint8_t *)d_sigs, (uint32_t *)d_codes);
+    }
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
+err_t launch_bign_pubkey_calc(size_t l, bool keygen, const void *d_privkeys, size_t n, void *d_pubkeys, void *d_codes, hipStream_t st)
+{
+    if (n == 0) return ERR_OK;
+    switch (l) {
+    case 128: return launch_bign_pubkey_calc_t<8>(keygen, d_privkeys, n, d_pubkeys, d_codes, st);
+    case 192: return launch_bign_pubkey_calc_t<12>(keygen, d_privkeys, n, d_pubkeys, d_codes, st);
+    case 256: return launch_bign_pubkey_calc_t<16>(keygen, d_privkeys, n, d_pubkeys, d_codes, st);
+    default: return ERR_BAD_PARAMS;
+    }
+}
+err_t launch_bign_sign(size_t l, int mode, const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
+                       const void *d_privkeys, const void *d_aux, size_t t_len, int t_shared, size_t n, void *d_sigs,
+                       void *d_codes, hipStream_t st)
+{
+    switch (l) {
+    case 128: return launch_bign_sign_t<8>(mode, oid_der, oid_len, d_hashes, d_privkeys, d_aux, t_len, t_shared, n, d_sigs, d_codes, st);
+    case 192: return launch_bign_sign_t<12>(mode, oid_der, oid_len, d_hashes, d_privkeys, d_aux, t_len, t_shared, n, d_sigs, d_codes, st);
+    case 256: return launch_bign_sign_t<16>(mode, oid_der, oid_len, d_hashes, d_privkeys, d_aux, t_len, t_shared, n, d_sigs, d_codes, st);
+    default: return ERR_BAD_PARAMS;
+    }
+}
+
+}  // namespace bee2hip

@@ -601,6 +601,254 @@ extern "C" err_t bign128PubkeyVal(const octet pubkey[64]) { return level_pubkey_
 extern "C" err_t bign192PubkeyVal(const octet pubkey[96]) { return level_pubkey_val(1, pubkey); }
 extern "C" err_t bign256PubkeyVal(const octet pubkey[128]) { return level_pubkey_val(2, pubkey); }
 
+// ---- 8f-4 tail: public key from private key, key generation, signing (bign_misc.c:182-229,373-417,
+// bign_sign.c:32-245).  Secrets cross the staging buffer t_scr[3]; it is overwritten with zeros before return.
+static void wipe_dev(void *p, size_t n) { if (p && n) (void)hipMemset(p, 0, n); }
+
+extern "C" err_t bee2hip_bignPubkeyCalcL_batch_dev(size_t l, const void *d_privkeys, size_t n, void *d_pubkeys,
+                                                   void *d_codes, void *stream)
+{
+    if (misaligned(d_privkeys, 4) || misaligned(d_pubkeys, 4) || misaligned(d_codes, 4)) return ERR_BAD_INPUT;
+    if (l != 128 && l != 192 && l != 256) return ERR_BAD_PARAMS;
+    if (n && (!d_privkeys || !d_pubkeys || !d_codes)) return ERR_BAD_INPUT;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    return launch_bign_pubkey_calc(l, false, d_privkeys, n, d_pubkeys, d_codes, as_stream(stream));
+}
+extern "C" err_t bee2hip_bignSign2L_batch_dev(size_t l, const octet oid_der[], size_t oid_len, const void *d_hashes,
+                                              const void *d_privkeys, const void *d_t, size_t t_len, int t_shared,
+                                              size_t n, void *d_sigs, void *d_codes, void *stream)
+{
+    if (misaligned(d_hashes, 16) || misaligned(d_privkeys, 4) || misaligned(d_sigs, 4) || misaligned(d_codes, 4)) return ERR_BAD_INPUT;
+    if (l != 128 && l != 192 && l != 256) return ERR_BAD_PARAMS;
+    if (n && (!d_hashes || !d_privkeys || !d_sigs || !d_codes)) return ERR_BAD_INPUT;
+    if (!oid_der_valid(oid_der, oid_len)) return ERR_BAD_OID;
+    if (!d_t) t_len = 0;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    return launch_bign_sign(l, 0, oid_der, oid_len, d_hashes, d_privkeys, t_len ? d_t : nullptr, t_len, t_shared, n, d_sigs,
+                            d_codes, as_stream(stream));
+}
+extern "C" err_t bee2hip_bignSignKL_batch_dev(size_t l, const octet oid_der[], size_t oid_len, const void *d_hashes,
+                                              const void *d_privkeys, const void *d_ks, size_t n, void *d_sigs,
+                                              void *d_codes, void *stream)
+{
+    if (misaligned(d_hashes, 16) || misaligned(d_privkeys, 4) || misaligned(d_ks, 4) || misaligned(d_sigs, 4) || misaligned(d_codes, 4)) return ERR_BAD_INPUT;
+    if (l != 128 && l != 192 && l != 256) return ERR_BAD_PARAMS;
+    if (n && (!d_hashes || !d_privkeys || !d_ks || !d_sigs || !d_codes)) return ERR_BAD_INPUT;
+    if (!oid_der_valid(oid_der, oid_len)) return ERR_BAD_OID;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    return launch_bign_sign(l, 1, oid_der, oid_len, d_hashes, d_privkeys, d_ks, 0, 0, n, d_sigs, d_codes, as_stream(stream));
+}
+
+extern "C" err_t bee2hip_bignPubkeyCalc_batch(const bign_params *params, const octet *privkeys, size_t n,
+                                              octet *pubkeys, err_t *codes)
+{
+    err_t code = params_check(params);
+    if (code != ERR_OK) return code;
+    if (n && (!privkeys || !pubkeys || !codes)) return ERR_BAD_INPUT;
+    if (n == 0) return ERR_OK;
+    code = ensure_device();
+    if (code != ERR_OK) return code;
+    const size_t no = params->l / 4;
+    const size_t db = no * n, po = (db + 15) & ~(size_t)15, co = (po + 2 * no * n + 15) & ~(size_t)15;
+    Scratch &s = t_scr[3];
+    code = s.need(co + 4 * n);
+    if (code != ERR_OK) return code;
+    octet *d = (octet *)s.p;
+    B2H_TRY(hipMemcpy(d, privkeys, db, hipMemcpyHostToDevice));
+    code = launch_bign_pubkey_calc(params->l, false, d, n, d + po, d + co, nullptr);
+    if (code == ERR_OK) {
+        hipError_t e = hipMemcpy(codes, d + co, 4 * n, hipMemcpyDeviceToHost);
+        // bee2 leaves the output alone when it fails: copy the keys of the good items only
+        std::vector<octet> tmp(2 * no * n);
+        if (e == hipSuccess) e = hipMemcpy(tmp.data(), d + po, 2 * no * n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) code = hip_fail(e, "bignPubkeyCalc copy");
+        else for (size_t i = 0; i < n; ++i) if (codes[i] == ERR_OK) memcpy(pubkeys + 2 * no * i, tmp.data() + 2 * no * i, 2 * no);
+    }
+    wipe_dev(d, db);
+    return code;
+}
+
+// mode 0: t (shared by the batch, may be null) -- bignSign2; mode 1: aux = one-time keys k[n][no] -- bignSign after its rng
+static err_t sign_batch_host(int mode, const bign_params *params, const octet oid_der[], size_t oid_len, const octet *hashes,
+                             const octet *privkeys, const octet *aux, size_t t_len, size_t n, octet *sigs, err_t *codes)
+{
+    err_t code = params_check(params);
+    if (code != ERR_OK) return code;
+    if (n && (!hashes || !privkeys || !sigs || !codes || (mode == 1 && !aux))) return ERR_BAD_INPUT;
+    if (!oid_der_valid(oid_der, oid_len)) return ERR_BAD_OID;
+    if (n == 0) return ERR_OK;
+    if (mode == 0 && !aux) t_len = 0;
+    code = ensure_device();
+    if (code != ERR_OK) return code;
+    const size_t no = params->l / 4, sg = no + no / 2;
+    // theta for additional input beyond what the nonce kernel assembles itself: the library's streaming belt-hash
+    // (beltHashStart / StepH / StepG below run on the device), one signature at a time
+    std::vector<octet> theta;
+    int dev_mode = mode;
+    size_t ab = mode == 1 ? no * n : t_len;
+    if (mode == 0 && t_len > 64) {
+        theta.resize(32 * n);
+        std::vector<octet> st(beltHash_keep());
+        for (size_t i = 0; i < n; ++i) {
+            beltHashStart(st.data());
+            beltHashStepH(oid_der, oid_len, st.data());
+            beltHashStepH(privkeys + no * i, no, st.data());
+            beltHashStepH(aux, t_len, st.data());
+            beltHashStepG(theta.data() + 32 * i, st.data());
+        }
+        memset(st.data(), 0, st.size());
+        aux = theta.data();
+        ab = 32 * n;
+        dev_mode = 2;
+    }
+    const size_t hb = no * n;
+    const size_t o_d = (hb + 15) & ~(size_t)15, o_a = (o_d + hb + 15) & ~(size_t)15, o_s = (o_a + ab + 15) & ~(size_t)15,
+                 o_c = (o_s + sg * n + 15) & ~(size_t)15;
+    Scratch &s = t_scr[3];
+    code = s.need(o_c + 4 * n);
+    if (code != ERR_OK) return code;
+    octet *d = (octet *)s.p;
+    B2H_TRY(hipMemcpy(d, hashes, hb, hipMemcpyHostToDevice));
+    B2H_TRY(hipMemcpy(d + o_d, privkeys, hb, hipMemcpyHostToDevice));
+    if (ab) B2H_TRY(hipMemcpy(d + o_a, aux, ab, hipMemcpyHostToDevice));
+    code = launch_bign_sign(params->l, dev_mode, oid_der, oid_len, d, d + o_d, ab ? d + o_a : nullptr, t_len, 1, n, d + o_s, d + o_c,
+                            nullptr);
+    if (code == ERR_OK) {
+        hipError_t e = hipMemcpy(codes, d + o_c, 4 * n, hipMemcpyDeviceToHost);
+        std::vector<octet> tmp(sg * n);
+        if (e == hipSuccess) e = hipMemcpy(tmp.data(), d + o_s, sg * n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) code = hip_fail(e, "bignSign copy");
+        else for (size_t i = 0; i < n; ++i) if (codes[i] == ERR_OK) memcpy(sigs + sg * i, tmp.data() + sg * i, sg);
+    }
+    wipe_dev(d + o_d, o_s - o_d);
+    if (!theta.empty()) memset(theta.data(), 0, theta.size());
+    return code;
+}
+extern "C" err_t bee2hip_bignSign2_batch(const bign_params *params, const octet oid_der[], size_t oid_len, const octet *hashes,
+                                         const octet *privkeys, const void *t, size_t t_len, size_t n, octet *sigs, err_t *codes)
+{
+    return sign_batch_host(0, params, oid_der, oid_len, hashes, privkeys, (const octet *)t, t_len, n, sigs, codes);
+}
+extern "C" err_t bee2hip_bignSignK_batch(const bign_params *params, const octet oid_der[], size_t oid_len, const octet *hashes,
+                                         const octet *privkeys, const octet *ks, size_t n, octet *sigs, err_t *codes)
+{
+    return sign_batch_host(1, params, oid_der, oid_len, hashes, privkeys, ks, 0, n, sigs, codes);
+}
+
+// ---- drop-ins.  Order of checks as the reference: parameters (bignParamsCheck), pointers, OID, private key.
+extern "C" err_t bignPubkeyCalc(octet pubkey[], const bign_params *params, const octet privkey[])
+{
+    err_t one = ERR_BAD_PRIVKEY;
+    if (!pubkey || !privkey) {
+        const err_t pc = params_check(params);
+        return pc != ERR_OK ? pc : ERR_BAD_INPUT;
+    }
+    const err_t code = bee2hip_bignPubkeyCalc_batch(params, privkey, 1, pubkey, &one);
+    return code != ERR_OK ? code : one;
+}
+// zzRandNZMod (zz_mod.c:463-485) on the host, exactly as bee2 calls the caller's generator: draws of no octets
+// until 0 < a < mod, at most B_PER_IMPOSSIBLE + 1 = 65 of them.  The comparison is the only arithmetic involved.
+static bool rand_nz_mod(octet *a, const octet *mod, size_t no, gen_i rng, void *rng_state)
+{
+    for (int tries = 0; tries <= 64; ++tries) {
+        rng(a, no, rng_state);
+        bool zero = true, less = false;
+        for (size_t i = 0; i < no; ++i) zero = zero && a[i] == 0;
+        for (size_t i = no; i-- > 0;) {
+            if (a[i] != mod[i]) { less = a[i] < mod[i]; break; }
+        }
+        if (!zero && less) return true;
+    }
+    return false;
+}
+extern "C" err_t bignKeypairGen(octet privkey[], octet pubkey[], const bign_params *params, gen_i rng, void *rng_state)
+{
+    err_t code = params_check(params);
+    if (code != ERR_OK) return code;
+    if (!privkey || !pubkey) return ERR_BAD_INPUT;
+    if (!rng) return ERR_BAD_RNG;
+    const size_t no = params->l / 4;
+    octet d[64];
+    // bignKeypairGenEc draws d below the FIELD modulus p (bign_misc.c:209), not below q
+    if (!rand_nz_mod(d, params->p, no, rng, rng_state)) return ERR_BAD_RNG;
+    // any d below 2^(2l) is multiplied, as bignMulBase does (no range check against q here)
+    code = ensure_device();
+    if (code == ERR_OK) {
+        Scratch &s = t_scr[3];
+        code = s.need(64 + 128 + 16);
+        if (code == ERR_OK) {
+            octet *dd = (octet *)s.p;
+            hipError_t e = hipMemcpy(dd, d, no, hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                code = launch_bign_pubkey_calc(params->l, true, dd, 1, dd + 64, dd + 192, nullptr);
+                octet q[128];
+                err_t one = ERR_BAD_PARAMS;
+                if (code == ERR_OK) e = hipMemcpy(q, dd + 64, 2 * no, hipMemcpyDeviceToHost);
+                if (code == ERR_OK && e == hipSuccess) e = hipMemcpy(&one, dd + 192, 4, hipMemcpyDeviceToHost);
+                if (code == ERR_OK && e == hipSuccess) {
+                    code = one;                                  // ERR_BAD_PARAMS when d G = O (bign_misc.c:214-218)
+                    if (one == ERR_OK) { memcpy(privkey, d, no); memcpy(pubkey, q, 2 * no); }
+                }
+            }
+            if (e != hipSuccess) code = hip_fail(e, "bignKeypairGen copy");
+            wipe_dev(dd, 64);
+        }
+    }
+    memset(d, 0, sizeof d);
+    return code;
+}
+extern "C" err_t bignSign(octet sig[], const bign_params *params, const octet oid_der[], size_t oid_len, const octet hash[],
+                          const octet privkey[], gen_i rng, void *rng_state)
+{
+    err_t code = params_check(params);
+    if (code != ERR_OK) return code;
+    const size_t no = params->l / 4;
+    if (!hash || !privkey || !sig || (hash < sig + no + no / 2 && sig < hash + no)) return ERR_BAD_INPUT;
+    if (!oid_der_valid(oid_der, oid_len)) return ERR_BAD_OID;
+    if (!rng) return ERR_BAD_RNG;
+    // d first (bign_sign.c:62-68): a bad key must not consume the generator
+    {
+        bool zero = true, less = false;
+        for (size_t i = 0; i < no; ++i) zero = zero && privkey[i] == 0;
+        for (size_t i = no; i-- > 0;) if (privkey[i] != params->q[i]) { less = privkey[i] < params->q[i]; break; }
+        if (zero || !less) return ERR_BAD_PRIVKEY;
+    }
+    octet k[64];
+    if (!rand_nz_mod(k, params->q, no, rng, rng_state)) return ERR_BAD_RNG;
+    err_t one = ERR_BAD_PRIVKEY;
+    code = bee2hip_bignSignK_batch(params, oid_der, oid_len, hash, privkey, k, 1, sig, &one);
+    memset(k, 0, sizeof k);
+    return code != ERR_OK ? code : one;
+}
+extern "C" err_t bignSign2(octet sig[], const bign_params *params, const octet oid_der[], size_t oid_len, const octet hash[],
+                           const octet privkey[], const void *t, size_t t_len)
+{
+    err_t code = params_check(params);
+    if (code != ERR_OK) return code;
+    const size_t no = params->l / 4;
+    if (!hash || !privkey || !sig || (hash < sig + no + no / 2 && sig < hash + no)) return ERR_BAD_INPUT;
+    if (!oid_der_valid(oid_der, oid_len)) return ERR_BAD_OID;
+    err_t one = ERR_BAD_PRIVKEY;
+    code = bee2hip_bignSign2_batch(params, oid_der, oid_len, hash, privkey, t, t_len, 1, sig, &one);
+    return code != ERR_OK ? code : one;
+}
+#define B2H_LEVEL_FACADE(L, IDX, OID)                                                                              \
+    extern "C" err_t bign##L##PubkeyCalc(octet pubkey[], const octet privkey[])                                     \
+    { bign_params p; bignParamsStd(&p, k_curves[IDX].name); return bignPubkeyCalc(pubkey, &p, privkey); }            \
+    extern "C" err_t bign##L##KeypairGen(octet privkey[], octet pubkey[], gen_i rng, void *rng_state)               \
+    { bign_params p; bignParamsStd(&p, k_curves[IDX].name); return bignKeypairGen(privkey, pubkey, &p, rng, rng_state); } \
+    extern "C" err_t bign##L##Sign(octet sig[], const octet hash[], const octet privkey[], gen_i rng, void *rng_state) \
+    { bign_params p; bignParamsStd(&p, k_curves[IDX].name); return bignSign(sig, &p, OID, 11, hash, privkey, rng, rng_state); } \
+    extern "C" err_t bign##L##Sign2(octet sig[], const octet hash[], const octet privkey[], const void *t, size_t t_len) \
+    { bign_params p; bignParamsStd(&p, k_curves[IDX].name); return bignSign2(sig, &p, OID, 11, hash, privkey, t, t_len); }
+B2H_LEVEL_FACADE(128, 0, k_oid_belt_hash)
+B2H_LEVEL_FACADE(192, 1, k_oid_bash384)
+B2H_LEVEL_FACADE(256, 2, k_oid_bash512)
+#undef B2H_LEVEL_FACADE
+
 extern "C" err_t bee2hip_debug_fe(int op, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream)
 {
     return launch_bign_debug_fe(128, op, d_a, d_b, d_out, n, as_stream(stream));

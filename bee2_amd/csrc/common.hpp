@@ -63,6 +63,12 @@ err_t launch_belt_hash_stream(void *d_hs, const void *d_data, size_t nblocks, in
 err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, const void *d_order, size_t n,
                          void *d_digests, hipStream_t st);
 err_t launch_bign_pubkey_val(size_t l, const void *d_pubkeys, size_t n, void *d_codes, hipStream_t st);
+// 8f-4 tail: Q = d G per private key (codes: ERR_OK / ERR_BAD_PRIVKEY); signing, mode 0 = bignSign2 (d_aux = t or
+// null), mode 1 = one-time keys supplied (d_aux = k)
+err_t launch_bign_pubkey_calc(size_t l, bool keygen, const void *d_privkeys, size_t n, void *d_pubkeys, void *d_codes, hipStream_t st);
+err_t launch_bign_sign(size_t l, int mode, const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
+                       const void *d_privkeys, const void *d_aux, size_t t_len, int t_shared, size_t n, void *d_sigs,
+                       void *d_codes, hipStream_t st);
 err_t launch_bign_debug_fe(size_t l, int op, const void *a, const void *b, void *out, size_t n, hipStream_t st);
 
 }  // namespace bee2hip

@@ -66,6 +66,10 @@ DROPIN_SYMBOLS = [
     "beltMACStepV", "beltMACStepV2", "beltMAC",
     "bignParamsStd", "bignVerify", "bign128Verify", "bign192Verify", "bign256Verify",
     "bignPubkeyVal", "bign128PubkeyVal", "bign192PubkeyVal", "bign256PubkeyVal",
+    "bignKeypairGen", "bignPubkeyCalc", "bignSign", "bignSign2",
+    "bign128KeypairGen", "bign128PubkeyCalc", "bign128Sign", "bign128Sign2",
+    "bign192KeypairGen", "bign192PubkeyCalc", "bign192Sign", "bign192Sign2",
+    "bign256KeypairGen", "bign256PubkeyCalc", "bign256Sign", "bign256Sign2",
 ]
 BATCH_SYMBOLS = [
     "bee2hip_bashF_batch", "bee2hip_beltCTR_bulk", "bee2hip_bignVerify_batch",
@@ -74,6 +78,8 @@ BATCH_SYMBOLS = [
     "bee2hip_beltModes_blocks_dev", "bee2hip_beltCBCEncr_batch_dev", "bee2hip_beltBDE_blocks_dev", "bee2hip_beltSDE_sectors_dev", "bee2hip_beltDWP_absorb_dev", "bee2hip_beltCHE_blocks_dev",
     "bee2hip_bign128Verify_batch_dev", "bee2hip_bignVerify_batch_dev", "bee2hip_bignVerifyL_batch_dev",
     "bee2hip_bignPubkeyVal_batch", "bee2hip_bignPubkeyValL_batch_dev",
+    "bee2hip_bignPubkeyCalc_batch", "bee2hip_bignSign2_batch", "bee2hip_bignSignK_batch",
+    "bee2hip_bignPubkeyCalcL_batch_dev", "bee2hip_bignSign2L_batch_dev", "bee2hip_bignSignKL_batch_dev",
     "bee2hip_bashHash_beltMAC_batch_dev",
     "bee2hip_set_device", "bee2hip_sync", "bee2hip_last_error", "bee2hip_version",
 ]
@@ -508,6 +514,109 @@ class Engine:
     def bignLVerify(self, l, hash_, sig, pubkey):
         """bign128Verify / bign192Verify / bign256Verify"""
         return getattr(self.lib, f"bign{l}Verify")(bytes(hash_), bytes(sig), bytes(pubkey))
+
+    # ------------------------------------- 8f-4 tail: keygen / pubkey calc / sign
+    GEN_I = ctypes.CFUNCTYPE(None, ctypes.c_void_p, _sz, ctypes.c_void_p)
+
+    @staticmethod
+    def rng_from_bytes(stream):
+        """gen_i callback that hands out consecutive bytes of `stream` (bytes); .used tells how many went"""
+        pos = [0]
+
+        def gen(buf, count, _state):
+            chunk = stream[pos[0]:pos[0] + count]
+            assert len(chunk) == count, "rng stream exhausted"
+            ctypes.memmove(buf, chunk, count)
+            pos[0] += count
+        cb = Engine.GEN_I(gen)
+        cb.pos = pos
+        return cb
+
+    def bignPubkeyCalc(self, params, privkey):
+        out = ctypes.create_string_buffer(params.l // 2)
+        code = self.lib.bignPubkeyCalc(out, ctypes.byref(params), bytes(privkey))
+        return code, out.raw
+
+    def bignLPubkeyCalc(self, l, privkey):
+        out = ctypes.create_string_buffer(l // 2)
+        return getattr(self.lib, f"bign{l}PubkeyCalc")(out, bytes(privkey)), out.raw
+
+    def bignKeypairGen(self, params, rng_cb):
+        priv = ctypes.create_string_buffer(params.l // 4)
+        pub = ctypes.create_string_buffer(params.l // 2)
+        code = self.lib.bignKeypairGen(priv, pub, ctypes.byref(params), rng_cb, None)
+        return code, priv.raw, pub.raw
+
+    def bignLKeypairGen(self, l, rng_cb):
+        priv = ctypes.create_string_buffer(l // 4)
+        pub = ctypes.create_string_buffer(l // 2)
+        code = getattr(self.lib, f"bign{l}KeypairGen")(priv, pub, rng_cb, None)
+        return code, priv.raw, pub.raw
+
+    def bignSign2(self, params, oid_der, hash_, privkey, t=None):
+        sig = ctypes.create_string_buffer(3 * params.l // 8)
+        code = self.lib.bignSign2(sig, ctypes.byref(params), bytes(oid_der), _sz(len(oid_der)), bytes(hash_),
+                                  bytes(privkey), t, _sz(len(t) if t else 0))
+        return code, sig.raw
+
+    def bignLSign2(self, l, hash_, privkey, t=None):
+        sig = ctypes.create_string_buffer(3 * l // 8)
+        code = getattr(self.lib, f"bign{l}Sign2")(sig, bytes(hash_), bytes(privkey), t, _sz(len(t) if t else 0))
+        return code, sig.raw
+
+    def bignSign(self, params, oid_der, hash_, privkey, rng_cb):
+        sig = ctypes.create_string_buffer(3 * params.l // 8)
+        code = self.lib.bignSign(sig, ctypes.byref(params), bytes(oid_der), _sz(len(oid_der)), bytes(hash_),
+                                 bytes(privkey), rng_cb, None)
+        return code, sig.raw
+
+    def bignLSign(self, l, hash_, privkey, rng_cb):
+        sig = ctypes.create_string_buffer(3 * l // 8)
+        code = getattr(self.lib, f"bign{l}Sign")(sig, bytes(hash_), bytes(privkey), rng_cb, None)
+        return code, sig.raw
+
+    def bignPubkeyCalc_batch(self, params, privkeys):
+        n = len(privkeys) // (params.l // 4)
+        pubs = ctypes.create_string_buffer(max(1, n * params.l // 2))
+        codes = (_u32 * max(n, 1))()
+        code = self.lib.bee2hip_bignPubkeyCalc_batch(ctypes.byref(params), bytes(privkeys), _sz(n), pubs, codes)
+        return code, pubs.raw[: n * params.l // 2], list(codes)[:n]
+
+    def bignSign2_batch(self, params, oid_der, hashes, privkeys, t=None):
+        n = len(hashes) // (params.l // 4)
+        sg = 3 * params.l // 8
+        sigs = ctypes.create_string_buffer(max(1, n * sg))
+        codes = (_u32 * max(n, 1))()
+        code = self.lib.bee2hip_bignSign2_batch(ctypes.byref(params), bytes(oid_der), _sz(len(oid_der)), bytes(hashes),
+                                                bytes(privkeys), t, _sz(len(t) if t else 0), _sz(n), sigs, codes)
+        return code, sigs.raw[: n * sg], list(codes)[:n]
+
+    def bignSignK_batch(self, params, oid_der, hashes, privkeys, ks):
+        n = len(hashes) // (params.l // 4)
+        sg = 3 * params.l // 8
+        sigs = ctypes.create_string_buffer(max(1, n * sg))
+        codes = (_u32 * max(n, 1))()
+        code = self.lib.bee2hip_bignSignK_batch(ctypes.byref(params), bytes(oid_der), _sz(len(oid_der)), bytes(hashes),
+                                                bytes(privkeys), bytes(ks), _sz(n), sigs, codes)
+        return code, sigs.raw[: n * sg], list(codes)[:n]
+
+    def bignPubkeyCalcL_batch_dev(self, l, privkeys, pubkeys, codes):
+        n = privkeys.numel() // (l // 4)
+        self._check(self.lib.bee2hip_bignPubkeyCalcL_batch_dev(_sz(l), self._ptr(privkeys), _sz(n), self._ptr(pubkeys),
+                                                               self._ptr(codes), self._stream()), "bignPubkeyCalcL_batch_dev")
+
+    def bignSign2L_batch_dev(self, l, oid_der, hashes, privkeys, sigs, codes, t=None, t_len=0, t_shared=True):
+        n = hashes.numel() // (l // 4)
+        self._check(self.lib.bee2hip_bignSign2L_batch_dev(
+            _sz(l), bytes(oid_der), _sz(len(oid_der)), self._ptr(hashes), self._ptr(privkeys),
+            self._ptr(t) if t is not None else None, _sz(t_len), int(bool(t_shared)), _sz(n), self._ptr(sigs),
+            self._ptr(codes), self._stream()), "bignSign2L_batch_dev")
+
+    def bignSignKL_batch_dev(self, l, oid_der, hashes, privkeys, ks, sigs, codes):
+        n = hashes.numel() // (l // 4)
+        self._check(self.lib.bee2hip_bignSignKL_batch_dev(
+            _sz(l), bytes(oid_der), _sz(len(oid_der)), self._ptr(hashes), self._ptr(privkeys), self._ptr(ks), _sz(n),
+            self._ptr(sigs), self._ptr(codes), self._stream()), "bignSignKL_batch_dev")
 
 
 _engine = None

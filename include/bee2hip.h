@@ -55,7 +55,9 @@ typedef uint32_t err_t;
 #define ERR_NOT_IMPLEMENTED  ((err_t)119)   /* err.h:92  */
 #define ERR_FILE_NOT_FOUND    ((err_t)202)   /* err.h:105 */
 #define ERR_BAD_OID          ((err_t)301)   /* err.h:132 */
+#define ERR_BAD_RNG          ((err_t)304)   /* err.h:138 */
 #define ERR_BAD_PARAMS       ((err_t)502)   /* err.h:180 */
+#define ERR_BAD_PRIVKEY      ((err_t)504)   /* err.h:184 */
 #define ERR_BAD_PUBKEY       ((err_t)505)   /* err.h:186 */
 #define ERR_BAD_SIG          ((err_t)510)   /* err.h:196 */
 #define ERR_BAD_MAC          ((err_t)511)   /* err.h:198 */
@@ -234,6 +236,34 @@ err_t bign128PubkeyVal(const octet pubkey[64]);
 err_t bign192PubkeyVal(const octet pubkey[96]);
 err_t bign256PubkeyVal(const octet pubkey[128]);
 
+/* SURVEY.md 8f-4, second half: key generation, public key from private key, signing.  Secret-handling device code:
+   constant-time at the instruction level (bee2_amd/csrc/bign_sign_kernels.hip states what that covers).
+   gen_i: include/bee2/defs.h (void (*)(void* buf, size_t count, void* state)), called on the HOST exactly as
+   zzRandNZMod calls it (src/math/zz/zz_mod.c:463-485); the scalar multiplications, the nonce derivation of
+   bignSign2 (belt-hash + belt-wbl), the hash tail and the arithmetic mod q run on the device.
+   bign.h:207-215,247-254,316-326,352-363; bign128.h:64-69,98-101,140-164 (and bign192.h, bign256.h);
+   src/crypto/bign/bign_misc.c:182-243,373-431, bign_sign.c:32-260.
+   Limit: oid_len <= 128 (as bignVerify here). */
+typedef void (*gen_i)(void *buf, size_t count, void *state);
+err_t bignKeypairGen(octet privkey[], octet pubkey[], const bign_params *params, gen_i rng, void *rng_state);
+err_t bignPubkeyCalc(octet pubkey[], const bign_params *params, const octet privkey[]);
+err_t bignSign(octet sig[], const bign_params *params, const octet oid_der[], size_t oid_len, const octet hash[],
+               const octet privkey[], gen_i rng, void *rng_state);
+err_t bignSign2(octet sig[], const bign_params *params, const octet oid_der[], size_t oid_len, const octet hash[],
+                const octet privkey[], const void *t, size_t t_len);
+err_t bign128KeypairGen(octet privkey[32], octet pubkey[64], gen_i rng, void *rng_state);
+err_t bign128PubkeyCalc(octet pubkey[64], const octet privkey[32]);
+err_t bign128Sign(octet sig[48], const octet hash[32], const octet privkey[32], gen_i rng, void *rng_state);
+err_t bign128Sign2(octet sig[48], const octet hash[32], const octet privkey[32], const void *t, size_t t_len);
+err_t bign192KeypairGen(octet privkey[48], octet pubkey[96], gen_i rng, void *rng_state);
+err_t bign192PubkeyCalc(octet pubkey[96], const octet privkey[48]);
+err_t bign192Sign(octet sig[72], const octet hash[48], const octet privkey[48], gen_i rng, void *rng_state);
+err_t bign192Sign2(octet sig[72], const octet hash[48], const octet privkey[48], const void *t, size_t t_len);
+err_t bign256KeypairGen(octet privkey[64], octet pubkey[128], gen_i rng, void *rng_state);
+err_t bign256PubkeyCalc(octet pubkey[128], const octet privkey[64]);
+err_t bign256Sign(octet sig[96], const octet hash[64], const octet privkey[64], gen_i rng, void *rng_state);
+err_t bign256Sign2(octet sig[96], const octet hash[64], const octet privkey[64], const void *t, size_t t_len);
+
 /* ======================================================================== *
  * (2) host-pointer batch API (new; SURVEY.md 8b "batch extension")
  * ======================================================================== */
@@ -251,6 +281,18 @@ err_t bee2hip_bignVerify_batch(const bign_params *params, const octet oid_der[],
 /* n public keys of params->l/2 octets each -> codes[n] = what bignPubkeyVal(params, key) returns */
 err_t bee2hip_bignPubkeyVal_batch(const bign_params *params, const octet *pubkeys, size_t n,
                                   err_t *codes);
+/* n private keys of params->l/4 octets -> n public keys of params->l/2 octets; codes[n] = what bignPubkeyCalc
+   returns per key (ERR_OK / ERR_BAD_PRIVKEY); the public key of a refused private key is left untouched */
+err_t bee2hip_bignPubkeyCalc_batch(const bign_params *params, const octet *privkeys, size_t n,
+                                   octet *pubkeys, err_t *codes);
+/* n deterministic signatures (bignSign2): hashes n*(l/4), privkeys n*(l/4), one additional input t (may be
+   NULL) shared by the batch -> sigs n*(3l/8), codes[n] = what bignSign2 returns per item */
+err_t bee2hip_bignSign2_batch(const bign_params *params, const octet oid_der[], size_t oid_len, const octet *hashes,
+                              const octet *privkeys, const void *t, size_t t_len, size_t n, octet *sigs, err_t *codes);
+/* n signatures with the one-time keys supplied (what bignSign computes once its rng has produced k in
+   {1..q-1}): ks n*(l/4); a k outside that range gives ERR_BAD_RNG for the item */
+err_t bee2hip_bignSignK_batch(const bign_params *params, const octet oid_der[], size_t oid_len, const octet *hashes,
+                              const octet *privkeys, const octet *ks, size_t n, octet *sigs, err_t *codes);
 /* n messages of msg_len bytes each (contiguous): bashHash(l) digest (l/4 bytes each,
    digests may be NULL) and beltMAC tag (8 bytes each, tags may be NULL) per message */
 err_t bee2hip_bashHash_beltMAC_batch(const octet *msgs, size_t msg_len, size_t n, size_t l,
@@ -333,6 +375,17 @@ err_t bee2hip_bignVerifyL_batch_dev(size_t l, const octet oid_der[], size_t oid_
                                     const void *d_hashes, const void *d_sigs,
                                     const void *d_pubkeys, size_t n, void *d_codes, void *stream);
 /* n public keys of l/2 octets, l in {128, 192, 256}; d_pubkeys 16-byte aligned, d_codes n x err_t */
+/* 8f-4 tail, device resident (private keys, one-time keys and t 4-byte aligned, hashes 16-byte).  d_codes as the
+   host forms; outputs of refused items are zero.  t: n x t_len octets, or one string of t_len octets when
+   t_shared != 0 (t_len <= 64 on this path; NULL = none) */
+err_t bee2hip_bignPubkeyCalcL_batch_dev(size_t l, const void *d_privkeys, size_t n, void *d_pubkeys, void *d_codes,
+                                        void *stream);
+err_t bee2hip_bignSign2L_batch_dev(size_t l, const octet oid_der[], size_t oid_len, const void *d_hashes,
+                                   const void *d_privkeys, const void *d_t, size_t t_len, int t_shared, size_t n,
+                                   void *d_sigs, void *d_codes, void *stream);
+err_t bee2hip_bignSignKL_batch_dev(size_t l, const octet oid_der[], size_t oid_len, const void *d_hashes,
+                                   const void *d_privkeys, const void *d_ks, size_t n, void *d_sigs, void *d_codes,
+                                   void *stream);
 err_t bee2hip_bignPubkeyValL_batch_dev(size_t l, const void *d_pubkeys, size_t n, void *d_codes,
                                        void *stream);
 err_t bee2hip_bashHash_beltMAC_batch_dev(const void *d_msgs, size_t msg_len, size_t n, size_t l,

@@ -476,6 +476,205 @@ void orc_bign128Verify_batch(const uint8_t *hashes, const uint8_t *sigs, const u
     orc_bignVerify_batch(128, OID_BELT_HASH, 11, hashes, sigs, pubkeys, n, codes, nthreads);
 }
 
+/* ============================================ SURVEY.md 8f-4, second half ===
+ * Key generation, public key from private key and signing on the three standard curves.
+ * Follows
+ *   bignPubkeyCalcEc   src/crypto/bign/bign_misc.c:373-417   (0 < d < q, Q = d G)
+ *   bignKeypairGenEc   src/crypto/bign/bign_misc.c:182-229   (d from zzRandNZMod, Q = d G)
+ *   zzRandNZMod        src/math/zz/zz_mod.c:463-485          (rng -> l bits, retry while 0 or >= mod)
+ *   bignSignEc         src/crypto/bign/bign_sign.c:32-112    (k from rng)
+ *   bignSign2Ec        src/crypto/bign/bign_sign.c:140-245   (k by STB 34.101.45 alg. 6.3.3)
+ *   zzSubMod           src/math/zz/zz_mod.c:120-132          (a - b, + mod on borrow; b is NOT reduced first)
+ * The scalar multiplication is a plain left-to-right double-and-add on the Jacobian code above
+ * (the reference uses precomputed tables and regular recoding, bignMulBase; the affine result is
+ * the same point).  Nothing here is constant-time -- this is the checker.
+ */
+#define ORC_BAD_PRIVKEY 504u
+#define ORC_BAD_RNG     304u
+
+/* R = k G, affine (x, y); 0 iff R == O */
+static int mul_base(const curve *E, fe *x, fe *y, const uint64_t k[MAXW])
+{
+    jac G, T;
+    fe zi, zi2;
+    memset(&G, 0, sizeof G);
+    memcpy(G.Y.v, E->yG, sizeof E->yG);
+    G.Z.v[0] = 1;
+    jac_set_inf(&T);
+    for (int i = 64 * E->n - 1; i >= 0; --i) {
+        jac_dbl(E, &T, &T);
+        if ((k[i >> 6] >> (i & 63)) & 1) jac_add(E, &T, &T, &G);
+    }
+    if (jac_is_inf(E, &T)) return 0;
+    fe_inv(E, &zi, &T.Z);
+    fe_sqr(E, &zi2, &zi);
+    fe_mul(E, x, &T.X, &zi2);
+    fe_mul(E, &zi2, &zi2, &zi);
+    fe_mul(E, y, &T.Y, &zi2);
+    return 1;
+}
+static int words_is_zero(const uint64_t *a, int n)
+{
+    uint64_t z = 0;
+    for (int i = 0; i < n; ++i) z |= a[i];
+    return z == 0;
+}
+/* x[0..nx) mod q by binary long division (test code: clarity over speed) */
+static void mod_q(const curve *E, uint64_t r[MAXW], const uint64_t *x, int nx)
+{
+    const int n = E->n;
+    uint64_t t[MAXW + 1];
+    memset(t, 0, sizeof t);
+    for (int bit = 64 * nx - 1; bit >= 0; --bit) {
+        for (int i = n; i > 0; --i) t[i] = (t[i] << 1) | (t[i - 1] >> 63);
+        t[0] = (t[0] << 1) | ((x[bit >> 6] >> (bit & 63)) & 1);
+        if (t[n] || words_cmp(t, E->q, n) >= 0) { uint64_t b = words_sub(t, t, E->q, n); t[n] -= b; }
+    }
+    memset(r, 0, sizeof(uint64_t) * MAXW);
+    memcpy(r, t, sizeof(uint64_t) * n);
+}
+/* zzSubMod semantics: c = a - b (mod 2^(64 n)), + q if the subtraction borrowed */
+static void sub_mod_q(const curve *E, uint64_t *c, const uint64_t *a, const uint64_t *b)
+{
+    if (words_sub(c, a, b, E->n)) words_add(c, c, E->q, E->n);
+}
+
+uint32_t orc_bignPubkeyCalc(size_t l, uint8_t *pubkey, const uint8_t *privkey)
+{
+    curve E;
+    uint64_t d[MAXW] = {0};
+    fe x, y;
+    if (l != 128 && l != 192 && l != 256) return ORC_BAD_PARAMS;
+    curve_init(&E, (int)l);
+    words_from_le(d, privkey, E.n);
+    if (words_is_zero(d, E.n) || words_cmp(d, E.q, E.n) >= 0) return ORC_BAD_PRIVKEY;
+    if (!mul_base(&E, &x, &y, d)) return ORC_BAD_PARAMS;
+    words_to_le(pubkey, x.v, E.n);
+    words_to_le(pubkey + l / 4, y.v, E.n);
+    return ORC_OK;
+}
+
+/* bignKeypairGen with the rng replaced by its output stream: `rnd` holds consecutive l/4-octet draws
+   (what gen_i would have written), *used tells how many were consumed.  NOTE: the reference draws d
+   below ec->f->mod = p (bign_misc.c:209), not below q. */
+uint32_t orc_bignKeypairGen(size_t l, uint8_t *privkey, uint8_t *pubkey, const uint8_t *rnd, size_t ndraws, size_t *used)
+{
+    curve E;
+    uint64_t d[MAXW] = {0};
+    size_t i = 0;
+    if (l != 128 && l != 192 && l != 256) return ORC_BAD_PARAMS;
+    curve_init(&E, (int)l);
+    for (;; ++i) {
+        if (i == ndraws) return ORC_BAD_RNG;
+        words_from_le(d, rnd + i * (l / 4), E.n);        /* wwBitSize(p) = 2l: nothing to trim */
+        if (!words_is_zero(d, E.n) && words_cmp(d, E.p, E.n) < 0) break;
+    }
+    if (used) *used = i + 1;
+    words_to_le(privkey, d, E.n);
+    {
+        fe x, y;
+        if (!mul_base(&E, &x, &y, d)) return ORC_BAD_PARAMS;
+        words_to_le(pubkey, x.v, E.n);
+        words_to_le(pubkey + l / 4, y.v, E.n);
+    }
+    return ORC_OK;
+}
+
+/* the common tail of bignSignEc / bignSign2Ec from "R <- k G" on (bign_sign.c:84-108 = :214-241) */
+static uint32_t sign_with_k(const curve *E, size_t l, uint8_t *sig, const uint8_t *oid_der, size_t oid_len,
+                            const uint8_t *hash, const uint64_t d[MAXW], const uint64_t k[MAXW])
+{
+    const int n = E->n, no = (int)l / 4;
+    fe x, y;
+    uint8_t msg[256 + 128], t[32];
+    uint64_t s0[MAXW] = {0}, prod[2 * MAXW] = {0}, s1[MAXW], H[MAXW] = {0};
+    if (!mul_base(E, &x, &y, k)) return ORC_BAD_PARAMS;
+    memcpy(msg, oid_der, oid_len);
+    words_to_le(msg + oid_len, x.v, n);
+    memcpy(msg + oid_len + no, hash, no);
+    orc_beltHash(t, msg, oid_len + 2 * no);
+    memcpy(sig, t, no / 2);                                      /* s0 = first l bits */
+    /* (s0 + 2^l) d */
+    for (int i = 0; i < n / 2; ++i) {
+        uint64_t w = 0;
+        for (int b = 7; b >= 0; --b) w = (w << 8) | sig[8 * i + b];
+        s0[i] = w;
+    }
+    s0[n / 2] = 1;
+    for (int i = 0; i <= n / 2; ++i) {
+        u128 carry = 0;
+        for (int j = 0; j < n; ++j) {
+            carry += (u128)s0[i] * d[j] + prod[i + j];
+            prod[i + j] = (uint64_t)carry;
+            carry >>= 64;
+        }
+        prod[i + n] += (uint64_t)carry;
+    }
+    mod_q(E, s1, prod, n + n / 2 + 1);
+    sub_mod_q(E, s1, k, s1);                                     /* k - (s0 + 2^l) d */
+    words_from_le(H, hash, n);
+    sub_mod_q(E, s1, s1, H);                                     /* ... - H, H as it is */
+    words_to_le(sig + no / 2, s1, n);
+    return ORC_OK;
+}
+
+/* OID DER syntax is not re-checked here (as in orc_bignVerify_ex): the product's check is pinned on its own
+   (tests/golden/bign_oid_der.json) */
+/* bignSign with the rng replaced by its output: k = first draw in {1..q-1} */
+uint32_t orc_bignSign_rnd(size_t l, uint8_t *sig, const uint8_t *oid_der, size_t oid_len, const uint8_t *hash,
+                          const uint8_t *privkey, const uint8_t *rnd, size_t ndraws, size_t *used)
+{
+    curve E;
+    uint64_t d[MAXW] = {0}, k[MAXW] = {0};
+    size_t i = 0;
+    if (l != 128 && l != 192 && l != 256) return ORC_BAD_PARAMS;
+    if (oid_len > 256) return ORC_BAD_OID;
+    curve_init(&E, (int)l);
+    words_from_le(d, privkey, E.n);
+    if (words_is_zero(d, E.n) || words_cmp(d, E.q, E.n) >= 0) return ORC_BAD_PRIVKEY;
+    for (;; ++i) {
+        if (i == ndraws) return ORC_BAD_RNG;
+        words_from_le(k, rnd + i * (l / 4), E.n);
+        if (!words_is_zero(k, E.n) && words_cmp(k, E.q, E.n) < 0) break;
+    }
+    if (used) *used = i + 1;
+    return sign_with_k(&E, l, sig, oid_der, oid_len, hash, d, k);
+}
+
+uint32_t orc_bignSign2(size_t l, uint8_t *sig, const uint8_t *oid_der, size_t oid_len, const uint8_t *hash,
+                       const uint8_t *privkey, const void *t, size_t t_len)
+{
+    curve E;
+    uint64_t d[MAXW] = {0}, k[MAXW] = {0};
+    uint8_t theta[32], kb[64], *msg;
+    uint32_t K[8];
+    if (l != 128 && l != 192 && l != 256) return ORC_BAD_PARAMS;
+    if (oid_len > 256) return ORC_BAD_OID;
+    curve_init(&E, (int)l);
+    const int n = E.n, no = (int)l / 4;
+    words_from_le(d, privkey, n);
+    if (words_is_zero(d, n) || words_cmp(d, E.q, n) >= 0) return ORC_BAD_PRIVKEY;
+    /* theta = belt-hash(oid || d || t) (:197-202) */
+    {
+        uint8_t stack_msg[256 + 64 + 256];
+        msg = stack_msg;
+        if (t_len > 256) return ORC_BAD_INPUT;                     /* checker limit, not the reference's */
+        memcpy(msg, oid_der, oid_len);
+        memcpy(msg + oid_len, privkey, no);
+        if (t) memcpy(msg + oid_len + no, t, t_len);
+        orc_beltHash(theta, msg, oid_len + no + (t ? t_len : 0));
+    }
+    /* k = H; k <- belt-wbl_theta(k) until k in {1..q-1} (:203-216) */
+    orc_beltKeyExpand2(K, theta, 32);
+    memcpy(kb, hash, no);
+    for (;;) {
+        orc_beltWBL(kb, (size_t)no / 16, K, 0);
+        words_from_le(k, kb, n);
+        if (!words_is_zero(k, n) && words_cmp(k, E.q, n) < 0) break;
+    }
+    return sign_with_k(&E, l, sig, oid_der, oid_len, hash, d, k);
+}
+
 /* ---- reference driver (see bash_oracle.c) ---- */
 typedef uint32_t (*ref_verify_fn)(const uint8_t *hash, const uint8_t *sig, const uint8_t *pubkey);
 typedef struct { const uint8_t *h, *s, *k; uint32_t *codes; ref_verify_fn f; size_t no; } ref_vjob;

@@ -164,6 +164,16 @@ void orc_bignVerify_batch(size_t l, const uint8_t *oid_der, size_t oid_len, cons
                           const uint8_t *sigs, const uint8_t *pubkeys, size_t n, uint32_t *codes,
                           int nthreads);
 
+/* SURVEY.md 8f-4, second half: public key from private key, key generation, signing
+   (bign_misc.c:182-229,373-417, bign_sign.c:32-245).  rng-driven entries take the rng's OUTPUT
+   (consecutive l/4-octet draws) instead of a callback. */
+uint32_t orc_bignPubkeyCalc(size_t l, uint8_t *pubkey, const uint8_t *privkey);
+uint32_t orc_bignKeypairGen(size_t l, uint8_t *privkey, uint8_t *pubkey, const uint8_t *rnd, size_t ndraws, size_t *used);
+uint32_t orc_bignSign_rnd(size_t l, uint8_t *sig, const uint8_t *oid_der, size_t oid_len, const uint8_t *hash,
+                          const uint8_t *privkey, const uint8_t *rnd, size_t ndraws, size_t *used);
+uint32_t orc_bignSign2(size_t l, uint8_t *sig, const uint8_t *oid_der, size_t oid_len, const uint8_t *hash,
+                       const uint8_t *privkey, const void *t, size_t t_len);
+
 /* ---- mixed bash512 + beltMAC per message (H4) ---------------------------- */
 void orc_bash512_beltMAC_batch(const uint8_t *msgs, size_t msg_len, size_t n,
                                const uint8_t *key, size_t key_len,

@@ -42,6 +42,8 @@ class Golden:
             self.belt_dwp = json.load(f)
         with open(os.path.join(GOLD, "belt_che.json")) as f:
             self.belt_che = json.load(f)
+        with open(os.path.join(GOLD, "bign_sign.json")) as f:
+            self.bign_sign = json.load(f)
 
     def bign_base_arrays(self):
         hs = b"".join(t[0] for t in self.bign_base)

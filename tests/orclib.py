@@ -221,6 +221,36 @@ class Oracle:
         self.lib.orc_bignPubkeyVal.restype = ctypes.c_uint32
         return self.lib.orc_bignPubkeyVal(_sz(l), bytes(pub))
 
+    # ---- 8f-4 tail (oracle/bign_oracle.c): rng-driven entries take the rng's output stream
+    def pubkey_calc(self, l, priv):
+        out = ctypes.create_string_buffer(l // 2)
+        self.lib.orc_bignPubkeyCalc.restype = ctypes.c_uint32
+        return self.lib.orc_bignPubkeyCalc(_sz(l), out, bytes(priv)), out.raw
+
+    def keypair_gen(self, l, rnd):
+        no = l // 4
+        priv = ctypes.create_string_buffer(no)
+        pub = ctypes.create_string_buffer(2 * no)
+        used = _sz(0)
+        self.lib.orc_bignKeypairGen.restype = ctypes.c_uint32
+        code = self.lib.orc_bignKeypairGen(_sz(l), priv, pub, bytes(rnd), _sz(len(rnd) // no), ctypes.byref(used))
+        return code, priv.raw, pub.raw, used.value
+
+    def sign2(self, l, oid, h, priv, t=None):
+        sig = ctypes.create_string_buffer(3 * l // 8)
+        self.lib.orc_bignSign2.restype = ctypes.c_uint32
+        code = self.lib.orc_bignSign2(_sz(l), sig, bytes(oid), _sz(len(oid)), bytes(h), bytes(priv), t, _sz(len(t) if t else 0))
+        return code, sig.raw
+
+    def sign_rnd(self, l, oid, h, priv, rnd):
+        no = l // 4
+        sig = ctypes.create_string_buffer(3 * l // 8)
+        used = _sz(0)
+        self.lib.orc_bignSign_rnd.restype = ctypes.c_uint32
+        code = self.lib.orc_bignSign_rnd(_sz(l), sig, bytes(oid), _sz(len(oid)), bytes(h), bytes(priv), bytes(rnd),
+                                         _sz(len(rnd) // no), ctypes.byref(used))
+        return code, sig.raw, used.value
+
     def pubkey_val_batch(self, l, pubs):
         n = len(pubs) // (l // 2)
         codes = (ctypes.c_uint32 * max(n, 1))()

@@ -252,3 +252,52 @@ def test_sigvfy_pipeline_oracle_vs_golden(orc, golden):
             assert dig == bytes.fromhex(it["digest"])
             assert orc.pubkey_val(l, pub) == it["pubkey_val"]
             assert orc.verify_l(l, LEVEL_OID[l], dig, sig, pub) == it["verify"]
+
+
+def test_bign_sign_keygen_oracle_vs_golden(orc, golden):
+    """SURVEY 8f-4 tail: the oracle's PubkeyCalc / KeypairGen / Sign / Sign2 against the reference's answers
+    (tests/golden/bign_sign.json, tools/make_golden_sign.py), incl. the STB 34.101.45 annex G vectors"""
+    S = golden.bign_sign
+    k = S["stb"]
+    oid = bytes.fromhex(k["oid"])
+    g1 = k["G1"]
+    code, priv, pub, used = orc.keypair_gen(128, bytes.fromhex(g1["rnd"]))
+    assert (code, priv.hex(), pub.hex(), used) == (0, g1["priv"], g1["pub"], 1)
+    assert orc.pubkey_calc(128, bytes.fromhex(g1["priv"])) == (0, bytes.fromhex(g1["pub"]))
+    for name in ("G2", "G3"):
+        c = k[name]
+        code, sig, _ = orc.sign_rnd(128, oid, bytes.fromhex(c["hash"]), bytes.fromhex(c["priv"]), bytes.fromhex(c["rnd"]))
+        assert (code, sig.hex()) == (0, c["sig"]), name
+    for name in ("G6", "G7"):
+        c = k[name]
+        t = None if c["t"] is None else bytes.fromhex(c["t"])
+        code, sig = orc.sign2(128, oid, bytes.fromhex(c["hash"]), bytes.fromhex(c["priv"]), t)
+        assert (code, sig.hex()) == (0, c["sig"]), name
+    for l in (128, 192, 256):
+        L = S[str(l)]
+        no = l // 4
+        for c in L["pubkey_calc"]:
+            code, pub = orc.pubkey_calc(l, bytes.fromhex(c["priv"]))
+            assert code == c["code"] and (code or pub.hex() == c["pub"]), c["priv"]
+        for c in L["keypair_gen"]:
+            code, priv, pub, used = orc.keypair_gen(l, bytes.fromhex(c["rnd"]))
+            if not c["defined"]:              # draw in [q, p): outside the reference multiplier's contract
+                assert used * no == c["used"]
+                continue
+            assert code == c["code"], c
+            if code == 0:
+                assert (priv.hex(), pub.hex(), used * no) == (c["priv"], c["pub"], c["used"])
+        for c in L["sign2"]:
+            if c["code"] == 301:
+                continue                      # OID syntax is the product's check (pinned by oid_der_cases.json)
+            t = None if c["t"] is None else bytes.fromhex(c["t"])
+            if t is not None and len(t) > 256:
+                continue                      # checker limit
+            code, sig = orc.sign2(l, bytes.fromhex(c["oid"]), bytes.fromhex(c["hash"]), bytes.fromhex(c["priv"]), t)
+            assert code == c["code"] and (code or sig.hex() == c["sig"]), c
+        for c in L["sign"]:
+            code, sig, used = orc.sign_rnd(l, bytes.fromhex(c["oid"]), bytes.fromhex(c["hash"]), bytes.fromhex(c["priv"]),
+                                           bytes.fromhex(c["rnd"]))
+            assert code == c["code"], c
+            if code == 0:
+                assert (sig.hex(), used * no) == (c["sig"], c["used"])

@@ -224,3 +224,24 @@ def test_belt_dwp_che_step_sequences_with_midstream_tags(orc, mode):
             assert rc == oc == (0 if mac == m.raw else 511)
             if rc == 0:
                 assert od == d2.raw[: len(crit)] == crit
+
+
+def test_sign2_pubkey_calc_random(orc):
+    """8f-4 tail: the oracle's bignSign2 / bignPubkeyCalc against the reference on random keys, hashes and
+    additional inputs, all three curves; every reference signature verifies under the reference"""
+    L = refgen.ref()
+    rnd = random.Random(0x5164)
+    oid = {128: bytes.fromhex("06092A7000020022651F51"), 192: bytes.fromhex("06092A7000020022654D0C"),
+           256: bytes.fromhex("06092A7000020022654D0D")}
+    for l in (128, 192, 256):
+        no, sg, pk = refgen.SIZES[l]
+        rng = refgen.Combo(4000 + l)
+        for it in range(200 if l == 128 else 60):
+            priv, pub = refgen.keypair_l(l, rng)
+            assert orc.pubkey_calc(l, priv) == (0, pub)
+            h = rng.bytes(no)
+            t = rnd.randbytes(rnd.randrange(0, 80)) if it % 3 else None
+            want = ctypes.create_string_buffer(sg)
+            assert getattr(L, f"bign{l}Sign2")(want, h, priv, t, _sz(len(t) if t else 0)) == 0
+            assert orc.sign2(l, oid[l], h, priv, t) == (0, want.raw)
+            assert refgen.verify_l(l, h, want.raw, pub) == 0
