@@ -57,7 +57,7 @@ def valu_picture(units_per_s, mix, lanes=64):
             "mix": mix}
 
 
-WORKLOADS = ("bashF", "ctr", "verify", "mixed", "modes", "ragged", "dwp")
+WORKLOADS = ("bashF", "ctr", "verify", "sign", "mixed", "modes", "ragged", "dwp", "latency")
 
 
 def parse():
@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--only", default="", help="comma list of {bashF,ctr,verify,mixed,modes,ragged,dwp}; default all")
+    ap.add_argument("--only", default="", help="comma list of {bashF,ctr,verify,sign,mixed,modes,ragged,dwp,latency}; default all")
     ap.add_argument("--ctr-gib", type=float, default=16.0)
     args = ap.parse_args()
     bad = set(x for x in args.only.split(",") if x) - set(WORKLOADS)
@@ -139,13 +139,40 @@ def timed(dist, steps, warmup, fn):
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
+    # hipEvents on the stream the kernels are launched on (torch's current stream: Engine._stream), recorded
+    # INSIDE the timed region around the same K launches: roofline.avg_launch_ms = their distance / K
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()
     for _ in range(steps):
         fn()
+    e1.record()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
-    return dist.max(time.perf_counter() - t0)
+    wall = time.perf_counter() - t0
+    timed.event_ms = e0.elapsed_time(e1) / steps
+    return dist.max(wall)
+
+
+timed.event_ms = 0.0
+
+
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc summary of this round (separate FETCH_SIZE /
+    WRITE_SIZE passes, FETCH_SIZE doubled for wide coalesced reads as MI355X_MICROARCH.md prescribes): a replay of
+    that profiling run, labelled as such -- counters cannot be collected inside an un-profiled bench run."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    if not os.path.exists(path):
+        return None, None
+    try:
+        d = json.load(open(path))
+        for k, v in d.get("kernels", {}).items():
+            if kernel_substr in k and "hbm_bytes_per_launch" in v:
+                return v["hbm_bytes_per_launch"], f"profiles/r02_pmc_summary.json @ {d.get('commit', '?')} ({v.get('note', 'rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE')})"
+    except Exception:
+        pass
+    return None, None
 
 
 # ------------------------------------------------------------------------- CPU baseline
@@ -294,25 +321,19 @@ def main():
         fill_seeded(st, 0xBA5F + dist.rank)                      # synthetic states, generated in HBM
         el = timed(dist, K, W, lambda: eng.bashF_batch_dev(st))
         value = N * n * K / el
-        ms_launch = eng.time_kernel(0, max(K, 50), st, n=n)       # hipEvents on the launch stream
+        ms_launch = timed.event_ms                                # hipEvents around the K timed launches themselves
         ach = BASHF_BYTES * n / (ms_launch * 1e-3) / 1e9
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01_bashF_pmc.json")
-        if os.path.exists(prof):
-            try:
-                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = pmc_traffic("bashF_tile_kernel")
         result = {
             "metric": "bashF perms/s", "value": value, "unit": "perms/s", "n_gpus": N, "steps": K, "warmup": W,
             "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "bashF batch: 2^20 independent 192-byte sponge states per GPU (BASELINE configs[1])",
                        "states_per_gpu": n, "parallelism": f"dp{N} (index-sharded, no data-path collective)"},
-            "roofline": {"kernel": "bashF_batch_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"kernel": "bashF_tile_kernel<0, 2, 124, 6, 3>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": ms_launch, "algorithmic_bytes_per_launch": BASHF_BYTES * n,
-                         "note": "VALU-issue bound in practice, see `valu` (DESIGN.md 2, 4.1)",
+                         "note": "power / VALU-issue bound in practice: the chip sustains 1.7-1.9 GHz under this kernel, see `valu` (DESIGN.md 2, 4.1)",
                          "valu": valu_picture(n / (ms_launch * 1e-3), BASHF_VALU)},
         }
         if dist.rank == 0 and N == 1:       # PCIe-inclusive rate: single-GPU runs only
@@ -338,14 +359,16 @@ def main():
         _, _, first = shard.ctr_shard(dist.rank, N, nbytes * N)     # rank r owns blocks [r nb, (r+1) nb)
         kc = max(3, min(K, 10))
         el = timed(dist, kc, 2, lambda: eng.beltCTR_blocks_dev(buf, kw, c0, first))
-        ms_launch = eng.time_kernel(1, kc, buf, n=nb)
+        ms_launch = timed.event_ms
         ach = CTR_BYTES_PER_BLOCK * nb / (ms_launch * 1e-3) / 1e9
+        ctr_traffic, ctr_traffic_src = pmc_traffic("beltCTR_blocks_kernel")
         others["beltCTR"] = {
             "metric": "beltCTR GiB/s", "value": N * nbytes * kc / el / 2 ** 30, "unit": "GiB/s", "steps": kc,
             "ms_per_step": el / kc * 1e3,
             "config": {"workload": f"beltCTR bulk encrypt, {nbytes / 2**30:.1f} GiB stream per GPU, one key (BASELINE configs[2])"},
             "roofline": {"kernel": "beltCTR_blocks_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms_launch,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": ctr_traffic, "traffic_source": ctr_traffic_src,
+                         "avg_launch_ms": ms_launch,
                          "note": "VALU/LDS-issue bound, not HBM: per block ~695 VALU ops (floor 930 GiB/s) and "
                                  "224 ds_read_b32 (floor 1146 GiB/s), DESIGN.md 2 and 4.2",
                          "valu": valu_picture(nb / (ms_launch * 1e-3), CTR_VALU)},
@@ -385,7 +408,7 @@ def main():
         codes = torch.empty(n, dtype=torch.int32, device="cuda")
         kv = max(3, min(K, 10))
         el = timed(dist, kv, 2, lambda: eng.bign128Verify_batch_dev(dh, ds, dk, codes))
-        ms_launch = eng.time_kernel(2, kv, dh, ds, dk, codes, n=n)
+        ms_launch = timed.event_ms
         got = codes.cpu().numpy()
         okmask = np.ones(n, dtype=bool)
         okmask[bad] = False
@@ -424,13 +447,15 @@ def main():
         nk = kk.numel() // 64
         kcodes = torch.empty(nk, dtype=torch.int32, device="cuda")
         el = timed(dist, kv, 2, lambda: eng.bignPubkeyValL_batch_dev(128, kk, kcodes))
-        ach = 68 * nk * kv / el / 1e9
+        ach = 68 * nk / (timed.event_ms * 1e-3) / 1e9
+        pv_traffic, pv_traffic_src = pmc_traffic("bign_pubkey_val_kernel")
         others["bignPubkeyVal"] = {
             "metric": "bign-curve256v1 public keys validated/s", "value": N * nk * kv / el, "unit": "keys/s", "steps": kv,
             "ms_per_step": el / kv * 1e3, "all_valid": bool((kcodes == 0).all()),
             "config": {"workload": f"bignPubkeyVal batch: {nk} keys per GPU (the 2048 genuine keys tiled)"},
             "roofline": {"kernel": "bign_pubkey_val_kernel<8>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pv_traffic, "traffic_source": pv_traffic_src,
+                         "avg_launch_ms": timed.event_ms,
                          "note": "68 B per key (64 in + 4 out); 2 squarings + 1 multiplication per key are ~0.3 ms of VALU work for "
                                  "2^24 keys, i.e. arithmetic and HBM demands are about equal; wall time per launch"}}
         if do_cpu:
@@ -484,6 +509,106 @@ def main():
                         "value": cnt / (time.perf_counter() - t0), "unit": "verifies/s", "cores": 1,
                         "kind": "reference", "sample": "1.5 s of bign%dVerify calls, one thread" % l}
             del th, ts, tp, tc
+
+    # ---------------------------------------------- 8f-4 tail: key generation / signing (constant-time kernels)
+    if "sign" in only:
+        from bee2_amd.engine import LEVEL_OID
+        l, no, sg = 128, 32, 48
+        n = 1 << 18
+        privs = torch.empty(no * n, dtype=torch.uint8, device="cuda")
+        fill_seeded(privs, 0x5164 + dist.rank)
+        privs.view(-1, no)[:, no - 1] &= 0x7F                       # d < 2^255 < q: every key valid
+        privs.view(-1, no)[:, 0] |= 1
+        hsh = torch.empty(no * n, dtype=torch.uint8, device="cuda")
+        fill_seeded(hsh, 0x5165 + dist.rank)
+        sigs = torch.empty(sg * n, dtype=torch.uint8, device="cuda")
+        pubs = torch.empty(2 * no * n, dtype=torch.uint8, device="cuda")
+        sc = torch.empty(n, dtype=torch.int32, device="cuda")
+        ks = max(3, min(K, 10))
+        el = timed(dist, ks, 2, lambda: eng.bignSign2L_batch_dev(l, LEVEL_OID[l], hsh, privs, sigs, sc))
+        ms_sign = timed.event_ms
+        el_k = timed(dist, ks, 2, lambda: eng.bignPubkeyCalcL_batch_dev(l, privs, pubs, sc))
+        ms_calc = timed.event_ms
+        vc = torch.empty(n, dtype=torch.int32, device="cuda")
+        eng.bignVerifyL_batch_dev(l, LEVEL_OID[l], hsh, sigs, pubs, vc)        # not timed: every signature must verify
+        torch.cuda.synchronize()
+        # 32x32+64 multiply-adds per signature: 64 windows x 13 multiplications x (64 + 8), a^(p-2) = 255 S x 52 + 13 M x 72,
+        # 2 M for the affine coordinates; the belt work (16 block encryptions) and the table scan have none
+        mads = 64 * 13 * 72 + 255 * 52 + 15 * 72
+        others["bignSign2"] = {
+            "metric": "bign-curve256v1 deterministic signatures/s", "value": N * n * ks / el, "unit": "signatures/s", "steps": ks,
+            "ms_per_step": el / ks * 1e3, "all_verify": bool((vc == 0).all() and (sc == 0).all()),
+            "config": {"workload": f"bignSign2 batch: {n} (hash, private key) pairs per GPU on bign-curve256v1, no additional input; "
+                                   "constant-time kernels (nonce by belt-hash + belt-wbl, comb with full-row table scans, "
+                                   "complete additions, a^(p-2)); every signature verified afterwards (untimed)"},
+            "roofline": {"kernels": "bign_sign_nonce + bign_mulbase_ct + bign_sign_tail", "bound": "valu-int", "avg_batch_ms": ms_sign,
+                         "mads_per_signature": mads, "achieved": mads * n / (ms_sign * 1e-3) / 1e12, "peak": MAD_PEAK_T,
+                         "unit": "T v_mad_u64_u32 lane-ops/s", "frac": mads * n / (ms_sign * 1e-3) / 1e12 / MAD_PEAK_T,
+                         "note": "same multiplier formulation as verification (each mad paired with a half-rate addc: 0.5 is the ceiling)"},
+            "pubkey_calc": {"value": N * n * ks / el_k, "unit": "keys/s", "ms_per_step": el_k / ks * 1e3, "avg_batch_ms": ms_calc},
+        }
+        if do_cpu:
+            import refgen
+            if refgen.have_ref():
+                ref = ctypes.CDLL(refgen.REF_SO)
+                ref.bign128Sign2.restype = ctypes.c_uint32
+                hh, pp = hsh[: no * 512].cpu().numpy().tobytes(), privs[: no * 512].cpu().numpy().tobytes()
+                out = ctypes.create_string_buffer(sg)
+                t0, cnt = time.perf_counter(), 0
+                while time.perf_counter() - t0 < 3.0:
+                    i = cnt % 512
+                    ref.bign128Sign2(out, hh[no * i: no * i + no], pp[no * i: no * i + no], None, ctypes.c_size_t(0))
+                    cnt += 1
+                others["bignSign2"]["cpu_baseline"] = {
+                    "value": cnt / (time.perf_counter() - t0), "unit": "signatures/s", "cores": 1, "kind": "reference",
+                    "sample": "3 s of bign128Sign2 calls on 512 of the same (hash, key) pairs, one thread "
+                              "(bee2's process-global curve object serialises threads, as for verification)"}
+        del privs, hsh, sigs, pubs, sc, vc
+
+    # ------------------------------------------- single-call latency of the drop-in entry points (host pointers)
+    if "latency" in only and dist.rank == 0 and N == 1:
+        lat = {}
+
+        def us_per_call(fn, reps):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return (time.perf_counter() - t0) / reps * 1e6
+        blk = ctypes.create_string_buffer(192)
+        lat["bashF (192 B)"] = us_per_call(lambda: eng.lib.bashF(blk, None), 200)
+        st_ctr = ctypes.create_string_buffer(eng.lib.beltCTR_keep())
+        eng.lib.beltCTRStart(st_ctr, H[128:160], ctypes.c_size_t(32), H[192:208])
+        b16 = ctypes.create_string_buffer(16)
+        lat["beltCTRStepE (16 B)"] = us_per_call(lambda: eng.lib.beltCTRStepE(b16, ctypes.c_size_t(16), st_ctr), 200)
+        b64k = ctypes.create_string_buffer(1 << 16)
+        lat["beltCTRStepE (64 KiB)"] = us_per_call(lambda: eng.lib.beltCTRStepE(b64k, ctypes.c_size_t(1 << 16), st_ctr), 100)
+        import goldenlib
+        Gk = goldenlib.Golden()
+        h0, s0, p0 = Gk.bign_base[0]
+        lat["bign128Verify"] = us_per_call(lambda: eng.lib.bign128Verify(h0, s0, p0), 50)
+        d0 = bytes(range(1, 33))
+        sg0 = ctypes.create_string_buffer(48)
+        lat["bign128Sign2"] = us_per_call(lambda: eng.lib.bign128Sign2(sg0, h0, d0, None, ctypes.c_size_t(0)), 50)
+        lat["beltHash (1 KiB)"] = us_per_call(lambda: eng.lib.beltHash(ctypes.create_string_buffer(32), bytes(1024), ctypes.c_size_t(1024)), 100)
+        entry = {"unit": "us per call", "gpu_dropin": lat,
+                 "note": "one call = H2D + launch(es) + D2H on the NULL stream; the drop-in is for source compatibility, the batch "
+                         "entry points are the fast path (INTEGRATION.md gives the crossover sizes)"}
+        if do_cpu:
+            import refgen
+            if refgen.have_ref():
+                ref = ctypes.CDLL(refgen.REF_SO)
+                cpu = {}
+                cpu["bashF (192 B)"] = us_per_call(lambda: ref.bashF(blk, None), 20000)
+                rst = ctypes.create_string_buffer(ref.beltCTR_keep())
+                ref.beltCTRStart(rst, H[128:160], ctypes.c_size_t(32), H[192:208])
+                cpu["beltCTRStepE (16 B)"] = us_per_call(lambda: ref.beltCTRStepE(b16, ctypes.c_size_t(16), rst), 20000)
+                cpu["beltCTRStepE (64 KiB)"] = us_per_call(lambda: ref.beltCTRStepE(b64k, ctypes.c_size_t(1 << 16), rst), 500)
+                cpu["bign128Verify"] = us_per_call(lambda: ref.bign128Verify(h0, s0, p0), 300)
+                cpu["bign128Sign2"] = us_per_call(lambda: ref.bign128Sign2(sg0, h0, d0, None, ctypes.c_size_t(0)), 300)
+                cpu["beltHash (1 KiB)"] = us_per_call(lambda: ref.beltHash(ctypes.create_string_buffer(32), bytes(1024), ctypes.c_size_t(1024)), 2000)
+                entry["cpu_reference"] = cpu
+        others["single_call_latency_us"] = entry
 
     # -------------------------------------------------------------------------- mixed
     if "mixed" in only:

@@ -1,14 +1,15 @@
 #!/bin/bash
-# rocprofv3 evidence for round 1 (run on the GPU box via gpurun; outputs under gpurun_out/prof)
+# rocprofv3 evidence for a round (run on the GPU box via gpurun; outputs under gpurun_out/prof;
+# then here: python tools/summarize_prof.py rNN)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd $R
 CMD="python bench.py --steps 20 --warmup 3 --no-cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- $CMD --only bashF,ctr --ctr-gib 4 > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- $CMD --only bashF,ctr,verify --ctr-gib 4 > $OUT/pmc_$c.log 2>&1
 done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $OUT/pmc_sq1 -o bench -- $CMD --ctr-gib 4 > $OUT/pmc_sq1.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq2 -o bench -- $CMD --ctr-gib 4 > $OUT/pmc_sq2.log 2>&1

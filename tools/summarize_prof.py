@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof (rocprofv3 output of tools/profile_r01.sh) into the small,
+"""Condense gpurun_out/prof (rocprofv3 output of tools/profile_round.sh) into the small,
 committed summaries under profiles/.   usage: python tools/summarize_prof.py r01"""
 import collections
 import csv
@@ -53,8 +53,27 @@ def main(tag):
             summary[f] = agg(p)
     with open(os.path.join(DST, f"{tag}_pmc_summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
-    # per-kernel HBM traffic for bench.py's roofline.traffic
-    for kern, fname, alg in (("bashF_batch_kernel", f"{tag}_bashF_pmc.json", 384 * (1 << 20)),):
+    # per-kernel HBM traffic for bench.py's roofline.traffic (pmc_traffic() replays it, labelled with file + commit)
+    import subprocess
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        commit = "?"
+    kernels = {}
+    for kern in ("bashF_tile_kernel", "bashF_batch_kernel", "beltCTR_blocks_kernel", "bign_pubkey_val_kernel"):
+        pickk = lambda d: next(((k, v) for k, v in d.items() if k.startswith(kern)), (None, None))  # noqa: E731
+        kf, fe = pickk(summary.get("pmc_FETCH_SIZE", {}))
+        kw, wr = pickk(summary.get("pmc_WRITE_SIZE", {}))
+        if fe and wr:
+            kernels[kf] = {"FETCH_SIZE_KiB": fe["FETCH_SIZE"], "WRITE_SIZE_KiB": wr["WRITE_SIZE"],
+                           "hbm_bytes_per_launch": (2 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024,
+                           "avg_duration_ns_under_pmc": fe["duration_ns"],
+                           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x 2 (gfx950)"}
+    summary["kernels"] = kernels
+    summary["commit"] = commit
+    with open(os.path.join(DST, f"{tag}_pmc_summary.json"), "w") as fh:
+        json.dump(summary, fh, indent=1)
+    for kern, fname, alg in (("bashF_tile_kernel" if tag != "r01" else "bashF_batch_kernel", f"{tag}_bashF_pmc.json", 384 * (1 << 20)),):
         pick = lambda d: next((v for k, v in d.items() if k.startswith(kern)), None)  # noqa: E731
         fe = pick(summary.get("pmc_FETCH_SIZE", {}))
         wr = pick(summary.get("pmc_WRITE_SIZE", {}))
