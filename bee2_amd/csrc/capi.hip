@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <vector>
 #include <stdio.h>
@@ -80,12 +81,36 @@ err_t ensure_device()
 // NULL stream is the exception -- every thread of the host-pointer / drop-in API launches on it, and
 // thread B's first kernel may run between thread A's first and second -- so there the key also carries
 // the calling thread.  (A caller who drives one non-null stream from several threads at once has to
-// serialise them himself, as for any stream.)  Buffers live until process exit.
+// serialise them himself, as for any stream.)  Stream-keyed buffers live until process exit; the NULL-stream
+// buffers of a thread are released when that thread exits (ThreadReaper below) -- a thread-per-request caller
+// of the drop-in API must not accumulate device memory.
 struct PoolEntry { int dev; hipStream_t st; int slot; unsigned tid; void *p; size_t bytes; };
 static std::mutex g_pool_mu;
 static std::vector<PoolEntry> g_pool;
 static std::atomic<unsigned> g_next_tid{1};
 static thread_local unsigned t_tid = 0;
+
+// The thread that loaded the library (normally the main thread) runs its thread_local destructors during process
+// teardown, when the HIP runtime may already be unusable: it leaks on purpose.  Every other thread exits while
+// the runtime is alive and frees what it owns.
+static const std::thread::id g_loader_thread = std::this_thread::get_id();
+static bool on_loader_thread() { return std::this_thread::get_id() == g_loader_thread; }
+struct ThreadReaper {
+    void touch() {}
+    ~ThreadReaper()
+    {
+        if (on_loader_thread() || t_tid == 0) return;
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size();) {
+            if (g_pool[i].tid == t_tid) {
+                if (g_pool[i].p) (void)hipFree(g_pool[i].p);      // the thread's calls were synchronous: nothing is in flight
+                g_pool[i] = g_pool.back();
+                g_pool.pop_back();
+            } else ++i;
+        }
+    }
+};
+static thread_local ThreadReaper t_reaper;
 
 err_t scratch_for_stream(hipStream_t st, int slot, size_t bytes, void **out)
 {
@@ -93,7 +118,7 @@ err_t scratch_for_stream(hipStream_t st, int slot, size_t bytes, void **out)
     B2H_TRY(hipGetDevice(&dev));
     unsigned tid = 0;
     if (st == nullptr) {
-        if (t_tid == 0) t_tid = g_next_tid.fetch_add(1);
+        if (t_tid == 0) { t_tid = g_next_tid.fetch_add(1); t_reaper.touch(); }
         tid = t_tid;
     }
     std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -134,7 +159,12 @@ struct Scratch {
         }
         return ERR_OK;
     }
-    ~Scratch() { /* process teardown: the runtime may already be gone; leak deliberately */ }
+    ~Scratch()
+    {
+        // thread exit: give the block back, except on the loader thread (process teardown, see ThreadReaper)
+        if (p && !on_loader_thread()) (void)hipFree(p);
+        p = nullptr;
+    }
 };
 static thread_local Scratch t_scr[4];
 

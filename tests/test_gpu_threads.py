@@ -63,3 +63,35 @@ def test_dropin_calls_from_eight_threads(orc, golden):
         th.join(timeout=300)
     assert not any(th.is_alive() for th in threads), "a thread is stuck"
     assert not errors, errors[:5]
+
+
+def test_short_lived_threads_do_not_leak_device_memory(orc, golden):
+    """a thread-per-request caller of the drop-in API: per-thread staging and NULL-stream scratch are released
+    when the thread exits (they used to stay allocated for ever)"""
+    import threading
+
+    import torch
+
+    from gpulib import engine
+    eng = engine()
+    h, s, p = golden.bign_base[0]
+    key = golden.H[128:160]
+
+    def one():
+        eng.set_device(0)
+        assert eng.bign128Verify(h, s, p) == 0
+        eng.beltMAC(bytes(1000), key)
+        eng.beltHash(bytes(70000))
+
+    def burst(k):
+        for _ in range(k):
+            t = threading.Thread(target=one)
+            t.start()
+            t.join()
+    burst(8)                                   # tables, first-use allocations
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    burst(150)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (4 << 20), f"device memory shrank by {(free0 - free1) >> 10} KiB over 150 threads"
