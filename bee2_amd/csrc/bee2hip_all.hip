@@ -7,3 +7,4 @@
 #include "bign_sign_kernels.hip"
 #include "mixed_kernels.hip"
 #include "capi.hip"
+#include "multi.hip"

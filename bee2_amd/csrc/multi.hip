@@ -1,0 +1,198 @@
+// multi.hip -- one host batch over every visible GPU from ONE process (VERDICT r01 "next" 3b).
+//
+// bench.py and the tests shard with one process per GPU over torch.distributed; a plain C caller of the
+// library (bee2cmd-style programs, examples/bsum_hip.c) has no such launcher.  The *_multi entry points give
+// him the same partition: the batch is cut into contiguous index ranges, one worker thread per device does
+// hipSetDevice + the single-device host entry on its range, nothing crosses devices (the 48 bytes of key +
+// counter are arguments of the call).  CTR hands every range its first_block so lanes compute
+// ctr0 + first + i + 1 directly (belt_ctr.c:27-35 -- the serial counter walk is not replayed).
+//
+// BEE2HIP_FAKE_DEVICES=k makes the library pretend there are k devices, mapped round-robin onto the real ones:
+// the sharding, the threads and the state hand-over can then be exercised on a one-GPU box
+// (tests/test_gpu_multi.py); bee2hip_multi_plan is the pure index arithmetic, callable without a GPU
+// (tests/test_multi_plan.py runs it against the oracle).
+#include <thread>
+#include <vector>
+#include "common.hpp"
+
+using namespace bee2hip;
+
+// range i of `parts` over n items: [n i / parts, n (i + 1) / parts) -- sizes differ by at most one; the same cut as
+// bee2_amd/shard.py shard_range, which bench.py and the torch.distributed tests use
+extern "C" err_t bee2hip_multi_plan(size_t n, int parts, int i, size_t *first, size_t *count)
+{
+    if (parts <= 0 || i < 0 || i >= parts || !first || !count) return ERR_BAD_INPUT;
+    const unsigned __int128 N = n;
+    const size_t lo = (size_t)(N * (unsigned)i / (unsigned)parts), hi = (size_t)(N * ((unsigned)i + 1u) / (unsigned)parts);
+    *first = lo;
+    *count = hi - lo;
+    return ERR_OK;
+}
+
+static int real_device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+extern "C" int bee2hip_device_count(void)
+{
+    const char *fake = getenv("BEE2HIP_FAKE_DEVICES");
+    if (fake && atoi(fake) > 0 && real_device_count() > 0) return atoi(fake);
+    return real_device_count();
+}
+
+namespace {
+// run job(i, parts) on logical device i = 0 .. parts-1, each in its own thread bound to real device i % real
+template <class F>
+err_t run_on_devices(int ndev, F job)
+{
+    const int real = real_device_count();
+    if (real <= 0) return hip_fail(hipErrorNoDevice, "hipGetDeviceCount");
+    int parts = ndev > 0 ? ndev : bee2hip_device_count();
+    if (parts <= 0) return ERR_BAD_INPUT;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    std::vector<err_t> codes((size_t)parts, ERR_OK);
+    std::vector<std::thread> th;
+    th.reserve((size_t)parts);
+    for (int i = 0; i < parts; ++i)
+        th.emplace_back([&, i]() {
+            err_t c = bee2hip_set_device(i % real);
+            if (c == ERR_OK) c = job(i, parts);
+            codes[(size_t)i] = c;
+        });
+    for (auto &t : th) t.join();
+    (void)hipSetDevice(prev);
+    for (err_t c : codes) if (c != ERR_OK) return c;
+    return ERR_OK;
+}
+}  // namespace
+
+extern "C" err_t bee2hip_bashF_batch_multi(octet *states, size_t n, int ndev)
+{
+    if (n == 0) return ERR_OK;
+    if (!states) return ERR_BAD_INPUT;
+    return run_on_devices(ndev, [=](int i, int parts) {
+        size_t lo, cnt;
+        bee2hip_multi_plan(n, parts, i, &lo, &cnt);
+        return bee2hip_bashF_batch(states + 192 * lo, cnt);
+    });
+}
+
+// belt_ctr_st as in capi.hip / belt_lcl.h:135-141
+struct multi_ctr_st { u32 key[8]; u32 ctr[4]; octet block[16]; size_t reserved; };
+
+extern "C" err_t bee2hip_beltCTR_bulk_multi(void *buf_, size_t count, void *ctr_state, int ndev)
+{
+    multi_ctr_st *st = (multi_ctr_st *)ctr_state;
+    octet *buf = (octet *)buf_;
+    if (!st || (count && !buf)) return ERR_BAD_INPUT;
+    // left-over gamma of the previous call and everything shorter than a few blocks: the single-device entry
+    if (st->reserved || count < 4096) return bee2hip_beltCTR_bulk(buf, count, ctr_state);
+    const size_t full = count / 16, tail = count % 16;
+    // whole blocks are cut into ranges; the LAST range also takes the partial tail and leaves the state behind
+    const multi_ctr_st start = *st;
+    multi_ctr_st last = *st;
+    const err_t code = run_on_devices(ndev, [&](int i, int parts) {
+        size_t lo, cnt;
+        bee2hip_multi_plan(full, parts, i, &lo, &cnt);
+        multi_ctr_st mine = start;
+        // jump the counter to this range: ctr0 + lo (128-bit little-endian add)
+        uint64_t c0 = (uint64_t)mine.ctr[0] | (uint64_t)mine.ctr[1] << 32, c1 = (uint64_t)mine.ctr[2] | (uint64_t)mine.ctr[3] << 32;
+        const uint64_t n0 = c0 + (uint64_t)lo;
+        c1 += n0 < c0;
+        mine.ctr[0] = (u32)n0; mine.ctr[1] = (u32)(n0 >> 32); mine.ctr[2] = (u32)c1; mine.ctr[3] = (u32)(c1 >> 32);
+        const bool is_last = i == parts - 1;
+        const err_t c = bee2hip_beltCTR_bulk(buf + 16 * lo, 16 * cnt + (is_last ? tail : 0), &mine);
+        if (is_last) last = mine;
+        return c;
+    });
+    if (code != ERR_OK) return code;
+    *st = last;                                   // counter after all blocks, gamma of the final block, reserved
+    return ERR_OK;
+}
+
+extern "C" err_t bee2hip_bignVerify_batch_multi(const bign_params *params, const octet oid_der[], size_t oid_len,
+                                                const octet *hashes, const octet *sigs, const octet *pubkeys,
+                                                size_t n, err_t *codes, int ndev)
+{
+    // argument checks once, in bignVerify's order, through an empty single-device call
+    err_t code = bee2hip_bignVerify_batch(params, oid_der, oid_len, hashes, sigs, pubkeys, 0, codes);
+    if (code != ERR_OK) return code;
+    if (n && (!hashes || !sigs || !pubkeys || !codes)) return ERR_BAD_INPUT;
+    if (n == 0) return ERR_OK;
+    const size_t no = params->l / 4;
+    return run_on_devices(ndev, [=](int i, int parts) {
+        size_t lo, cnt;
+        bee2hip_multi_plan(n, parts, i, &lo, &cnt);
+        return bee2hip_bignVerify_batch(params, oid_der, oid_len, hashes + no * lo, sigs + (no + no / 2) * lo,
+                                        pubkeys + 2 * no * lo, cnt, codes + lo);
+    });
+}
+
+extern "C" err_t bee2hip_bignSign2_batch_multi(const bign_params *params, const octet oid_der[], size_t oid_len,
+                                               const octet *hashes, const octet *privkeys, const void *t, size_t t_len,
+                                               size_t n, octet *sigs, err_t *codes, int ndev)
+{
+    err_t code = bee2hip_bignSign2_batch(params, oid_der, oid_len, hashes, privkeys, t, t_len, 0, sigs, codes);
+    if (code != ERR_OK) return code;
+    if (n && (!hashes || !privkeys || !sigs || !codes)) return ERR_BAD_INPUT;
+    if (n == 0) return ERR_OK;
+    const size_t no = params->l / 4;
+    return run_on_devices(ndev, [=](int i, int parts) {
+        size_t lo, cnt;
+        bee2hip_multi_plan(n, parts, i, &lo, &cnt);
+        return bee2hip_bignSign2_batch(params, oid_der, oid_len, hashes + no * lo, privkeys + no * lo, t, t_len, cnt,
+                                       sigs + (no + no / 2) * lo, codes + lo);
+    });
+}
+
+extern "C" err_t bee2hip_bashHash_beltMAC_batch_multi(const octet *msgs, size_t msg_len, size_t n, size_t l,
+                                                      const octet key[], size_t key_len, octet *digests, octet *tags,
+                                                      int ndev)
+{
+    err_t code = bee2hip_bashHash_beltMAC_batch(msgs, msg_len, 0, l, key, key_len, digests, tags);
+    if (code != ERR_OK) return code;
+    if (n && msg_len && !msgs) return ERR_BAD_INPUT;
+    if (n == 0) return ERR_OK;
+    const size_t dlen = digests ? l / 4 : 0;
+    return run_on_devices(ndev, [=](int i, int parts) {
+        size_t lo, cnt;
+        bee2hip_multi_plan(n, parts, i, &lo, &cnt);
+        return bee2hip_bashHash_beltMAC_batch(msgs + msg_len * lo, msg_len, cnt, l, key, key_len,
+                                              digests ? digests + dlen * lo : nullptr, tags ? tags + 8 * lo : nullptr);
+    });
+}
+
+// ragged messages: ranges of whole messages with about equal BYTE counts (a range's cost is its bytes)
+extern "C" err_t bee2hip_hash_ragged_multi(size_t alg, const octet *data, const uint64_t *offsets, size_t n,
+                                           octet *digests, int ndev)
+{
+    if (alg != 0 && alg != 128 && alg != 192 && alg != 256) return ERR_BAD_PARAMS;
+    if (n == 0) return ERR_OK;
+    if (!offsets || !digests) return ERR_BAD_INPUT;
+    for (size_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i]) return ERR_BAD_INPUT;
+    if (offsets[n] != offsets[0] && !data) return ERR_BAD_INPUT;
+    const size_t dlen = alg ? alg / 4 : 32;
+    int parts = ndev > 0 ? ndev : bee2hip_device_count();
+    if (parts <= 0) return hip_fail(hipErrorNoDevice, "hipGetDeviceCount");
+    // cut[i] = first message of range i: the first index whose start offset reaches i / parts of the bytes
+    std::vector<size_t> cut((size_t)parts + 1, n);
+    cut[0] = 0;
+    const uint64_t base = offsets[0], total = offsets[n] - base;
+    size_t m = 0;
+    for (int i = 1; i < parts; ++i) {
+        const uint64_t want = base + total / (uint64_t)parts * (uint64_t)i;
+        while (m < n && offsets[m] < want) ++m;
+        cut[(size_t)i] = m;
+    }
+    return run_on_devices(parts, [&](int i, int) {
+        const size_t lo = cut[(size_t)i], hi = cut[(size_t)i + 1];
+        if (hi <= lo) return (err_t)ERR_OK;
+        std::vector<uint64_t> off(hi - lo + 1);
+        for (size_t k = lo; k <= hi; ++k) off[k - lo] = offsets[k] - offsets[lo];
+        return bee2hip_hash_ragged(alg, data + offsets[lo], off.data(), hi - lo, digests + dlen * lo);
+    });
+}

@@ -79,6 +79,9 @@ BATCH_SYMBOLS = [
     "bee2hip_bign128Verify_batch_dev", "bee2hip_bignVerify_batch_dev", "bee2hip_bignVerifyL_batch_dev",
     "bee2hip_bignPubkeyVal_batch", "bee2hip_bignPubkeyValL_batch_dev",
     "bee2hip_bignPubkeyCalc_batch", "bee2hip_bignSign2_batch", "bee2hip_bignSignK_batch",
+    "bee2hip_device_count", "bee2hip_multi_plan", "bee2hip_bashF_batch_multi", "bee2hip_beltCTR_bulk_multi",
+    "bee2hip_bignVerify_batch_multi", "bee2hip_bignSign2_batch_multi", "bee2hip_bashHash_beltMAC_batch_multi",
+    "bee2hip_hash_ragged_multi",
     "bee2hip_bignPubkeyCalcL_batch_dev", "bee2hip_bignSign2L_batch_dev", "bee2hip_bignSignKL_batch_dev",
     "bee2hip_bashHash_beltMAC_batch_dev",
     "bee2hip_set_device", "bee2hip_sync", "bee2hip_last_error", "bee2hip_version",
@@ -116,7 +119,7 @@ class Engine:
             if f is not None and name.startswith(("bee2hip_", "bash", "belt", "bign")) and \
                     name not in ("bee2hip_last_error", "bee2hip_version", "beltH", "bashF_deep",
                                  "bashHash_keep", "beltCTR_keep", "beltMAC_keep", "beltECB_keep",
-                                 "beltCBC_keep", "bash_platform"):
+                                 "beltCBC_keep", "bash_platform", "bee2hip_device_count"):
                 f.restype = _u32
 
     # ------------------------------------------------------------------ util

@@ -83,7 +83,9 @@ class Dist:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
-        self.on = self.world > 1
+        # under torchrun the process group is set up even for one rank, so that a single-GPU box exercises the very
+        # RCCL calls (init with device_id, broadcast, all-reduce, barrier) the 2/4/8-GPU runs make
+        self.on = self.world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
         self.backend = os.environ.get("BEE2_BENCH_BACKEND", "nccl")
         ndev = max(1, torch.cuda.device_count())
         self.device = self.local % ndev

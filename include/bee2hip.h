@@ -318,6 +318,26 @@ err_t bee2hip_hash_ragged_dev(size_t alg, const void *d_data, const void *d_offs
 err_t bee2hip_hash_ragged_ordered_dev(size_t alg, const void *d_data, const void *d_offsets,
                                       const void *d_order, size_t n, void *d_digests, void *stream);
 
+/* ---- one host batch over several GPUs from one process --------------------------------
+   The batch is cut into contiguous index ranges (bee2hip_multi_plan), one worker thread per device runs the
+   single-device entry above on its range; no data crosses devices.  ndev = number of devices to use, 0 = all
+   visible ones (bee2hip_device_count).  Results are those of the single-device call, item for item; the CTR
+   state is left exactly as bee2hip_beltCTR_bulk leaves it. */
+int bee2hip_device_count(void);
+err_t bee2hip_multi_plan(size_t n, int parts, int i, size_t *first, size_t *count);
+err_t bee2hip_bashF_batch_multi(octet *states, size_t n, int ndev);
+err_t bee2hip_beltCTR_bulk_multi(void *buf, size_t count, void *ctr_state, int ndev);
+err_t bee2hip_bignVerify_batch_multi(const bign_params *params, const octet oid_der[], size_t oid_len,
+                                     const octet *hashes, const octet *sigs, const octet *pubkeys, size_t n,
+                                     err_t *codes, int ndev);
+err_t bee2hip_bignSign2_batch_multi(const bign_params *params, const octet oid_der[], size_t oid_len,
+                                    const octet *hashes, const octet *privkeys, const void *t, size_t t_len, size_t n,
+                                    octet *sigs, err_t *codes, int ndev);
+err_t bee2hip_bashHash_beltMAC_batch_multi(const octet *msgs, size_t msg_len, size_t n, size_t l, const octet key[],
+                                           size_t key_len, octet *digests, octet *tags, int ndev);
+err_t bee2hip_hash_ragged_multi(size_t alg, const octet *data, const uint64_t *offsets, size_t n, octet *digests,
+                                int ndev);
+
 /* ======================================================================== *
  * (3) device-pointer batch API (buffers in HBM; async on `stream`)
  *     Device pointers to states, blocks, sectors, messages and verify records must be 16-byte

@@ -1,0 +1,105 @@
+"""-m gpu: the *_multi host entry points (one process, one worker thread per device).  On a one-GPU
+box BEE2HIP_FAKE_DEVICES makes the library run k logical devices on the one real GPU, so the partition, the worker
+threads and the CTR state hand-over are exercised; on a multi-GPU box the same tests use the real devices too."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from bee2_amd import engine as E
+from gpulib import engine
+
+pytestmark = pytest.mark.gpu
+_sz = ctypes.c_size_t
+
+
+@pytest.fixture(params=[1, 3, 8])
+def devices(request):
+    os.environ["BEE2HIP_FAKE_DEVICES"] = str(request.param)
+    yield request.param
+    os.environ.pop("BEE2HIP_FAKE_DEVICES", None)
+
+
+def test_device_count_and_fake(devices):
+    eng = engine()
+    assert eng.lib.bee2hip_device_count() == devices
+
+
+def test_bashF_and_mixed_multi(orc, golden, devices):
+    eng = engine()
+    n = 10_001
+    data = orc.fill(192 * n, 0xBA5F)
+    buf = ctypes.create_string_buffer(data, len(data))
+    assert eng.lib.bee2hip_bashF_batch_multi(buf, _sz(n), 0) == 0
+    assert buf.raw == orc.bashF_batch(data, nthreads=8)
+    m, ml = 2_003, 1024
+    msgs = orc.fill(m * ml, 0x4D1C)
+    key = golden.H[128:160]
+    dig = ctypes.create_string_buffer(64 * m)
+    tag = ctypes.create_string_buffer(8 * m)
+    assert eng.lib.bee2hip_bashHash_beltMAC_batch_multi(msgs, _sz(ml), _sz(m), _sz(256), key, _sz(32), dig, tag, 0) == 0
+    wd, wt = orc.mixed_batch(msgs, ml, key, nthreads=8)
+    assert dig.raw == wd and tag.raw == wt
+
+
+def test_ctr_multi_leaves_the_state_of_the_serial_call(orc, golden, devices):
+    eng = engine()
+    key, iv = golden.H[128:160], golden.H[192:208]
+    msg = orc.fill(1_000_003, 0xBE17)                 # ragged tail: 3 bytes into the last block
+    want = orc.ctr(msg, key, iv)
+    for cut in (0, 5, 4096 + 7):                       # leading piece through the single-device entry, left-over gamma
+        st1 = ctypes.create_string_buffer(eng.lib.beltCTR_keep())
+        st2 = ctypes.create_string_buffer(eng.lib.beltCTR_keep())
+        eng.lib.beltCTRStart(st1, key, _sz(32), iv)
+        eng.lib.beltCTRStart(st2, key, _sz(32), iv)
+        a = ctypes.create_string_buffer(msg, len(msg))
+        b = ctypes.create_string_buffer(msg, len(msg))
+        if cut:
+            assert eng.lib.bee2hip_beltCTR_bulk(a, _sz(cut), st1) == 0
+            assert eng.lib.bee2hip_beltCTR_bulk(b, _sz(cut), st2) == 0
+        assert eng.lib.bee2hip_beltCTR_bulk(ctypes.byref(a, cut), _sz(len(msg) - cut), st1) == 0
+        assert eng.lib.bee2hip_beltCTR_bulk_multi(ctypes.byref(b, cut), _sz(len(msg) - cut), st2, 0) == 0
+        assert a.raw == want and b.raw == want
+        assert st1.raw == st2.raw                      # counter, gamma block, reserved: identical
+        # and the stream continues correctly from that state
+        more = ctypes.create_string_buffer(bytes(100), 100)
+        more2 = ctypes.create_string_buffer(bytes(100), 100)
+        eng.lib.beltCTRStepE(more, _sz(100), st1)
+        eng.lib.beltCTRStepE(more2, _sz(100), st2)
+        assert more.raw == more2.raw
+
+
+def test_verify_sign_and_ragged_multi(orc, golden, devices):
+    eng = engine()
+    P = eng.bignParamsStd(E.CURVE_NAME[128])
+    oid = E.LEVEL_OID[128]
+    hs, ss, ps = golden.bign_base_arrays()
+    n = 1500
+    bad = bytearray(ss[:48 * n])
+    for i in range(0, n, 7):
+        bad[48 * i + 3] ^= 1
+    codes = (ctypes.c_uint32 * n)()
+    assert eng.lib.bee2hip_bignVerify_batch_multi(ctypes.byref(P), oid, _sz(11), hs[:32 * n], bytes(bad), ps[:64 * n], _sz(n), codes, 0) == 0
+    assert list(codes) == orc.verify_batch(hs[:32 * n], bytes(bad), ps[:64 * n], nthreads=8)
+    privs = orc.fill(32 * 300, 0x51)
+    sig = ctypes.create_string_buffer(48 * 300)
+    sc = (ctypes.c_uint32 * 300)()
+    assert eng.lib.bee2hip_bignSign2_batch_multi(ctypes.byref(P), oid, _sz(11), hs[:32 * 300], privs, None, _sz(0), _sz(300), sig, sc, 0) == 0
+    for i in (0, 1, 99, 100, 101, 299):
+        assert orc.sign2(128, oid, hs[32 * i: 32 * i + 32], privs[32 * i: 32 * i + 32], None) == (sc[i], sig.raw[48 * i: 48 * i + 48])
+    # argument errors surface as from the single-device call
+    assert eng.lib.bee2hip_bignVerify_batch_multi(ctypes.byref(P), b"\x06\x01", _sz(2), hs, ss, ps, _sz(4), codes, 0) == E.ERR_BAD_OID
+    # ragged: byte-balanced ranges of whole messages
+    import random
+    rnd = random.Random(devices)
+    msgs = [rnd.randbytes(rnd.choice((0, 1, 31, 32, 33, 500, 5000, 70_000))) for _ in range(400)]
+    data = b"".join(msgs)
+    offs = np.zeros(len(msgs) + 1, dtype=np.uint64)
+    np.cumsum([len(m) for m in msgs], out=offs[1:])
+    for alg, dlen in ((0, 32), (128, 32), (256, 64)):
+        out = ctypes.create_string_buffer(dlen * len(msgs))
+        assert eng.lib.bee2hip_hash_ragged_multi(_sz(alg), data, offs.ctypes.data_as(ctypes.c_void_p), _sz(len(msgs)), out, 0) == 0
+        for i, m in enumerate(msgs):
+            want = orc.belt_hash(m) if alg == 0 else orc.bashHash(alg, m)[1]
+            assert out.raw[dlen * i: dlen * (i + 1)] == want, (alg, i)
