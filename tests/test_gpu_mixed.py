@@ -180,7 +180,72 @@ def test_bsum_front_end_example(orc, golden, tmp_path):
         for line, name in zip(out, names):
             data = open(name, "rb").read()
             want = orc.belt_hash(data) if alg == 0 else orc.bashHash(alg, data)[1]
-            assert line == f"{want.hex().upper()}  {name}"
+            assert line == f"{want.hex()}  {name}"             # lower case, two spaces: bsumPrint (bsum.c:207-224)
+        # check mode (bsumCheck, bsum.c:226-306): all good -> exit 0 and "name: OK" per line
+        sums = tmp_path / f"sums{alg}.txt"
+        sums.write_text("\n".join(out) + "\n")
+        r = subprocess.run([str(exe), flag, "-c", str(sums)], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.splitlines() == [f"{n}: OK" for n in names] and r.stderr == ""
+        # one wrong digest, one missing file, one malformed line, CRLF line ends, upper-case hex
+        lines = list(out)
+        lines[1] = ("0" if lines[1][0] != "0" else "1") + lines[1][1:]
+        lines[2] = lines[2].split("  ")[0].upper() + "  " + names[2] + "\r"
+        lines.append(lines[0].split("  ")[0] + "  " + str(tmp_path / "missing.bin"))
+        lines.append("not a checksum line")
+        sums.write_text("\n".join(lines) + "\n")
+        r = subprocess.run([str(exe), flag, "-c", str(sums)], capture_output=True, text=True)
+        assert r.returncode != 0
+        # the missing file is reported while the list is read, the verdicts after the single launch
+        assert sorted(r.stdout.splitlines()) == sorted([f"{names[0]}: OK", f"{names[1]}: FAILED [checksum]", f"{names[2]}: OK", f"{names[3]}: OK",
+                                                        f"{names[4]}: OK", f"{tmp_path / 'missing.bin'}: FAILED [open]"])
+        assert r.stderr.splitlines() == ["WARNING: 1 input line (out of 7) is improperly formatted",
+                                         "WARNING: 1 listed file could not be opened or read",
+                                         "WARNING: 1 computed checksum did not match"]
+
+
+def test_sigvfy_front_end_example(orc, golden, tmp_path):
+    """examples/sigvfy_hip.c: the batch shape of `bee2cmd sig vfy` (hash the file, bign128PubkeyVal, bign128Verify) from
+    plain C on device-resident buffers; files signed here with the library's own bign128Sign2, verdicts per line"""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("cc") is None:
+        pytest.skip("no C compiler on this box")
+    exe = tmp_path / "sigvfy_hip"
+    lib = os.path.join(root, "bee2_amd", "lib")
+    subprocess.check_call(["cc", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "sigvfy_hip.c"),
+                           "-L" + lib, "-lbee2hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + lib,
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    eng = engine()
+    lines, want = [], []
+    for i, n in enumerate((0, 1, 100, 4096, 70000, 33)):
+        p = tmp_path / f"s{i}.bin"
+        data = orc.fill(n, 500 + i)
+        p.write_bytes(data)
+        d = orc.fill(32, 900 + i)
+        code, pub = eng.bignLPubkeyCalc(128, d)
+        assert code == 0
+        code, sig = eng.bignLSign2(128, orc.belt_hash(data), d)
+        assert code == 0 and orc.verify(orc.belt_hash(data), sig, pub) == 0
+        verdict = "OK"
+        if i == 2:
+            sig = bytes([sig[0] ^ 1]) + sig[1:]
+            verdict = "FAILED [signature]"
+        if i == 4:
+            pub = pub[:32] + bytes([pub[32] ^ 1]) + pub[33:]
+            verdict = "FAILED [pubkey]"
+        lines.append(f"{p} {sig.hex()} {pub.hex()}")
+        want.append(f"{p}: {verdict}")
+    lines.append(f"{tmp_path / 'nofile.bin'} {'00' * 48} {'00' * 64}")
+    lst = tmp_path / "list.txt"
+    lst.write_text("\n".join(lines) + "\n")
+    r = subprocess.run([str(exe), str(lst)], capture_output=True, text=True)
+    assert r.returncode == 1
+    assert sorted(r.stdout.splitlines()) == sorted(want + [f"{tmp_path / 'nofile.bin'}: FAILED [open]"])
+    lst.write_text("\n".join(l for l, w in zip(lines, want) if w.endswith("OK")) + "\n")
+    r = subprocess.run([str(exe), str(lst)], capture_output=True, text=True)
+    assert r.returncode == 0 and all(x.endswith(": OK") for x in r.stdout.splitlines()) and len(r.stdout.splitlines()) == 4
 
 
 def test_c_selftest_example_runs_the_stb_vectors(golden, tmp_path):
