@@ -8,6 +8,9 @@ rm -rf $OUT; mkdir -p $OUT
 cd $R
 CMD="python bench.py --steps 20 --warmup 3 --no-cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
+# the headline workload alone: the full run also launches the bashF kernel on single states (drop-in latency leg, sponge
+# finalisation), which would pull the per-kernel average away from the batch launches the roofline is about
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bashF -o bench -- $CMD --only bashF > $OUT/stats_bashF.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- $CMD --only bashF,ctr,verify --ctr-gib 4 > $OUT/pmc_$c.log 2>&1
 done

@@ -40,6 +40,9 @@ def agg(path):
 def main(tag):
     os.makedirs(DST, exist_ok=True)
     shutil.copy(os.path.join(SRC, "stats", "bench_kernel_stats.csv"), os.path.join(DST, f"{tag}_kernel_stats.csv"))
+    hb = os.path.join(SRC, "stats_bashF", "bench_kernel_stats.csv")
+    if os.path.exists(hb):
+        shutil.copy(hb, os.path.join(DST, f"{tag}_kernel_stats_bashF_only.csv"))
     summary = {"command": "rocprofv3 --kernel-trace --stats / --pmc <set> -- python bench.py --steps 20 --warmup 3 --no-cpu "
                           "(PMC passes: --ctr-gib 4; FETCH/WRITE passes: --only bashF,ctr)",
                "note": "counter values are per-launch averages; FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts "
