@@ -193,8 +193,97 @@ def f_ragged_mixed(rnd):
     return ok and gd == dig and gt == tag
 
 
+def f_sign(rnd):
+    """8f-4 tail: public keys, deterministic signatures (random t lengths, random OID lengths, bad keys mixed in),
+    signatures with supplied one-time keys; every good signature must also verify on the device"""
+    import ctypes
+    from bee2_amd import engine as E
+    l = rnd.choice((128, 128, 192, 256))
+    no, sg = l // 4, 3 * l // 8
+    P = eng.bignParamsStd(E.CURVE_NAME[l])
+    q = int.from_bytes(bytes(P.q)[:no], "little")
+    n = max(1, size(rnd, 1500 if l == 128 else 300, (1, 64, 256, 257)))
+    privs = bytearray(orc.fill(no * n, rnd.getrandbits(32)))
+    for i in range(n):
+        k = rnd.randrange(40)
+        if k == 0:
+            privs[no * i: no * (i + 1)] = bytes(no)
+        elif k == 1:
+            privs[no * i: no * (i + 1)] = ((q + rnd.randrange(0, 5)) % (1 << (8 * no))).to_bytes(no, "little")
+        elif k == 2:
+            privs[no * i: no * (i + 1)] = rnd.choice((1, 2, q - 1, q - 2, q - 16, 15, 16, 1 << 128)).to_bytes(no, "little")
+    privs = bytes(privs)
+    hashes = bytearray(orc.fill(no * n, rnd.getrandbits(32)))
+    if rnd.randrange(3) == 0:
+        hashes[:no] = b"\xff" * no                               # H >= q
+    hashes = bytes(hashes)
+    oid = LEVEL_OID[l]
+    if rnd.randrange(3) == 0:
+        k = rnd.choice((1, 2, 3, 4, 5, 8, 13, 20, 61, 126))
+        oid = bytes([0x06, k] if k < 128 else [0x06, 0x81, k]) + bytes([0x2A] + [rnd.randrange(1, 128) for _ in range(k - 1)])
+    t = rnd.choice((None, b"", rnd.randbytes(rnd.randrange(1, 65)), rnd.randbytes(rnd.randrange(65, 200))))
+    code, pubs, pc = eng.bignPubkeyCalc_batch(P, privs)
+    if code:
+        return False
+    for i in range(n):
+        w = orc.pubkey_calc(l, privs[no * i: no * (i + 1)])
+        if w[0] != pc[i] or (w[0] == 0 and w[1] != pubs[2 * no * i: 2 * no * (i + 1)]):
+            return False
+    code, sigs, sc = eng.bignSign2_batch(P, oid, hashes, privs, t)
+    if code:
+        return False
+    for i in range(n):
+        w = orc.sign2(l, oid, hashes[no * i: no * (i + 1)], privs[no * i: no * (i + 1)], t)
+        if w[0] != sc[i] or (w[0] == 0 and w[1] != sigs[sg * i: sg * (i + 1)]):
+            return False
+    good = [i for i in range(n) if sc[i] == 0]
+    if good:
+        code, vc = eng.bignVerify_batch(b"".join(hashes[no * i: no * (i + 1)] for i in good), b"".join(sigs[sg * i: sg * (i + 1)] for i in good),
+                                        b"".join(pubs[2 * no * i: 2 * no * (i + 1)] for i in good), oid_der=oid, params=P)
+        if code or any(vc):
+            return False
+    ks = orc.fill(no * n, rnd.getrandbits(32))
+    code, sigs2, kc = eng.bignSignK_batch(P, oid, hashes, privs, ks)
+    if code:
+        return False
+    for i in range(0, n, max(1, n // 40)):
+        w = orc.sign_rnd(l, oid, hashes[no * i: no * (i + 1)], privs[no * i: no * (i + 1)], ks[no * i: no * (i + 1)])
+        if w[0] != kc[i] or (w[0] == 0 and w[1] != sigs2[sg * i: sg * (i + 1)]):
+            return False
+    return True
+
+
+def f_multi(rnd):
+    """the *_multi host entries under a random logical device count (BEE2HIP_FAKE_DEVICES)"""
+    import ctypes
+    os.environ["BEE2HIP_FAKE_DEVICES"] = str(rnd.choice((1, 2, 3, 5, 8)))
+    try:
+        n = max(1, size(rnd, 50_000, (1, 7, 8, 9, 4096)))
+        data = orc.fill(192 * n, rnd.getrandbits(32))
+        buf = ctypes.create_string_buffer(data, len(data))
+        if eng.lib.bee2hip_bashF_batch_multi(buf, ctypes.c_size_t(n), 0) or buf.raw != orc.bashF_batch(data, nthreads=8):
+            return False
+        key, iv = rnd.randbytes(rnd.choice((16, 24, 32))), rnd.randbytes(16)
+        m = size(rnd, 1 << 21, (4095, 4096, 4097, 65536))
+        msg = orc.fill(m, rnd.getrandbits(32))
+        cut = rnd.choice((0, 0, 3, 16, 100)) if m > 200 else 0
+        st = ctypes.create_string_buffer(eng.lib.beltCTR_keep())
+        eng.lib.beltCTRStart(st, key, ctypes.c_size_t(len(key)), iv)
+        b = ctypes.create_string_buffer(msg, max(1, len(msg)))
+        if cut and eng.lib.bee2hip_beltCTR_bulk(b, ctypes.c_size_t(cut), st):
+            return False
+        if eng.lib.bee2hip_beltCTR_bulk_multi(ctypes.byref(b, cut), ctypes.c_size_t(m - cut), st, 0):
+            return False
+        more = ctypes.create_string_buffer(bytes(40), 40)
+        eng.lib.beltCTRStepE(more, ctypes.c_size_t(40), st)
+        want = orc.ctr(msg + bytes(40), key, iv)
+        return b.raw[:m] + more.raw == want
+    finally:
+        os.environ.pop("BEE2HIP_FAKE_DEVICES", None)
+
+
 FAMILIES = [("bashF", f_bashF), ("beltCTR", f_ctr), ("mac/hash", f_mac_hash), ("modes", f_modes), ("dwp/che", f_aead),
-            ("verify", f_verify), ("ragged/mixed", f_ragged_mixed)]
+            ("verify", f_verify), ("ragged/mixed", f_ragged_mixed), ("sign", f_sign), ("multi", f_multi)]
 
 
 def main(seconds, seed):
