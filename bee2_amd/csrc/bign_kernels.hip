@@ -6,9 +6,14 @@
 // One lane per signature; per-signature result is the bee2 err_t the reference returns.
 //
 // The reference computes R = s1' G + (s0 + 2^l) Q with interleaved width-5/6 NAF
-// (ecAddMulA, src/math/ec.c:1183-1273): data-dependent branching, 2l+1 doublings.  Any
-// correct algorithm yields the same affine R, so the GPU uses a wavefront-friendly
-// schedule instead (N = number of 32-bit limbs = l/16):
+// (ecAddMulA, src/math/ec.c:1183-1273): data-dependent branching, 2l+1 doublings.  For a public
+// key ON the curve any correct algorithm yields the same affine R, so the GPU uses a
+// wavefront-friendly schedule instead (N = number of 32-bit limbs = l/16).  (Neither bignVerify
+// nor this code checks that Q is on the curve; for an off-curve Q the a = -3 formulas never see
+// b and "u G + v Q" depends on the order of additions, so R differs between the two -- both then
+// return ERR_BAD_SIG because the hash of x_R matches s0 with probability 2^-l only.  Parity on
+// off-curve keys is therefore probabilistic, not structural; callers run bignPubkeyVal first,
+// as bee2cmd does.)
 //   * G part: fixed-base comb, no doublings: 2N windows x 16 bits, 2N x 65535 affine points
 //     (64 / 144 / 256 MiB for l = 128 / 192 / 256, built once per device and curve in 3 / 10 /
 //     22 ms: bign_gtable_kernel makes an 8-bit seed table by double-and-add, bign_gtable16_kernel
@@ -20,7 +25,7 @@
 //     fe_inv_safegcd) and shared between signatures (Montgomery's trick).
 // Exceptional cases of the addition law (operand O, P = +-Q) cannot occur for honest
 // inputs; lanes that hit one are flagged and recomputed by bign_slow_kernel with the
-// complete (branchy) formulas, so verdicts are exact for every input.
+// complete (branchy) formulas, so verdicts are exact for every on-curve key.
 //
 // Kernels per batch (same stream): [points ->] prep -> main -> slow -> inv -> tail.
 //   prep : range checks (bign_sign.c:306-318), u = s1 + H mod q (:320-327),

@@ -218,7 +218,10 @@ typedef struct {
 } bign_params;
 /* bign.h:100-107, src/crypto/bign/bign_params.c:180-230: "1.2.112.0.2.0.34.101.45.3.{1,2,3}" */
 err_t bignParamsStd(bign_params *params, const char *name);
-/* bign.h:395-402, src/crypto/bign/bign_sign.c:349-361 */
+/* bign.h:395-402, src/crypto/bign/bign_sign.c:349-361.
+   Limits of this implementation (both report ERR_NOT_IMPLEMENTED, never a wrong verdict): params must be one of
+   the three standard sets bignParamsStd returns; oid_len <= 128 octets (the kernels stage the DER OID as a launch
+   argument; bee2 accepts any valid DER OID). */
 err_t bignVerify(const bign_params *params, const octet oid_der[], size_t oid_len,
                  const octet hash[], const octet sig[], const octet pubkey[]);
 /* include/bee2/crypto/bign128.h:174-178, src/crypto/bign/bign128.c:177-185 */
