@@ -27,7 +27,7 @@ __constant__ uint8_t c_beltH[256];
 
 constexpr int CTR_WG = 1024;
 typedef BeltTabTwo CtrTab;          // 64 KiB: two workgroups (32 wavefronts) per CU
-constexpr int CTR_ILP = 2;          // independent blocks per lane per step
+constexpr int CTR_ILP = 1;          // independent blocks per lane per step (r02 A/B: 1 beats 2 by 1.3-1.5 %, profiles/r02_belt_variants.txt)
 
 struct BeltKey { uint32_t k[8]; };
 struct BeltCtr { uint32_t c[4]; };
@@ -43,35 +43,39 @@ __device__ __forceinline__ void ctr_at(uint32_t (&x)[4], const BeltCtr &c0, uint
     x[2] = (uint32_t)nhi; x[3] = (uint32_t)(nhi >> 32);
 }
 
-__global__ __launch_bounds__(CTR_WG)
+// Tab / ILP are template parameters so that the round-2 A/B (profiles/r02_belt_variants.txt)
+// runs the very same body: the product is <CtrTab, CTR_ILP>; the others are reachable only through
+// bee2hip_internal_tune(1, v).
+template <class Tab, int ILP>
+__global__ __launch_bounds__(CTR_WG, (BeltTabWide::kBytes / Tab::kBytes) * (CTR_WG / 256))
 void beltCTR_blocks_kernel(uint4 *__restrict__ buf, size_t nblocks, BeltKey key, BeltCtr ctr0,
                            uint64_t first, uint4 *__restrict__ last_gamma)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    CtrTab::fill(smem, threadIdx.x, CTR_WG);
+    Tab::fill(smem, threadIdx.x, CTR_WG);
     __syncthreads();
-    const CtrTab T(smem);
+    const Tab T(smem);
 
     uint32_t K[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) K[i] = key.k[i];
 
-    // tile = CTR_WG * CTR_ILP consecutive blocks; tiles are dealt round-robin to workgroups
-    const size_t tile = (size_t)CTR_WG * CTR_ILP;
+    // tile = CTR_WG * ILP consecutive blocks; tiles are dealt round-robin to workgroups
+    const size_t tile = (size_t)CTR_WG * ILP;
     for (size_t t0 = (size_t)blockIdx.x * tile; t0 < nblocks; t0 += (size_t)gridDim.x * tile) {
-        uint4 data[CTR_ILP];
-        uint32_t g[CTR_ILP][4];
-        bool live[CTR_ILP];
+        uint4 data[ILP];
+        uint32_t g[ILP][4];
+        bool live[ILP];
 #pragma unroll
-        for (int u = 0; u < CTR_ILP; ++u) {
+        for (int u = 0; u < ILP; ++u) {
             const size_t i = t0 + (size_t)u * CTR_WG + threadIdx.x;
             live[u] = i < nblocks;
             if (live[u]) data[u] = buf[i];
             ctr_at(g[u], ctr0, first + i + 1);
         }
-        belt_encr_n<CTR_ILP>(T, g, K);
+        belt_encr_n<ILP>(T, g, K);
 #pragma unroll
-        for (int u = 0; u < CTR_ILP; ++u) {
+        for (int u = 0; u < ILP; ++u) {
             const size_t i = t0 + (size_t)u * CTR_WG + threadIdx.x;
             if (live[u]) {
                 uint4 o;
@@ -596,7 +600,6 @@ void belt_decr_blocks_kernel(uint4 *__restrict__ blocks, size_t nblocks, BeltKey
 
 // per-device launch facts (several devices may be driven from one process)
 static int g_num_cus[64];
-static bool g_ctr_attr[64];
 static int cur_dev()
 {
     int dev = 0;
@@ -622,27 +625,47 @@ err_t upload_beltH(const uint8_t *H)
     return ERR_OK;
 }
 
+static int g_ctr_variant = 0;
+void set_ctr_variant(int v) { g_ctr_variant = v; }
+
+template <class Tab, int ILP>
+static err_t launch_ctr_t(void *d_buf, size_t nblocks, const BeltKey &k, const BeltCtr &c, uint64_t first,
+                          void *d_last_gamma, hipStream_t st)
+{
+    static bool attr[64];
+    auto kern = beltCTR_blocks_kernel<Tab, ILP>;
+    if (!attr[cur_dev()]) {
+        B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    Tab::kBytes));
+        attr[cur_dev()] = true;
+    }
+    const size_t tile = (size_t)CTR_WG * ILP;
+    size_t grid = (nblocks + tile - 1) / tile;
+    const size_t cap = (size_t)num_cus() * (BeltTabWide::kBytes / Tab::kBytes);
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CTR_WG), Tab::kBytes, st, (uint4 *)d_buf, nblocks, k, c, first,
+                       (uint4 *)d_last_gamma);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
 err_t launch_belt_ctr_blocks(void *d_buf, size_t nblocks, const uint32_t key[8],
                              const uint32_t ctr0[4], uint64_t first, void *d_last_gamma,
                              hipStream_t st)
 {
     if (nblocks == 0) return ERR_OK;
-    if (!g_ctr_attr[cur_dev()]) {
-        B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(beltCTR_blocks_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, CtrTab::kBytes));
-        g_ctr_attr[cur_dev()] = true;
-    }
     BeltKey k; BeltCtr c;
     for (int i = 0; i < 8; ++i) k.k[i] = key[i];
     for (int i = 0; i < 4; ++i) c.c[i] = ctr0[i];
-    const size_t tile = (size_t)CTR_WG * CTR_ILP;
-    size_t grid = (nblocks + tile - 1) / tile;
-    const size_t cap = (size_t)num_cus() * (BeltTabWide::kBytes / CtrTab::kBytes);
-    if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(beltCTR_blocks_kernel, dim3((unsigned)grid), dim3(CTR_WG), CtrTab::kBytes,
-                       st, (uint4 *)d_buf, nblocks, k, c, first, (uint4 *)d_last_gamma);
-    B2H_TRY(hipGetLastError());
-    return ERR_OK;
+    switch (g_ctr_variant) {          // A/B only (bee2hip_internal_tune(1, v)); 0 = the product
+    case 1: return launch_ctr_t<BeltTabTwo, 2>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    case 2: return launch_ctr_t<BeltTabTwo, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    case 3: return launch_ctr_t<BeltTabTwo, 4>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    case 4: return launch_ctr_t<BeltTabWide, 2>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    case 5: return launch_ctr_t<BeltTabWide, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    case 6: return launch_ctr_t<BeltTabWide, 4>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    default: return launch_ctr_t<CtrTab, CTR_ILP>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    }
 }
 
 template <int MODE>

@@ -132,28 +132,34 @@ void chain(const uint32_t *in, uint32_t *out, int reps)
 
 int main()
 {
-    const int waves_per_simd = 4, nwg = 1024 * waves_per_simd / 4, nthr = nwg * 256, reps = 2000;
-    uint32_t *h = (uint32_t *)malloc((size_t)nthr * 64), *o0 = (uint32_t *)malloc((size_t)nthr * 64), *o1 = (uint32_t *)malloc((size_t)nthr * 64);
+    // wavefronts per SIMD: 4 = the verification kernel at full load; <= 1 = a small batch (one wavefront alone on
+    // its SIMD issues an instruction every ~5 cycles whatever its class, so instruction COUNT decides there)
+    const int reps = 2000, max_thr = 4096 * 64;
+    uint32_t *h = (uint32_t *)malloc((size_t)max_thr * 64), *o0 = (uint32_t *)malloc((size_t)max_thr * 64), *o1 = (uint32_t *)malloc((size_t)max_thr * 64);
     uint64_t s = 0x9E3779B97F4A7C15ull;
-    for (size_t i = 0; i < (size_t)nthr * 16; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = (uint32_t)(s >> 16); }
+    for (size_t i = 0; i < (size_t)max_thr * 16; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = (uint32_t)(s >> 16); }
     uint32_t *din, *dout;
-    hipMalloc(&din, (size_t)nthr * 64); hipMalloc(&dout, (size_t)nthr * 64);
-    hipMemcpy(din, h, (size_t)nthr * 64, hipMemcpyHostToDevice);
+    hipMalloc(&din, (size_t)max_thr * 64); hipMalloc(&dout, (size_t)max_thr * 64);
+    hipMemcpy(din, h, (size_t)max_thr * 64, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 2; ++mode) {
-        for (int rep = 0; rep < 3; ++rep) {
-            hipEventRecord(e0);
-            if (mode == 0) hipLaunchKernelGGL(chain<0>, dim3(nwg), dim3(256), 0, 0, din, dout, reps);
-            else hipLaunchKernelGGL(chain<1>, dim3(nwg), dim3(256), 0, 0, din, dout, reps);
-            hipEventRecord(e1); hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1);
-            if (rep == 2) printf("%s limbs: %.3f ms for %d x (mul + sqr) at %d wavefronts/SIMD -> %.1f SIMD cycles (2.4 GHz) per mul+sqr pair per wavefront\n",
-                                 mode ? "29-bit" : "32-bit", ms, reps, waves_per_simd, ms * 1e-3 * 2.4e9 / reps / waves_per_simd);
-        }
-        hipMemcpy(mode ? o1 : o0, dout, (size_t)nthr * 64, hipMemcpyDeviceToHost);
-    }
     size_t bad = 0;
-    for (size_t i = 0; i < (size_t)nthr * 16; ++i) bad += o0[i] != o1[i];
+    for (int nwave : {256, 1024, 2048, 4096}) {
+        const int nthr = nwave * 64;
+        float t[2] = {0, 0};
+        for (int mode = 0; mode < 2; ++mode) {
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEventRecord(e0);
+                if (mode == 0) hipLaunchKernelGGL(chain<0>, dim3(nwave), dim3(64), 0, 0, din, dout, reps);
+                else hipLaunchKernelGGL(chain<1>, dim3(nwave), dim3(64), 0, 0, din, dout, reps);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                hipEventElapsedTime(&t[mode], e0, e1);
+            }
+            hipMemcpy(mode ? o1 : o0, dout, (size_t)nthr * 64, hipMemcpyDeviceToHost);
+        }
+        for (size_t i = 0; i < (size_t)nthr * 16; ++i) bad += o0[i] != o1[i];
+        printf("%.2f wavefronts/SIMD: 32-bit limbs %.3f ms, 29-bit limbs %.3f ms for %d x (mul + sqr)  -> x%.2f\n",
+               nwave / 1024.0, t[0], t[1], reps, t[0] / t[1]);
+    }
     printf("results %s (%zu words differ)\n", bad ? "DIFFER" : "identical", bad);
     return bad != 0;
 }
