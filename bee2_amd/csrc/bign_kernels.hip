@@ -40,6 +40,8 @@
 #include <mutex>
 #include "belt_dev.hpp"
 #include "bign_dev.hpp"
+#include "bign_fe29.hpp"
+#include "bign_quad29.hpp"
 #include "common.hpp"
 #include "bign_curves.inc"
 
@@ -158,15 +160,15 @@ __device__ __forceinline__ void to_affine(feT<N> &x, feT<N> &y, const jacT<N> &T
 }
 
 // --------------------------------------------------------------------- prep ---
-// one signature: range checks, the scalars u and w, and 1Q..8Q (1Q affine, 2Q..8Q Jacobian: X, Y in the table
-// rows, Z aside).  Sets the status; returns true when the table is to be normalised (no exceptional case).
+// one signature: range checks (status written on failure), Q, and the scalars u and w, which also go to the scratch
+// (the slow path reads u from there).  `write` = false for the lanes of a quad that only need the values.
 template <int N>
-__device__ __forceinline__ bool prep_points(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
-                                            const uint8_t *__restrict__ pubkeys, size_t idx, const VerifyScratch &S)
+__device__ __forceinline__ bool prep_scalars(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
+                                             const uint8_t *__restrict__ pubkeys, size_t idx, const VerifyScratch &S,
+                                             bool write, affT<N> &Q, feT<N> &u, uint32_t (&w)[N / 2 + 1])
 {
     constexpr int NO = 4 * N;                       // octets per field element
 
-    affT<N> Q;
     load_fe_bytes(Q.x, pubkeys + 2 * NO * idx);
     load_fe_bytes(Q.y, pubkeys + 2 * NO * idx + NO);
     feT<N> s1, H;
@@ -181,9 +183,9 @@ __device__ __forceinline__ bool prep_points(const uint8_t *__restrict__ hashes, 
     P[0] = 0u - CurveC<N>::C;
 
     // qrFrom rejects coordinates >= p (bign_sign.c:306-311); there is no on-curve check
-    if (limbs_ge(Q.x.v, P) || limbs_ge(Q.y.v, P)) { S.status[idx] = ERR_BAD_PUBKEY; return false; }
+    if (limbs_ge(Q.x.v, P) || limbs_ge(Q.y.v, P)) { if (write) S.status[idx] = ERR_BAD_PUBKEY; return false; }
     // s1 >= q (bign_sign.c:313-318)
-    if (limbs_ge(s1.v, q)) { S.status[idx] = ERR_BAD_SIG; return false; }
+    if (limbs_ge(s1.v, q)) { if (write) S.status[idx] = ERR_BAD_SIG; return false; }
 
     // H <- H - q if H >= q ; u <- (s1 + H) mod q   (bign_sign.c:320-327)
     {
@@ -208,10 +210,9 @@ __device__ __forceinline__ bool prep_points(const uint8_t *__restrict__ hashes, 
             t[i] = (uint32_t)d; borrow = (uint32_t)(d >> 32) & 1u;
         }
         const bool ge = carry || !borrow;            // s1 + H >= q
-        feT<N> u;
 #pragma unroll
         for (int i = 0; i < N; ++i) u.v[i] = ge ? t[i] : s[i];
-        store_soa(S.u, S.n_pad, idx, u);
+        if (write) store_soa(S.u, S.n_pad, idx, u);
     }
     // v = s0 + 2^l ; w = v + 0x8888...8 (4N+1 nibbles) so that digit_i = nibble_i(w) - 8
     {
@@ -220,9 +221,25 @@ __device__ __forceinline__ bool prep_points(const uint8_t *__restrict__ hashes, 
         for (int i = 0; i <= N / 2; ++i) {
             const uint32_t vi = i < N / 2 ? *reinterpret_cast<const uint32_t *>(sig + 4 * i) : 1u;
             c += (uint64_t)vi + (i < N / 2 ? 0x88888888u : 0x8u);
-            S.w[(size_t)i * S.n_pad + idx] = (uint32_t)c;
+            w[i] = (uint32_t)c;
+            if (write) S.w[(size_t)i * S.n_pad + idx] = (uint32_t)c;
             c >>= 32;
         }
+    }
+    return true;
+}
+
+// one signature: prep_scalars, then 1Q..8Q (1Q affine, 2Q..8Q Jacobian: X, Y in the table rows, Z aside).  Sets
+// the status; returns true when the table is to be normalised (no exceptional case).
+template <int N>
+__device__ __forceinline__ bool prep_points(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
+                                            const uint8_t *__restrict__ pubkeys, size_t idx, const VerifyScratch &S)
+{
+    affT<N> Q;
+    {
+        feT<N> u;
+        uint32_t w[N / 2 + 1];
+        if (!prep_scalars<N>(hashes, sigs, pubkeys, idx, S, true, Q, u, w)) return false;
     }
     // table 1Q..8Q: 1Q as given, 2Q..8Q Jacobian for now (bign_prep_kernel normalises them).  Any exceptional
     // case -> slow path.
@@ -383,6 +400,195 @@ void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
     // inversion between several signatures; X goes to rx[], Z takes the place of u (used up)
     store_soa(S.rx, S.n_pad, idx, T.X);
     store_soa(S.u, S.n_pad, idx, T.Z);
+}
+
+// ------------------------------------------------------- main, small batches ---
+// The same double-scalar multiplication on the signed 29-bit limbs of bign_fe29.hpp, for batches that leave a
+// wavefront alone on its SIMD (<= 2^16 signatures): there a kernel costs its instruction count and this form
+// has 0.69 of the instructions of the 32-bit one.  Reads the scratch bign_prep_kernel<8> wrote (affine 1Q..8Q in
+// 32-bit words, converted on load: 2 instructions per limb) and leaves (X, Z) for bign_inv_kernel like the big
+// kernel.  Exceptional cases: every one of them (T = O, T = +-E, table point O) zeroes Z3 = Z1 H and all Z after it,
+// so ONE test of the final Z sends the same signatures to bign_slow_kernel as the per-addition flags of
+// bign_main_kernel do.
+__global__ __launch_bounds__(256)
+void bign_main29_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
+{
+    constexpr int N = 8, NW = N / 2 + 1, W = Comb<N>::W;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    if (S.status[idx] != ST_PENDING) return;
+    uint32_t w[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) w[i] = S.w[(size_t)i * S.n_pad + idx];
+
+    jac29 T;
+    affT<N> E;
+    aff29 E29;
+    load_qaff(E, S, (int)(w[NW - 1] & 15u) - 9, idx);       // top digit: 1 or 2
+    f29_from_words(T.X, E.x);
+    f29_from_words(T.Y, E.y);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) T.Z.l[i] = i == 0;
+
+#pragma unroll 1
+    for (int i = 4 * N - 1; i >= 0; --i) {
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) jac29_dbl(T);
+        const int d = (int)(w[NW - 2] >> 28) - 8;
+#pragma unroll
+        for (int l = NW - 2; l > 0; --l) w[l] = (w[l] << 4) | (w[l - 1] >> 28);
+        w[0] <<= 4;
+        if (d != 0) {
+            load_qaff(E, S, (d < 0 ? -d : d) - 1, idx);
+            f29_from_words(E29.x, E.x);
+            f29_from_words(E29.y, E.y);
+            if (d < 0) f29_neg(E29.y, E29.y);
+            jac29_madd(T, E29);
+        }
+    }
+    feT<N> u;
+    load_soa(u, S.u, S.n_pad, idx);
+#pragma unroll 1
+    for (int win = 0; win < 32 * N / W; ++win) {
+        const uint32_t b = u.v[0] & ((1u << W) - 1u);
+#pragma unroll
+        for (int l = 0; l < N - 1; ++l) u.v[l] = (u.v[l] >> W) | (u.v[l + 1] << (32 - W));
+        u.v[N - 1] >>= W;
+        if (b != 0) {
+            load_aff(E, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
+            f29_from_words(E29.x, E.x);
+            f29_from_words(E29.y, E.y);
+            jac29_madd(T, E29);
+        }
+    }
+    feT<N> X, Z;
+    f29_to_words(Z, T.Z);
+    if (fe_is_zero(Z)) { S.status[idx] = ST_SLOW; return; }
+    f29_to_words(X, T.X);
+    store_soa(S.rx, S.n_pad, idx, X);
+    store_soa(S.u, S.n_pad, idx, Z);
+}
+
+// ------------------------------------------------- prep + main, smallest batches ---
+// One signature per DPP quad (bign_quad29.hpp): up to 2^15 signatures the lanes are there for the taking (2^15 x 4
+// lanes = two wavefronts per SIMD), and four lanes walk the 128 dependent doublings 2.6x as fast as one
+// (tools/ubench/quad_dbl.hip).  The kernel does what prep + main do for the larger batches: range checks and
+// scalars (every lane of the quad, the first one writes), the table 1Q..8Q -- kept JACOBIAN with Z^2 beside it: with
+// spare lanes the general addition costs the same four levels as the mixed one, so no normalisation and no
+// inversion -- in LDS as [entry][X, Y, Z, ZZ][limb][signature], each field element written by one lane of the quad;
+// then 4N+1 signed radix-16 digits of v and the 2N comb windows of u through ONE addition site.  Leaves (X, Z) for
+// bign_inv_kernel.  Exceptional cases zero Z (bign_quad29.hpp) and go to bign_slow_kernel.
+// WG = 64 (one wavefront, 16 signatures, 18 KiB of LDS) up to 2^13 signatures; 256 above, so that the four
+// wavefronts of a workgroup land on the four SIMDs of a CU (one-wavefront workgroups are placed unevenly: 2^14
+// signatures took 436 us against 370 us for 2^13).
+template <int WG>
+__global__ __launch_bounds__(WG)
+void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
+                        const uint8_t *__restrict__ pubkeys, size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
+{
+    constexpr int N = 8, NW = N / 2 + 1, W = Comb<N>::W, NS = WG / 4;
+    __shared__ int32_t s_tab[8 * 4 * 9 * NS];
+    const uint32_t q = threadIdx.x & 3u, sl = threadIdx.x >> 2;
+    const size_t idx = (size_t)blockIdx.x * NS + sl;
+    if (idx >= n) return;                           // whole quads leave together
+    affT<N> Q;
+    feT<N> u;
+    uint32_t w[NW];
+    if (!prep_scalars<N>(hashes, sigs, pubkeys, idx, S, q == 0, Q, u, w)) return;
+
+    // lane q of the quad owns field element q (X, Y, Z, ZZ) of every table entry
+    const auto put = [&](int e, const qjac29 &P) {
+        const fe29 &f = q == 0 ? P.X : q == 1 ? P.Y : q == 2 ? P.Z : P.D;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) s_tab[((e * 4 + (int)q) * 9 + l) * NS + sl] = f.l[l];
+    };
+    const auto get = [&](qent29 &E, int e) {
+        const int32_t *b = s_tab + (size_t)e * 4 * 9 * NS + sl;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) {
+            E.X.l[l] = b[(0 * 9 + l) * NS]; E.Y.l[l] = b[(1 * 9 + l) * NS];
+            E.Z.l[l] = b[(2 * 9 + l) * NS]; E.ZZ.l[l] = b[(3 * 9 + l) * NS];
+        }
+    };
+
+    qent29 E;                                       // Q as a table entry: affine
+    f29_from_words(E.X, Q.x);
+    f29_from_words(E.Y, Q.y);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) E.Z.l[i] = E.ZZ.l[i] = i == 0;
+    qjac29 A, T, Wk;
+    A.X = E.X; A.Y = E.Y; A.Z = E.Z; A.D = E.Z;
+    T = A;
+    put(0, A);
+    // 2Q..8Q as two chains (A: 2Q 4Q 8Q, T: 3Q 6Q 7Q, 5Q = 4Q + Q), one doubling site and one addition site:
+    // step = (operation, source chain, destination chain, entry)
+#pragma unroll 1
+    for (int step = 0; step < 7; ++step) {
+        // step:      0      1      2      3      4      5      6
+        // op:       dbl    add    dbl    dbl    add    add    dbl
+        // source:    A      A      A      T      T      A      A
+        // dest:      A      T      A      T      T      T      A
+        // entry:     1      2      3      5      6      4      7
+        const bool is_add = (0x32 >> step) & 1, from_t = (0x18 >> step) & 1, to_t = (0x3A >> step) & 1;
+        const int entry = (int)((0x7465321u >> (4 * step)) & 15u);
+        Wk = from_t ? T : A;
+        if (is_add) quad29_add(Wk, E, q);
+        else quad29_dbl(Wk, q);
+        put(entry, Wk);
+        if (to_t) T = Wk; else A = Wk;
+    }
+    __syncthreads();                                // makes the table writes visible to the quad (wavefronts that
+                                                    // left early do not take part in the barrier)
+
+    // top digit d_{4N} = nibble_{4N}(w) - 8 is 1 or 2
+    get(E, (int)(w[NW - 1] & 15u) - 9);
+    T.X = E.X; T.Y = E.Y; T.Z = E.Z; T.D = E.ZZ;
+#pragma unroll 1
+    for (int it = 4 * N - 1 + 32 * N / W; it >= 0; --it) {
+        bool have;
+        if (it >= 32 * N / W) {                     // a digit of v: 4 doublings, then +- |d| Q from the LDS table
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) quad29_dbl(T, q);
+            const int d = (int)(w[NW - 2] >> 28) - 8;
+#pragma unroll
+            for (int l = NW - 2; l > 0; --l) w[l] = (w[l] << 4) | (w[l - 1] >> 28);
+            w[0] <<= 4;
+            have = d != 0;
+            if (have) {
+                get(E, (d < 0 ? -d : d) - 1);
+                if (d < 0) f29_neg(E.Y, E.Y);
+            }
+        } else {                                    // a comb window of u: affine point from the table of G
+            const int win = 32 * N / W - 1 - it;
+            const uint32_t b = u.v[0] & ((1u << W) - 1u);
+#pragma unroll
+            for (int l = 0; l < N - 1; ++l) u.v[l] = (u.v[l] >> W) | (u.v[l + 1] << (32 - W));
+            u.v[N - 1] >>= W;
+            have = b != 0;
+            if (have) {
+                affT<N> G;
+                load_aff(G, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
+                f29_from_words(E.X, G.x);
+                f29_from_words(E.Y, G.y);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) E.Z.l[i] = E.ZZ.l[i] = i == 0;
+            }
+        }
+        if (have) quad29_add(T, E, q);
+    }
+    feT<N> X, Z;
+    f29_to_words(Z, T.Z);
+    const bool zero = fe_is_zero(Z);
+    if (q == 0) {
+        if (zero) {
+            S.status[idx] = ST_SLOW;
+        } else {
+            f29_to_words(X, T.X);
+            store_soa(S.rx, S.n_pad, idx, X);
+            store_soa(S.u, S.n_pad, idx, Z);
+            S.status[idx] = ST_PENDING;
+        }
+    }
 }
 
 // --------------------------------------------------------------------- slow ---
@@ -676,6 +882,49 @@ __global__ void bign_debug_fe_kernel(int op, const uint32_t *a, const uint32_t *
         for (int i = 0; i < N; ++i) { w[i] = x.v[i]; w[N + i] = y.v[i]; }
         if (op == 9) fe_reduce<1>(r, w); else fe_reduce<3>(r, w);
     } break;
+    case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28:
+        if constexpr (N == 8) {           // the 29-bit-limb forms of bign_fe29.hpp (256-bit curve only)
+            fe29 a29, b29, r29, t29;
+            f29_from_words(a29, x);
+            f29_from_words(b29, y);
+            switch (op) {
+            case 20: f29_mul(r29, a29, b29); break;
+            case 21: f29_sqr(r29, a29); break;
+            case 22: f29_mul<3>(r29, a29, b29); break;
+            case 23: f29_sqr<8>(r29, a29); break;
+            case 24: f29_sub(r29, a29, b29); break;                                          // lazy, straight out
+            case 25: f29_sub(t29, a29, b29); f29_add(r29, a29, b29); f29_mul<3>(r29, t29, r29); break;   // 3 (a-b)(a+b)
+            case 26: f29_sub(t29, a29, b29); f29_sub(t29, t29, b29); f29_sub(t29, t29, b29); f29_carry(t29);
+                     f29_neg(r29, b29); f29_mul<4>(r29, t29, r29); break;                    // 4 (a - 3b)(-b)
+            case 27: f29_sub(t29, a29, b29); f29_sqr<8>(r29, t29); break;                     // 8 (a-b)^2
+            default: f29_add(t29, a29, b29); f29_sub(r29, a29, b29); f29_mul<2>(r29, r29, t29);
+                     f29_sub(r29, r29, a29); f29_sub(r29, r29, a29); f29_sub(r29, r29, a29); break;  // 2(a-b)(a+b) - 3a
+            }
+            f29_to_words(r, r29);
+        } else {
+            r = x;
+        }
+        break;
+    case 29: case 30:
+        if constexpr (N == 8) {           // point doubling / addition in the 29-bit form: affine x of 2P / of 2P + P
+            jac29 T;
+            f29_from_words(T.X, x);
+            f29_from_words(T.Y, y);
+            for (int i = 0; i < 9; ++i) T.Z.l[i] = i == 0;
+            aff29 E;
+            E.x = T.X; E.y = T.Y;
+            jac29_dbl(T);
+            if (op == 30) jac29_madd(T, E);
+            feT<N> X, Z;
+            f29_to_words(X, T.X);
+            f29_to_words(Z, T.Z);
+            feT<N> zi = fe_inv(Z);
+            fe_sqr(zi, zi);
+            fe_mul(r, X, zi);
+        } else {
+            r = x;
+        }
+        break;
     default: {
         jacT<N> P; P.X = x; P.Y = y; fe_set_one(P.Z);
         jac_dbl(P);
@@ -769,6 +1018,9 @@ static err_t bign_scratch(hipStream_t st, size_t n, VerifyScratch &S)
     return ERR_OK;
 }
 
+static int g_verify_path = 0;
+void set_verify_path(int v) { g_verify_path = v; }
+
 template <int N>
 static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
                                   const void *d_sigs, const void *d_pubkeys, size_t n, void *d_codes,
@@ -791,13 +1043,41 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
     const unsigned g256 = (unsigned)((n + 255) / 256), g64 = (unsigned)((n + 63) / 64);
     const size_t sp = n >= ((size_t)1 << 18) ? 2 : 1;     // signatures per lane in prep (shared inversion)
     const size_t plan = (n + sp - 1) / sp;
-    if (N != 8)
-        hipLaunchKernelGGL(bign_points_kernel<N>, dim3(g256), dim3(256), 0, st, (const uint8_t *)d_hashes,
-                           (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S);
-    hipLaunchKernelGGL(bign_prep_kernel<N>, dim3((unsigned)((plan + 255) / 256)), dim3(256), 0, st,
-                       (const uint8_t *)d_hashes, (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, plan,
-                       (int)sp, S);
-    hipLaunchKernelGGL(bign_main_kernel<N>, dim3(g256), dim3(256), 0, st, n, S, (const uint4 *)gtab);
+    // Which kernels walk the scalar multiplication (256-bit curve; g_verify_path: 0 by size, 1 always the 32-bit
+    // kernels, 2 the 29-bit main kernel, 3 the quad kernel -- tests and A/B):
+    //   <= 2^15 signatures: one signature per quad, 29-bit limbs (prep + main in one kernel, no table inversion)
+    //   <= 2^16           : one lane per signature, 29-bit limbs (at most one wavefront per SIMD: instruction count)
+    //   above             : one lane per signature, 32-bit limbs (the throughput form)
+    int path = 1;
+    if constexpr (N == 8) {
+        path = g_verify_path ? g_verify_path : n <= ((size_t)1 << 15) ? 3 : n <= ((size_t)1 << 16) ? 2 : 1;
+        if (path == 3) {
+            if (n <= ((size_t)1 << 13))
+                hipLaunchKernelGGL(bign_quad29_kernel<64>, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, st,
+                                   (const uint8_t *)d_hashes, (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S,
+                                   (const uint4 *)gtab);
+            else
+                hipLaunchKernelGGL(bign_quad29_kernel<256>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st,
+                                   (const uint8_t *)d_hashes, (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S,
+                                   (const uint4 *)gtab);
+        }
+    }
+    if (path != 3) {
+        if (N != 8)
+            hipLaunchKernelGGL(bign_points_kernel<N>, dim3(g256), dim3(256), 0, st, (const uint8_t *)d_hashes,
+                               (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S);
+        hipLaunchKernelGGL(bign_prep_kernel<N>, dim3((unsigned)((plan + 255) / 256)), dim3(256), 0, st,
+                           (const uint8_t *)d_hashes, (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, plan,
+                           (int)sp, S);
+        if constexpr (N == 8) {
+            if (path == 2) {
+                const unsigned wg = n <= ((size_t)1 << 14) ? 64u : 256u;
+                hipLaunchKernelGGL(bign_main29_kernel, dim3((unsigned)((n + wg - 1) / wg)), dim3(wg), 0, st, n, S,
+                                   (const uint4 *)gtab);
+            }
+        }
+        if (path != 2) hipLaunchKernelGGL(bign_main_kernel<N>, dim3(g256), dim3(256), 0, st, n, S, (const uint4 *)gtab);
+    }
     hipLaunchKernelGGL(bign_slow_kernel<N>, dim3(g64), dim3(64), 0, st, (const uint8_t *)d_sigs,
                        (const uint8_t *)d_pubkeys, n, S);
     // signatures per inversion.  Each lane runs one chain (division steps, then 5 multiplications per

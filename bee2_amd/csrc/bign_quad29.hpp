@@ -1,0 +1,166 @@
+// bign_quad29.hpp -- one signature on FOUR adjacent lanes (a DPP quad), field elements on the signed 29-bit limbs
+// of bign_fe29.hpp: the point operations of the smallest verification batches (<= 2^14 signatures).
+//
+// v Q is 32N dependent doublings; with one lane per signature a batch below 2^16 signatures is one wavefront per
+// SIMD walking that chain, so its time does not depend on its size (the latency floor).  A doubling's
+// multiplications have dependency depth 3, a general addition's depth 4: lane k of a quad takes the k-th
+// multiplication of a level, the products travel with v_mov_b32 quad_perm broadcasts, the limb-wise additions are
+// evaluated by all four lanes, so the state (X, Y, Z, Z^2) stays replicated.  The spare lanes buy the formulas'
+// small multiples as separately scaled products (4 X g AND 8 X g, 3 X^2 AND 3 Z^4), which also keeps every sum
+// inside the bounds of the carry-free limbs: a doubling needs no carry pass at all, an addition one.
+// Same group law as jac_dbl / jac_add (bign_dev.hpp), hence the same exceptional cases; each of them zeroes Z3 and
+// every Z after it, and the caller tests the final Z once.
+// tools/ubench/quad_dbl.hip: x1.6 (32-bit limbs, bign_quad.hpp) on a lone wavefront; this form measured there too.
+#pragma once
+#include "bign_fe29.hpp"
+
+namespace bee2hip {
+
+// a from lane K of the quad.  Written as asm on purpose: with __builtin_amdgcn_mov_dpp LLVM folds the broadcast into
+// the consuming v_sub_u32 (v_subrev_u32_dpp ... quad_perm) and the differences of two broadcasts then came out wrong
+// on gfx950 (tools/ubench/quad29_check.hip: alpha = bcast<2> - bcast<3> returned bcast<2> - bcast<0>); explicit
+// v_mov_b32_dpp instructions are exact.
+template <int K>
+__device__ __forceinline__ void q29_bcast(fe29 &r, const fe29 &a)
+{
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+        asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[%2,%2,%2,%2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                     : "=v"(r.l[i]) : "v"(a.l[i]), "n"(K));
+}
+__device__ __forceinline__ void q29_pick(fe29 &r, bool p, const fe29 &a, const fe29 &b)
+{
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = p ? a.l[i] : b.l[i];
+}
+
+// r = K a b with a per-lane K in {1, 2, 3, 4, 8}
+__device__ __forceinline__ void f29_mul_k(fe29 &r, const fe29 &a, const fe29 &b, int32_t K)
+{
+    int32_t c[18];
+    int64_t acc = 0;
+    static_for<0, 17>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        static_for<(k > 8 ? k - 8 : 0), (k < 8 ? k : 8) + 1>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            acc += (int64_t)a.l[i] * b.l[k - i];
+        });
+        c[k] = (int32_t)acc & F29_M;
+        acc >>= 29;
+    });
+    c[17] = (int32_t)acc;
+    const int32_t KF = K * F29_FOLD;
+    int64_t cy = 0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        int64_t t = (int64_t)c[9 + j] * KF + cy;
+        t += (int64_t)c[j] * K;
+        r.l[j] = (int32_t)t & F29_M;
+        cy = t >> 29;
+    }
+    const int32_t t0 = r.l[0] + (int32_t)cy * F29_FOLD;
+    r.l[0] = t0 & F29_M;
+    r.l[1] += t0 >> 29;
+}
+
+struct qjac29 { fe29 X, Y, Z, D; };                // D = Z^2; X, Y: L1; Z, D: N; replicated in the quad
+struct qent29 { fe29 X, Y, Z, ZZ; };               // X, Y: L1; Z, ZZ = Z^2: N (affine: 1, 1)
+
+// T <- 2T, a = -3, three levels.  Bounds in units of u = 2^29 (operand bounds of a product must multiply to <= 3):
+//   A: Y^2 | 2 Y Z | 3 X^2 | 3 D^2        (1 x 1 each)      alpha = 3 X^2 - 3 Z^4                      L1
+//   B: 4 X g | 8 X g | Z3^2 | alpha^2      (1 x 1 each)      X3 = alpha^2 - 8 X g                       L1
+//   C: alpha (4 X g - X3) | 8 g^2          (1 x 2, 1 x 1)    Y3 = ... - 8 g^2                           L1
+__device__ __forceinline__ void quad29_dbl(qjac29 &T, uint32_t q)
+{
+    const bool q0 = q == 0, q1 = q == 1, q2 = q == 2, lo = q < 2;
+    fe29 a, b, r, gamma, alpha, b4, t;
+    // level A
+    q29_pick(a, q2, T.X, T.D);
+    q29_pick(a, lo, T.Y, a);
+    q29_pick(b, q1, T.Z, a);
+    f29_mul_k(r, a, b, q0 ? 1 : q1 ? 2 : 3);
+    q29_bcast<0>(gamma, r);
+    q29_bcast<1>(T.Z, r);                           // Z3 = 2 Y Z
+    q29_bcast<2>(alpha, r);
+    q29_bcast<3>(t, r);
+    f29_sub(alpha, alpha, t);
+    // level B
+    q29_pick(a, q2, T.Z, alpha);
+    q29_pick(a, lo, T.X, a);
+    q29_pick(b, lo, gamma, a);
+    f29_mul_k(r, a, b, q0 ? 4 : q1 ? 8 : 1);
+    q29_bcast<0>(b4, r);
+    q29_bcast<1>(t, r);                             // 8 X g
+    q29_bcast<2>(T.D, r);                           // D3 = Z3^2
+    q29_bcast<3>(T.X, r);                           // alpha^2
+    f29_sub(T.X, T.X, t);                           // X3
+    f29_sub(t, b4, T.X);                            // [-1, 2]
+    // level C
+    q29_pick(a, q0, alpha, gamma);
+    q29_pick(b, q0, t, gamma);
+    f29_mul_k(r, a, b, q1 ? 8 : 1);
+    q29_bcast<0>(T.Y, r);
+    q29_bcast<1>(t, r);
+    f29_sub(T.Y, T.Y, t);                           // Y3
+}
+
+// T <- T + E, general addition (add-1998-cmo-2 with Z1^2 carried and Z2^2 tabulated) in four levels:
+//   1: X1 ZZ2 | X2 D | Z1 D | Y1 ZZ2             H = U2 - U1 (L1)
+//   2: Y2 Z1^3 | H^2 | Z1 Z2 | (Y1 ZZ2) Z2       r = S2 - S1 (L1)
+//   3: H H^2 | U1 H^2 | (Z1 Z2) H | r^2          X3 = r^2 - H^3 - 2V  ([-3, 1] -> carry -> N)
+//   4: r (V - X3) | S1 H^3 | Z3^2                Y3 (L1), D3
+__device__ __forceinline__ void quad29_add(qjac29 &T, const qent29 &E, uint32_t q)
+{
+    const bool q0 = q == 0, q1 = q == 1, q2 = q == 2;
+    fe29 a, b, r, U1, S1, H, HH, rr, V, t;
+    // level 1
+    q29_pick(a, q2, T.Z, T.Y);
+    q29_pick(a, q1, E.X, a);
+    q29_pick(a, q0, T.X, a);
+    q29_pick(b, q1 || q2, T.D, E.ZZ);
+    f29_mul(r, a, b);
+    q29_bcast<0>(U1, r);
+    q29_bcast<1>(H, r);
+    q29_bcast<2>(t, r);                             // Z1^3
+    f29_sub(H, H, U1);
+    // level 2 (lane 3 multiplies its own Y1 ZZ2 by Z2)
+    q29_pick(a, q0, E.Y, T.Z);
+    q29_pick(a, q1, H, a);
+    q29_pick(a, q == 3, r, a);
+    q29_pick(b, q0, t, E.Z);
+    q29_pick(b, q1, H, b);
+    f29_mul(r, a, b);
+    q29_bcast<0>(rr, r);
+    q29_bcast<1>(HH, r);
+    q29_bcast<2>(t, r);                             // Z1 Z2
+    q29_bcast<3>(S1, r);
+    f29_sub(rr, rr, S1);
+    // level 3
+    q29_pick(a, q2, t, rr);
+    q29_pick(a, q1, U1, a);
+    q29_pick(a, q0, H, a);
+    q29_pick(b, q2, H, rr);
+    q29_pick(b, q0 || q1, HH, b);
+    f29_mul(r, a, b);
+    q29_bcast<0>(H, r);                             // H^3
+    q29_bcast<1>(V, r);
+    q29_bcast<2>(T.Z, r);                           // Z3
+    q29_bcast<3>(t, r);                             // r^2
+    f29_sub(t, t, H);
+    f29_sub(t, t, V);
+    f29_sub(T.X, t, V);
+    f29_carry(T.X);                                 // X3, N
+    f29_sub(t, V, T.X);
+    // level 4
+    q29_pick(a, q0, rr, S1);
+    q29_pick(a, q2, T.Z, a);
+    q29_pick(b, q0, t, H);
+    q29_pick(b, q2, T.Z, b);
+    f29_mul(r, a, b);
+    q29_bcast<0>(t, r);
+    q29_bcast<1>(V, r);
+    q29_bcast<2>(T.D, r);                           // D3
+    f29_sub(T.Y, t, V);                             // Y3
+}
+
+}  // namespace bee2hip

@@ -1090,12 +1090,13 @@ extern "C" err_t bee2hip_bashHash_beltMAC_batch(const octet *msgs, size_t msg_le
 
 // ============================================================ internal tuning hook ===
 // A/B switch for experiment builds (tools/bashf_ab.py); not part of the product ABI (BEE2HIP_INTERNAL).
-namespace bee2hip { void set_bashF_variant(int v); void set_ctr_variant(int v); }
+namespace bee2hip { void set_bashF_variant(int v); void set_ctr_variant(int v); void set_verify_path(int v); }
 extern "C" err_t bee2hip_internal_tune(int key, int value)
 {
     switch (key) {
     case 0: bee2hip::set_bashF_variant(value); return ERR_OK;
     case 1: bee2hip::set_ctr_variant(value); return ERR_OK;
+    case 2: bee2hip::set_verify_path(value); return ERR_OK;
     default: return ERR_BAD_INPUT;
     }
 }

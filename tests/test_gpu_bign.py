@@ -49,6 +49,105 @@ def test_field_ops_vs_python_ints():
         assert got == want, f"field op {op}"
 
 
+def _limb_patterns(rnd):
+    """256-bit values whose 29-bit limbs sit at the corners the carry-free accumulation has to survive"""
+    M = (1 << 29) - 1
+    vals = []
+    for pat in ([M] * 9, [0] * 9, [M, 0] * 5, [0, M] * 5, [1] * 9, [M - 1] * 9, [M] + [0] * 8, [0] * 8 + [M]):
+        vals.append(sum(l << (29 * i) for i, l in enumerate(pat[:9])) & ((1 << 256) - 1))
+    for _ in range(64):
+        limbs = [rnd.choice([0, 1, M, M - 1, rnd.getrandbits(29)]) for _ in range(9)]
+        vals.append(sum(l << (29 * i) for i, l in enumerate(limbs)) & ((1 << 256) - 1))
+    return vals
+
+
+def test_field_ops_29bit_limbs_vs_python_ints():
+    """bign_fe29.hpp (the small-batch form: nine signed 29-bit limbs, lazy additions) against big-int arithmetic:
+    multiplication / squaring with the folded small multiples, lazy differences and sums fed straight into
+    multiplications at the bounds the point formulas use, the exact conversion back to 32-bit words"""
+    eng = engine()
+    rnd = random.Random(29)
+    special = [0, 1, 2, 188, 189, 190, P - 2, P - 1, P, P + 1, P + 188, 2 ** 256 - 1, 2 ** 255,
+               2 ** 232, 2 ** 232 - 1, 2 ** 29 - 1, 2 ** 29, (1 << 256) - (1 << 32)] + _limb_patterns(rnd)
+    pool = special + [rnd.getrandbits(256) for _ in range(300)]
+    A = [a for a in special for _ in special] + [rnd.choice(pool) for _ in range(8192)]
+    B = [b for _ in special for b in special] + [rnd.choice(pool) for _ in range(8192)]
+    ops = {20: lambda a, b: a * b % P, 21: lambda a, b: a * a % P, 22: lambda a, b: 3 * a * b % P,
+           23: lambda a, b: 8 * a * a % P, 24: lambda a, b: (a - b) % P, 25: lambda a, b: 3 * (a - b) * (a + b) % P,
+           26: lambda a, b: 4 * (a - 3 * b) * (-b) % P, 27: lambda a, b: 8 * (a - b) ** 2 % P,
+           28: lambda a, b: (2 * (a - b) * (a + b) - 3 * a) % P}
+    for op, f in ops.items():
+        got = _fe_run(eng, op, A, B)
+        want = [f(a, b) for a, b in zip(A, B)]
+        bad = [(hex(a), hex(b)) for a, b, g, w in zip(A, B, got, want) if g != w]
+        assert not bad, f"29-bit field op {op}: {len(bad)} wrong, first {bad[0]}"
+
+
+def test_point_ops_29bit_limbs_match_the_32bit_ones(golden):
+    """2P and 3P = 2P + P of public keys from the fixtures: affine x from jac29_dbl / jac29_madd == from the
+    Python group law"""
+    eng = engine()
+    _, _, ps = golden.bign_base_arrays()
+    pts = [(int.from_bytes(ps[64 * i:64 * i + 32], "little"), int.from_bytes(ps[64 * i + 32:64 * i + 64], "little"))
+           for i in range(512)]
+
+    def dbl(x, y):
+        lam = (3 * x * x - 3) * pow(2 * y, P - 2, P) % P
+        x3 = (lam * lam - 2 * x) % P
+        return x3, (lam * (x - x3) - y) % P
+
+    def add(x1, y1, x2, y2):
+        lam = (y2 - y1) * pow(x2 - x1, P - 2, P) % P
+        x3 = (lam * lam - x1 - x2) % P
+        return x3, (lam * (x1 - x3) - y1) % P
+
+    X = [p[0] for p in pts]
+    Y = [p[1] for p in pts]
+    assert _fe_run(eng, 29, X, Y) == [dbl(x, y)[0] for x, y in pts]
+    assert _fe_run(eng, 30, X, Y) == [add(*dbl(x, y), x, y)[0] for x, y in pts]
+
+
+@pytest.mark.parametrize("path", [1, 2, 3])
+def test_bign_both_main_kernels_on_edge_and_base_sets(golden, path):
+    """The batch size picks the main kernel (29-bit limbs up to 2^16 signatures, 32-bit above); here each is FORCED
+    (bee2hip_internal_tune(2, path): 1 = 32-bit limbs, 2 = 29-bit limbs, 3 = one signature per quad) over the 433 edge cases (exceptional group-law cases
+    included: they must reach the slow path from either kernel), the valid base set, and a 70 000-signature tiling
+    with every 7th signature corrupted -- a size the 29-bit kernel never sees unforced."""
+    eng = engine()
+    tune = eng.lib.bee2hip_internal_tune
+    tune.restype = ctypes.c_uint32
+    assert tune(2, path) == 0
+    try:
+        Ecases = golden.bign_edge
+        eh = b"".join(bytes.fromhex(e["hash"]) for e in Ecases)
+        es = b"".join(bytes.fromhex(e["sig"]) for e in Ecases)
+        ep = b"".join(bytes.fromhex(e["pubkey"]) for e in Ecases)
+        codes = torch.full((len(Ecases),), -1, dtype=torch.int32, device="cuda")
+        eng.bign128Verify_batch_dev(dev(eh), dev(es), dev(ep), codes)
+        torch.cuda.synchronize()
+        got = [int(c) & 0xFFFFFFFF for c in codes.cpu().numpy()]
+        bad = [(e["name"], g, e["code"]) for e, g in zip(Ecases, got) if g != e["code"]]
+        assert not bad, bad[:10]
+        hs, ss, ps = golden.bign_base_arrays()
+        n0 = len(hs) // 32
+        reps = 70_000 // n0 + 1
+        H = np.frombuffer(hs * reps, dtype=np.uint8).copy()
+        S = np.frombuffer(ss * reps, dtype=np.uint8).copy()
+        K = np.frombuffer(ps * reps, dtype=np.uint8).copy()
+        n = 70_000
+        H, S, K = H[: 32 * n], S[: 48 * n], K[: 64 * n]
+        S.reshape(n, 48)[::7, 5] ^= 0x40                      # s0 of every 7th signature
+        codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        eng.bign128Verify_batch_dev(torch.from_numpy(H).cuda(), torch.from_numpy(S).cuda(), torch.from_numpy(K).cuda(), codes)
+        torch.cuda.synchronize()
+        got = codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        want = np.zeros(n, dtype=np.int64)
+        want[::7] = 510
+        assert np.array_equal(got, want)
+    finally:
+        tune(2, 0)
+
+
 def test_bign_G2_G3_dropin(golden):
     eng = engine()
     params = eng.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")

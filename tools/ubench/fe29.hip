@@ -6,10 +6,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
-#include "bign_dev.hpp"
+#include "bign_fe29.hpp"
 using namespace bee2hip;
 
-struct fe29 { uint32_t l[9]; };
+struct ufe29 { uint32_t l[9]; };
+#define fe29 ufe29
 constexpr uint32_t M29 = (1u << 29) - 1u;
 constexpr uint32_t FOLD = 189u * 32u;          // 2^261 mod p
 
@@ -119,6 +120,15 @@ void chain(const uint32_t *in, uint32_t *out, int reps)
 #pragma unroll 1
         for (int r = 0; r < reps; ++r) { fe_mul(x, x, y); fe_sqr(y, x); }
         fe_canon(x, x); fe_canon(y, y);
+    } else if (MODE == 2) {                     // the signed form of bign_fe29.hpp (what the kernels use)
+#undef fe29
+        bee2hip::fe29 a, b;
+#define fe29 ufe29
+        f29_from_words(a, x); f29_from_words(b, y);
+#pragma unroll 1
+        for (int r = 0; r < reps; ++r) { f29_mul(a, a, b); f29_sqr(b, a); }
+        f29_to_words(x, a); f29_to_words(y, b);
+        fe_canon(x, x); fe_canon(y, y);
     } else {
         fe29 a, b;
         to29(a, x); to29(b, y);
@@ -145,20 +155,21 @@ int main()
     size_t bad = 0;
     for (int nwave : {256, 1024, 2048, 4096}) {
         const int nthr = nwave * 64;
-        float t[2] = {0, 0};
-        for (int mode = 0; mode < 2; ++mode) {
+        float t[3] = {0, 0, 0};
+        for (int mode = 0; mode < 3; ++mode) {
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(e0);
                 if (mode == 0) hipLaunchKernelGGL(chain<0>, dim3(nwave), dim3(64), 0, 0, din, dout, reps);
-                else hipLaunchKernelGGL(chain<1>, dim3(nwave), dim3(64), 0, 0, din, dout, reps);
+                else if (mode == 1) hipLaunchKernelGGL(chain<1>, dim3(nwave), dim3(64), 0, 0, din, dout, reps);
+                else hipLaunchKernelGGL(chain<2>, dim3(nwave), dim3(64), 0, 0, din, dout, reps);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 hipEventElapsedTime(&t[mode], e0, e1);
             }
             hipMemcpy(mode ? o1 : o0, dout, (size_t)nthr * 64, hipMemcpyDeviceToHost);
+            if (mode) for (size_t i = 0; i < (size_t)nthr * 16; ++i) bad += o0[i] != o1[i];
         }
-        for (size_t i = 0; i < (size_t)nthr * 16; ++i) bad += o0[i] != o1[i];
-        printf("%.2f wavefronts/SIMD: 32-bit limbs %.3f ms, 29-bit limbs %.3f ms for %d x (mul + sqr)  -> x%.2f\n",
-               nwave / 1024.0, t[0], t[1], reps, t[0] / t[1]);
+        printf("%.2f wavefronts/SIMD: 32-bit limbs %.3f ms, 29-bit unsigned %.3f ms (x%.2f), 29-bit signed (bign_fe29.hpp) %.3f ms (x%.2f) for %d x (mul + sqr)\n",
+               nwave / 1024.0, t[0], t[1], t[0] / t[1], t[2], t[0] / t[2], reps);
     }
     printf("results %s (%zu words differ)\n", bad ? "DIFFER" : "identical", bad);
     return bad != 0;
