@@ -430,6 +430,17 @@ def main():
                                  "v_mad_u64_u32 micro-benchmark (profiles/r01_valu_rates_ubench.txt); every mad is "
                                  "paired with a half-rate v_addc_co_u32, so 0.5 is the practical ceiling"},
         }
+        if dist.rank == 0:
+            # the latency floor: prefixes of the same device-resident batch; up to 2^15 signatures run
+            # one per DPP quad, up to 2^16 on 29-bit limbs, above on 32-bit limbs (profiles/r02_verify_small.txt)
+            small = {}
+            for e in (10, 13, 14, 15, 16, 17):
+                m = 1 << e
+                for _ in range(2):
+                    eng.time_kernel(2, 3, dh, ds, dk, codes, n=m)
+                ms_b = eng.time_kernel(2, 20, dh, ds, dk, codes, n=m)
+                small[f"2^{e}"] = {"ms_per_batch": ms_b, "verifies_per_s": m / (ms_b * 1e-3)}
+            others["bignVerify"]["batch_size_sweep"] = small
         if dist.rank == 0 and N == 1:       # PCIe-inclusive rate: single-GPU runs only
             hcodes = np.empty(n, dtype=np.uint32)
             prm = eng.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
