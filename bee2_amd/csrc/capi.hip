@@ -1134,9 +1134,13 @@ extern "C" err_t bee2hip_time_kernel(int which, int reps, void *d_a, void *d_b, 
     u32 kw[8], c0[4];
     beltKeyExpand2(kw, H + 128, 32);
     for (int i = 0; i < 4; ++i) c0[i] = load32le(H + 192 + 4 * i);
-    hipEvent_t e0, e1;
-    B2H_TRY(hipEventCreate(&e0));
-    B2H_TRY(hipEventCreate(&e1));
+    struct Events {                       // destroyed on every return path
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
+    B2H_TRY(hipEventCreate(&ev.e0));
+    B2H_TRY(hipEventCreate(&ev.e1));
+    hipEvent_t e0 = ev.e0, e1 = ev.e1;
     B2H_TRY(hipEventRecord(e0, st));
     for (int r = 0; r < reps && code == ERR_OK; ++r) {
         switch (which) {
@@ -1151,8 +1155,6 @@ extern "C" err_t bee2hip_time_kernel(int which, int reps, void *d_a, void *d_b, 
     B2H_TRY(hipEventSynchronize(e1));
     float total = 0;
     B2H_TRY(hipEventElapsedTime(&total, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     *ms = total / (float)reps;
     return code;
 }

@@ -437,13 +437,18 @@ def test_bign_pubkey_val_batch_and_dropin(orc, golden, l):
 
 @pytest.mark.parametrize("l,n", [(128, 2 * 32768 + 37), (128, 9 * 32768 - 5), (192, 2 * 65536 + 37), (256, 2 * 65536 + 3),
                                  (128, 2 ** 18 + 1), (192, 2 ** 18 + 3), (256, 2 ** 18 + 1),
-                                 (128, 32767), (128, 32768), (128, 65535), (128, 65536), (128, 2 ** 18 - 1), (128, 2 ** 18)])
+                                 (128, 32767), (128, 32768), (128, 65535), (128, 65536), (128, 2 ** 18 - 1), (128, 2 ** 18),
+                                 # round 2: the quad kernel's workgroup switch (2^13) and the kernel switches at 2^15 / 2^16
+                                 (128, 3), (128, 17), (128, 8191), (128, 8192), (128, 8193), (128, 16385), (128, 32769),
+                                 (128, 65537)])
 def test_bign_shared_inversion_groups_with_mixed_statuses(golden, l, n):
     """bign_inv_kernel shares one inversion between K signatures (K = n / 32768 resp. n / 65536, here 2, 4 and 8)
     and from 2^18 signatures on bign_prep_kernel normalises the tables of two signatures with one inversion.
     Batches whose groups mix genuine signatures with every edge case of the reference-generated fixtures
     (range errors that never reach the inversion, R = O, slow-path lanes, wrong signatures), sizes that
-    are not multiples of K: each code must be the reference's."""
+    are not multiples of K: each code must be the reference's.  On the 256-bit curve the sizes also sit on both sides
+    of every kernel choice: one signature per quad up to 2^15 (64-thread workgroups up to 2^13), 29-bit limbs up to
+    2^16, 32-bit limbs above."""
     eng = engine()
     if l == 128:
         hs, ss, ps = golden.bign_base_arrays()
@@ -466,7 +471,8 @@ def test_bign_shared_inversion_groups_with_mixed_statuses(golden, l, n):
     got = codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, (l, n, bad[:5], got[bad[:5]], want[bad[:5]])
-    assert {0, 505, 510} <= set(int(x) for x in np.unique(got))
+    if n >= 1000:
+        assert {0, 505, 510} <= set(int(x) for x in np.unique(got))
 
 
 def test_bign_oid_lengths_every_alignment(golden):
