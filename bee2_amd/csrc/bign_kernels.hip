@@ -429,35 +429,38 @@ void bign_main29_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gta
     f29_from_words(T.Y, E.y);
 #pragma unroll
     for (int i = 0; i < 9; ++i) T.Z.l[i] = i == 0;
-
-#pragma unroll 1
-    for (int i = 4 * N - 1; i >= 0; --i) {
-#pragma unroll 1
-        for (int k = 0; k < 4; ++k) jac29_dbl(T);
-        const int d = (int)(w[NW - 2] >> 28) - 8;
-#pragma unroll
-        for (int l = NW - 2; l > 0; --l) w[l] = (w[l] << 4) | (w[l - 1] >> 28);
-        w[0] <<= 4;
-        if (d != 0) {
-            load_qaff(E, S, (d < 0 ? -d : d) - 1, idx);
-            f29_from_words(E29.x, E.x);
-            f29_from_words(E29.y, E.y);
-            if (d < 0) f29_neg(E29.y, E29.y);
-            jac29_madd(T, E29);
-        }
-    }
     feT<N> u;
     load_soa(u, S.u, S.n_pad, idx);
+
+    // 4N digits of v (4 doublings + one addition from the table of Q each), then the 2N comb windows of u, through
+    // ONE addition site (the code of this kernel is what a lone wavefront pays for)
 #pragma unroll 1
-    for (int win = 0; win < 32 * N / W; ++win) {
-        const uint32_t b = u.v[0] & ((1u << W) - 1u);
+    for (int it = 4 * N - 1 + 32 * N / W; it >= 0; --it) {
+        bool have;
+        bool negate = false;
+        if (it >= 32 * N / W) {
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) jac29_dbl(T);
+            const int d = (int)(w[NW - 2] >> 28) - 8;
 #pragma unroll
-        for (int l = 0; l < N - 1; ++l) u.v[l] = (u.v[l] >> W) | (u.v[l + 1] << (32 - W));
-        u.v[N - 1] >>= W;
-        if (b != 0) {
-            load_aff(E, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
+            for (int l = NW - 2; l > 0; --l) w[l] = (w[l] << 4) | (w[l - 1] >> 28);
+            w[0] <<= 4;
+            have = d != 0;
+            negate = d < 0;
+            if (have) load_qaff(E, S, (d < 0 ? -d : d) - 1, idx);
+        } else {
+            const int win = 32 * N / W - 1 - it;
+            const uint32_t b = u.v[0] & ((1u << W) - 1u);
+#pragma unroll
+            for (int l = 0; l < N - 1; ++l) u.v[l] = (u.v[l] >> W) | (u.v[l + 1] << (32 - W));
+            u.v[N - 1] >>= W;
+            have = b != 0;
+            if (have) load_aff(E, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
+        }
+        if (have) {
             f29_from_words(E29.x, E.x);
             f29_from_words(E29.y, E.y);
+            if (negate) f29_neg(E29.y, E29.y);
             jac29_madd(T, E29);
         }
     }
@@ -478,17 +481,18 @@ void bign_main29_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gta
 // inversion -- in LDS as [entry][X, Y, Z, ZZ][limb][signature], each field element written by one lane of the quad;
 // then 4N+1 signed radix-16 digits of v and the 2N comb windows of u through ONE addition site.  Leaves (X, Z) for
 // bign_inv_kernel.  Exceptional cases zero Z (bign_quad29.hpp) and go to bign_slow_kernel.
-// WG = 64 (one wavefront, 16 signatures, 18 KiB of LDS) up to 2^13 signatures; 256 above, so that the four
-// wavefronts of a workgroup land on the four SIMDs of a CU (one-wavefront workgroups are placed unevenly: 2^14
-// signatures took 436 us against 370 us for 2^13).
-template <int WG>
+// LANES = 4: a quad per signature (n <= 2^14); LANES = 2: a pair (2^14 < n <= 2^15, where quads would already put two
+// wavefronts on a SIMD: 718 us against the 370 us of a lone wavefront; pairs keep one wavefront per SIMD up to 2^15).
+// WG = 64 (one wavefront) up to 2^13 signatures; 256 above, so that the four wavefronts of a workgroup land on the
+// four SIMDs of a CU.  LDS: 1152 B per signature.
+template <int WG, int LANES>
 __global__ __launch_bounds__(WG)
 void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
                         const uint8_t *__restrict__ pubkeys, size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
 {
-    constexpr int N = 8, NW = N / 2 + 1, W = Comb<N>::W, NS = WG / 4;
-    __shared__ int32_t s_tab[8 * 4 * 9 * NS];
-    const uint32_t q = threadIdx.x & 3u, sl = threadIdx.x >> 2;
+    constexpr int N = 8, NW = N / 2 + 1, W = Comb<N>::W, NS = WG / LANES;
+    extern __shared__ int32_t s_tab[];              // [8 entries][X, Y, Z, ZZ][9 limbs][NS signatures]
+    const uint32_t q = threadIdx.x % LANES, sl = threadIdx.x / LANES;
     const size_t idx = (size_t)blockIdx.x * NS + sl;
     if (idx >= n) return;                           // whole quads leave together
     affT<N> Q;
@@ -496,12 +500,19 @@ void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
     uint32_t w[NW];
     if (!prep_scalars<N>(hashes, sigs, pubkeys, idx, S, q == 0, Q, u, w)) return;
 
-    // lane q of the quad owns field element q (X, Y, Z, ZZ) of every table entry
+    // the lanes of a signature share the writes: lane q owns field element q (X, Y, Z, ZZ) of every table entry
+    // (a pair: q and q + 2)
     const auto put = [&](int e, const qjac29 &P) {
-        const fe29 &f = q == 0 ? P.X : q == 1 ? P.Y : q == 2 ? P.Z : P.D;
 #pragma unroll
-        for (int l = 0; l < 9; ++l) s_tab[((e * 4 + (int)q) * 9 + l) * NS + sl] = f.l[l];
+        for (int k = 0; k < 4 / LANES; ++k) {
+            const int fi = (int)q + LANES * k;
+            const fe29 &f = fi == 0 ? P.X : fi == 1 ? P.Y : fi == 2 ? P.Z : P.D;
+#pragma unroll
+            for (int l = 0; l < 9; ++l) s_tab[((e * 4 + fi) * 9 + l) * NS + sl] = f.l[l];
+        }
     };
+    const auto dbl = [&](qjac29 &P) { if constexpr (LANES == 4) quad29_dbl(P, q); else pair29_dbl(P, q); };
+    const auto add = [&](qjac29 &P, const qent29 &Q2) { if constexpr (LANES == 4) quad29_add(P, Q2, q); else pair29_add(P, Q2, q); };
     const auto get = [&](qent29 &E, int e) {
         const int32_t *b = s_tab + (size_t)e * 4 * 9 * NS + sl;
 #pragma unroll
@@ -532,8 +543,8 @@ void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
         const bool is_add = (0x32 >> step) & 1, from_t = (0x18 >> step) & 1, to_t = (0x3A >> step) & 1;
         const int entry = (int)((0x7465321u >> (4 * step)) & 15u);
         Wk = from_t ? T : A;
-        if (is_add) quad29_add(Wk, E, q);
-        else quad29_dbl(Wk, q);
+        if (is_add) add(Wk, E);
+        else dbl(Wk);
         put(entry, Wk);
         if (to_t) T = Wk; else A = Wk;
     }
@@ -548,7 +559,7 @@ void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
         bool have;
         if (it >= 32 * N / W) {                     // a digit of v: 4 doublings, then +- |d| Q from the LDS table
 #pragma unroll 1
-            for (int k = 0; k < 4; ++k) quad29_dbl(T, q);
+            for (int k = 0; k < 4; ++k) dbl(T);
             const int d = (int)(w[NW - 2] >> 28) - 8;
 #pragma unroll
             for (int l = NW - 2; l > 0; --l) w[l] = (w[l] << 4) | (w[l - 1] >> 28);
@@ -574,7 +585,7 @@ void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
                 for (int i = 0; i < 9; ++i) E.Z.l[i] = E.ZZ.l[i] = i == 0;
             }
         }
-        if (have) quad29_add(T, E, q);
+        if (have) add(T, E);
     }
     feT<N> X, Z;
     f29_to_words(Z, T.Z);
@@ -1018,8 +1029,8 @@ static err_t bign_scratch(hipStream_t st, size_t n, VerifyScratch &S)
     return ERR_OK;
 }
 
-static int g_verify_path = 0;
-void set_verify_path(int v) { g_verify_path = v; }
+static int g_verify_path = 0, g_verify_lanes = 0;
+void set_verify_path(int v) { g_verify_path = v & 15; g_verify_lanes = v >> 4; }   // 0x43: quads at every size
 
 template <int N>
 static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
@@ -1044,22 +1055,31 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
     const size_t sp = n >= ((size_t)1 << 18) ? 2 : 1;     // signatures per lane in prep (shared inversion)
     const size_t plan = (n + sp - 1) / sp;
     // Which kernels walk the scalar multiplication (256-bit curve; g_verify_path: 0 by size, 1 always the 32-bit
-    // kernels, 2 the 29-bit main kernel, 3 the quad kernel -- tests and A/B):
-    //   <= 2^15 signatures: one signature per quad, 29-bit limbs (prep + main in one kernel, no table inversion)
+    // kernels, 2 the 29-bit main kernel, 3 the quad / pair kernel, + 16 x lanes to force quads (0x43) or pairs (0x23)
+    // -- tests and A/B):
+    //   <= 2^14 signatures: one signature per quad, 29-bit limbs (prep + main in one kernel, no table inversion)
+    //   <= 2^15           : one signature per pair of lanes, same kernel
     //   <= 2^16           : one lane per signature, 29-bit limbs (at most one wavefront per SIMD: instruction count)
     //   above             : one lane per signature, 32-bit limbs (the throughput form)
     int path = 1;
     if constexpr (N == 8) {
         path = g_verify_path ? g_verify_path : n <= ((size_t)1 << 15) ? 3 : n <= ((size_t)1 << 16) ? 2 : 1;
         if (path == 3) {
-            if (n <= ((size_t)1 << 13))
-                hipLaunchKernelGGL(bign_quad29_kernel<64>, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, st,
-                                   (const uint8_t *)d_hashes, (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S,
-                                   (const uint4 *)gtab);
-            else
-                hipLaunchKernelGGL(bign_quad29_kernel<256>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st,
-                                   (const uint8_t *)d_hashes, (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S,
-                                   (const uint4 *)gtab);
+            const auto launch = [&](auto kern, unsigned wg, unsigned lanes) -> err_t {
+                const unsigned ns = wg / lanes;
+                const size_t lds = (size_t)8 * 4 * 9 * ns * 4;
+                if (lds > 48 * 1024)
+                    B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3((unsigned)((n + ns - 1) / ns)), dim3(wg), lds, st, (const uint8_t *)d_hashes,
+                                   (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S, (const uint4 *)gtab);
+                return ERR_OK;
+            };
+            const int lanes = g_verify_lanes ? g_verify_lanes : n <= ((size_t)1 << 14) ? 4 : 2;
+            if (lanes == 2) code = launch(bign_quad29_kernel<256, 2>, 256, 2);
+            else if (n <= ((size_t)1 << 13)) code = launch(bign_quad29_kernel<64, 4>, 64, 4);
+            else code = launch(bign_quad29_kernel<256, 4>, 256, 4);
+            if (code != ERR_OK) return code;
         }
     }
     if (path != 3) {

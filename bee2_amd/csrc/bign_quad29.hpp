@@ -16,17 +16,32 @@
 
 namespace bee2hip {
 
-// a from lane K of the quad.  Written as asm on purpose: with __builtin_amdgcn_mov_dpp LLVM folds the broadcast into
-// the consuming v_sub_u32 (v_subrev_u32_dpp ... quad_perm) and the differences of two broadcasts then came out wrong
-// on gfx950 (tools/ubench/quad29_check.hip: alpha = bcast<2> - bcast<3> returned bcast<2> - bcast<0>); explicit
-// v_mov_b32_dpp instructions are exact.
+// a from lane K of the quad.  ONE asm block per field element, on purpose:
+//  * with __builtin_amdgcn_mov_dpp LLVM folds the broadcast into the consuming v_sub_u32 (v_subrev_u32_dpp ... quad_perm)
+//    and the differences of two broadcasts came out wrong on gfx950 (tools/ubench/quad29_check.hip);
+//  * with one asm statement per limb the scheduler is free to place the VALU instruction that produces limb i right
+//    in front of the v_mov_b32_dpp that reads it, and the hazard "VALU writes a VGPR -> DPP reads it within two
+//    instructions" is nobody's job inside inline asm (LLVM's hazard recogniser does not look into it): results then
+//    depended on the schedule (the same source was right in the kernel and wrong in the micro-benchmark).
+// A block of nine moves behind one `s_nop 1` cannot be split, and its outputs are early-clobber because the inputs
+// are still being read while the first outputs are written.
+#define Q29_DPP9(CTRL)                                                                                                   \
+    asm volatile("s_nop 1\n\t"                                                                                           \
+                 "v_mov_b32_dpp %0, %9 " CTRL "\n\tv_mov_b32_dpp %1, %10 " CTRL "\n\tv_mov_b32_dpp %2, %11 " CTRL "\n\t"   \
+                 "v_mov_b32_dpp %3, %12 " CTRL "\n\tv_mov_b32_dpp %4, %13 " CTRL "\n\tv_mov_b32_dpp %5, %14 " CTRL "\n\t" \
+                 "v_mov_b32_dpp %6, %15 " CTRL "\n\tv_mov_b32_dpp %7, %16 " CTRL "\n\tv_mov_b32_dpp %8, %17 " CTRL         \
+                 : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]),  \
+                   "=&v"(r.l[7]), "=&v"(r.l[8])                                                                            \
+                 : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),  \
+                   "v"(a.l[8]))
 template <int K>
 __device__ __forceinline__ void q29_bcast(fe29 &r, const fe29 &a)
 {
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-        asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[%2,%2,%2,%2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-                     : "=v"(r.l[i]) : "v"(a.l[i]), "n"(K));
+    static_assert(K >= 0 && K < 4, "lane of the quad");
+    if constexpr (K == 0) Q29_DPP9("quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    else if constexpr (K == 1) Q29_DPP9("quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    else if constexpr (K == 2) Q29_DPP9("quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    else Q29_DPP9("quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1");
 }
 __device__ __forceinline__ void q29_pick(fe29 &r, bool p, const fe29 &a, const fe29 &b)
 {
@@ -161,6 +176,99 @@ __device__ __forceinline__ void quad29_add(qjac29 &T, const qent29 &E, uint32_t 
     q29_bcast<1>(V, r);
     q29_bcast<2>(T.D, r);                           // D3
     f29_sub(T.Y, t, V);                             // Y3
+}
+
+// ------------------------------------------------------------------ two lanes per signature ---
+// Between 2^14 and 2^15 signatures quads would already share SIMDs (two wavefronts each); a PAIR of lanes per
+// signature keeps one wavefront per SIMD there.  Same formulas and bounds, two multiplications per level: a doubling
+// is five levels (two of them pure squarings), a general addition eight.
+template <int K>
+__device__ __forceinline__ void p29_bcast(fe29 &r, const fe29 &a)      // a from lane K of the pair
+{
+    static_assert(K == 0 || K == 1, "lane of the pair");
+    if constexpr (K == 0) Q29_DPP9("quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    else Q29_DPP9("quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1");
+}
+
+//   1: Y^2 | 2 Y Z      2: 3 X^2 | 3 D^2      3: 4 X g | 8 X g      4: alpha^2 | Z3^2      5: alpha (4 X g - X3) | 8 g^2
+__device__ __forceinline__ void pair29_dbl(qjac29 &T, uint32_t p)
+{
+    const bool p0 = p == 0;
+    fe29 a, b, r, gamma, alpha, b4, t;
+    q29_pick(b, p0, T.Y, T.Z);
+    f29_mul_k(r, T.Y, b, p0 ? 1 : 2);
+    p29_bcast<0>(gamma, r);
+    q29_pick(a, p0, T.X, T.D);
+    p29_bcast<1>(T.Z, r);                           // Z3 = 2 Y Z (after T.Z was read)
+    f29_sqr<3>(r, a);
+    p29_bcast<0>(alpha, r);
+    p29_bcast<1>(t, r);
+    f29_sub(alpha, alpha, t);                       // 3 X^2 - 3 Z^4
+    f29_mul_k(r, T.X, gamma, p0 ? 4 : 8);
+    p29_bcast<0>(b4, r);
+    p29_bcast<1>(t, r);                             // 8 X g
+    q29_pick(a, p0, alpha, T.Z);
+    f29_sqr(r, a);
+    p29_bcast<0>(T.X, r);
+    p29_bcast<1>(T.D, r);                           // D3 = Z3^2
+    f29_sub(T.X, T.X, t);                           // X3
+    f29_sub(t, b4, T.X);                            // [-1, 2]
+    q29_pick(a, p0, alpha, gamma);
+    q29_pick(b, p0, t, gamma);
+    f29_mul_k(r, a, b, p0 ? 1 : 8);
+    p29_bcast<0>(T.Y, r);
+    p29_bcast<1>(t, r);
+    f29_sub(T.Y, T.Y, t);                           // Y3
+}
+
+//   1: X1 ZZ2 | X2 D      2: Z1 D | Y1 ZZ2      3: Y2 Z1^3 | (Y1 ZZ2) Z2      4: H^2 | Z1 Z2
+//   5: H H^2 | U1 H^2     6: r^2 | (Z1 Z2) H    7: r (V - X3) | S1 H^3        8: Z3^2 (both lanes)
+__device__ __forceinline__ void pair29_add(qjac29 &T, const qent29 &E, uint32_t p)
+{
+    const bool p0 = p == 0;
+    fe29 a, b, r, U1, S1, H, HH, rr, V, t, w;
+    q29_pick(a, p0, T.X, E.X);
+    q29_pick(b, p0, E.ZZ, T.D);
+    f29_mul(r, a, b);
+    p29_bcast<0>(U1, r);
+    p29_bcast<1>(H, r);
+    f29_sub(H, H, U1);                              // U2 - U1
+    q29_pick(a, p0, T.Z, T.Y);
+    q29_pick(b, p0, T.D, E.ZZ);
+    f29_mul(r, a, b);                               // Z1^3 | Y1 ZZ2
+    q29_pick(a, p0, E.Y, r);
+    p29_bcast<0>(t, r);
+    q29_pick(b, p0, t, E.Z);
+    f29_mul(r, a, b);
+    p29_bcast<0>(rr, r);
+    p29_bcast<1>(S1, r);
+    f29_sub(rr, rr, S1);                            // r = S2 - S1
+    q29_pick(a, p0, H, T.Z);
+    q29_pick(b, p0, H, E.Z);
+    f29_mul(r, a, b);
+    p29_bcast<0>(HH, r);
+    p29_bcast<1>(w, r);                             // Z1 Z2
+    q29_pick(a, p0, H, U1);
+    f29_mul(r, a, HH);
+    p29_bcast<0>(t, r);                             // H^3
+    p29_bcast<1>(V, r);
+    q29_pick(a, p0, rr, w);
+    q29_pick(b, p0, rr, H);
+    f29_mul(r, a, b);
+    p29_bcast<1>(T.Z, r);                           // Z3
+    p29_bcast<0>(a, r);                             // r^2
+    f29_sub(a, a, t);
+    f29_sub(a, a, V);
+    f29_sub(T.X, a, V);
+    f29_carry(T.X);                                 // X3, N
+    f29_sub(b, V, T.X);
+    q29_pick(a, p0, rr, S1);
+    q29_pick(b, p0, b, t);
+    f29_mul(r, a, b);
+    p29_bcast<0>(a, r);
+    p29_bcast<1>(b, r);
+    f29_sub(T.Y, a, b);                             // Y3
+    f29_sqr(T.D, T.Z);                              // D3, the same in both lanes
 }
 
 }  // namespace bee2hip

@@ -338,6 +338,27 @@ def main():
                          "note": "power / VALU-issue bound in practice: the chip sustains 1.7-1.9 GHz under this kernel, see `valu` (DESIGN.md 2, 4.1)",
                          "valu": valu_picture(n / (ms_launch * 1e-3), BASHF_VALU)},
         }
+        # the shader clock the chip sustained: one wavefront on a side stream spins beside 40 more launches (outside the
+        # timed region) and reads s_memtime against the 100 MHz s_memrealtime.  A box that clocks down (power: ~1.9 GHz
+        # under this kernel is normal; one box of the pool ran everything at half speed) shows up here.
+        try:
+            side = torch.cuda.Stream()
+            probe = torch.zeros(2, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            eng.lib.bee2hip_internal_clock_probe(ctypes.c_void_p(probe.data_ptr()), ctypes.c_uint(int(ms_launch * 1e3 * 40 * 0.8)),
+                                                 ctypes.c_void_p(side.cuda_stream))
+            for _ in range(40):
+                eng.bashF_batch_dev(st)
+            torch.cuda.synchronize()
+            c = probe.cpu().numpy()
+            result["roofline"]["shader_clock_ghz_under_kernel"] = float(c[0]) / (float(c[1]) * 10.0)
+            eng.lib.bee2hip_internal_clock_probe(ctypes.c_void_p(probe.data_ptr()), ctypes.c_uint(2000), ctypes.c_void_p(side.cuda_stream))
+            torch.cuda.synchronize()
+            c = probe.cpu().numpy()
+            result["roofline"]["shader_clock_ghz_idle"] = float(c[0]) / (float(c[1]) * 10.0)
+        except Exception as e:                                    # the probe is a diagnostic, never a reason to fail the bench
+            result["roofline"]["shader_clock_ghz_under_kernel"] = None
+            result["roofline"]["shader_clock_note"] = repr(e)
         if dist.rank == 0 and N == 1:       # PCIe-inclusive rate: single-GPU runs only
             host = st.cpu().numpy()                               # pageable host copy of the same batch
             hp = ctypes.c_void_p(host.ctypes.data)

@@ -107,10 +107,11 @@ def test_point_ops_29bit_limbs_match_the_32bit_ones(golden):
     assert _fe_run(eng, 30, X, Y) == [add(*dbl(x, y), x, y)[0] for x, y in pts]
 
 
-@pytest.mark.parametrize("path", [1, 2, 3])
+@pytest.mark.parametrize("path", [1, 2, 3, 0x43, 0x23])
 def test_bign_both_main_kernels_on_edge_and_base_sets(golden, path):
     """The batch size picks the main kernel (29-bit limbs up to 2^16 signatures, 32-bit above); here each is FORCED
-    (bee2hip_internal_tune(2, path): 1 = 32-bit limbs, 2 = 29-bit limbs, 3 = one signature per quad) over the 433 edge cases (exceptional group-law cases
+    (bee2hip_internal_tune(2, path): 1 = 32-bit limbs, 2 = 29-bit limbs, 3 = one signature per quad or pair of lanes
+    by size, 0x43 = quads, 0x23 = pairs) over the 433 edge cases (exceptional group-law cases
     included: they must reach the slow path from either kernel), the valid base set, and a 70 000-signature tiling
     with every 7th signature corrupted -- a size the 29-bit kernel never sees unforced."""
     eng = engine()

@@ -165,6 +165,39 @@ __global__ __launch_bounds__(64) void quad29_kernel(int digits, uint32_t *out, u
     out[idx * 17 + 16] = 1;
 }
 
+// two lanes per point on the 29-bit limbs
+__global__ __launch_bounds__(64) void pair29_kernel(int digits, uint32_t *out, uint64_t *cycles, uint32_t zero)
+{
+    const uint32_t q = threadIdx.x & 1u;
+    feT<8> gx, gy;
+    fe_set_zero(gx);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gy.v[i] = c_yG[i];
+    gx.v[0] = out[(size_t)blockIdx.x * 64 * 17 + threadIdx.x] & zero;
+    qent29 E;
+    f29_from_words(E.X, gx);
+    f29_from_words(E.Y, gy);
+    for (int i = 0; i < 9; ++i) E.Z.l[i] = E.ZZ.l[i] = i == 0;
+    qjac29 T;
+    T.X = E.X; T.Y = E.Y; T.Z = E.Z; T.D = E.Z;
+    pair29_dbl(T, q);
+    const uint64_t t0 = now();
+#pragma unroll 1
+    for (int d = 0; d < digits; ++d) {
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) pair29_dbl(T, q);
+        pair29_add(T, E, q);
+    }
+    const uint64_t t1 = now();
+    const size_t idx = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+    feT<8> X, Z;
+    f29_to_words(X, T.X); f29_to_words(Z, T.Z);
+    fe_canon(X, X); fe_canon(Z, Z);
+    for (int i = 0; i < 8; ++i) { out[idx * 17 + i] = X.v[i]; out[idx * 17 + 8 + i] = Z.v[i]; }
+    out[idx * 17 + 16] = 1;
+}
+
 __global__ __launch_bounds__(64) void quad_kernel(int digits, uint32_t *out, uint64_t *cycles, uint32_t zero)
 {
     const uint32_t q = threadIdx.x & 3u;
@@ -211,13 +244,13 @@ int main(int argc, char **argv)
     const int digits = argc > 1 ? atoi(argv[1]) : 32;
     for (int blocks : {256, 1024, 2048, 4096}) {
         const size_t n = (size_t)blocks * 64;
-        uint32_t *oa, *ob, *oc, *od, *bad;
+        uint32_t *oa, *ob, *oc, *od, *oe, *bad;
         uint64_t *ca, *cb;
-        hipMalloc(&oa, n * 17 * 4); hipMalloc(&ob, n * 17 * 4); hipMalloc(&oc, n * 17 * 4); hipMalloc(&od, n * 17 * 4); hipMalloc(&bad, 4);
+        hipMalloc(&oa, n * 17 * 4); hipMalloc(&ob, n * 17 * 4); hipMalloc(&oc, n * 17 * 4); hipMalloc(&od, n * 17 * 4); hipMalloc(&oe, n * 17 * 4); hipMalloc(&bad, 4);
         hipMalloc(&ca, blocks * 8); hipMalloc(&cb, blocks * 8);
         hipMemset(bad, 0, 4);
-        hipEvent_t e0, e1, e2, e3, e4;
-        hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2); hipEventCreate(&e3); hipEventCreate(&e4);
+        hipEvent_t e0, e1, e2, e3, e4, e5;
+        hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2); hipEventCreate(&e3); hipEventCreate(&e4); hipEventCreate(&e5);
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
             hipLaunchKernelGGL(serial_kernel, dim3(blocks), dim3(64), 0, 0, digits, oa, ca, 0u);
@@ -228,13 +261,16 @@ int main(int argc, char **argv)
             hipEventRecord(e3);
             hipLaunchKernelGGL(quad29_kernel, dim3(blocks), dim3(64), 0, 0, digits, od, cb, 0u);
             hipEventRecord(e4);
+            hipLaunchKernelGGL(pair29_kernel, dim3(blocks), dim3(64), 0, 0, digits, oe, cb, 0u);
+            hipEventRecord(e5);
             hipDeviceSynchronize();
         }
-        float ms_s, ms_q, ms_29, ms_29c;
-        hipEventElapsedTime(&ms_s, e0, e1); hipEventElapsedTime(&ms_q, e1, e2); hipEventElapsedTime(&ms_29, e2, e3); hipEventElapsedTime(&ms_29c, e3, e4);
+        float ms_s, ms_q, ms_29, ms_29c, ms_p;
+        hipEventElapsedTime(&ms_s, e0, e1); hipEventElapsedTime(&ms_q, e1, e2); hipEventElapsedTime(&ms_29, e2, e3); hipEventElapsedTime(&ms_29c, e3, e4); hipEventElapsedTime(&ms_p, e4, e5);
         hipLaunchKernelGGL(compare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, oa, ob, n, bad);
         hipLaunchKernelGGL(compare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, oa, oc, n, bad);
         hipLaunchKernelGGL(compare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, oa, od, n, bad);
+        hipLaunchKernelGGL(compare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, oa, oe, n, bad);
         uint32_t hbad = 0;
         hipMemcpy(&hbad, bad, 4, hipMemcpyDeviceToHost);
         std::vector<uint64_t> ha(blocks), hb(blocks);
@@ -243,8 +279,8 @@ int main(int argc, char **argv)
         double sa = 0, sb = 0;
         for (int i = 0; i < blocks; ++i) { sa += ha[i]; sb += hb[i]; }
         // s_memtime counts at 100 MHz on gfx950: report the kernel times as well
-        printf("%5d wavefronts (%.2f per SIMD): serial %.1f us, quad %.1f us (x%.2f), serial 29-bit limbs %.1f us (x%.2f), quad 29-bit limbs %.1f us (x%.2f); mismatches %u of %zu\n",
-               blocks, blocks / 1024.0, ms_s * 1e3, ms_q * 1e3, ms_s / ms_q, ms_29 * 1e3, ms_s / ms_29, ms_29c * 1e3, ms_s / ms_29c, hbad, 3 * n);
+        printf("%5d wavefronts (%.2f per SIMD): serial %.1f us, quad %.1f us (x%.2f), serial 29-bit limbs %.1f us (x%.2f), quad 29-bit limbs %.1f us (x%.2f), pair 29-bit limbs %.1f us (x%.2f); mismatches %u of %zu\n",
+               blocks, blocks / 1024.0, ms_s * 1e3, ms_q * 1e3, ms_s / ms_q, ms_29 * 1e3, ms_s / ms_29, ms_29c * 1e3, ms_s / ms_29c, ms_p * 1e3, ms_s / ms_p, hbad, 4 * n);
         hipFree(oa); hipFree(ob); hipFree(bad); hipFree(ca); hipFree(cb);
     }
     return 0;
