@@ -143,30 +143,89 @@ err_t scratch_for_stream(hipStream_t st, int slot, size_t bytes, void **out)
 }
 
 // scratch device buffer for the host-pointer API, grown on demand, per thread
+// Staging for the host-pointer entry points, per thread and slot.  Small requests (<= 64 KiB: every drop-in call on a
+// block, a state, a signature ...) are served from a PINNED, device-mapped host buffer: the caller's bytes are copied
+// into it by the CPU, the kernels read and write it across PCIe, and the result is copied out after one stream
+// synchronise -- no hipMemcpy at all (a hipMemcpy of a few bytes costs ~10 us each way; bashF() went from 33 to
+// ~15 us per call).  Larger requests use device memory and hipMemcpy as before.  h2d() / d2h() below pick the path
+// from the pointer.
+constexpr size_t PINNED_MAX = 64 * 1024;      // size of the pinned buffer
+static size_t g_pinned_limit = PINNED_MAX;     // requests up to this size use it (bee2hip_internal_tune(3, bytes): A/B)
 struct Scratch {
-    void *p = nullptr;
-    size_t cap = 0;
+    void *p = nullptr;          // what the current request uses: pin or devp
+    void *pin = nullptr;        // PINNED_MAX bytes of mapped host memory, allocated on first small request
+    void *devp = nullptr;
+    size_t cap = 0;             // of devp
     int dev = -1;
-    err_t need(size_t n)
+    // `chain` = the kernel walks the input as one dependent chain on a lane or two (sponge absorption, the belt-hash
+    // iteration): there every load is a PCIe round trip on the critical path, and pinned staging only pays below ~2 KiB
+    // (tools/pinned_ab.py: belt-hash of 16 KiB 2.49 ms pinned vs 2.23 ms copied; of 1 KiB 186 vs 200 us)
+    err_t need(size_t n, bool chain = false)
     {
         int cur = 0;
         B2H_TRY(hipGetDevice(&cur));
-        if (p && (cur != dev || cap < n)) { (void)hipFree(p); p = nullptr; cap = 0; }
-        if (!p) {
-            size_t want = n < 4096 ? 4096 : n;
-            if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return out_of_memory(); }
-            cap = want; dev = cur;
+        if (n <= (chain && g_pinned_limit > 2048 ? (size_t)2048 : g_pinned_limit)) {
+            if (!pin && hipHostMalloc(&pin, PINNED_MAX, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+                pin = nullptr;
+                return out_of_memory();
+            }
+            p = pin;
+            return ERR_OK;
         }
+        if (devp && (cur != dev || cap < n)) { (void)hipFree(devp); devp = nullptr; cap = 0; }
+        if (!devp) {
+            if (hipMalloc(&devp, n) != hipSuccess) { devp = nullptr; return out_of_memory(); }
+            cap = n; dev = cur;
+        }
+        p = devp;
         return ERR_OK;
     }
     ~Scratch()
     {
-        // thread exit: give the block back, except on the loader thread (process teardown, see ThreadReaper)
-        if (p && !on_loader_thread()) (void)hipFree(p);
-        p = nullptr;
+        // thread exit: give the blocks back, except on the loader thread (process teardown, see ThreadReaper)
+        if (!on_loader_thread()) {
+            if (devp) (void)hipFree(devp);
+            if (pin) (void)hipHostFree(pin);
+        }
+        p = devp = pin = nullptr;
     }
 };
 static thread_local Scratch t_scr[4];
+
+static inline bool in_pinned(const void *q)
+{
+    for (const Scratch &sc : t_scr)
+        if (sc.pin && (const char *)q >= (const char *)sc.pin && (const char *)q < (const char *)sc.pin + PINNED_MAX) return true;
+    return false;
+}
+// host -> staging.  Pinned: the NULL stream is idle here (every host entry point ends with d2h or a synchronise), and
+// a kernel launched afterwards sees what the CPU wrote.
+static inline hipError_t h2d(void *d, const void *h, size_t n)
+{
+    if (in_pinned(d)) { memcpy(d, h, n); return hipSuccess; }
+    return hipMemcpy(d, h, n, hipMemcpyHostToDevice);
+}
+// staging -> host, after everything queued on the NULL stream
+static inline hipError_t d2h(void *h, const void *d, size_t n)
+{
+    if (in_pinned(d)) {
+        const hipError_t e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) return e;
+        memcpy(h, d, n);
+        return hipSuccess;
+    }
+    return hipMemcpy(h, d, n, hipMemcpyDeviceToHost);
+}
+static inline hipError_t zero_staging(void *d, size_t n)
+{
+    if (in_pinned(d)) {
+        const hipError_t e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) return e;
+        memset(d, 0, n);
+        return hipSuccess;
+    }
+    return hipMemset(d, 0, n);
+}
 
 }  // namespace bee2hip
 
@@ -225,10 +284,10 @@ extern "C" err_t bee2hip_bashF_batch(octet *states, size_t n)
     Scratch &s = t_scr[0];
     err_t code = s.need(n * 192);
     if (code != ERR_OK) return code;
-    B2H_TRY(hipMemcpy(s.p, states, n * 192, hipMemcpyHostToDevice));
+    B2H_TRY(h2d(s.p, states, n * 192));
     code = launch_bashF_batch(s.p, n, nullptr);
     if (code != ERR_OK) return code;
-    B2H_TRY(hipMemcpy(states, s.p, n * 192, hipMemcpyDeviceToHost));
+    B2H_TRY(d2h(states, s.p, n * 192));
     return ERR_OK;
 }
 
@@ -240,10 +299,10 @@ static err_t encr_host_blocks(uint32_t *blocks, size_t n, const u32 key[8])
     Scratch &s = t_scr[1];
     code = s.need(n * 16);
     if (code != ERR_OK) return code;
-    B2H_TRY(hipMemcpy(s.p, blocks, n * 16, hipMemcpyHostToDevice));
+    B2H_TRY(h2d(s.p, blocks, n * 16));
     code = launch_belt_encr_blocks(s.p, n, key, nullptr);
     if (code != ERR_OK) return code;
-    B2H_TRY(hipMemcpy(blocks, s.p, n * 16, hipMemcpyDeviceToHost));
+    B2H_TRY(d2h(blocks, s.p, n * 16));
     return ERR_OK;
 }
 
@@ -359,13 +418,13 @@ extern "C" err_t bee2hip_beltCTR_bulk(void *buf_, size_t count, void *ctr_state)
     code = s.need(nblk * 16 + 16);
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
-    if (tail) B2H_TRY(hipMemset(d + full * 16, 0, 16));
-    B2H_TRY(hipMemcpy(d, buf, count, hipMemcpyHostToDevice));
+    if (tail) B2H_TRY(zero_staging(d + full * 16, 16));
+    B2H_TRY(h2d(d, buf, count));
     // first_block = 0: the offset is relative to the state's *current* counter
     code = launch_belt_ctr_blocks(d, nblk, st->key, st->ctr, 0, d + nblk * 16, nullptr);
     if (code != ERR_OK) return code;
-    B2H_TRY(hipMemcpy(buf, d, count, hipMemcpyDeviceToHost));
-    B2H_TRY(hipMemcpy(st->block, d + nblk * 16, 16, hipMemcpyDeviceToHost));
+    B2H_TRY(d2h(buf, d, count));
+    B2H_TRY(d2h(st->block, d + nblk * 16, 16));
     ctr_add(st->ctr, nblk);                        // what nblk beltBlockIncU32 calls leave
     st->reserved = tail ? 16 - tail : 0;
     return ERR_OK;
@@ -537,12 +596,12 @@ extern "C" err_t bee2hip_bignVerify_batch(const bign_params *params, const octet
     code = s.need(co + n * 4);
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
-    B2H_TRY(hipMemcpy(d, hashes, hb, hipMemcpyHostToDevice));
-    B2H_TRY(hipMemcpy(d + so, sigs, sb, hipMemcpyHostToDevice));
-    B2H_TRY(hipMemcpy(d + po, pubkeys, pb, hipMemcpyHostToDevice));
+    B2H_TRY(h2d(d, hashes, hb));
+    B2H_TRY(h2d(d + so, sigs, sb));
+    B2H_TRY(h2d(d + po, pubkeys, pb));
     code = launch_bign_verify(params->l, oid_der, oid_len, d, d + so, d + po, n, d + co, nullptr);
     if (code != ERR_OK) return code;
-    B2H_TRY(hipMemcpy(codes, d + co, 4 * n, hipMemcpyDeviceToHost));
+    B2H_TRY(d2h(codes, d + co, 4 * n));
     return ERR_OK;
 }
 
@@ -604,10 +663,10 @@ extern "C" err_t bee2hip_bignPubkeyVal_batch(const bign_params *params, const oc
     code = s.need(co + n * 4);
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
-    B2H_TRY(hipMemcpy(d, pubkeys, pb, hipMemcpyHostToDevice));
+    B2H_TRY(h2d(d, pubkeys, pb));
     code = launch_bign_pubkey_val(params->l, d, n, d + co, nullptr);
     if (code != ERR_OK) return code;
-    B2H_TRY(hipMemcpy(codes, d + co, 4 * n, hipMemcpyDeviceToHost));
+    B2H_TRY(d2h(codes, d + co, 4 * n));
     return ERR_OK;
 }
 
@@ -633,7 +692,7 @@ extern "C" err_t bign256PubkeyVal(const octet pubkey[128]) { return level_pubkey
 
 // ---- 8f-4 tail: public key from private key, key generation, signing (bign_misc.c:182-229,373-417,
 // bign_sign.c:32-245).  Secrets cross the staging buffer t_scr[3]; it is overwritten with zeros before return.
-static void wipe_dev(void *p, size_t n) { if (p && n) (void)hipMemset(p, 0, n); }
+static void wipe_dev(void *p, size_t n) { if (p && n) (void)zero_staging(p, n); }
 
 extern "C" err_t bee2hip_bignPubkeyCalcL_batch_dev(size_t l, const void *d_privkeys, size_t n, void *d_pubkeys,
                                                    void *d_codes, void *stream)
@@ -687,13 +746,13 @@ extern "C" err_t bee2hip_bignPubkeyCalc_batch(const bign_params *params, const o
     code = s.need(co + 4 * n);
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
-    B2H_TRY(hipMemcpy(d, privkeys, db, hipMemcpyHostToDevice));
+    B2H_TRY(h2d(d, privkeys, db));
     code = launch_bign_pubkey_calc(params->l, false, d, n, d + po, d + co, nullptr);
     if (code == ERR_OK) {
-        hipError_t e = hipMemcpy(codes, d + co, 4 * n, hipMemcpyDeviceToHost);
+        hipError_t e = d2h(codes, d + co, 4 * n);
         // bee2 leaves the output alone when it fails: copy the keys of the good items only
         std::vector<octet> tmp(2 * no * n);
-        if (e == hipSuccess) e = hipMemcpy(tmp.data(), d + po, 2 * no * n, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = d2h(tmp.data(), d + po, 2 * no * n);
         if (e != hipSuccess) code = hip_fail(e, "bignPubkeyCalc copy");
         else for (size_t i = 0; i < n; ++i) if (codes[i] == ERR_OK) memcpy(pubkeys + 2 * no * i, tmp.data() + 2 * no * i, 2 * no);
     }
@@ -741,15 +800,15 @@ static err_t sign_batch_host(int mode, const bign_params *params, const octet oi
     code = s.need(o_c + 4 * n);
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
-    B2H_TRY(hipMemcpy(d, hashes, hb, hipMemcpyHostToDevice));
-    B2H_TRY(hipMemcpy(d + o_d, privkeys, hb, hipMemcpyHostToDevice));
-    if (ab) B2H_TRY(hipMemcpy(d + o_a, aux, ab, hipMemcpyHostToDevice));
+    B2H_TRY(h2d(d, hashes, hb));
+    B2H_TRY(h2d(d + o_d, privkeys, hb));
+    if (ab) B2H_TRY(h2d(d + o_a, aux, ab));
     code = launch_bign_sign(params->l, dev_mode, oid_der, oid_len, d, d + o_d, ab ? d + o_a : nullptr, t_len, 1, n, d + o_s, d + o_c,
                             nullptr);
     if (code == ERR_OK) {
-        hipError_t e = hipMemcpy(codes, d + o_c, 4 * n, hipMemcpyDeviceToHost);
+        hipError_t e = d2h(codes, d + o_c, 4 * n);
         std::vector<octet> tmp(sg * n);
-        if (e == hipSuccess) e = hipMemcpy(tmp.data(), d + o_s, sg * n, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = d2h(tmp.data(), d + o_s, sg * n);
         if (e != hipSuccess) code = hip_fail(e, "bignSign copy");
         else for (size_t i = 0; i < n; ++i) if (codes[i] == ERR_OK) memcpy(sigs + sg * i, tmp.data() + sg * i, sg);
     }
@@ -811,13 +870,13 @@ extern "C" err_t bignKeypairGen(octet privkey[], octet pubkey[], const bign_para
         code = s.need(64 + 128 + 16);
         if (code == ERR_OK) {
             octet *dd = (octet *)s.p;
-            hipError_t e = hipMemcpy(dd, d, no, hipMemcpyHostToDevice);
+            hipError_t e = h2d(dd, d, no);
             if (e == hipSuccess) {
                 code = launch_bign_pubkey_calc(params->l, true, dd, 1, dd + 64, dd + 192, nullptr);
                 octet q[128];
                 err_t one = ERR_BAD_PARAMS;
-                if (code == ERR_OK) e = hipMemcpy(q, dd + 64, 2 * no, hipMemcpyDeviceToHost);
-                if (code == ERR_OK && e == hipSuccess) e = hipMemcpy(&one, dd + 192, 4, hipMemcpyDeviceToHost);
+                if (code == ERR_OK) e = d2h(q, dd + 64, 2 * no);
+                if (code == ERR_OK && e == hipSuccess) e = d2h(&one, dd + 192, 4);
                 if (code == ERR_OK && e == hipSuccess) {
                     code = one;                                  // ERR_BAD_PARAMS when d G = O (bign_misc.c:214-218)
                     if (one == ERR_OK) { memcpy(privkey, d, no); memcpy(pubkey, q, 2 * no); }
@@ -906,11 +965,11 @@ extern "C" void bashHashStart(void *state, size_t l)
 static err_t sponge_host(bash_hash_st *st, const octet *buf, size_t count)
 {
     Scratch &s = t_scr[0];
-    err_t code = s.need(sizeof(bash_hash_st) + count + 16);
+    err_t code = s.need(sizeof(bash_hash_st) + count + 16, true);
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
-    B2H_TRY(hipMemcpy(d, st, sizeof *st, hipMemcpyHostToDevice));
-    B2H_TRY(hipMemcpy(d + sizeof *st, buf, count, hipMemcpyHostToDevice));
+    B2H_TRY(h2d(d, st, sizeof *st));
+    B2H_TRY(h2d(d + sizeof *st, buf, count));
     const octet *dd = d + sizeof *st;
     // large chunk: byte-wise up to the next block boundary, whole rate blocks with 8 lanes (a 3x shorter chain,
     // DESIGN.md 4.7), the remainder byte-wise again
@@ -925,7 +984,7 @@ static err_t sponge_host(bash_hash_st *st, const octet *buf, size_t count)
         code = launch_bash_sponge(d, dd, 0, count, 1, 0, nullptr);
         if (code != ERR_OK) return code;
     }
-    B2H_TRY(hipMemcpy(st, d, sizeof *st, hipMemcpyDeviceToHost));
+    B2H_TRY(d2h(st, d, sizeof *st));
     return ERR_OK;
 }
 
@@ -989,11 +1048,11 @@ static err_t mac_host(belt_mac_st *st, const octet *buf, size_t count, int mode)
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
     const size_t off = (sizeof(belt_mac_st) + 15) & ~(size_t)15;
-    B2H_TRY(hipMemcpy(d, st, sizeof *st, hipMemcpyHostToDevice));
-    if (count) B2H_TRY(hipMemcpy(d + off, buf, count, hipMemcpyHostToDevice));
+    B2H_TRY(h2d(d, st, sizeof *st));
+    if (count) B2H_TRY(h2d(d + off, buf, count));
     code = launch_belt_mac(d, d + off, 0, count, 1, mode, nullptr);
     if (code != ERR_OK) return code;
-    B2H_TRY(hipMemcpy(st, d, sizeof *st, hipMemcpyDeviceToHost));
+    B2H_TRY(d2h(st, d, sizeof *st));
     return ERR_OK;
 }
 
@@ -1079,12 +1138,12 @@ extern "C" err_t bee2hip_bashHash_beltMAC_batch(const octet *msgs, size_t msg_le
     err_t code = s.need(in_b + dg_b + n * 8 + 16);
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
-    if (n * msg_len) B2H_TRY(hipMemcpy(d, msgs, n * msg_len, hipMemcpyHostToDevice));
+    if (n * msg_len) B2H_TRY(h2d(d, msgs, n * msg_len));
     code = bee2hip_bashHash_beltMAC_batch_dev(d, msg_len, n, l, key, key_len, digests ? d + in_b : nullptr,
                                               tags ? d + in_b + dg_b : nullptr, nullptr);
     if (code != ERR_OK) return code;
-    if (digests) B2H_TRY(hipMemcpy(digests, d + in_b, n * dlen, hipMemcpyDeviceToHost));
-    if (tags) B2H_TRY(hipMemcpy(tags, d + in_b + dg_b, n * 8, hipMemcpyDeviceToHost));
+    if (digests) B2H_TRY(d2h(digests, d + in_b, n * dlen));
+    if (tags) B2H_TRY(d2h(tags, d + in_b + dg_b, n * 8));
     return ERR_OK;
 }
 
@@ -1097,6 +1156,7 @@ extern "C" err_t bee2hip_internal_tune(int key, int value)
     case 0: bee2hip::set_bashF_variant(value); return ERR_OK;
     case 1: bee2hip::set_ctr_variant(value); return ERR_OK;
     case 2: bee2hip::set_verify_path(value); return ERR_OK;
+    case 3: bee2hip::g_pinned_limit = value < 0 ? 0 : (size_t)value > bee2hip::PINNED_MAX ? bee2hip::PINNED_MAX : (size_t)value; return ERR_OK;
     default: return ERR_BAD_INPUT;
     }
 }
@@ -1167,10 +1227,10 @@ static err_t decr_host_blocks(uint32_t *blocks, size_t n, const u32 key[8])
     Scratch &s = t_scr[1];
     code = s.need(n * 16);
     if (code != ERR_OK) return code;
-    B2H_TRY(hipMemcpy(s.p, blocks, n * 16, hipMemcpyHostToDevice));
+    B2H_TRY(h2d(s.p, blocks, n * 16));
     code = launch_belt_decr_blocks(s.p, n, key, nullptr);
     if (code != ERR_OK) return code;
-    B2H_TRY(hipMemcpy(blocks, s.p, n * 16, hipMemcpyDeviceToHost));
+    B2H_TRY(d2h(blocks, s.p, n * 16));
     return ERR_OK;
 }
 
@@ -1225,10 +1285,10 @@ static err_t modes_host(int mode, octet *buf, size_t nblocks, const u32 key[8], 
     octet *d = (octet *)s.p;
     u32 iv[4] = {0, 0, 0, 0};
     if (chain) for (int i = 0; i < 4; ++i) iv[i] = load32le(chain + 4 * i);
-    B2H_TRY(hipMemcpy(d, buf, bytes, hipMemcpyHostToDevice));
+    B2H_TRY(h2d(d, buf, bytes));
     code = launch_belt_modes(mode, d, d + bytes, nblocks, key, iv, nullptr);
     if (code != ERR_OK) return code;
-    B2H_TRY(hipMemcpy(buf, d + bytes, bytes, hipMemcpyDeviceToHost));
+    B2H_TRY(d2h(buf, d + bytes, bytes));
     return ERR_OK;
 }
 
@@ -1321,11 +1381,11 @@ static err_t dwp_absorb_host(u32 t_out[4], const u32 t[4], const u32 r[4], const
     code = sc.need(off + 16);
     if (code != ERR_OK) return code;
     octet *d = (octet *)sc.p;
-    if (nbytes) B2H_TRY(hipMemcpy(d, data, nbytes, hipMemcpyHostToDevice));
+    if (nbytes) B2H_TRY(h2d(d, data, nbytes));
     code = launch_belt_polyhash(d, nbytes, r, t, d + off, nullptr);
     if (code != ERR_OK) return code;
     octet out[16];
-    B2H_TRY(hipMemcpy(out, d + off, 16, hipMemcpyDeviceToHost));
+    B2H_TRY(d2h(out, d + off, 16));
     for (int i = 0; i < 4; ++i) t_out[i] = load32le(out + 4 * i);
     return ERR_OK;
 }
@@ -1438,14 +1498,14 @@ static err_t hash_stream_host(u32 hs[12], const octet *data, size_t nblocks, int
     if (code != ERR_OK) return code;
     Scratch &sc = t_scr[2];
     const size_t bytes = nblocks * 32;
-    code = sc.need(bytes + 64);
+    code = sc.need(bytes + 64, true);
     if (code != ERR_OK) return code;
     octet *d = (octet *)sc.p;
-    if (bytes) B2H_TRY(hipMemcpy(d, data, bytes, hipMemcpyHostToDevice));
-    B2H_TRY(hipMemcpy(d + bytes, hs, 48, hipMemcpyHostToDevice));
+    if (bytes) B2H_TRY(h2d(d, data, bytes));
+    B2H_TRY(h2d(d + bytes, hs, 48));
     code = launch_belt_hash_stream(d + bytes, d, nblocks, fin, lo, hi, nullptr);
     if (code != ERR_OK) return code;
-    B2H_TRY(hipMemcpy(hs, d + bytes, 48, hipMemcpyDeviceToHost));
+    B2H_TRY(d2h(hs, d + bytes, 48));
     return ERR_OK;
 }
 extern "C" void beltHashStepH(const void *buf, size_t count, void *state)
@@ -1543,11 +1603,11 @@ static err_t sde_host(int decr, octet *buf, size_t count, const octet iv[16], be
     code = sc.need(count + 16);
     if (code != ERR_OK) return code;
     octet *d = (octet *)sc.p;
-    B2H_TRY(hipMemcpy(d, buf, count, hipMemcpyHostToDevice));
-    B2H_TRY(hipMemcpy(d + count, iv, 16, hipMemcpyHostToDevice));
+    B2H_TRY(h2d(d, buf, count));
+    B2H_TRY(h2d(d + count, iv, 16));
     code = launch_belt_sde(decr, d, count / 16, 1, st->wbl->key, d + count, nullptr);
     if (code != ERR_OK) return code;
-    B2H_TRY(hipMemcpy(buf, d, count, hipMemcpyDeviceToHost));
+    B2H_TRY(d2h(buf, d, count));
     st->wbl->round = decr ? 0 : 2 * (uint64_t)(count / 16);     // where the reference's loops stop (belt_wbl.c)
     return ERR_OK;
 }
@@ -1620,12 +1680,12 @@ static err_t che_blocks_host(octet *buf, size_t nblocks, belt_che_st *st)
     code = sc.need(bytes + 16);
     if (code != ERR_OK) return code;
     octet *d = (octet *)sc.p;
-    B2H_TRY(hipMemcpy(d, buf, bytes, hipMemcpyHostToDevice));
+    B2H_TRY(h2d(d, buf, bytes));
     code = launch_belt_che(d, d, nblocks, st->mac.ctr.key, st->s, 0, d + bytes, nullptr);
     if (code != ERR_OK) return code;
     octet snew[16];
-    B2H_TRY(hipMemcpy(buf, d, bytes, hipMemcpyDeviceToHost));
-    B2H_TRY(hipMemcpy(snew, d + bytes, 16, hipMemcpyDeviceToHost));
+    B2H_TRY(d2h(buf, d, bytes));
+    B2H_TRY(d2h(snew, d + bytes, 16));
     for (int i = 0; i < 4; ++i) st->s[i] = load32le(snew + 4 * i);
     return ERR_OK;
 }
@@ -1730,12 +1790,12 @@ static err_t bde_host(int decr, octet *buf, size_t nblocks, belt_bde_st *st)
     code = sc.need(bytes + 16);
     if (code != ERR_OK) return code;
     octet *d = (octet *)sc.p;
-    B2H_TRY(hipMemcpy(d, buf, bytes, hipMemcpyHostToDevice));
+    B2H_TRY(h2d(d, buf, bytes));
     code = launch_belt_bde(decr, d, d, nblocks, st->key, st->s, 0, d + bytes, nullptr);
     if (code != ERR_OK) return code;
     octet snew[16];
-    B2H_TRY(hipMemcpy(buf, d, bytes, hipMemcpyDeviceToHost));
-    B2H_TRY(hipMemcpy(snew, d + bytes, 16, hipMemcpyDeviceToHost));
+    B2H_TRY(d2h(buf, d, bytes));
+    B2H_TRY(d2h(snew, d + bytes, 16));
     // what the reference's last iteration leaves behind (belt_bde.c:56-63): s, block = <s>, block1 = Y ^ <s>
     for (int i = 0; i < 4; ++i) st->s[i] = load32le(snew + 4 * i);
     memcpy(st->block, snew, 16);
@@ -1797,11 +1857,11 @@ extern "C" void beltCBCStepE(void *buf_, size_t count, void *state)
         if (code == ERR_OK) code = s.need(full * 16 + 16);
         die_on(code, "beltCBCStepE");
         octet *d = (octet *)s.p;
-        die_on(hipMemcpy(d, buf, full * 16, hipMemcpyHostToDevice) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
-        die_on(hipMemcpy(d + full * 16, st->block, 16, hipMemcpyHostToDevice) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
+        die_on(h2d(d, buf, full * 16) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
+        die_on(h2d(d + full * 16, st->block, 16) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
         die_on(launch_belt_cbc_encr(d, full, 1, st->key, d + full * 16, nullptr), "beltCBCStepE");
-        die_on(hipMemcpy(buf, d, full * 16, hipMemcpyDeviceToHost) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
-        die_on(hipMemcpy(st->block, d + full * 16, 16, hipMemcpyDeviceToHost) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
+        die_on(d2h(buf, d, full * 16) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
+        die_on(d2h(st->block, d + full * 16, 16) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
     }
     if (tail) {                                   // stealing, belt_cbc.c:86-93
         octet *p = buf + full * 16;
@@ -1902,11 +1962,11 @@ extern "C" err_t bee2hip_hash_ragged(size_t alg, const octet *data, const uint64
     err_t code = s.need(go + n * dlen + 16);
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
-    if (total) B2H_TRY(hipMemcpy(d, data, total, hipMemcpyHostToDevice));
-    B2H_TRY(hipMemcpy(d + oo, offsets, ob, hipMemcpyHostToDevice));
-    B2H_TRY(hipMemcpy(d + ro, ord.data(), n * 4, hipMemcpyHostToDevice));
+    if (total) B2H_TRY(h2d(d, data, total));
+    B2H_TRY(h2d(d + oo, offsets, ob));
+    B2H_TRY(h2d(d + ro, ord.data(), n * 4));
     code = bee2hip_hash_ragged_ordered_dev(alg, d, d + oo, d + ro, n, d + go, nullptr);
     if (code != ERR_OK) return code;
-    B2H_TRY(hipMemcpy(digests, d + go, n * dlen, hipMemcpyDeviceToHost));
+    B2H_TRY(d2h(digests, d + go, n * dlen));
     return ERR_OK;
 }
