@@ -5,6 +5,7 @@
 #include "belt_kernels.hip"
 #include "bign_kernels.hip"
 #include "bign_sign_kernels.hip"
+#include "bign_generic_kernels.hip"
 #include "mixed_kernels.hip"
 #include "capi.hip"
 #include "multi.hip"

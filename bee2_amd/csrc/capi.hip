@@ -492,10 +492,12 @@ static bool all_zero(const octet *p, size_t n)
     return acc == 0;
 }
 
-// bignParamsCheck (bign_params.c:244-280), then: only the three standard curves have device
-// constants; other valid-looking parameter sets report ERR_NOT_IMPLEMENTED.
-static err_t params_check(const bign_params *params)
+// bignParamsCheck (bign_params.c:244-280).  *standard = one of the three parameter sets of STB 34.101.45 annex B, which
+// have their own kernels; anything else that passes goes to the general-curve kernels where they exist (verification,
+// public-key validation) and is ERR_NOT_IMPLEMENTED elsewhere (the constant-time signing path).
+static err_t params_check2(const bign_params *params, bool *standard)
 {
+    *standard = false;
     if (!params) return ERR_BAD_INPUT;
     if (2 * params->l % 64) return ERR_NOT_IMPLEMENTED;
     const size_t no = 2 * params->l / 8;
@@ -510,12 +512,19 @@ static err_t params_check(const bign_params *params)
     if (params->l != 128 && params->l != 192 && params->l != 256) return ERR_BAD_PARAMS;
     for (const StdCurve &c : k_curves) {
         if (c.l != params->l) continue;
-        if (memcmp(params->p, c.p, no) || memcmp(params->a, c.a, no) || memcmp(params->b, c.b, no) ||
-            memcmp(params->q, c.q, no) || memcmp(params->yG, c.yG, no))
-            return ERR_NOT_IMPLEMENTED;
-        return ERR_OK;
+        *standard = !(memcmp(params->p, c.p, no) || memcmp(params->a, c.a, no) || memcmp(params->b, c.b, no) ||
+                      memcmp(params->q, c.q, no) || memcmp(params->yG, c.yG, no));
+        break;
     }
-    return ERR_NOT_IMPLEMENTED;
+    return ERR_OK;
+}
+// for the entry points that serve the standard curves only
+static err_t params_check(const bign_params *params)
+{
+    bool standard;
+    const err_t code = params_check2(params, &standard);
+    if (code != ERR_OK) return code;
+    return standard ? ERR_OK : ERR_NOT_IMPLEMENTED;
 }
 
 // oidFromDER(0, der, count) != SIZE_MAX  (src/core/oid.c:94-101, src/core/der.c:114-258,921-975):
@@ -582,8 +591,13 @@ extern "C" err_t bee2hip_bignVerify_batch(const bign_params *params, const octet
                                           size_t n, err_t *codes)
 {
     // order of checks as bignVerify: params first (bign_sign.c:355-356), then inputs, then OID
-    err_t code = params_check(params);
+    bool standard;
+    err_t code = params_check2(params, &standard);
     if (code != ERR_OK) return code;
+    if (!standard) {                              // bignEcCreate judges the parameters next (bign_sign.c:357-358)
+        code = bign_generic_check(params);
+        if (code != ERR_OK) return code;
+    }
     if (n && (!hashes || !sigs || !pubkeys || !codes)) return ERR_BAD_INPUT;
     if (!oid_der_valid(oid_der, oid_len)) return ERR_BAD_OID;
     if (n == 0) return ERR_OK;
@@ -599,7 +613,8 @@ extern "C" err_t bee2hip_bignVerify_batch(const bign_params *params, const octet
     B2H_TRY(h2d(d, hashes, hb));
     B2H_TRY(h2d(d + so, sigs, sb));
     B2H_TRY(h2d(d + po, pubkeys, pb));
-    code = launch_bign_verify(params->l, oid_der, oid_len, d, d + so, d + po, n, d + co, nullptr);
+    code = standard ? launch_bign_verify(params->l, oid_der, oid_len, d, d + so, d + po, n, d + co, nullptr)
+                    : launch_bign_verify_generic(params, oid_der, oid_len, d, d + so, d + po, n, d + co, nullptr);
     if (code != ERR_OK) return code;
     B2H_TRY(d2h(codes, d + co, 4 * n));
     return ERR_OK;
@@ -610,7 +625,9 @@ extern "C" err_t bignVerify(const bign_params *params, const octet oid_der[], si
 {
     err_t one = ERR_BAD_SIG;
     if (!hash || !sig || !pubkey) {
-        const err_t pc = params_check(params);
+        bool standard;
+        err_t pc = params_check2(params, &standard);
+        if (pc == ERR_OK && !standard) pc = bign_generic_check(params);
         return pc != ERR_OK ? pc : ERR_BAD_INPUT;
     }
     const err_t code = bee2hip_bignVerify_batch(params, oid_der, oid_len, hash, sig, pubkey, 1, &one);
@@ -651,9 +668,14 @@ extern "C" err_t bee2hip_bignPubkeyValL_batch_dev(size_t l, const void *d_pubkey
 extern "C" err_t bee2hip_bignPubkeyVal_batch(const bign_params *params, const octet *pubkeys, size_t n,
                                              err_t *codes)
 {
-    // bignPubkeyVal: params first (bign_misc.c:358-359), then the key
-    err_t code = params_check(params);
+    // bignPubkeyVal: params first (bign_misc.c:358-361), then the key
+    bool standard;
+    err_t code = params_check2(params, &standard);
     if (code != ERR_OK) return code;
+    if (!standard) {
+        code = bign_generic_check(params);
+        if (code != ERR_OK) return code;
+    }
     if (n && (!pubkeys || !codes)) return ERR_BAD_INPUT;
     if (n == 0) return ERR_OK;
     code = ensure_device();
@@ -664,7 +686,8 @@ extern "C" err_t bee2hip_bignPubkeyVal_batch(const bign_params *params, const oc
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
     B2H_TRY(h2d(d, pubkeys, pb));
-    code = launch_bign_pubkey_val(params->l, d, n, d + co, nullptr);
+    code = standard ? launch_bign_pubkey_val(params->l, d, n, d + co, nullptr)
+                    : launch_bign_pubkey_val_generic(params, d, n, d + co, nullptr);
     if (code != ERR_OK) return code;
     B2H_TRY(d2h(codes, d + co, 4 * n));
     return ERR_OK;
@@ -674,7 +697,9 @@ extern "C" err_t bignPubkeyVal(const bign_params *params, const octet pubkey[])
 {
     err_t one = ERR_BAD_PUBKEY;
     if (!pubkey) {
-        const err_t pc = params_check(params);
+        bool standard;
+        err_t pc = params_check2(params, &standard);
+        if (pc == ERR_OK && !standard) pc = bign_generic_check(params);
         return pc != ERR_OK ? pc : ERR_BAD_INPUT;
     }
     const err_t code = bee2hip_bignPubkeyVal_batch(params, pubkey, 1, &one);

@@ -63,6 +63,11 @@ err_t launch_belt_hash_stream(void *d_hs, const void *d_data, size_t nblocks, in
 err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, const void *d_order, size_t n,
                          void *d_digests, hipStream_t st);
 err_t launch_bign_pubkey_val(size_t l, const void *d_pubkeys, size_t n, void *d_codes, hipStream_t st);
+// non-standard parameter sets (bign_generic_kernels.hip): params already through bignParamsCheck's tests
+err_t launch_bign_verify_generic(const bign_params *params, const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
+                                 const void *d_sigs, const void *d_pubkeys, size_t n, void *d_codes, hipStream_t st);
+err_t bign_generic_check(const bign_params *params);
+err_t launch_bign_pubkey_val_generic(const bign_params *params, const void *d_pubkeys, size_t n, void *d_codes, hipStream_t st);
 // 8f-4 tail: Q = d G per private key (codes: ERR_OK / ERR_BAD_PRIVKEY); signing, mode 0 = bignSign2 (d_aux = t or
 // null), mode 1 = one-time keys supplied (d_aux = k)
 err_t launch_bign_pubkey_calc(size_t l, bool keygen, const void *d_privkeys, size_t n, void *d_pubkeys, void *d_codes, hipStream_t st);

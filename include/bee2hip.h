@@ -219,9 +219,13 @@ typedef struct {
 /* bign.h:100-107, src/crypto/bign/bign_params.c:180-230: "1.2.112.0.2.0.34.101.45.3.{1,2,3}" */
 err_t bignParamsStd(bign_params *params, const char *name);
 /* bign.h:395-402, src/crypto/bign/bign_sign.c:349-361.
-   Limits of this implementation (both report ERR_NOT_IMPLEMENTED, never a wrong verdict): params must be one of
-   the three standard sets bignParamsStd returns; oid_len <= 128 octets (the kernels stage the DER OID as a launch
-   argument; bee2 accepts any valid DER OID). */
+   Any parameter set that passes bignParamsCheck + bignEcCreate is served (bignVerify and bignPubkeyVal; batch forms
+   likewise): the three standard sets by the throughput kernels, every other set by general-curve kernels (Montgomery
+   arithmetic, general coefficient a; 21 / 51 / 100 ms per batch of up to a few thousand signatures on the three
+   levels -- a completeness path, not a throughput path).  The signing side
+   (bignKeypairGen, bignPubkeyCalc, bignSign*) serves the standard sets only and reports ERR_NOT_IMPLEMENTED otherwise.
+   One limit, reported as ERR_NOT_IMPLEMENTED, never as a wrong verdict: oid_len <= 128 octets (the kernels stage the
+   DER OID as a launch argument; bee2 accepts any valid DER OID). */
 err_t bignVerify(const bign_params *params, const octet oid_der[], size_t oid_len,
                  const octet hash[], const octet sig[], const octet pubkey[]);
 /* include/bee2/crypto/bign128.h:174-178, src/crypto/bign/bign128.c:177-185 */

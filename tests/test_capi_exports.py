@@ -98,8 +98,13 @@ def test_argument_checks_need_no_gpu(lib_path):
     bad.p[0] = 0x42
     assert eng.bignVerify(bad, E.OID_BELT_HASH_DER, h, s, k) == E.ERR_BAD_PARAMS
     other = eng.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
-    other.b[0] ^= 1                       # a different (valid-looking) curve: no device constants
-    assert eng.bignVerify(other, E.OID_BELT_HASH_DER, h, s, k) == E.ERR_NOT_IMPLEMENTED
+    other.b[0] ^= 1                       # a different (valid-looking) curve: served by the general-curve kernels, so
+    # without a GPU the call must fail loudly with the device error (there is no CPU fallback), with one it verifies
+    assert eng.bignVerify(other, E.OID_BELT_HASH_DER, h, s, k) in (E.ERR_BEE2HIP_DEVICE, E.ERR_BAD_SIG)
+    assert eng.bignVerify(other, b"\x06\x01", h, s, k) == E.ERR_BAD_OID         # still before any device work
+    other.a[0:32] = other.p[0:32]         # a = p: what bignEcCreate rejects (bign_ec.c:64-70), before inputs and OID
+    assert eng.bignVerify(other, b"\x06\x01", h, s, k) == E.ERR_BAD_PARAMS
+    assert eng.bignPubkeyVal(other, None if False else k) == E.ERR_BAD_PARAMS
 
 
 def test_oid_der_validation_matches_reference_on_invalid_inputs(lib_path):

@@ -1,0 +1,101 @@
+"""GPU: bignVerify / bignPubkeyVal on NON-STANDARD parameter sets (bign_generic_kernels.hip) against the fixtures the
+reference produced (tests/golden/bign_generic.json) and against the Python restatement (tests/orc_generic.py) on
+fresh random damage."""
+import ctypes
+import json
+import os
+import random
+
+import pytest
+
+import orc_generic as OG
+from bee2_amd.engine import bign_params
+from gpulib import engine
+
+pytestmark = pytest.mark.gpu
+
+FIX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bign_generic.json")))
+
+
+def mk(c):
+    prm = bign_params()
+    prm.l = c["l"]
+    for f in ("p", "a", "b", "q", "yG"):
+        raw = bytes.fromhex(c[f])
+        ctypes.memmove(getattr(prm, f), raw + bytes(64 - len(raw)), 64)
+    return prm
+
+
+def test_generic_verify_batches_match_the_reference():
+    """every case of a curve in ONE bee2hip_bignVerify_batch call: valid signatures on isomorphic images of the standard
+    curves (reference as signer) and on random-prime curves (no-wrap signatures the reference accepts), damaged variants"""
+    eng = engine()
+    for ci, c in enumerate(FIX["curves"]):
+        prm = mk(c)
+        cases = [x for x in FIX["cases"] if x["curve"] == ci]
+        H = b"".join(bytes.fromhex(x["hash"]) for x in cases)
+        S = b"".join(bytes.fromhex(x["sig"]) for x in cases)
+        K = b"".join(bytes.fromhex(x["pubkey"]) for x in cases)
+        code, got = eng.bignVerify_batch(H, S, K, oid_der=bytes.fromhex(cases[0]["oid"]), params=prm)
+        assert code == 0, (ci, code)
+        bad = [(x["name"], g, x["code"]) for x, g in zip(cases, got) if g != x["code"]]
+        assert not bad, (ci, c["kind"], c["l"], bad[:5])
+        assert 0 in got and 510 in got
+
+
+def test_generic_verify_dropin_and_pubkey_val():
+    eng = engine()
+    for ci, c in enumerate(FIX["curves"]):
+        prm = mk(c)
+        cases = [x for x in FIX["cases"] if x["curve"] == ci][:3]
+        for x in cases:
+            got = eng.bignVerify(prm, bytes.fromhex(x["oid"]), bytes.fromhex(x["hash"]), bytes.fromhex(x["sig"]), bytes.fromhex(x["pubkey"]))
+            assert got == x["code"], (ci, x["name"], got)
+        pv = [x for x in FIX["pubkey_val"] if x["curve"] == ci]
+        code, got = eng.bignPubkeyVal_batch(b"".join(bytes.fromhex(x["pubkey"]) for x in pv), prm)
+        assert code == 0 and got == [x["code"] for x in pv], (ci, got)
+        assert eng.bignPubkeyVal(prm, bytes.fromhex(pv[0]["pubkey"])) == pv[0]["code"]
+
+
+def test_malformed_parameter_sets_report_the_reference_codes():
+    eng = engine()
+    for c in FIX["bad_params"]:
+        prm = mk(c)
+        h, s, k = (bytes.fromhex(c[x]) for x in ("hash", "sig", "pubkey"))
+        assert eng.bignVerify(prm, bytes.fromhex(c["oid"]), h, s, k) == c["verify"], c["name"]
+        assert eng.bignPubkeyVal(prm, k) == c["pubkey_val"], c["name"]
+        # precedence as bignVerify: parameters (incl. what bignEcCreate rejects), then inputs, then the OID
+        codes = (ctypes.c_uint32 * 1)()
+        code = eng.lib.bee2hip_bignVerify_batch(ctypes.byref(prm), b"\x06\x01", ctypes.c_size_t(2), h, s, k, ctypes.c_size_t(1), codes)
+        assert code == (c["verify"] if c["verify"] not in (0, 505, 510) else 301), c["name"]     # 301 = ERR_BAD_OID
+
+
+def test_generic_verify_random_damage_vs_python_restatement(orc):
+    """fresh corruptions of the fixture triples (the fixtures fix only a few): the Python restatement, pinned to the
+    reference by tests/test_oracle_golden.py, is the checker"""
+    eng = engine()
+    rnd = random.Random(0x67656E)
+    for ci, c in enumerate(FIX["curves"]):
+        if c["l"] == 256 and c["kind"] == "rnd":
+            continue                                            # the Python checker needs ~0.3 s per 512-bit case
+        prm = mk(c)
+        P = OG.Params.from_hex(c)
+        no = c["l"] // 4
+        good = [x for x in FIX["cases"] if x["curve"] == ci and x["name"] == "good"]
+        H, S, K, want = b"", b"", b"", []
+        for _ in range(12):
+            x = rnd.choice(good)
+            h, s, k = (bytearray.fromhex(x[f]) for f in ("hash", "sig", "pubkey"))
+            r = rnd.randrange(5)
+            if r == 1:
+                s[rnd.randrange(len(s))] ^= 1 << rnd.randrange(8)
+            elif r == 2:
+                h[rnd.randrange(no)] ^= 1 << rnd.randrange(8)
+            elif r == 3:
+                k[rnd.randrange(2 * no)] ^= 1 << rnd.randrange(8)
+            elif r == 4:
+                s[no // 2:] = rnd.getrandbits(8 * no).to_bytes(no, "little")
+            H += bytes(h); S += bytes(s); K += bytes(k)
+            want.append(OG.verify(P, bytes.fromhex(x["oid"]), bytes(h), bytes(s), bytes(k), orc.belt_hash))
+        code, got = eng.bignVerify_batch(H, S, K, oid_der=bytes.fromhex(good[0]["oid"]), params=prm)
+        assert code == 0 and got == want, (ci, got, want)

@@ -301,3 +301,28 @@ def test_bign_sign_keygen_oracle_vs_golden(orc, golden):
             assert code == c["code"], c
             if code == 0:
                 assert (sig.hex(), used * no) == (c["sig"], c["used"])
+
+
+def test_generic_parameter_sets_python_restatement_vs_reference_fixtures(orc):
+    """tests/orc_generic.py (pure-Python bignVerify / bignPubkeyVal over arbitrary parameter sets, the checker of the
+    general-curve kernels) against tests/golden/bign_generic.json, whose codes the reference itself produced
+    (tools/make_golden_generic.py): isomorphic images of the standard curves (a != -3, reference as signer), random
+    primes with crafted no-wrap signatures the reference accepts, damaged variants, malformed parameter sets."""
+    import json
+    import os
+    import orc_generic as OG
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bign_generic.json")))
+    PP = [OG.Params.from_hex(c) for c in d["curves"]]
+    assert {c["kind"] for c in d["curves"]} == {"iso", "rnd"} and {c["l"] for c in d["curves"]} == {128, 192, 256}
+    for c in d["cases"]:
+        got = OG.verify(PP[c["curve"]], bytes.fromhex(c["oid"]), bytes.fromhex(c["hash"]), bytes.fromhex(c["sig"]),
+                        bytes.fromhex(c["pubkey"]), orc.belt_hash)
+        assert got == c["code"], (c["curve"], c["name"])
+    assert {c["code"] for c in d["cases"]} == {0, 505, 510}
+    for c in d["pubkey_val"]:
+        assert OG.pubkey_val(PP[c["curve"]], bytes.fromhex(c["pubkey"])) == c["code"]
+    for c in d["bad_params"]:
+        P = OG.Params(c["l"], *(bytes.fromhex(c[k]) for k in ("p", "a", "b", "q", "yG")))
+        h, s, k = (bytes.fromhex(c[x]) for x in ("hash", "sig", "pubkey"))
+        assert OG.verify(P, bytes.fromhex(c["oid"]), h, s, k, orc.belt_hash) == c["verify"], c["name"]
+        assert OG.pubkey_val(P, k) == c["pubkey_val"], c["name"]
