@@ -4,6 +4,7 @@ and corruptions, every entry point family.  TEST INFRASTRUCTURE (uses oracle/): 
    python tests/fuzz_gpu.py [seconds] [seed]
 Prints one line per family with the number of cases, and stops at the first mismatch with a
 reproducer (family, seed of the case)."""
+import ctypes
 import os
 import random
 import sys
@@ -138,7 +139,57 @@ def _triples(l):
     return _base[l]
 
 
+_generic = None
+
+
+def f_verify_generic(rnd):
+    """a non-standard parameter set (general-curve kernels): fixture triples, fresh damage, the Python restatement as checker"""
+    global _generic
+    import json
+    import orc_generic as OG
+    from bee2_amd.engine import bign_params
+    if _generic is None:
+        _generic = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bign_generic.json")))
+    ci = rnd.randrange(len(_generic["curves"]))
+    c = _generic["curves"][ci]
+    if c["l"] == 256:
+        ci = 0
+        c = _generic["curves"][0]
+    prm = bign_params()
+    prm.l = c["l"]
+    for f in ("p", "a", "b", "q", "yG"):
+        raw = bytes.fromhex(c[f])
+        ctypes.memmove(getattr(prm, f), raw + bytes(64 - len(raw)), 64)
+    P = OG.Params.from_hex(c)
+    no = c["l"] // 4
+    good = [x for x in _generic["cases"] if x["curve"] == ci and x["name"] == "good"]
+    H, S, K, want = b"", b"", b"", []
+    for _ in range(rnd.randrange(1, 9)):
+        x = rnd.choice(good)
+        h, s, k = (bytearray.fromhex(x[f]) for f in ("hash", "sig", "pubkey"))
+        r = rnd.randrange(6)
+        if r == 1:
+            s[rnd.randrange(len(s))] ^= 1 << rnd.randrange(8)
+        elif r == 2:
+            h[rnd.randrange(no)] ^= 1 << rnd.randrange(8)
+        elif r == 3:
+            k[rnd.randrange(2 * no)] ^= 1 << rnd.randrange(8)
+        elif r == 4:
+            s[no // 2:] = b"\xff" * no
+        elif r == 5:
+            k[:no] = b"\xff" * no
+        H += bytes(h); S += bytes(s); K += bytes(k)
+        want.append(OG.verify(P, bytes.fromhex(x["oid"]), bytes(h), bytes(s), bytes(k), orc.belt_hash))
+    code, got = eng.bignVerify_batch(H, S, K, oid_der=bytes.fromhex(good[0]["oid"]), params=prm)
+    if code != 0 or got != want:
+        return False
+    code, got = eng.bignPubkeyVal_batch(K, prm)
+    return code == 0 and got == [OG.pubkey_val(P, K[2 * no * i:2 * no * (i + 1)]) for i in range(len(want))]
+
+
 def f_verify(rnd):
+    if rnd.randrange(12) == 0:
+        return f_verify_generic(rnd)
     l = rnd.choice((128, 128, 192, 256))
     base = _triples(l)
     n = max(1, size(rnd, 6000 if l == 128 else 800, (64, 256, 1024)))
