@@ -33,7 +33,7 @@ template <int N>
 __device__ __forceinline__ bool g_ge(const uint32_t (&a)[N], const uint32_t (&b)[N])
 {
     uint32_t borrow = 0;
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) {
         const uint64_t d = (uint64_t)a[i] - b[i] - borrow;
         borrow = (uint32_t)(d >> 32) & 1u;
@@ -44,7 +44,7 @@ template <int N>
 __device__ __forceinline__ bool g_is_zero(const gfe<N> &a)
 {
     uint32_t z = 0;
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) z |= a.v[i];
     return z == 0;
 }
@@ -52,7 +52,7 @@ template <int N>
 __device__ __forceinline__ bool g_eq(const gfe<N> &a, const gfe<N> &b)
 {
     uint32_t z = 0;
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) z |= a.v[i] ^ b.v[i];
     return z == 0;
 }
@@ -62,16 +62,16 @@ __device__ __noinline__ void g_add(gfe<N> &r, const gfe<N> &a, const gfe<N> &b, 
 {
     uint32_t t[N], s[N];
     uint64_t c = 0;
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) { c += (uint64_t)a.v[i] + b.v[i]; t[i] = (uint32_t)c; c >>= 32; }
     uint32_t borrow = 0;
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) {
         const uint64_t d = (uint64_t)t[i] - C.p[i] - borrow;
         s[i] = (uint32_t)d; borrow = (uint32_t)(d >> 32) & 1u;
     }
     const bool ge = c != 0 || borrow == 0;
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) r.v[i] = ge ? s[i] : t[i];
 }
 template <int N>
@@ -79,13 +79,13 @@ __device__ __noinline__ void g_sub(gfe<N> &r, const gfe<N> &a, const gfe<N> &b, 
 {
     uint32_t t[N];
     uint32_t borrow = 0;
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) {
         const uint64_t d = (uint64_t)a.v[i] - b.v[i] - borrow;
         t[i] = (uint32_t)d; borrow = (uint32_t)(d >> 32) & 1u;
     }
     uint64_t c = 0;
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) {
         c += (uint64_t)t[i] + (borrow ? C.p[i] : 0u);
         r.v[i] = (uint32_t)c; c >>= 32;
@@ -137,7 +137,7 @@ __device__ __forceinline__ void g_sqr(gfe<N> &r, const gfe<N> &a, const GenCurve
 template <int N>
 __device__ __forceinline__ void g_set(gfe<N> &r, const uint32_t (&w)[N])
 {
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) r.v[i] = w[i];
 }
 // a^(p-2) (Montgomery domain in, Montgomery domain out); 0 -> 0

@@ -221,7 +221,7 @@ err_t bignParamsStd(bign_params *params, const char *name);
 /* bign.h:395-402, src/crypto/bign/bign_sign.c:349-361.
    Any parameter set that passes bignParamsCheck + bignEcCreate is served (bignVerify and bignPubkeyVal; batch forms
    likewise): the three standard sets by the throughput kernels, every other set by general-curve kernels (Montgomery
-   arithmetic, general coefficient a; 21 / 51 / 100 ms per batch of up to a few thousand signatures on the three
+   arithmetic, general coefficient a; 14 / 35 / 72 ms per batch of up to a few thousand signatures on the three
    levels -- a completeness path, not a throughput path).  The signing side
    (bignKeypairGen, bignPubkeyCalc, bignSign*) serves the standard sets only and reports ERR_NOT_IMPLEMENTED otherwise.
    One limit, reported as ERR_NOT_IMPLEMENTED, never as a wrong verdict: oid_len <= 128 octets (the kernels stage the
