@@ -949,18 +949,18 @@ extern "C" err_t bignSign2(octet sig[], const bign_params *params, const octet o
     code = bee2hip_bignSign2_batch(params, oid_der, oid_len, hash, privkey, t, t_len, 1, sig, &one);
     return code != ERR_OK ? code : one;
 }
-#define B2H_LEVEL_FACADE(L, IDX, OID)                                                                              \
-    extern "C" err_t bign##L##PubkeyCalc(octet pubkey[], const octet privkey[])                                     \
+#define B2H_LEVEL_FACADE(L, IDX, OID, NO)                                                                          \
+    extern "C" err_t bign##L##PubkeyCalc(octet pubkey[2 * NO], const octet privkey[NO])                             \
     { bign_params p; bignParamsStd(&p, k_curves[IDX].name); return bignPubkeyCalc(pubkey, &p, privkey); }            \
-    extern "C" err_t bign##L##KeypairGen(octet privkey[], octet pubkey[], gen_i rng, void *rng_state)               \
+    extern "C" err_t bign##L##KeypairGen(octet privkey[NO], octet pubkey[2 * NO], gen_i rng, void *rng_state)       \
     { bign_params p; bignParamsStd(&p, k_curves[IDX].name); return bignKeypairGen(privkey, pubkey, &p, rng, rng_state); } \
-    extern "C" err_t bign##L##Sign(octet sig[], const octet hash[], const octet privkey[], gen_i rng, void *rng_state) \
+    extern "C" err_t bign##L##Sign(octet sig[NO + NO / 2], const octet hash[NO], const octet privkey[NO], gen_i rng, void *rng_state) \
     { bign_params p; bignParamsStd(&p, k_curves[IDX].name); return bignSign(sig, &p, OID, 11, hash, privkey, rng, rng_state); } \
-    extern "C" err_t bign##L##Sign2(octet sig[], const octet hash[], const octet privkey[], const void *t, size_t t_len) \
+    extern "C" err_t bign##L##Sign2(octet sig[NO + NO / 2], const octet hash[NO], const octet privkey[NO], const void *t, size_t t_len) \
     { bign_params p; bignParamsStd(&p, k_curves[IDX].name); return bignSign2(sig, &p, OID, 11, hash, privkey, t, t_len); }
-B2H_LEVEL_FACADE(128, 0, k_oid_belt_hash)
-B2H_LEVEL_FACADE(192, 1, k_oid_bash384)
-B2H_LEVEL_FACADE(256, 2, k_oid_bash512)
+B2H_LEVEL_FACADE(128, 0, k_oid_belt_hash, 32)
+B2H_LEVEL_FACADE(192, 1, k_oid_bash384, 48)
+B2H_LEVEL_FACADE(256, 2, k_oid_bash512, 64)
 #undef B2H_LEVEL_FACADE
 
 extern "C" err_t bee2hip_debug_fe(int op, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream)
