@@ -380,8 +380,11 @@ __device__ __forceinline__ int32_t sg_divsteps_30(int32_t zeta, uint32_t f, uint
     return zeta;
 }
 
-// a^-1 mod p for canonical a (0 -> 0); no fallback
-template <int N>
+// a^-1 mod p for canonical a (0 -> 0); no fallback.  CT = true: no early exit -- all MAX_ITER iterations run whatever
+// the value (the bound of the half-delta variant, (45907 b + 26313) / 19929 division steps for b-bit inputs: 590 / 886 /
+// 1181 for the three curves, is below 30 MAX_ITER = 660 / 960 / 1260), and nothing else in the function depends on
+// the data (masks only): the form the signing kernels use on secret Z coordinates.
+template <int N, bool CT = false>
 __device__ __noinline__ feT<N> fe_inv_safegcd(feT<N> a)
 {
     using SG = SafeGcd<N>;
@@ -399,10 +402,12 @@ __device__ __noinline__ feT<N> fe_inv_safegcd(feT<N> a)
     int32_t zeta = -1;
 #pragma unroll 1
     for (int it = 0; it < SG::MAX_ITER; ++it) {
-        int32_t nz = 0;
+        if (!CT) {
+            int32_t nz = 0;
 #pragma unroll
-        for (int i = 0; i < L; ++i) nz |= g[i];
-        if (!__any(nz != 0)) break;
+            for (int i = 0; i < L; ++i) nz |= g[i];
+            if (!__any(nz != 0)) break;
+        }
         uint32_t uu, vv, qq, rr;
         zeta = sg_divsteps_30(zeta, (uint32_t)f[0], (uint32_t)g[0], uu, vv, qq, rr);
         const int32_t u = (int32_t)uu, v = (int32_t)vv, q = (int32_t)qq, r = (int32_t)rr;

@@ -19,8 +19,9 @@
 //   * the additions use the COMPLETE projective formulas of Renes, Costello and Batina (algorithm 5: a = -3,
 //     mixed, 11 M + 2 m_b), so there is no exceptional case to branch on: k = q - 2 d_0, acc = O, digit = 0
 //     all go through the same instructions (a zero digit adds a dummy point and keeps the old accumulator);
-//   * the inversion for the affine result is a^(p-2) (fe_inv: fixed chain of squarings and multiplications),
-//     not the division-step inversion of the verify path, whose trip count depends on the operand;
+//   * the inversion for the affine result is by division steps with a FIXED number of iterations (fe_inv_safegcd<N, true>;
+//     round 2 first used a^(p-2), a fixed chain of squarings and multiplications four times as long),
+//     where the verify path's variant of the same function leaves its loop as soon as g = 0 in the whole wavefront;
 //   * belt (theta = belt-hash(oid || d || t), k = belt-wbl_theta(H)) looks its S-box up in LDS at secret
 //     indices, as every table-driven belt does.  The table used here is BeltTabTwo, whose copies are
 //     bank-private (lane l only ever touches bank l mod 32, belt_dev.hpp): an access takes the same LDS
@@ -181,12 +182,19 @@ __device__ __forceinline__ uint32_t mul_base_ct(feT<N> &x, feT<N> &y, const uint
     // affine: x = X / Z, y = Y / Z with the fixed exponentiation chain (Z = 0 only for k = 0 mod q: gives 0)
     feT<N> zc;
     fe_canon(zc, acc.Z);
-    const feT<N> zi = fe_inv(zc);
+    // division steps with a fixed iteration count (bign_dev.hpp, fe_inv_safegcd<N, true>): a quarter of the
+    // instructions of the a^(p-2) chain, which was a fifth of this kernel.  The product Z * Z^-1 is checked with masks;
+    // a failure (never observed; the bound on the number of steps is proven) is reported like k G = O, i.e. loudly.
+    const feT<N> zi = fe_inv_safegcd<N, true>(zc);
+    feT<N> chk;
+    fe_mul(chk, zc, zi);
+    fe_canon(chk, chk);
+    chk.v[0] ^= 1u;                                // 0 iff Z * Z^-1 == 1
     fe_mul(x, acc.X, zi);
     fe_mul(y, acc.Y, zi);
     fe_canon(x, x);
     fe_canon(y, y);
-    return ct_is_zero(zc.v);                       // all-ones iff k G = O
+    return ct_is_zero(zc.v) | ~ct_is_zero(chk.v);  // all-ones iff k G = O (or the inversion check failed)
 }
 
 template <int N>
