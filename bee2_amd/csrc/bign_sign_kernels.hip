@@ -212,8 +212,11 @@ __device__ __forceinline__ void load_words_bytes(uint32_t (&r)[N], const uint8_t
 //         (bign_misc.c:209-218); codes[i] = ERR_BAD_PARAMS when d G = O (d = q), else ERR_OK.
 // MODE 0 (signing): no codes; every lane computes.
 // xy_out: n x 8N octets (x || y), or with X_ONLY n x 4N octets.
+#ifndef SIGN_MULBASE_WAVES
+#define SIGN_MULBASE_WAVES 3        // 168 VGPRs, 15 spilled: +2.2 % over 2 (186 VGPRs); 4 (128 VGPRs, 110-124 spilled): -31 %
+#endif
 template <int N, int MODE, bool X_ONLY>
-__global__ __launch_bounds__(256, (N == 8 ? 2 : 1))
+__global__ __launch_bounds__(256, (N == 8 ? SIGN_MULBASE_WAVES : 1))
 void bign_mulbase_ct_kernel(const uint8_t *__restrict__ scalars, size_t n, uint32_t *__restrict__ codes,
                             uint8_t *__restrict__ xy_out, const uint32_t *__restrict__ gtab8)
 {
