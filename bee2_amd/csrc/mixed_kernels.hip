@@ -580,13 +580,22 @@ void belt_hash_stream_kernel(uint32_t *__restrict__ hs, const uint8_t *__restric
 #pragma unroll
     for (int k = 0; k < 4; ++k) s[k] = hs[8 + k];
     const uint32_t *w = reinterpret_cast<const uint32_t *>(data);           // scratch buffer: 4-byte aligned
+    uint32_t Xn[8];
+    if (nblocks) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) X[k] = w[k];
+    }
 #pragma unroll 1
     for (size_t b = 0; b < nblocks; ++b) {
+        if (b + 1 < nblocks) {                      // the next block is in flight while this one is compressed
 #pragma unroll
-        for (int k = 0; k < 8; ++k) X[k] = w[8 * b + k];
+            for (int k = 0; k < 8; ++k) Xn[k] = w[8 * (b + 1) + k];
+        }
         belt_compress_pair(T, s1, h, X, odd);
 #pragma unroll
         for (int k = 0; k < 4; ++k) s[k] ^= s1[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) X[k] = Xn[k];
     }
     if (fin) {
         X[0] = (uint32_t)bits_lo; X[1] = (uint32_t)(bits_lo >> 32); X[2] = (uint32_t)bits_hi; X[3] = (uint32_t)(bits_hi >> 32);
@@ -637,13 +646,33 @@ void belt_hash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__r
     for (int k = 0; k < 8; ++k)
         h[k] = (uint32_t)c_beltH[4 * k] | (uint32_t)c_beltH[4 * k + 1] << 8 |
                (uint32_t)c_beltH[4 * k + 2] << 16 | (uint32_t)c_beltH[4 * k + 3] << 24;
-    while (left >= 32) {
+    // The chain step is two dependent encryptions (~3.5 us on a lone pair of lanes); a global load issued when its
+    // block is needed would add its ~1 us of latency to EVERY step, so the nine aligned words that hold block b + 1
+    // are requested before block b is compressed (round 2: the ragged batch, whose time is its longest chain).
+    {
+        const uint32_t *wp = reinterpret_cast<const uint32_t *>((uintptr_t)p & ~(uintptr_t)3);
+        const uint32_t sh = ((uint32_t)(uintptr_t)p & 3u) * 8u;
+        uint32_t W[9], Wn[9];
+        if (left >= 32) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) X[k] = load32_any(p + 4 * k);
-        belt_compress_pair(T, s1, h, X, odd);
+            for (int k = 0; k < 8; ++k) W[k] = wp[k];
+            W[8] = sh ? wp[8] : 0u;
+        }
+        while (left >= 32) {
+            if (left >= 64) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] ^= s1[k];
-        p += 32; left -= 32;
+                for (int k = 0; k < 8; ++k) Wn[k] = wp[8 + k];
+                Wn[8] = sh ? wp[16] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) X[k] = __builtin_amdgcn_alignbit(W[k + 1], W[k], sh);
+            belt_compress_pair(T, s1, h, X, odd);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] ^= s1[k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) W[k] = Wn[k];
+            wp += 8; p += 32; left -= 32;
+        }
     }
     if (left) {                                        // the last, zero-padded block (belt_hash.c:115-119)
 #pragma unroll
