@@ -27,7 +27,9 @@
 // inputs; lanes that hit one are flagged and recomputed by bign_slow_kernel with the
 // complete (branchy) formulas, so verdicts are exact for every on-curve key.
 //
-// Kernels per batch (same stream): [points ->] prep -> main -> slow -> inv -> tail.
+// Kernels per batch (same stream): [points ->] prep -> main -> slow -> inv -> tail; on the 256-bit curve the batch size
+// picks who walks the scalar multiplication: bign_quad29_kernel (= prep + main; a quad of lanes per signature up to
+// 2^14 signatures, a pair up to 2^15), prep + bign_main29_kernel (29-bit limbs, up to 2^16), prep + bign_main_kernel.
 //   prep : range checks (bign_sign.c:306-318), u = s1 + H mod q (:320-327),
 //          v = s0 + 2^l (:329-330), affine Q table (on the wider curves the first half of this,
 //          everything up to the Jacobian table points, is a kernel of its own: points)

@@ -8,6 +8,11 @@
 // products with v_mov_b32 quad_perm broadcasts and evaluates the cheap additions redundantly in all four lanes, so
 // the state (X, Y, Z, Z^2) stays replicated.  Same formulas as jac_dbl / jac_add (dbl-2001-b, add-1998-cmo-2), i.e.
 // the same group elements and the same exceptional cases, which go to bign_slow_kernel as before.
+//
+// MEASUREMENT ONLY (tools/ubench/quad_dbl.hip: x1.6 on a lone wavefront): the kernels use the 29-bit-limb form of the
+// same idea, bign_quad29.hpp (x2.5), and its single-block asm broadcasts.  The __builtin_amdgcn_mov_dpp broadcasts
+// below are safe HERE only because every consumer is a carry chain (v_sub_co / v_subb), which LLVM does not fold a
+// DPP operand into -- see the note in bign_quad29.hpp before reusing them.
 #pragma once
 #include "bign_dev.hpp"
 

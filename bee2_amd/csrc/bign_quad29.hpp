@@ -1,5 +1,6 @@
-// bign_quad29.hpp -- one signature on FOUR adjacent lanes (a DPP quad), field elements on the signed 29-bit limbs
-// of bign_fe29.hpp: the point operations of the smallest verification batches (<= 2^14 signatures).
+// bign_quad29.hpp -- one signature on FOUR adjacent lanes (a DPP quad) or on a PAIR of lanes, field elements on the
+// signed 29-bit limbs of bign_fe29.hpp: the point operations of the small verification batches (quads up to 2^14
+// signatures, pairs up to 2^15; bign_quad29_kernel in bign_kernels.hip).
 //
 // v Q is 32N dependent doublings; with one lane per signature a batch below 2^16 signatures is one wavefront per
 // SIMD walking that chain, so its time does not depend on its size (the latency floor).  A doubling's
@@ -10,7 +11,7 @@
 // inside the bounds of the carry-free limbs: a doubling needs no carry pass at all, an addition one.
 // Same group law as jac_dbl / jac_add (bign_dev.hpp), hence the same exceptional cases; each of them zeroes Z3 and
 // every Z after it, and the caller tests the final Z once.
-// tools/ubench/quad_dbl.hip: x1.6 (32-bit limbs, bign_quad.hpp) on a lone wavefront; this form measured there too.
+// tools/ubench/quad_dbl.hip on a lone wavefront: quads x2.5, pairs x1.9, quads on 32-bit limbs (bign_quad.hpp) x1.6.
 #pragma once
 #include "bign_fe29.hpp"
 
