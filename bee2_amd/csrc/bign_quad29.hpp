@@ -11,7 +11,7 @@
 // inside the bounds of the carry-free limbs: a doubling needs no carry pass at all, an addition one.
 // Same group law as jac_dbl / jac_add (bign_dev.hpp), hence the same exceptional cases; each of them zeroes Z3 and
 // every Z after it, and the caller tests the final Z once.
-// tools/ubench/quad_dbl.hip on a lone wavefront: quads x2.5, pairs x1.9, quads on 32-bit limbs (bign_quad.hpp) x1.6.
+// tools/ubench/quad_dbl.hip on a lone wavefront: quads x2.5, pairs x1.9, quads on 32-bit limbs (tools/ubench/bign_quad32.hpp) x1.6.
 #pragma once
 #include "bign_fe29.hpp"
 

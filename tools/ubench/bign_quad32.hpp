@@ -1,4 +1,4 @@
-// bign_quad.hpp -- one signature on FOUR adjacent lanes (a DPP quad): the point operations of bign_dev.hpp with the
+// bign_quad32.hpp -- one signature on FOUR adjacent lanes (a DPP quad): the point operations of bign_dev.hpp with the
 // field multiplications of one dependency level spread over the lanes of the quad.
 //
 // Why (DESIGN.md 4.3 "latency floor"): v Q needs 32N dependent doublings, and with one lane per

@@ -1,14 +1,14 @@
 // Micro-benchmark: the dependent doubling / addition chain of v Q (4 doublings + 1 addition per digit) with one
 // lane per point (jac_dbl / jac_madd of bign_dev.hpp) against four lanes per point (quad_dbl / quad_add of
-// bign_quad.hpp), on wavefronts that are ALONE on their SIMD -- the regime of a small verification batch.
-// Build: hipcc --offload-arch=gfx950 -O3 -I bee2_amd/csrc -I include tools/ubench/quad_dbl.hip -o tools/ubench/quad_dbl
+// bign_quad32.hpp beside this file), on wavefronts that are ALONE on their SIMD -- the regime of a small verification batch.
+// Build: hipcc --offload-arch=gfx950 -O3 -I bee2_amd/csrc -I include -I tools/ubench tools/ubench/quad_dbl.hip -o tools/ubench/quad_dbl
 // Run on the GPU: ./quad_dbl   (prints shader cycles per digit and checks that both chains reach the same point)
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "bign_quad.hpp"
+#include "bign_quad32.hpp"
 #include "bign_fe29.hpp"
 #include "bign_quad29.hpp"
 #include "bign_curves.inc"
