@@ -10,8 +10,10 @@
 // x0.98-0.99 at 2 and 4 (there the half-rate instructions decide and the two forms tie) -- so this form serves the
 // small batches only (bign_main29_kernel) and the 32-bit form stays the throughput path.
 //
-// Representation: value = sum l[i] 2^(29 i), i = 0..8, limbs int32, any value (positive or negative) congruent to
-// the residue.  2^261 = 2^5 * 2^256 = 6048 (mod p).  "u" below = 2^29.
+// Representation: value = sum l[i] 2^(B i), i = 0..L-1, limbs int32, any value (positive or negative) congruent to
+// the residue; p = 2^(32N) - c.  256-bit curve (the graded one, after which the file is named): L = 9, B = 29,
+// 2^261 = 2^5 * 2^256 = 6048 (mod p).  384-bit: L = 14, B = 28, 2^392 = 2^8 * 317.  512-bit: L = 19, B = 27,
+// 2^513 = 2 * 569 (template LZ<N>).  "u" below = 2^B.
 //   N  (normalised) : output of f29_mul / f29_sqr / f29_carry: l[2..8] in [0, u), l[1] within 2 and l[0] within 2^16 of [0, u)
 //   L1 (lazy)       : |l[i]| <= u + 2^16: a difference of two N values, or the negation of one
 // Additions and subtractions are limb-wise with no carries at all; a multiplication accepts operands whose limb
@@ -23,154 +25,203 @@
 
 namespace bee2hip {
 
-struct fe29 { int32_t l[9]; };
+// limb layout per curve: L limbs of B bits, TOP = bits of the value that the last limb holds below 2^(32N),
+// FOLD = 2^(B L) mod p
+template <int N> struct LZ;
+template <> struct LZ<8> { static constexpr int L = 9, B = 29, TOP = 24; static constexpr int32_t FOLD = 189 << 5; };
+template <> struct LZ<12> { static constexpr int L = 14, B = 28, TOP = 20; static constexpr int32_t FOLD = 317 << 8; };
+template <> struct LZ<16> { static constexpr int L = 19, B = 27, TOP = 26; static constexpr int32_t FOLD = 569 << 1; };
+
+template <int N> struct lzT {
+    static constexpr int L = LZ<N>::L, B = LZ<N>::B;
+    static constexpr int32_t M = (1 << LZ<N>::B) - 1;
+    int32_t l[LZ<N>::L];
+};
+typedef lzT<8> fe29;
 constexpr int32_t F29_M = (1 << 29) - 1;
 constexpr int32_t F29_FOLD = 189 * 32;                  // 2^261 mod p
 
-// 8 x 32-bit words (any value < 2^256) -> N
-__device__ __forceinline__ void f29_from_words(fe29 &r, const feT<8> &a)
+// N x 32-bit words (any value < 2^(32N)) -> N
+template <int N>
+__device__ __forceinline__ void f29_from_words(lzT<N> &r, const feT<N> &a)
 {
+    constexpr int L = LZ<N>::L, B = LZ<N>::B;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const int bit = 29 * i, w = bit >> 5, sh = bit & 31;
-        const uint32_t lo = a.v[w], hi = w + 1 < 8 ? a.v[w + 1] : 0u;
+    for (int i = 0; i < L; ++i) {
+        const int bit = B * i, w = bit >> 5, sh = bit & 31;
+        const uint32_t lo = a.v[w], hi = w + 1 < N ? a.v[w + 1] : 0u;
         const uint32_t x = sh ? __builtin_amdgcn_alignbit(hi, lo, sh) : lo;
-        r.l[i] = (int32_t)(x & (uint32_t)F29_M);
+        r.l[i] = (int32_t)(x & (uint32_t)lzT<N>::M);
     }
 }
 
-// one floor-carry pass, the carry out of limb 8 folded back into limb 0: |l[i]| < 4 u in, N out
-__device__ __forceinline__ void f29_carry(fe29 &a)
+// one floor-carry pass, the carry out of the last limb folded back into limb 0: |l[i]| < 4 u in, N out
+template <int N>
+__device__ __forceinline__ void f29_carry(lzT<N> &a)
 {
+    constexpr int L = LZ<N>::L, B = LZ<N>::B;
     int32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < L; ++i) {
         const int32_t t = a.l[i] + c;
-        a.l[i] = t & F29_M;
-        c = t >> 29;
+        a.l[i] = t & lzT<N>::M;
+        c = t >> B;
     }
-    a.l[0] += c * F29_FOLD;
+    a.l[0] += c * LZ<N>::FOLD;
 }
 
-__device__ __forceinline__ void f29_add(fe29 &r, const fe29 &a, const fe29 &b)
+template <int N>
+__device__ __forceinline__ void f29_add(lzT<N> &r, const lzT<N> &a, const lzT<N> &b)
 {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
+    for (int i = 0; i < LZ<N>::L; ++i) r.l[i] = a.l[i] + b.l[i];
 }
-__device__ __forceinline__ void f29_sub(fe29 &r, const fe29 &a, const fe29 &b)
+template <int N>
+__device__ __forceinline__ void f29_sub(lzT<N> &r, const lzT<N> &a, const lzT<N> &b)
 {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] - b.l[i];
+    for (int i = 0; i < LZ<N>::L; ++i) r.l[i] = a.l[i] - b.l[i];
 }
-__device__ __forceinline__ void f29_neg(fe29 &r, const fe29 &a)
+template <int N>
+__device__ __forceinline__ void f29_neg(lzT<N> &r, const lzT<N> &a)
 {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) r.l[i] = -a.l[i];
+    for (int i = 0; i < LZ<N>::L; ++i) r.l[i] = -a.l[i];
+}
+template <int N>
+__device__ __forceinline__ void f29_set_one(lzT<N> &r)
+{
+#pragma unroll
+    for (int i = 0; i < LZ<N>::L; ++i) r.l[i] = i == 0;
 }
 
-// c[0..17] (c[k] in [0, u) for k < 17, c[17] signed) -> r = K (lo + 2^261 hi), N
-template <int K>
-__device__ __forceinline__ void f29_fold(fe29 &r, const int32_t (&c)[18])
+// c[0 .. 2L) (c[k] in [0, u) for k < 2L - 1, the last one signed) -> r = K (lo + 2^(B L) hi), N; K may be a per-lane value
+template <int N>
+__device__ __forceinline__ void f29_fold_k(lzT<N> &r, const int32_t (&c)[2 * LZ<N>::L], int32_t K, bool k_is_one)
 {
+    constexpr int L = LZ<N>::L, B = LZ<N>::B;
+    const int32_t KF = K * LZ<N>::FOLD;                // <= 8 * 81152
     int64_t cy = 0;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        int64_t t = (int64_t)c[9 + j] * (int64_t)(F29_FOLD * K) + cy;
-        if (K == 1) t += c[j];
+    for (int j = 0; j < L; ++j) {
+        int64_t t = (int64_t)c[L + j] * KF + cy;
+        if (k_is_one) t += c[j];
         else t += (int64_t)c[j] * K;
-        r.l[j] = (int32_t)t & F29_M;
-        cy = t >> 29;
+        r.l[j] = (int32_t)t & lzT<N>::M;
+        cy = t >> B;
     }
-    // |cy| < 2^17: its weight is 2^261 again
-    const int32_t t0 = r.l[0] + (int32_t)cy * F29_FOLD;
-    r.l[0] = t0 & F29_M;
-    r.l[1] += t0 >> 29;
+    // |cy| < 2^21: its weight is 2^(B L) again
+    const int64_t t0 = (int64_t)r.l[0] + cy * LZ<N>::FOLD;
+    r.l[0] = (int32_t)t0 & lzT<N>::M;
+    r.l[1] += (int32_t)(t0 >> B);
 }
 
-template <int K = 1>
-__device__ __forceinline__ void f29_mul(fe29 &r, const fe29 &a, const fe29 &b)
+template <int N>
+__device__ __forceinline__ void f29_product(int32_t (&c)[2 * LZ<N>::L], const lzT<N> &a, const lzT<N> &b)
 {
-    int32_t c[18];
+    constexpr int L = LZ<N>::L, B = LZ<N>::B;
     int64_t acc = 0;
-    static_for<0, 17>([&](auto kc) __attribute__((always_inline)) {
+    static_for<0, 2 * L - 1>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
-        static_for<(k > 8 ? k - 8 : 0), (k < 8 ? k : 8) + 1>([&](auto ic) __attribute__((always_inline)) {
+        static_for<(k > L - 1 ? k - (L - 1) : 0), (k < L - 1 ? k : L - 1) + 1>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
             acc += (int64_t)a.l[i] * b.l[k - i];
         });
-        c[k] = (int32_t)acc & F29_M;
-        acc >>= 29;
+        c[k] = (int32_t)acc & lzT<N>::M;
+        acc >>= B;
     });
-    c[17] = (int32_t)acc;
-    f29_fold<K>(r, c);
+    c[2 * L - 1] = (int32_t)acc;
 }
 
-template <int K = 1>
-__device__ __forceinline__ void f29_sqr(fe29 &r, const fe29 &a)
+template <int K = 1, int N>
+__device__ __forceinline__ void f29_mul(lzT<N> &r, const lzT<N> &a, const lzT<N> &b)
 {
-    int32_t c[18], d[9];
+    int32_t c[2 * LZ<N>::L];
+    f29_product(c, a, b);
+    f29_fold_k(r, c, K, K == 1);
+}
+// r = K a b with a per-lane K in {1, 2, 3, 4, 8}
+template <int N>
+__device__ __forceinline__ void f29_mul_k(lzT<N> &r, const lzT<N> &a, const lzT<N> &b, int32_t K)
+{
+    int32_t c[2 * LZ<N>::L];
+    f29_product(c, a, b);
+    f29_fold_k(r, c, K, false);
+}
+
+template <int K = 1, int N>
+__device__ __forceinline__ void f29_sqr(lzT<N> &r, const lzT<N> &a)
+{
+    constexpr int L = LZ<N>::L, B = LZ<N>::B;
+    int32_t c[2 * L], d[L];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) d[i] = a.l[i] * 2;
+    for (int i = 0; i < L; ++i) d[i] = a.l[i] * 2;
     int64_t acc = 0;
-    static_for<0, 17>([&](auto kc) __attribute__((always_inline)) {
+    static_for<0, 2 * L - 1>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
-        static_for<(k > 8 ? k - 8 : 0), (k < 8 ? k : 8) + 1>([&](auto ic) __attribute__((always_inline)) {
+        static_for<(k > L - 1 ? k - (L - 1) : 0), (k < L - 1 ? k : L - 1) + 1>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
             constexpr int j = k - i;
             if constexpr (i < j) acc += (int64_t)a.l[i] * d[j];
             else if constexpr (i == j) acc += (int64_t)a.l[i] * a.l[i];
         });
-        c[k] = (int32_t)acc & F29_M;
-        acc >>= 29;
+        c[k] = (int32_t)acc & lzT<N>::M;
+        acc >>= B;
     });
-    c[17] = (int32_t)acc;
-    f29_fold<K>(r, c);
+    c[2 * L - 1] = (int32_t)acc;
+    f29_fold_k(r, c, K, K == 1);
 }
 
-// any |l[i]| < 4 u -> 8 x 32-bit words, weakly reduced (a value in [0, 2^256) congruent to the residue), exactly
-__device__ __forceinline__ void f29_to_words(feT<8> &r, fe29 a)
+// any |l[i]| < 4 u -> N x 32-bit words, weakly reduced (a value in [0, 2^(32N)) congruent to the residue), exactly
+template <int N>
+__device__ __forceinline__ void f29_to_words(feT<N> &r, lzT<N> a)
 {
-    f29_carry(a);                                   // N: value in (-2^16, 2^261 + 2^17)
-    // + p (limbs of 2^256 - 189) makes the value positive; carry without wrap (limb 8 keeps what is above 2^232)
+    constexpr int L = LZ<N>::L, B = LZ<N>::B, TOP = LZ<N>::TOP;
+    constexpr int32_t M = lzT<N>::M, C = (int32_t)CurveC<N>::C, TM = (1 << TOP) - 1;
+    f29_carry(a);                                   // N: value in (-2^20, 2^(B L) + 2^20)
+    // + p (limbs of 2^(32N) - c) makes the value positive; carry without wrap (the last limb keeps what is above its TOP bits)
     int32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const int32_t pi = i == 0 ? F29_M + 1 - 189 : i < 8 ? F29_M : (1 << 24) - 1;
+    for (int i = 0; i < L; ++i) {
+        const int32_t pi = i == 0 ? M + 1 - C : i < L - 1 ? M : TM;
         const int32_t t = a.l[i] + pi + c;
-        if (i < 8) { a.l[i] = t & F29_M; c = t >> 29; }
-        else a.l[i] = t;                            // in [0, 2^29 + 2^24]
-    }
-    // fold the bits from 2^256 up (limb 8 holds bits 232..): top < 64
-    int32_t top = a.l[8] >> 24;
-    a.l[8] &= (1 << 24) - 1;
-    c = top * 189;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const int32_t t = a.l[i] + c;
-        if (i < 8) { a.l[i] = t & F29_M; c = t >> 29; }
+        if (i < L - 1) { a.l[i] = t & M; c = t >> B; }
         else a.l[i] = t;
     }
-    // a second wrap leaves a value below 64 * 189 + 189: no further carry
-    top = a.l[8] >> 24;
-    a.l[8] &= (1 << 24) - 1;
-    a.l[0] += top * 189;
+    // fold the bits from 2^(32N) up
+    int32_t top = a.l[L - 1] >> TOP;
+    a.l[L - 1] &= TM;
+    c = top * C;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        const int lo = 32 * w / 29, sh = 32 * w % 29;
+    for (int i = 0; i < L; ++i) {
+        const int32_t t = a.l[i] + c;
+        if (i < L - 1) { a.l[i] = t & M; c = t >> B; }
+        else a.l[i] = t;
+    }
+    // a second wrap leaves a value below (2^(B - TOP) + 2) c: no further carry
+    top = a.l[L - 1] >> TOP;
+    a.l[L - 1] &= TM;
+    a.l[0] += top * C;
+#pragma unroll
+    for (int w = 0; w < N; ++w) {
+        const int lo = 32 * w / B, sh = 32 * w % B;
         uint64_t v = (uint64_t)(uint32_t)a.l[lo] >> sh;
-        v |= (uint64_t)(uint32_t)a.l[lo + 1] << (29 - sh);
-        if (lo + 2 < 9 && 58 - sh < 32) v |= (uint64_t)(uint32_t)a.l[lo + 2] << (58 - sh);
+        v |= (uint64_t)(uint32_t)a.l[lo + 1] << (B - sh);
+        if (lo + 2 < L && 2 * B - sh < 32) v |= (uint64_t)(uint32_t)a.l[lo + 2] << (2 * B - sh);
         r.v[w] = (uint32_t)v;
     }
 }
 
-struct jac29 { fe29 X, Y, Z; };                    // X, Z: N; Y: L1
-struct aff29 { fe29 x, y; };                       // x: N; y: N or L1 (negated table entry)
+template <int N> struct ljacT { lzT<N> X, Y, Z; };         // X, Z: N; Y: L1
+template <int N> struct laffT { lzT<N> x, y; };            // x: N; y: N or L1 (negated table entry)
+typedef ljacT<8> jac29;
+typedef laffT<8> aff29;
 
 // T <- 2T (jac_dbl of bign_dev.hpp, same formulas).  Bounds in units of u:
-__device__ __forceinline__ void jac29_dbl(jac29 &T)
+template <int N>
+__device__ __forceinline__ void jac29_dbl(ljacT<N> &T)
 {
-    fe29 delta, gamma, beta4, alpha, t0, t1;
+    lzT<N> delta, gamma, beta4, alpha, t0, t1;
     f29_sqr(delta, T.Z);                            // N
     f29_sqr(gamma, T.Y);                            // 1 x 1
     f29_mul<4>(beta4, T.X, gamma);                  // 4 X Y^2
@@ -190,9 +241,10 @@ __device__ __forceinline__ void jac29_dbl(jac29 &T)
 
 // T <- T + E, E affine (jac_madd).  Exceptional cases (T = O, T = +-E) are NOT flagged here: each of them makes
 // Z3 = Z1 H = 0, every later Z is a multiple of it, and the caller tests the final Z once.
-__device__ __forceinline__ void jac29_madd(jac29 &T, const aff29 &E)
+template <int N>
+__device__ __forceinline__ void jac29_madd(ljacT<N> &T, const laffT<N> &E)
 {
-    fe29 Z1Z1, U2, S2, H, HH, HHH, r, V, t;
+    lzT<N> Z1Z1, U2, S2, H, HH, HHH, r, V, t;
     f29_sqr(Z1Z1, T.Z);
     f29_mul(U2, E.x, Z1Z1);
     f29_mul(t, T.Z, Z1Z1);

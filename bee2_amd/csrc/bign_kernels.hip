@@ -429,8 +429,7 @@ void bign_main29_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gta
     load_qaff(E, S, (int)(w[NW - 1] & 15u) - 9, idx);       // top digit: 1 or 2
     f29_from_words(T.X, E.x);
     f29_from_words(T.Y, E.y);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) T.Z.l[i] = i == 0;
+    f29_set_one(T.Z);
     feT<N> u;
     load_soa(u, S.u, S.n_pad, idx);
 
@@ -487,13 +486,13 @@ void bign_main29_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gta
 // wavefronts on a SIMD: 718 us against the 370 us of a lone wavefront; pairs keep one wavefront per SIMD up to 2^15).
 // WG = 64 (one wavefront) up to 2^13 signatures; 256 above, so that the four wavefronts of a workgroup land on the
 // four SIMDs of a CU.  LDS: 1152 B per signature.
-template <int WG, int LANES>
+template <int N, int WG, int LANES>
 __global__ __launch_bounds__(WG)
 void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
                         const uint8_t *__restrict__ pubkeys, size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
 {
-    constexpr int N = 8, NW = N / 2 + 1, W = Comb<N>::W, NS = WG / LANES;
-    extern __shared__ int32_t s_tab[];              // [8 entries][X, Y, Z, ZZ][9 limbs][NS signatures]
+    constexpr int NW = N / 2 + 1, W = Comb<N>::W, NS = WG / LANES, L = LZ<N>::L;
+    extern __shared__ int32_t s_tab[];              // [8 entries][X, Y, Z, ZZ][L limbs][NS signatures]
     const uint32_t q = threadIdx.x % LANES, sl = threadIdx.x / LANES;
     const size_t idx = (size_t)blockIdx.x * NS + sl;
     if (idx >= n) return;                           // whole quads leave together
@@ -504,32 +503,32 @@ void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
 
     // the lanes of a signature share the writes: lane q owns field element q (X, Y, Z, ZZ) of every table entry
     // (a pair: q and q + 2)
-    const auto put = [&](int e, const qjac29 &P) {
+    const auto put = [&](int e, const lqjacT<N> &P) {
 #pragma unroll
         for (int k = 0; k < 4 / LANES; ++k) {
             const int fi = (int)q + LANES * k;
-            const fe29 &f = fi == 0 ? P.X : fi == 1 ? P.Y : fi == 2 ? P.Z : P.D;
+            const lzT<N> &f = fi == 0 ? P.X : fi == 1 ? P.Y : fi == 2 ? P.Z : P.D;
 #pragma unroll
-            for (int l = 0; l < 9; ++l) s_tab[((e * 4 + fi) * 9 + l) * NS + sl] = f.l[l];
+            for (int l = 0; l < L; ++l) s_tab[((e * 4 + fi) * L + l) * NS + sl] = f.l[l];
         }
     };
-    const auto dbl = [&](qjac29 &P) { if constexpr (LANES == 4) quad29_dbl(P, q); else pair29_dbl(P, q); };
-    const auto add = [&](qjac29 &P, const qent29 &Q2) { if constexpr (LANES == 4) quad29_add(P, Q2, q); else pair29_add(P, Q2, q); };
-    const auto get = [&](qent29 &E, int e) {
-        const int32_t *b = s_tab + (size_t)e * 4 * 9 * NS + sl;
+    const auto dbl = [&](lqjacT<N> &P) { if constexpr (LANES == 4) quad29_dbl(P, q); else pair29_dbl(P, q); };
+    const auto add = [&](lqjacT<N> &P, const lqentT<N> &Q2) { if constexpr (LANES == 4) quad29_add(P, Q2, q); else pair29_add(P, Q2, q); };
+    const auto get = [&](lqentT<N> &E, int e) {
+        const int32_t *b = s_tab + (size_t)e * 4 * L * NS + sl;
 #pragma unroll
-        for (int l = 0; l < 9; ++l) {
-            E.X.l[l] = b[(0 * 9 + l) * NS]; E.Y.l[l] = b[(1 * 9 + l) * NS];
-            E.Z.l[l] = b[(2 * 9 + l) * NS]; E.ZZ.l[l] = b[(3 * 9 + l) * NS];
+        for (int l = 0; l < L; ++l) {
+            E.X.l[l] = b[(0 * L + l) * NS]; E.Y.l[l] = b[(1 * L + l) * NS];
+            E.Z.l[l] = b[(2 * L + l) * NS]; E.ZZ.l[l] = b[(3 * L + l) * NS];
         }
     };
 
-    qent29 E;                                       // Q as a table entry: affine
+    lqentT<N> E;                                    // Q as a table entry: affine
     f29_from_words(E.X, Q.x);
     f29_from_words(E.Y, Q.y);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) E.Z.l[i] = E.ZZ.l[i] = i == 0;
-    qjac29 A, T, Wk;
+    f29_set_one(E.Z);
+    f29_set_one(E.ZZ);
+    lqjacT<N> A, T, Wk;
     A.X = E.X; A.Y = E.Y; A.Z = E.Z; A.D = E.Z;
     T = A;
     put(0, A);
@@ -583,8 +582,8 @@ void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
                 load_aff(G, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
                 f29_from_words(E.X, G.x);
                 f29_from_words(E.Y, G.y);
-#pragma unroll
-                for (int i = 0; i < 9; ++i) E.Z.l[i] = E.ZZ.l[i] = i == 0;
+                f29_set_one(E.Z);
+                f29_set_one(E.ZZ);
             }
         }
         if (have) add(T, E);
@@ -895,49 +894,58 @@ __global__ void bign_debug_fe_kernel(int op, const uint32_t *a, const uint32_t *
         for (int i = 0; i < N; ++i) { w[i] = x.v[i]; w[N + i] = y.v[i]; }
         if (op == 9) fe_reduce<1>(r, w); else fe_reduce<3>(r, w);
     } break;
-    case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28:
-        if constexpr (N == 8) {           // the 29-bit-limb forms of bign_fe29.hpp (256-bit curve only)
-            fe29 a29, b29, r29, t29;
-            f29_from_words(a29, x);
-            f29_from_words(b29, y);
-            switch (op) {
-            case 20: f29_mul(r29, a29, b29); break;
-            case 21: f29_sqr(r29, a29); break;
-            case 22: f29_mul<3>(r29, a29, b29); break;
-            case 23: f29_sqr<8>(r29, a29); break;
-            case 24: f29_sub(r29, a29, b29); break;                                          // lazy, straight out
-            case 25: f29_sub(t29, a29, b29); f29_add(r29, a29, b29); f29_mul<3>(r29, t29, r29); break;   // 3 (a-b)(a+b)
-            case 26: f29_sub(t29, a29, b29); f29_sub(t29, t29, b29); f29_sub(t29, t29, b29); f29_carry(t29);
-                     f29_neg(r29, b29); f29_mul<4>(r29, t29, r29); break;                    // 4 (a - 3b)(-b)
-            case 27: f29_sub(t29, a29, b29); f29_sqr<8>(r29, t29); break;                     // 8 (a-b)^2
-            default: f29_add(t29, a29, b29); f29_sub(r29, a29, b29); f29_mul<2>(r29, r29, t29);
-                     f29_sub(r29, r29, a29); f29_sub(r29, r29, a29); f29_sub(r29, r29, a29); break;  // 2(a-b)(a+b) - 3a
-            }
-            f29_to_words(r, r29);
-        } else {
-            r = x;
+    case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: {
+        // the lazy-limb forms of bign_fe29.hpp (29 / 28 / 27-bit limbs on the three curves)
+        lzT<N> a29, b29, r29, t29;
+        f29_from_words(a29, x);
+        f29_from_words(b29, y);
+        switch (op) {
+        case 20: f29_mul(r29, a29, b29); break;
+        case 21: f29_sqr(r29, a29); break;
+        case 22: f29_mul<3>(r29, a29, b29); break;
+        case 23: f29_sqr<8>(r29, a29); break;
+        case 24: f29_sub(r29, a29, b29); break;                                          // lazy, straight out
+        case 25: f29_sub(t29, a29, b29); f29_add(r29, a29, b29); f29_mul<3>(r29, t29, r29); break;   // 3 (a-b)(a+b)
+        case 26: f29_sub(t29, a29, b29); f29_sub(t29, t29, b29); f29_sub(t29, t29, b29); f29_carry(t29);
+                 f29_neg(r29, b29); f29_mul<4>(r29, t29, r29); break;                    // 4 (a - 3b)(-b)
+        case 27: f29_sub(t29, a29, b29); f29_sqr<8>(r29, t29); break;                     // 8 (a-b)^2
+        default: f29_add(t29, a29, b29); f29_sub(r29, a29, b29); f29_mul<2>(r29, r29, t29);
+                 f29_sub(r29, r29, a29); f29_sub(r29, r29, a29); f29_sub(r29, r29, a29); break;  // 2(a-b)(a+b) - 3a
         }
-        break;
-    case 29: case 30:
-        if constexpr (N == 8) {           // point doubling / addition in the 29-bit form: affine x of 2P / of 2P + P
-            jac29 T;
+        f29_to_words(r, r29);
+    } break;
+    case 29: case 30: case 31: case 32: {
+        // point doubling / addition in the lazy-limb forms: affine x of 2P (29: one lane, 31: quad) / of 2P + P (30, 32)
+        feT<N> X, Z;
+        if (op <= 30) {
+            ljacT<N> T;
             f29_from_words(T.X, x);
             f29_from_words(T.Y, y);
-            for (int i = 0; i < 9; ++i) T.Z.l[i] = i == 0;
-            aff29 E;
+            f29_set_one(T.Z);
+            laffT<N> E;
             E.x = T.X; E.y = T.Y;
             jac29_dbl(T);
             if (op == 30) jac29_madd(T, E);
-            feT<N> X, Z;
             f29_to_words(X, T.X);
             f29_to_words(Z, T.Z);
-            feT<N> zi = fe_inv(Z);
-            fe_sqr(zi, zi);
-            fe_mul(r, X, zi);
         } else {
-            r = x;
+            // every quad of the launch works on the point of its FIRST lane (the test repeats each point four times)
+            lqjacT<N> T;
+            f29_from_words(T.X, x);
+            f29_from_words(T.Y, y);
+            f29_set_one(T.Z);
+            f29_set_one(T.D);
+            lqentT<N> E;
+            E.X = T.X; E.Y = T.Y; E.Z = T.Z; E.ZZ = T.Z;
+            quad29_dbl(T, (uint32_t)threadIdx.x & 3u);
+            if (op == 32) quad29_add(T, E, (uint32_t)threadIdx.x & 3u);
+            f29_to_words(X, T.X);
+            f29_to_words(Z, T.Z);
         }
-        break;
+        feT<N> zi = fe_inv(Z);
+        fe_sqr(zi, zi);
+        fe_mul(r, X, zi);
+    } break;
     default: {
         jacT<N> P; P.X = x; P.Y = y; fe_set_one(P.Z);
         jac_dbl(P);
@@ -1056,33 +1064,38 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
     const unsigned g256 = (unsigned)((n + 255) / 256), g64 = (unsigned)((n + 63) / 64);
     const size_t sp = n >= ((size_t)1 << 18) ? 2 : 1;     // signatures per lane in prep (shared inversion)
     const size_t plan = (n + sp - 1) / sp;
-    // Which kernels walk the scalar multiplication (256-bit curve; g_verify_path: 0 by size, 1 always the 32-bit
+    // Which kernels walk the scalar multiplication (g_verify_path: 0 by size, 1 always the 32-bit
     // kernels, 2 the 29-bit main kernel, 3 the quad / pair kernel, + 16 x lanes to force quads (0x43) or pairs (0x23)
     // -- tests and A/B):
     //   <= 2^14 signatures: one signature per quad, 29-bit limbs (prep + main in one kernel, no table inversion)
-    //   <= 2^15           : one signature per pair of lanes, same kernel
+    //   <= 2^15           : one signature per pair of lanes, same kernel (256-bit curve; the wider ones use quads up
+    //                       to 2^14 and the 32-bit kernels above: 28- / 27-bit limbs, LZ<N>)
     //   <= 2^16           : one lane per signature, 29-bit limbs (at most one wavefront per SIMD: instruction count)
     //   above             : one lane per signature, 32-bit limbs (the throughput form)
     int path = 1;
-    if constexpr (N == 8) {
-        path = g_verify_path ? g_verify_path : n <= ((size_t)1 << 15) ? 3 : n <= ((size_t)1 << 16) ? 2 : 1;
-        if (path == 3) {
-            const auto launch = [&](auto kern, unsigned wg, unsigned lanes) -> err_t {
-                const unsigned ns = wg / lanes;
-                const size_t lds = (size_t)8 * 4 * 9 * ns * 4;
-                if (lds > 48 * 1024)
-                    B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(kern, dim3((unsigned)((n + ns - 1) / ns)), dim3(wg), lds, st, (const uint8_t *)d_hashes,
-                                   (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S, (const uint4 *)gtab);
-                return ERR_OK;
-            };
-            const int lanes = g_verify_lanes ? g_verify_lanes : n <= ((size_t)1 << 14) ? 4 : 2;
-            if (lanes == 2) code = launch(bign_quad29_kernel<256, 2>, 256, 2);
-            else if (n <= ((size_t)1 << 13)) code = launch(bign_quad29_kernel<64, 4>, 64, 4);
-            else code = launch(bign_quad29_kernel<256, 4>, 256, 4);
-            if (code != ERR_OK) return code;
+    if constexpr (N == 8) path = g_verify_path ? g_verify_path : n <= ((size_t)1 << 15) ? 3 : n <= ((size_t)1 << 16) ? 2 : 1;
+    else path = g_verify_path == 1 || g_verify_path == 3 ? g_verify_path : n <= ((size_t)1 << 14) ? 3 : 1;   // quads only
+    if (path == 3) {
+        const auto launch = [&](auto kern, unsigned wg, unsigned lanes) -> err_t {
+            const unsigned ns = wg / lanes;
+            const size_t lds = (size_t)8 * 4 * LZ<N>::L * ns * 4;
+            if (lds > 48 * 1024)
+                B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)((n + ns - 1) / ns)), dim3(wg), lds, st, (const uint8_t *)d_hashes,
+                               (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S, (const uint4 *)gtab);
+            return ERR_OK;
+        };
+        int lanes = 4;
+        if constexpr (N == 8) lanes = g_verify_lanes ? g_verify_lanes : n <= ((size_t)1 << 14) ? 4 : 2;
+        if constexpr (N == 8) {
+            if (lanes == 2) code = launch(bign_quad29_kernel<8, 256, 2>, 256, 2);
         }
+        if (lanes != 2) {
+            if (n <= ((size_t)1 << 13)) code = launch(bign_quad29_kernel<N, 64, 4>, 64, 4);
+            else code = launch(bign_quad29_kernel<N, 256, 4>, 256, 4);
+        }
+        if (code != ERR_OK) return code;
     }
     if (path != 3) {
         if (N != 8)

@@ -26,70 +26,50 @@ namespace bee2hip {
 //    depended on the schedule (the same source was right in the kernel and wrong in the micro-benchmark).
 // A block of nine moves behind one `s_nop 1` cannot be split, and its outputs are early-clobber because the inputs
 // are still being read while the first outputs are written.
-#define Q29_DPP9(CTRL)                                                                                                   \
-    asm volatile("s_nop 1\n\t"                                                                                           \
-                 "v_mov_b32_dpp %0, %9 " CTRL "\n\tv_mov_b32_dpp %1, %10 " CTRL "\n\tv_mov_b32_dpp %2, %11 " CTRL "\n\t"   \
-                 "v_mov_b32_dpp %3, %12 " CTRL "\n\tv_mov_b32_dpp %4, %13 " CTRL "\n\tv_mov_b32_dpp %5, %14 " CTRL "\n\t" \
-                 "v_mov_b32_dpp %6, %15 " CTRL "\n\tv_mov_b32_dpp %7, %16 " CTRL "\n\tv_mov_b32_dpp %8, %17 " CTRL         \
-                 : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]),  \
-                   "=&v"(r.l[7]), "=&v"(r.l[8])                                                                            \
-                 : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),  \
-                   "v"(a.l[8]))
-template <int K>
-__device__ __forceinline__ void q29_bcast(fe29 &r, const fe29 &a)
+#define Q29_BLK7(R, A, O, CTRL) \
+    asm volatile("s_nop 1\n\t" "v_mov_b32_dpp %0, %7 " CTRL "\n\t" "v_mov_b32_dpp %1, %8 " CTRL "\n\t" "v_mov_b32_dpp %2, %9 " CTRL "\n\t" "v_mov_b32_dpp %3, %10 " CTRL "\n\t" "v_mov_b32_dpp %4, %11 " CTRL "\n\t" "v_mov_b32_dpp %5, %12 " CTRL "\n\t" "v_mov_b32_dpp %6, %13 " CTRL "\n\t" "" : "=&v"((R)[(O) + 0]), "=&v"((R)[(O) + 1]), "=&v"((R)[(O) + 2]), "=&v"((R)[(O) + 3]), "=&v"((R)[(O) + 4]), "=&v"((R)[(O) + 5]), "=&v"((R)[(O) + 6]) : "v"((A)[(O) + 0]), "v"((A)[(O) + 1]), "v"((A)[(O) + 2]), "v"((A)[(O) + 3]), "v"((A)[(O) + 4]), "v"((A)[(O) + 5]), "v"((A)[(O) + 6]))
+#define Q29_BLK9(R, A, O, CTRL) \
+    asm volatile("s_nop 1\n\t" "v_mov_b32_dpp %0, %9 " CTRL "\n\t" "v_mov_b32_dpp %1, %10 " CTRL "\n\t" "v_mov_b32_dpp %2, %11 " CTRL "\n\t" "v_mov_b32_dpp %3, %12 " CTRL "\n\t" "v_mov_b32_dpp %4, %13 " CTRL "\n\t" "v_mov_b32_dpp %5, %14 " CTRL "\n\t" "v_mov_b32_dpp %6, %15 " CTRL "\n\t" "v_mov_b32_dpp %7, %16 " CTRL "\n\t" "v_mov_b32_dpp %8, %17 " CTRL "\n\t" "" : "=&v"((R)[(O) + 0]), "=&v"((R)[(O) + 1]), "=&v"((R)[(O) + 2]), "=&v"((R)[(O) + 3]), "=&v"((R)[(O) + 4]), "=&v"((R)[(O) + 5]), "=&v"((R)[(O) + 6]), "=&v"((R)[(O) + 7]), "=&v"((R)[(O) + 8]) : "v"((A)[(O) + 0]), "v"((A)[(O) + 1]), "v"((A)[(O) + 2]), "v"((A)[(O) + 3]), "v"((A)[(O) + 4]), "v"((A)[(O) + 5]), "v"((A)[(O) + 6]), "v"((A)[(O) + 7]), "v"((A)[(O) + 8]))
+#define Q29_BLK10(R, A, O, CTRL) \
+    asm volatile("s_nop 1\n\t" "v_mov_b32_dpp %0, %10 " CTRL "\n\t" "v_mov_b32_dpp %1, %11 " CTRL "\n\t" "v_mov_b32_dpp %2, %12 " CTRL "\n\t" "v_mov_b32_dpp %3, %13 " CTRL "\n\t" "v_mov_b32_dpp %4, %14 " CTRL "\n\t" "v_mov_b32_dpp %5, %15 " CTRL "\n\t" "v_mov_b32_dpp %6, %16 " CTRL "\n\t" "v_mov_b32_dpp %7, %17 " CTRL "\n\t" "v_mov_b32_dpp %8, %18 " CTRL "\n\t" "v_mov_b32_dpp %9, %19 " CTRL "\n\t" "" : "=&v"((R)[(O) + 0]), "=&v"((R)[(O) + 1]), "=&v"((R)[(O) + 2]), "=&v"((R)[(O) + 3]), "=&v"((R)[(O) + 4]), "=&v"((R)[(O) + 5]), "=&v"((R)[(O) + 6]), "=&v"((R)[(O) + 7]), "=&v"((R)[(O) + 8]), "=&v"((R)[(O) + 9]) : "v"((A)[(O) + 0]), "v"((A)[(O) + 1]), "v"((A)[(O) + 2]), "v"((A)[(O) + 3]), "v"((A)[(O) + 4]), "v"((A)[(O) + 5]), "v"((A)[(O) + 6]), "v"((A)[(O) + 7]), "v"((A)[(O) + 8]), "v"((A)[(O) + 9]))
+// L limbs through blocks of at most ten moves (an asm statement takes at most 30 operands): 9 = 9, 14 = 7 + 7, 19 = 10 + 9
+#define Q29_DPP_ALL(CTRL)                                                                       \
+    do {                                                                                        \
+        if constexpr (LZ<N>::L == 9) { Q29_BLK9(r.l, a.l, 0, CTRL); }                           \
+        else if constexpr (LZ<N>::L == 14) { Q29_BLK7(r.l, a.l, 0, CTRL); Q29_BLK7(r.l, a.l, 7, CTRL); } \
+        else { Q29_BLK10(r.l, a.l, 0, CTRL); Q29_BLK9(r.l, a.l, 10, CTRL); }                    \
+    } while (0)
+template <int K, int N>
+__device__ __forceinline__ void q29_bcast(lzT<N> &r, const lzT<N> &a)
 {
     static_assert(K >= 0 && K < 4, "lane of the quad");
-    if constexpr (K == 0) Q29_DPP9("quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1");
-    else if constexpr (K == 1) Q29_DPP9("quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1");
-    else if constexpr (K == 2) Q29_DPP9("quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1");
-    else Q29_DPP9("quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    static_assert(LZ<N>::L == 9 || LZ<N>::L == 14 || LZ<N>::L == 19, "limb counts the blocks are written for");
+    if constexpr (K == 0) Q29_DPP_ALL("quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    else if constexpr (K == 1) Q29_DPP_ALL("quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    else if constexpr (K == 2) Q29_DPP_ALL("quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    else Q29_DPP_ALL("quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1");
 }
-__device__ __forceinline__ void q29_pick(fe29 &r, bool p, const fe29 &a, const fe29 &b)
+template <int N>
+__device__ __forceinline__ void q29_pick(lzT<N> &r, bool p, const lzT<N> &a, const lzT<N> &b)
 {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) r.l[i] = p ? a.l[i] : b.l[i];
+    for (int i = 0; i < LZ<N>::L; ++i) r.l[i] = p ? a.l[i] : b.l[i];
 }
 
-// r = K a b with a per-lane K in {1, 2, 3, 4, 8}
-__device__ __forceinline__ void f29_mul_k(fe29 &r, const fe29 &a, const fe29 &b, int32_t K)
-{
-    int32_t c[18];
-    int64_t acc = 0;
-    static_for<0, 17>([&](auto kc) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
-        static_for<(k > 8 ? k - 8 : 0), (k < 8 ? k : 8) + 1>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            acc += (int64_t)a.l[i] * b.l[k - i];
-        });
-        c[k] = (int32_t)acc & F29_M;
-        acc >>= 29;
-    });
-    c[17] = (int32_t)acc;
-    const int32_t KF = K * F29_FOLD;
-    int64_t cy = 0;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        int64_t t = (int64_t)c[9 + j] * KF + cy;
-        t += (int64_t)c[j] * K;
-        r.l[j] = (int32_t)t & F29_M;
-        cy = t >> 29;
-    }
-    const int32_t t0 = r.l[0] + (int32_t)cy * F29_FOLD;
-    r.l[0] = t0 & F29_M;
-    r.l[1] += t0 >> 29;
-}
-
-struct qjac29 { fe29 X, Y, Z, D; };                // D = Z^2; X, Y: L1; Z, D: N; replicated in the quad
-struct qent29 { fe29 X, Y, Z, ZZ; };               // X, Y: L1; Z, ZZ = Z^2: N (affine: 1, 1)
+template <int N> struct lqjacT { lzT<N> X, Y, Z, D; };    // D = Z^2; X, Y: L1; Z, D: N; replicated in the quad
+template <int N> struct lqentT { lzT<N> X, Y, Z, ZZ; };   // X, Y: L1; Z, ZZ = Z^2: N (affine: 1, 1)
+typedef lqjacT<8> qjac29;
+typedef lqentT<8> qent29;
 
 // T <- 2T, a = -3, three levels.  Bounds in units of u = 2^29 (operand bounds of a product must multiply to <= 3):
 //   A: Y^2 | 2 Y Z | 3 X^2 | 3 D^2        (1 x 1 each)      alpha = 3 X^2 - 3 Z^4                      L1
 //   B: 4 X g | 8 X g | Z3^2 | alpha^2      (1 x 1 each)      X3 = alpha^2 - 8 X g                       L1
 //   C: alpha (4 X g - X3) | 8 g^2          (1 x 2, 1 x 1)    Y3 = ... - 8 g^2                           L1
-__device__ __forceinline__ void quad29_dbl(qjac29 &T, uint32_t q)
+template <int N>
+__device__ __forceinline__ void quad29_dbl(lqjacT<N> &T, uint32_t q)
 {
     const bool q0 = q == 0, q1 = q == 1, q2 = q == 2, lo = q < 2;
-    fe29 a, b, r, gamma, alpha, b4, t;
+    lzT<N> a, b, r, gamma, alpha, b4, t;
     // level A
     q29_pick(a, q2, T.X, T.D);
     q29_pick(a, lo, T.Y, a);
@@ -125,10 +105,11 @@ __device__ __forceinline__ void quad29_dbl(qjac29 &T, uint32_t q)
 //   2: Y2 Z1^3 | H^2 | Z1 Z2 | (Y1 ZZ2) Z2       r = S2 - S1 (L1)
 //   3: H H^2 | U1 H^2 | (Z1 Z2) H | r^2          X3 = r^2 - H^3 - 2V  ([-3, 1] -> carry -> N)
 //   4: r (V - X3) | S1 H^3 | Z3^2                Y3 (L1), D3
-__device__ __forceinline__ void quad29_add(qjac29 &T, const qent29 &E, uint32_t q)
+template <int N>
+__device__ __forceinline__ void quad29_add(lqjacT<N> &T, const lqentT<N> &E, uint32_t q)
 {
     const bool q0 = q == 0, q1 = q == 1, q2 = q == 2;
-    fe29 a, b, r, U1, S1, H, HH, rr, V, t;
+    lzT<N> a, b, r, U1, S1, H, HH, rr, V, t;
     // level 1
     q29_pick(a, q2, T.Z, T.Y);
     q29_pick(a, q1, E.X, a);
@@ -183,19 +164,20 @@ __device__ __forceinline__ void quad29_add(qjac29 &T, const qent29 &E, uint32_t 
 // Between 2^14 and 2^15 signatures quads would already share SIMDs (two wavefronts each); a PAIR of lanes per
 // signature keeps one wavefront per SIMD there.  Same formulas and bounds, two multiplications per level: a doubling
 // is five levels (two of them pure squarings), a general addition eight.
-template <int K>
-__device__ __forceinline__ void p29_bcast(fe29 &r, const fe29 &a)      // a from lane K of the pair
+template <int K, int N>
+__device__ __forceinline__ void p29_bcast(lzT<N> &r, const lzT<N> &a)      // a from lane K of the pair
 {
     static_assert(K == 0 || K == 1, "lane of the pair");
-    if constexpr (K == 0) Q29_DPP9("quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1");
-    else Q29_DPP9("quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    if constexpr (K == 0) Q29_DPP_ALL("quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    else Q29_DPP_ALL("quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1");
 }
 
 //   1: Y^2 | 2 Y Z      2: 3 X^2 | 3 D^2      3: 4 X g | 8 X g      4: alpha^2 | Z3^2      5: alpha (4 X g - X3) | 8 g^2
-__device__ __forceinline__ void pair29_dbl(qjac29 &T, uint32_t p)
+template <int N>
+__device__ __forceinline__ void pair29_dbl(lqjacT<N> &T, uint32_t p)
 {
     const bool p0 = p == 0;
-    fe29 a, b, r, gamma, alpha, b4, t;
+    lzT<N> a, b, r, gamma, alpha, b4, t;
     q29_pick(b, p0, T.Y, T.Z);
     f29_mul_k(r, T.Y, b, p0 ? 1 : 2);
     p29_bcast<0>(gamma, r);
@@ -224,10 +206,11 @@ __device__ __forceinline__ void pair29_dbl(qjac29 &T, uint32_t p)
 
 //   1: X1 ZZ2 | X2 D      2: Z1 D | Y1 ZZ2      3: Y2 Z1^3 | (Y1 ZZ2) Z2      4: H^2 | Z1 Z2
 //   5: H H^2 | U1 H^2     6: r^2 | (Z1 Z2) H    7: r (V - X3) | S1 H^3        8: Z3^2 (both lanes)
-__device__ __forceinline__ void pair29_add(qjac29 &T, const qent29 &E, uint32_t p)
+template <int N>
+__device__ __forceinline__ void pair29_add(lqjacT<N> &T, const lqentT<N> &E, uint32_t p)
 {
     const bool p0 = p == 0;
-    fe29 a, b, r, U1, S1, H, HH, rr, V, t, w;
+    lzT<N> a, b, r, U1, S1, H, HH, rr, V, t, w;
     q29_pick(a, p0, T.X, E.X);
     q29_pick(b, p0, E.ZZ, T.D);
     f29_mul(r, a, b);

@@ -13,6 +13,7 @@ def test_fe29_formulas_stay_inside_their_bounds():
 
 def test_fe29_bound_checker_catches_an_overflow():
     """the checker is not vacuous: a product of two sums of two normalised values (4 u^2 per term) must trip it"""
+    fe29_bounds.configure(8)                        # the tightest layout: 9 x 29 bits
     n = fe29_bounds.norm()
     s = fe29_bounds.add(n, n)
     try:

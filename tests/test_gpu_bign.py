@@ -49,47 +49,76 @@ def test_field_ops_vs_python_ints():
         assert got == want, f"field op {op}"
 
 
-def _limb_patterns(rnd):
-    """256-bit values whose 29-bit limbs sit at the corners the carry-free accumulation has to survive"""
-    M = (1 << 29) - 1
+LAZY = {128: (9, 29, 189), 192: (14, 28, 317), 256: (19, 27, 569)}      # limbs, bits per limb, c of p = 2^(2l) - c
+
+
+def _fe_run_l(eng, l, op, A, B):
+    nb = l // 4
+    ta = dev(b"".join(x.to_bytes(nb, "little") for x in A))
+    tb = dev(b"".join(x.to_bytes(nb, "little") for x in B))
+    out = torch.empty_like(ta)
+    code = eng.lib.bee2hip_debug_feL(ctypes.c_size_t(l), op, ctypes.c_void_p(ta.data_ptr()), ctypes.c_void_p(tb.data_ptr()),
+                                     ctypes.c_void_p(out.data_ptr()), ctypes.c_size_t(len(A)), None)
+    assert code == 0
+    torch.cuda.synchronize()
+    raw = host(out)
+    return [int.from_bytes(raw[i:i + nb], "little") for i in range(0, len(raw), nb)]
+
+
+def _limb_patterns(rnd, l):
+    """2l-bit values whose lazy limbs sit at the corners the carry-free accumulation has to survive"""
+    L, Bb, _ = LAZY[l]
+    M = (1 << Bb) - 1
+    mask = (1 << (2 * l)) - 1
     vals = []
-    for pat in ([M] * 9, [0] * 9, [M, 0] * 5, [0, M] * 5, [1] * 9, [M - 1] * 9, [M] + [0] * 8, [0] * 8 + [M]):
-        vals.append(sum(l << (29 * i) for i, l in enumerate(pat[:9])) & ((1 << 256) - 1))
+    for pat in ([M] * L, [0] * L, [M, 0] * L, [0, M] * L, [1] * L, [M - 1] * L, [M] + [0] * (L - 1), [0] * (L - 1) + [M]):
+        vals.append(sum(x << (Bb * i) for i, x in enumerate(pat[:L])) & mask)
     for _ in range(64):
-        limbs = [rnd.choice([0, 1, M, M - 1, rnd.getrandbits(29)]) for _ in range(9)]
-        vals.append(sum(l << (29 * i) for i, l in enumerate(limbs)) & ((1 << 256) - 1))
+        limbs = [rnd.choice([0, 1, M, M - 1, rnd.getrandbits(Bb)]) for _ in range(L)]
+        vals.append(sum(x << (Bb * i) for i, x in enumerate(limbs)) & mask)
     return vals
 
 
-def test_field_ops_29bit_limbs_vs_python_ints():
-    """bign_fe29.hpp (the small-batch form: nine signed 29-bit limbs, lazy additions) against big-int arithmetic:
-    multiplication / squaring with the folded small multiples, lazy differences and sums fed straight into
-    multiplications at the bounds the point formulas use, the exact conversion back to 32-bit words"""
+@pytest.mark.parametrize("l", [128, 192, 256])
+def test_field_ops_lazy_limbs_vs_python_ints(l):
+    """bign_fe29.hpp (the small-batch form: signed 29 / 28 / 27-bit limbs on the three curves, lazy additions) against
+    big-int arithmetic: multiplication / squaring with the folded small multiples, lazy differences and sums fed
+    straight into multiplications at the bounds the point formulas use, the exact conversion back to 32-bit words"""
     eng = engine()
-    rnd = random.Random(29)
-    special = [0, 1, 2, 188, 189, 190, P - 2, P - 1, P, P + 1, P + 188, 2 ** 256 - 1, 2 ** 255,
-               2 ** 232, 2 ** 232 - 1, 2 ** 29 - 1, 2 ** 29, (1 << 256) - (1 << 32)] + _limb_patterns(rnd)
-    pool = special + [rnd.getrandbits(256) for _ in range(300)]
-    A = [a for a in special for _ in special] + [rnd.choice(pool) for _ in range(8192)]
-    B = [b for _ in special for b in special] + [rnd.choice(pool) for _ in range(8192)]
+    rnd = random.Random(29 + l)
+    L, Bb, c = LAZY[l]
+    P = 2 ** (2 * l) - c
+    special = [0, 1, 2, c - 1, c, c + 1, P - 2, P - 1, P, P + 1, P + c - 1, 2 ** (2 * l) - 1, 2 ** (2 * l - 1),
+               2 ** (Bb * (L - 1)), 2 ** (Bb * (L - 1)) - 1, 2 ** Bb - 1, 2 ** Bb, (1 << (2 * l)) - (1 << 32)] + _limb_patterns(rnd, l)
+    pool = special + [rnd.getrandbits(2 * l) for _ in range(300)]
+    extra = 8192 if l == 128 else 2048
+    A = [a for a in special for _ in special] + [rnd.choice(pool) for _ in range(extra)]
+    B = [b for _ in special for b in special] + [rnd.choice(pool) for _ in range(extra)]
     ops = {20: lambda a, b: a * b % P, 21: lambda a, b: a * a % P, 22: lambda a, b: 3 * a * b % P,
            23: lambda a, b: 8 * a * a % P, 24: lambda a, b: (a - b) % P, 25: lambda a, b: 3 * (a - b) * (a + b) % P,
            26: lambda a, b: 4 * (a - 3 * b) * (-b) % P, 27: lambda a, b: 8 * (a - b) ** 2 % P,
            28: lambda a, b: (2 * (a - b) * (a + b) - 3 * a) % P}
     for op, f in ops.items():
-        got = _fe_run(eng, op, A, B)
+        got = _fe_run_l(eng, l, op, A, B)
         want = [f(a, b) for a, b in zip(A, B)]
         bad = [(hex(a), hex(b)) for a, b, g, w in zip(A, B, got, want) if g != w]
-        assert not bad, f"29-bit field op {op}: {len(bad)} wrong, first {bad[0]}"
+        assert not bad, f"l = {l}, lazy-limb field op {op}: {len(bad)} wrong, first {bad[0]}"
 
 
-def test_point_ops_29bit_limbs_match_the_32bit_ones(golden):
-    """2P and 3P = 2P + P of public keys from the fixtures: affine x from jac29_dbl / jac29_madd == from the
-    Python group law"""
+@pytest.mark.parametrize("l", [128, 192, 256])
+def test_point_ops_lazy_limbs_match_the_group_law(golden, l):
+    """2P and 3P = 2P + P of public keys from the fixtures: affine x from jac29_dbl / jac29_madd (one lane per point)
+    and from quad29_dbl / quad29_add (a DPP quad per point: every point is passed four times) == the Python group law"""
     eng = engine()
-    _, _, ps = golden.bign_base_arrays()
-    pts = [(int.from_bytes(ps[64 * i:64 * i + 32], "little"), int.from_bytes(ps[64 * i + 32:64 * i + 64], "little"))
-           for i in range(512)]
+    c = LAZY[l][2]
+    P = 2 ** (2 * l) - c
+    no = l // 4
+    if l == 128:
+        _, _, ps = golden.bign_base_arrays()
+        keys = [ps[64 * i:64 * i + 64] for i in range(256)]
+    else:
+        keys = [bytes.fromhex(t["pubkey"]) for t in golden.bign_big[str(l)]["base"]]
+    pts = [(int.from_bytes(k[:no], "little"), int.from_bytes(k[no:], "little")) for k in keys]
 
     def dbl(x, y):
         lam = (3 * x * x - 3) * pow(2 * y, P - 2, P) % P
@@ -103,8 +132,14 @@ def test_point_ops_29bit_limbs_match_the_32bit_ones(golden):
 
     X = [p[0] for p in pts]
     Y = [p[1] for p in pts]
-    assert _fe_run(eng, 29, X, Y) == [dbl(x, y)[0] for x, y in pts]
-    assert _fe_run(eng, 30, X, Y) == [add(*dbl(x, y), x, y)[0] for x, y in pts]
+    want2 = [dbl(x, y)[0] for x, y in pts]
+    want3 = [add(*dbl(x, y), x, y)[0] for x, y in pts]
+    assert _fe_run_l(eng, l, 29, X, Y) == want2
+    assert _fe_run_l(eng, l, 30, X, Y) == want3
+    X4 = [x for x in X for _ in range(4)]
+    Y4 = [y for y in Y for _ in range(4)]
+    assert _fe_run_l(eng, l, 31, X4, Y4) == [w for w in want2 for _ in range(4)]
+    assert _fe_run_l(eng, l, 32, X4, Y4) == [w for w in want3 for _ in range(4)]
 
 
 @pytest.mark.parametrize("path", [1, 2, 3, 0x43, 0x23])
@@ -370,6 +405,47 @@ def test_crandall_reduction_carry_ripple(l):
         assert not bad, (l, K, len(bad), bad[:3])
 
 
+@pytest.mark.parametrize("l,path", [(192, 1), (192, 3), (256, 1), (256, 3)])
+def test_bign_big_curves_both_kernel_sets(golden, l, path):
+    """the wider curves: the r01 kernels (32-bit limbs, one lane per signature) and the quad kernel on 28- / 27-bit
+    limbs (bign_fe29.hpp LZ<12>, LZ<16>), each FORCED over the base and edge fixtures and a 20 000-signature tiling with
+    every 5th signature corrupted (quads are chosen unforced up to 2^14)"""
+    eng = engine()
+    tune = eng.lib.bee2hip_internal_tune
+    tune.restype = ctypes.c_uint32
+    assert tune(2, path) == 0
+    try:
+        d = golden.bign_big[str(l)]
+        oid = E.LEVEL_OID[l]
+        no = l // 4
+        cases = [dict(t, code=0, name="base") for t in d["base"]] + d["edge"]
+        hs = b"".join(bytes.fromhex(c["hash"]) for c in cases)
+        ss = b"".join(bytes.fromhex(c["sig"]) for c in cases)
+        ps = b"".join(bytes.fromhex(c["pubkey"]) for c in cases)
+        codes = torch.full((len(cases),), -1, dtype=torch.int32, device="cuda")
+        eng.bignVerifyL_batch_dev(l, oid, dev(hs), dev(ss), dev(ps), codes)
+        torch.cuda.synchronize()
+        got = [int(c) & 0xFFFFFFFF for c in codes.cpu().numpy()]
+        bad = [(c["name"], g, c["code"]) for c, g in zip(cases, got) if g != c["code"]]
+        assert not bad, bad[:10]
+        base = d["base"]
+        n = 20_000
+        reps = n // len(base) + 1
+        H = np.frombuffer(b"".join(bytes.fromhex(t["hash"]) for t in base) * reps, dtype=np.uint8).copy()[: no * n]
+        S = np.frombuffer(b"".join(bytes.fromhex(t["sig"]) for t in base) * reps, dtype=np.uint8).copy()[: (no + no // 2) * n]
+        K = np.frombuffer(b"".join(bytes.fromhex(t["pubkey"]) for t in base) * reps, dtype=np.uint8).copy()[: 2 * no * n]
+        S.reshape(n, no + no // 2)[::5, 3] ^= 0x10
+        codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        eng.bignVerifyL_batch_dev(l, oid, torch.from_numpy(H).cuda(), torch.from_numpy(S).cuda(), torch.from_numpy(K).cuda(), codes)
+        torch.cuda.synchronize()
+        got = codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        want = np.zeros(n, dtype=np.int64)
+        want[::5] = 510
+        assert np.array_equal(got, want)
+    finally:
+        tune(2, 0)
+
+
 @pytest.mark.parametrize("l", [192, 256])
 def test_bign_big_curves_batch_and_dropin(orc, golden, l):
     eng = engine()
@@ -443,7 +519,7 @@ def test_bign_pubkey_val_batch_and_dropin(orc, golden, l):
                                  (128, 32767), (128, 32768), (128, 65535), (128, 65536), (128, 2 ** 18 - 1), (128, 2 ** 18),
                                  # round 2: the quad kernel's workgroup switch (2^13) and the kernel switches at 2^15 / 2^16
                                  (128, 3), (128, 17), (128, 8191), (128, 8192), (128, 8193), (128, 16385), (128, 32769),
-                                 (128, 65537)])
+                                 (128, 65537), (192, 8193), (192, 16384), (192, 16385), (256, 8192), (256, 16385)])
 def test_bign_shared_inversion_groups_with_mixed_statuses(golden, l, n):
     """bign_inv_kernel shares one inversion between K signatures (K = n / 32768 resp. n / 65536, here 2, 4 and 8)
     and from 2^18 signatures on bign_prep_kernel normalises the tables of two signatures with one inversion.

@@ -7,11 +7,18 @@ and quad29_add, starting from the documented input contracts (N / L1), and asser
   * every 32-bit intermediate stays inside int32,
   * the outputs satisfy the contracts the next operation assumes (a fixed point: the outputs are fed back in).
 Run: python tools/fe29_bounds.py   (pure Python, no GPU; also run by tests/test_fe29_bounds.py)"""
-U = 1 << 29
-M = U - 1
-FOLD = 189 * 32
 I64 = 1 << 63
 I32 = 1 << 31
+LAYOUT = {8: (9, 29, 189 << 5), 12: (14, 28, 317 << 8), 16: (19, 27, 569 << 1)}      # LZ<N>: L, B, FOLD
+L, B, U, M, FOLD = 9, 29, 1 << 29, (1 << 29) - 1, 189 << 5
+
+
+def configure(n):
+    """limb layout of the curve with N = n 32-bit words (bign_fe29.hpp, LZ<N>)"""
+    global L, B, U, M, FOLD
+    L, B, FOLD = LAYOUT[n]
+    U = 1 << B
+    M = U - 1
 
 
 class Fe:
@@ -19,7 +26,7 @@ class Fe:
 
     def __init__(self, lo, hi):
         self.lo, self.hi = list(lo), list(hi)
-        assert len(self.lo) == 9 and all(a <= b for a, b in zip(self.lo, self.hi))
+        assert len(self.lo) == L and all(a <= b for a, b in zip(self.lo, self.hi))
         assert all(-I32 <= a and b < I32 for a, b in zip(self.lo, self.hi)), "int32 overflow"
 
     def __repr__(self):
@@ -29,9 +36,9 @@ class Fe:
         return all(a >= c and b <= d for a, b, c, d in zip(self.lo, self.hi, other.lo, other.hi))
 
 
-def norm(slack0=1 << 16, slack1=2):
-    """N: l[2..8] in [0, u), l[1] within slack1 and l[0] within slack0 of [0, u)"""
-    return Fe([-slack0, -slack1] + [0] * 7, [M + slack0, M + slack1] + [M] * 7)
+def norm(slack0=1 << 20, slack1=1 << 9):
+    """N: l[2..] in [0, u), l[1] within slack1 and l[0] within slack0 of [0, u)"""
+    return Fe([-slack0, -slack1] + [0] * (L - 2), [M + slack0, M + slack1] + [M] * (L - 2))
 
 
 def lazy1():
@@ -41,7 +48,7 @@ def lazy1():
 
 
 def one():
-    return Fe([1] + [0] * 8, [1] + [0] * 8)
+    return Fe([1] + [0] * (L - 1), [1] + [0] * (L - 1))
 
 
 def add(a, b):
@@ -67,26 +74,27 @@ def _prod(alo, ahi, blo, bhi):
 
 def _fold(clo, chi, K, what):
     """f29_fold: c[0..16] in [0, u), c[17] = [clo, chi]"""
-    lo, hi = [0] * 9, [0] * 9
+    lo, hi = [0] * L, [0] * L
     cy_lo = cy_hi = 0
-    for j in range(9):
-        hlo, hhi = (0, M) if j < 8 else (clo, chi)
+    for j in range(L):
+        hlo, hhi = (0, M) if j < L - 1 else (clo, chi)
         t_lo = hlo * FOLD * K + cy_lo + 0
         t_hi = hhi * FOLD * K + cy_hi + M * K
         assert -I64 <= t_lo and t_hi < I64, what
         lo[j], hi[j] = 0, M
-        cy_lo, cy_hi = t_lo >> 29, t_hi >> 29
-    assert -I32 <= cy_lo * FOLD and cy_hi * FOLD + M < I32, f"{what}: wrap of the fold carry leaves int32"
-    t0_lo, t0_hi = cy_lo * FOLD, M + cy_hi * FOLD
+        cy_lo, cy_hi = t_lo >> B, t_hi >> B
+    assert -I32 <= cy_lo and cy_hi < I32 and -I32 <= K * FOLD < I32, f"{what}: the fold carry / scale leaves int32"
+    t0_lo, t0_hi = cy_lo * FOLD, M + cy_hi * FOLD           # int64 in the device code
+    assert -I64 <= t0_lo and t0_hi < I64
     lo[0], hi[0] = 0, M
-    lo[1], hi[1] = (t0_lo >> 29), M + (t0_hi >> 29)
+    lo[1], hi[1] = (t0_lo >> B), M + (t0_hi >> B)
     return Fe(lo, hi)
 
 
 def mul(a, b, K=1, what="mul", square=False):
     acc_lo = acc_hi = 0
-    for k in range(17):
-        for i in range(max(0, k - 8), min(k, 8) + 1):
+    for k in range(2 * L - 1):
+        for i in range(max(0, k - (L - 1)), min(k, L - 1) + 1):
             j = k - i
             if square and i > j:
                 continue
@@ -101,9 +109,9 @@ def mul(a, b, K=1, what="mul", square=False):
             acc_lo += p_lo
             acc_hi += p_hi
             assert -I64 <= acc_lo and acc_hi < I64, f"{what}: column {k} leaves int64 ({acc_lo / I64:.3f}, {acc_hi / I64:.3f})"
-        acc_lo >>= 29
-        acc_hi >>= 29
-    assert -I32 <= acc_lo and acc_hi < I32, f"{what}: c[17] leaves int32"
+        acc_lo >>= B
+        acc_hi >>= B
+    assert -I32 <= acc_lo and acc_hi < I32, f"{what}: the top column leaves int32"
     return _fold(acc_lo, acc_hi, K, what)
 
 
@@ -112,13 +120,13 @@ def sqr(a, K=1, what="sqr"):
 
 
 def carry(a, what="carry"):
-    lo, hi = [0] * 9, [0] * 9
+    lo, hi = [0] * L, [0] * L
     c_lo = c_hi = 0
-    for i in range(9):
+    for i in range(L):
         t_lo, t_hi = a.lo[i] + c_lo, a.hi[i] + c_hi
         assert -I32 <= t_lo and t_hi < I32, what
         lo[i], hi[i] = 0, M
-        c_lo, c_hi = t_lo >> 29, t_hi >> 29
+        c_lo, c_hi = t_lo >> B, t_hi >> B
     lo[0], hi[0] = c_lo * FOLD, M + c_hi * FOLD
     return Fe(lo, hi)
 
@@ -190,27 +198,44 @@ def quad29_add(X, Y, Z, D, ex, ey, ez, ezz):
     return X3, Y3, Z3, D3
 
 
+def pair29_dbl(X, Y, Z, D):
+    gamma = sqr(Y, 1, "pdbl Y^2")
+    Z3 = mul(Y, Z, 2, "pdbl 2 Y Z")
+    alpha = sub(sqr(X, 3, "pdbl 3 X^2"), sqr(D, 3, "pdbl 3 D^2"))
+    b4 = mul(X, gamma, 4, "pdbl 4 X g")
+    b8 = mul(X, gamma, 8, "pdbl 8 X g")
+    X3 = sub(sqr(alpha, 1, "pdbl alpha^2"), b8)
+    D3 = sqr(Z3, 1, "pdbl Z3^2")
+    Y3 = sub(mul(alpha, sub(b4, X3), 1, "pdbl alpha (4b - X3)"), mul(gamma, gamma, 8, "pdbl 8 g^2"))
+    return X3, Y3, Z3, D3
+
+
 def main():
-    N, L1 = norm(), lazy1()
-    # one lane per point: contract X, Z: N; Y: L1; table / comb entries x: N, y: N or its negation (L1)
-    X3, Y3, Z3 = jac29_dbl(N, L1, N)
-    assert X3.within(N) and Z3.within(N) and Y3.within(L1), "jac29_dbl breaks its own contract"
-    X3, Y3, Z3 = jac29_madd(N, L1, N, N, L1)
-    assert X3.within(N) and Z3.within(N) and Y3.within(L1), "jac29_madd breaks its own contract"
-    for v in (X3, Y3, Z3):
-        to_words_ok(v, "to_words")
-    print("jac29_dbl / jac29_madd: accumulators inside int64, contract (X, Z: N; Y: L1) is a fixed point")
-    # quads: contract X, Y: L1 (X: N after an addition, which lies within L1); Z, D: N; entries X, Y: L1, Z, ZZ: N
-    X3, Y3, Z3, D3 = quad29_dbl(L1, L1, N, N)
-    assert X3.within(L1) and Y3.within(L1) and Z3.within(N) and D3.within(N), "quad29_dbl breaks its own contract"
-    X3, Y3, Z3, D3 = quad29_add(L1, L1, N, N, L1, L1, N, N)
-    assert X3.within(L1) and Y3.within(L1) and Z3.within(N) and D3.within(N), "quad29_add breaks its own contract"
-    for v in (X3, Y3, Z3):
-        to_words_ok(v, "to_words")
-    print("quad29_dbl / quad29_add: accumulators inside int64, contract (X, Y: L1; Z, D: N) is a fixed point")
-    # the debug ops of tests/test_gpu_bign.py (op 26: (a - 3b) carried, times -b scaled by 4; op 28: 2 (a-b)(a+b) - 3a)
-    mul(carry(sub(sub(sub(N, N), N), N)), neg(N), 4, "debug op 26")
-    to_words_ok(sub(sub(sub(mul(sub(N, N), add(N, N), 2, "debug op 28"), N), N), N), "debug op 28")
+    for n in (8, 12, 16):
+        configure(n)
+        N, L1 = norm(), lazy1()
+        # one lane per point: contract X, Z: N; Y: L1; table / comb entries x: N, y: N or its negation (L1)
+        X3, Y3, Z3 = jac29_dbl(N, L1, N)
+        assert X3.within(N) and Z3.within(N) and Y3.within(L1), "jac29_dbl breaks its own contract"
+        X3, Y3, Z3 = jac29_madd(N, L1, N, N, L1)
+        assert X3.within(N) and Z3.within(N) and Y3.within(L1), "jac29_madd breaks its own contract"
+        for v in (X3, Y3, Z3):
+            to_words_ok(v, "to_words")
+        # quads and pairs: contract X, Y: L1 (X: N after an addition, which lies within L1); Z, D: N; entries X, Y: L1, Z, ZZ: N
+        for dbl in (quad29_dbl, pair29_dbl):
+            X3, Y3, Z3, D3 = dbl(L1, L1, N, N)
+            assert X3.within(L1) and Y3.within(L1) and Z3.within(N) and D3.within(N), "the doubling breaks its own contract"
+        X3, Y3, Z3, D3 = quad29_add(L1, L1, N, N, L1, L1, N, N)          # pair29_add: the same products in another order
+        assert X3.within(L1) and Y3.within(L1) and Z3.within(N) and D3.within(N), "quad29_add breaks its own contract"
+        for v in (X3, Y3, Z3):
+            to_words_ok(v, "to_words")
+        if n == 8:
+            # the debug ops of tests/test_gpu_bign.py (op 26: (a - 3b) carried, times -b scaled by 4; op 28: 2 (a-b)(a+b) - 3a)
+            mul(carry(sub(sub(sub(N, N), N), N)), neg(N), 4, "debug op 26")
+            to_words_ok(sub(sub(sub(mul(sub(N, N), add(N, N), 2, "debug op 28"), N), N), N), "debug op 28")
+        print(f"N = {n}: {L} limbs of {B} bits, fold {FOLD}: every accumulator inside int64, "
+              "the contracts (X, Z: N; Y: L1 / X, Y: L1; Z, D: N) are fixed points of all six formulas")
+    configure(8)
     return 0
 
 
