@@ -526,6 +526,25 @@ def main():
                 "steps": kl, "ms_per_step": el / kl * 1e3, "all_valid": bool((tc == 0).all()),
                 "config": {"workload": f"{nl} signatures per GPU on the {2 * l}-bit curve (SURVEY 8f-4; 2^18 as configs[3]: 2^16 leaves one wavefront per SIMD), "
                                        f"{len(base)} genuine triples tiled"}}
+            if dist.rank == 0:
+                # small batches (prefixes of the same tiling): the quad kernel up to 2^14 signatures, the r01 kernels above
+                small = {}
+                no_l = l // 4
+                for e in (10, 13, 14, 15):
+                    m = 1 << e
+                    args = (th[: no_l * m], ts[: (no_l + no_l // 2) * m], tp[: 2 * no_l * m], tc[:m])
+                    for _ in range(2):
+                        eng.bignVerifyL_batch_dev(l, LEVEL_OID[l], *args)
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(5):
+                        eng.bignVerifyL_batch_dev(l, LEVEL_OID[l], *args)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms_b = e0.elapsed_time(e1) / 5
+                    small[f"2^{e}"] = {"ms_per_batch": ms_b, "verifies_per_s": m / (ms_b * 1e-3)}
+                others[f"bignVerify_l{l}"]["batch_size_sweep"] = small
             if do_cpu:
                 import refgen
                 if refgen.have_ref():
