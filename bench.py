@@ -345,9 +345,11 @@ def main():
             side = torch.cuda.Stream()
             probe = torch.zeros(2, dtype=torch.int64, device="cuda")
             torch.cuda.synchronize()
+            for _ in range(20):                                   # the queue is already full when the probe arrives
+                eng.bashF_batch_dev(st)
             eng.lib.bee2hip_internal_clock_probe(ctypes.c_void_p(probe.data_ptr()), ctypes.c_uint(int(ms_launch * 1e3 * 40 * 0.8)),
                                                  ctypes.c_void_p(side.cuda_stream))
-            for _ in range(40):
+            for _ in range(60):
                 eng.bashF_batch_dev(st)
             torch.cuda.synchronize()
             c = probe.cpu().numpy()
