@@ -491,29 +491,36 @@ __global__ __launch_bounds__(WG)
 void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
                         const uint8_t *__restrict__ pubkeys, size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
 {
-    constexpr int NW = N / 2 + 1, W = Comb<N>::W, NS = WG / LANES, L = LZ<N>::L;
+    // LANES = 8: a quad plus a HELPER quad per signature (up to 2^13 signatures the lanes are there): the helper adds up
+    // the comb windows of u while the main quad walks v Q -- 16 of the 49 additions leave the critical path -- and hands
+    // its point over at the end (one more addition).  Both quads run the same instructions: the helper's additions
+    // ride on the main quad's, its doublings are masked off.
+    constexpr int NW = N / 2 + 1, W = Comb<N>::W, NS = WG / LANES, L = LZ<N>::L, QL = LANES == 8 ? 4 : LANES;
+    constexpr bool HELPER = LANES == 8;
     extern __shared__ int32_t s_tab[];              // [8 entries][X, Y, Z, ZZ][L limbs][NS signatures]
-    const uint32_t q = threadIdx.x % LANES, sl = threadIdx.x / LANES;
+    const uint32_t q = threadIdx.x % QL, sl = threadIdx.x / LANES;
+    const bool helper = HELPER && ((threadIdx.x >> 2) & 1u);
     const size_t idx = (size_t)blockIdx.x * NS + sl;
     if (idx >= n) return;                           // whole quads leave together
     affT<N> Q;
     feT<N> u;
     uint32_t w[NW];
-    if (!prep_scalars<N>(hashes, sigs, pubkeys, idx, S, q == 0, Q, u, w)) return;
+    if (!prep_scalars<N>(hashes, sigs, pubkeys, idx, S, q == 0 && !helper, Q, u, w)) return;
 
     // the lanes of a signature share the writes: lane q owns field element q (X, Y, Z, ZZ) of every table entry
     // (a pair: q and q + 2)
     const auto put = [&](int e, const lqjacT<N> &P) {
+        if (helper) return;
 #pragma unroll
-        for (int k = 0; k < 4 / LANES; ++k) {
-            const int fi = (int)q + LANES * k;
+        for (int k = 0; k < 4 / QL; ++k) {
+            const int fi = (int)q + QL * k;
             const lzT<N> &f = fi == 0 ? P.X : fi == 1 ? P.Y : fi == 2 ? P.Z : P.D;
 #pragma unroll
             for (int l = 0; l < L; ++l) s_tab[((e * 4 + fi) * L + l) * NS + sl] = f.l[l];
         }
     };
-    const auto dbl = [&](lqjacT<N> &P) { if constexpr (LANES == 4) quad29_dbl(P, q); else pair29_dbl(P, q); };
-    const auto add = [&](lqjacT<N> &P, const lqentT<N> &Q2) { if constexpr (LANES == 4) quad29_add(P, Q2, q); else pair29_add(P, Q2, q); };
+    const auto dbl = [&](lqjacT<N> &P) { if constexpr (QL == 4) quad29_dbl(P, q); else pair29_dbl(P, q); };
+    const auto add = [&](lqjacT<N> &P, const lqentT<N> &Q2) { if constexpr (QL == 4) quad29_add(P, Q2, q); else pair29_add(P, Q2, q); };
     const auto get = [&](lqentT<N> &E, int e) {
         const int32_t *b = s_tab + (size_t)e * 4 * L * NS + sl;
 #pragma unroll
@@ -555,10 +562,24 @@ void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
     // top digit d_{4N} = nibble_{4N}(w) - 8 is 1 or 2
     get(E, (int)(w[NW - 1] & 15u) - 9);
     T.X = E.X; T.Y = E.Y; T.Z = E.Z; T.D = E.ZZ;
+    bool empty = helper;                            // the helper's sum starts at O: its first point is copied, not added
 #pragma unroll 1
-    for (int it = 4 * N - 1 + 32 * N / W; it >= 0; --it) {
-        bool have;
-        if (it >= 32 * N / W) {                     // a digit of v: 4 doublings, then +- |d| Q from the LDS table
+    for (int it = 4 * N - 1 + (HELPER ? 0 : 32 * N / W); it >= 0; --it) {
+        const bool digit_step = HELPER || it >= 32 * N / W;
+        const int win = HELPER ? 4 * N - 1 - it : 32 * N / W - 1 - it;      // the comb window of this step (helper: one per digit step)
+        // a comb window of u: affine point from the table of G.  The helper asks for it FIRST, so that the main quad's
+        // doublings cover the trip to memory.
+        affT<N> G;
+        uint32_t b = 0;
+        if ((HELPER ? helper : !digit_step) && win < 32 * N / W) {
+            b = u.v[0] & ((1u << W) - 1u);
+#pragma unroll
+            for (int l = 0; l < N - 1; ++l) u.v[l] = (u.v[l] >> W) | (u.v[l + 1] << (32 - W));
+            u.v[N - 1] >>= W;
+            if (b != 0) load_aff(G, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
+        }
+        bool have = b != 0;
+        if (digit_step && !helper) {                // a digit of v: 4 doublings, then +- |d| Q from the LDS table
 #pragma unroll 1
             for (int k = 0; k < 4; ++k) dbl(T);
             const int d = (int)(w[NW - 2] >> 28) - 8;
@@ -570,23 +591,25 @@ void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
                 get(E, (d < 0 ? -d : d) - 1);
                 if (d < 0) f29_neg(E.Y, E.Y);
             }
-        } else {                                    // a comb window of u: affine point from the table of G
-            const int win = 32 * N / W - 1 - it;
-            const uint32_t b = u.v[0] & ((1u << W) - 1u);
-#pragma unroll
-            for (int l = 0; l < N - 1; ++l) u.v[l] = (u.v[l] >> W) | (u.v[l + 1] << (32 - W));
-            u.v[N - 1] >>= W;
-            have = b != 0;
-            if (have) {
-                affT<N> G;
-                load_aff(G, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
-                f29_from_words(E.X, G.x);
-                f29_from_words(E.Y, G.y);
-                f29_set_one(E.Z);
-                f29_set_one(E.ZZ);
-            }
+        } else if (have) {
+            f29_from_words(E.X, G.x);
+            f29_from_words(E.Y, G.y);
+            f29_set_one(E.Z);
+            f29_set_one(E.ZZ);
         }
-        if (have) add(T, E);
+        if (have) {
+            if (empty) { T.X = E.X; T.Y = E.Y; T.Z = E.Z; T.D = E.ZZ; empty = false; }
+            else add(T, E);
+        }
+    }
+    if constexpr (HELPER) {                         // main quad: T += the helper's sum (lanes + 4)
+        q29_from_next_quad(E.X, T.X);
+        q29_from_next_quad(E.Y, T.Y);
+        q29_from_next_quad(E.Z, T.Z);
+        q29_from_next_quad(E.ZZ, T.D);
+        const int helper_empty = __shfl_down((int)empty, 4);
+        if (helper) return;
+        if (!helper_empty) add(T, E);
     }
     feT<N> X, Z;
     f29_to_words(Z, T.Z);
@@ -1065,7 +1088,7 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
     const size_t sp = n >= ((size_t)1 << 18) ? 2 : 1;     // signatures per lane in prep (shared inversion)
     const size_t plan = (n + sp - 1) / sp;
     // Which kernels walk the scalar multiplication (g_verify_path: 0 by size, 1 always the 32-bit
-    // kernels, 2 the 29-bit main kernel, 3 the quad / pair kernel, + 16 x lanes to force quads (0x43) or pairs (0x23)
+    // kernels, 2 the 29-bit main kernel, 3 the quad / pair kernel, + 16 x lanes to force quads (0x43), pairs (0x23) or quads with a helper quad (0x83; 0x93 / 0xA3 with 64 / 256 lanes per block)
     // -- tests and A/B):
     //   <= 2^14 signatures: one signature per quad, 29-bit limbs (prep + main in one kernel, no table inversion)
     //   <= 2^15           : one signature per pair of lanes, same kernel (256-bit curve; the wider ones use quads up
@@ -1087,12 +1110,19 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
             return ERR_OK;
         };
         int lanes = 4;
-        if constexpr (N == 8) lanes = g_verify_lanes ? g_verify_lanes : n <= ((size_t)1 << 14) ? 4 : 2;
+        if constexpr (N == 8) lanes = g_verify_lanes == 2 ? 2 : g_verify_lanes ? 4 : n <= ((size_t)1 << 14) ? 4 : 2;
         if constexpr (N == 8) {
             if (lanes == 2) code = launch(bign_quad29_kernel<8, 256, 2>, 256, 2);
         }
         if (lanes != 2) {
-            if (n <= ((size_t)1 << 13)) code = launch(bign_quad29_kernel<N, 64, 4>, 64, 4);
+            // up to 2^13 signatures a helper quad per signature takes the comb of u off the main quad's chain (x1.05, x1.10
+            // at 2^13).  Four-wave blocks, because wavefronts of a block share a CU's instruction fetches and this
+            // kernel is long; around 2^12 one-wave blocks spread over all CUs win (tools/verify_helper_ab.py).
+            const bool helper = g_verify_lanes >= 8 || (g_verify_lanes == 0 && n <= ((size_t)1 << 13));
+            const bool one_wave = g_verify_lanes == 9 || (g_verify_lanes != 10 && n > ((size_t)3 << 10) && n <= ((size_t)1 << 12));
+            if (helper && one_wave) code = launch(bign_quad29_kernel<N, 64, 8>, 64, 8);
+            else if (helper) code = launch(bign_quad29_kernel<N, 256, 8>, 256, 8);
+            else if (n <= ((size_t)1 << 13)) code = launch(bign_quad29_kernel<N, 64, 4>, 64, 4);
             else code = launch(bign_quad29_kernel<N, 256, 4>, 256, 4);
         }
         if (code != ERR_OK) return code;

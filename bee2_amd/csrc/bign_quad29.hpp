@@ -49,6 +49,12 @@ __device__ __forceinline__ void q29_bcast(lzT<N> &r, const lzT<N> &a)
     else if constexpr (K == 2) Q29_DPP_ALL("quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1");
     else Q29_DPP_ALL("quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1");
 }
+// a from the lane four places up (the helper quad of an 8-lane group hands its point to the main quad)
+template <int N>
+__device__ __forceinline__ void q29_from_next_quad(lzT<N> &r, const lzT<N> &a)
+{
+    Q29_DPP_ALL("row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+}
 template <int N>
 __device__ __forceinline__ void q29_pick(lzT<N> &r, bool p, const lzT<N> &a, const lzT<N> &b)
 {

@@ -220,7 +220,7 @@ def f_verify(rnd):
     codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
     # which kernels walk the scalar multiplication is a matter of batch size (32-bit limbs / 29-bit limbs / one
     # signature per quad on the 256-bit curve): half of the cases force one of the three instead
-    path = rnd.choice((0, 0, 0, 0, 1, 2, 0x43, 0x23))
+    path = rnd.choice((0, 0, 0, 0, 1, 2, 0x43, 0x23, 0x83))
     eng.lib.bee2hip_internal_tune(2, path)
     try:
         eng.bignVerifyL_batch_dev(l, oid, dev(H), dev(S), dev(P), codes)

@@ -142,11 +142,11 @@ def test_point_ops_lazy_limbs_match_the_group_law(golden, l):
     assert _fe_run_l(eng, l, 32, X4, Y4) == [w for w in want3 for _ in range(4)]
 
 
-@pytest.mark.parametrize("path", [1, 2, 3, 0x43, 0x23])
+@pytest.mark.parametrize("path", [1, 2, 3, 0x43, 0x23, 0x83])
 def test_bign_both_main_kernels_on_edge_and_base_sets(golden, path):
     """The batch size picks the main kernel (29-bit limbs up to 2^16 signatures, 32-bit above); here each is FORCED
     (bee2hip_internal_tune(2, path): 1 = 32-bit limbs, 2 = 29-bit limbs, 3 = one signature per quad or pair of lanes
-    by size, 0x43 = quads, 0x23 = pairs) over the 433 edge cases (exceptional group-law cases
+    by size, 0x43 = quads, 0x23 = pairs, 0x83 = quad + helper quad) over the 433 edge cases (exceptional group-law cases
     included: they must reach the slow path from either kernel), the valid base set, and a 70 000-signature tiling
     with every 7th signature corrupted -- a size the 29-bit kernel never sees unforced."""
     eng = engine()
