@@ -38,6 +38,7 @@ from bee2_amd import shard  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BASHF_BYTES = 384                # algorithmic bytes per permutation (192 read + 192 written)
 CTR_BYTES_PER_BLOCK = 32         # 16 read + 16 written per 16-byte block
+LDS_CTR_CEIL_GIBPS = 256 * 2.17e9 / 7 * 16 / 2 ** 30   # 224 ds_read_b32 per block = 7 LDS clocks per block per CU
 MADS_PER_VERIFY = 976 * 72 + 685 * 52 + 3000   # v_mad_u64_u32 per signature: affine table, shared inversion
 MAD_PEAK_T = 30.0                # measured: 256 CU x 4 SIMD x 64 lanes x 2.31 GHz / 5.05 cycles
 
@@ -68,6 +69,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--only", default="", help="comma list of {bashF,ctr,verify,sign,mixed,modes,ragged,dwp,latency}; default all")
     ap.add_argument("--ctr-gib", type=float, default=16.0)
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="ranks only form the process group, reduce one number and rank 0 prints the line's launch fields "
+                         "(no GPU work; tests/test_bench_launch.py runs this on CPU with BEE2_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
     bad = set(x for x in args.only.split(",") if x) - set(WORKLOADS)
     if bad:                                # fail before any GPU work, not with an empty JSON line
@@ -75,11 +79,37 @@ def parse():
     return args
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment (how the driver calls the bench): become the
+    launcher -- re-run this very command line under torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 --
+    and pass the ranks' output and exit code through.  Returns only when this process IS a rank (or N == 1)."""
+    if args.gpus <= 1 or "RANK" in os.environ:
+        return
+    backend = os.environ.get("BEE2_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and not args.launch_selftest:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"[bench] --gpus {args.gpus} but this node shows {have} GPU(s); refusing to report n_gpus={args.gpus} "
+                     "(set BEE2_BENCH_BACKEND=gloo to run the N-rank code path on fewer devices)")
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] self-launch: {' '.join(cmd)}", file=sys.stderr)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 class Dist:
     """one process per GPU; RCCL ('nccl') by default.  BEE2_BENCH_BACKEND=gloo runs the same
     code with CPU-side collectives (lets the N>1 path be exercised on a box with one GPU)."""
 
-    def __init__(self, want):
+    def __init__(self, want, use_cuda=True):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -87,9 +117,10 @@ class Dist:
         # RCCL calls (init with device_id, broadcast, all-reduce, barrier) the 2/4/8-GPU runs make
         self.on = self.world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
         self.backend = os.environ.get("BEE2_BENCH_BACKEND", "nccl")
-        ndev = max(1, torch.cuda.device_count())
-        self.device = self.local % ndev
-        torch.cuda.set_device(self.device)
+        self.ndev = torch.cuda.device_count()
+        self.device = self.local % max(1, self.ndev)
+        if use_cuda:
+            torch.cuda.set_device(self.device)
         if self.on:
             import torch.distributed as dist
             self.dist = dist
@@ -98,8 +129,17 @@ class Dist:
             else:
                 dist.init_process_group(self.backend)
         self.cdev = "cuda" if self.backend == "nccl" else "cpu"
-        if want != self.world and self.rank == 0:
-            print(f"[bench] note: --gpus {want} but WORLD_SIZE={self.world}; using {self.world}", file=sys.stderr)
+        if want != self.world:
+            # never report an n_gpus that is not the number of ranks that ran
+            raise SystemExit(f"[bench] --gpus {want} but WORLD_SIZE={self.world}: launch with --nproc-per-node {want} "
+                             f"(or run `python bench.py --gpus {want}` and let it launch the ranks itself)")
+
+    def sum(self, x):
+        if not self.on:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=self.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
 
     def barrier(self):
         if self.on:
@@ -296,6 +336,16 @@ def cpu_baseline(which, cores):
 # --------------------------------------------------------------------------------- main
 def main():
     args = parse()
+    self_launch(args)                         # --gpus N > 1 without RANK: does not return
+    if args.launch_selftest:
+        dist = Dist(args.gpus, use_cuda=False)
+        seen = int(dist.sum(1.0))             # one all-reduce: every rank counted
+        slowest = dist.max(float(dist.rank))
+        if dist.rank == 0:
+            print(json.dumps({"metric": "launch selftest", "n_gpus": dist.world, "roofline": {"n_ranks_seen": seen},
+                              "max_rank": int(slowest), "backend": dist.backend}))
+        dist.close()
+        return
     dist = Dist(args.gpus)
     eng = bee2_amd.load()                     # fails loudly without libbee2hip.so
     eng.set_device(torch.cuda.current_device())
@@ -361,6 +411,16 @@ def main():
         except Exception as e:                                    # the probe is a diagnostic, never a reason to fail the bench
             result["roofline"]["shader_clock_ghz_under_kernel"] = None
             result["roofline"]["shader_clock_note"] = repr(e)
+        # the same kernel on a batch that cannot sit in the 256 MiB Infinity Cache: 2^22 states = 768 MiB read + written
+        # per launch; reported as flat keys next to the cache-resident headline
+        n22 = 1 << 22
+        st22 = torch.empty(192 * n22, dtype=torch.uint8, device="cuda")
+        fill_seeded(st22, 0xBA5F + 0x22 + dist.rank)
+        timed(dist, max(3, min(K, 20)), 2, lambda: eng.bashF_batch_dev(st22))
+        ms22 = timed.event_ms
+        result["roofline"]["ms_2p22"] = ms22
+        result["roofline"]["frac_2p22"] = BASHF_BYTES * n22 / (ms22 * 1e-3) / 1e9 / HBM_PEAK_GBS
+        del st22
         if dist.rank == 0 and N == 1:       # PCIe-inclusive rate: single-GPU runs only
             host = st.cpu().numpy()                               # pageable host copy of the same batch
             hp = ctypes.c_void_p(host.ctypes.data)
@@ -899,6 +959,41 @@ def main():
                   "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": o["config"]}
         for k, v in o.items():            # keep the workload's own fields (roofline, cpu_baseline, extras)
             result.setdefault(k, v)
+    # FLAT scalar copies of the other two BASELINE metrics (and what bounds them) inside the two objects the driver's
+    # record keeps -- `others` is nested and does not survive its parse.  Per-GPU figures for the
+    # fractions (value / N), whole-job figures for the rates.
+    rf = result.setdefault("roofline", {})
+    rf["n_ranks_seen"] = int(dist.sum(1.0))
+    rf["n_devices_visible"] = dist.ndev
+    if isinstance(rf.get("valu"), dict):
+        rf["valu_frac"] = rf["valu"]["frac_of_simd_cycles"]
+    cb = result.get("cpu_baseline")
+    if cb is None:
+        cb = result["cpu_baseline"] = {"value": None, "unit": result.get("unit"), "cores": cores, "kind": None,
+                                       "sample": "not timed: cpu_baseline runs on rank 0 at N=1 only" if N > 1 else "not timed (--no-cpu)"}
+    o = others.get("beltCTR")
+    if o:
+        rf["beltCTR_GiBps"] = o["value"]
+        rf["beltCTR_frac"] = o["roofline"]["frac"]
+        rf["beltCTR_lds_frac"] = o["value"] / N / LDS_CTR_CEIL_GIBPS
+        rf["beltCTR_ms"] = o["roofline"]["avg_launch_ms"]
+        if "cpu_baseline" in o:
+            cb["beltCTR_GiBps"] = o["cpu_baseline"]["value"]
+            cb["beltCTR_GiBps_single_thread"] = o["cpu_baseline"].get("single_thread")
+    o = others.get("bignVerify")
+    if o:
+        rf["bignVerify_sigs_per_s"] = o["value"]
+        rf["bignVerify_frac"] = o["roofline"]["frac"]
+        rf["bignVerify_ms"] = o["roofline"]["avg_batch_ms"]
+        rf["bignVerify_verdicts_ok"] = o["verdicts_as_expected"]
+        if "cpu_baseline" in o:
+            cb["bignVerify_sigs_per_s"] = o["cpu_baseline"]["value"]
+            cb["bignVerify_sigs_per_s_single_thread"] = o["cpu_baseline"].get("single_thread")
+    o = others.get("bash512_beltMAC")
+    if o:
+        rf["mixed_msgs_per_s"] = o["value"]
+        if "cpu_baseline" in o:
+            cb["mixed_msgs_per_s"] = o["cpu_baseline"]["value"]
     result["others"] = others
     result["host"] = {"cpu_count": cores, "device": torch.cuda.get_device_name(torch.cuda.current_device()),
                       "engine": eng.version()}
