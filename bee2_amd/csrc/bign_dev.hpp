@@ -41,6 +41,15 @@ template <> struct CurveC<12> { static constexpr uint32_t C = 317u; static const
 template <> struct CurveC<16> { static constexpr uint32_t C = 569u; static constexpr int LOWBITS = 10; };
 
 template <int N> struct feT { uint32_t v[N]; };
+
+// Two flavours of the field operations.  CtOps (the default): straight-line code only, what the signing kernels
+// need (their operands are secret).  VtOps: VERIFICATION ONLY (all operands public): the second carry pass of an
+// addition / subtraction / Crandall fold -- needed with probability 2^-24 (a + b wraps past 2^(32N) AND limb 0 then
+// overflows on +c) resp. 2^-40 per lane -- is skipped by a wavefront-uniform branch on the carry mask the first
+// pass leaves in an SGPR pair, and the carry chains are written as v_add(c)_co_u32 chains instead of 64-bit adds of
+// zero-extended limbs.  Results are identical, bit for bit; only the instruction count depends on the data.
+struct CtOps { static constexpr bool VT = false; };
+struct VtOps { static constexpr bool VT = true; };
 template <int N> struct jacT { feT<N> X, Y, Z; };          // O <=> Z == 0 (mod p)
 template <int N> struct affT { feT<N> x, y; };
 typedef feT<8> fe;
@@ -107,10 +116,30 @@ __device__ __forceinline__ bool limbs_ge(const uint32_t (&a)[N], const uint32_t 
 // r = a + b (mod p), weakly reduced.  Carry out of 2^(32N) folds back as +c; a second
 // carry can only come from inputs in the c-value zone [p, 2^(32N)) and then the wrapped
 // value is < c, so a final +c on limb 0 alone is exact.
-template <int N>
+template <class P = CtOps, int N>
 __device__ __forceinline__ void fe_add(feT<N> &r, const feT<N> &a, const feT<N> &b)
 {
     constexpr uint32_t C = CurveC<N>::C;
+    if constexpr (P::VT) {
+        uint32_t t[N], k;
+        uint64_t cy, cy2;
+        const uint32_t cv = C;
+        asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(t[0]), "=s"(cy) : "v"(a.v[0]), "v"(b.v[0]));
+#pragma unroll
+        for (int i = 1; i < N; ++i)
+            asm("v_addc_co_u32 %0, %1, %2, %3, %1" : "=v"(t[i]), "+s"(cy) : "v"(a.v[i]), "v"(b.v[i]));
+        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(k) : "v"(cv), "s"(cy));           // wrapped past 2^(32N): + c
+        asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(t[0]), "=s"(cy2) : "v"(t[0]), "v"(k));
+        if (__builtin_expect(cy2 != 0, 0)) {                                            // limb 0 overflowed in some lane
+#pragma unroll
+            for (int i = 1; i < N; ++i) asm("v_addc_co_u32 %0, %1, 0, %0, %1" : "+v"(t[i]), "+s"(cy2));
+            uint32_t top;
+            asm("v_addc_co_u32 %0, %1, 0, 0, %1" : "=v"(top), "+s"(cy2));
+            t[0] += (0u - top) & C;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = t[i];
+    } else {
     uint64_t c = 0;
     uint32_t t[N];
 #pragma unroll
@@ -120,12 +149,33 @@ __device__ __forceinline__ void fe_add(feT<N> &r, const feT<N> &a, const feT<N> 
 #pragma unroll
     for (int i = 1; i < N; ++i) { f += t[i]; r.v[i] = (uint32_t)f; f >>= 32; }
     r.v[0] += (uint32_t)f ? C : 0u;
+    }
 }
 // r = a - b (mod p), weakly reduced (borrow folds back as -c, mirrored reasoning)
-template <int N>
+template <class P = CtOps, int N>
 __device__ __forceinline__ void fe_sub(feT<N> &r, const feT<N> &a, const feT<N> &b)
 {
     constexpr uint32_t C = CurveC<N>::C;
+    if constexpr (P::VT) {
+        uint32_t t[N], k;
+        uint64_t bw, bw2;
+        const uint32_t cv = C;
+        asm("v_sub_co_u32 %0, %1, %2, %3" : "=v"(t[0]), "=s"(bw) : "v"(a.v[0]), "v"(b.v[0]));
+#pragma unroll
+        for (int i = 1; i < N; ++i)
+            asm("v_subb_co_u32 %0, %1, %2, %3, %1" : "=v"(t[i]), "+s"(bw) : "v"(a.v[i]), "v"(b.v[i]));
+        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(k) : "v"(cv), "s"(bw));            // borrowed from 2^(32N): - c
+        asm("v_sub_co_u32 %0, %1, %2, %3" : "=v"(t[0]), "=s"(bw2) : "v"(t[0]), "v"(k));
+        if (__builtin_expect(bw2 != 0, 0)) {
+#pragma unroll
+            for (int i = 1; i < N; ++i) asm("v_subb_co_u32 %0, %1, %0, 0, %1" : "+v"(t[i]), "+s"(bw2));
+            uint32_t top;                                                               // 0 or 0xFFFFFFFF
+            asm("v_subb_co_u32 %0, %1, 0, 0, %1" : "=v"(top), "+s"(bw2));
+            t[0] -= top & C;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = t[i];
+    } else {
     uint32_t t[N];
     uint32_t borrow = 0;
 #pragma unroll
@@ -141,14 +191,15 @@ __device__ __forceinline__ void fe_sub(feT<N> &r, const feT<N> &a, const feT<N> 
         r.v[i] = (uint32_t)d; bw = (uint32_t)(d >> 32) & 1u;
     }
     r.v[0] -= bw ? C : 0u;
+    }
 }
-template <int N>
-__device__ __forceinline__ void fe_dbl(feT<N> &r, const feT<N> &a) { fe_add(r, a, a); }
-template <int N>
+template <class P = CtOps, int N>
+__device__ __forceinline__ void fe_dbl(feT<N> &r, const feT<N> &a) { fe_add<P>(r, a, a); }
+template <class P = CtOps, int N>
 __device__ __forceinline__ void fe_neg(feT<N> &r, const feT<N> &a)
 {
     feT<N> z; fe_set_zero(z);
-    fe_sub(r, z, a);
+    fe_sub<P>(r, z, a);
 }
 // the unique representative in [0, p)
 template <int N>
@@ -168,7 +219,7 @@ __device__ __forceinline__ void fe_canon(feT<N> &r, const feT<N> &a)
 // w[0..2N) -> r = K * (lo + c*hi) mod p, weakly reduced.  K is a small compile-time
 // post-scale (1, 2, 3, 4, 8): r = K * (a*b).  K*c <= 4552, so lo*K + hi*K*c needs 2N
 // multiplies instead of N when K > 1 -- still far cheaper than K-1 modular additions.
-template <uint32_t K, int N>
+template <uint32_t K, class P = CtOps, int N>
 __device__ __forceinline__ void fe_reduce(feT<N> &r, const uint32_t (&w)[2 * N])
 {
     constexpr uint32_t C = CurveC<N>::C;
@@ -187,6 +238,21 @@ __device__ __forceinline__ void fe_reduce(feT<N> &r, const uint32_t (&w)[2 * N])
     // zero-extends every limb into a register pair: 2 v_mov + 1 v_lshl_add_u64 per limb.)
     const uint32_t cc = (uint32_t)c * C;
     uint64_t cy;
+    if constexpr (P::VT) {
+        // cc < 2^24: the carry leaves limb 1 with probability 2^-40 per lane -- two limbs, then a wavefront-uniform test
+        asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(t[0]), "=s"(cy) : "v"(t[0]), "v"(cc));
+        asm("v_addc_co_u32 %0, %1, 0, %0, %1" : "+v"(t[1]), "+s"(cy));
+        if (__builtin_expect(cy != 0, 0)) {
+#pragma unroll
+            for (int i = 2; i < N; ++i) asm("v_addc_co_u32 %0, %1, 0, %0, %1" : "+v"(t[i]), "+s"(cy));
+            uint32_t top;
+            asm("v_addc_co_u32 %0, %1, 0, 0, %1" : "=v"(top), "+s"(cy));
+            t[0] += (0u - top) & C;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = t[i];
+        return;
+    }
     asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(r.v[0]), "=s"(cy) : "v"(t[0]), "v"(cc));
 #pragma unroll
     for (int i = 1; i < N; ++i)
@@ -199,7 +265,7 @@ __device__ __forceinline__ void fe_reduce(feT<N> &r, const uint32_t (&w)[2 * N])
 
 // ------------------------------------------------------------- mul / sqr ---
 // product scanning: column k sums a[i]*b[k-i] into (c2 : acc64)
-template <uint32_t K, int N>
+template <uint32_t K, class P = CtOps, int N>
 __device__ __forceinline__ void fe_mul_body(feT<N> &r, const feT<N> &a, const feT<N> &b)
 {
     uint32_t w[2 * N];
@@ -216,7 +282,7 @@ __device__ __forceinline__ void fe_mul_body(feT<N> &r, const feT<N> &a, const fe
         acc = (acc >> 32) | ((uint64_t)c2 << 32);
     });
     w[2 * N - 1] = (uint32_t)acc;
-    fe_reduce<K>(r, w);
+    fe_reduce<K, P>(r, w);
 }
 
 // Squaring with N(N+3)/2 multiplications instead of N^2: row i multiplies a_i by the vector
@@ -224,7 +290,7 @@ __device__ __forceinline__ void fe_mul_body(feT<N> &r, const feT<N> &a, const fe
 // e_j = a_j << 1 is the doubled limb WITHOUT the bit shifted in from a_{j-1} (that bit belongs
 // to the part of 2a below position i+1, which row i does not use).  Same product-scanning
 // accumulator as fe_mul (cf. zzSqr, src/math/zz/zz_mul.c:112-154, which doubles afterwards).
-template <uint32_t K, int N>
+template <uint32_t K, class P = CtOps, int N>
 __device__ __forceinline__ void fe_sqr_body(feT<N> &r, const feT<N> &a)
 {
     uint32_t d[N + 1], e[N];
@@ -256,38 +322,38 @@ __device__ __forceinline__ void fe_sqr_body(feT<N> &r, const feT<N> &a)
         acc = (acc >> 32) | ((uint64_t)c2 << 32);
         c2 = 0;
     });
-    fe_reduce<K>(r, w);
+    fe_reduce<K, P>(r, w);
 }
 
 // The 256-bit curve (the graded path) inlines every multiplication.  For N = 12 / 16 the fully
 // unrolled bodies (144 / 256 multiply-adds) are compiled ONCE per (K, N) as real functions taking
 // and returning elements by value (in VGPRs): it keeps the build in seconds instead of minutes and
 // relieves the register allocator of the callers.
-template <uint32_t K, int N>
+template <uint32_t K, class P, int N>
 __device__ __noinline__ feT<N> fe_mul_call(feT<N> a, feT<N> b)
 {
     feT<N> r;
-    fe_mul_body<K>(r, a, b);
+    fe_mul_body<K, P>(r, a, b);
     return r;
 }
-template <uint32_t K, int N>
+template <uint32_t K, class P, int N>
 __device__ __noinline__ feT<N> fe_sqr_call(feT<N> a)
 {
     feT<N> r;
-    fe_sqr_body<K>(r, a);
+    fe_sqr_body<K, P>(r, a);
     return r;
 }
-template <uint32_t K = 1, int N>
+template <uint32_t K = 1, class P = CtOps, int N>
 __device__ __forceinline__ void fe_mul(feT<N> &r, const feT<N> &a, const feT<N> &b)
 {
-    if (N == 8) fe_mul_body<K>(r, a, b);
-    else r = fe_mul_call<K, N>(a, b);
+    if (N == 8) fe_mul_body<K, P>(r, a, b);
+    else r = fe_mul_call<K, P, N>(a, b);
 }
-template <uint32_t K = 1, int N>
+template <uint32_t K = 1, class P = CtOps, int N>
 __device__ __forceinline__ void fe_sqr(feT<N> &r, const feT<N> &a)
 {
-    if (N == 8) fe_sqr_body<K>(r, a);
-    else r = fe_sqr_call<K, N>(a);
+    if (N == 8) fe_sqr_body<K, P>(r, a);
+    else r = fe_sqr_call<K, P, N>(a);
 }
 
 template <int N>
@@ -494,82 +560,82 @@ __device__ __forceinline__ feT<N> fe_inv_checked(const feT<N> &x)
 // ----------------------------------------------------------------- points ---
 // T <- 2T, a = -3.  4M + 4S + 6 add/sub.  Z3 = 2YZ, so Y = 0 or Z = 0 gives O as in
 // ecp_j.c:258-263.  (dbl-2001-b with the small multiples moved into the reductions.)
-template <int N>
+template <int N, class P = CtOps>
 __device__ __forceinline__ void jac_dbl(jacT<N> &T)
 {
     feT<N> delta, gamma, beta4, alpha, t0, t1;
-    fe_sqr(delta, T.Z);
-    fe_sqr(gamma, T.Y);
-    fe_mul<4>(beta4, T.X, gamma);            // 4 X Y^2
-    fe_sub(t0, T.X, delta);
-    fe_add(t1, T.X, delta);
-    fe_mul<3>(alpha, t0, t1);                // 3 (X - Z^2)(X + Z^2)
-    fe_mul<2>(T.Z, T.Y, T.Z);                // Z3 = 2 Y Z
-    fe_sqr(t0, alpha);
-    fe_dbl(t1, beta4);
-    fe_sub(T.X, t0, t1);                     // X3 = alpha^2 - 8 beta
-    fe_sqr<8>(t1, gamma);                    // 8 Y^4
-    fe_sub(t0, beta4, T.X);
-    fe_mul(t0, alpha, t0);
-    fe_sub(T.Y, t0, t1);                     // Y3 = alpha (4 beta - X3) - 8 Y^4
+    fe_sqr<1, P>(delta, T.Z);
+    fe_sqr<1, P>(gamma, T.Y);
+    fe_mul<4, P>(beta4, T.X, gamma);            // 4 X Y^2
+    fe_sub<P>(t0, T.X, delta);
+    fe_add<P>(t1, T.X, delta);
+    fe_mul<3, P>(alpha, t0, t1);                // 3 (X - Z^2)(X + Z^2)
+    fe_mul<2, P>(T.Z, T.Y, T.Z);                // Z3 = 2 Y Z
+    fe_sqr<1, P>(t0, alpha);
+    fe_dbl<P>(t1, beta4);
+    fe_sub<P>(T.X, t0, t1);                     // X3 = alpha^2 - 8 beta
+    fe_sqr<8, P>(t1, gamma);                    // 8 Y^4
+    fe_sub<P>(t0, beta4, T.X);
+    fe_mul<1, P>(t0, alpha, t0);
+    fe_sub<P>(T.Y, t0, t1);                     // Y3 = alpha (4 beta - X3) - 8 Y^4
 }
 
 // T <- T + E for Jacobian E (add-1998-cmo-2, 12M + 4S).  Returns false when the generic
 // formula does not apply (either operand O, or T = +-E): the caller then marks the
 // signature for the complete slow path (ecp_j.c:416-427,455-464 handle these inline).
-template <int N>
+template <int N, class P = CtOps>
 __device__ __forceinline__ bool jac_add(jacT<N> &T, const jacT<N> &E)
 {
     feT<N> Z1Z1, Z2Z2, U1, U2, S1, S2, H, HH, HHH, r, V, t;
     const bool bad_in = fe_is_zero(T.Z) || fe_is_zero(E.Z);
-    fe_sqr(Z1Z1, T.Z);
-    fe_sqr(Z2Z2, E.Z);
-    fe_mul(U1, T.X, Z2Z2);
-    fe_mul(U2, E.X, Z1Z1);
-    fe_mul(t, E.Z, Z2Z2);  fe_mul(S1, T.Y, t);
-    fe_mul(t, T.Z, Z1Z1);  fe_mul(S2, E.Y, t);
-    fe_sub(H, U2, U1);
+    fe_sqr<1, P>(Z1Z1, T.Z);
+    fe_sqr<1, P>(Z2Z2, E.Z);
+    fe_mul<1, P>(U1, T.X, Z2Z2);
+    fe_mul<1, P>(U2, E.X, Z1Z1);
+    fe_mul<1, P>(t, E.Z, Z2Z2);  fe_mul<1, P>(S1, T.Y, t);
+    fe_mul<1, P>(t, T.Z, Z1Z1);  fe_mul<1, P>(S2, E.Y, t);
+    fe_sub<P>(H, U2, U1);
     const bool bad = bad_in || fe_is_zero(H);
-    fe_sub(r, S2, S1);
-    fe_sqr(HH, H);
-    fe_mul(HHH, H, HH);
-    fe_mul(V, U1, HH);
-    fe_mul(t, T.Z, E.Z);   fe_mul(T.Z, t, H);           // Z3 = Z1 Z2 H
-    fe_sqr(t, r);
-    fe_sub(t, t, HHH);
-    fe_dbl(U2, V);
-    fe_sub(T.X, t, U2);                                 // X3 = r^2 - H^3 - 2V
-    fe_sub(t, V, T.X);
-    fe_mul(t, r, t);
-    fe_mul(S2, S1, HHH);
-    fe_sub(T.Y, t, S2);                                 // Y3 = r (V - X3) - S1 H^3
+    fe_sub<P>(r, S2, S1);
+    fe_sqr<1, P>(HH, H);
+    fe_mul<1, P>(HHH, H, HH);
+    fe_mul<1, P>(V, U1, HH);
+    fe_mul<1, P>(t, T.Z, E.Z);   fe_mul<1, P>(T.Z, t, H);           // Z3 = Z1 Z2 H
+    fe_sqr<1, P>(t, r);
+    fe_sub<P>(t, t, HHH);
+    fe_dbl<P>(U2, V);
+    fe_sub<P>(T.X, t, U2);                                 // X3 = r^2 - H^3 - 2V
+    fe_sub<P>(t, V, T.X);
+    fe_mul<1, P>(t, r, t);
+    fe_mul<1, P>(S2, S1, HHH);
+    fe_sub<P>(T.Y, t, S2);                                 // Y3 = r (V - X3) - S1 H^3
     return !bad;
 }
 
 // T <- T + E for affine E (madd, 8M + 3S); same contract as jac_add
-template <int N>
+template <int N, class P = CtOps>
 __device__ __forceinline__ bool jac_madd(jacT<N> &T, const affT<N> &E)
 {
     feT<N> Z1Z1, U2, S2, H, HH, HHH, r, V, t;
     const bool bad_in = fe_is_zero(T.Z);
-    fe_sqr(Z1Z1, T.Z);
-    fe_mul(U2, E.x, Z1Z1);
-    fe_mul(t, T.Z, Z1Z1);  fe_mul(S2, E.y, t);
-    fe_sub(H, U2, T.X);
+    fe_sqr<1, P>(Z1Z1, T.Z);
+    fe_mul<1, P>(U2, E.x, Z1Z1);
+    fe_mul<1, P>(t, T.Z, Z1Z1);  fe_mul<1, P>(S2, E.y, t);
+    fe_sub<P>(H, U2, T.X);
     const bool bad = bad_in || fe_is_zero(H);
-    fe_sub(r, S2, T.Y);
-    fe_sqr(HH, H);
-    fe_mul(HHH, H, HH);
-    fe_mul(V, T.X, HH);
-    fe_mul(T.Z, T.Z, H);                                // Z3 = Z1 H
-    fe_sqr(t, r);
-    fe_sub(t, t, HHH);
-    fe_dbl(U2, V);
-    fe_sub(T.X, t, U2);
-    fe_sub(t, V, T.X);
-    fe_mul(t, r, t);
-    fe_mul(S2, T.Y, HHH);
-    fe_sub(T.Y, t, S2);
+    fe_sub<P>(r, S2, T.Y);
+    fe_sqr<1, P>(HH, H);
+    fe_mul<1, P>(HHH, H, HH);
+    fe_mul<1, P>(V, T.X, HH);
+    fe_mul<1, P>(T.Z, T.Z, H);                                // Z3 = Z1 H
+    fe_sqr<1, P>(t, r);
+    fe_sub<P>(t, t, HHH);
+    fe_dbl<P>(U2, V);
+    fe_sub<P>(T.X, t, U2);
+    fe_sub<P>(t, V, T.X);
+    fe_mul<1, P>(t, r, t);
+    fe_mul<1, P>(S2, T.Y, HHH);
+    fe_sub<P>(T.Y, t, S2);
     return !bad;
 }
 

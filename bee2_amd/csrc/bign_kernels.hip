@@ -255,13 +255,13 @@ __device__ __forceinline__ bool prep_points(const uint8_t *__restrict__ hashes, 
     jacT<N> A, T;
     store_qxy(S, 0, idx, Q.x, Q.y);
     A.X = Q.x; A.Y = Q.y; fe_set_one(A.Z);
-    jac_dbl(A);                           put(1, A);      // 2Q
-    T = A;   ok &= jac_madd(T, Q);        put(2, T);      // 3Q
-    jac_dbl(A);                           put(3, A);      // 4Q
-    jac_dbl(T);                           put(5, T);      // 6Q
-    ok &= jac_madd(T, Q);                 put(6, T);      // 7Q
-    T = A;   ok &= jac_madd(T, Q);        put(4, T);      // 5Q
-    jac_dbl(A);                           put(7, A);      // 8Q
+    jac_dbl<N, VtOps>(A);                           put(1, A);      // 2Q
+    T = A;   ok &= jac_madd<N, VtOps>(T, Q);        put(2, T);      // 3Q
+    jac_dbl<N, VtOps>(A);                           put(3, A);      // 4Q
+    jac_dbl<N, VtOps>(T);                           put(5, T);      // 6Q
+    ok &= jac_madd<N, VtOps>(T, Q);                 put(6, T);      // 7Q
+    T = A;   ok &= jac_madd<N, VtOps>(T, Q);        put(4, T);      // 5Q
+    jac_dbl<N, VtOps>(A);                           put(7, A);      // 8Q
     S.status[idx] = ok ? ST_PENDING : ST_SLOW;
     return ok;
 }
@@ -309,7 +309,7 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
         for (int k = 0; k < 7; ++k) {
             store_soa(Cs + (size_t)k * N * S.n_pad, S.n_pad, idx, acc);
             load_soa(z, Zs + (size_t)k * N * S.n_pad, S.n_pad, idx);
-            fe_mul(acc, acc, z);
+            fe_mul<1, VtOps>(acc, acc, z);
         }
     }
     if (!todo) return;
@@ -321,17 +321,17 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
 #pragma unroll 1
         for (int k = 6; k >= 0; --k) {
             load_soa(v, Cs + (size_t)k * N * S.n_pad, S.n_pad, idx);
-            fe_mul(zi, inv, v);                           // 1 / Z_k
+            fe_mul<1, VtOps>(zi, inv, v);                           // 1 / Z_k
             load_soa(z, Zs + (size_t)k * N * S.n_pad, S.n_pad, idx);
-            fe_mul(inv, inv, z);                          // 1 / (product before Z_k)
+            fe_mul<1, VtOps>(inv, inv, z);                          // 1 / (product before Z_k)
             uint32_t *b = S.qtab + (size_t)(k + 1) * 2 * N * S.n_pad;
-            fe_sqr(zi2, zi);
+            fe_sqr<1, VtOps>(zi2, zi);
             load_soa(v, b, S.n_pad, idx);
-            fe_mul(v, v, zi2);
+            fe_mul<1, VtOps>(v, v, zi2);
             store_soa(b, S.n_pad, idx, v);                // x = X / Z^2
-            fe_mul(zi2, zi2, zi);
+            fe_mul<1, VtOps>(zi2, zi2, zi);
             load_soa(v, b + (size_t)N * S.n_pad, S.n_pad, idx);
-            fe_mul(v, v, zi2);
+            fe_mul<1, VtOps>(v, v, zi2);
             store_soa(b + (size_t)N * S.n_pad, S.n_pad, idx, v);   // y = Y / Z^3
         }
     }
@@ -369,7 +369,7 @@ void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
 #pragma unroll 1
     for (int i = 4 * N - 1; i >= 0; --i) {
 #pragma unroll 1
-        for (int k = 0; k < 4; ++k) jac_dbl(T);
+        for (int k = 0; k < 4; ++k) jac_dbl<N, VtOps>(T);
         const int d = (int)(w[NW - 2] >> 28) - 8;       // next digit, in [-8, 7]
 #pragma unroll
         for (int l = NW - 2; l > 0; --l) w[l] = (w[l] << 4) | (w[l - 1] >> 28);
@@ -377,8 +377,8 @@ void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
         if (d != 0) {
             affT<N> E;
             load_qaff(E, S, (d < 0 ? -d : d) - 1, idx);
-            if (d < 0) fe_neg(E.y, E.y);
-            ok &= jac_madd(T, E);
+            if (d < 0) fe_neg<VtOps>(E.y, E.y);
+            ok &= jac_madd<N, VtOps>(T, E);
         }
     }
     // + u G : comb over the W-bit windows of u (mixed additions only)
@@ -393,7 +393,7 @@ void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
         if (b != 0) {
             affT<N> E;
             load_aff(E, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
-            ok &= jac_madd(T, E);
+            ok &= jac_madd<N, VtOps>(T, E);
         }
     }
     ok &= !fe_is_zero(T.Z);
@@ -694,7 +694,7 @@ void bign_inv_kernel(size_t n, size_t lanes, int K, VerifyScratch S)
         if (idx >= n) break;
         if (S.status[idx] == ST_PENDING) {
             load_soa(z, Z, S.n_pad, idx);
-            fe_mul(acc, acc, z);
+            fe_mul<1, VtOps>(acc, acc, z);
         }
         store_soa(PZ, S.n_pad, idx, acc);             // product of the pending Z up to and including t
     }
@@ -706,13 +706,13 @@ void bign_inv_kernel(size_t n, size_t lanes, int K, VerifyScratch S)
         feT<N> zi = inv;
         if (t > 0) {
             load_soa(acc, PZ, S.n_pad, idx - lanes);
-            fe_mul(zi, inv, acc);                     // 1 / Z_t
+            fe_mul<1, VtOps>(zi, inv, acc);                     // 1 / Z_t
             load_soa(z, Z, S.n_pad, idx);
-            fe_mul(inv, inv, z);                      // 1 / (product up to t - 1)
+            fe_mul<1, VtOps>(inv, inv, z);                      // 1 / (product up to t - 1)
         }
-        fe_sqr(zi, zi);
+        fe_sqr<1, VtOps>(zi, zi);
         load_soa(z, S.rx, S.n_pad, idx);
-        fe_mul(zi, z, zi);
+        fe_mul<1, VtOps>(zi, z, zi);
         fe_canon(zi, zi);
         store_soa(S.rx, S.n_pad, idx, zi);
     }
@@ -1097,7 +1097,9 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
     //   above             : one lane per signature, 32-bit limbs (the throughput form)
     int path = 1;
     if constexpr (N == 8) path = g_verify_path ? g_verify_path : n <= ((size_t)1 << 15) ? 3 : n <= ((size_t)1 << 16) ? 2 : 1;
-    else path = g_verify_path == 1 || g_verify_path == 3 ? g_verify_path : n <= ((size_t)1 << 14) ? 3 : 1;   // quads only
+    // wider curves, quads only: up to 2^14 signatures they leave one wavefront per SIMD; up to 2^15 two, which costs twice
+    // the time (2.4 / 4.7 ms) and still beats the one-lane kernels' latency floor (3.4 / 6.7 ms, profiles/r03_verify_wide.txt)
+    else path = g_verify_path == 1 || g_verify_path == 3 ? g_verify_path : n <= ((size_t)1 << 15) ? 3 : 1;
     if (path == 3) {
         const auto launch = [&](auto kern, unsigned wg, unsigned lanes) -> err_t {
             const unsigned ns = wg / lanes;

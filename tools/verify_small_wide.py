@@ -25,17 +25,17 @@ def timed(fn, reps=10):
 
 for l in (192, 256):
     base = G.bign_big[str(l)]["base"]
-    for e in (8, 11, 13, 14, 15):
-        n = 1 << e
+    for n in (1 << 8, 1 << 11, 1 << 13, 1 << 14, 3 << 13, 1 << 15, 5 << 13, 3 << 14, 1 << 16):
         reps = n // len(base) + 1
         h, s, k = (torch.tensor(list((b"".join(bytes.fromhex(t[f]) for t in base) * reps)[: w * n]), dtype=torch.uint8).cuda()
                    for f, w in (("hash", l // 4), ("sig", 3 * l // 8), ("pubkey", l // 2)))
         codes = torch.empty(n, dtype=torch.int32, device="cuda")
         row = []
-        for path in (1, 0):
+        for path in (1, 3, 0):
             tune(2, path)
             ms = timed(lambda: eng.bignVerifyL_batch_dev(l, LEVEL_OID[l], h, s, k, codes))
             assert int((codes != 0).sum()) == 0
             row.append(ms)
         tune(2, 0)
-        print(f"l = {l}, 2^{e} signatures: r01 kernels {row[0]:.3f} ms, by size {row[1]:.3f} ms (x{row[0] / row[1]:.2f}); {n / row[1] / 1e3:.2f} M verifies/s")
+        print(f"l = {l}, {n} signatures: one-lane kernels {row[0]:.3f} ms, quads {row[1]:.3f} ms, by size {row[2]:.3f} ms "
+              f"(x{row[0] / row[2]:.2f}); {n / row[2] / 1e3:.2f} M verifies/s")
