@@ -912,6 +912,26 @@ __global__ void bign_debug_fe_kernel(int op, const uint32_t *a, const uint32_t *
     case 5: fe_mul<3>(r, x, y); break;
     case 6: fe_sqr<8>(r, x); break;
     case 7: r = x; break;
+    // 100 + op: the same operation in its verification flavour (VtOps: carry chains with rare wavefront-uniform branches)
+    case 100: fe_mul<1, VtOps>(r, x, y); break;
+    case 101: fe_sqr<1, VtOps>(r, x); break;
+    case 102: fe_add<VtOps>(r, x, y); break;
+    case 103: fe_sub<VtOps>(r, x, y); break;
+    case 105: fe_mul<3, VtOps>(r, x, y); break;
+    case 106: fe_sqr<8, VtOps>(r, x); break;
+    case 104: fe_neg<VtOps>(r, x); break;
+    case 109: case 110: {
+        uint32_t w[2 * N];
+        for (int i = 0; i < N; ++i) { w[i] = x.v[i]; w[N + i] = y.v[i]; }
+        if (op == 109) fe_reduce<1, VtOps>(r, w); else fe_reduce<3, VtOps>(r, w);
+    } break;
+    case 108: {
+        jacT<N> P; P.X = x; P.Y = y; fe_set_one(P.Z);
+        jac_dbl<N, VtOps>(P);
+        feT<N> zi = fe_inv(P.Z);
+        fe_sqr(zi, zi);
+        fe_mul(r, P.X, zi);
+    } break;
     case 9: case 10: {                    // fe_reduce on a raw 2N-limb value: a = low half, b = high half
         uint32_t w[2 * N];
         for (int i = 0; i < N; ++i) { w[i] = x.v[i]; w[N + i] = y.v[i]; }

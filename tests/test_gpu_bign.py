@@ -392,7 +392,7 @@ def test_crandall_reduction_carry_ripple(l):
     ta = dev(b"".join(x.to_bytes(nb, "little") for x in Ls))
     tb = dev(b"".join(x.to_bytes(nb, "little") for x in Hs))
     out = torch.empty_like(ta)
-    for op, K in ((9, 1), (10, 3)):
+    for op, K in ((9, 1), (10, 3), (109, 1), (110, 3)):          # 109 / 110: the verification flavour (rare-branch ripple)
         code = eng.lib.bee2hip_debug_feL(ctypes.c_size_t(l), op, ctypes.c_void_p(ta.data_ptr()),
                                          ctypes.c_void_p(tb.data_ptr()), ctypes.c_void_p(out.data_ptr()),
                                          ctypes.c_size_t(len(Ls)), None)
@@ -403,6 +403,67 @@ def test_crandall_reduction_carry_ripple(l):
         want = [K * (a + R * b) % P for a, b in zip(Ls, Hs)]
         bad = [(i, hex(Ls[i]), hex(Hs[i])) for i in range(len(Ls)) if got[i] != want[i]]
         assert not bad, (l, K, len(bad), bad[:3])
+
+
+@pytest.mark.parametrize("l", [128, 192, 256])
+def test_field_ops_verification_flavour_rare_carry_branches(l):
+    """the VtOps forms of add / sub / neg / mul / sqr / fold (debug ops 100 + op; what bign_main_kernel and bign_prep_kernel
+    run): the second carry pass sits behind a wavefront-uniform branch taken with probability 2^-24 per lane on random
+    data, so the operands are crafted to take it -- a + b = 2^(2l) + x with limb 0 of x within c of 2^32 and 0..N-1 limbs
+    of ones above it (the carry ripples that far, and out of the top for a, b >= p), a - b = -(y) with limb 0 of
+    2^(2l) - y below c over 0..N-1 zero limbs, folds that land within +-2 of 2^(32N) -- mixed with random lanes in the
+    same wavefronts, and compared with Python integers AND with the straight-line (CtOps) form of the same operation."""
+    eng = engine()
+    rnd = random.Random(1000 + l)
+    C = {128: 189, 192: 317, 256: 569}[l]
+    bits, nb = 2 * l, l // 4
+    R = 1 << bits
+    P = R - C
+    N = bits // 32
+    A, B = [], []
+    for j in range(N):                       # ripple length j limbs
+        ones = ((1 << (32 * j)) - 1) << 32
+        for k in list(range(1, 6)) + [C - 1, C, C + 1, C + 2]:
+            for hi in (0, 1 << (32 * (j + 1)) if j + 1 < N else 0, rnd.getrandbits(bits) >> (32 * (j + 1)) << (32 * (j + 1))):
+                x = (hi & (R - 1)) | ones | ((1 << 32) - k)                   # a + b = R + x
+                a = rnd.randrange(x + 1, R) if x + 1 < R else R - 1
+                b = R + x - a
+                if 0 <= b < R:
+                    A.append(a); B.append(b)
+                y = R - ((hi & (R - 1) & ~((1 << (32 * (j + 1))) - 1)) | (k - 1))   # a - b = -y: t = R - y has limb 0 = k - 1 < c
+                b2 = rnd.randrange(y, R) if y < R else R - 1
+                a2 = b2 - y
+                if 0 <= a2 < R:
+                    A.append(a2); B.append(b2)
+    zone = [P + i for i in range(C)]          # non-canonical operands: second wrap of an addition
+    A += [R - 1, R - 1, P, R - 1, 0, 0, 1] + [rnd.choice(zone) for _ in range(64)] + [rnd.getrandbits(bits) for _ in range(2000)]
+    B += [R - 1, P, P, 1, R - 1, P, R - 1] + [rnd.choice(zone) for _ in range(64)] + [rnd.getrandbits(bits) for _ in range(2000)]
+    order = list(range(len(A)))
+    rnd.shuffle(order)                        # rare lanes spread over the wavefronts
+    A = [A[i] for i in order]; B = [B[i] for i in order]
+    ta = dev(b"".join(x.to_bytes(nb, "little") for x in A))
+    tb = dev(b"".join(x.to_bytes(nb, "little") for x in B))
+    out = torch.empty_like(ta)
+
+    def run(op):
+        code = eng.lib.bee2hip_debug_feL(ctypes.c_size_t(l), op, ctypes.c_void_p(ta.data_ptr()), ctypes.c_void_p(tb.data_ptr()),
+                                         ctypes.c_void_p(out.data_ptr()), ctypes.c_size_t(len(A)), None)
+        assert code == 0
+        torch.cuda.synchronize()
+        raw = host(out)
+        return [int.from_bytes(raw[i:i + nb], "little") for i in range(0, len(raw), nb)]
+    ops = {0: lambda a, b: a * b % P, 1: lambda a, b: a * a % P, 2: lambda a, b: (a + b) % P, 3: lambda a, b: (a - b) % P,
+           5: lambda a, b: 3 * a * b % P, 6: lambda a, b: 8 * a * a % P, 9: lambda a, b: (a + R * b) % P,
+           10: lambda a, b: 3 * (a + R * b) % P}
+    for op, f in ops.items():
+        want = [f(a, b) for a, b in zip(A, B)]
+        vt, ct = run(100 + op), run(op)
+        bad = [(i, hex(A[i]), hex(B[i])) for i in range(len(A)) if vt[i] != want[i]]
+        assert not bad, (l, op, len(bad), bad[:3])
+        assert ct == want
+    assert run(104) == [(-a) % P for a in A]
+    # the point doubling in both flavours (x of 2P for Z = 1; any field values, on the curve or not -- same formulas)
+    assert run(108) == run(8)
 
 
 @pytest.mark.parametrize("l,path", [(192, 1), (192, 3), (256, 1), (256, 3)])
