@@ -170,6 +170,37 @@ struct BeltTabTwo {
     }
 };
 
+// EXPERIMENT (round 3; tools/belt_ab.py variants 10 / 11, profiles/r03_belt_hybrid.txt): the two-table
+// LDS layout for most G-boxes, and every G-box for which `via_l1<R0, SLOT>()` says so looked up through the vector L1
+// instead -- four rotated tables of 256 dwords in global memory (4 KiB, L1-resident), one global_load_dword per byte
+// with the table selector in the immediate offset -- so that TA/TCP cycles run beside the LDS pipe.  Not the product.
+extern __device__ uint32_t d_beltT4[1024];
+template <int ROUNDS>                  // bit i-1 set: the last G-box of round i goes through the L1
+struct BeltTabHyb : BeltTabTwo {
+    __device__ explicit BeltTabHyb(const uint8_t *l) : BeltTabTwo(l) {}
+    template <int R0>
+    __device__ __forceinline__ GParts g_l1(uint32_t x) const
+    {
+        const uint32_t o0 = shl_c<2>(x) & 0x3FCu, o1 = shr_c<6>(x) & 0x3FCu, o2 = shr_c<14>(x) & 0x3FCu, o3 = shr_c<22>(x) & 0x3FCu;
+        const uint8_t *t = reinterpret_cast<const uint8_t *>(d_beltT4);
+        const uint32_t t0 = *reinterpret_cast<const uint32_t *>(t + ((R0 + 0) & 3) * 1024 + o0);
+        const uint32_t t1 = *reinterpret_cast<const uint32_t *>(t + ((R0 + 1) & 3) * 1024 + o1);
+        const uint32_t t2 = *reinterpret_cast<const uint32_t *>(t + ((R0 + 2) & 3) * 1024 + o2);
+        const uint32_t t3 = *reinterpret_cast<const uint32_t *>(t + ((R0 + 3) & 3) * 1024 + o3);
+        GParts r;
+        r.p = xor3(t0, t1, t2);
+        r.q = t3;
+        return r;
+    }
+    // SLOT = position of the G-box inside its round (0..6), I = round (1..8)
+    template <int R0, int SLOT, int I>
+    __device__ __forceinline__ GParts gs(uint32_t x) const
+    {
+        if constexpr (SLOT == 6 && ((ROUNDS >> (I - 1)) & 1)) return g_l1<R0>(x);
+        else return BeltTabTwo::template g<R0>(x);
+    }
+};
+
 struct BeltTabSmall {
     static constexpr int kBytes = 4 * 256 * 4;             // 4096
     const uint8_t *lds;
@@ -274,6 +305,18 @@ __device__ __forceinline__ void belt_decr(const Tab &T, uint32_t (&x)[4], const 
 // N independent blocks in lockstep: each G-box step is issued for all N blocks before the
 // next step, so 4N LDS reads are in flight per wave (the LDS round trip, not the VALU, is
 // what a single E_K chain waits on).
+// G-box number SLOT of a round: tables with a slot-aware accessor (BeltTabHyb) choose their path by it
+template <int R0, int SLOT, int I, class Tab>
+__device__ __forceinline__ auto gbox(const Tab &T, uint32_t x, int) -> decltype(T.template gs<R0, SLOT, I>(x))
+{
+    return T.template gs<R0, SLOT, I>(x);
+}
+template <int R0, int SLOT, int I, class Tab>
+__device__ __forceinline__ GParts gbox(const Tab &T, uint32_t x, long)
+{
+    return T.template g<R0>(x);
+}
+
 template <int N, int I, class Tab>
 __device__ __forceinline__ void belt_round_n(const Tab &T, uint32_t (&a)[N], uint32_t (&b)[N],
                                              uint32_t (&c)[N], uint32_t (&d)[N], const uint32_t (&K)[8])
@@ -281,19 +324,19 @@ __device__ __forceinline__ void belt_round_n(const Tab &T, uint32_t (&a)[N], uin
     constexpr int o = 7 * I - 7;
     GParts g[N];
 #pragma unroll
-    for (int u = 0; u < N; ++u) g[u] = T.template g<0>(a[u] + K[(o + 0) & 7]);
+    for (int u = 0; u < N; ++u) g[u] = gbox<0, 0, I>(T, a[u] + K[(o + 0) & 7], 0);
 #pragma unroll
     for (int u = 0; u < N; ++u) b[u] = xor3(b[u], g[u].p, g[u].q);
 #pragma unroll
-    for (int u = 0; u < N; ++u) g[u] = T.template g<2>(d[u] + K[(o + 1) & 7]);
+    for (int u = 0; u < N; ++u) g[u] = gbox<2, 1, I>(T, d[u] + K[(o + 1) & 7], 0);
 #pragma unroll
     for (int u = 0; u < N; ++u) c[u] = xor3(c[u], g[u].p, g[u].q);
 #pragma unroll
-    for (int u = 0; u < N; ++u) g[u] = T.template g<1>(b[u] + K[(o + 2) & 7]);
+    for (int u = 0; u < N; ++u) g[u] = gbox<1, 2, I>(T, b[u] + K[(o + 2) & 7], 0);
 #pragma unroll
     for (int u = 0; u < N; ++u) a[u] -= g[u].p ^ g[u].q;
 #pragma unroll
-    for (int u = 0; u < N; ++u) g[u] = T.template g<2>(b[u] + c[u] + K[(o + 3) & 7]);
+    for (int u = 0; u < N; ++u) g[u] = gbox<2, 3, I>(T, b[u] + c[u] + K[(o + 3) & 7], 0);
 #pragma unroll
     for (int u = 0; u < N; ++u) {
         const uint32_t e = xor3(g[u].p, g[u].q, (uint32_t)I);
@@ -301,15 +344,15 @@ __device__ __forceinline__ void belt_round_n(const Tab &T, uint32_t (&a)[N], uin
         c[u] -= e;
     }
 #pragma unroll
-    for (int u = 0; u < N; ++u) g[u] = T.template g<1>(c[u] + K[(o + 4) & 7]);
+    for (int u = 0; u < N; ++u) g[u] = gbox<1, 4, I>(T, c[u] + K[(o + 4) & 7], 0);
 #pragma unroll
     for (int u = 0; u < N; ++u) d[u] += g[u].p ^ g[u].q;
 #pragma unroll
-    for (int u = 0; u < N; ++u) g[u] = T.template g<2>(a[u] + K[(o + 5) & 7]);
+    for (int u = 0; u < N; ++u) g[u] = gbox<2, 5, I>(T, a[u] + K[(o + 5) & 7], 0);
 #pragma unroll
     for (int u = 0; u < N; ++u) b[u] = xor3(b[u], g[u].p, g[u].q);
 #pragma unroll
-    for (int u = 0; u < N; ++u) g[u] = T.template g<0>(d[u] + K[(o + 6) & 7]);
+    for (int u = 0; u < N; ++u) g[u] = gbox<0, 6, I>(T, d[u] + K[(o + 6) & 7], 0);
 #pragma unroll
     for (int u = 0; u < N; ++u) c[u] = xor3(c[u], g[u].p, g[u].q);
 }

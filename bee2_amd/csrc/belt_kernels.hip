@@ -24,10 +24,23 @@
 namespace bee2hip {
 
 __constant__ uint8_t c_beltH[256];
+__device__ uint32_t d_beltT4[1024];       // experiment only (BeltTabHyb): rotl(S, 5 / 13 / 21 / 29), 4 x 256 dwords
 
 constexpr int CTR_WG = 1024;
 typedef BeltTabTwo CtrTab;          // 64 KiB: two workgroups (32 wavefronts) per CU
 constexpr int CTR_ILP = 1;          // independent blocks per lane per step (r02 A/B: 1 beats 2 by 1.3-1.5 %, profiles/r02_belt_variants.txt)
+
+typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));      // what the non-temporal builtins accept
+__device__ __forceinline__ uint4 nt_load16(const uint4 *p)
+{
+    const v4u_t v = __builtin_nontemporal_load(reinterpret_cast<const v4u_t *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store16(uint4 *p, const uint4 o)
+{
+    v4u_t v = {o.x, o.y, o.z, o.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<v4u_t *>(p));
+}
 
 struct BeltKey { uint32_t k[8]; };
 struct BeltCtr { uint32_t c[4]; };
@@ -46,7 +59,10 @@ __device__ __forceinline__ void ctr_at(uint32_t (&x)[4], const BeltCtr &c0, uint
 // Tab / ILP are template parameters so that the round-2 A/B (profiles/r02_belt_variants.txt)
 // runs the very same body: the product is <CtrTab, CTR_ILP>; the others are reachable only through
 // bee2hip_internal_tune(1, v).
-template <class Tab, int ILP>
+// MEM (round-3 A/B; profiles/r03_belt_mem_ab.txt): bit 0 = non-temporal loads and stores of the
+// stream (read once, written once), bit 1 = every workgroup walks ONE contiguous range of tiles instead of taking every
+// gridDim-th tile (a new 2 MiB page per tile and workgroup).
+template <class Tab, int ILP, int MEM = 0>
 __global__ __launch_bounds__(CTR_WG, (BeltTabWide::kBytes / Tab::kBytes) * (CTR_WG / 256))
 void beltCTR_blocks_kernel(uint4 *__restrict__ buf, size_t nblocks, BeltKey key, BeltCtr ctr0,
                            uint64_t first, uint4 *__restrict__ last_gamma)
@@ -62,7 +78,12 @@ void beltCTR_blocks_kernel(uint4 *__restrict__ buf, size_t nblocks, BeltKey key,
 
     // tile = CTR_WG * ILP consecutive blocks; tiles are dealt round-robin to workgroups
     const size_t tile = (size_t)CTR_WG * ILP;
-    for (size_t t0 = (size_t)blockIdx.x * tile; t0 < nblocks; t0 += (size_t)gridDim.x * tile) {
+    const size_t ntiles = (nblocks + tile - 1) / tile;
+    const size_t per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+    const size_t t_begin = (MEM & 2) ? (size_t)blockIdx.x * per_wg * tile : (size_t)blockIdx.x * tile;
+    const size_t t_end = (MEM & 2) ? ((size_t)blockIdx.x + 1) * per_wg * tile : nblocks;
+    const size_t t_step = (MEM & 2) ? tile : (size_t)gridDim.x * tile;
+    for (size_t t0 = t_begin; t0 < nblocks && t0 < t_end; t0 += t_step) {
         uint4 data[ILP];
         uint32_t g[ILP][4];
         bool live[ILP];
@@ -70,7 +91,7 @@ void beltCTR_blocks_kernel(uint4 *__restrict__ buf, size_t nblocks, BeltKey key,
         for (int u = 0; u < ILP; ++u) {
             const size_t i = t0 + (size_t)u * CTR_WG + threadIdx.x;
             live[u] = i < nblocks;
-            if (live[u]) data[u] = buf[i];
+            if (live[u]) data[u] = (MEM & 1) ? nt_load16(&buf[i]) : buf[i];
             ctr_at(g[u], ctr0, first + i + 1);
         }
         belt_encr_n<ILP>(T, g, K);
@@ -81,7 +102,7 @@ void beltCTR_blocks_kernel(uint4 *__restrict__ buf, size_t nblocks, BeltKey key,
                 uint4 o;
                 o.x = data[u].x ^ g[u][0]; o.y = data[u].y ^ g[u][1];
                 o.z = data[u].z ^ g[u][2]; o.w = data[u].w ^ g[u][3];
-                buf[i] = o;
+                if (MEM & 1) nt_store16(&buf[i], o); else buf[i] = o;
                 // streaming state needs the gamma of the final block (belt_ctr.c:89-96)
                 if (last_gamma && i == nblocks - 1)
                     *last_gamma = make_uint4(g[u][0], g[u][1], g[u][2], g[u][3]);
@@ -622,18 +643,25 @@ static int num_cus()
 err_t upload_beltH(const uint8_t *H)
 {
     B2H_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_beltH), H, 256));
+    uint32_t t4[1024];
+    for (int i = 0; i < 1024; ++i) {
+        const uint32_t v = H[i & 255];
+        const int r = 5 + 8 * (i >> 8);
+        t4[i] = (v << r) | (v >> (32 - r));
+    }
+    B2H_TRY(hipMemcpyToSymbol(HIP_SYMBOL(d_beltT4), t4, sizeof t4));
     return ERR_OK;
 }
 
 static int g_ctr_variant = 0;
 void set_ctr_variant(int v) { g_ctr_variant = v; }
 
-template <class Tab, int ILP>
+template <class Tab, int ILP, int MEM = 0>
 static err_t launch_ctr_t(void *d_buf, size_t nblocks, const BeltKey &k, const BeltCtr &c, uint64_t first,
                           void *d_last_gamma, hipStream_t st)
 {
     static bool attr[64];
-    auto kern = beltCTR_blocks_kernel<Tab, ILP>;
+    auto kern = beltCTR_blocks_kernel<Tab, ILP, MEM>;
     if (!attr[cur_dev()]) {
         B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     Tab::kBytes));
@@ -664,7 +692,15 @@ err_t launch_belt_ctr_blocks(void *d_buf, size_t nblocks, const uint32_t key[8],
     case 4: return launch_ctr_t<BeltTabWide, 2>(d_buf, nblocks, k, c, first, d_last_gamma, st);
     case 5: return launch_ctr_t<BeltTabWide, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);
     case 6: return launch_ctr_t<BeltTabWide, 4>(d_buf, nblocks, k, c, first, d_last_gamma, st);
-    default: return launch_ctr_t<CtrTab, CTR_ILP>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    case 7: return launch_ctr_t<CtrTab, CTR_ILP, 1>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    case 8: return launch_ctr_t<CtrTab, CTR_ILP, 2>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    case 9: return launch_ctr_t<CtrTab, CTR_ILP, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    case 10: return launch_ctr_t<BeltTabHyb<0xFF>, 1>(d_buf, nblocks, k, c, first, d_last_gamma, st);   // 32 of 224 lookups via L1
+    case 11: return launch_ctr_t<BeltTabHyb<0x55>, 1>(d_buf, nblocks, k, c, first, d_last_gamma, st);   // 16
+    case 12: return launch_ctr_t<BeltTabHyb<0x11>, 1>(d_buf, nblocks, k, c, first, d_last_gamma, st);   // 8
+    case 13: return launch_ctr_t<CtrTab, CTR_ILP, 0>(d_buf, nblocks, k, c, first, d_last_gamma, st);   // the round-2 product
+    // product (round 3): contiguous tile ranges + non-temporal stream accesses, +1 % (profiles/r03_belt_mem_ab.txt)
+    default: return launch_ctr_t<CtrTab, CTR_ILP, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);
     }
 }
 

@@ -14,13 +14,20 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import bee2_amd  # noqa: E402
 import orclib  # noqa: E402
 
-NAMES = {0: "product: T5/T29 two-table 64 KiB, 1 block/lane, 8 w/SIMD (26 VGPRs)",
+NAMES = {0: "product (round 3): two-table 64 KiB, 1 block/lane, contiguous tile ranges + non-temporal accesses",
+         13: "round-2 product: two-table 64 KiB, 1 block/lane, tiles dealt round-robin, plain loads/stores",
          1: "two-table, 2 blocks/lane, 8 w/SIMD (45 VGPRs) = the r01 product",
          2: "two-table, 3 blocks/lane, 8 w/SIMD (64 VGPRs, 2 spills)",
          3: "two-table, 4 blocks/lane, 8 w/SIMD (64 VGPRs, 40 spills)",
          4: "four-table 128 KiB (no post-shifts), 2 blocks/lane, 4 w/SIMD (45 VGPRs)",
          5: "four-table, 3 blocks/lane, 4 w/SIMD (66 VGPRs)",
-         6: "four-table, 4 blocks/lane, 4 w/SIMD (88 VGPRs)"}
+         6: "four-table, 4 blocks/lane, 4 w/SIMD (88 VGPRs)",
+         7: "product + non-temporal loads/stores",
+         8: "product, one contiguous range of tiles per workgroup",
+         9: "product, contiguous ranges + non-temporal",
+         10: "hybrid: 8 of 56 G-boxes (32 of 224 lookups) through the vector L1",
+         11: "hybrid: 4 of 56 G-boxes (16 lookups) through the vector L1",
+         12: "hybrid: 2 of 56 G-boxes (8 lookups) through the vector L1"}
 
 
 def main():
