@@ -194,6 +194,26 @@ constexpr int bashF_tile_lds()
     // STORE = P in {2, 4, 8}: P passes of 64 / P records through a slab of that many padded records
     return (LOAD == 1 || STORE == 1) ? 64 * BASHF_PAD : LOAD == 2 ? 7168 : (STORE == 2 || STORE == 4 || STORE == 8) ? (64 / STORE) * BASHF_PAD : 0;
 }
+typedef uint32_t bash_v4u __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 bashF_ld16(const uint4 *p)
+{
+    if constexpr (NT) {
+        const bash_v4u v = __builtin_nontemporal_load(reinterpret_cast<const bash_v4u *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    } else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void bashF_st16(uint4 *p, const uint4 o)
+{
+    if constexpr (NT) {
+        bash_v4u v = {o.x, o.y, o.z, o.w};
+        __builtin_nontemporal_store(v, reinterpret_cast<bash_v4u *>(p));
+    } else *p = o;
+}
+
+// FLAGS: 1 = priority 3 until the loads are out, 2 = priority 3 for the store phase, 4 = non-temporal loads,
+// 8 = non-temporal stores (round-3 A/B, profiles/r03_bashF_nt_ab.txt)
 template <int LOAD, int STORE, int ORDER, int MINW, int FLAGS = 0>
 __global__ __launch_bounds__(BASHF_WG, MINW)
 void bashF_tile_kernel(uint8_t *__restrict__ states, size_t n)
@@ -219,7 +239,7 @@ void bashF_tile_kernel(uint8_t *__restrict__ states, size_t n)
         const uint4 *p = reinterpret_cast<const uint4 *>(g + r * BASHF_REC);
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-            const uint4 v = p[j];
+            const uint4 v = bashF_ld16<(FLAGS & 4) != 0>(p + j);
             a[2 * j].lo = v.x; a[2 * j].hi = v.y; a[2 * j + 1].lo = v.z; a[2 * j + 1].hi = v.w;
         }
     } else if constexpr (LOAD == 1) {
@@ -281,7 +301,7 @@ void bashF_tile_kernel(uint8_t *__restrict__ states, size_t n)
                 if (o < bytes) {
                     const int rec = o / BASHF_REC, off = o % BASHF_REC;
                     const uint4 v = *reinterpret_cast<const uint4 *>(wl + rec * BASHF_PAD + off);
-                    *reinterpret_cast<uint4 *>(g + h * SLAB + o) = v;
+                    bashF_st16<(FLAGS & 8) != 0>(reinterpret_cast<uint4 *>(g + h * SLAB + o), v);
                 }
             }
         }
@@ -384,6 +404,9 @@ err_t launch_bashF_batch(void *d_states, size_t n, hipStream_t st)
     case 40: TILE(9, 9, 128, 4); break;      // ablation: rounds only, priority
     case 41: TILE(9, 9, 28, 4); break;       //           rounds only, no priority
     case 42: TILE(0, 2, -1, 4); break;       //           memory only: direct load, half-slab store
+    case 70: TILEF(0, 2, 124, 6, 3 | 4); break;      // product + non-temporal loads
+    case 71: TILEF(0, 2, 124, 6, 3 | 8); break;      // product + non-temporal stores
+    case 72: TILEF(0, 2, 124, 6, 3 | 12); break;     // product + both
     default: TILEF(0, 2, 124, 6, 3);         // product (v61): W = 4, priority, direct load, half-slab store
     }
 #undef TILE

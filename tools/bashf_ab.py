@@ -34,6 +34,7 @@ NAMES = {0: "r01 product: VGPR-staged load, slab store, staged order",
          58: "PRIO W=2, direct store, load prio", 59: "PRIO r01 staged, quarter-slab store, load prio",
          60: "PRIO W=2, quarter-slab, load+store prio", 61: "PRIO W=4, half-slab, load+store prio",
          62: "PRIO W=8, quarter-slab, load+store prio", 63: "PRIO W=4, quarter-slab, load+store prio",
+         70: "product (v61) + non-temporal loads", 71: "product + non-temporal stores", 72: "product + non-temporal loads and stores",
          40: "ablation: rounds only, W=8, PRIO", 41: "ablation: rounds only, W=8, no priority",
          42: "ablation: memory only (direct load, half-slab store)", 43: "ablation: memory only (direct load + store)",
          44: "ablation: rounds only, W=4, PRIO (6 w/SIMD)", 45: "ablation: rounds only, W=2, PRIO (8 w/SIMD)",
