@@ -2,8 +2,9 @@
 //
 // Host side of the engine: argument checks and state bookkeeping mirror bee2's
 // C functions line for line in *behaviour* (same names, same state layouts, same
-// error codes); every primitive evaluation is a kernel launch.  There is no CPU
-// implementation of bashF / E_K / EC arithmetic in this library.
+// error codes).  Every batch / _dev / _multi entry point and every bign operation evaluates its primitives in
+// kernels; the bee2 drop-in symbols do so too, except for small single calls, which take the host path of
+// host_small.hpp ("host path for small single calls" below says exactly when).
 #include <algorithm>
 #include <atomic>
 #include <mutex>
@@ -14,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "common.hpp"
+#include "host_small.hpp"
 #include "bign_curves.inc"   // (#pragma once: shared with bign_kernels.hip in the unity build)
 
 namespace bee2hip {
@@ -227,6 +229,87 @@ static inline hipError_t zero_staging(void *d, size_t n)
     return hipMemset(d, 0, n);
 }
 
+
+// ------------------------------------------------- host path for small single calls ---
+// host_small.hpp has the what and why.  Who runs where:
+//   BEE2HIP_FORCE=gpu   every drop-in call evaluates its primitives on the GPU (rounds 1-2 behaviour; a device failure
+//                       inside a void function aborts with a message)
+//   BEE2HIP_FORCE=cpu   every drop-in call that has a host path takes it, whatever its size (tests run the fixtures so)
+//   unset (auto)        by crossover: single primitives (bashF, one block), block-parallel modes below 8 KiB per call
+//                       and the serial chains of ONE message (sponge, CBC-MAC, belt-hash, CBC encryption, a belt-sde
+//                       sector: one lane of the GPU runs them at 3-7 MB/s, a host core at 60-170 MB/s) on the host;
+//                       everything else, every bign operation and EVERY batch / _dev / _multi entry point on the GPU.
+// In every mode the calling thread must have initialised its HIP device first (ensure_device): without a GPU the
+// library fails exactly as before.  In auto mode a GPU path that fails twice (once more after hipDeviceSynchronize) is
+// finished on the host with a warning on stderr instead of abort() -- bee2's Step functions cannot report errors and a
+// long-running service must survive a transient device fault.
+enum { FORCE_AUTO = 0, FORCE_GPU = 1, FORCE_CPU = 2 };
+enum { K_PRIM = 0, K_PARALLEL = 1, K_SERIAL = 2, K_POLY = 3 };
+static std::atomic<int> g_force{-1};
+static std::atomic<unsigned long long> g_n_host{0}, g_n_gpu{0}, g_n_fallback{0};
+static std::atomic<int> g_inject_fail{0};                  // tests: make the next n GPU attempts of a drop-in helper fail
+static hostp::BeltTables g_hostT;
+static std::once_flag g_hostT_once;
+static const hostp::BeltTables &hostT()
+{
+    std::call_once(g_hostT_once, [] { hostp::belt_tables(g_hostT, host_beltH()); });
+    return g_hostT;
+}
+static int force_mode()
+{
+    int m = g_force.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char *e = getenv("BEE2HIP_FORCE");
+        m = !e ? FORCE_AUTO : !strcmp(e, "gpu") ? FORCE_GPU : !strcmp(e, "cpu") ? FORCE_CPU : FORCE_AUTO;
+        g_force.store(m);
+    }
+    return m;
+}
+static bool host_wanted(int kind, size_t bytes)
+{
+    const int m = force_mode();
+    if (m == FORCE_GPU) return false;
+    if (m == FORCE_CPU) return true;
+    switch (kind) {
+    case K_PRIM: return bytes <= 1024;          // one permutation / up to 64 blocks: 0.3-0.5 us each vs ~20 us per launch
+    case K_PARALLEL: return bytes < 8192;       // INTEGRATION.md crossover table (CTR: 16 KiB 36 us vs 79 us on one core)
+    case K_POLY: return bytes <= 1024;          // the bit-serial host product: 0.4 us per block
+    default: return true;                       // K_SERIAL: one message = one dependent chain
+    }
+}
+static thread_local bool t_dev_seen = false;
+static inline err_t device_seen()
+{
+    if (t_dev_seen) return ERR_OK;
+    const err_t code = ensure_device();
+    if (code == ERR_OK) t_dev_seen = true;
+    return code;
+}
+// run a drop-in helper: `gpu` stages, launches and copies back (returns err_t, leaves the caller's data untouched when it
+// fails); `host` does the same work with host_small.hpp
+template <class G, class H>
+static err_t with_host(int kind, size_t bytes, const char *what, G gpu, H host)
+{
+    err_t code = device_seen();
+    if (code != ERR_OK) return code;            // no usable GPU: an error (void callers: die_on), never a silent CPU run
+    if (host_wanted(kind, bytes)) { host(); g_n_host.fetch_add(1, std::memory_order_relaxed); return ERR_OK; }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (g_inject_fail.load(std::memory_order_relaxed) > 0 && g_inject_fail.fetch_sub(1) > 0)
+            code = ERR_BEE2HIP_DEVICE;
+        else
+            code = gpu();
+        if (code == ERR_OK) { g_n_gpu.fetch_add(1, std::memory_order_relaxed); return ERR_OK; }
+        if (code != ERR_BEE2HIP_DEVICE) return code;         // bad input, out of memory: report, nothing to retry
+        (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+    }
+    if (force_mode() == FORCE_GPU) return code;
+    fprintf(stderr, "libbee2hip: %s: device path failed twice (%s); finished on the host\n", what, t_err);
+    host();
+    g_n_fallback.fetch_add(1, std::memory_order_relaxed);
+    return ERR_OK;
+}
+
 }  // namespace bee2hip
 
 using namespace bee2hip;
@@ -294,16 +377,18 @@ extern "C" err_t bee2hip_bashF_batch(octet *states, size_t n)
 // E_K over host blocks (n small): the only way the drop-in layer evaluates belt
 static err_t encr_host_blocks(uint32_t *blocks, size_t n, const u32 key[8])
 {
-    err_t code = ensure_device();
-    if (code != ERR_OK) return code;
-    Scratch &s = t_scr[1];
-    code = s.need(n * 16);
-    if (code != ERR_OK) return code;
-    B2H_TRY(h2d(s.p, blocks, n * 16));
-    code = launch_belt_encr_blocks(s.p, n, key, nullptr);
-    if (code != ERR_OK) return code;
-    B2H_TRY(d2h(blocks, s.p, n * 16));
-    return ERR_OK;
+    return with_host(K_PRIM, n * 16, "belt block encryption", [&]() -> err_t {
+        err_t code = ensure_device();
+        if (code != ERR_OK) return code;
+        Scratch &s = t_scr[1];
+        code = s.need(n * 16);
+        if (code != ERR_OK) return code;
+        B2H_TRY(h2d(s.p, blocks, n * 16));
+        code = launch_belt_encr_blocks(s.p, n, key, nullptr);
+        if (code != ERR_OK) return code;
+        B2H_TRY(d2h(blocks, s.p, n * 16));
+        return ERR_OK;
+    }, [&] { for (size_t i = 0; i < n; ++i) hostp::belt_encr(hostT(), blocks + 4 * i, key); });
 }
 
 // a device failure inside a void bee2 function cannot be reported through the bee2
@@ -321,7 +406,7 @@ extern "C" const char bash_platform[] = "BASH_HIP_GFX950";
 extern "C" void bashF(octet block[192], void *stack)
 {
     (void)stack;                                   // bashF_deep() == 0
-    die_on(bee2hip_bashF_batch(block, 1), "bashF");
+    die_on(with_host(K_PRIM, 192, "bashF", [&] { return bee2hip_bashF_batch(block, 1); }, [&] { hostp::bashF(block); }), "bashF");
 }
 extern "C" size_t bashF_deep(void) { return 0; }
 
@@ -394,7 +479,9 @@ static inline void ctr_add(u32 c[4], uint64_t add)
     c[0] = (u32)nlo; c[1] = (u32)(nlo >> 32); c[2] = (u32)hi; c[3] = (u32)(hi >> 32);
 }
 
-extern "C" err_t bee2hip_beltCTR_bulk(void *buf_, size_t count, void *ctr_state)
+// allow_host: the bee2 drop-ins (beltCTRStepE, beltCTR, beltDWPStepE ...) may finish a small call on the host; the batch
+// entry point bee2hip_beltCTR_bulk never does
+static err_t ctr_bulk(void *buf_, size_t count, void *ctr_state, bool allow_host)
 {
     belt_ctr_st *st = (belt_ctr_st *)ctr_state;
     octet *buf = (octet *)buf_;
@@ -410,29 +497,37 @@ extern "C" err_t bee2hip_beltCTR_bulk(void *buf_, size_t count, void *ctr_state)
     // whole blocks plus, if the tail is partial, one more gamma block: all on the GPU.
     // The tail is staged zero-padded to a full block; the kernel also hands back the
     // gamma of the final block, which the streaming state keeps (belt_ctr.c:89-96,101-108).
-    const size_t full = count / 16, tail = count % 16;
-    const size_t nblk = full + (tail ? 1 : 0);
-    err_t code = ensure_device();
-    if (code != ERR_OK) return code;
-    Scratch &s = t_scr[2];
-    code = s.need(nblk * 16 + 16);
-    if (code != ERR_OK) return code;
-    octet *d = (octet *)s.p;
-    if (tail) B2H_TRY(zero_staging(d + full * 16, 16));
-    B2H_TRY(h2d(d, buf, count));
-    // first_block = 0: the offset is relative to the state's *current* counter
-    code = launch_belt_ctr_blocks(d, nblk, st->key, st->ctr, 0, d + nblk * 16, nullptr);
-    if (code != ERR_OK) return code;
-    B2H_TRY(d2h(buf, d, count));
-    B2H_TRY(d2h(st->block, d + nblk * 16, 16));
-    ctr_add(st->ctr, nblk);                        // what nblk beltBlockIncU32 calls leave
-    st->reserved = tail ? 16 - tail : 0;
-    return ERR_OK;
+    const auto gpu = [&]() -> err_t {
+        const size_t full = count / 16, tail = count % 16;
+        const size_t nblk = full + (tail ? 1 : 0);
+        err_t code = ensure_device();
+        if (code != ERR_OK) return code;
+        Scratch &s = t_scr[2];
+        code = s.need(nblk * 16 + 16);
+        if (code != ERR_OK) return code;
+        octet *d = (octet *)s.p;
+        if (tail) B2H_TRY(zero_staging(d + full * 16, 16));
+        B2H_TRY(h2d(d, buf, count));
+        // first_block = 0: the offset is relative to the state's *current* counter
+        code = launch_belt_ctr_blocks(d, nblk, st->key, st->ctr, 0, d + nblk * 16, nullptr);
+        if (code != ERR_OK) return code;
+        octet last[16];
+        B2H_TRY(d2h(last, d + nblk * 16, 16));
+        B2H_TRY(d2h(buf, d, count));
+        memcpy(st->block, last, 16);
+        ctr_add(st->ctr, nblk);                        // what nblk beltBlockIncU32 calls leave
+        st->reserved = tail ? 16 - tail : 0;
+        return ERR_OK;
+    };
+    if (!allow_host) return gpu();
+    return with_host(K_PARALLEL, count, "beltCTRStepE", gpu,
+                     [&] { hostp::ctr_blocks(hostT(), buf, count, st->key, st->ctr, st->block, &st->reserved); });
 }
+extern "C" err_t bee2hip_beltCTR_bulk(void *buf, size_t count, void *ctr_state) { return ctr_bulk(buf, count, ctr_state, false); }
 
 extern "C" void beltCTRStepE(void *buf, size_t count, void *state)
 {
-    die_on(bee2hip_beltCTR_bulk(buf, count, state), "beltCTRStepE");
+    die_on(ctr_bulk(buf, count, state, true), "beltCTRStepE");
 }
 
 extern "C" err_t beltCTR(void *dest, const void *src, size_t count, const octet key[], size_t len,
@@ -444,7 +539,7 @@ extern "C" err_t beltCTR(void *dest, const void *src, size_t count, const octet 
     if (!st) return ERR_OUTOFMEMORY;
     beltCTRStart(st, key, len, iv);
     memmove(dest, src, count);
-    err_t code = bee2hip_beltCTR_bulk(dest, count, st);
+    err_t code = ctr_bulk(dest, count, st, true);
     delete st;
     return code;
 }
@@ -987,7 +1082,7 @@ extern "C" void bashHashStart(void *state, size_t l)
 }
 
 // run the device sponge over `count` host bytes for one state
-static err_t sponge_host(bash_hash_st *st, const octet *buf, size_t count)
+static err_t sponge_gpu(bash_hash_st *st, const octet *buf, size_t count)
 {
     Scratch &s = t_scr[0];
     err_t code = s.need(sizeof(bash_hash_st) + count + 16, true);
@@ -1013,6 +1108,12 @@ static err_t sponge_host(bash_hash_st *st, const octet *buf, size_t count)
     return ERR_OK;
 }
 
+static err_t sponge_host(bash_hash_st *st, const octet *buf, size_t count)
+{
+    return with_host(K_SERIAL, count, "bashHashStepH", [&] { return sponge_gpu(st, buf, count); },
+                     [&] { hostp::sponge_absorb(st->s, st->buf_len, &st->pos, buf, count); });
+}
+
 extern "C" void bashHashStepH(const void *buf, size_t count, void *state)
 {
     bash_hash_st *st = (bash_hash_st *)state;
@@ -1031,7 +1132,8 @@ static void hash_final(bash_hash_st *st)
     memcpy(st->s1, st->s, 192);
     memset(st->s1 + st->pos, 0, st->buf_len - st->pos);
     st->s1[st->pos] = 0x40;
-    die_on(bee2hip_bashF_batch(st->s1, 1), "bashHashStepG");
+    die_on(with_host(K_PRIM, 192, "bashHashStepG", [&] { return bee2hip_bashF_batch(st->s1, 1); }, [&] { hostp::bashF(st->s1); }),
+           "bashHashStepG");
 }
 
 extern "C" void bashHashStepG(octet hash[], size_t hash_len, void *state)
@@ -1066,19 +1168,21 @@ extern "C" size_t beltMAC_keep(void) { return sizeof(belt_mac_st); }
 
 static err_t mac_host(belt_mac_st *st, const octet *buf, size_t count, int mode)
 {
-    err_t code = ensure_device();
-    if (code != ERR_OK) return code;
-    Scratch &s = t_scr[1];
-    code = s.need(sizeof(belt_mac_st) + 8 + count + 16);
-    if (code != ERR_OK) return code;
-    octet *d = (octet *)s.p;
-    const size_t off = (sizeof(belt_mac_st) + 15) & ~(size_t)15;
-    B2H_TRY(h2d(d, st, sizeof *st));
-    if (count) B2H_TRY(h2d(d + off, buf, count));
-    code = launch_belt_mac(d, d + off, 0, count, 1, mode, nullptr);
-    if (code != ERR_OK) return code;
-    B2H_TRY(d2h(st, d, sizeof *st));
-    return ERR_OK;
+    return with_host(K_SERIAL, count, "beltMAC", [&]() -> err_t {
+        err_t code = ensure_device();
+        if (code != ERR_OK) return code;
+        Scratch &s = t_scr[1];
+        code = s.need(sizeof(belt_mac_st) + 8 + count + 16);
+        if (code != ERR_OK) return code;
+        octet *d = (octet *)s.p;
+        const size_t off = (sizeof(belt_mac_st) + 15) & ~(size_t)15;
+        B2H_TRY(h2d(d, st, sizeof *st));
+        if (count) B2H_TRY(h2d(d + off, buf, count));
+        code = launch_belt_mac(d, d + off, 0, count, 1, mode, nullptr);
+        if (code != ERR_OK) return code;
+        B2H_TRY(d2h(st, d, sizeof *st));
+        return ERR_OK;
+    }, [&] { hostp::mac_step(hostT(), st->key, st->s, st->r, st->mac, st->block, &st->filled, buf, count, mode); });
 }
 
 extern "C" void beltMACStart(void *state, const octet key[], size_t len)
@@ -1182,8 +1286,17 @@ extern "C" err_t bee2hip_internal_tune(int key, int value)
     case 1: bee2hip::set_ctr_variant(value); return ERR_OK;
     case 2: bee2hip::set_verify_path(value); return ERR_OK;
     case 3: bee2hip::g_pinned_limit = value < 0 ? 0 : (size_t)value > bee2hip::PINNED_MAX ? bee2hip::PINNED_MAX : (size_t)value; return ERR_OK;
+    case 4: bee2hip::g_force.store(value == 1 ? bee2hip::FORCE_GPU : value == 2 ? bee2hip::FORCE_CPU : bee2hip::FORCE_AUTO); return ERR_OK;   // as BEE2HIP_FORCE
+    case 5: bee2hip::g_inject_fail.store(value); return ERR_OK;       // tests: the next `value` GPU attempts of drop-in helpers fail
     default: return ERR_BAD_INPUT;
     }
+}
+
+// drop-in helper calls so far: which = 0 host path (by size or by BEE2HIP_FORCE=cpu), 1 GPU path, 2 finished on the host
+// after the GPU path failed twice
+extern "C" unsigned long long bee2hip_internal_stat(int which)
+{
+    return which == 0 ? bee2hip::g_n_host.load() : which == 1 ? bee2hip::g_n_gpu.load() : bee2hip::g_n_fallback.load();
 }
 
 // shader-clock probe: one wavefront spins for `us` microseconds of s_memrealtime (100 MHz) and reports how many
@@ -1247,16 +1360,18 @@ extern "C" err_t bee2hip_time_kernel(int which, int reps, void *d_a, void *d_b, 
 // ============================================ 8f-1: block decrypt, ECB, CBC ===
 static err_t decr_host_blocks(uint32_t *blocks, size_t n, const u32 key[8])
 {
-    err_t code = ensure_device();
-    if (code != ERR_OK) return code;
-    Scratch &s = t_scr[1];
-    code = s.need(n * 16);
-    if (code != ERR_OK) return code;
-    B2H_TRY(h2d(s.p, blocks, n * 16));
-    code = launch_belt_decr_blocks(s.p, n, key, nullptr);
-    if (code != ERR_OK) return code;
-    B2H_TRY(d2h(blocks, s.p, n * 16));
-    return ERR_OK;
+    return with_host(K_PRIM, n * 16, "belt block decryption", [&]() -> err_t {
+        err_t code = ensure_device();
+        if (code != ERR_OK) return code;
+        Scratch &s = t_scr[1];
+        code = s.need(n * 16);
+        if (code != ERR_OK) return code;
+        B2H_TRY(h2d(s.p, blocks, n * 16));
+        code = launch_belt_decr_blocks(s.p, n, key, nullptr);
+        if (code != ERR_OK) return code;
+        B2H_TRY(d2h(blocks, s.p, n * 16));
+        return ERR_OK;
+    }, [&] { for (size_t i = 0; i < n; ++i) hostp::belt_decr(hostT(), blocks + 4 * i, key); });
 }
 
 extern "C" void beltBlockDecr2(u32 block[4], const u32 key[8])
@@ -1301,20 +1416,22 @@ extern "C" err_t bee2hip_beltCBCEncr_batch_dev(void *d_msgs, size_t nblk, size_t
 static err_t modes_host(int mode, octet *buf, size_t nblocks, const u32 key[8], const octet chain[16])
 {
     if (nblocks == 0) return ERR_OK;
-    err_t code = ensure_device();
-    if (code != ERR_OK) return code;
-    Scratch &s = t_scr[2];
     const size_t bytes = nblocks * 16;
-    code = s.need(2 * bytes);
-    if (code != ERR_OK) return code;
-    octet *d = (octet *)s.p;
     u32 iv[4] = {0, 0, 0, 0};
     if (chain) for (int i = 0; i < 4; ++i) iv[i] = load32le(chain + 4 * i);
-    B2H_TRY(h2d(d, buf, bytes));
-    code = launch_belt_modes(mode, d, d + bytes, nblocks, key, iv, nullptr);
-    if (code != ERR_OK) return code;
-    B2H_TRY(d2h(buf, d + bytes, bytes));
-    return ERR_OK;
+    return with_host(K_PARALLEL, bytes, "belt ECB / CBC blocks", [&]() -> err_t {
+        err_t code = ensure_device();
+        if (code != ERR_OK) return code;
+        Scratch &s = t_scr[2];
+        code = s.need(2 * bytes);
+        if (code != ERR_OK) return code;
+        octet *d = (octet *)s.p;
+        B2H_TRY(h2d(d, buf, bytes));
+        code = launch_belt_modes(mode, d, d + bytes, nblocks, key, iv, nullptr);
+        if (code != ERR_OK) return code;
+        B2H_TRY(d2h(buf, d + bytes, bytes));
+        return ERR_OK;
+    }, [&] { hostp::modes_blocks(hostT(), mode, buf, nblocks, key, iv); });
 }
 
 struct belt_ecb_st {          // belt_ecb.c:42-46
@@ -1399,20 +1516,26 @@ extern "C" err_t bee2hip_beltDWP_absorb_dev(const void *d_data, size_t nbytes, c
 // t_out <- t after absorbing `nbytes` of host data (zero-padded to whole blocks), on the GPU
 static err_t dwp_absorb_host(u32 t_out[4], const u32 t[4], const u32 r[4], const octet *data, size_t nbytes)
 {
-    err_t code = ensure_device();
-    if (code != ERR_OK) return code;
-    Scratch &sc = t_scr[2];
-    const size_t off = (nbytes + 15) & ~(size_t)15;
-    code = sc.need(off + 16);
-    if (code != ERR_OK) return code;
-    octet *d = (octet *)sc.p;
-    if (nbytes) B2H_TRY(h2d(d, data, nbytes));
-    code = launch_belt_polyhash(d, nbytes, r, t, d + off, nullptr);
-    if (code != ERR_OK) return code;
-    octet out[16];
-    B2H_TRY(d2h(out, d + off, 16));
-    for (int i = 0; i < 4; ++i) t_out[i] = load32le(out + 4 * i);
-    return ERR_OK;
+    return with_host(K_POLY, nbytes, "belt-dwp authentication", [&]() -> err_t {
+        err_t code = ensure_device();
+        if (code != ERR_OK) return code;
+        Scratch &sc = t_scr[2];
+        const size_t off = (nbytes + 15) & ~(size_t)15;
+        code = sc.need(off + 16);
+        if (code != ERR_OK) return code;
+        octet *d = (octet *)sc.p;
+        if (nbytes) B2H_TRY(h2d(d, data, nbytes));
+        code = launch_belt_polyhash(d, nbytes, r, t, d + off, nullptr);
+        if (code != ERR_OK) return code;
+        octet out[16];
+        B2H_TRY(d2h(out, d + off, 16));
+        for (int i = 0; i < 4; ++i) t_out[i] = load32le(out + 4 * i);
+        return ERR_OK;
+    }, [&] {
+        u32 acc[4] = {t[0], t[1], t[2], t[3]};
+        hostp::polyhash(acc, r, data, nbytes);
+        for (int i = 0; i < 4; ++i) t_out[i] = acc[i];
+    });
 }
 // buffered absorb shared by StepI / StepA (belt_dwp.c:79-106,128-154): whole blocks go to the GPU in one call
 static void dwp_feed(belt_dwp_st *st, const octet *p, size_t count, const char *who)
@@ -1519,19 +1642,21 @@ extern "C" void beltHashStart(void *state)
 // hs <- hs after nblocks 32-byte blocks of host data (+ the final length block when fin); on the GPU
 static err_t hash_stream_host(u32 hs[12], const octet *data, size_t nblocks, int fin, uint64_t lo, uint64_t hi)
 {
-    err_t code = ensure_device();
-    if (code != ERR_OK) return code;
-    Scratch &sc = t_scr[2];
-    const size_t bytes = nblocks * 32;
-    code = sc.need(bytes + 64, true);
-    if (code != ERR_OK) return code;
-    octet *d = (octet *)sc.p;
-    if (bytes) B2H_TRY(h2d(d, data, bytes));
-    B2H_TRY(h2d(d + bytes, hs, 48));
-    code = launch_belt_hash_stream(d + bytes, d, nblocks, fin, lo, hi, nullptr);
-    if (code != ERR_OK) return code;
-    B2H_TRY(d2h(hs, d + bytes, 48));
-    return ERR_OK;
+    return with_host(K_SERIAL, nblocks * 32, "beltHash", [&]() -> err_t {
+        err_t code = ensure_device();
+        if (code != ERR_OK) return code;
+        Scratch &sc = t_scr[2];
+        const size_t bytes = nblocks * 32;
+        code = sc.need(bytes + 64, true);
+        if (code != ERR_OK) return code;
+        octet *d = (octet *)sc.p;
+        if (bytes) B2H_TRY(h2d(d, data, bytes));
+        B2H_TRY(h2d(d + bytes, hs, 48));
+        code = launch_belt_hash_stream(d + bytes, d, nblocks, fin, lo, hi, nullptr);
+        if (code != ERR_OK) return code;
+        B2H_TRY(d2h(hs, d + bytes, 48));
+        return ERR_OK;
+    }, [&] { hostp::hash_stream(hostT(), hs, data, nblocks, fin, lo, hi); });
 }
 extern "C" void beltHashStepH(const void *buf, size_t count, void *state)
 {
@@ -1622,19 +1747,22 @@ extern "C" err_t bee2hip_beltSDE_sectors_dev(int decr, void *d_sectors, size_t s
 }
 static err_t sde_host(int decr, octet *buf, size_t count, const octet iv[16], belt_sde_st *st)
 {
-    err_t code = ensure_device();
-    if (code != ERR_OK) return code;
-    Scratch &sc = t_scr[2];
-    code = sc.need(count + 16);
-    if (code != ERR_OK) return code;
-    octet *d = (octet *)sc.p;
-    B2H_TRY(h2d(d, buf, count));
-    B2H_TRY(h2d(d + count, iv, 16));
-    code = launch_belt_sde(decr, d, count / 16, 1, st->wbl->key, d + count, nullptr);
-    if (code != ERR_OK) return code;
-    B2H_TRY(d2h(buf, d, count));
-    st->wbl->round = decr ? 0 : 2 * (uint64_t)(count / 16);     // where the reference's loops stop (belt_wbl.c)
-    return ERR_OK;
+    const err_t rc = with_host(K_SERIAL, count, "beltSDE", [&]() -> err_t {
+        err_t code = ensure_device();
+        if (code != ERR_OK) return code;
+        Scratch &sc = t_scr[2];
+        code = sc.need(count + 16);
+        if (code != ERR_OK) return code;
+        octet *d = (octet *)sc.p;
+        B2H_TRY(h2d(d, buf, count));
+        B2H_TRY(h2d(d + count, iv, 16));
+        code = launch_belt_sde(decr, d, count / 16, 1, st->wbl->key, d + count, nullptr);
+        if (code != ERR_OK) return code;
+        B2H_TRY(d2h(buf, d, count));
+        return ERR_OK;
+    }, [&] { hostp::sde_sector(hostT(), decr, buf, count, iv, st->wbl->key); });
+    if (rc == ERR_OK) st->wbl->round = decr ? 0 : 2 * (uint64_t)(count / 16);     // where the reference's loops stop (belt_wbl.c)
+    return rc;
 }
 extern "C" void beltSDEStepE(void *buf, size_t count, const octet iv[16], void *state)
 {
@@ -1698,21 +1826,23 @@ extern "C" err_t bee2hip_beltCHE_blocks_dev(const void *d_src, void *d_dst, size
 static err_t che_blocks_host(octet *buf, size_t nblocks, belt_che_st *st)
 {
     if (nblocks == 0) return ERR_OK;
-    err_t code = ensure_device();
-    if (code != ERR_OK) return code;
-    Scratch &sc = t_scr[2];
     const size_t bytes = nblocks * 16;
-    code = sc.need(bytes + 16);
-    if (code != ERR_OK) return code;
-    octet *d = (octet *)sc.p;
-    B2H_TRY(h2d(d, buf, bytes));
-    code = launch_belt_che(d, d, nblocks, st->mac.ctr.key, st->s, 0, d + bytes, nullptr);
-    if (code != ERR_OK) return code;
-    octet snew[16];
-    B2H_TRY(d2h(buf, d, bytes));
-    B2H_TRY(d2h(snew, d + bytes, 16));
-    for (int i = 0; i < 4; ++i) st->s[i] = load32le(snew + 4 * i);
-    return ERR_OK;
+    return with_host(K_PARALLEL, bytes, "beltCHEStepE", [&]() -> err_t {
+        err_t code = ensure_device();
+        if (code != ERR_OK) return code;
+        Scratch &sc = t_scr[2];
+        code = sc.need(bytes + 16);
+        if (code != ERR_OK) return code;
+        octet *d = (octet *)sc.p;
+        B2H_TRY(h2d(d, buf, bytes));
+        code = launch_belt_che(d, d, nblocks, st->mac.ctr.key, st->s, 0, d + bytes, nullptr);
+        if (code != ERR_OK) return code;
+        octet snew[16];
+        B2H_TRY(d2h(snew, d + bytes, 16));
+        B2H_TRY(d2h(buf, d, bytes));
+        for (int i = 0; i < 4; ++i) st->s[i] = load32le(snew + 4 * i);
+        return ERR_OK;
+    }, [&] { hostp::che_blocks(hostT(), buf, nblocks, st->mac.ctr.key, st->s); });
 }
 extern "C" void beltCHEStepE(void *buf_, size_t count, void *state)
 {
@@ -1808,21 +1938,27 @@ extern "C" err_t bee2hip_beltBDE_blocks_dev(int decr, const void *d_src, void *d
 static err_t bde_host(int decr, octet *buf, size_t nblocks, belt_bde_st *st)
 {
     if (nblocks == 0) return ERR_OK;
-    err_t code = ensure_device();
-    if (code != ERR_OK) return code;
-    Scratch &sc = t_scr[2];
     const size_t bytes = nblocks * 16;
-    code = sc.need(bytes + 16);
-    if (code != ERR_OK) return code;
-    octet *d = (octet *)sc.p;
-    B2H_TRY(h2d(d, buf, bytes));
-    code = launch_belt_bde(decr, d, d, nblocks, st->key, st->s, 0, d + bytes, nullptr);
-    if (code != ERR_OK) return code;
-    octet snew[16];
-    B2H_TRY(d2h(buf, d, bytes));
-    B2H_TRY(d2h(snew, d + bytes, 16));
+    const err_t rc = with_host(K_PARALLEL, bytes, "beltBDE", [&]() -> err_t {
+        err_t code = ensure_device();
+        if (code != ERR_OK) return code;
+        Scratch &sc = t_scr[2];
+        code = sc.need(bytes + 16);
+        if (code != ERR_OK) return code;
+        octet *d = (octet *)sc.p;
+        B2H_TRY(h2d(d, buf, bytes));
+        code = launch_belt_bde(decr, d, d, nblocks, st->key, st->s, 0, d + bytes, nullptr);
+        if (code != ERR_OK) return code;
+        octet snew[16];
+        B2H_TRY(d2h(snew, d + bytes, 16));
+        B2H_TRY(d2h(buf, d, bytes));
+        for (int i = 0; i < 4; ++i) st->s[i] = load32le(snew + 4 * i);
+        return ERR_OK;
+    }, [&] { hostp::bde_blocks(hostT(), decr, buf, nblocks, st->key, st->s); });
+    if (rc != ERR_OK) return rc;
     // what the reference's last iteration leaves behind (belt_bde.c:56-63): s, block = <s>, block1 = Y ^ <s>
-    for (int i = 0; i < 4; ++i) st->s[i] = load32le(snew + 4 * i);
+    octet snew[16];
+    for (int i = 0; i < 4; ++i) store32le(snew + 4 * i, st->s[i]);
     memcpy(st->block, snew, 16);
     for (int i = 0; i < 16; ++i) st->block1[i] = buf[bytes - 16 + i] ^ snew[i];
     return ERR_OK;
@@ -1876,17 +2012,24 @@ extern "C" void beltCBCStepE(void *buf_, size_t count, void *state)
     octet *buf = (octet *)buf_;
     const size_t full = count / 16, tail = count % 16;
     if (full) {
-        // the serial chain runs on one lane of the per-message kernel (n = 1)
-        err_t code = ensure_device();
-        Scratch &s = t_scr[2];
-        if (code == ERR_OK) code = s.need(full * 16 + 16);
-        die_on(code, "beltCBCStepE");
-        octet *d = (octet *)s.p;
-        die_on(h2d(d, buf, full * 16) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
-        die_on(h2d(d + full * 16, st->block, 16) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
-        die_on(launch_belt_cbc_encr(d, full, 1, st->key, d + full * 16, nullptr), "beltCBCStepE");
-        die_on(d2h(buf, d, full * 16) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
-        die_on(d2h(st->block, d + full * 16, 16) == hipSuccess ? ERR_OK : ERR_BEE2HIP_DEVICE, "beltCBCStepE");
+        // the serial chain runs on one lane of the per-message kernel (n = 1), or on the host
+        die_on(with_host(K_SERIAL, full * 16, "beltCBCStepE", [&]() -> err_t {
+            err_t code = ensure_device();
+            if (code != ERR_OK) return code;
+            Scratch &s = t_scr[2];
+            code = s.need(full * 16 + 16);
+            if (code != ERR_OK) return code;
+            octet *d = (octet *)s.p;
+            B2H_TRY(h2d(d, buf, full * 16));
+            B2H_TRY(h2d(d + full * 16, st->block, 16));
+            code = launch_belt_cbc_encr(d, full, 1, st->key, d + full * 16, nullptr);
+            if (code != ERR_OK) return code;
+            octet chain[16];
+            B2H_TRY(d2h(chain, d + full * 16, 16));
+            B2H_TRY(d2h(buf, d, full * 16));
+            memcpy(st->block, chain, 16);
+            return ERR_OK;
+        }, [&] { hostp::cbc_encr_blocks(hostT(), buf, full, st->key, st->block); }), "beltCBCStepE");
     }
     if (tail) {                                   // stealing, belt_cbc.c:86-93
         octet *p = buf + full * 16;

@@ -88,7 +88,7 @@ BATCH_SYMBOLS = [
 ]
 # include/bee2hip_internal.h: test / bench hooks, not product ABI
 INTERNAL_SYMBOLS = ["bee2hip_time_kernel", "bee2hip_debug_fe", "bee2hip_debug_feL", "bee2hip_internal_tune",
-                    "bee2hip_internal_clock_probe"]
+                    "bee2hip_internal_clock_probe", "bee2hip_internal_stat"]
 
 
 def lib_exports(path=LIB_PATH):
@@ -111,6 +111,8 @@ class Engine:
         for name in ("bee2hip_last_error", "bee2hip_version"):
             getattr(L, name).restype = ctypes.c_char_p
         L.beltH.restype = ctypes.POINTER(ctypes.c_ubyte)
+        if hasattr(L, "bee2hip_internal_stat"):
+            L.bee2hip_internal_stat.restype = ctypes.c_ulonglong
         for name in ("bashF_deep", "bashHash_keep", "beltCTR_keep", "beltMAC_keep", "beltECB_keep", "beltCBC_keep"):
             if hasattr(L, name):
                 getattr(L, name).restype = _sz
@@ -119,7 +121,7 @@ class Engine:
             if f is not None and name.startswith(("bee2hip_", "bash", "belt", "bign")) and \
                     name not in ("bee2hip_last_error", "bee2hip_version", "beltH", "bashF_deep",
                                  "bashHash_keep", "beltCTR_keep", "beltMAC_keep", "beltECB_keep",
-                                 "beltCBC_keep", "bash_platform", "bee2hip_device_count"):
+                                 "beltCBC_keep", "bash_platform", "bee2hip_device_count", "bee2hip_internal_stat"):
                 f.restype = _u32
 
     # ------------------------------------------------------------------ util

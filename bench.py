@@ -692,24 +692,34 @@ def main():
                 fn()
             return (time.perf_counter() - t0) / reps * 1e6
         blk = ctypes.create_string_buffer(192)
-        lat["bashF (192 B)"] = us_per_call(lambda: eng.lib.bashF(blk, None), 200)
         st_ctr = ctypes.create_string_buffer(eng.lib.beltCTR_keep())
         eng.lib.beltCTRStart(st_ctr, H[128:160], ctypes.c_size_t(32), H[192:208])
         b16 = ctypes.create_string_buffer(16)
-        lat["beltCTRStepE (16 B)"] = us_per_call(lambda: eng.lib.beltCTRStepE(b16, ctypes.c_size_t(16), st_ctr), 200)
         b64k = ctypes.create_string_buffer(1 << 16)
-        lat["beltCTRStepE (64 KiB)"] = us_per_call(lambda: eng.lib.beltCTRStepE(b64k, ctypes.c_size_t(1 << 16), st_ctr), 100)
         import goldenlib
         Gk = goldenlib.Golden()
         h0, s0, p0 = Gk.bign_base[0]
-        lat["bign128Verify"] = us_per_call(lambda: eng.lib.bign128Verify(h0, s0, p0), 50)
         d0 = bytes(range(1, 33))
         sg0 = ctypes.create_string_buffer(48)
-        lat["bign128Sign2"] = us_per_call(lambda: eng.lib.bign128Sign2(sg0, h0, d0, None, ctypes.c_size_t(0)), 50)
-        lat["beltHash (1 KiB)"] = us_per_call(lambda: eng.lib.beltHash(ctypes.create_string_buffer(32), bytes(1024), ctypes.c_size_t(1024)), 100)
-        entry = {"unit": "us per call", "gpu_dropin": lat,
-                 "note": "one call = H2D + launch(es) + D2H on the NULL stream; the drop-in is for source compatibility, the batch "
-                         "entry points are the fast path (INTEGRATION.md gives the crossover sizes)"}
+
+        def measure(fast):
+            lat = {}
+            lat["bashF (192 B)"] = us_per_call(lambda: eng.lib.bashF(blk, None), 20000 if fast else 200)
+            lat["beltCTRStepE (16 B)"] = us_per_call(lambda: eng.lib.beltCTRStepE(b16, ctypes.c_size_t(16), st_ctr), 20000 if fast else 200)
+            lat["beltCTRStepE (64 KiB)"] = us_per_call(lambda: eng.lib.beltCTRStepE(b64k, ctypes.c_size_t(1 << 16), st_ctr), 100)
+            lat["bign128Verify"] = us_per_call(lambda: eng.lib.bign128Verify(h0, s0, p0), 50)
+            lat["bign128Sign2"] = us_per_call(lambda: eng.lib.bign128Sign2(sg0, h0, d0, None, ctypes.c_size_t(0)), 50)
+            lat["beltHash (1 KiB)"] = us_per_call(lambda: eng.lib.beltHash(ctypes.create_string_buffer(32), bytes(1024), ctypes.c_size_t(1024)), 2000 if fast else 100)
+            return lat
+        lat = measure(True)                                        # the default: small calls on the host path, by size
+        eng.lib.bee2hip_internal_tune(4, 1)                        # as BEE2HIP_FORCE=gpu: every primitive in a kernel (rounds 1-2)
+        lat_gpu = measure(False)
+        eng.lib.bee2hip_internal_tune(4, 0)
+        entry = {"unit": "us per call", "dropin": lat, "dropin_forced_gpu": lat_gpu,
+                 "note": "dropin = the library as a caller gets it: single primitives, block-parallel modes under 8 KiB per call and "
+                         "one-message serial chains run on the host path (bee2_amd/csrc/host_small.hpp), everything else is H2D + "
+                         "launch(es) + D2H on the NULL stream; dropin_forced_gpu = BEE2HIP_FORCE=gpu (every primitive in a kernel); "
+                         "the batch entry points are the fast path (INTEGRATION.md gives the crossover sizes)"}
         if do_cpu:
             import refgen
             if refgen.have_ref():

@@ -37,6 +37,12 @@ err_t bee2hip_internal_clock_probe(void *d_out16, unsigned us, void *stream);
    (0 = by batch size, 1 = 32-bit limbs, 2 = 29-bit limbs, 3 = one signature per quad / pair by size, 0x43 = quads,
    0x23 = pairs, 0x83 = quad + helper quad; tests force each) */
 err_t bee2hip_internal_tune(int key, int value);
+/* (key 3 = size limit of the pinned staging buffer; key 4 = path of the drop-in layer's small calls, as the environment
+   variable BEE2HIP_FORCE: 0 auto (by size), 1 gpu, 2 cpu -- bee2_amd/csrc/host_small.hpp; key 5 = fault injection: the
+   next `value` GPU attempts of drop-in helpers report a device failure) */
+/* drop-in helper calls so far: which = 0 taken on the host path, 1 on the GPU, 2 finished on the host after the GPU path
+   failed twice */
+unsigned long long bee2hip_internal_stat(int which);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

@@ -24,3 +24,38 @@ def orc():
 def golden():
     import orclib
     return orclib.Golden()
+
+
+# ---- the drop-in layer has two ways to evaluate a small single call (bee2_amd/csrc/host_small.hpp): every -m gpu test of
+# the modules below runs once with BEE2HIP_FORCE=gpu semantics (every primitive in a kernel: the coverage rounds 1-2 had)
+# and once with =cpu (every drop-in call that has a host path takes it, at every size).  All other tests run in the
+# default "auto" mode (crossover by size), which is what a caller gets.
+DROPIN_TEST_MODULES = {"test_gpu_bash", "test_gpu_belt", "test_gpu_belt_bde", "test_gpu_belt_dwp", "test_gpu_belt_modes",
+                       "test_gpu_belt_sde", "test_gpu_threads"}
+FORCE_CODE = {"auto": 0, "gpu": 1, "cpu": 2}
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.module.__name__ in DROPIN_TEST_MODULES and "force_path" in metafunc.fixturenames:
+        metafunc.parametrize("force_path", ["gpu", "cpu"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def force_path(request):
+    mode = getattr(request, "param", None)
+    if mode is None or request.node.get_closest_marker("gpu") is None:
+        yield "auto"
+        return
+    import bee2_amd
+    lib = bee2_amd.load().lib
+    lib.bee2hip_internal_tune(4, FORCE_CODE[mode])
+    before = [lib.bee2hip_internal_stat(i) for i in range(3)]
+    yield mode
+    after = [lib.bee2hip_internal_stat(i) for i in range(3)]
+    lib.bee2hip_internal_tune(4, 0)
+    # the mode did what it says: no host-path call under "gpu", no GPU drop-in helper call under "cpu", no fault fallback
+    if mode == "gpu":
+        assert after[0] == before[0], "host path taken under BEE2HIP_FORCE=gpu"
+    else:
+        assert after[1] == before[1], "GPU drop-in helper ran under BEE2HIP_FORCE=cpu"
+    assert after[2] == before[2]

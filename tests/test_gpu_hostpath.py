@@ -1,0 +1,118 @@
+"""-m gpu: the drop-in layer's path policy (bee2_amd/csrc/capi.hip "host path for small single calls").
+Default mode: small single calls on the host, large ones and every batch entry point on the GPU; a device failure in the
+middle of a void bee2 function is retried once and then finished on the host (never abort() in auto mode); with
+BEE2HIP_FORCE=gpu the failure is fatal, as in rounds 1-2."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from bee2_amd import engine as E
+from gpulib import engine
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _stats(lib):
+    return [lib.bee2hip_internal_stat(i) for i in range(3)]
+
+
+def test_auto_mode_crossovers(orc):
+    eng = engine()
+    L = eng.lib
+    L.bee2hip_internal_tune(4, 0)
+    H = orc.beltH()
+    # one permutation, one block, a 16-byte CTR step: host
+    s0 = _stats(L)
+    st = ctypes.create_string_buffer(orc.fill(192, 1), 192)
+    L.bashF(st, None)
+    assert st.raw == orc.bashF(orc.fill(192, 1))
+    cs = ctypes.create_string_buffer(L.beltCTR_keep())
+    L.beltCTRStart(cs, H[128:160], ctypes.c_size_t(32), H[192:208])
+    b = ctypes.create_string_buffer(bytes(16), 16)
+    L.beltCTRStepE(b, ctypes.c_size_t(16), cs)
+    assert b.raw == orc.ctr(bytes(16), H[128:160], H[192:208])
+    s1 = _stats(L)
+    assert s1[0] > s0[0] and s1[1] == s0[1]
+    # a 64 KiB CTR call: GPU
+    msg = orc.fill(1 << 16, 2)
+    out = ctypes.create_string_buffer(1 << 16)
+    assert L.beltCTR(out, msg, ctypes.c_size_t(1 << 16), H[128:160], ctypes.c_size_t(32), H[192:208]) == 0
+    assert out.raw == orc.ctr(msg, H[128:160], H[192:208])
+    s2 = _stats(L)
+    assert s2[1] == s1[1] + 1                      # the bulk encryption (the start's E_K(iv) is a single block: host)
+    # a serial chain of one message: host at every size
+    big = orc.fill(1 << 20, 3)
+    dig = ctypes.create_string_buffer(32)
+    assert L.bashHash(dig, ctypes.c_size_t(128), big, ctypes.c_size_t(len(big))) == 0
+    assert dig.raw == orc.bashHash(128, big)[1]
+    assert L.beltHash(dig, big, ctypes.c_size_t(len(big))) == 0
+    assert dig.raw == orc.belt_hash(big)
+    s3 = _stats(L)
+    assert s3[1] == s2[1] and s3[2] == 0
+    # the batch entry point never takes the host path, whatever the size
+    one = np.frombuffer(orc.fill(192, 4), dtype=np.uint8).copy()
+    assert L.bee2hip_bashF_batch(ctypes.c_void_p(one.ctypes.data), ctypes.c_size_t(1)) == 0
+    assert one.tobytes() == orc.bashF(orc.fill(192, 4))
+    cs2 = ctypes.create_string_buffer(L.beltCTR_keep())
+    L.beltCTRStart(cs2, H[128:160], ctypes.c_size_t(32), H[192:208])
+    s4 = _stats(L)
+    b2 = ctypes.create_string_buffer(bytes(48), 48)
+    assert L.bee2hip_beltCTR_bulk(b2, ctypes.c_size_t(48), cs2) == 0
+    assert b2.raw == orc.ctr(bytes(48), H[128:160], H[192:208])
+    assert _stats(L)[0] == s4[0]
+
+
+def test_device_fault_is_retried_then_finished_on_the_host(orc):
+    eng = engine()
+    L = eng.lib
+    L.bee2hip_internal_tune(4, 0)
+    H = orc.beltH()
+    msg = orc.fill(1 << 16, 5)
+    cs = ctypes.create_string_buffer(L.beltCTR_keep())
+    L.beltCTRStart(cs, H[128:160], ctypes.c_size_t(32), H[192:208])
+    want = orc.ctr(msg + msg, H[128:160], H[192:208])
+    s0 = _stats(L)
+    # one failure: the retry succeeds on the GPU
+    L.bee2hip_internal_tune(5, 1)
+    b = ctypes.create_string_buffer(msg, len(msg))
+    L.beltCTRStepE(b, ctypes.c_size_t(len(msg)), cs)
+    assert b.raw == want[: len(msg)]
+    s1 = _stats(L)
+    assert s1[1] == s0[1] + 1 and s1[2] == s0[2]
+    # two failures: finished on the host, same bytes, same state afterwards
+    L.bee2hip_internal_tune(5, 2)
+    b = ctypes.create_string_buffer(msg, len(msg))
+    L.beltCTRStepE(b, ctypes.c_size_t(len(msg)), cs)
+    assert b.raw == want[len(msg):]
+    s2 = _stats(L)
+    assert s2[2] == s1[2] + 1
+    L.bee2hip_internal_tune(5, 0)
+
+
+def test_forced_gpu_mode_stays_fatal_on_a_device_fault():
+    code = ("import ctypes, sys; sys.path[:0] = [%r, %r]; import bee2_amd; L = bee2_amd.load().lib; "
+            "L.bee2hip_internal_tune(5, 2); b = ctypes.create_string_buffer(192); L.bashF(b, None); print('survived')"
+            % (ROOT, os.path.join(ROOT, "tests")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BEE2HIP_FORCE="gpu"), capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "survived" not in r.stdout and "bashF failed" in r.stderr
+
+
+@pytest.mark.parametrize("mode", ["gpu", "cpu", None])
+def test_reference_test_suite_passes_in_every_mode(mode):
+    """bee2's own tests (oracle/_ref/testbee2_hip, tests/test_gpu_reftests.py) with the drop-in layer forced either way"""
+    binp = os.path.join(ROOT, "oracle", "_ref", "testbee2_hip")
+    if not os.path.exists(binp):
+        pytest.skip("oracle/_ref/testbee2_hip not built")
+    env = dict(os.environ)
+    env.pop("BEE2HIP_FORCE", None)
+    if mode:
+        env["BEE2HIP_FORCE"] = mode
+    r = subprocess.run([binp], capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0 and "Err" not in r.stdout, r.stdout + r.stderr[-1000:]
+    assert r.stdout.count(": OK") == 6
