@@ -965,9 +965,9 @@ def main():
     if not result:                        # --only without bashF: promote the first other metric
         k0 = next(iter(others))
         o = others.pop(k0)
-        result = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "n_gpus": N, "steps": o["steps"],
-                  "warmup": W, "ms_per_step": o["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-                  "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": o["config"]}
+        result = {"metric": o.get("metric", k0), "value": o.get("value"), "unit": o.get("unit"), "n_gpus": N, "steps": o.get("steps", K),
+                  "warmup": W, "ms_per_step": o.get("ms_per_step"), "higher_is_better": True, "scaling": "weak",
+                  "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": o.get("config", {"workload": k0})}
         for k, v in o.items():            # keep the workload's own fields (roofline, cpu_baseline, extras)
             result.setdefault(k, v)
     # FLAT scalar copies of the other two BASELINE metrics (and what bounds them) inside the two objects the driver's

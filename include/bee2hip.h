@@ -8,13 +8,22 @@
  *
  *  (1) bee2 DROP-IN symbols: same names, signatures and error behaviour as the
  *      bee2 functions they replace, so a bee2 caller can link this library instead
- *      of those objects.  States are caller-owned PODs of X_keep() bytes that may be
- *      memcpy-cloned, as in bee2; belt_ctr_st, belt_mac_st and bash_hash_st have
- *      bee2's exact layout, the other states are opaque.  Every primitive evaluation
- *      (bashF, E_K / D_K, GF(2^128) products, the double-scalar multiplication) runs
- *      on the GPU; there is no CPU fallback, and a device failure inside a `void`
- *      function aborts with a message.  Each declaration cites the bee2 interface it
- *      replaces.  All of them may be called from several threads at once.
+ *      of those objects (bee2's own test/crypto sources pass against it:
+ *      oracle/Makefile `reftests`).  States are caller-owned PODs of X_keep() bytes that
+ *      may be memcpy-cloned, as in bee2; belt_ctr_st, belt_mac_st and bash_hash_st have
+ *      bee2's exact layout, the other states are opaque.  Where a call runs: every bign
+ *      operation and every large call evaluates its primitives (bashF, E_K / D_K,
+ *      GF(2^128) products, the scalar multiplications) on the GPU; a SMALL single call
+ *      -- one bashF, one block, a block-parallel mode under 8 KiB per call, the serial
+ *      chain of one message (sponge, CBC-MAC, belt-hash, CBC encryption, one belt-sde
+ *      sector) -- takes the library's own host path (bee2_amd/csrc/host_small.hpp;
+ *      SURVEY.md 8b "single-call path; may run on CPU"), because one launch costs 20 us
+ *      where a host core needs 0.3.  BEE2HIP_FORCE=gpu|cpu overrides the choice.  In
+ *      every mode the calling thread needs a working HIP device: there is no GPU-less
+ *      operation.  A device failure inside a `void` function is retried once and then
+ *      finished on the host with a message on stderr (BEE2HIP_FORCE=gpu: abort with a
+ *      message).  Each declaration cites the bee2 interface it replaces.  All of them
+ *      may be called from several threads at once.
  *
  *  (2) bee2hip_*  host-pointer batch API: the caller hands host buffers; the
  *      library stages H2D, launches, stages D2H.
