@@ -310,6 +310,84 @@ static err_t with_host(int kind, size_t bytes, const char *what, G gpu, H host)
     return ERR_OK;
 }
 
+// ---------------------------------------------- duplex staging of large in-place host batches ---
+// PCIe is full duplex and this box's two SDMA directions do run side by side -- 53 GiB/s each way alone, 87-90 GiB/s
+// together -- but only for copies issued with hipMemcpyAsync on two non-blocking streams, and, the caller's buffers being
+// ordinary pageable memory (an async copy of pageable memory holds its calling thread), from two host threads
+// (tools/ubench/pcie_duplex.hip, profiles/r03_pcie_duplex.txt: blocking hipMemcpy from two threads serialises, 48 GiB/s).
+// A large in-place batch is therefore cut into chunks: the calling thread uploads chunk c and queues its kernel behind
+// the copy on the same stream; a helper thread downloads chunk c - 1 on a second stream as soon as its kernel is through.
+// launch(dev_chunk, first_unit, units, stream) queues the kernel(s) for `units` units starting at unit `first_unit`.
+constexpr size_t DUPLEX_MIN = (size_t)48 << 20;          // below this the two copies cost < 2 ms: not worth a thread
+static int g_duplex_log2_states = 16, g_duplex_log2_blocks = 20;   // chunk sizes (bee2hip_internal_tune 6 / 7: sweep)
+struct DuplexStreams {
+    hipStream_t up = nullptr, dn = nullptr;
+    int dev = -1;
+    err_t get()
+    {
+        int cur = 0;
+        B2H_TRY(hipGetDevice(&cur));
+        if (up && cur == dev) return ERR_OK;
+        if (up) { (void)hipStreamDestroy(up); (void)hipStreamDestroy(dn); up = dn = nullptr; }
+        B2H_TRY(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+        B2H_TRY(hipStreamCreateWithFlags(&dn, hipStreamNonBlocking));
+        dev = cur;
+        return ERR_OK;
+    }
+    ~DuplexStreams() { if (up && !on_loader_thread()) { (void)hipStreamDestroy(up); (void)hipStreamDestroy(dn); } }
+};
+static thread_local DuplexStreams t_duplex;
+
+template <class Launch>
+static err_t duplex_inplace(octet *host, octet *dev, size_t unit_bytes, size_t units, size_t chunk_units, Launch launch)
+{
+    err_t code = t_duplex.get();
+    if (code != ERR_OK) return code;
+    const size_t nch = (units + chunk_units - 1) / chunk_units;
+    std::vector<hipEvent_t> ev(nch, nullptr);
+    for (size_t c = 0; c < nch; ++c)
+        if (hipEventCreateWithFlags(&ev[c], hipEventDisableTiming) != hipSuccess) {
+            for (size_t k = 0; k < c; ++k) (void)hipEventDestroy(ev[k]);
+            return hip_fail(hipGetLastError(), "hipEventCreate");
+        }
+    std::atomic<size_t> queued{0};
+    std::atomic<int> failed{0};
+    int devno = 0;
+    (void)hipGetDevice(&devno);
+    const hipStream_t sup = t_duplex.up, sdn = t_duplex.dn;
+    std::thread down([&] {
+        if (hipSetDevice(devno) != hipSuccess) { failed.store(1); return; }
+        for (size_t c = 0; c < nch; ++c) {
+            while (queued.load(std::memory_order_acquire) <= c) {
+                if (failed.load()) return;
+                std::this_thread::yield();
+            }
+            const size_t first = c * chunk_units, cnt = std::min(chunk_units, units - first);
+            if (hipStreamWaitEvent(sdn, ev[c], 0) != hipSuccess ||
+                hipMemcpyAsync(host + first * unit_bytes, dev + first * unit_bytes, cnt * unit_bytes, hipMemcpyDeviceToHost, sdn) != hipSuccess) {
+                failed.store(1);
+                return;
+            }
+        }
+        if (hipStreamSynchronize(sdn) != hipSuccess) failed.store(1);
+    });
+    for (size_t c = 0; c < nch && !failed.load(); ++c) {
+        const size_t first = c * chunk_units, cnt = std::min(chunk_units, units - first);
+        if (hipMemcpyAsync(dev + first * unit_bytes, host + first * unit_bytes, cnt * unit_bytes, hipMemcpyHostToDevice, sup) != hipSuccess) {
+            failed.store(1);
+            break;
+        }
+        code = launch(dev + first * unit_bytes, first, cnt, sup);
+        if (code != ERR_OK || hipEventRecord(ev[c], sup) != hipSuccess) { failed.store(1); break; }
+        queued.store(c + 1, std::memory_order_release);
+    }
+    down.join();
+    (void)hipStreamSynchronize(sup);
+    for (size_t c = 0; c < nch; ++c) (void)hipEventDestroy(ev[c]);
+    if (failed.load()) return code != ERR_OK ? code : hip_fail(hipGetLastError(), "duplex staging");
+    return ERR_OK;
+}
+
 }  // namespace bee2hip
 
 using namespace bee2hip;
@@ -367,6 +445,9 @@ extern "C" err_t bee2hip_bashF_batch(octet *states, size_t n)
     Scratch &s = t_scr[0];
     err_t code = s.need(n * 192);
     if (code != ERR_OK) return code;
+    if (n * 192 >= DUPLEX_MIN)              // chunks of 2^16 states = 12 MiB: upload, permute and download overlap
+        return duplex_inplace(states, (octet *)s.p, 192, n, (size_t)1 << g_duplex_log2_states,
+                              [](octet *d, size_t, size_t cnt, hipStream_t st) { return launch_bashF_batch(d, cnt, st); });
     B2H_TRY(h2d(s.p, states, n * 192));
     code = launch_bashF_batch(s.p, n, nullptr);
     if (code != ERR_OK) return code;
@@ -498,6 +579,25 @@ static err_t ctr_bulk(void *buf_, size_t count, void *ctr_state, bool allow_host
     // The tail is staged zero-padded to a full block; the kernel also hands back the
     // gamma of the final block, which the streaming state keeps (belt_ctr.c:89-96,101-108).
     const auto gpu = [&]() -> err_t {
+        if (count >= DUPLEX_MIN) {
+            // all but the last (at most one) chunk through the duplex pipeline, whole blocks; what is left -- with the partial
+            // block and the gamma the state keeps -- takes the plain path below, from the advanced counter
+            const size_t CH = (size_t)1 << g_duplex_log2_blocks;             // blocks per chunk (2^20 = 16 MiB)
+            const size_t pipe_blocks = (count - 1) / (16 * CH) * CH;
+            err_t pc = ensure_device();
+            if (pc != ERR_OK) return pc;
+            Scratch &ps = t_scr[2];
+            pc = ps.need(pipe_blocks * 16);
+            if (pc != ERR_OK) return pc;
+            const u32 *key = st->key, *ctr = st->ctr;
+            pc = duplex_inplace(buf, (octet *)ps.p, 16, pipe_blocks, CH, [key, ctr](octet *d, size_t first, size_t cnt, hipStream_t s2) {
+                return launch_belt_ctr_blocks(d, cnt, key, ctr, first, nullptr, s2);
+            });
+            if (pc != ERR_OK) return pc;
+            ctr_add(st->ctr, pipe_blocks);
+            buf += pipe_blocks * 16;
+            count -= pipe_blocks * 16;
+        }
         const size_t full = count / 16, tail = count % 16;
         const size_t nblk = full + (tail ? 1 : 0);
         err_t code = ensure_device();
@@ -538,7 +638,7 @@ extern "C" err_t beltCTR(void *dest, const void *src, size_t count, const octet 
     belt_ctr_st *st = new (std::nothrow) belt_ctr_st;
     if (!st) return ERR_OUTOFMEMORY;
     beltCTRStart(st, key, len, iv);
-    memmove(dest, src, count);
+    if (dest != src) memmove(dest, src, count);
     err_t code = ctr_bulk(dest, count, st, true);
     delete st;
     return code;
@@ -1288,6 +1388,8 @@ extern "C" err_t bee2hip_internal_tune(int key, int value)
     case 3: bee2hip::g_pinned_limit = value < 0 ? 0 : (size_t)value > bee2hip::PINNED_MAX ? bee2hip::PINNED_MAX : (size_t)value; return ERR_OK;
     case 4: bee2hip::g_force.store(value == 1 ? bee2hip::FORCE_GPU : value == 2 ? bee2hip::FORCE_CPU : bee2hip::FORCE_AUTO); return ERR_OK;   // as BEE2HIP_FORCE
     case 5: bee2hip::g_inject_fail.store(value); return ERR_OK;       // tests: the next `value` GPU attempts of drop-in helpers fail
+    case 6: bee2hip::g_duplex_log2_states = value; return ERR_OK;     // chunk of the duplex host pipeline, bashF states (log2)
+    case 7: bee2hip::g_duplex_log2_blocks = value; return ERR_OK;     //                                   belt blocks (log2)
     default: return ERR_BAD_INPUT;
     }
 }

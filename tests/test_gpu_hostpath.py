@@ -116,3 +116,43 @@ def test_reference_test_suite_passes_in_every_mode(mode):
     r = subprocess.run([binp], capture_output=True, text=True, timeout=1200, env=env)
     assert r.returncode == 0 and "Err" not in r.stdout, r.stdout + r.stderr[-1000:]
     assert r.stdout.count(": OK") == 6
+
+
+def test_duplex_pipeline_of_large_host_batches_bashF(orc):
+    """>= 48 MiB through bee2hip_bashF_batch: chunks uploaded by the caller's thread and downloaded by a helper thread on a
+    second stream (capi.hip duplex_inplace); ragged last chunk; every state against the oracle"""
+    eng = engine()
+    n = (1 << 18) + 4099                       # 51 MB, 17 chunks of 2^14 states, the last one ragged
+    data = np.frombuffer(orc.fill(192 * n, 0xD0B1), dtype=np.uint8).copy()
+    want = orc.bashF_batch(data.tobytes(), 8)
+    assert eng.lib.bee2hip_bashF_batch(ctypes.c_void_p(data.ctypes.data), ctypes.c_size_t(n)) == 0
+    assert data.tobytes() == want
+
+
+def test_duplex_pipeline_of_a_large_ctr_call_keeps_the_streaming_state(orc):
+    eng = engine()
+    L = eng.lib
+    H = orc.beltH()
+    n = (100 << 20) + 5                        # 24 chunks of 4 MiB through the pipeline, 4 MiB + 5 bytes on the plain path
+    kw, c0 = orc.ctr_start(H[128:160], H[192:208])
+    msg = np.frombuffer(orc.fill(n + 27, 0xD0B2), dtype=np.uint8).copy()
+    want = msg.copy()
+    whole = (n + 27 + 15) // 16 * 16
+    pad = np.zeros(whole, dtype=np.uint8)
+    pad[: n + 27] = msg
+    orc.ctr_blocks_np(pad, kw, c0, first=0, nthreads=8)
+    want = pad[: n + 27].tobytes()
+    st = ctypes.create_string_buffer(L.beltCTR_keep())
+    L.beltCTRStart(st, H[128:160], ctypes.c_size_t(32), H[192:208])
+    L.beltCTRStepE(ctypes.c_void_p(msg.ctypes.data), ctypes.c_size_t(n), st)
+    L.beltCTRStepE(ctypes.c_void_p(msg.ctypes.data + n), ctypes.c_size_t(27), st)      # continues inside the last gamma block
+    assert msg.tobytes() == want
+    # and the one-shot form
+    msg2 = np.frombuffer(orc.fill(n, 0xD0B3), dtype=np.uint8).copy()
+    pad2 = np.zeros((n + 15) // 16 * 16, dtype=np.uint8)
+    pad2[:n] = msg2
+    orc.ctr_blocks_np(pad2, kw, c0, first=0, nthreads=8)
+    out = np.empty(n, dtype=np.uint8)
+    assert L.beltCTR(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(msg2.ctypes.data), ctypes.c_size_t(n), H[128:160],
+                     ctypes.c_size_t(32), H[192:208]) == 0
+    assert out.tobytes() == pad2[:n].tobytes()
