@@ -390,9 +390,8 @@ err_t verify_generic_t(const bign_params *params, const uint8_t *oid_der, size_t
     code = bign_scratch<N>(st, n, S);
     if (code != ERR_OK) return code;
     OidArg oid;
-    memset(&oid, 0, sizeof oid);
-    oid.len = (uint32_t)oid_len;
-    memcpy(oid.der, oid_der, oid_len);
+    code = make_oid_arg(oid, oid_der, oid_len, st);
+    if (code != ERR_OK) return code;
     const unsigned g64 = (unsigned)((n + 63) / 64);
     hipLaunchKernelGGL(bign_generic_verify_kernel<N>, dim3(g64), dim3(64), 0, st, (const uint8_t *)d_hashes,
                        (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S, C);
@@ -408,7 +407,6 @@ err_t verify_generic_t(const bign_params *params, const uint8_t *oid_der, size_t
 err_t launch_bign_verify_generic(const bign_params *params, const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
                                  const void *d_sigs, const void *d_pubkeys, size_t n, void *d_codes, hipStream_t st)
 {
-    if (oid_len > OID_MAX) return ERR_NOT_IMPLEMENTED;
     if (params->l == 128) return verify_generic_t<8>(params, oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, st);
     if (params->l == 192) return verify_generic_t<12>(params, oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, st);
     if (params->l == 256) return verify_generic_t<16>(params, oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, st);

@@ -719,8 +719,61 @@ void bign_inv_kernel(size_t n, size_t lanes, int K, VerifyScratch S)
 }
 
 // --------------------------------------------------------------------- tail ---
-constexpr int OID_MAX = 128;                      // longest DER OID the kernel stages
-struct OidArg { uint32_t len; uint8_t der[OID_MAX]; };
+// The DER OID that leads the hashed message travels as a kernel argument.  bee2 accepts any valid DER OID (bign_sign.c:
+// 268-300), so a longer one is split: its whole 32-byte blocks -- the same for every signature of the batch -- are absorbed
+// ONCE by the streaming belt-hash kernel into a 48-byte state h || s in device scratch (hs0, pre_len octets), and the
+// per-signature kernels start from that state with the remaining len < 32 octets in der[].
+constexpr int OID_MAX = 128;                      // longest OID piece a kernel stages itself
+struct OidArg {
+    uint32_t len;                 // octets in der[]
+    uint32_t pre_len;             // octets already absorbed into *hs0 (a multiple of 32; 0 = none)
+    const uint32_t *hs0;          // device: belt-hash state h[8] || s[4] after pre_len octets (valid when pre_len != 0)
+    uint8_t der[OID_MAX];
+};
+// belt-hash state of a lane at the start of its message: the standard's initial value (belt_hash.c:52) or the OID prefix's
+__device__ __forceinline__ void oid_hash_start(uint32_t (&h)[8], uint32_t (&s)[4], const OidArg &oid)
+{
+    if (oid.pre_len) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = oid.hs0[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] = oid.hs0[8 + i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            h[i] = (uint32_t)c_beltH[4 * i] | (uint32_t)c_beltH[4 * i + 1] << 8 |
+                   (uint32_t)c_beltH[4 * i + 2] << 16 | (uint32_t)c_beltH[4 * i + 3] << 24;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] = 0;
+    }
+}
+err_t make_oid_arg(OidArg &oa, const uint8_t *oid_der, size_t oid_len, hipStream_t st)
+{
+    memset(&oa, 0, sizeof oa);
+    size_t pre = 0;
+    if (oid_len > OID_MAX) {
+        if (oid_len >> 28) return ERR_BAD_OID;            // the bit length is carried in 32 bits below
+        pre = oid_len / 32 * 32;
+        void *scr = nullptr;
+        err_t code = scratch_for_stream(st, 12, 48 + pre, &scr);
+        if (code != ERR_OK) return code;
+        uint32_t init[12];
+        const uint8_t *H = host_beltH();
+        for (int i = 0; i < 8; ++i)
+            init[i] = (uint32_t)H[4 * i] | (uint32_t)H[4 * i + 1] << 8 | (uint32_t)H[4 * i + 2] << 16 | (uint32_t)H[4 * i + 3] << 24;
+        for (int i = 8; i < 12; ++i) init[i] = 0;
+        // pageable sources: the runtime has taken its copy when these calls return
+        B2H_TRY(hipMemcpyAsync(scr, init, 48, hipMemcpyHostToDevice, st));
+        B2H_TRY(hipMemcpyAsync((uint8_t *)scr + 48, oid_der, pre, hipMemcpyHostToDevice, st));
+        code = launch_belt_hash_stream(scr, (uint8_t *)scr + 48, pre / 32, 0, 0, 0, st);
+        if (code != ERR_OK) return code;
+        oa.hs0 = (const uint32_t *)scr;
+        oa.pre_len = (uint32_t)pre;
+    }
+    oa.len = (uint32_t)(oid_len - pre);
+    memcpy(oa.der, oid_der + pre, oa.len);
+    return ERR_OK;
+}
 
 // Tab = BeltTabSmall: 64-thread workgroups, 4 KiB table with bank conflicts (any curve, any batch size);
 // Tab = BeltTabTwo: 1024-thread workgroups around the conflict-free 64 KiB table of the CTR kernel -- worth its
@@ -775,11 +828,8 @@ void bign_tail_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
     };
 
     // belt-hash (src/crypto/belt/belt_hash.c:43-171)
-    uint32_t h[8], s[4] = {0, 0, 0, 0}, X[8], s1[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        h[i] = (uint32_t)c_beltH[4 * i] | (uint32_t)c_beltH[4 * i + 1] << 8 |
-               (uint32_t)c_beltH[4 * i + 2] << 16 | (uint32_t)c_beltH[4 * i + 3] << 24;
+    uint32_t h[8], s[4], X[8], s1[4];
+    oid_hash_start(h, s, oid);
     const uint32_t nblk = (L + 31) / 32;
 #pragma unroll 1
     for (uint32_t b = 0; b < nblk; ++b) {
@@ -790,7 +840,7 @@ void bign_tail_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
         for (int i = 0; i < 4; ++i) s[i] ^= s1[i];
     }
     // final block: <bit length>_128 || s  (belt_hash.c:120-135, belt_lcl.c:25-51)
-    X[0] = L << 3; X[1] = 0; X[2] = 0; X[3] = 0;
+    X[0] = (L + oid.pre_len) << 3; X[1] = (L + oid.pre_len) >> 29; X[2] = 0; X[3] = 0;
     X[4] = s[0]; X[5] = s[1]; X[6] = s[2]; X[7] = s[3];
     belt_compress(T, s1, h, X);
     // the first l bits = N/2 words of the hash must equal s0 (beltHashStepV2(sig, no/2, ..))
@@ -1101,9 +1151,8 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
     code = bign_scratch<N>(st, n, S);
     if (code != ERR_OK) return code;
     OidArg oid;
-    memset(&oid, 0, sizeof oid);
-    oid.len = (uint32_t)oid_len;
-    memcpy(oid.der, oid_der, oid_len);
+    code = make_oid_arg(oid, oid_der, oid_len, st);
+    if (code != ERR_OK) return code;
     const unsigned g256 = (unsigned)((n + 255) / 256), g64 = (unsigned)((n + 63) / 64);
     const size_t sp = n >= ((size_t)1 << 18) ? 2 : 1;     // signatures per lane in prep (shared inversion)
     const size_t plan = (n + sp - 1) / sp;
@@ -1203,7 +1252,6 @@ err_t launch_bign_verify(size_t l, const uint8_t *oid_der, size_t oid_len, const
                          hipStream_t st)
 {
     if (n == 0) return ERR_OK;
-    if (oid_len > OID_MAX) return ERR_NOT_IMPLEMENTED;
     if (l == 128) return launch_bign_verify_t<8>(oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, st);
     if (l == 192) return launch_bign_verify_t<12>(oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, st);
     if (l == 256) return launch_bign_verify_t<16>(oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, st);

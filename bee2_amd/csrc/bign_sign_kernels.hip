@@ -248,14 +248,13 @@ void bign_mulbase_ct_kernel(const uint8_t *__restrict__ scalars, size_t n, uint3
 // ------------------------------------------------ belt-hash of a short message ---
 // words of the message live in an LDS row per lane (secret data: the row is lane-private); nw = number of
 // 32-bit words that hold message bytes, len = message length in octets (wavefront-uniform).
+// The hash starts from the standard's initial value, or from the state the OID's leading whole blocks left (OidArg,
+// bign_kernels.hip): len counts the octets in the row, oid.pre_len those absorbed before it.
 template <class Tab>
-__device__ __forceinline__ void belt_hash_row(const Tab &T, uint32_t (&h)[8], const uint32_t *row, uint32_t len)
+__device__ __forceinline__ void belt_hash_row(const Tab &T, uint32_t (&h)[8], const uint32_t *row, uint32_t len, const OidArg &oid)
 {
-    uint32_t s[4] = {0, 0, 0, 0}, X[8], s1[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        h[i] = (uint32_t)c_beltH[4 * i] | (uint32_t)c_beltH[4 * i + 1] << 8 |
-               (uint32_t)c_beltH[4 * i + 2] << 16 | (uint32_t)c_beltH[4 * i + 3] << 24;
+    uint32_t s[4], X[8], s1[4];
+    oid_hash_start(h, s, oid);
     const uint32_t nblk = (len + 31) / 32;
 #pragma unroll 1
     for (uint32_t b = 0; b < nblk; ++b) {
@@ -265,7 +264,7 @@ __device__ __forceinline__ void belt_hash_row(const Tab &T, uint32_t (&h)[8], co
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i] ^= s1[i];
     }
-    X[0] = len << 3; X[1] = 0; X[2] = 0; X[3] = 0;                  // <bit length>_128 || s (belt_hash.c:120-135)
+    X[0] = (len + oid.pre_len) << 3; X[1] = (len + oid.pre_len) >> 29; X[2] = 0; X[3] = 0;   // <bit length>_128 || s (belt_hash.c:120-135)
     X[4] = s[0]; X[5] = s[1]; X[6] = s[2]; X[7] = s[3];
     belt_compress(T, s1, h, X);
 }
@@ -330,7 +329,7 @@ void bign_sign_nonce_kernel(const uint8_t *__restrict__ hashes, const uint8_t *_
         const uint8_t *tp = t + (size_t)t_stride * idx;
         for (uint32_t i = 0; i < t_len; ++i) row_put_bytes(row, oid.len + NO + i, tp[i]);
     }
-    belt_hash_row(T, theta, row, len);
+    belt_hash_row(T, theta, row, len, oid);
     for (uint32_t i = 0; i < nwords; ++i) row[i] = 0;                        // wipe d from LDS
     }
 
@@ -523,7 +522,7 @@ void bign_sign_tail_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__
         }
     }
     uint32_t h[8];
-    belt_hash_row(T, h, row, len);
+    belt_hash_row(T, h, row, len, oid);
 
     // (s0 + 2^l) d : (N/2 + 1) x N limbs
     uint32_t s0[N / 2 + 1];
@@ -571,15 +570,6 @@ static err_t sign_scratch(hipStream_t st, size_t n, SignScratch &S)
     return ERR_OK;
 }
 
-static err_t make_oid_arg(OidArg &oa, const uint8_t *oid_der, size_t oid_len)
-{
-    if (oid_len > OID_MAX) return ERR_NOT_IMPLEMENTED;
-    oa.len = (uint32_t)oid_len;
-    memset(oa.der, 0, sizeof oa.der);
-    memcpy(oa.der, oid_der, oid_len);
-    return ERR_OK;
-}
-
 template <int N>
 static err_t launch_bign_pubkey_calc_t(bool keygen, const void *d_privkeys, size_t n, void *d_pubkeys, void *d_codes, hipStream_t st)
 {
@@ -609,7 +599,7 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
     if (n == 0) return ERR_OK;
     if (mode == 0 && d_aux && t_len > (size_t)SIGN_T_MAX) return ERR_NOT_IMPLEMENTED;
     OidArg oa;
-    err_t code = make_oid_arg(oa, oid_der, oid_len);
+    err_t code = make_oid_arg(oa, oid_der, oid_len, st);
     if (code != ERR_OK) return code;
     const uint32_t *tab = nullptr;
     code = bign_table8<N>(&tab, st);

@@ -24,6 +24,7 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 // different streams never share a buffer, two on the same stream are ordered by the stream.
 // Grown on demand; growing frees the old block only after the stream has drained.
 err_t scratch_for_stream(hipStream_t st, int slot, size_t bytes, void **out);
+const uint8_t *host_beltH();                              // the belt S-box, generated once on the host (capi.hip)
 
 // ---- kernel launchers (defined next to their kernels) ----
 err_t launch_bashF_batch(void *d_states, size_t n, hipStream_t st);

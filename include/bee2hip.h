@@ -233,8 +233,8 @@ err_t bignParamsStd(bign_params *params, const char *name);
    arithmetic, general coefficient a; 14 / 35 / 72 ms per batch of up to a few thousand signatures on the three
    levels -- a completeness path, not a throughput path).  The signing side
    (bignKeypairGen, bignPubkeyCalc, bignSign*) serves the standard sets only and reports ERR_NOT_IMPLEMENTED otherwise.
-   One limit, reported as ERR_NOT_IMPLEMENTED, never as a wrong verdict: oid_len <= 128 octets (the kernels stage the
-   DER OID as a launch argument; bee2 accepts any valid DER OID). */
+   Any valid DER OID is served, as in bee2: beyond 128 octets its leading whole 32-byte blocks are belt-hashed once per
+   batch and the per-signature kernels continue from that state (tests/golden/bign_oid_long.json: 129 .. 4099 octets). */
 err_t bignVerify(const bign_params *params, const octet oid_der[], size_t oid_len,
                  const octet hash[], const octet sig[], const octet pubkey[]);
 /* include/bee2/crypto/bign128.h:174-178, src/crypto/bign/bign128.c:177-185 */
@@ -258,8 +258,7 @@ err_t bign256PubkeyVal(const octet pubkey[128]);
    zzRandNZMod calls it (src/math/zz/zz_mod.c:463-485); the scalar multiplications, the nonce derivation of
    bignSign2 (belt-hash + belt-wbl), the hash tail and the arithmetic mod q run on the device.
    bign.h:207-215,247-254,316-326,352-363; bign128.h:64-69,98-101,140-164 (and bign192.h, bign256.h);
-   src/crypto/bign/bign_misc.c:182-243,373-431, bign_sign.c:32-260.
-   Limit: oid_len <= 128 (as bignVerify here). */
+   src/crypto/bign/bign_misc.c:182-243,373-431, bign_sign.c:32-260. */
 typedef void (*gen_i)(void *buf, size_t count, void *state);
 err_t bignKeypairGen(octet privkey[], octet pubkey[], const bign_params *params, gen_i rng, void *rng_state);
 err_t bignPubkeyCalc(octet pubkey[], const bign_params *params, const octet privkey[]);

@@ -76,6 +76,8 @@ static const uint8_t B256[64] = {
     0x88, 0xB0, 0xAD, 0xDA, 0xE3, 0x13, 0xCE, 0x17, 0x51, 0x25, 0x5D, 0xDD, 0xEE, 0xA9, 0xC6, 0x5B,
     0x89, 0x58, 0xFD, 0x60, 0x6A, 0x5D, 0x8C, 0xD8, 0x43, 0x8C, 0x3B, 0x93, 0x44, 0x59, 0xB4, 0x6C};
 
+/* longest DER OID the checker takes (stack buffers below); the reference takes any length */
+#define ORC_OID_MAX 8192
 /* DER of the pre-hash OIDs of the level-fixed facades: belt-hash, bash384, bash512 */
 static const uint8_t OID_BELT_HASH[11] = {0x06, 0x09, 0x2A, 0x70, 0x00, 0x02, 0x00, 0x22, 0x65, 0x1F, 0x51};
 static const uint8_t OID_BASH384[11] = {0x06, 0x09, 0x2A, 0x70, 0x00, 0x02, 0x00, 0x22, 0x65, 0x4D, 0x0C};
@@ -366,9 +368,9 @@ uint32_t orc_bignVerify_ex(size_t l, const uint8_t *oid_der, size_t oid_len, con
     uint64_t s1[MAXW] = {0}, H[MAXW] = {0}, u[SCW] = {0}, v[SCW] = {0};
     jac G, Q;
     fe rx;
-    uint8_t msg[256 + 128], t[32];
+    uint8_t msg[ORC_OID_MAX + 128], t[32];
     if (l != 128 && l != 192 && l != 256) return ORC_BAD_PARAMS;
-    if (oid_len > 256) return ORC_BAD_OID;
+    if (oid_len > ORC_OID_MAX) return ORC_BAD_OID;                /* checker limit, not the reference's */
     curve_init(&E, (int)l);
     const int n = E.n, no = (int)l / 4;
     memset(&Q, 0, sizeof Q);
@@ -586,7 +588,7 @@ static uint32_t sign_with_k(const curve *E, size_t l, uint8_t *sig, const uint8_
 {
     const int n = E->n, no = (int)l / 4;
     fe x, y;
-    uint8_t msg[256 + 128], t[32];
+    uint8_t msg[ORC_OID_MAX + 128], t[32];
     uint64_t s0[MAXW] = {0}, prod[2 * MAXW] = {0}, s1[MAXW], H[MAXW] = {0};
     if (!mul_base(E, &x, &y, k)) return ORC_BAD_PARAMS;
     memcpy(msg, oid_der, oid_len);
@@ -628,7 +630,7 @@ uint32_t orc_bignSign_rnd(size_t l, uint8_t *sig, const uint8_t *oid_der, size_t
     uint64_t d[MAXW] = {0}, k[MAXW] = {0};
     size_t i = 0;
     if (l != 128 && l != 192 && l != 256) return ORC_BAD_PARAMS;
-    if (oid_len > 256) return ORC_BAD_OID;
+    if (oid_len > ORC_OID_MAX) return ORC_BAD_OID;                /* checker limit, not the reference's */
     curve_init(&E, (int)l);
     words_from_le(d, privkey, E.n);
     if (words_is_zero(d, E.n) || words_cmp(d, E.q, E.n) >= 0) return ORC_BAD_PRIVKEY;
@@ -649,14 +651,14 @@ uint32_t orc_bignSign2(size_t l, uint8_t *sig, const uint8_t *oid_der, size_t oi
     uint8_t theta[32], kb[64], *msg;
     uint32_t K[8];
     if (l != 128 && l != 192 && l != 256) return ORC_BAD_PARAMS;
-    if (oid_len > 256) return ORC_BAD_OID;
+    if (oid_len > ORC_OID_MAX) return ORC_BAD_OID;                /* checker limit, not the reference's */
     curve_init(&E, (int)l);
     const int n = E.n, no = (int)l / 4;
     words_from_le(d, privkey, n);
     if (words_is_zero(d, n) || words_cmp(d, E.q, n) >= 0) return ORC_BAD_PRIVKEY;
     /* theta = belt-hash(oid || d || t) (:197-202) */
     {
-        uint8_t stack_msg[256 + 64 + 256];
+        uint8_t stack_msg[ORC_OID_MAX + 64 + 256];
         msg = stack_msg;
         if (t_len > 256) return ORC_BAD_INPUT;                     /* checker limit, not the reference's */
         memcpy(msg, oid_der, oid_len);

@@ -32,6 +32,8 @@ class Golden:
             self.bign_pubkey_val = json.load(f)
         with open(os.path.join(GOLD, "bign_oid_lengths.json")) as f:
             self.bign_oid_lengths = json.load(f)
+        with open(os.path.join(GOLD, "bign_oid_long.json")) as f:
+            self.bign_oid_long = json.load(f)
         with open(os.path.join(GOLD, "sigvfy_pipeline.json")) as f:
             self.sigvfy_pipeline = json.load(f)
         with open(os.path.join(GOLD, "belt_bde_random.json")) as f:

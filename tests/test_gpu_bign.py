@@ -641,6 +641,38 @@ def test_bign_oid_lengths_every_alignment(golden):
                               bytes.fromhex(c["pubkey"])) == c["code"]
 
 
+def test_bign_long_oids_prefix_hashed_once_per_batch(golden):
+    """OIDs beyond the 128 octets a kernel stages (129 .. 4099 DER octets, every block alignment of the prefix): the whole
+    32-byte blocks of the OID are absorbed once per batch and the per-signature kernels start from that state.  Device
+    batches on all three curves, the generic drop-in, and -- for the valid entries -- the deterministic signature itself."""
+    eng = engine()
+    groups = {}
+    for c in golden.bign_oid_long:
+        groups.setdefault((c["l"], c["oid"]), []).append(c)
+    assert len(groups) == 66
+    for (l, oid_hex), cs in groups.items():
+        oid = bytes.fromhex(oid_hex)
+        cs = cs * 70
+        hs = b"".join(bytes.fromhex(c["hash"]) for c in cs)
+        ss = b"".join(bytes.fromhex(c["sig"]) for c in cs)
+        ps = b"".join(bytes.fromhex(c["pubkey"]) for c in cs)
+        codes = torch.full((len(cs),), -1, dtype=torch.int32, device="cuda")
+        eng.bignVerifyL_batch_dev(l, oid, dev(hs), dev(ss), dev(ps), codes)
+        torch.cuda.synchronize()
+        got = [int(x) & 0xFFFFFFFF for x in codes.cpu().numpy()]
+        assert got == [c["code"] for c in cs], (l, len(oid))
+    for l in (128, 192, 256):
+        params = eng.bignParamsStd(E.CURVE_NAME[l])
+        for c in [c for c in golden.bign_oid_long if c["l"] == l]:
+            oid, h, sg, pub = (bytes.fromhex(c[k]) for k in ("oid", "hash", "sig", "pubkey"))
+            assert eng.bignVerify(params, oid, h, sg, pub) == c["code"]
+            if c["code"] == 0:
+                out = ctypes.create_string_buffer(len(sg))
+                assert eng.lib.bignSign2(out, ctypes.byref(params), oid, ctypes.c_size_t(len(oid)), h, bytes.fromhex(c["privkey"]),
+                                         None, ctypes.c_size_t(0)) == 0
+                assert out.raw == sg, (l, len(oid))
+
+
 def test_bign_big_batch_every_entry_against_the_oracle(orc, golden):
     """2^18 + 17 signatures on the 256-bit curve (shared inversions in prep and inv, big-table tail), HALF of them
     damaged by a random bit flip in the hash, s0, s1 or the public key -- each damaged key gives a table of its

@@ -242,6 +242,17 @@ def test_bign_oid_lengths_oracle_vs_golden(orc, golden):
         assert got == c["code"], (c["l"], len(c["oid"]) // 2)
 
 
+def test_bign_long_oids_oracle_vs_golden(orc, golden):
+    """OIDs of 129 .. 4099 DER octets (reference as signer): the checker itself must agree before the GPU path is held to it"""
+    for c in golden.bign_oid_long:
+        got = orc.verify_l(c["l"], bytes.fromhex(c["oid"]), bytes.fromhex(c["hash"]), bytes.fromhex(c["sig"]),
+                           bytes.fromhex(c["pubkey"]))
+        assert got == c["code"], (c["l"], len(c["oid"]) // 2)
+        if c["code"] == 0:
+            assert orc.sign2(c["l"], bytes.fromhex(c["oid"]), bytes.fromhex(c["hash"]), bytes.fromhex(c["privkey"]))[1] == \
+                bytes.fromhex(c["sig"])
+
+
 def test_sigvfy_pipeline_oracle_vs_golden(orc, golden):
     """hash -> bignPubkeyVal -> bignVerify as `bee2cmd sig vfy` chains them (cmd_sig.c:461-490), reference verdicts"""
     from bee2_amd.engine import LEVEL_OID

@@ -614,6 +614,46 @@ def oid_len_cases(seed=0x01DA):
     return out
 
 
+def oid_long_cases(seed=0x01DB):
+    """The same beyond the 128 octets a kernel stages itself (round 3: the OID's whole 32-byte blocks are pre-hashed once per
+    batch, bee2_amd/csrc/bign_kernels.hip make_oid_arg): DER lengths around the block boundaries of the prefix (129 .. 164),
+    the one- / two-byte length forms (255 / 256 / 257 octets) and a few long ones.  The private key is kept so that the
+    deterministic signature can be reproduced as well."""
+    import random
+    L = refgen.ref()
+    out = []
+    rnd = random.Random(seed)
+
+    def der_total(total):
+        for hdr, enc in ((2, lambda n: bytes([0x06, n])), (3, lambda n: bytes([0x06, 0x81, n])),
+                         (4, lambda n: bytes([0x06, 0x82, n >> 8, n & 255]))):
+            n = total - hdr
+            if (hdr == 2 and n < 128) or (hdr == 3 and 128 <= n < 256) or (hdr == 4 and 256 <= n < 65536):
+                return enc(n) + bytes([0x2A]) + bytes(rnd.randrange(1, 128) for _ in range(n - 1))
+        raise ValueError(total)
+
+    for l in (128, 192, 256):
+        prm = refparams(l)
+        no = l // 4
+        for total in (129, 131, 132, 133, 159, 160, 161, 162, 163, 164, 191, 192, 193, 255, 256, 257, 258, 260, 261, 300, 1000, 4099):     # 130 and 259 octets do not exist in DER
+            oid = der_total(total)
+            assert len(oid) == total
+            priv = int_le(rnd.randrange(1, 2 ** (l - 1)), no)
+            pub = refgen.pubkey_calc_l(l, priv)
+            h = rnd.randbytes(no)
+            sig = ctypes.create_string_buffer(no + no // 2)
+            assert L.bignSign2(sig, ctypes.byref(prm), oid, _sz(len(oid)), h, priv, None, _sz(0)) == 0
+            for kind in ("valid", "flip"):
+                sg = bytearray(sig.raw)
+                if kind == "flip":
+                    sg[rnd.randrange(len(sg))] ^= 1 << rnd.randrange(8)
+                code = L.bignVerify(ctypes.byref(prm), oid, _sz(len(oid)), h, bytes(sg), pub)
+                assert code == (0 if kind == "valid" else 510)
+                out.append({"l": l, "oid": oid.hex(), "hash": h.hex(), "sig": bytes(sg).hex(), "pubkey": pub.hex(),
+                            "privkey": priv.hex(), "code": code})
+    return out
+
+
 def sigvfy_pipeline(seed=0x51F7):
     """`bee2cmd sig vfy`-shaped batch (cmd/core/cmd_sig.c:461-490): messages of ragged lengths, their belt-hash
     (level 128) or bash384 / bash512 digest as pre-hash, a public key and a signature per message (reference as
@@ -714,6 +754,8 @@ def main():
         json.dump(pubkey_val_cases(), f)
     with open(os.path.join(GOLD, "bign_oid_lengths.json"), "w") as f:
         json.dump(oid_len_cases(), f)
+    with open(os.path.join(GOLD, "bign_oid_long.json"), "w") as f:
+        json.dump(oid_long_cases(), f)
     with open(os.path.join(GOLD, "sigvfy_pipeline.json"), "w") as f:
         json.dump(sigvfy_pipeline(), f)
     with open(os.path.join(GOLD, "stb_kat.json"), "w") as f:
