@@ -81,6 +81,17 @@ __device__ __forceinline__ uint32_t ct_in_range_q(const uint32_t (&x)[N])
     for (int i = 0; i < N; ++i) q[i] = curve_q<N>()[i];
     return ~ct_is_zero(x) & ct_lt(x, q);
 }
+// the group order as a launch argument: the nonce / range-check kernels serve any parameter set (round 3: signing on
+// non-standard sets, bign_generic_kernels.hip); std = 1 means "the standard set of this level" (q from constant memory)
+template <int N> struct QArg { uint32_t q[N]; uint32_t std; };
+template <int N>
+__device__ __forceinline__ uint32_t ct_in_range_q(const uint32_t (&x)[N], const QArg<N> &qa)
+{
+    uint32_t q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = qa.std ? curve_q<N>()[i] : qa.q[i];       // qa.std is wavefront-uniform and public
+    return ~ct_is_zero(x) & ct_lt(x, q);
+}
 
 // ------------------------------------------------- complete mixed addition ---
 // P <- P + Q on y^2 = x^3 - 3x + b, P = (X : Y : Z) homogeneous projective (x = X / Z, O = (0 : 1 : 0)),
@@ -286,7 +297,7 @@ template <int N>
 __global__ __launch_bounds__(SIGN_WG)
 void bign_sign_nonce_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ privkeys,
                             const uint8_t *__restrict__ t, uint32_t t_len, uint32_t t_stride,
-                            const uint8_t *__restrict__ theta_in, size_t n, OidArg oid,
+                            const uint8_t *__restrict__ theta_in, size_t n, OidArg oid, QArg<N> qa,
                             uint32_t *__restrict__ status, uint8_t *__restrict__ k_out)
 {
     constexpr int NO = 4 * N;
@@ -302,7 +313,7 @@ void bign_sign_nonce_kernel(const uint8_t *__restrict__ hashes, const uint8_t *_
 
     uint32_t d[N];
     load_words_bytes(d, privkeys + NO * idx);
-    const uint32_t d_ok = ct_in_range_q(d);
+    const uint32_t d_ok = ct_in_range_q(d, qa);
     status[idx] = ct_sel(d_ok, ST_PENDING, ERR_BAD_PRIVKEY_V);
 
     // ---- theta = belt-hash(oid || d || t) (or taken from the caller: additional input longer than SIGN_T_MAX is
@@ -382,8 +393,9 @@ void bign_sign_nonce_kernel(const uint8_t *__restrict__ hashes, const uint8_t *_
         for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) kk[4 * j + i] = r[j][i];
-        done |= ct_in_range_q(kk);
-        if (__all(done != 0)) break;          // fails with probability < 2^-126 per signature (see the header)
+        done |= ct_in_range_q(kk, qa);
+        if (__all(done != 0)) break;          // fails with probability < 2^-126 per signature (see the header; a non-standard
+                                              // q may sit anywhere in [2^(2l-1), 2^2l): up to one rejection in two there)
     }
     uint32_t *ko = reinterpret_cast<uint32_t *>(k_out + NO * idx);
 #pragma unroll
@@ -393,7 +405,7 @@ void bign_sign_nonce_kernel(const uint8_t *__restrict__ hashes, const uint8_t *_
 // bignSign with the one-time key supplied (bign_sign.c:71-82 after the rng): d and k range checks only
 template <int N>
 __global__ __launch_bounds__(256)
-void bign_sign_kcheck_kernel(const uint8_t *__restrict__ privkeys, const uint8_t *__restrict__ ks, size_t n,
+void bign_sign_kcheck_kernel(const uint8_t *__restrict__ privkeys, const uint8_t *__restrict__ ks, size_t n, QArg<N> qa,
                              uint32_t *__restrict__ status)
 {
     constexpr int NO = 4 * N;
@@ -402,7 +414,7 @@ void bign_sign_kcheck_kernel(const uint8_t *__restrict__ privkeys, const uint8_t
     uint32_t d[N], k[N];
     load_words_bytes(d, privkeys + NO * idx);
     load_words_bytes(k, ks + NO * idx);
-    const uint32_t d_ok = ct_in_range_q(d), k_ok = ct_in_range_q(k);
+    const uint32_t d_ok = ct_in_range_q(d, qa), k_ok = ct_in_range_q(k, qa);
     status[idx] = ct_sel(d_ok, ct_sel(k_ok, ST_PENDING, ERR_BAD_RNG_V), ERR_BAD_PRIVKEY_V);
 }
 
@@ -609,6 +621,9 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
     if (code != ERR_OK) return code;
     const unsigned grid = (unsigned)((n + SIGN_WG - 1) / SIGN_WG);
     const uint8_t *kptr;
+    QArg<N> qa;
+    memset(&qa, 0, sizeof qa);
+    qa.std = 1;
     if (mode == 0 || mode == 2) {
         constexpr int ROW = (OID_MAX + 64 + SIGN_T_MAX + 31) / 32 * 8 + 1;
         const size_t lds = BeltTabTwo::kBytes + (size_t)SIGN_WG * ROW * 4;
@@ -620,11 +635,11 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
         const uint8_t *tp = mode == 0 ? (const uint8_t *)d_aux : nullptr;
         hipLaunchKernelGGL(bign_sign_nonce_kernel<N>, dim3(grid), dim3(SIGN_WG), lds, st, (const uint8_t *)d_hashes,
                            (const uint8_t *)d_privkeys, tp, (uint32_t)(tp ? t_len : 0),
-                           (uint32_t)(t_shared ? 0 : t_len), mode == 2 ? (const uint8_t *)d_aux : nullptr, n, oa, S.status, S.k);
+                           (uint32_t)(t_shared ? 0 : t_len), mode == 2 ? (const uint8_t *)d_aux : nullptr, n, oa, qa, S.status, S.k);
         kptr = S.k;
     } else {
         hipLaunchKernelGGL(bign_sign_kcheck_kernel<N>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           (const uint8_t *)d_privkeys, (const uint8_t *)d_aux, n, S.status);
+                           (const uint8_t *)d_privkeys, (const uint8_t *)d_aux, n, qa, S.status);
         B2H_TRY(hipMemcpyAsync(S.k, d_aux, n * 4 * N, hipMemcpyDeviceToDevice, st));
         kptr = S.k;
     }

@@ -714,12 +714,27 @@ static err_t params_check2(const bign_params *params, bool *standard)
     return ERR_OK;
 }
 // for the entry points that serve the standard curves only
+// the signing side (bignPubkeyCalc, bignKeypairGen, bignSign*): every set bignParamsCheck + bignEcCreate accept;
+// *standard tells which kernels serve it (the table-driven ones of bign_sign_kernels.hip, or the general-curve
+// constant-time ladder of bign_generic_kernels.hip)
+static err_t params_check_sign(const bign_params *params, bool *standard)
+{
+    const err_t code = params_check2(params, standard);
+    if (code != ERR_OK) return code;
+    return *standard ? ERR_OK : bign_generic_check(params);
+}
 static err_t params_check(const bign_params *params)
 {
     bool standard;
-    const err_t code = params_check2(params, &standard);
+    return params_check_sign(params, &standard);
+}
+static err_t pubkey_calc_any(const bign_params *params, bool keygen, const void *d_privkeys, size_t n, void *d_pubkeys, void *d_codes)
+{
+    bool standard;
+    const err_t code = params_check_sign(params, &standard);
     if (code != ERR_OK) return code;
-    return standard ? ERR_OK : ERR_NOT_IMPLEMENTED;
+    return standard ? launch_bign_pubkey_calc(params->l, keygen, d_privkeys, n, d_pubkeys, d_codes, nullptr)
+                    : launch_bign_pubkey_calc_generic(params, keygen, d_privkeys, n, d_pubkeys, d_codes, nullptr);
 }
 
 // oidFromDER(0, der, count) != SIZE_MAX  (src/core/oid.c:94-101, src/core/der.c:114-258,921-975):
@@ -967,7 +982,7 @@ extern "C" err_t bee2hip_bignPubkeyCalc_batch(const bign_params *params, const o
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
     B2H_TRY(h2d(d, privkeys, db));
-    code = launch_bign_pubkey_calc(params->l, false, d, n, d + po, d + co, nullptr);
+    code = pubkey_calc_any(params, false, d, n, d + po, d + co);
     if (code == ERR_OK) {
         hipError_t e = d2h(codes, d + co, 4 * n);
         // bee2 leaves the output alone when it fails: copy the keys of the good items only
@@ -1023,8 +1038,15 @@ static err_t sign_batch_host(int mode, const bign_params *params, const octet oi
     B2H_TRY(h2d(d, hashes, hb));
     B2H_TRY(h2d(d + o_d, privkeys, hb));
     if (ab) B2H_TRY(h2d(d + o_a, aux, ab));
-    code = launch_bign_sign(params->l, dev_mode, oid_der, oid_len, d, d + o_d, ab ? d + o_a : nullptr, t_len, 1, n, d + o_s, d + o_c,
-                            nullptr);
+    {
+        bool standard;
+        code = params_check_sign(params, &standard);
+        if (code == ERR_OK)
+            code = standard ? launch_bign_sign(params->l, dev_mode, oid_der, oid_len, d, d + o_d, ab ? d + o_a : nullptr, t_len, 1, n,
+                                               d + o_s, d + o_c, nullptr)
+                            : launch_bign_sign_generic(params, dev_mode, oid_der, oid_len, d, d + o_d, ab ? d + o_a : nullptr, t_len, 1,
+                                                       n, d + o_s, d + o_c, nullptr);
+    }
     if (code == ERR_OK) {
         hipError_t e = d2h(codes, d + o_c, 4 * n);
         std::vector<octet> tmp(sg * n);
@@ -1092,7 +1114,7 @@ extern "C" err_t bignKeypairGen(octet privkey[], octet pubkey[], const bign_para
             octet *dd = (octet *)s.p;
             hipError_t e = h2d(dd, d, no);
             if (e == hipSuccess) {
-                code = launch_bign_pubkey_calc(params->l, true, dd, 1, dd + 64, dd + 192, nullptr);
+                code = pubkey_calc_any(params, true, dd, 1, dd + 64, dd + 192);
                 octet q[128];
                 err_t one = ERR_BAD_PARAMS;
                 if (code == ERR_OK) e = d2h(q, dd + 64, 2 * no);

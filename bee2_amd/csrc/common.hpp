@@ -71,6 +71,11 @@ err_t bign_generic_check(const bign_params *params);
 err_t launch_bign_pubkey_val_generic(const bign_params *params, const void *d_pubkeys, size_t n, void *d_codes, hipStream_t st);
 // 8f-4 tail: Q = d G per private key (codes: ERR_OK / ERR_BAD_PRIVKEY); signing, mode 0 = bignSign2 (d_aux = t or
 // null), mode 1 = one-time keys supplied (d_aux = k)
+err_t launch_bign_pubkey_calc_generic(const bign_params *params, bool keygen, const void *d_privkeys, size_t n, void *d_pubkeys,
+                                      void *d_codes, hipStream_t st);
+err_t launch_bign_sign_generic(const bign_params *params, int mode, const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
+                               const void *d_privkeys, const void *d_aux, size_t t_len, int t_shared, size_t n, void *d_sigs,
+                               void *d_codes, hipStream_t st);
 err_t launch_bign_pubkey_calc(size_t l, bool keygen, const void *d_privkeys, size_t n, void *d_pubkeys, void *d_codes, hipStream_t st);
 err_t launch_bign_sign(size_t l, int mode, const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
                        const void *d_privkeys, const void *d_aux, size_t t_len, int t_shared, size_t n, void *d_sigs,

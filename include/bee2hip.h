@@ -231,8 +231,9 @@ err_t bignParamsStd(bign_params *params, const char *name);
    Any parameter set that passes bignParamsCheck + bignEcCreate is served (bignVerify and bignPubkeyVal; batch forms
    likewise): the three standard sets by the throughput kernels, every other set by general-curve kernels (Montgomery
    arithmetic, general coefficient a; 14 / 35 / 72 ms per batch of up to a few thousand signatures on the three
-   levels -- a completeness path, not a throughput path).  The signing side
-   (bignKeypairGen, bignPubkeyCalc, bignSign*) serves the standard sets only and reports ERR_NOT_IMPLEMENTED otherwise.
+   levels -- a completeness path, not a throughput path).  The signing side (bignKeypairGen, bignPubkeyCalc, bignSign*)
+   serves them too: a constant-time double-and-add-always ladder with complete additions on the general curve, arithmetic
+   mod q in Montgomery form (bign_generic_kernels.hip; tests/golden/bign_generic_sign.json holds the reference's answers).
    Any valid DER OID is served, as in bee2: beyond 128 octets its leading whole 32-byte blocks are belt-hashed once per
    batch and the per-signature kernels continue from that state (tests/golden/bign_oid_long.json: 129 .. 4099 octets). */
 err_t bignVerify(const bign_params *params, const octet oid_der[], size_t oid_len,

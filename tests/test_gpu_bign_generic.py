@@ -99,3 +99,74 @@ def test_generic_verify_random_damage_vs_python_restatement(orc):
             want.append(OG.verify(P, bytes.fromhex(x["oid"]), bytes(h), bytes(s), bytes(k), orc.belt_hash))
         code, got = eng.bignVerify_batch(H, S, K, oid_der=bytes.fromhex(good[0]["oid"]), params=prm)
         assert code == 0 and got == want, (ci, got, want)
+
+
+SFIX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bign_generic_sign.json")))
+
+
+@pytest.mark.parametrize("which", range(len(SFIX)))
+def test_generic_signing_side_matches_the_reference(which):
+    """round 3: bignPubkeyCalc / bignKeypairGen / bignSign2 / bignSign on isomorphic images of the standard curves (a != -3;
+    the constant-time general-curve ladder of bign_generic_kernels.hip) -- keys 0, 1, q - 1, q, 2^2l - 1, hashes at and beyond
+    q, additional input up to 200 octets (the host-hashed theta path), a 203-octet OID, rejected rng draws, a malformed OID;
+    every expected value from the reference (tools/make_golden_generic_sign.py).  What is signed here must also verify here."""
+    eng = engine()
+    ent = SFIX[which]
+    c = FIX["curves"][ent["curve"]]
+    P = mk(c)
+    no = c["l"] // 4
+    for x in ent["pubkey_calc"]:
+        code, pub = eng.bignPubkeyCalc(P, bytes.fromhex(x["priv"]))
+        assert code == x["code"], x["priv"]
+        if code == 0:
+            assert pub.hex() == x["pub"]
+            assert eng.bignPubkeyVal(P, pub) == 0
+    for x in ent["keypair_gen"]:
+        rng = eng.rng_from_bytes(bytes.fromhex(x["rnd"]) + bytes(70 * no))
+        code, priv, pub = eng.bignKeypairGen(P, rng)
+        assert code == x["code"], x
+        if code == 0:
+            assert (priv.hex(), pub.hex(), rng.pos[0]) == (x["priv"], x["pub"], x["used"])
+    for x in ent["sign2"]:
+        t = None if x["t"] is None else bytes.fromhex(x["t"])
+        oid, h, d = (bytes.fromhex(x[k]) for k in ("oid", "hash", "priv"))
+        code, sig = eng.bignSign2(P, oid, h, d, t)
+        assert code == x["code"], x
+        if code == 0:
+            assert sig.hex() == x["sig"], x
+            assert eng.bignVerify(P, oid, h, sig, eng.bignPubkeyCalc(P, d)[1]) == 0
+    for x in ent["sign"]:
+        rng = eng.rng_from_bytes(bytes.fromhex(x["rnd"]))
+        code, sig = eng.bignSign(P, bytes.fromhex(x["oid"]), bytes.fromhex(x["hash"]), bytes.fromhex(x["priv"]), rng)
+        assert code == x["code"], x
+        if code == 0:
+            assert (sig.hex(), rng.pos[0]) == (x["sig"], x["used"])
+        else:
+            assert rng.pos[0] == 0
+
+
+def test_generic_sign_batch_and_verify_roundtrip():
+    """a batch of a few hundred deterministic signatures on a non-standard set through bee2hip_bignSign2_batch, every one
+    verified by bee2hip_bignVerify_batch on the same set, plus refused keys in the middle of the batch"""
+    eng = engine()
+    c = FIX["curves"][SFIX[0]["curve"]]
+    P = mk(c)
+    no = c["l"] // 4
+    q = int.from_bytes(bytes.fromhex(c["q"]), "little")
+    rnd = random.Random(99)
+    n = 200
+    privs = [rnd.randrange(1, q).to_bytes(no, "little") for _ in range(n)]
+    privs[17] = bytes(no)
+    privs[150] = q.to_bytes(no, "little")
+    hs = [rnd.randbytes(no) for _ in range(n)]
+    oid = bytes.fromhex(SFIX[0]["sign2"][0]["oid"])
+    code, sigs, codes = eng.bignSign2_batch(P, oid, b"".join(hs), b"".join(privs), None)
+    assert code == 0
+    assert [i for i in range(n) if codes[i] != 0] == [17, 150] and codes[17] == codes[150] == 504
+    good = [i for i in range(n) if codes[i] == 0]
+    pcode, pubs, pcodes = eng.bignPubkeyCalc_batch(P, b"".join(privs[i] for i in good))
+    assert pcode == 0 and all(x == 0 for x in pcodes)
+    sg = no + no // 2
+    vcode, vcodes = eng.bignVerify_batch(b"".join(hs[i] for i in good), b"".join(sigs[sg * i: sg * i + sg] for i in good), pubs,
+                                         oid_der=oid, params=P)
+    assert vcode == 0 and all(x == 0 for x in vcodes)
