@@ -556,8 +556,12 @@ void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
         put(entry, Wk);
         if (to_t) T = Wk; else A = Wk;
     }
-    __syncthreads();                                // makes the table writes visible to the quad (wavefronts that
-                                                    // left early do not take part in the barrier)
+    // The table entries of a signature are written and read by the lanes of ONE wavefront (LANES <= 8 consecutive lanes), and
+    // a wavefront's DS operations execute in order: all that is needed is that the writes have been issued before the reads
+    // -- no workgroup barrier, which wavefronts that left early (idx >= n, a refused signature) would not have reached
+    // (formally undefined in HIP, even though gfx9 drops terminated wavefronts from the barrier count).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
 
     // top digit d_{4N} = nibble_{4N}(w) - 8 is 1 or 2
     get(E, (int)(w[NW - 1] & 15u) - 9);

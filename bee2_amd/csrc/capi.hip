@@ -928,6 +928,12 @@ extern "C" err_t bign256PubkeyVal(const octet pubkey[128]) { return level_pubkey
 // ---- 8f-4 tail: public key from private key, key generation, signing (bign_misc.c:182-229,373-417,
 // bign_sign.c:32-245).  Secrets cross the staging buffer t_scr[3]; it is overwritten with zeros before return.
 static void wipe_dev(void *p, size_t n) { if (p && n) (void)zero_staging(p, n); }
+// staged secrets are zeroed on EVERY way out of a host entry point (early error returns, an allocation that throws)
+struct WipeGuard {
+    void *p;
+    size_t n;
+    ~WipeGuard() { wipe_dev(p, n); }
+};
 
 extern "C" err_t bee2hip_bignPubkeyCalcL_batch_dev(size_t l, const void *d_privkeys, size_t n, void *d_pubkeys,
                                                    void *d_codes, void *stream)
@@ -981,17 +987,19 @@ extern "C" err_t bee2hip_bignPubkeyCalc_batch(const bign_params *params, const o
     code = s.need(co + 4 * n);
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
+    const WipeGuard wipe{d, db};
     B2H_TRY(h2d(d, privkeys, db));
     code = pubkey_calc_any(params, false, d, n, d + po, d + co);
     if (code == ERR_OK) {
         hipError_t e = d2h(codes, d + co, 4 * n);
         // bee2 leaves the output alone when it fails: copy the keys of the good items only
-        std::vector<octet> tmp(2 * no * n);
-        if (e == hipSuccess) e = d2h(tmp.data(), d + po, 2 * no * n);
+        octet *tmp = new (std::nothrow) octet[2 * no * n];
+        if (!tmp) return ERR_OUTOFMEMORY;                       // (the guard above wipes the staged keys)
+        if (e == hipSuccess) e = d2h(tmp, d + po, 2 * no * n);
         if (e != hipSuccess) code = hip_fail(e, "bignPubkeyCalc copy");
-        else for (size_t i = 0; i < n; ++i) if (codes[i] == ERR_OK) memcpy(pubkeys + 2 * no * i, tmp.data() + 2 * no * i, 2 * no);
+        else for (size_t i = 0; i < n; ++i) if (codes[i] == ERR_OK) memcpy(pubkeys + 2 * no * i, tmp + 2 * no * i, 2 * no);
+        delete[] tmp;
     }
-    wipe_dev(d, db);
     return code;
 }
 
@@ -1024,6 +1032,9 @@ static err_t sign_batch_host(int mode, const bign_params *params, const octet oi
             beltHashStepG(theta.data() + 32 * i, st.data());
         }
         memset(st.data(), 0, st.size());
+        // with BEE2HIP_FORCE=gpu the streaming belt-hash staged the private keys and its state through t_scr[2] (pinned or
+        // device memory): wipe it (in the default mode these hashes run on the host path and stage nothing)
+        if (t_scr[2].p) (void)zero_staging(t_scr[2].p, std::min<size_t>(t_scr[2].p == t_scr[2].pin ? PINNED_MAX : t_scr[2].cap, 4096));
         aux = theta.data();
         ab = 32 * n;
         dev_mode = 2;
@@ -1035,6 +1046,7 @@ static err_t sign_batch_host(int mode, const bign_params *params, const octet oi
     code = s.need(o_c + 4 * n);
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
+    const WipeGuard wipe{d + o_d, o_s - o_d};              // private keys and one-time keys / t / theta
     B2H_TRY(h2d(d, hashes, hb));
     B2H_TRY(h2d(d + o_d, privkeys, hb));
     if (ab) B2H_TRY(h2d(d + o_a, aux, ab));
@@ -1054,19 +1066,22 @@ static err_t sign_batch_host(int mode, const bign_params *params, const octet oi
         if (e != hipSuccess) code = hip_fail(e, "bignSign copy");
         else for (size_t i = 0; i < n; ++i) if (codes[i] == ERR_OK) memcpy(sigs + sg * i, tmp.data() + sg * i, sg);
     }
-    wipe_dev(d + o_d, o_s - o_d);
     if (!theta.empty()) memset(theta.data(), 0, theta.size());
     return code;
 }
 extern "C" err_t bee2hip_bignSign2_batch(const bign_params *params, const octet oid_der[], size_t oid_len, const octet *hashes,
                                          const octet *privkeys, const void *t, size_t t_len, size_t n, octet *sigs, err_t *codes)
 {
-    return sign_batch_host(0, params, oid_der, oid_len, hashes, privkeys, (const octet *)t, t_len, n, sigs, codes);
+    try {
+        return sign_batch_host(0, params, oid_der, oid_len, hashes, privkeys, (const octet *)t, t_len, n, sigs, codes);
+    } catch (const std::bad_alloc &) { return ERR_OUTOFMEMORY; }      // nothing may unwind through the C ABI
 }
 extern "C" err_t bee2hip_bignSignK_batch(const bign_params *params, const octet oid_der[], size_t oid_len, const octet *hashes,
                                          const octet *privkeys, const octet *ks, size_t n, octet *sigs, err_t *codes)
 {
-    return sign_batch_host(1, params, oid_der, oid_len, hashes, privkeys, ks, 0, n, sigs, codes);
+    try {
+        return sign_batch_host(1, params, oid_der, oid_len, hashes, privkeys, ks, 0, n, sigs, codes);
+    } catch (const std::bad_alloc &) { return ERR_OUTOFMEMORY; }
 }
 
 // ---- drop-ins.  Order of checks as the reference: parameters (bignParamsCheck), pointers, OID, private key.
