@@ -120,78 +120,51 @@ template <class P = CtOps, int N>
 __device__ __forceinline__ void fe_add(feT<N> &r, const feT<N> &a, const feT<N> &b)
 {
     constexpr uint32_t C = CurveC<N>::C;
-    if constexpr (P::VT) {
-        uint32_t t[N], k;
-        uint64_t cy, cy2;
-        const uint32_t cv = C;
-        asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(t[0]), "=s"(cy) : "v"(a.v[0]), "v"(b.v[0]));
+    uint32_t t[N], k;
+    uint64_t cy, cy2;
+    const uint32_t cv = C;
+    asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(t[0]), "=s"(cy) : "v"(a.v[0]), "v"(b.v[0]));
 #pragma unroll
-        for (int i = 1; i < N; ++i)
-            asm("v_addc_co_u32 %0, %1, %2, %3, %1" : "=v"(t[i]), "+s"(cy) : "v"(a.v[i]), "v"(b.v[i]));
-        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(k) : "v"(cv), "s"(cy));           // wrapped past 2^(32N): + c
-        asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(t[0]), "=s"(cy2) : "v"(t[0]), "v"(k));
-        if (__builtin_expect(cy2 != 0, 0)) {                                            // limb 0 overflowed in some lane
+    for (int i = 1; i < N; ++i)
+        asm("v_addc_co_u32 %0, %1, %2, %3, %1" : "=v"(t[i]), "+s"(cy) : "v"(a.v[i]), "v"(b.v[i]));
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(k) : "v"(cv), "s"(cy));           // wrapped past 2^(32N): + c
+    asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(t[0]), "=s"(cy2) : "v"(t[0]), "v"(k));
+    // limb 0 overflowed in some lane (probability 2^-24 on random data): ripple.  The verification flavour skips the
+    // pass with a wavefront-uniform branch; the constant-time flavour always runs it (round 3: the same carry chains
+    // instead of 64-bit adds of zero-extended limbs: 20 half-rate instructions instead of ~50 mixed ones).
+    if (!P::VT || __builtin_expect(cy2 != 0, 0)) {
 #pragma unroll
-            for (int i = 1; i < N; ++i) asm("v_addc_co_u32 %0, %1, 0, %0, %1" : "+v"(t[i]), "+s"(cy2));
-            uint32_t top;
-            asm("v_addc_co_u32 %0, %1, 0, 0, %1" : "=v"(top), "+s"(cy2));
-            t[0] += (0u - top) & C;
-        }
-#pragma unroll
-        for (int i = 0; i < N; ++i) r.v[i] = t[i];
-    } else {
-    uint64_t c = 0;
-    uint32_t t[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) { c += (uint64_t)a.v[i] + b.v[i]; t[i] = (uint32_t)c; c >>= 32; }
-    uint64_t f = (uint64_t)t[0] + ((uint32_t)c ? C : 0u);
-    r.v[0] = (uint32_t)f; f >>= 32;
-#pragma unroll
-    for (int i = 1; i < N; ++i) { f += t[i]; r.v[i] = (uint32_t)f; f >>= 32; }
-    r.v[0] += (uint32_t)f ? C : 0u;
+        for (int i = 1; i < N; ++i) asm("v_addc_co_u32 %0, %1, 0, %0, %1" : "+v"(t[i]), "+s"(cy2));
+        uint32_t top;
+        asm("v_addc_co_u32 %0, %1, 0, 0, %1" : "=v"(top), "+s"(cy2));
+        t[0] += (0u - top) & C;
     }
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = t[i];
 }
 // r = a - b (mod p), weakly reduced (borrow folds back as -c, mirrored reasoning)
 template <class P = CtOps, int N>
 __device__ __forceinline__ void fe_sub(feT<N> &r, const feT<N> &a, const feT<N> &b)
 {
     constexpr uint32_t C = CurveC<N>::C;
-    if constexpr (P::VT) {
-        uint32_t t[N], k;
-        uint64_t bw, bw2;
-        const uint32_t cv = C;
-        asm("v_sub_co_u32 %0, %1, %2, %3" : "=v"(t[0]), "=s"(bw) : "v"(a.v[0]), "v"(b.v[0]));
+    uint32_t t[N], k;
+    uint64_t bw, bw2;
+    const uint32_t cv = C;
+    asm("v_sub_co_u32 %0, %1, %2, %3" : "=v"(t[0]), "=s"(bw) : "v"(a.v[0]), "v"(b.v[0]));
 #pragma unroll
-        for (int i = 1; i < N; ++i)
-            asm("v_subb_co_u32 %0, %1, %2, %3, %1" : "=v"(t[i]), "+s"(bw) : "v"(a.v[i]), "v"(b.v[i]));
-        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(k) : "v"(cv), "s"(bw));            // borrowed from 2^(32N): - c
-        asm("v_sub_co_u32 %0, %1, %2, %3" : "=v"(t[0]), "=s"(bw2) : "v"(t[0]), "v"(k));
-        if (__builtin_expect(bw2 != 0, 0)) {
+    for (int i = 1; i < N; ++i)
+        asm("v_subb_co_u32 %0, %1, %2, %3, %1" : "=v"(t[i]), "+s"(bw) : "v"(a.v[i]), "v"(b.v[i]));
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(k) : "v"(cv), "s"(bw));            // borrowed from 2^(32N): - c
+    asm("v_sub_co_u32 %0, %1, %2, %3" : "=v"(t[0]), "=s"(bw2) : "v"(t[0]), "v"(k));
+    if (!P::VT || __builtin_expect(bw2 != 0, 0)) {                                   // as fe_add
 #pragma unroll
-            for (int i = 1; i < N; ++i) asm("v_subb_co_u32 %0, %1, %0, 0, %1" : "+v"(t[i]), "+s"(bw2));
-            uint32_t top;                                                               // 0 or 0xFFFFFFFF
-            asm("v_subb_co_u32 %0, %1, 0, 0, %1" : "=v"(top), "+s"(bw2));
-            t[0] -= top & C;
-        }
-#pragma unroll
-        for (int i = 0; i < N; ++i) r.v[i] = t[i];
-    } else {
-    uint32_t t[N];
-    uint32_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const uint64_t d = (uint64_t)a.v[i] - b.v[i] - borrow;
-        t[i] = (uint32_t)d; borrow = (uint32_t)(d >> 32) & 1u;
+        for (int i = 1; i < N; ++i) asm("v_subb_co_u32 %0, %1, %0, 0, %1" : "+v"(t[i]), "+s"(bw2));
+        uint32_t top;                                                               // 0 or 0xFFFFFFFF
+        asm("v_subb_co_u32 %0, %1, 0, 0, %1" : "=v"(top), "+s"(bw2));
+        t[0] -= top & C;
     }
-    const uint32_t sub = borrow ? C : 0u;
-    uint32_t bw = 0;
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const uint64_t d = (uint64_t)t[i] - (i == 0 ? sub : 0u) - bw;
-        r.v[i] = (uint32_t)d; bw = (uint32_t)(d >> 32) & 1u;
-    }
-    r.v[0] -= bw ? C : 0u;
-    }
+    for (int i = 0; i < N; ++i) r.v[i] = t[i];
 }
 template <class P = CtOps, int N>
 __device__ __forceinline__ void fe_dbl(feT<N> &r, const feT<N> &a) { fe_add<P>(r, a, a); }
@@ -343,16 +316,23 @@ __device__ __noinline__ feT<N> fe_sqr_call(feT<N> a)
     fe_sqr_body<K, P>(r, a);
     return r;
 }
+// Round 3: the verification kernels of the wider curves inline their multiplications too (BIGN_INLINE_WIDE = 1): the
+// out-of-line calls cost by-value register shuffles and spills -- bign_main_kernel<12> 191 VGPRs + 64 B scratch -> 180 and
+// none, <16> 251 + 80 B -> 240 and none; 2^18 signatures +21 % / +16 % (profiles/r03_verify_wide.txt), and the build takes
+// the same three minutes.  The constant-time (signing) kernels keep the calls.
+#ifndef BIGN_INLINE_WIDE
+#define BIGN_INLINE_WIDE 1
+#endif
 template <uint32_t K = 1, class P = CtOps, int N>
 __device__ __forceinline__ void fe_mul(feT<N> &r, const feT<N> &a, const feT<N> &b)
 {
-    if (N == 8) fe_mul_body<K, P>(r, a, b);
+    if (N == 8 || (BIGN_INLINE_WIDE && P::VT)) fe_mul_body<K, P>(r, a, b);
     else r = fe_mul_call<K, P, N>(a, b);
 }
 template <uint32_t K = 1, class P = CtOps, int N>
 __device__ __forceinline__ void fe_sqr(feT<N> &r, const feT<N> &a)
 {
-    if (N == 8) fe_sqr_body<K, P>(r, a);
+    if (N == 8 || (BIGN_INLINE_WIDE && P::VT)) fe_sqr_body<K, P>(r, a);
     else r = fe_sqr_call<K, P, N>(a);
 }
 
