@@ -1138,10 +1138,33 @@ static err_t bign_scratch(hipStream_t st, size_t n, VerifyScratch &S)
 
 static int g_verify_path = 0, g_verify_lanes = 0;
 void set_verify_path(int v) { g_verify_path = v & 15; g_verify_lanes = v >> 4; }   // 0x43: quads at every size
+static int g_verify_split = 0;                       // 0 = by size, 1 = never, 2 / 3 / 4 = that many parts (A/B)
+void set_verify_split(int v) { g_verify_split = v; }
+
+// EXPERIMENT (round 3, off by default): a big batch as PARTS on separate streams, each part its own prep -> main -> slow ->
+// inv -> tail chain, part p + 1 starting when part p's prep is through, so that the phases that leave the SIMDs half empty
+// -- prep (two wavefronts per SIMD around one serial inversion), inv (512 wavefronts on 1024 SIMDs), tail (LDS-bound) --
+// run beside another part's main kernel instead of alone.  It does not pay (profiles/r03_verify_split.txt).  The parts share the scratch (disjoint index ranges of the same
+// signature-fastest arrays) and the comb table; the caller's stream is forked and joined with events.
+struct AuxStreams {
+    hipStream_t s[3] = {nullptr, nullptr, nullptr};
+    int dev = -1;
+    err_t get()
+    {
+        int cur = 0;
+        B2H_TRY(hipGetDevice(&cur));
+        if (s[0] && cur == dev) return ERR_OK;
+        for (hipStream_t &x : s) { if (x) (void)hipStreamDestroy(x); x = nullptr; }
+        for (hipStream_t &x : s) B2H_TRY(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+        dev = cur;
+        return ERR_OK;
+    }
+};
+static thread_local AuxStreams t_aux;
 
 template <int N>
-static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const void *d_hashes,
-                                  const void *d_sigs, const void *d_pubkeys, size_t n, void *d_codes,
+static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const void *d_hashes_all,
+                                  const void *d_sigs_all, const void *d_pubkeys_all, size_t n, void *d_codes_all,
                                   hipStream_t st)
 {
     uint4 *gtab = nullptr;
@@ -1151,14 +1174,26 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
         code = bign_table<N>(&gtab, st);
     }
     if (code != ERR_OK) return code;
-    VerifyScratch S;
-    code = bign_scratch<N>(st, n, S);
+    VerifyScratch S_all;
+    code = bign_scratch<N>(st, n, S_all);
     if (code != ERR_OK) return code;
     OidArg oid;
     code = make_oid_arg(oid, oid_der, oid_len, st);
     if (code != ERR_OK) return code;
+    const size_t n_total = n;
+    constexpr size_t NO_ = 4 * N;
+    // one chain over the signatures [off, off + cnt) on stream `st`; ev_prep (may be null) is recorded behind the prep kernel
+    const auto run_range = [&, gtab, oid](size_t off, size_t cnt, hipStream_t st, hipEvent_t ev_prep) -> err_t {
+    VerifyScratch S = S_all;
+    S.status += off; S.u += off; S.w += off; S.qtab += off; S.qz += off; S.rx += off;
+    const size_t n = cnt;
+    const uint8_t *d_hashes = (const uint8_t *)d_hashes_all + NO_ * off;
+    const uint8_t *d_sigs = (const uint8_t *)d_sigs_all + (NO_ + NO_ / 2) * off;
+    const uint8_t *d_pubkeys = (const uint8_t *)d_pubkeys_all + 2 * NO_ * off;
+    uint32_t *d_codes = (uint32_t *)d_codes_all + off;
+    err_t code = ERR_OK;
     const unsigned g256 = (unsigned)((n + 255) / 256), g64 = (unsigned)((n + 63) / 64);
-    const size_t sp = n >= ((size_t)1 << 18) ? 2 : 1;     // signatures per lane in prep (shared inversion)
+    const size_t sp = n_total >= ((size_t)1 << 18) ? 2 : 1;     // signatures per lane in prep (shared inversion)
     const size_t plan = (n + sp - 1) / sp;
     // Which kernels walk the scalar multiplication (g_verify_path: 0 by size, 1 always the 32-bit
     // kernels, 2 the 29-bit main kernel, 3 the quad / pair kernel, + 16 x lanes to force quads (0x43), pairs (0x23) or quads with a helper quad (0x83; 0x93 / 0xA3 with 64 / 256 lanes per block)
@@ -1209,6 +1244,7 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
         hipLaunchKernelGGL(bign_prep_kernel<N>, dim3((unsigned)((plan + 255) / 256)), dim3(256), 0, st,
                            (const uint8_t *)d_hashes, (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, plan,
                            (int)sp, S);
+        if (ev_prep) B2H_TRY(hipEventRecord(ev_prep, st));
         if constexpr (N == 8) {
             if (path == 2) {
                 const unsigned wg = n <= ((size_t)1 << 14) ? 64u : 256u;
@@ -1247,6 +1283,45 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
                            (const uint8_t *)d_sigs, n, S, oid, (uint32_t *)d_codes);
     }
     B2H_TRY(hipGetLastError());
+    return ERR_OK;
+    };   // run_range
+
+    // parts: only the one-lane throughput kernels of a big batch
+    size_t parts = 1;
+    {
+        const bool one_lane = N == 8 ? (g_verify_path == 1 || (g_verify_path == 0 && n_total > ((size_t)1 << 16)))
+                                     : (g_verify_path == 1 || (g_verify_path == 0 && n_total > ((size_t)1 << 15)));
+        // measured (profiles/r03_verify_split.txt): no gain -- 2 parts -1.5 % at 2^18, +-0 at 2^19 / 2^20, 3-4 parts -5..-30 %; the
+        // default is therefore ONE part, and the parts stay reachable through bee2hip_internal_tune(8, parts) for the record
+        if (one_lane) parts = g_verify_split >= 2 ? (size_t)g_verify_split : 1;
+        if (parts > 4) parts = 4;
+        if (n_total < parts * 4096) parts = 1;
+    }
+    if (parts == 1) return run_range(0, n_total, st, nullptr);
+    code = t_aux.get();
+    if (code != ERR_OK) return code;
+    hipEvent_t ev[9];                               // fork, prep done x 4, join x 4
+    for (hipEvent_t &e : ev) e = nullptr;
+    const auto cleanup = [&]() { for (hipEvent_t &e : ev) if (e) (void)hipEventDestroy(e); };
+    for (size_t i = 0; i < 1 + 2 * parts; ++i)
+        if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { cleanup(); return hip_fail(hipGetLastError(), "hipEventCreate"); }
+    const size_t per = ((n_total / parts + 255) / 256) * 256;
+    hipError_t he = hipEventRecord(ev[0], st);       // everything queued so far (inputs, the OID prefix) is before the fork
+    for (size_t p = 0; p < parts && he == hipSuccess && code == ERR_OK; ++p) {
+        const size_t off = p * per, cnt = p + 1 == parts ? n_total - off : per;
+        const hipStream_t sp_ = p == 0 ? st : t_aux.s[p - 1];
+        if (p) {
+            he = hipStreamWaitEvent(sp_, ev[0], 0);
+            if (he == hipSuccess) he = hipStreamWaitEvent(sp_, ev[p], 0);          // the previous part's prep is through
+            if (he != hipSuccess) break;
+        }
+        code = run_range(off, cnt, sp_, ev[1 + p]);
+        if (code == ERR_OK && p) he = hipEventRecord(ev[1 + parts + p], sp_);
+    }
+    for (size_t p = 1; p < parts && he == hipSuccess && code == ERR_OK; ++p) he = hipStreamWaitEvent(st, ev[1 + parts + p], 0);
+    cleanup();                                      // destroying a pending event is allowed: it is released when it completes
+    if (code != ERR_OK) return code;
+    if (he != hipSuccess) return hip_fail(he, "verify parts");
     return ERR_OK;
 }
 

@@ -1415,7 +1415,7 @@ extern "C" err_t bee2hip_bashHash_beltMAC_batch(const octet *msgs, size_t msg_le
 
 // ============================================================ internal tuning hook ===
 // A/B switch for experiment builds (tools/bashf_ab.py); not part of the product ABI (BEE2HIP_INTERNAL).
-namespace bee2hip { void set_bashF_variant(int v); void set_ctr_variant(int v); void set_verify_path(int v); }
+namespace bee2hip { void set_bashF_variant(int v); void set_ctr_variant(int v); void set_verify_path(int v); void set_verify_split(int v); }
 extern "C" err_t bee2hip_internal_tune(int key, int value)
 {
     switch (key) {
@@ -1425,6 +1425,7 @@ extern "C" err_t bee2hip_internal_tune(int key, int value)
     case 3: bee2hip::g_pinned_limit = value < 0 ? 0 : (size_t)value > bee2hip::PINNED_MAX ? bee2hip::PINNED_MAX : (size_t)value; return ERR_OK;
     case 4: bee2hip::g_force.store(value == 1 ? bee2hip::FORCE_GPU : value == 2 ? bee2hip::FORCE_CPU : bee2hip::FORCE_AUTO); return ERR_OK;   // as BEE2HIP_FORCE
     case 5: bee2hip::g_inject_fail.store(value); return ERR_OK;       // tests: the next `value` GPU attempts of drop-in helpers fail
+    case 8: bee2hip::set_verify_split(value); return ERR_OK;          // parts of a big verification batch (0 by size, 1 never, 2..4)
     case 6: bee2hip::g_duplex_log2_states = value; return ERR_OK;     // chunk of the duplex host pipeline, bashF states (log2)
     case 7: bee2hip::g_duplex_log2_blocks = value; return ERR_OK;     //                                   belt blocks (log2)
     default: return ERR_BAD_INPUT;
