@@ -375,6 +375,59 @@ __device__ __forceinline__ void belt_encr_n(const Tab &T, uint32_t (&x)[N][4], c
     for (int u = 0; u < N; ++u) { x[u][0] = b[u]; x[u][1] = d[u]; x[u][2] = a[u]; x[u][3] = c[u]; }
 }
 
+// E_K for a COUNTER stream.  Words 2 and 3 of the block (bits 64..127 of the counter) are the same for every block of a
+// launch unless the low 64 bits wrap inside it, so the second G-box of round 1 -- c ^= G21(d + k_2) -- does not depend on
+// the block: pre_c = c ^ G21(d + k_2) is computed once per thread and 55 G-boxes per block are left of 56 (round 3,
+// profiles/r03_belt_mem_ab.txt).  The caller guarantees the precondition (launch_ctr_t checks the range on the host).
+template <int N, class Tab>
+__device__ __forceinline__ void belt_encr_n_ctr(const Tab &T, uint32_t (&x)[N][4], const uint32_t (&K)[8], uint32_t pre_c)
+{
+    uint32_t a[N], b[N], c[N], d[N];
+    GParts g[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) { a[u] = x[u][0]; b[u] = x[u][1]; c[u] = pre_c; d[u] = x[u][3]; }
+    {   // round 1, steps 1 and 3..7 (belt_round_n<N, 1> without its second G-box)
+        constexpr int I = 1;
+#pragma unroll
+        for (int u = 0; u < N; ++u) g[u] = gbox<0, 0, I>(T, a[u] + K[0], 0);
+#pragma unroll
+        for (int u = 0; u < N; ++u) b[u] = xor3(b[u], g[u].p, g[u].q);
+#pragma unroll
+        for (int u = 0; u < N; ++u) g[u] = gbox<1, 2, I>(T, b[u] + K[2], 0);
+#pragma unroll
+        for (int u = 0; u < N; ++u) a[u] -= g[u].p ^ g[u].q;
+#pragma unroll
+        for (int u = 0; u < N; ++u) g[u] = gbox<2, 3, I>(T, b[u] + c[u] + K[3], 0);
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            const uint32_t e = xor3(g[u].p, g[u].q, (uint32_t)I);
+            b[u] += e;
+            c[u] -= e;
+        }
+#pragma unroll
+        for (int u = 0; u < N; ++u) g[u] = gbox<1, 4, I>(T, c[u] + K[4], 0);
+#pragma unroll
+        for (int u = 0; u < N; ++u) d[u] += g[u].p ^ g[u].q;
+#pragma unroll
+        for (int u = 0; u < N; ++u) g[u] = gbox<2, 5, I>(T, a[u] + K[5], 0);
+#pragma unroll
+        for (int u = 0; u < N; ++u) b[u] = xor3(b[u], g[u].p, g[u].q);
+#pragma unroll
+        for (int u = 0; u < N; ++u) g[u] = gbox<0, 6, I>(T, d[u] + K[6], 0);
+#pragma unroll
+        for (int u = 0; u < N; ++u) c[u] = xor3(c[u], g[u].p, g[u].q);
+    }
+    belt_round_n<N, 2>(T, b, d, a, c, K);
+    belt_round_n<N, 3>(T, d, c, b, a, K);
+    belt_round_n<N, 4>(T, c, a, d, b, K);
+    belt_round_n<N, 5>(T, a, b, c, d, K);
+    belt_round_n<N, 6>(T, b, d, a, c, K);
+    belt_round_n<N, 7>(T, d, c, b, a, K);
+    belt_round_n<N, 8>(T, c, a, d, b, K);
+#pragma unroll
+    for (int u = 0; u < N; ++u) { x[u][0] = b[u]; x[u][1] = d[u]; x[u][2] = a[u]; x[u][3] = c[u]; }
+}
+
 // sigma1/sigma2 of belt-compress (src/crypto/belt/belt_compr.c:27-87):
 //   s1 = E_X(h0 ^ h1) ^ h0 ^ h1 ; h0' = E_{s1 || h1}(X0) ^ X0 ; h1' = E_{~s1 || h0}(X1) ^ X1
 template <class Tab>

@@ -59,6 +59,8 @@ __device__ __forceinline__ void ctr_at(uint32_t (&x)[4], const BeltCtr &c0, uint
 // Tab / ILP are template parameters so that the round-2 A/B (profiles/r02_belt_variants.txt)
 // runs the very same body: the product is <CtrTab, CTR_ILP>; the others are reachable only through
 // bee2hip_internal_tune(1, v).
+// MEM bit 2 (round 3): the counter's upper half does not change inside the launch (checked by launch_ctr_t): the second
+// G-box of round 1 is hoisted out of the block loop (belt_encr_n_ctr).
 // MEM (round-3 A/B; profiles/r03_belt_mem_ab.txt): bit 0 = non-temporal loads and stores of the
 // stream (read once, written once), bit 1 = every workgroup walks ONE contiguous range of tiles instead of taking every
 // gridDim-th tile (a new 2 MiB page per tile and workgroup).
@@ -77,6 +79,13 @@ void beltCTR_blocks_kernel(uint4 *__restrict__ buf, size_t nblocks, BeltKey key,
     for (int i = 0; i < 8; ++i) K[i] = key.k[i];
 
     // tile = CTR_WG * ILP consecutive blocks; tiles are dealt round-robin to workgroups
+    uint32_t pre_c = 0;
+    if constexpr ((MEM & 4) != 0) {
+        uint32_t x0[4];
+        ctr_at(x0, ctr0, first + 1);
+        const GParts g0 = T.template g<2>(x0[3] + K[1]);
+        pre_c = xor3(x0[2], g0.p, g0.q);
+    }
     const size_t tile = (size_t)CTR_WG * ILP;
     const size_t ntiles = (nblocks + tile - 1) / tile;
     const size_t per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
@@ -94,7 +103,8 @@ void beltCTR_blocks_kernel(uint4 *__restrict__ buf, size_t nblocks, BeltKey key,
             if (live[u]) data[u] = (MEM & 1) ? nt_load16(&buf[i]) : buf[i];
             ctr_at(g[u], ctr0, first + i + 1);
         }
-        belt_encr_n<ILP>(T, g, K);
+        if constexpr ((MEM & 4) != 0) belt_encr_n_ctr<ILP>(T, g, K, pre_c);
+        else belt_encr_n<ILP>(T, g, K);
 #pragma unroll
         for (int u = 0; u < ILP; ++u) {
             const size_t i = t0 + (size_t)u * CTR_WG + threadIdx.x;
@@ -699,8 +709,17 @@ err_t launch_belt_ctr_blocks(void *d_buf, size_t nblocks, const uint32_t key[8],
     case 11: return launch_ctr_t<BeltTabHyb<0x55>, 1>(d_buf, nblocks, k, c, first, d_last_gamma, st);   // 16
     case 12: return launch_ctr_t<BeltTabHyb<0x11>, 1>(d_buf, nblocks, k, c, first, d_last_gamma, st);   // 8
     case 13: return launch_ctr_t<CtrTab, CTR_ILP, 0>(d_buf, nblocks, k, c, first, d_last_gamma, st);   // the round-2 product
+    case 14: return launch_ctr_t<CtrTab, CTR_ILP, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);   // round 3 without the hoisted G-box
     // product (round 3): contiguous tile ranges + non-temporal stream accesses, +1 % (profiles/r03_belt_mem_ab.txt)
-    default: return launch_ctr_t<CtrTab, CTR_ILP, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    default: {
+        // block i uses ctr0 + ((first + 1 + i) mod 2^64): the upper 64 bits of that sum stay put over the launch unless the
+        // lower 64 bits wrap inside it or the 64-bit offset itself does (then the carry into the upper half goes away again)
+        const uint64_t lo = ((uint64_t)c.c[1] << 32) | c.c[0];
+        const uint64_t a0 = first + 1, a1 = a0 + (nblocks - 1);
+        const uint64_t s0 = lo + a0, e0 = s0 + (nblocks - 1);
+        if (e0 >= s0 && a1 >= a0) return launch_ctr_t<CtrTab, CTR_ILP, 7>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+        return launch_ctr_t<CtrTab, CTR_ILP, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    }
     }
 }
 

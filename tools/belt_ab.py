@@ -14,7 +14,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import bee2_amd  # noqa: E402
 import orclib  # noqa: E402
 
-NAMES = {0: "product (round 3): two-table 64 KiB, 1 block/lane, contiguous tile ranges + non-temporal accesses",
+NAMES = {0: "product (round 3): two-table 64 KiB, 1 block/lane, contiguous ranges, nt accesses, round-1 G-box of (c, d) hoisted",
+         14: "round 3 without the hoisted round-1 G-box (56 G-boxes per block)",
          13: "round-2 product: two-table 64 KiB, 1 block/lane, tiles dealt round-robin, plain loads/stores",
          1: "two-table, 2 blocks/lane, 8 w/SIMD (45 VGPRs) = the r01 product",
          2: "two-table, 3 blocks/lane, 8 w/SIMD (64 VGPRs, 2 spills)",
