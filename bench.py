@@ -38,7 +38,7 @@ from bee2_amd import shard  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BASHF_BYTES = 384                # algorithmic bytes per permutation (192 read + 192 written)
 CTR_BYTES_PER_BLOCK = 32         # 16 read + 16 written per 16-byte block
-LDS_CTR_CEIL_GIBPS = 256 * 2.17e9 / 7 * 16 / 2 ** 30   # 224 ds_read_b32 per block = 7 LDS clocks per block per CU
+LDS_CTR_CEIL_GIBPS = 256 * 2.17e9 / (220 * 2 / 64) * 16 / 2 ** 30   # 220 ds_read_b32 per block (round 3: 55 G-boxes) = 6.875 LDS clocks per block per CU
 MADS_PER_VERIFY = 976 * 72 + 685 * 52 + 3000   # v_mad_u64_u32 per signature: affine table, shared inversion
 MAD_PEAK_T = 30.0                # measured: 256 CU x 4 SIMD x 64 lanes x 2.31 GHz / 5.05 cycles
 
@@ -48,7 +48,7 @@ MAD_PEAK_T = 30.0                # measured: 256 CU x 4 SIMD x 64 lanes x 2.31 G
 # 80 % of that.  Per-unit instruction counts are the ISA's (hipcc -S), not estimates.
 SIMD_CYCLES_PER_S = 1024 * 2.4e9
 BASHF_VALU = {"full_rate": 4 * 684, "half_rate": 4 * 384}          # per permutation-wavefront (24 rounds)
-CTR_VALU = {"full_rate": 695, "half_rate": 19, "ds_read_b32": 224}  # per block-wavefront
+CTR_VALU = {"full_rate": 681, "half_rate": 18, "ds_read_b32": 220}  # per block-wavefront (loop body of beltCTR_blocks_kernel<BeltTabTwo, 1, 7>, llvm-objdump)
 
 
 def valu_picture(units_per_s, mix, lanes=64):
@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--only", default="", help="comma list of {bashF,ctr,verify,sign,mixed,modes,ragged,dwp,latency}; default all")
     ap.add_argument("--ctr-gib", type=float, default=16.0)
+    ap.add_argument("--headline-only", action="store_true",
+                    help="bashF: only the 2^20-state launches (no 2^22 leg, no host-pointer leg) -- what tools/profile_round.sh "
+                         "profiles, so that rocprofv3's per-kernel averages are over launches of ONE size")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="ranks only form the process group, reduce one number and rank 0 prints the line's launch fields "
                          "(no GPU work; tests/test_bench_launch.py runs this on CPU with BEE2_BENCH_BACKEND=gloo)")
@@ -204,14 +207,16 @@ def pmc_traffic(kernel_substr):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc summary of this round (separate FETCH_SIZE /
     WRITE_SIZE passes, FETCH_SIZE doubled for wide coalesced reads as MI355X_MICROARCH.md prescribes): a replay of
     that profiling run, labelled as such -- counters cannot be collected inside an un-profiled bench run."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-    if not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_summary.json")))
+    if not found:
         return None, None
+    path = found[-1]                                       # the newest round's counters
     try:
         d = json.load(open(path))
         for k, v in d.get("kernels", {}).items():
             if kernel_substr in k and "hbm_bytes_per_launch" in v:
-                return v["hbm_bytes_per_launch"], f"profiles/r02_pmc_summary.json @ {d.get('commit', '?')} ({v.get('note', 'rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE')})"
+                return v["hbm_bytes_per_launch"], f"profiles/{os.path.basename(path)} @ {d.get('commit', '?')} ({v.get('note', 'rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE')})"
     except Exception:
         pass
     return None, None
@@ -413,15 +418,16 @@ def main():
             result["roofline"]["shader_clock_note"] = repr(e)
         # the same kernel on a batch that cannot sit in the 256 MiB Infinity Cache: 2^22 states = 768 MiB read + written
         # per launch; reported as flat keys next to the cache-resident headline
-        n22 = 1 << 22
-        st22 = torch.empty(192 * n22, dtype=torch.uint8, device="cuda")
-        fill_seeded(st22, 0xBA5F + 0x22 + dist.rank)
-        timed(dist, max(3, min(K, 20)), 2, lambda: eng.bashF_batch_dev(st22))
-        ms22 = timed.event_ms
-        result["roofline"]["ms_2p22"] = ms22
-        result["roofline"]["frac_2p22"] = BASHF_BYTES * n22 / (ms22 * 1e-3) / 1e9 / HBM_PEAK_GBS
-        del st22
-        if dist.rank == 0 and N == 1:       # PCIe-inclusive rate: single-GPU runs only
+        if not args.headline_only:
+            n22 = 1 << 22
+            st22 = torch.empty(192 * n22, dtype=torch.uint8, device="cuda")
+            fill_seeded(st22, 0xBA5F + 0x22 + dist.rank)
+            timed(dist, max(3, min(K, 20)), 2, lambda: eng.bashF_batch_dev(st22))
+            ms22 = timed.event_ms
+            result["roofline"]["ms_2p22"] = ms22
+            result["roofline"]["frac_2p22"] = BASHF_BYTES * n22 / (ms22 * 1e-3) / 1e9 / HBM_PEAK_GBS
+            del st22
+        if dist.rank == 0 and N == 1 and not args.headline_only:       # PCIe-inclusive rate: single-GPU runs only
             host = st.cpu().numpy()                               # pageable host copy of the same batch
             hp = ctypes.c_void_p(host.ctypes.data)
             v, ms = host_api_rate(lambda: eng._check(eng.lib.bee2hip_bashF_batch(hp, ctypes.c_size_t(n)), "bashF_batch"), n)
@@ -454,11 +460,12 @@ def main():
             "roofline": {"kernel": "beltCTR_blocks_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": ctr_traffic, "traffic_source": ctr_traffic_src,
                          "avg_launch_ms": ms_launch,
-                         "note": "VALU/LDS-issue bound, not HBM: per block ~695 VALU ops (floor 930 GiB/s) and "
-                                 "224 ds_read_b32 (floor 1146 GiB/s), DESIGN.md 2 and 4.2",
+                         "note": "VALU/LDS-issue bound, not HBM: per block ~700 VALU ops (VALU-only build 930 GiB/s) and "
+                                 "220 ds_read_b32 (LDS-only build 1146 GiB/s), 10.0 CU-cycles per block at every stream size "
+                                 "(profiles/r03_belt_mem_ab.txt), DESIGN.md 2 and 4.2",
                          "valu": valu_picture(nb / (ms_launch * 1e-3), CTR_VALU)},
         }
-        if dist.rank == 0 and N == 1:       # PCIe-inclusive rate: single-GPU runs only
+        if dist.rank == 0 and N == 1 and not args.headline_only:       # PCIe-inclusive rate: single-GPU runs only
             hn = 1 << 30                                          # 1 GiB through the drop-in one-shot beltCTR
             host = np.zeros(hn, dtype=np.uint8)
             hp = ctypes.c_void_p(host.ctypes.data)

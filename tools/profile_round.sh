@@ -10,9 +10,9 @@ CMD="python bench.py --steps 20 --warmup 3 --no-cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
 # the headline workload alone: the full run also launches the bashF kernel on single states (drop-in latency leg, sponge
 # finalisation), which would pull the per-kernel average away from the batch launches the roofline is about
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bashF -o bench -- $CMD --only bashF > $OUT/stats_bashF.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bashF -o bench -- $CMD --only bashF --headline-only > $OUT/stats_bashF.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- $CMD --only bashF,ctr,verify --ctr-gib 4 > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- $CMD --only bashF,ctr,verify --ctr-gib 4 --headline-only > $OUT/pmc_$c.log 2>&1
 done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $OUT/pmc_sq1 -o bench -- $CMD --ctr-gib 4 > $OUT/pmc_sq1.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq2 -o bench -- $CMD --ctr-gib 4 > $OUT/pmc_sq2.log 2>&1
