@@ -39,7 +39,10 @@
 //   tail : belt-hash(oid || x_R || H) == s0 ? (bign_sign.c:337-343)
 // HBM traffic is irrelevant here (148 B of input per ~5e5 VALU ops at l = 128): the bound is
 // the integer multiplier rate.
+#include <algorithm>
 #include <mutex>
+#include <utility>
+#include <vector>
 #include "belt_dev.hpp"
 #include "bign_dev.hpp"
 #include "bign_fe29.hpp"
@@ -1212,9 +1215,16 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
         const auto launch = [&](auto kern, unsigned wg, unsigned lanes) -> err_t {
             const unsigned ns = wg / lanes;
             const size_t lds = (size_t)8 * 4 * LZ<N>::L * ns * 4;
-            if (lds > 48 * 1024)
-                B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (lds > 48 * 1024) {               // once per (device, kernel), not per launch
+                static std::mutex attr_mu;
+                static std::vector<std::pair<int, const void *>> attr_done;
+                const std::pair<int, const void *> key(cur_dev(), reinterpret_cast<const void *>(kern));
+                std::lock_guard<std::mutex> lk(attr_mu);
+                if (std::find(attr_done.begin(), attr_done.end(), key) == attr_done.end()) {
+                    B2H_TRY(hipFuncSetAttribute(key.second, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    attr_done.push_back(key);
+                }
+            }
             hipLaunchKernelGGL(kern, dim3((unsigned)((n + ns - 1) / ns)), dim3(wg), lds, st, (const uint8_t *)d_hashes,
                                (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S, (const uint4 *)gtab);
             return ERR_OK;

@@ -11,6 +11,9 @@
 // the sharding, the threads and the state hand-over can then be exercised on a one-GPU box
 // (tests/test_gpu_multi.py); bee2hip_multi_plan is the pure index arithmetic, callable without a GPU
 // (tests/test_multi_plan.py runs it against the oracle).
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "common.hpp"
@@ -43,7 +46,55 @@ extern "C" int bee2hip_device_count(void)
 }
 
 namespace {
-// run job(i, parts) on logical device i = 0 .. parts-1, each in its own thread bound to real device i % real
+// Worker pool: ONE persistent thread per logical device, created on first use and kept for the life of the process
+// (fresh std::threads per call threw their per-thread staging -- pinned blocks, device scratch, the NULL-stream
+// pool -- away at every return and paid device-synchronising frees for it).  A worker binds its device once; its
+// thread-local staging therefore survives between calls.  Calls from several host threads take turns (one batch over
+// all devices at a time).  The pool is never destroyed: the workers sleep on a condition variable until process exit.
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<err_t()> job;          // set by the dispatcher, cleared by the worker
+    bool has_job = false, done = false;
+    err_t code = ERR_OK;
+    int device = -1;                     // real device this worker is bound to
+};
+struct Pool {
+    std::mutex call_mu;                  // one multi-device batch at a time
+    std::vector<Worker *> w;
+    Worker *get(size_t i, int real_dev)
+    {
+        while (w.size() <= i) w.push_back(nullptr);
+        if (w[i] && w[i]->device == real_dev) return w[i];
+        // (a worker bound to another device -- the visible device set changed: BEE2HIP_FAKE_DEVICES in tests -- is left idle)
+        Worker *k = new Worker;
+        k->device = real_dev;
+        k->th = std::thread([k, real_dev] {
+            const err_t bind = bee2hip_set_device(real_dev);
+            for (;;) {
+                std::unique_lock<std::mutex> lk(k->mu);
+                k->cv.wait(lk, [k] { return k->has_job; });
+                std::function<err_t()> f = std::move(k->job);
+                lk.unlock();
+                const err_t c = bind != ERR_OK ? bind : f();
+                lk.lock();
+                k->code = c; k->has_job = false; k->done = true;
+                k->cv.notify_all();
+            }
+        });
+        k->th.detach();
+        w[i] = k;
+        return k;
+    }
+};
+Pool &pool()
+{
+    static Pool *p = new Pool;           // leaked on purpose: no join at exit
+    return *p;
+}
+
+// run job(i, parts) on logical device i = 0 .. parts-1, each on its pool worker bound to real device i % real
 template <class F>
 err_t run_on_devices(int ndev, F job)
 {
@@ -51,21 +102,24 @@ err_t run_on_devices(int ndev, F job)
     if (real <= 0) return hip_fail(hipErrorNoDevice, "hipGetDeviceCount");
     int parts = ndev > 0 ? ndev : bee2hip_device_count();
     if (parts <= 0) return ERR_BAD_INPUT;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
-    std::vector<err_t> codes((size_t)parts, ERR_OK);
-    std::vector<std::thread> th;
-    th.reserve((size_t)parts);
-    for (int i = 0; i < parts; ++i)
-        th.emplace_back([&, i]() {
-            err_t c = bee2hip_set_device(i % real);
-            if (c == ERR_OK) c = job(i, parts);
-            codes[(size_t)i] = c;
-        });
-    for (auto &t : th) t.join();
-    (void)hipSetDevice(prev);
-    for (err_t c : codes) if (c != ERR_OK) return c;
-    return ERR_OK;
+    Pool &P = pool();
+    std::lock_guard<std::mutex> call(P.call_mu);
+    std::vector<Worker *> ws((size_t)parts);
+    for (int i = 0; i < parts; ++i) {
+        Worker *k = ws[(size_t)i] = P.get((size_t)i, i % real);
+        std::lock_guard<std::mutex> lk(k->mu);
+        k->job = [job, i, parts]() -> err_t { return job(i, parts); };
+        k->done = false;
+        k->has_job = true;
+        k->cv.notify_all();
+    }
+    err_t first_bad = ERR_OK;
+    for (Worker *k : ws) {
+        std::unique_lock<std::mutex> lk(k->mu);
+        k->cv.wait(lk, [k] { return k->done; });
+        if (k->code != ERR_OK && first_bad == ERR_OK) first_bad = k->code;
+    }
+    return first_bad;
 }
 }  // namespace
 
