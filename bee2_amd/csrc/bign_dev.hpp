@@ -200,10 +200,22 @@ __device__ __forceinline__ void fe_reduce(feT<N> &r, const uint32_t (&w)[2 * N])
     uint64_t c = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        // c < 2^46 always: K*C*(2^32-1) + K*(2^32-1) + c fits easily in 64 bits
-        uint64_t s = (uint64_t)w[N + i] * (K * C) + c;
-        if (K == 1) s += w[i];
-        else s += (uint64_t)w[i] * K;
+        // s = w[N+i] * (K C) + w[i] * K + c as TWO multiply-adds into one 64-bit accumulator (c < 2^14, so nothing overflows).
+        // Left to the compiler, "w[i] * K" became v_lshlrev_b64 + two v_and + v_lshl_add_u64 for K = 2, 4, 8 and "+ w[i]" a
+        // zero-extension plus v_lshl_add_u64 for K = 1 (13 / 7 issue cycles per limb where the multiplier needs 5).
+        if constexpr (N > 12 || !P::VT) {   // 512-bit curve and the signing kernels: the compiler's form is 1.5 % faster there (register pressure)
+            uint64_t s0 = (uint64_t)w[N + i] * (K * C) + c;
+            if (K == 1) s0 += w[i];
+            else s0 += (uint64_t)w[i] * K;
+            t[i] = (uint32_t)s0; c = s0 >> 32;
+            continue;
+        }
+        uint64_t s, unused;
+        const uint32_t kc = K * C;
+        // (the carry is a SOURCE pair of the first multiply-add, not its destination: (hi(s), 0) then costs one v_mov, the zero
+        // register being shared; as "+v" the compiler copied the pair first, v_mov_b32 + v_mov_b64 per limb)
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(s), "=s"(unused) : "v"(w[N + i]), "s"(kc), "v"(c));
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(s), "=s"(unused) : "v"(w[i]), "n"(K));
         t[i] = (uint32_t)s; c = s >> 32;
     }
     // fold the top (c <= K*(C+1) < 2^14, so c*C < 2^24) once more, then the at-most-one final carry.
