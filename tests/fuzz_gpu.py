@@ -340,8 +340,72 @@ def f_multi(rnd):
         os.environ.pop("BEE2HIP_FAKE_DEVICES", None)
 
 
+def f_sign_generic(rnd):
+    """round 3: the signing side on a non-standard parameter set (isomorphic images of the standard curves: q is the group
+    order).  Checker: the Python restatement of bignVerify (tests/orc_generic.py) must accept every signature the library
+    makes, the library must verify them itself, and the public key must come out of bignPubkeyVal as valid; refused private
+    keys keep their codes.  Long OIDs (up to ~600 octets) ride along on this family and on the standard curves (oracle)."""
+    global _generic
+    import json
+    import orc_generic as OG
+    from bee2_amd import engine as E
+    from bee2_amd.engine import bign_params
+    if _generic is None:
+        _generic = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bign_generic.json")))
+    iso = [i for i, c in enumerate(_generic["curves"]) if c["kind"] == "iso" and c["l"] <= 192]
+    c = _generic["curves"][rnd.choice(iso)]
+    prm = bign_params()
+    prm.l = c["l"]
+    for f in ("p", "a", "b", "q", "yG"):
+        raw = bytes.fromhex(c[f])
+        ctypes.memmove(getattr(prm, f), raw + bytes(64 - len(raw)), 64)
+    P = OG.Params.from_hex(c)
+    l, no = c["l"], c["l"] // 4
+    q = int.from_bytes(bytes.fromhex(c["q"]), "little")
+    total = rnd.choice((11, 40, 129, 131, 160, 161, 200, 257, 258, 300, 600))
+    hdr = 2 if total <= 129 else 3 if total <= 258 else 4
+    body = total - hdr
+    if (hdr == 2 and body >= 128) or (hdr == 3 and not 128 <= body < 256) or (hdr == 4 and body < 256):
+        total, hdr, body = 11, 2, 9
+    oid = (bytes([0x06, body]) if hdr == 2 else bytes([0x06, 0x81, body]) if hdr == 3 else bytes([0x06, 0x82, body >> 8, body & 255])) + \
+        bytes([0x2A] + [rnd.randrange(1, 128) for _ in range(body - 1)])
+    n = rnd.randrange(1, 6)
+    privs = [rnd.randrange(1, q).to_bytes(no, "little") for _ in range(n)]
+    bad = rnd.randrange(n) if rnd.randrange(3) == 0 else -1
+    if bad >= 0:
+        privs[bad] = rnd.choice((0, q, (1 << (8 * no)) - 1)).to_bytes(no, "little")
+    hs = [rnd.randbytes(no) for _ in range(n)]
+    t = rnd.choice((None, rnd.randbytes(rnd.randrange(1, 65)), rnd.randbytes(rnd.randrange(65, 150))))
+    code, sigs, sc = eng.bignSign2_batch(prm, oid, b"".join(hs), b"".join(privs), t)
+    if code:
+        return False
+    sg = no + no // 2
+    for i in range(n):
+        if i == bad:
+            if sc[i] != 504:
+                return False
+            continue
+        if sc[i] != 0:
+            return False
+        pc, pub = eng.bignPubkeyCalc(prm, privs[i])
+        s_i = sigs[sg * i: sg * (i + 1)]
+        if pc != 0 or eng.bignPubkeyVal(prm, pub) != 0 or OG.pubkey_val(P, pub) != 0:
+            return False
+        if OG.verify(P, oid, hs[i], s_i, pub, orc.belt_hash) != 0 or eng.bignVerify(prm, oid, hs[i], s_i, pub) != 0:
+            return False
+    # the same OID on the standard curve of the level: the C oracle reproduces the deterministic signature
+    Ps = eng.bignParamsStd(E.CURVE_NAME[l])
+    qs = int.from_bytes(bytes(Ps.q)[:no], "little")
+    d = rnd.randrange(1, qs).to_bytes(no, "little")
+    code, sig = eng.bignSign2(Ps, oid, hs[0], d, t)
+    w = orc.sign2(l, oid, hs[0], d, t)
+    if code != w[0] or (code == 0 and sig != w[1]):
+        return False
+    return code != 0 or eng.bignVerify(Ps, oid, hs[0], sig, eng.bignPubkeyCalc(Ps, d)[1]) == orc.verify_l(l, oid, hs[0], sig, orc.pubkey_calc(l, d)[1]) == 0
+
+
 FAMILIES = [("bashF", f_bashF), ("beltCTR", f_ctr), ("mac/hash", f_mac_hash), ("modes", f_modes), ("dwp/che", f_aead),
-            ("verify", f_verify), ("ragged/mixed", f_ragged_mixed), ("sign", f_sign), ("multi", f_multi)]
+            ("verify", f_verify), ("ragged/mixed", f_ragged_mixed), ("sign", f_sign), ("multi", f_multi), ("sign-generic", f_sign_generic)]
 
 
 def main(seconds, seed):

@@ -42,3 +42,24 @@ for _ in range(2):
     eng.bignPubkeyCalcL_batch_dev(l, privs, pubs, codes)
 torch.cuda.synchronize()
 assert int(codes.abs().sum()) == 0
+
+# round 3: the signing side on a NON-STANDARD parameter set (general-curve constant-time ladder, bign_generic_kernels.hip):
+# the same key classes through the host batch entry points on an isomorphic image of the level's standard curve
+import ctypes  # noqa: E402
+import json  # noqa: E402
+from bee2_amd.engine import bign_params  # noqa: E402
+FIX = json.load(open(os.path.join(ROOT, "tests", "golden", "bign_generic.json")))
+c = next(x for x in FIX["curves"] if x["kind"] == "iso" and x["l"] == l)
+prm = bign_params()
+prm.l = l
+for f in ("p", "a", "b", "q", "yG"):
+    raw = bytes.fromhex(c[f])
+    ctypes.memmove(getattr(prm, f), raw + bytes(64 - len(raw)), 64)
+m = 512
+gp = b"".join(d.to_bytes(no, "little") for d in ds[:m])
+gh = orc.fill(no * m, 0xC7)
+for _ in range(2):
+    code, gs, gc = eng.bignSign2_batch(prm, E.LEVEL_OID[l], gh, gp, None)
+    assert code == 0 and not any(gc)
+    code, gpub, gcodes = eng.bignPubkeyCalc_batch(prm, gp)
+    assert code == 0 and not any(gcodes)
