@@ -562,7 +562,16 @@ __device__ __forceinline__ void jac_dbl(jacT<N> &T)
     fe_sub<P>(t0, T.X, delta);
     fe_add<P>(t1, T.X, delta);
     fe_mul<3, P>(alpha, t0, t1);                // 3 (X - Z^2)(X + Z^2)
+#ifdef BIGN_DBL_2001B
+    // experiment: dbl-2001-b proper, Z3 = (Y + Z)^2 - gamma - delta: a squaring and three
+    // additions instead of the multiplication 2 Y Z (3M + 5S)
+    fe_add<P>(t0, T.Y, T.Z);
+    fe_sqr<1, P>(t0, t0);
+    fe_sub<P>(t0, t0, gamma);
+    fe_sub<P>(T.Z, t0, delta);
+#else
     fe_mul<2, P>(T.Z, T.Y, T.Z);                // Z3 = 2 Y Z
+#endif
     fe_sqr<1, P>(t0, alpha);
     fe_dbl<P>(t1, beta4);
     fe_sub<P>(T.X, t0, t1);                     // X3 = alpha^2 - 8 beta
