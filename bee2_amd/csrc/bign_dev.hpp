@@ -66,10 +66,16 @@ __device__ __forceinline__ void mac(uint64_t &acc, uint32_t &c2, uint32_t a, uin
 }
 // The first product of a column WRITES c2 (= 0 + 0 + carry) instead of accumulating into it, so
 // the counter needs no zero-initialising v_mov per column.
-template <bool FIRST>
+// NOCARRY: the sum cannot leave 64 bits -- column 0 (one product into an empty accumulator) and the last column (the whole
+// product fits 2N limbs) -- so the carry is not collected (round 3: 2 of the 64 / 44 v_addc_co_u32 of a product)
+template <bool FIRST, bool NOCARRY = false>
 __device__ __forceinline__ void mac_col(uint64_t &acc, uint32_t &c2, uint32_t a, uint32_t b)
 {
-    if constexpr (FIRST) {
+    if constexpr (NOCARRY) {
+        uint64_t cy;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(a), "v"(b));
+        if constexpr (FIRST) c2 = 0;
+    } else if constexpr (FIRST) {
         uint64_t cy;
         asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(a), "v"(b));
         asm("v_addc_co_u32 %0, %1, 0, 0, %1" : "=v"(c2), "+s"(cy));
@@ -261,7 +267,7 @@ __device__ __forceinline__ void fe_mul_body(feT<N> &r, const feT<N> &a, const fe
         constexpr int i0 = k < N ? 0 : k - N + 1;          // first row with a product in column k
         static_for<i0, (k < N ? k : N - 1) + 1>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
-            mac_col<i == i0>(acc, c2, a.v[i], b.v[k - i]);
+            mac_col<i == i0, k == 0 || k == 2 * N - 2>(acc, c2, a.v[i], b.v[k - i]);
         });
         w[k] = (uint32_t)acc;
         acc = (acc >> 32) | ((uint64_t)c2 << 32);
@@ -299,7 +305,7 @@ __device__ __forceinline__ void fe_sqr_body(feT<N> &r, const feT<N> &a)
             constexpr int i = decltype(ic)::value;
             constexpr int j = k - i;                 // position inside row i's vector
             constexpr bool first = i == (k < N ? 0 : k - N);   // column k's first product (k <= 2N-2)
-            if constexpr (j == i) mac_col<first>(acc, c2, a.v[i], a.v[i]);
+            if constexpr (j == i) mac_col<first, k == 0 || k == 2 * N - 2>(acc, c2, a.v[i], a.v[i]);
             else if constexpr (j == i + 1 && j < N) mac_col<first>(acc, c2, a.v[i], e[j]);
             else if constexpr (j >= i + 2 && j <= N) mac_col<first>(acc, c2, a.v[i], d[j]);
         });
