@@ -320,6 +320,7 @@ static err_t with_host(int kind, size_t bytes, const char *what, G gpu, H host)
 // launch(dev_chunk, first_unit, units, stream) queues the kernel(s) for `units` units starting at unit `first_unit`.
 constexpr size_t DUPLEX_MIN = (size_t)48 << 20;          // below this the two copies cost < 2 ms: not worth a thread
 static int g_duplex_log2_states = 16, g_duplex_log2_blocks = 20;   // chunk sizes (bee2hip_internal_tune 6 / 7: sweep)
+static int g_duplex_ramp = 0;                                      // quarter / half chunks at both ends (tune 9): measured -2 %, off
 struct DuplexStreams {
     hipStream_t up = nullptr, dn = nullptr;
     int dev = -1;
@@ -343,7 +344,25 @@ static err_t duplex_inplace(octet *host, octet *dev, size_t unit_bytes, size_t u
 {
     err_t code = t_duplex.get();
     if (code != ERR_OK) return code;
-    const size_t nch = (units + chunk_units - 1) / chunk_units;
+    // chunk boundaries: full chunks, with a quarter and a half chunk at either end when there are enough of them -- the first
+    // upload and the last download are the only transfers with nothing in the other direction beside them (knob 9)
+    std::vector<size_t> cut;
+    {
+        const size_t q = chunk_units / 4, h = chunk_units / 2;
+        const bool ramp = g_duplex_ramp && q && units >= 6 * chunk_units;
+        size_t pos = 0;
+        cut.push_back(0);
+        if (ramp) { cut.push_back(pos += q); cut.push_back(pos += h); }
+        const size_t tail = ramp ? q + h : 0;
+        while (units - pos > chunk_units + tail) cut.push_back(pos += chunk_units);
+        if (ramp) {
+            const size_t rest = units - pos - tail;       // <= chunk_units, > 0
+            cut.push_back(pos += rest);
+            cut.push_back(pos += h);
+        }
+        cut.push_back(units);
+    }
+    const size_t nch = cut.size() - 1;
     std::vector<hipEvent_t> ev(nch, nullptr);
     for (size_t c = 0; c < nch; ++c)
         if (hipEventCreateWithFlags(&ev[c], hipEventDisableTiming) != hipSuccess) {
@@ -362,7 +381,7 @@ static err_t duplex_inplace(octet *host, octet *dev, size_t unit_bytes, size_t u
                 if (failed.load()) return;
                 std::this_thread::yield();
             }
-            const size_t first = c * chunk_units, cnt = std::min(chunk_units, units - first);
+            const size_t first = cut[c], cnt = cut[c + 1] - first;
             if (hipStreamWaitEvent(sdn, ev[c], 0) != hipSuccess ||
                 hipMemcpyAsync(host + first * unit_bytes, dev + first * unit_bytes, cnt * unit_bytes, hipMemcpyDeviceToHost, sdn) != hipSuccess) {
                 failed.store(1);
@@ -372,7 +391,7 @@ static err_t duplex_inplace(octet *host, octet *dev, size_t unit_bytes, size_t u
         if (hipStreamSynchronize(sdn) != hipSuccess) failed.store(1);
     });
     for (size_t c = 0; c < nch && !failed.load(); ++c) {
-        const size_t first = c * chunk_units, cnt = std::min(chunk_units, units - first);
+        const size_t first = cut[c], cnt = cut[c + 1] - first;
         if (hipMemcpyAsync(dev + first * unit_bytes, host + first * unit_bytes, cnt * unit_bytes, hipMemcpyHostToDevice, sup) != hipSuccess) {
             failed.store(1);
             break;
@@ -1428,6 +1447,7 @@ extern "C" err_t bee2hip_internal_tune(int key, int value)
     case 8: bee2hip::set_verify_split(value); return ERR_OK;          // parts of a big verification batch (0 by size, 1 never, 2..4)
     case 6: bee2hip::g_duplex_log2_states = value; return ERR_OK;     // chunk of the duplex host pipeline, bashF states (log2)
     case 7: bee2hip::g_duplex_log2_blocks = value; return ERR_OK;     //                                   belt blocks (log2)
+    case 9: bee2hip::g_duplex_ramp = value; return ERR_OK;            // ramped chunk sizes at the ends of the pipeline
     default: return ERR_BAD_INPUT;
     }
 }

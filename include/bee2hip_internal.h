@@ -39,7 +39,9 @@ err_t bee2hip_internal_clock_probe(void *d_out16, unsigned us, void *stream);
 err_t bee2hip_internal_tune(int key, int value);
 /* (key 3 = size limit of the pinned staging buffer; key 4 = path of the drop-in layer's small calls, as the environment
    variable BEE2HIP_FORCE: 0 auto (by size), 1 gpu, 2 cpu -- bee2_amd/csrc/host_small.hpp; key 5 = fault injection: the
-   next `value` GPU attempts of drop-in helpers report a device failure) */
+   next `value` GPU attempts of drop-in helpers report a device failure; keys 6 / 7 = log2 of the chunk of the duplex host
+   pipeline in bashF states / belt blocks; key 8 = parts a big verification batch is split into (0 by size, 1 never);
+   key 9 = quarter and half chunks at both ends of the duplex pipeline (0 = product: measured -2 %)) */
 /* drop-in helper calls so far: which = 0 taken on the host path, 1 on the GPU, 2 finished on the host after the GPU path
    failed twice */
 unsigned long long bee2hip_internal_stat(int which);
