@@ -142,6 +142,9 @@ __device__ __forceinline__ void proj_madd_complete(projT<N> &P, const affT<N> &Q
     P.Y = Y3;
 }
 
+template <int N>
+__device__ __forceinline__ uint32_t proj_to_affine_ct(feT<N> &x, feT<N> &y, const projT<N> &acc);
+
 // -------------------------------------------------------------- k G, affine ---
 // R = k G for a secret k (any N-limb value; the callers have k in {1 .. q - 1}).  gtab8 is the verify path's 8-bit
 // seed table: entry (win, b) = b 2^(8 win) G affine, 2N words, at index win * 256 + b; window w of 4 bits reads
@@ -190,7 +193,13 @@ __device__ __forceinline__ uint32_t mul_base_ct(feT<N> &x, feT<N> &y, const uint
             acc.Z.v[l] = ct_sel(keep, acc.Z.v[l], sum.Z.v[l]);
         }
     }
-    // affine: x = X / Z, y = Y / Z with the fixed exponentiation chain (Z = 0 only for k = 0 mod q: gives 0)
+    return proj_to_affine_ct(x, y, acc);
+}
+
+// affine x = X / Z, y = Y / Z of a secret point; all-ones iff the point is O (Z = 0: k = 0 mod q) -- then x = y = 0
+template <int N>
+__device__ __forceinline__ uint32_t proj_to_affine_ct(feT<N> &x, feT<N> &y, const projT<N> &acc)
+{
     feT<N> zc;
     fe_canon(zc, acc.Z);
     // division steps with a fixed iteration count (bign_dev.hpp, fe_inv_safegcd<N, true>): a quarter of the
@@ -214,6 +223,157 @@ __device__ __forceinline__ void load_words_bytes(uint32_t (&r)[N], const uint8_t
     const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
 #pragma unroll
     for (int i = 0; i < N; ++i) r[i] = w[i];
+}
+
+// ---------------------------------------------- k G by a whole wavefront ---
+// P <- P + Q, both homogeneous projective, a = -3: Renes-Costello-Batina algorithm 4 (12M + 2 m_b + 29a), complete like the
+// mixed form above.  tools/model_rcb_a3_full.py checks this operation sequence against affine arithmetic (every pair of
+// points of a small odd-order curve, the standard curves, and the schedule below).
+template <int N>
+__device__ __forceinline__ void proj_add_complete(projT<N> &P, const projT<N> &Q, const feT<N> &b)
+{
+    feT<N> t0, t1, t2, t3, t4, X3, Y3, Z3;
+    fe_mul(t0, P.X, Q.X);
+    fe_mul(t1, P.Y, Q.Y);
+    fe_mul(t2, P.Z, Q.Z);
+    fe_add(t3, P.X, P.Y);
+    fe_add(t4, Q.X, Q.Y);
+    fe_mul(t3, t3, t4);
+    fe_add(t4, t0, t1);
+    fe_sub(t3, t3, t4);                 // X1 Y2 + X2 Y1
+    fe_add(t4, P.Y, P.Z);
+    fe_add(X3, Q.Y, Q.Z);
+    fe_mul(t4, t4, X3);
+    fe_add(X3, t1, t2);
+    fe_sub(t4, t4, X3);                 // Y1 Z2 + Y2 Z1
+    fe_add(X3, P.X, P.Z);
+    fe_add(Y3, Q.X, Q.Z);
+    fe_mul(X3, X3, Y3);
+    fe_add(Y3, t0, t2);
+    fe_sub(Y3, X3, Y3);                 // X1 Z2 + X2 Z1
+    fe_mul(Z3, b, t2);
+    fe_sub(X3, Y3, Z3);
+    fe_add(Z3, X3, X3);
+    fe_add(X3, X3, Z3);
+    fe_sub(Z3, t1, X3);
+    fe_add(X3, t1, X3);
+    fe_mul(Y3, b, Y3);
+    fe_add(t1, t2, t2);
+    fe_add(t2, t1, t2);
+    fe_sub(Y3, Y3, t2);
+    fe_sub(Y3, Y3, t0);
+    fe_add(t1, Y3, Y3);
+    fe_add(Y3, t1, Y3);
+    fe_add(t1, t0, t0);
+    fe_add(t0, t1, t0);
+    fe_sub(t0, t0, t2);
+    fe_mul(t1, t4, Y3);
+    fe_mul(t2, t0, Y3);
+    fe_mul(Y3, X3, Z3);
+    fe_add(Y3, Y3, t2);
+    fe_mul(X3, t3, X3);
+    fe_sub(P.X, X3, t1);
+    fe_mul(Z3, t4, Z3);
+    fe_mul(t1, t3, t0);
+    fe_add(P.Z, Z3, t1);
+    P.Y = Y3;
+}
+
+// R = k G for ONE secret k by the 64 lanes of a wavefront (small batches: with one lane per scalar a lone wavefront walks
+// 8N dependent additions, 0.6 ms whatever the batch).  Lane j takes the 4-bit windows j, j + 64, ...: the same masked scan
+// of the window's 15 table entries as mul_base_ct (the addresses depend on the lane, not on k), then a butterfly of
+// log2(64) = 6 complete additions leaves the sum in every lane.  No branch, address or shuffle pattern depends on k.
+// Returns as mul_base_ct; every lane holds the result.
+template <int N>
+__device__ __forceinline__ uint32_t mul_base_coop(feT<N> &x, feT<N> &y, const uint8_t *__restrict__ kbytes,
+                                                  const uint32_t *__restrict__ gtab8)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    feT<N> b;
+#pragma unroll
+    for (int i = 0; i < N; ++i) b.v[i] = curve_b<N>()[i];
+    projT<N> acc;
+    fe_set_zero(acc.X); fe_set_one(acc.Y); fe_set_zero(acc.Z);          // O
+#pragma unroll 1
+    for (int t = 0; t < (8 * N + 63) / 64; ++t) {
+        const int w = lane + 64 * t;
+        const bool mine = w < 8 * N;                 // not a secret
+        const int wc = mine ? w : 0;
+        uint32_t dg = ((uint32_t)kbytes[wc >> 1] >> (4 * (wc & 1))) & 15u;
+        dg = mine ? dg : 0u;
+        const uint32_t *row = gtab8 + ((size_t)(wc >> 1) * GT8_ENTRIES) * (2 * N);
+        const int sh = 4 * (wc & 1);
+        affT<N> E;
+        fe_set_zero(E.x); fe_set_zero(E.y);
+#pragma unroll 1
+        for (int j = 1; j < 16; ++j) {
+            const uint32_t m = ct_eq_small(dg, (uint32_t)j);
+            const uint4 *e = reinterpret_cast<const uint4 *>(row + (size_t)(j << sh) * (2 * N));
+#pragma unroll
+            for (int l = 0; l < N / 4; ++l) {
+                const uint4 ex = e[l], ey = e[N / 4 + l];
+                E.x.v[4 * l + 0] = bitop3<0xF8>(E.x.v[4 * l + 0], ex.x, m);
+                E.x.v[4 * l + 1] = bitop3<0xF8>(E.x.v[4 * l + 1], ex.y, m);
+                E.x.v[4 * l + 2] = bitop3<0xF8>(E.x.v[4 * l + 2], ex.z, m);
+                E.x.v[4 * l + 3] = bitop3<0xF8>(E.x.v[4 * l + 3], ex.w, m);
+                E.y.v[4 * l + 0] = bitop3<0xF8>(E.y.v[4 * l + 0], ey.x, m);
+                E.y.v[4 * l + 1] = bitop3<0xF8>(E.y.v[4 * l + 1], ey.y, m);
+                E.y.v[4 * l + 2] = bitop3<0xF8>(E.y.v[4 * l + 2], ey.z, m);
+                E.y.v[4 * l + 3] = bitop3<0xF8>(E.y.v[4 * l + 3], ey.w, m);
+            }
+        }
+        projT<N> sum = acc;
+        proj_madd_complete(sum, E, b);               // digit 0: E = (0, 0) is not a point; the old accumulator is kept
+        const uint32_t keep = ct_eq_small(dg, 0u);
+#pragma unroll
+        for (int l = 0; l < N; ++l) {
+            acc.X.v[l] = ct_sel(keep, acc.X.v[l], sum.X.v[l]);
+            acc.Y.v[l] = ct_sel(keep, acc.Y.v[l], sum.Y.v[l]);
+            acc.Z.v[l] = ct_sel(keep, acc.Z.v[l], sum.Z.v[l]);
+        }
+    }
+#pragma unroll 1
+    for (int s = 1; s < 64; s <<= 1) {
+        projT<N> o;
+#pragma unroll
+        for (int l = 0; l < N; ++l) {
+            o.X.v[l] = (uint32_t)__shfl_xor((int)acc.X.v[l], s, 64);
+            o.Y.v[l] = (uint32_t)__shfl_xor((int)acc.Y.v[l], s, 64);
+            o.Z.v[l] = (uint32_t)__shfl_xor((int)acc.Z.v[l], s, 64);
+        }
+        proj_add_complete(acc, o, b);
+    }
+    return proj_to_affine_ct(x, y, acc);
+}
+
+// One wavefront per scalar (block = 64 lanes, grid = n); modes and outputs as bign_mulbase_ct_kernel.
+template <int N, int MODE, bool X_ONLY>
+__global__ __launch_bounds__(64)
+void bign_mulbase_coop_kernel(const uint8_t *__restrict__ scalars, size_t n, uint32_t *__restrict__ codes,
+                              uint8_t *__restrict__ xy_out, const uint32_t *__restrict__ gtab8)
+{
+    constexpr int NO = 4 * N;
+    const size_t idx = blockIdx.x;
+    if (idx >= n) return;
+    uint32_t valid = ~0u;
+    if constexpr (MODE == 1) {
+        uint32_t k[N];
+        load_words_bytes(k, scalars + NO * idx);
+        valid = ct_in_range_q(k);
+    }
+    feT<N> x, y;
+    const uint32_t inf = mul_base_coop(x, y, scalars + NO * idx, gtab8);
+    if constexpr (MODE == 2) valid = ~inf;
+    if (threadIdx.x != 0) return;
+    if constexpr (MODE == 1) codes[idx] = ct_sel(valid, (uint32_t)ERR_OK, ERR_BAD_PRIVKEY_V);
+    if constexpr (MODE == 2) codes[idx] = ct_sel(inf, (uint32_t)ERR_BAD_PARAMS, (uint32_t)ERR_OK);
+    uint32_t *o = reinterpret_cast<uint32_t *>(xy_out + (X_ONLY ? NO : 2 * NO) * idx);
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = x.v[i] & valid;
+    if constexpr (!X_ONLY) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[N + i] = y.v[i] & valid;
+    }
 }
 
 // scalars: n x 4N octets (LE).
@@ -582,6 +742,13 @@ static err_t sign_scratch(hipStream_t st, size_t n, SignScratch &S)
     return ERR_OK;
 }
 
+// k G by one lane per scalar (throughput) or one wavefront per scalar (latency): g_sign_coop_max = largest batch the wavefront
+// form takes (bee2hip_internal_tune 10).  profiles/r03_sign_coop.txt: 120 against 660-700 us up to 2^10 scalars on the 256-bit
+// curve, 0.40 against 4.0-4.1 ms on the 512-bit one; the forms meet between 2^13 and 2^14 on all three.
+static int g_sign_coop_max = 1 << 13;
+void set_sign_coop(int v) { g_sign_coop_max = v; }
+static inline bool mulbase_coop(size_t n) { return n <= (size_t)(g_sign_coop_max < 0 ? 0 : g_sign_coop_max); }
+
 template <int N>
 static err_t launch_bign_pubkey_calc_t(bool keygen, const void *d_privkeys, size_t n, void *d_pubkeys, void *d_codes, hipStream_t st)
 {
@@ -589,7 +756,14 @@ static err_t launch_bign_pubkey_calc_t(bool keygen, const void *d_privkeys, size
     err_t code = bign_table8<N>(&tab, st);
     if (code != ERR_OK) return code;
     const unsigned grid = (unsigned)((n + 255) / 256);
-    if (!keygen)
+    if (mulbase_coop(n)) {
+        if (!keygen)
+            hipLaunchKernelGGL((bign_mulbase_coop_kernel<N, 1, false>), dim3((unsigned)n), dim3(64), 0, st,
+                               (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab);
+        else
+            hipLaunchKernelGGL((bign_mulbase_coop_kernel<N, 2, false>), dim3((unsigned)n), dim3(64), 0, st,
+                               (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab);
+    } else if (!keygen)
         hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 1, false>), dim3(grid), dim3(256), 0, st, (const uint8_t *)d_privkeys, n,
                            (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab);
     else
@@ -643,8 +817,12 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
         B2H_TRY(hipMemcpyAsync(S.k, d_aux, n * 4 * N, hipMemcpyDeviceToDevice, st));
         kptr = S.k;
     }
-    hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 0, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, kptr, n,
-                       (uint32_t *)nullptr, S.rx, tab);
+    if (mulbase_coop(n))
+        hipLaunchKernelGGL((bign_mulbase_coop_kernel<N, 0, true>), dim3((unsigned)n), dim3(64), 0, st, kptr, n,
+                           (uint32_t *)nullptr, S.rx, tab);
+    else
+        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 0, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, kptr, n,
+                           (uint32_t *)nullptr, S.rx, tab);
     {
         constexpr int ROW = (OID_MAX + 2 * 64 + 31) / 32 * 8 + 1;
         const size_t lds = BeltTabTwo::kBytes + (size_t)SIGN_WG * ROW * 4;

@@ -53,7 +53,7 @@ def test_stb_annex_G_vectors(golden):
 
 
 @pytest.mark.parametrize("l", [128, 192, 256])
-def test_golden_cases_dropin(golden, l):
+def test_golden_cases_dropin(golden, l, mulbase):
     """every case of the fixture through the drop-in functions: keys 0, 1, q-1, q-2, q, 2^2l - 1; hashes at and
     beyond q; additional input of 0..300 octets; rejected rng draws; foreign, long and malformed OIDs"""
     eng = engine()
@@ -92,8 +92,18 @@ def test_golden_cases_dropin(golden, l):
             assert rng.pos[0] == 0                    # a bad private key must not consume the generator
 
 
+@pytest.fixture(params=["lane_per_scalar", "wavefront_per_scalar"])
+def mulbase(request):
+    """k G of the signing side: one lane per scalar (bign_mulbase_ct_kernel, the throughput form) or one wavefront per
+    scalar (bign_mulbase_coop_kernel, batches up to 2^13 by default) -- forced at every size, default restored"""
+    eng = engine()
+    eng.lib.bee2hip_internal_tune(10, 0 if request.param == "lane_per_scalar" else 1 << 30)
+    yield request.param
+    eng.lib.bee2hip_internal_tune(10, 1 << 13)
+
+
 @pytest.mark.parametrize("l", [128, 192, 256])
-def test_batch_vs_oracle_and_verify_roundtrip(orc, l):
+def test_batch_vs_oracle_and_verify_roundtrip(orc, l, mulbase):
     """host batch API on seeded random items with bad keys mixed in: codes and outputs per item as the oracle,
     outputs of refused items untouched; then every signature verifies under its public key on the device"""
     eng = engine()
@@ -136,6 +146,36 @@ def test_batch_vs_oracle_and_verify_roundtrip(orc, l):
         assert kcodes[i] == w[0], i
         if w[0] == 0:
             assert sigs2[sg * i: sg * (i + 1)] == w[1]
+
+
+@pytest.mark.parametrize("l", [128, 192, 256])
+def test_base_point_multiples_of_special_scalars(orc, l, mulbase):
+    """d G for d = 1, 2, 15, 16, 2^(4 j), q - 1, q - 2 and digit patterns that leave most windows empty or full; d = 0 and
+    d >= q are refused with the reference's code; one-time key k = q - 1 and k = 1 sign like the oracle"""
+    eng = engine()
+    P = _params(eng, l)
+    no, sg = l // 4, 3 * l // 8
+    q = int.from_bytes(bytes(P.q)[:no], "little")
+    ds = [1, 2, 15, 16, 17, q - 1, q - 2, q >> 1, 0, q, q + 1, (1 << (8 * no)) - 1,
+          int("f0" * no, 16) % q, int("0f" * no, 16) % q, int("01" * no, 16), 1 << (8 * no - 5)]
+    ds += [1 << (4 * j) for j in range(1, 2 * no, 7)] + [15 << (4 * j) for j in range(0, 2 * no - 1, 5)]
+    privs = b"".join(d.to_bytes(no, "little") for d in ds)
+    code, pubs, codes = eng.bignPubkeyCalc_batch(P, privs)
+    assert code == 0
+    for i, d in enumerate(ds):
+        w = orc.pubkey_calc(l, privs[no * i: no * (i + 1)])
+        assert codes[i] == w[0], hex(d)
+        assert pubs[2 * no * i: 2 * no * (i + 1)] == (w[1] if w[0] == 0 else bytes(2 * no)), hex(d)
+    oid = E.LEVEL_OID[l]
+    good = [d for d in ds if 0 < d < q]
+    hashes = orc.fill(no * len(good), 0x77 + l)
+    dd = b"".join((q - 1 - i).to_bytes(no, "little") for i in range(len(good)))
+    kk = b"".join(d.to_bytes(no, "little") for d in good)
+    code, sigs, kcodes = eng.bignSignK_batch(P, oid, hashes, dd, kk)
+    assert code == 0
+    for i in range(len(good)):
+        w = orc.sign_rnd(l, oid, hashes[no * i: no * (i + 1)], dd[no * i: no * (i + 1)], kk[no * i: no * (i + 1)])
+        assert (kcodes[i], sigs[sg * i: sg * (i + 1)] if w[0] == 0 else None) == (w[0], w[1] if w[0] == 0 else None), i
 
 
 def test_device_batch_sign_verify_pipeline_2pow16(orc):

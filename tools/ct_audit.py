@@ -15,7 +15,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
-KERNELS = ("bign_mulbase_ct_kernel", "bign_sign_nonce_kernel", "bign_sign_kcheck_kernel", "bign_sign_tail_kernel",
+KERNELS = ("bign_mulbase_ct_kernel", "bign_mulbase_coop_kernel", "bign_sign_nonce_kernel", "bign_sign_kcheck_kernel", "bign_sign_tail_kernel",
            "bign_generic_mulbase_kernel", "bign_generic_sign_tail_kernel")
 
 

@@ -1,6 +1,7 @@
 """Dynamic side of the constant-time check: sign the SAME hashes with private keys of a given class and let
 rocprofv3 count the executed instructions of every signing kernel.  Secret-independent control flow means the
-counts are identical for every class.  usage (under rocprofv3 --pmc ...): python tools/ct_dynamic.py <class> [l]
+counts are identical for every class.  usage (under rocprofv3 --pmc ...): python tools/ct_dynamic.py <class> [l] [log2 n]
+(n = 2^14 runs k G one lane per scalar, n <= 2^13 one wavefront per scalar: bign_mulbase_coop_kernel)
 classes: random | small (d = 1 .. 16) | ones (d = q - 1 - i) | sparse (d = 2^k + 1) | dense (d = ~sparse mod q)"""
 import os
 import sys
@@ -16,7 +17,7 @@ from bee2_amd import engine as E  # noqa: E402
 cls = sys.argv[1]
 l = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 no, sg = l // 4, 3 * l // 8
-n = 1 << 14
+n = 1 << (int(sys.argv[3]) if len(sys.argv) > 3 else 14)
 eng = bee2_amd.load()
 eng.set_device(0)
 orc = orclib.load()
