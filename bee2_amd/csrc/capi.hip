@@ -320,6 +320,8 @@ static err_t with_host(int kind, size_t bytes, const char *what, G gpu, H host)
 // launch(dev_chunk, first_unit, units, stream) queues the kernel(s) for `units` units starting at unit `first_unit`.
 constexpr size_t DUPLEX_MIN = (size_t)48 << 20;          // below this the two copies cost < 2 ms: not worth a thread
 static int g_duplex_log2_states = 16, g_duplex_log2_blocks = 20;   // chunk sizes (bee2hip_internal_tune 6 / 7: sweep)
+constexpr size_t VERIFY_PIPE_MIN = (size_t)1 << 19, VERIFY_PIPE_CHUNK = (size_t)1 << 18;   // host-pointer verification batches
+static int g_verify_pipe = 1;                                      // (tune 11: A/B)
 static int g_duplex_ramp = 0;                                      // quarter / half chunks at both ends (tune 9): measured -2 %, off
 struct DuplexStreams {
     hipStream_t up = nullptr, dn = nullptr;
@@ -839,6 +841,35 @@ extern "C" err_t bee2hip_bignVerify_batch(const bign_params *params, const octet
     code = s.need(co + n * 4);
     if (code != ERR_OK) return code;
     octet *d = (octet *)s.p;
+    if (standard && n >= VERIFY_PIPE_MIN && g_verify_pipe) {
+        // big host batch: chunk c + 1 is uploaded (its own stream) while the kernels of chunk c run -- the 144 n octets
+        // of input are a quarter of the time of the whole call otherwise (profiles/r03_verify_hostpipe.txt)
+        code = t_duplex.get();
+        if (code != ERR_OK) return code;
+        const hipStream_t up = t_duplex.up, st = t_duplex.dn;
+        const size_t CH = VERIFY_PIPE_CHUNK, nch = (n + CH - 1) / CH, sg = no + no / 2;
+        std::vector<hipEvent_t> ev(nch, nullptr);
+        hipError_t he = hipSuccess;
+        for (size_t c = 0; c < nch && he == hipSuccess; ++c) he = hipEventCreateWithFlags(&ev[c], hipEventDisableTiming);
+        for (size_t c = 0; c < nch && he == hipSuccess && code == ERR_OK; ++c) {
+            const size_t first = c * CH, cnt = std::min(CH, n - first);
+            he = hipMemcpyAsync(d + first * no, hashes + first * no, cnt * no, hipMemcpyHostToDevice, up);
+            if (he == hipSuccess) he = hipMemcpyAsync(d + so + first * sg, sigs + first * sg, cnt * sg, hipMemcpyHostToDevice, up);
+            if (he == hipSuccess) he = hipMemcpyAsync(d + po + first * 2 * no, pubkeys + first * 2 * no, cnt * 2 * no, hipMemcpyHostToDevice, up);
+            if (he == hipSuccess) he = hipEventRecord(ev[c], up);
+            if (he == hipSuccess) he = hipStreamWaitEvent(st, ev[c], 0);
+            if (he == hipSuccess)
+                code = launch_bign_verify(params->l, oid_der, oid_len, d + first * no, d + so + first * sg, d + po + first * 2 * no,
+                                          cnt, d + co + 4 * first, st);
+        }
+        if (he == hipSuccess) he = hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(up);
+        for (size_t c = 0; c < nch; ++c) if (ev[c]) (void)hipEventDestroy(ev[c]);
+        if (code != ERR_OK) return code;
+        B2H_TRY(he);
+        B2H_TRY(hipMemcpy(codes, d + co, 4 * n, hipMemcpyDeviceToHost));
+        return ERR_OK;
+    }
     B2H_TRY(h2d(d, hashes, hb));
     B2H_TRY(h2d(d + so, sigs, sb));
     B2H_TRY(h2d(d + po, pubkeys, pb));
@@ -1447,6 +1478,7 @@ extern "C" err_t bee2hip_internal_tune(int key, int value)
     case 8: bee2hip::set_verify_split(value); return ERR_OK;          // parts of a big verification batch (0 by size, 1 never, 2..4)
     case 6: bee2hip::g_duplex_log2_states = value; return ERR_OK;     // chunk of the duplex host pipeline, bashF states (log2)
     case 7: bee2hip::g_duplex_log2_blocks = value; return ERR_OK;     //                                   belt blocks (log2)
+    case 11: bee2hip::g_verify_pipe = value; return ERR_OK;           // chunked upload of big host-pointer verification batches
     case 10: bee2hip::set_sign_coop(value); return ERR_OK;            // largest batch whose k G runs one wavefront per scalar
     case 9: bee2hip::g_duplex_ramp = value; return ERR_OK;            // ramped chunk sizes at the ends of the pipeline
     default: return ERR_BAD_INPUT;

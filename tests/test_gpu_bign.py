@@ -285,6 +285,34 @@ def test_bign_full_size_2pow18_tiled_and_corrupted(orc, golden):
     assert set(want_bad) <= {0, 505, 510} and 510 in want_bad
 
 
+def test_bign_big_host_batch_is_uploaded_in_chunks(golden):
+    """bee2hip_bignVerify_batch with host pointers and 2^19 + 777 signatures: chunks of 2^18 are uploaded while the previous
+    chunk is verified (capi.hip, knob 11); the codes are those of the one-piece path and of the device-resident entry"""
+    eng = engine()
+    hs, ss, ps = golden.bign_base_arrays()
+    nb = len(hs) // 32
+    n = (1 << 19) + 777
+    reps = (n + nb - 1) // nb
+    H = np.tile(np.frombuffer(hs, dtype=np.uint8), reps).reshape(-1, 32)[:n].copy()
+    S = np.tile(np.frombuffer(ss, dtype=np.uint8), reps).reshape(-1, 48)[:n].copy()
+    K = np.tile(np.frombuffer(ps, dtype=np.uint8), reps).reshape(-1, 64)[:n].copy()
+    rnd = random.Random(0x19)
+    bad = sorted(rnd.sample(range(n), 5000) + [0, (1 << 18) - 1, 1 << 18, (1 << 19) - 1, 1 << 19, n - 1])
+    for i in bad:
+        S[i, rnd.randrange(48)] ^= 1 << rnd.randrange(8)
+    codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    eng.bign128Verify_batch_dev(dev(H.reshape(-1)), dev(S.reshape(-1)), dev(K.reshape(-1)), codes)
+    torch.cuda.synchronize()
+    want = [int(c) & 0xFFFFFFFF for c in codes.cpu().numpy()]
+    assert all(want[i] != 0 for i in bad) and sum(1 for c in want if c) == len(set(bad))
+    hb, sb, kb = H.tobytes(), S.tobytes(), K.tobytes()
+    for knob in (1, 0):
+        eng.lib.bee2hip_internal_tune(11, knob)
+        code, got = eng.bignVerify_batch(hb, sb, kb)
+        assert code == 0 and got == want, knob
+    eng.lib.bee2hip_internal_tune(11, 1)
+
+
 def test_concurrent_batches_on_two_streams_do_not_share_scratch(orc, golden):
     """two verify batches in flight on different streams (library scratch is per stream)"""
     eng = engine()
