@@ -18,6 +18,10 @@
 // belt_encr_blocks_kernel : E_K over n blocks in place (ctr0 = E_K(iv) of
 //   beltCTRStart, belt_ctr.c:55-64; r = E_K(0) of beltMACStart, belt_mac.c:47-56;
 //   the drop-in beltBlockEncr*).
+#include <algorithm>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include "belt_dev.hpp"
 #include "common.hpp"
 
@@ -650,6 +654,20 @@ static int num_cus()
     return g_num_cus[dev];
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize, once per (device, kernel) and safe from any thread (the flags used to be
+// plain static bools per call site: a benign race, but a race)
+static hipError_t dyn_lds_once(const void *kern, size_t bytes)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, const void *>> done;
+    const std::pair<int, const void *> key(cur_dev(), kern);
+    std::lock_guard<std::mutex> lk(mu);
+    if (std::find(done.begin(), done.end(), key) != done.end()) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done.push_back(key);
+    return e;
+}
+
 err_t upload_beltH(const uint8_t *H)
 {
     B2H_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_beltH), H, 256));
@@ -670,13 +688,8 @@ template <class Tab, int ILP, int MEM = 0>
 static err_t launch_ctr_t(void *d_buf, size_t nblocks, const BeltKey &k, const BeltCtr &c, uint64_t first,
                           void *d_last_gamma, hipStream_t st)
 {
-    static bool attr[64];
     auto kern = beltCTR_blocks_kernel<Tab, ILP, MEM>;
-    if (!attr[cur_dev()]) {
-        B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    Tab::kBytes));
-        attr[cur_dev()] = true;
-    }
+    B2H_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), Tab::kBytes));
     const size_t tile = (size_t)CTR_WG * ILP;
     size_t grid = (nblocks + tile - 1) / tile;
     const size_t cap = (size_t)num_cus() * (BeltTabWide::kBytes / Tab::kBytes);
@@ -727,13 +740,8 @@ template <int MODE>
 static err_t launch_modes_t(const void *d_src, void *d_dst, size_t nblocks, const BeltKey &k, const BeltCtr &iv,
                             hipStream_t st)
 {
-    static bool attr[64];
     auto kern = belt_modes_kernel<MODE>;
-    if (!attr[cur_dev()]) {
-        B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, CtrTab::kBytes));
-        attr[cur_dev()] = true;
-    }
+    B2H_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), CtrTab::kBytes));
     size_t grid = (nblocks + CTR_WG - 1) / CTR_WG;
     const size_t cap = (size_t)num_cus() * (BeltTabWide::kBytes / CtrTab::kBytes);
     if (grid > cap) grid = cap;
@@ -761,13 +769,8 @@ template <int DECR>
 static err_t launch_bde_t(const void *d_src, void *d_dst, uint64_t nblocks, uint64_t chunk, unsigned grid,
                           const BeltKey &k, const uint4 *tweaks, hipStream_t st)
 {
-    static bool attr[64];
     auto kern = belt_bde_kernel<DECR>;
-    if (!attr[cur_dev()]) {
-        B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, CtrTab::kBytes));
-        attr[cur_dev()] = true;
-    }
+    B2H_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), CtrTab::kBytes));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(CTR_WG), CtrTab::kBytes, st, (const uint4 *)d_src, (uint4 *)d_dst,
                        nblocks, chunk, k, tweaks);
     B2H_TRY(hipGetLastError());
@@ -815,25 +818,17 @@ err_t launch_belt_sde(int decr, void *d_sectors, size_t nblk, size_t nsectors, c
 {
     if (nsectors == 0) return ERR_OK;
     if (nblk < 2 || nblk > 0x7fffffffull) return ERR_BAD_INPUT;
-    static bool attr[64][2];
     const void *kern = decr ? reinterpret_cast<const void *>(belt_sde_kernel<1>)
                             : reinterpret_cast<const void *>(belt_sde_kernel<0>);
-    if (!attr[cur_dev()][decr ? 1 : 0]) {
-        B2H_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, CtrTab::kBytes));
-        attr[cur_dev()][decr ? 1 : 0] = true;
-    }
+    B2H_TRY(dyn_lds_once(kern, CtrTab::kBytes));
     BeltKey k;
     for (int i = 0; i < 8; ++i) k.k[i] = key[i];
     const unsigned grid = (unsigned)((nsectors + CTR_WG - 1) / CTR_WG);
     constexpr int SDE_LINE = 8;                                    // 128-byte lines: 4-block lines measured slower, esp. decryption
     if (nblk % SDE_LINE == 0 && nblk >= 2 * SDE_LINE) {             // whole-line accesses per lane (see the kernel)
-        static bool lattr[64][2];
         const void *lk = decr ? reinterpret_cast<const void *>(belt_sde_lines_kernel<1, SDE_LINE>)
                               : reinterpret_cast<const void *>(belt_sde_lines_kernel<0, SDE_LINE>);
-        if (!lattr[cur_dev()][decr ? 1 : 0]) {
-            B2H_TRY(hipFuncSetAttribute(lk, hipFuncAttributeMaxDynamicSharedMemorySize, CtrTab::kBytes));
-            lattr[cur_dev()][decr ? 1 : 0] = true;
-        }
+        B2H_TRY(dyn_lds_once(lk, CtrTab::kBytes));
         if (decr)
             hipLaunchKernelGGL((belt_sde_lines_kernel<1, SDE_LINE>), dim3(grid), dim3(CTR_WG), CtrTab::kBytes, st,
                                (uint4 *)d_sectors, (uint32_t)nblk, (uint64_t)nsectors, k, (const uint4 *)d_ivs);
@@ -857,12 +852,7 @@ err_t launch_belt_che(const void *d_src, void *d_dst, size_t nblocks, const uint
                       uint64_t first, void *d_s_out, hipStream_t st)
 {
     if (nblocks == 0 && !d_s_out) return ERR_OK;
-    static bool attr[64];
-    if (!attr[cur_dev()]) {
-        B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(belt_che_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, CtrTab::kBytes));
-        attr[cur_dev()] = true;
-    }
+    B2H_TRY(dyn_lds_once(reinterpret_cast<const void *>(belt_che_kernel), CtrTab::kBytes));
     BeltKey k; BeltCtr s0;
     for (int i = 0; i < 8; ++i) k.k[i] = key[i];
     for (int i = 0; i < 4; ++i) s0.c[i] = s[i];
@@ -926,12 +916,7 @@ err_t launch_belt_cbc_encr(void *d_msgs, size_t nblk, size_t n, const uint32_t k
     if (n == 0) return ERR_OK;
     BeltKey k;
     for (int i = 0; i < 8; ++i) k.k[i] = key[i];
-    static bool cattr[64];
-    if (!cattr[cur_dev()]) {
-        B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(belt_cbc_encr_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, CtrTab::kBytes));
-        cattr[cur_dev()] = true;
-    }
+    B2H_TRY(dyn_lds_once(reinterpret_cast<const void *>(belt_cbc_encr_kernel), CtrTab::kBytes));
     hipLaunchKernelGGL(belt_cbc_encr_kernel, dim3((unsigned)((n + CTR_WG - 1) / CTR_WG)), dim3(CTR_WG), CtrTab::kBytes, st,
                        (uint4 *)d_msgs, nblk, n, k, (uint4 *)d_ivs);
     B2H_TRY(hipGetLastError());

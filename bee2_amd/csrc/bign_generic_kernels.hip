@@ -656,7 +656,7 @@ err_t sign_generic_t(const bign_params *params, int mode, const uint8_t *oid_der
     if (mode == 0 || mode == 2) {
         constexpr int ROW = (OID_MAX + 64 + SIGN_T_MAX + 31) / 32 * 8 + 1;
         const size_t lds = BeltTabTwo::kBytes + (size_t)SIGN_WG * ROW * 4;
-        B2H_TRY(hipFuncSetAttribute((const void *)bign_sign_nonce_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        B2H_TRY(dyn_lds_once((const void *)bign_sign_nonce_kernel<N>, lds));
         const uint8_t *tp = mode == 0 ? (const uint8_t *)d_aux : nullptr;
         hipLaunchKernelGGL(bign_sign_nonce_kernel<N>, dim3(grid), dim3(SIGN_WG), lds, st, (const uint8_t *)d_hashes,
                            (const uint8_t *)d_privkeys, tp, (uint32_t)(tp ? t_len : 0), (uint32_t)(t_shared ? 0 : t_len),
@@ -671,7 +671,7 @@ err_t sign_generic_t(const bign_params *params, int mode, const uint8_t *oid_der
     {
         constexpr int ROW = (OID_MAX + 2 * 64 + 31) / 32 * 8 + 1;
         const size_t lds = BeltTabTwo::kBytes + (size_t)SIGN_WG * ROW * 4;
-        B2H_TRY(hipFuncSetAttribute((const void *)bign_generic_sign_tail_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        B2H_TRY(dyn_lds_once((const void *)bign_generic_sign_tail_kernel<N>, lds));
         hipLaunchKernelGGL(bign_generic_sign_tail_kernel<N>, dim3(grid), dim3(SIGN_WG), lds, st, (const uint8_t *)d_hashes,
                            (const uint8_t *)d_privkeys, (const uint8_t *)S.rx, S.k, n, oa, Cq, (const uint32_t *)S.status,
                            (uint8_t *)d_sigs, (uint32_t *)d_codes);

@@ -1215,16 +1215,7 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
         const auto launch = [&](auto kern, unsigned wg, unsigned lanes) -> err_t {
             const unsigned ns = wg / lanes;
             const size_t lds = (size_t)8 * 4 * LZ<N>::L * ns * 4;
-            if (lds > 48 * 1024) {               // once per (device, kernel), not per launch
-                static std::mutex attr_mu;
-                static std::vector<std::pair<int, const void *>> attr_done;
-                const std::pair<int, const void *> key(cur_dev(), reinterpret_cast<const void *>(kern));
-                std::lock_guard<std::mutex> lk(attr_mu);
-                if (std::find(attr_done.begin(), attr_done.end(), key) == attr_done.end()) {
-                    B2H_TRY(hipFuncSetAttribute(key.second, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    attr_done.push_back(key);
-                }
-            }
+            if (lds > 48 * 1024) B2H_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), lds));   // once per (device, kernel)
             hipLaunchKernelGGL(kern, dim3((unsigned)((n + ns - 1) / ns)), dim3(wg), lds, st, (const uint8_t *)d_hashes,
                                (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S, (const uint4 *)gtab);
             return ERR_OK;
@@ -1279,12 +1270,7 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
     if (N == 8 && n >= 65536) {
         auto kern = bign_tail_kernel<N, BeltTabTwo, 1024>;
         const size_t lds = BeltTabTwo::kBytes + 1024 * row_bytes;
-        static bool attr_set[64];
-        if (!attr_set[cur_dev()]) {
-            B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set[cur_dev()] = true;
-        }
+        B2H_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), lds, st, (const uint8_t *)d_hashes,
                            (const uint8_t *)d_sigs, n, S, oid, (uint32_t *)d_codes);
     } else {

@@ -801,11 +801,7 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
     if (mode == 0 || mode == 2) {
         constexpr int ROW = (OID_MAX + 64 + SIGN_T_MAX + 31) / 32 * 8 + 1;
         const size_t lds = BeltTabTwo::kBytes + (size_t)SIGN_WG * ROW * 4;
-        static bool attr_done[64];
-        if (!attr_done[cur_dev()]) {
-            B2H_TRY(hipFuncSetAttribute((const void *)bign_sign_nonce_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_done[cur_dev()] = true;
-        }
+        B2H_TRY(dyn_lds_once((const void *)bign_sign_nonce_kernel<N>, lds));
         const uint8_t *tp = mode == 0 ? (const uint8_t *)d_aux : nullptr;
         hipLaunchKernelGGL(bign_sign_nonce_kernel<N>, dim3(grid), dim3(SIGN_WG), lds, st, (const uint8_t *)d_hashes,
                            (const uint8_t *)d_privkeys, tp, (uint32_t)(tp ? t_len : 0),
@@ -826,11 +822,7 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
     {
         constexpr int ROW = (OID_MAX + 2 * 64 + 31) / 32 * 8 + 1;
         const size_t lds = BeltTabTwo::kBytes + (size_t)SIGN_WG * ROW * 4;
-        static bool attr_done[64];
-        if (!attr_done[cur_dev()]) {
-            B2H_TRY(hipFuncSetAttribute((const void *)bign_sign_tail_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_done[cur_dev()] = true;
-        }
+        B2H_TRY(dyn_lds_once((const void *)bign_sign_tail_kernel<N>, lds));
         hipLaunchKernelGGL(bign_sign_tail_kernel<N>, dim3(grid), dim3(SIGN_WG), lds, st, (const uint8_t *)d_hashes,
                            (const uint8_t *)d_privkeys, (const uint8_t *)S.rx, S.k, n, oa, (const uint32_t *)S.status,
                            (uint8_t *)d_sigs, (uint32_t *)d_codes);

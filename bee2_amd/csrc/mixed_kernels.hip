@@ -779,13 +779,7 @@ err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, cons
             const bool wide = n >= (size_t)num_cus() * 1024;
             const void *kern = wide ? reinterpret_cast<const void *>(belt_hash_ragged_kernel<BeltTabTwo, 1024>)
                                     : reinterpret_cast<const void *>(belt_hash_ragged_kernel<BeltTabTwo, 256>);
-            static bool attr_set[2][64];
-            int dev_id = 0;
-            B2H_TRY(hipGetDevice(&dev_id));
-            if (!attr_set[wide][dev_id & 63]) {
-                B2H_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, BeltTabTwo::kBytes));
-                attr_set[wide][dev_id & 63] = true;
-            }
+            B2H_TRY(dyn_lds_once(kern, BeltTabTwo::kBytes));
             if (wide)
                 hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabTwo, 1024>), dim3((unsigned)((n + 1023) / 1024)),
                                    dim3(1024), BeltTabTwo::kBytes, st, data, off, ord, n, dig, RAGGED_LONG);
@@ -838,15 +832,7 @@ static err_t launch_fused_t(const void *d_msgs, size_t msg_len, size_t n, size_t
 {
     auto kern = hash_mac_fused_kernel<RW, HASH, MAC>;
     const size_t lds = MAC ? (size_t)BeltTabWide::kBytes : 0;
-    if (MAC) {
-        static bool attr_set[64];
-        const int dev = cur_dev();
-        if (!attr_set[dev]) {
-            B2H_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set[dev] = true;
-        }
-    }
+    if (MAC) B2H_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), lds));
     const size_t grid = (n + FUSED_WG - 1) / FUSED_WG;
     if (grid > 0x7fffffffull) return ERR_BAD_INPUT;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FUSED_WG), lds, st, (const uint4 *)d_msgs, msg_len, n,
