@@ -279,24 +279,26 @@ __device__ __forceinline__ void proj_add_complete(projT<N> &P, const projT<N> &Q
     P.Y = Y3;
 }
 
-// R = k G for ONE secret k by the 64 lanes of a wavefront (small batches: with one lane per scalar a lone wavefront walks
-// 8N dependent additions, 0.6 ms whatever the batch).  Lane j takes the 4-bit windows j, j + 64, ...: the same masked scan
-// of the window's 15 table entries as mul_base_ct (the addresses depend on the lane, not on k), then a butterfly of
-// log2(64) = 6 complete additions leaves the sum in every lane.  No branch, address or shuffle pattern depends on k.
-// Returns as mul_base_ct; every lane holds the result.
-template <int N>
+// R = k G for ONE secret k by LANES adjacent lanes of a wavefront (small batches: with one lane per scalar a lone wavefront
+// walks 8N dependent additions, 0.6 ms whatever the batch).  Lane j of the group takes the 4-bit windows j, j + LANES, ...:
+// the same masked scan of each window's 15 table entries as mul_base_ct (the addresses depend on the lane, not on k), then a
+// butterfly of log2(LANES) complete additions leaves the sum in every lane of the group.  No branch, address or shuffle
+// pattern depends on k.  LANES = 64 is the latency form (one window per lane on the 256-bit curve); 16 and 4 trade depth for
+// work and fill the device at 2^12 and 2^14 scalars (profiles/r03_sign_coop.txt).  Returns as mul_base_ct.
+template <int N, int LANES>
 __device__ __forceinline__ uint32_t mul_base_coop(feT<N> &x, feT<N> &y, const uint8_t *__restrict__ kbytes,
                                                   const uint32_t *__restrict__ gtab8)
 {
-    const int lane = (int)(threadIdx.x & 63u);
+    static_assert(LANES >= 2 && LANES <= 64 && (LANES & (LANES - 1)) == 0, "lanes per scalar: a power of two within a wavefront");
+    const int lane = (int)(threadIdx.x & (unsigned)(LANES - 1));
     feT<N> b;
 #pragma unroll
     for (int i = 0; i < N; ++i) b.v[i] = curve_b<N>()[i];
     projT<N> acc;
     fe_set_zero(acc.X); fe_set_one(acc.Y); fe_set_zero(acc.Z);          // O
 #pragma unroll 1
-    for (int t = 0; t < (8 * N + 63) / 64; ++t) {
-        const int w = lane + 64 * t;
+    for (int t = 0; t < (8 * N + LANES - 1) / LANES; ++t) {
+        const int w = lane + LANES * t;
         const bool mine = w < 8 * N;                 // not a secret
         const int wc = mine ? w : 0;
         uint32_t dg = ((uint32_t)kbytes[wc >> 1] >> (4 * (wc & 1))) & 15u;
@@ -333,7 +335,7 @@ __device__ __forceinline__ uint32_t mul_base_coop(feT<N> &x, feT<N> &y, const ui
         }
     }
 #pragma unroll 1
-    for (int s = 1; s < 64; s <<= 1) {
+    for (int s = 1; s < LANES; s <<= 1) {              // partners stay inside the aligned group of LANES lanes
         projT<N> o;
 #pragma unroll
         for (int l = 0; l < N; ++l) {
@@ -346,15 +348,15 @@ __device__ __forceinline__ uint32_t mul_base_coop(feT<N> &x, feT<N> &y, const ui
     return proj_to_affine_ct(x, y, acc);
 }
 
-// One wavefront per scalar (block = 64 lanes, grid = n); modes and outputs as bign_mulbase_ct_kernel.
-template <int N, int MODE, bool X_ONLY>
+// LANES lanes per scalar (block = one wavefront = 64 / LANES scalars); modes and outputs as bign_mulbase_ct_kernel.
+template <int N, int MODE, bool X_ONLY, int LANES>
 __global__ __launch_bounds__(64)
 void bign_mulbase_coop_kernel(const uint8_t *__restrict__ scalars, size_t n, uint32_t *__restrict__ codes,
                               uint8_t *__restrict__ xy_out, const uint32_t *__restrict__ gtab8)
 {
     constexpr int NO = 4 * N;
-    const size_t idx = blockIdx.x;
-    if (idx >= n) return;
+    const size_t idx = (size_t)blockIdx.x * (64 / LANES) + threadIdx.x / LANES;
+    if (idx >= n) return;                            // a whole group leaves: no partner of a working lane goes missing
     uint32_t valid = ~0u;
     if constexpr (MODE == 1) {
         uint32_t k[N];
@@ -362,9 +364,9 @@ void bign_mulbase_coop_kernel(const uint8_t *__restrict__ scalars, size_t n, uin
         valid = ct_in_range_q(k);
     }
     feT<N> x, y;
-    const uint32_t inf = mul_base_coop(x, y, scalars + NO * idx, gtab8);
+    const uint32_t inf = mul_base_coop<N, LANES>(x, y, scalars + NO * idx, gtab8);
     if constexpr (MODE == 2) valid = ~inf;
-    if (threadIdx.x != 0) return;
+    if ((threadIdx.x & (unsigned)(LANES - 1)) != 0) return;
     if constexpr (MODE == 1) codes[idx] = ct_sel(valid, (uint32_t)ERR_OK, ERR_BAD_PRIVKEY_V);
     if constexpr (MODE == 2) codes[idx] = ct_sel(inf, (uint32_t)ERR_BAD_PARAMS, (uint32_t)ERR_OK);
     uint32_t *o = reinterpret_cast<uint32_t *>(xy_out + (X_ONLY ? NO : 2 * NO) * idx);
@@ -742,12 +744,32 @@ static err_t sign_scratch(hipStream_t st, size_t n, SignScratch &S)
     return ERR_OK;
 }
 
-// k G by one lane per scalar (throughput) or one wavefront per scalar (latency): g_sign_coop_max = largest batch the wavefront
-// form takes (bee2hip_internal_tune 10).  profiles/r03_sign_coop.txt: 120 against 660-700 us up to 2^10 scalars on the 256-bit
-// curve, 0.40 against 4.0-4.1 ms on the 512-bit one; the forms meet between 2^13 and 2^14 on all three.
-static int g_sign_coop_max = 1 << 13;
-void set_sign_coop(int v) { g_sign_coop_max = v; }
-static inline bool mulbase_coop(size_t n) { return n <= (size_t)(g_sign_coop_max < 0 ? 0 : g_sign_coop_max); }
+// k G by one lane per scalar (throughput) or by 64 / 16 / 4 lanes per scalar (latency; each form fills the device -- one
+// wavefront per SIMD -- at 2^10 / 2^12 / 2^14 scalars).  g_sign_lanes: 0 = by batch size, 1 = always one lane, 4 / 16 / 64
+// forced (bee2hip_internal_tune 10).  tools/sign_coop_ab.py measures all four at every size on the three curves
+// (profiles/r03_sign_coop.txt): 64 lanes up to 2^10 scalars, 16 up to 2^13, 4 up to 2^16 (2^15 for public keys on the 512-bit
+// curve), one lane above -- e.g. 2^12 signatures on the 256-bit curve in 0.22 instead of 0.77 ms, 2^15 in 0.43.
+static int g_sign_lanes = 0;
+void set_sign_coop(int v) { g_sign_lanes = v; }
+static inline int mulbase_lanes(size_t n, bool wide_xy)
+{
+    if (g_sign_lanes == 1 || g_sign_lanes == 4 || g_sign_lanes == 16 || g_sign_lanes == 64) return g_sign_lanes;
+    return n <= ((size_t)1 << 10) ? 64 : n <= ((size_t)1 << 13) ? 16 : n <= ((size_t)1 << (wide_xy ? 15 : 16)) ? 4 : 1;
+}
+template <int N, int MODE, bool X_ONLY>
+static void launch_mulbase(int lanes, const uint8_t *scalars, size_t n, uint32_t *codes, uint8_t *out, const uint32_t *tab, hipStream_t st)
+{
+    const auto grid = [n](int l) { return dim3((unsigned)((n * (size_t)l + 63) / 64)); };
+    if (lanes == 64)
+        hipLaunchKernelGGL((bign_mulbase_coop_kernel<N, MODE, X_ONLY, 64>), grid(64), dim3(64), 0, st, scalars, n, codes, out, tab);
+    else if (lanes == 16)
+        hipLaunchKernelGGL((bign_mulbase_coop_kernel<N, MODE, X_ONLY, 16>), grid(16), dim3(64), 0, st, scalars, n, codes, out, tab);
+    else if (lanes == 4)
+        hipLaunchKernelGGL((bign_mulbase_coop_kernel<N, MODE, X_ONLY, 4>), grid(4), dim3(64), 0, st, scalars, n, codes, out, tab);
+    else
+        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, MODE, X_ONLY>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scalars, n,
+                           codes, out, tab);
+}
 
 template <int N>
 static err_t launch_bign_pubkey_calc_t(bool keygen, const void *d_privkeys, size_t n, void *d_pubkeys, void *d_codes, hipStream_t st)
@@ -755,20 +777,10 @@ static err_t launch_bign_pubkey_calc_t(bool keygen, const void *d_privkeys, size
     const uint32_t *tab = nullptr;
     err_t code = bign_table8<N>(&tab, st);
     if (code != ERR_OK) return code;
-    const unsigned grid = (unsigned)((n + 255) / 256);
-    if (mulbase_coop(n)) {
-        if (!keygen)
-            hipLaunchKernelGGL((bign_mulbase_coop_kernel<N, 1, false>), dim3((unsigned)n), dim3(64), 0, st,
-                               (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab);
-        else
-            hipLaunchKernelGGL((bign_mulbase_coop_kernel<N, 2, false>), dim3((unsigned)n), dim3(64), 0, st,
-                               (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab);
-    } else if (!keygen)
-        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 1, false>), dim3(grid), dim3(256), 0, st, (const uint8_t *)d_privkeys, n,
-                           (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab);
+    if (!keygen)
+        launch_mulbase<N, 1, false>(mulbase_lanes(n, N == 16), (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab, st);
     else
-        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 2, false>), dim3(grid), dim3(256), 0, st, (const uint8_t *)d_privkeys, n,
-                           (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab);
+        launch_mulbase<N, 2, false>(mulbase_lanes(n, N == 16), (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab, st);
     B2H_TRY(hipGetLastError());
     return ERR_OK;
 }
@@ -813,12 +825,7 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
         B2H_TRY(hipMemcpyAsync(S.k, d_aux, n * 4 * N, hipMemcpyDeviceToDevice, st));
         kptr = S.k;
     }
-    if (mulbase_coop(n))
-        hipLaunchKernelGGL((bign_mulbase_coop_kernel<N, 0, true>), dim3((unsigned)n), dim3(64), 0, st, kptr, n,
-                           (uint32_t *)nullptr, S.rx, tab);
-    else
-        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 0, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, kptr, n,
-                           (uint32_t *)nullptr, S.rx, tab);
+    launch_mulbase<N, 0, true>(mulbase_lanes(n, false), kptr, n, (uint32_t *)nullptr, S.rx, tab, st);
     {
         constexpr int ROW = (OID_MAX + 2 * 64 + 31) / 32 * 8 + 1;
         const size_t lds = BeltTabTwo::kBytes + (size_t)SIGN_WG * ROW * 4;

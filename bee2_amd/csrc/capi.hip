@@ -1479,7 +1479,7 @@ extern "C" err_t bee2hip_internal_tune(int key, int value)
     case 6: bee2hip::g_duplex_log2_states = value; return ERR_OK;     // chunk of the duplex host pipeline, bashF states (log2)
     case 7: bee2hip::g_duplex_log2_blocks = value; return ERR_OK;     //                                   belt blocks (log2)
     case 11: bee2hip::g_verify_pipe = value; return ERR_OK;           // chunked upload of big host-pointer verification batches
-    case 10: bee2hip::set_sign_coop(value); return ERR_OK;            // largest batch whose k G runs one wavefront per scalar
+    case 10: bee2hip::set_sign_coop(value); return ERR_OK;            // lanes per scalar of k G, signing side (0 = by batch size)
     case 9: bee2hip::g_duplex_ramp = value; return ERR_OK;            // ramped chunk sizes at the ends of the pipeline
     default: return ERR_BAD_INPUT;
     }

@@ -92,14 +92,14 @@ def test_golden_cases_dropin(golden, l, mulbase):
             assert rng.pos[0] == 0                    # a bad private key must not consume the generator
 
 
-@pytest.fixture(params=["lane_per_scalar", "wavefront_per_scalar"])
+@pytest.fixture(params=[1, 4, 16, 64], ids=lambda v: f"{v}_lanes_per_scalar")
 def mulbase(request):
-    """k G of the signing side: one lane per scalar (bign_mulbase_ct_kernel, the throughput form) or one wavefront per
-    scalar (bign_mulbase_coop_kernel, batches up to 2^13 by default) -- forced at every size, default restored"""
+    """k G of the signing side: one lane per scalar (bign_mulbase_ct_kernel, the throughput form) or 4 / 16 / 64 lanes per
+    scalar (bign_mulbase_coop_kernel; the product picks by batch size) -- each forced at every size, default restored"""
     eng = engine()
-    eng.lib.bee2hip_internal_tune(10, 0 if request.param == "lane_per_scalar" else 1 << 30)
+    eng.lib.bee2hip_internal_tune(10, request.param)
     yield request.param
-    eng.lib.bee2hip_internal_tune(10, 1 << 13)
+    eng.lib.bee2hip_internal_tune(10, 0)
 
 
 @pytest.mark.parametrize("l", [128, 192, 256])

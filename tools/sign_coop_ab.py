@@ -1,4 +1,4 @@
-"""k G of the signing side, one lane per scalar against one wavefront per scalar (bee2hip_internal_tune 10), by batch size:
+"""k G of the signing side by 1 / 4 / 16 / 64 lanes per scalar (bee2hip_internal_tune 10), by batch size:
 device-resident bignPubkeyCalc and bignSign2 batches, wall clock around launch + synchronize (min of 7), and the single-call
 drop-in latencies.  python tools/sign_coop_ab.py [l]   (on the GPU)"""
 import os, sys, time
@@ -23,8 +23,9 @@ def clock(fn, reps=7):
     return best * 1e6
 
 
-print(f"l = {l}: us per batch (lane per scalar / wavefront per scalar)")
-for e in (0, 4, 6, 8, 10, 11, 12, 13, 14, 15, 16):
+FORMS = (1, 4, 16, 64)
+print(f"l = {l}: us per batch, k G by 1 / 4 / 16 / 64 lanes per scalar (* = what the product picks)")
+for e in (0, 4, 8, 10, 11, 12, 13, 14, 15, 16, 17):
     n = 1 << e
     pr = rng.integers(0, 256, no * n, dtype=np.uint8); pr[no - 1::no] &= 0x7F
     privs = torch.from_numpy(pr).cuda()
@@ -32,23 +33,27 @@ for e in (0, 4, 6, 8, 10, 11, 12, 13, 14, 15, 16):
     pubs = torch.empty(2 * no * n, dtype=torch.uint8, device="cuda")
     sigs = torch.empty(sg * n, dtype=torch.uint8, device="cuda")
     c1 = torch.empty(n, dtype=torch.int32, device="cuda")
-    row = []
-    keep = []
-    for v in (0, 1 << 30):
+    row, keep = [], []
+    for v in FORMS:
+        if v > 1 and n * v > (1 << 21):
+            row.append(None); continue
         L.bee2hip_internal_tune(10, v)
         tp = clock(lambda: eng.bignPubkeyCalcL_batch_dev(l, privs, pubs, c1))
         ts = clock(lambda: eng.bignSign2L_batch_dev(l, oid, hashes, privs, sigs, c1))
         torch.cuda.synchronize()
         keep.append((pubs.clone(), sigs.clone()))
         row.append((tp, ts))
-    assert torch.equal(keep[0][0], keep[1][0]) and torch.equal(keep[0][1], keep[1][1])
-    print(f"  n = 2^{e:<2d}  pubkey calc {row[0][0]:8.1f} / {row[1][0]:8.1f}    sign2 {row[0][1]:8.1f} / {row[1][1]:8.1f}", flush=True)
+    assert all(torch.equal(keep[0][0], k[0]) and torch.equal(keep[0][1], k[1]) for k in keep)
+    L.bee2hip_internal_tune(10, 0)
+    auto = clock(lambda: eng.bignSign2L_batch_dev(l, oid, hashes, privs, sigs, c1))
+    fmt = lambda i: " / ".join("      --" if r is None else f"{r[i]:8.1f}" for r in row)
+    print(f"  n = 2^{e:<2d}  pubkey calc {fmt(0)}    sign2 {fmt(1)}    product sign2 {auto:8.1f}", flush=True)
 
 P = eng.bignParamsStd(E.CURVE_NAME[l])
 priv = bytes(pr[:no]); h = bytes(range(no))
-for v in (0, 1 << 30):
+for v in (1, 0):
     L.bee2hip_internal_tune(10, v)
     tc = clock(lambda: eng.bignPubkeyCalc(P, priv), reps=20)
     ts = clock(lambda: eng.bignSign2(P, oid, h, priv, None), reps=20)
-    print(f"  drop-in single call, {'wavefront' if v else 'lane'} per scalar: bignPubkeyCalc {tc:7.1f} us   bignSign2 {ts:7.1f} us")
-L.bee2hip_internal_tune(10, 1 << 13)
+    print(f"  drop-in single call, {'product (64 lanes)' if v == 0 else 'one lane'} per scalar: bignPubkeyCalc {tc:7.1f} us   bignSign2 {ts:7.1f} us")
+L.bee2hip_internal_tune(10, 0)
