@@ -664,12 +664,27 @@ def main():
             "config": {"workload": f"bignSign2 batch: {n} (hash, private key) pairs per GPU on bign-curve256v1, no additional input; "
                                    "constant-time kernels (nonce by belt-hash + belt-wbl, comb with full-row table scans, "
                                    "complete additions, inversion by a fixed number of division steps); every signature verified afterwards (untimed)"},
-            "roofline": {"kernels": "bign_sign_nonce + bign_mulbase_ct + bign_sign_tail", "bound": "valu-int", "avg_batch_ms": ms_sign,
+            "roofline": {"kernels": "bign_sign_nonce + bign_mulbase_ct (one lane per signature at this size) + bign_sign_tail", "bound": "valu-int", "avg_batch_ms": ms_sign,
                          "mads_per_signature": mads, "achieved": mads * n / (ms_sign * 1e-3) / 1e12, "peak": MAD_PEAK_T,
                          "unit": "T v_mad_u64_u32 lane-ops/s", "frac": mads * n / (ms_sign * 1e-3) / 1e12 / MAD_PEAK_T,
                          "note": "same multiplier formulation as verification (each mad paired with a half-rate addc: 0.5 is the ceiling)"},
             "pubkey_calc": {"value": N * n * ks / el_k, "unit": "keys/s", "ms_per_step": el_k / ks * 1e3, "avg_batch_ms": ms_calc},
         }
+        if dist.rank == 0:
+            # prefixes of the same device-resident batch: k G runs on 64 / 16 / 4 lanes per signature up to 2^10 / 2^13 / 2^16
+            # signatures, one lane above (profiles/r03_sign_coop.txt); wall clock around launch + synchronise, best of 5
+            small = {}
+            for e in (0, 10, 12, 14, 15, 16):
+                m = 1 << e
+                best = 1e9
+                for _ in range(6):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    eng.bignSign2L_batch_dev(l, LEVEL_OID[l], hsh[: no * m], privs[: no * m], sigs[: sg * m], sc[:m])
+                    torch.cuda.synchronize()
+                    best = min(best, time.perf_counter() - t0)
+                small[f"2^{e}"] = {"ms_per_batch": best * 1e3, "signatures_per_s": m / best}
+            others["bignSign2"]["batch_size_sweep"] = small
         if do_cpu:
             import refgen
             if refgen.have_ref():
