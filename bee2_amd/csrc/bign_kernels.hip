@@ -917,6 +917,49 @@ void bign_gtable16_kernel(const uint4 *__restrict__ gtab8, uint4 *__restrict__ g
     store_aff(e, x, y);
 }
 
+// Table of the signing side's one-lane kernel (round 3): signed 6-bit windows, entry (i, j) = j 2^(6i) G, j = 1..32, at
+// index i * 32 + j - 1; W6 = ceil((32N + 1) / 6) windows (43 / 65 / 86), the last one takes what is left of the scalar
+// plus the carry of the recoding (at most 16 / 1 / 4).  From the seed table: j 2^(6i) = lo 2^(8a) + hi 2^(8a + 8); the one
+// multiple outside it that a digit can ask for is 2^(32N) G = 2 (128 2^(32N - 8) G).  Entries no digit reaches are zero.
+template <int N> struct Win6 { static constexpr int W = (32 * N + 1 + 5) / 6; };
+template <int N>
+__global__ __launch_bounds__(64)
+void bign_gtable6_kernel(const uint4 *__restrict__ gtab8, uint4 *__restrict__ gtab6)
+{
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= Win6<N>::W * 32) return;
+    const int i = id / 32, j = id % 32 + 1;
+    const int a = (6 * i) >> 3, r = (6 * i) & 7;
+    const int v = j << r, part[2] = {v & 255, v >> 8};
+    uint4 *e = gtab6 + (size_t)id * (N / 2);
+    jacT<N> T, E;
+    fe_set_zero(T.X); fe_set_one(T.Y); fe_set_zero(T.Z);
+    bool reachable = true;
+    for (int h = 0; h < 2; ++h) {
+        const int m = part[h], win = a + h;
+        if (m == 0) continue;
+        affT<N> A;
+        if (win < 4 * N) {
+            load_aff(A, gtab8 + ((size_t)win * GT8_ENTRIES + m) * (N / 2));
+            E.X = A.x; E.Y = A.y; fe_set_one(E.Z);
+        } else if (win == 4 * N && m == 1) {
+            load_aff(A, gtab8 + ((size_t)(4 * N - 1) * GT8_ENTRIES + 128) * (N / 2));
+            E.X = A.x; E.Y = A.y; fe_set_one(E.Z);
+            jac_dbl(E);
+        } else {
+            reachable = false;
+            continue;
+        }
+        jac_add_complete(T, E);
+    }
+    if (!reachable) { for (int k = 0; k < N / 2; ++k) e[k] = make_uint4(0, 0, 0, 0); return; }
+    feT<N> x, y;
+    to_affine(x, y, T);
+    fe_canon(x, x);
+    fe_canon(y, y);
+    store_aff(e, x, y);
+}
+
 // -------------------------------------------------------------- pubkey val ---
 // bignPubkeyValEc (bign_misc.c:319-352): both coordinates < p (qrFrom) and the point on the curve,
 // ecpIsOnA (src/math/ecp/ecp_a.c:36-60): (x^2 + a) x + b == y^2 with a = p - 3 on all three
@@ -1062,6 +1105,7 @@ __global__ void bign_debug_fe_kernel(int op, const uint32_t *a, const uint32_t *
 struct BignDevice {
     uint4 *gtab8[3] = {nullptr, nullptr, nullptr};     // 8-bit seed table per curve (index N/4 - 2): 4N x 256 affine points
     uint4 *gtab[3] = {nullptr, nullptr, nullptr};      // 16-bit comb table per curve, built from the seed table
+    uint4 *gtab6[3] = {nullptr, nullptr, nullptr};     // signed 6-bit windows (signing side, one lane per scalar)
 };
 static BignDevice g_bign[64];
 static std::mutex g_bign_mu;          // table construction is per device, shared by threads
@@ -1095,6 +1139,31 @@ static err_t bign_table8(const uint32_t **out, hipStream_t st)
     const err_t code = bign_table8_locked<N>(&t, st);
     *out = reinterpret_cast<const uint32_t *>(t);
     return code;
+}
+
+// seed table and the signed 6-bit table made from it (88 / 200 / 352 KiB)
+template <int N>
+static err_t bign_table6(const uint32_t **out8, const uint32_t **out6, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_bign_mu);
+    uint4 *t8 = nullptr;
+    err_t code = bign_table8_locked<N>(&t8, st);
+    if (code != ERR_OK) return code;
+    int dev = 0;
+    B2H_TRY(hipGetDevice(&dev));
+    uint4 *&slot = g_bign[dev].gtab6[N / 4 - 2];
+    if (!slot) {
+        uint4 *t6 = nullptr;
+        const size_t entries = (size_t)Win6<N>::W * 32;
+        if (hipMalloc((void **)&t6, entries * 8 * N) != hipSuccess) { (void)hipGetLastError(); return ERR_OUTOFMEMORY; }
+        hipLaunchKernelGGL(bign_gtable6_kernel<N>, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, st, (const uint4 *)t8, t6);
+        B2H_TRY(hipGetLastError());
+        B2H_TRY(hipStreamSynchronize(st));
+        slot = t6;
+    }
+    *out8 = reinterpret_cast<const uint32_t *>(t8);
+    *out6 = reinterpret_cast<const uint32_t *>(slot);
+    return ERR_OK;
 }
 
 template <int N>

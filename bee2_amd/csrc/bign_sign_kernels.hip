@@ -217,6 +217,63 @@ __device__ __forceinline__ uint32_t proj_to_affine_ct(feT<N> &x, feT<N> &y, cons
     return ct_is_zero(zc.v) | ~ct_is_zero(chk.v);  // all-ones iff k G = O (or the inversion check failed)
 }
 
+// The same with SIGNED 6-bit windows (round 3): W6 = ceil((32N + 1) / 6) complete additions instead of 8N (43 / 65 / 86
+// against 64 / 96 / 128), each after a masked scan of the window's 32 table entries |d| 2^(6w) G (gtab6, bign_kernels.hip
+// bign_gtable6_kernel) and a masked negation of y.  The digits come out of the scalar low to high with the usual carry:
+// t = bits + carry in [0, 64], d = t - 64 [t >= 32] in [-32, 31]; the last window holds what is left of k plus the carry
+// (<= 16 / 1 / 4), never negative, so no carry leaves it.  Nothing but masks touches d.
+template <int N>
+__device__ __forceinline__ uint32_t mul_base_ct6(feT<N> &x, feT<N> &y, const uint32_t (&k)[N], const uint32_t *__restrict__ gtab6)
+{
+    uint32_t kk[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) kk[i] = k[i];
+    feT<N> b;
+#pragma unroll
+    for (int i = 0; i < N; ++i) b.v[i] = curve_b<N>()[i];
+    projT<N> acc;
+    fe_set_zero(acc.X); fe_set_one(acc.Y); fe_set_zero(acc.Z);          // O
+    uint32_t carry = 0;
+#pragma unroll 1
+    for (int w = 0; w < Win6<N>::W; ++w) {
+        const uint32_t t = (kk[0] & 63u) + carry;                       // 0 .. 64
+#pragma unroll
+        for (int i = 0; i < N - 1; ++i) kk[i] = __builtin_amdgcn_alignbit(kk[i + 1], kk[i], 6);
+        kk[N - 1] >>= 6;
+        carry = (t + 32u) >> 6;                                         // 1 iff t >= 32
+        const uint32_t d = t - (carry << 6);                            // two's complement of the digit
+        const uint32_t neg = (uint32_t)((int32_t)d >> 31);              // all-ones iff d < 0
+        const uint32_t mag = (d ^ neg) - neg;                           // |d| in 0 .. 32
+        const uint32_t *row = gtab6 + (size_t)w * 32 * (2 * N);         // depends on w only: scalar loads
+        affT<N> E;
+        fe_set_zero(E.x); fe_set_zero(E.y);
+#pragma unroll 8
+        for (int j = 1; j <= 32; ++j) {
+            const uint32_t m = ct_eq_small(mag, (uint32_t)j);
+            const uint32_t *e = row + (size_t)(j - 1) * (2 * N);
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                E.x.v[l] = bitop3<0xF8>(E.x.v[l], e[l], m);             // a | (b & c)
+                E.y.v[l] = bitop3<0xF8>(E.y.v[l], e[N + l], m);
+            }
+        }
+        feT<N> ny;
+        fe_neg(ny, E.y);                                                // p - y (p for the dummy entry of digit 0)
+#pragma unroll
+        for (int l = 0; l < N; ++l) E.y.v[l] = ct_sel(neg, ny.v[l], E.y.v[l]);
+        projT<N> sum = acc;
+        proj_madd_complete(sum, E, b);                                  // digit 0: (0, 0) is not a point; the old accumulator is kept
+        const uint32_t keep = ct_eq_small(mag, 0u);
+#pragma unroll
+        for (int l = 0; l < N; ++l) {
+            acc.X.v[l] = ct_sel(keep, acc.X.v[l], sum.X.v[l]);
+            acc.Y.v[l] = ct_sel(keep, acc.Y.v[l], sum.Y.v[l]);
+            acc.Z.v[l] = ct_sel(keep, acc.Z.v[l], sum.Z.v[l]);
+        }
+    }
+    return proj_to_affine_ct(x, y, acc);
+}
+
 template <int N>
 __device__ __forceinline__ void load_words_bytes(uint32_t (&r)[N], const uint8_t *p)
 {
@@ -388,10 +445,10 @@ void bign_mulbase_coop_kernel(const uint8_t *__restrict__ scalars, size_t n, uin
 #ifndef SIGN_MULBASE_WAVES
 #define SIGN_MULBASE_WAVES 3        // 168 VGPRs, 15 spilled: +2.2 % over 2 (186 VGPRs); 4 (128 VGPRs, 110-124 spilled): -31 %
 #endif
-template <int N, int MODE, bool X_ONLY>
+template <int N, int MODE, bool X_ONLY, bool W6 = false>
 __global__ __launch_bounds__(256, (N == 8 ? SIGN_MULBASE_WAVES : 1))
 void bign_mulbase_ct_kernel(const uint8_t *__restrict__ scalars, size_t n, uint32_t *__restrict__ codes,
-                            uint8_t *__restrict__ xy_out, const uint32_t *__restrict__ gtab8)
+                            uint8_t *__restrict__ xy_out, const uint32_t *__restrict__ gtab8)      // W6: the signed 6-bit table
 {
     constexpr int NO = 4 * N;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -404,7 +461,9 @@ void bign_mulbase_ct_kernel(const uint8_t *__restrict__ scalars, size_t n, uint3
         codes[idx] = ct_sel(valid, (uint32_t)ERR_OK, ERR_BAD_PRIVKEY_V);
     }
     feT<N> x, y;
-    const uint32_t inf = mul_base_ct(x, y, k, gtab8);
+    uint32_t inf;
+    if constexpr (W6) inf = mul_base_ct6(x, y, k, gtab8);
+    else inf = mul_base_ct(x, y, k, gtab8);
     if constexpr (MODE == 2) {
         valid = ~inf;
         codes[idx] = ct_sel(inf, (uint32_t)ERR_BAD_PARAMS, (uint32_t)ERR_OK);
@@ -745,19 +804,26 @@ static err_t sign_scratch(hipStream_t st, size_t n, SignScratch &S)
 }
 
 // k G by one lane per scalar (throughput) or by 64 / 16 / 4 lanes per scalar (latency; each form fills the device -- one
-// wavefront per SIMD -- at 2^10 / 2^12 / 2^14 scalars).  g_sign_lanes: 0 = by batch size, 1 = always one lane, 4 / 16 / 64
-// forced (bee2hip_internal_tune 10).  tools/sign_coop_ab.py measures all four at every size on the three curves
-// (profiles/r03_sign_coop.txt): 64 lanes up to 2^10 scalars, 16 up to 2^13, 4 up to 2^16 (2^15 for public keys on the 512-bit
-// curve), one lane above -- e.g. 2^12 signatures on the 256-bit curve in 0.22 instead of 0.77 ms, 2^15 in 0.43.
+// wavefront per SIMD -- at 2^10 / 2^12 / 2^14 scalars).  g_sign_lanes: 0 = by batch size, 1 / 101 = always one lane (signed
+// 6-bit / unsigned 4-bit windows), 4 / 16 / 64 forced (bee2hip_internal_tune 10).  tools/sign_coop_ab.py measures all five at
+// every size on the three curves (profiles/r03_sign_coop.txt): 64 lanes up to 2^10 scalars, 16 up to 2^13, 4 up to 2^15, one
+// lane with signed 6-bit windows above -- except on the 512-bit curve beyond 2^16 scalars, where the 4-bit windows stay faster
+// once several wavefronts share a SIMD (12.6 against 10.4 ms at 2^18).
 static int g_sign_lanes = 0;
 void set_sign_coop(int v) { g_sign_lanes = v; }
-static inline int mulbase_lanes(size_t n, bool wide_xy)
+static inline int mulbase_lanes(size_t n, int N)
 {
-    if (g_sign_lanes == 1 || g_sign_lanes == 4 || g_sign_lanes == 16 || g_sign_lanes == 64) return g_sign_lanes;
-    return n <= ((size_t)1 << 10) ? 64 : n <= ((size_t)1 << 13) ? 16 : n <= ((size_t)1 << (wide_xy ? 15 : 16)) ? 4 : 1;
+    if (g_sign_lanes == 1 || g_sign_lanes == 4 || g_sign_lanes == 16 || g_sign_lanes == 64 || g_sign_lanes == 101) return g_sign_lanes;
+    if (n <= ((size_t)1 << 10)) return 64;
+    if (n <= ((size_t)1 << 13)) return 16;
+    if (n <= ((size_t)1 << 15)) return 4;
+    return N == 16 && n > ((size_t)1 << 16) ? 101 : 1;
 }
+// lanes: 64 / 16 / 4 = cooperative forms on the 4-bit windows of the seed table; 1 = one lane per scalar, signed 6-bit windows
+// (tab6); 101 = one lane per scalar on the 4-bit windows (the round-2 kernel, kept for A/B and as a second opinion in the tests)
 template <int N, int MODE, bool X_ONLY>
-static void launch_mulbase(int lanes, const uint8_t *scalars, size_t n, uint32_t *codes, uint8_t *out, const uint32_t *tab, hipStream_t st)
+static void launch_mulbase(int lanes, const uint8_t *scalars, size_t n, uint32_t *codes, uint8_t *out, const uint32_t *tab,
+                           const uint32_t *tab6, hipStream_t st)
 {
     const auto grid = [n](int l) { return dim3((unsigned)((n * (size_t)l + 63) / 64)); };
     if (lanes == 64)
@@ -766,21 +832,24 @@ static void launch_mulbase(int lanes, const uint8_t *scalars, size_t n, uint32_t
         hipLaunchKernelGGL((bign_mulbase_coop_kernel<N, MODE, X_ONLY, 16>), grid(16), dim3(64), 0, st, scalars, n, codes, out, tab);
     else if (lanes == 4)
         hipLaunchKernelGGL((bign_mulbase_coop_kernel<N, MODE, X_ONLY, 4>), grid(4), dim3(64), 0, st, scalars, n, codes, out, tab);
-    else
-        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, MODE, X_ONLY>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scalars, n,
+    else if (lanes == 101)
+        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, MODE, X_ONLY, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scalars, n,
                            codes, out, tab);
+    else
+        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, MODE, X_ONLY, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scalars, n,
+                           codes, out, tab6);
 }
 
 template <int N>
 static err_t launch_bign_pubkey_calc_t(bool keygen, const void *d_privkeys, size_t n, void *d_pubkeys, void *d_codes, hipStream_t st)
 {
-    const uint32_t *tab = nullptr;
-    err_t code = bign_table8<N>(&tab, st);
+    const uint32_t *tab = nullptr, *tab6 = nullptr;
+    err_t code = bign_table6<N>(&tab, &tab6, st);
     if (code != ERR_OK) return code;
     if (!keygen)
-        launch_mulbase<N, 1, false>(mulbase_lanes(n, N == 16), (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab, st);
+        launch_mulbase<N, 1, false>(mulbase_lanes(n, N), (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab, tab6, st);
     else
-        launch_mulbase<N, 2, false>(mulbase_lanes(n, N == 16), (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab, st);
+        launch_mulbase<N, 2, false>(mulbase_lanes(n, N), (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab, tab6, st);
     B2H_TRY(hipGetLastError());
     return ERR_OK;
 }
@@ -799,8 +868,8 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
     OidArg oa;
     err_t code = make_oid_arg(oa, oid_der, oid_len, st);
     if (code != ERR_OK) return code;
-    const uint32_t *tab = nullptr;
-    code = bign_table8<N>(&tab, st);
+    const uint32_t *tab = nullptr, *tab6 = nullptr;
+    code = bign_table6<N>(&tab, &tab6, st);
     if (code != ERR_OK) return code;
     SignScratch S;
     code = sign_scratch<N>(st, n, S);
@@ -825,7 +894,7 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
         B2H_TRY(hipMemcpyAsync(S.k, d_aux, n * 4 * N, hipMemcpyDeviceToDevice, st));
         kptr = S.k;
     }
-    launch_mulbase<N, 0, true>(mulbase_lanes(n, false), kptr, n, (uint32_t *)nullptr, S.rx, tab, st);
+    launch_mulbase<N, 0, true>(mulbase_lanes(n, N), kptr, n, (uint32_t *)nullptr, S.rx, tab, tab6, st);
     {
         constexpr int ROW = (OID_MAX + 2 * 64 + 31) / 32 * 8 + 1;
         const size_t lds = BeltTabTwo::kBytes + (size_t)SIGN_WG * ROW * 4;

@@ -92,10 +92,11 @@ def test_golden_cases_dropin(golden, l, mulbase):
             assert rng.pos[0] == 0                    # a bad private key must not consume the generator
 
 
-@pytest.fixture(params=[1, 4, 16, 64], ids=lambda v: f"{v}_lanes_per_scalar")
+@pytest.fixture(params=[1, 101, 4, 16, 64], ids=lambda v: "1_lane_4bit_windows" if v == 101 else f"{v}_lanes_per_scalar")
 def mulbase(request):
-    """k G of the signing side: one lane per scalar (bign_mulbase_ct_kernel, the throughput form) or 4 / 16 / 64 lanes per
-    scalar (bign_mulbase_coop_kernel; the product picks by batch size) -- each forced at every size, default restored"""
+    """k G of the signing side: one lane per scalar (bign_mulbase_ct_kernel: signed 6-bit windows, the throughput form; 101 =
+    its round-2 form on unsigned 4-bit windows) or 4 / 16 / 64 lanes per scalar (bign_mulbase_coop_kernel; the product picks
+    by batch size) -- each forced at every size, default restored"""
     eng = engine()
     eng.lib.bee2hip_internal_tune(10, request.param)
     yield request.param
@@ -159,6 +160,10 @@ def test_base_point_multiples_of_special_scalars(orc, l, mulbase):
     ds = [1, 2, 15, 16, 17, q - 1, q - 2, q >> 1, 0, q, q + 1, (1 << (8 * no)) - 1,
           int("f0" * no, 16) % q, int("0f" * no, 16) % q, int("01" * no, 16), 1 << (8 * no - 5)]
     ds += [1 << (4 * j) for j in range(1, 2 * no, 7)] + [15 << (4 * j) for j in range(0, 2 * no - 1, 5)]
+    # signed 6-bit windows: every window 32 (digit -32 + carry), 31 (largest positive), 33, 63 (carry chains), mixtures
+    bits = 8 * no
+    rep = lambda pat: sum(v << (6 * i) for i, v in enumerate((pat * (bits // 6 + 2))[: bits // 6 + 1])) % (1 << (bits - 1))
+    ds += [rep([32]), rep([31]), rep([33]), rep([63]), rep([31, 32]), rep([32, 63, 0]), rep([63, 63, 31, 0, 32]), rep([0, 0, 32])]
     privs = b"".join(d.to_bytes(no, "little") for d in ds)
     code, pubs, codes = eng.bignPubkeyCalc_batch(P, privs)
     assert code == 0
