@@ -222,7 +222,38 @@ __device__ __forceinline__ uint32_t proj_to_affine_ct(feT<N> &x, feT<N> &y, cons
 // bign_gtable6_kernel) and a masked negation of y.  The digits come out of the scalar low to high with the usual carry:
 // t = bits + carry in [0, 64], d = t - 64 [t >= 32] in [-32, 31]; the last window holds what is left of k plus the carry
 // (<= 16 / 1 / 4), never negative, so no carry leaves it.  Nothing but masks touches d.
+// JAC: the accumulator in Jacobian coordinates and the mixed addition 8M + 3S (madd-2007-bl shape, as jac_madd of the
+// verification side, written here without its flags) instead of the complete 11M + 2 m_b one.  The formula is not complete, the
+// SCHEDULE makes it safe: before window w the accumulator is A G with |A| <= 32 (64^w - 1) / 63 < 64^w <= |d_w 64^w|, all below
+// q / 2 up to the last window, so A = +-d_w 64^w (mod q) cannot happen and A = 0 only while every digit so far was 0 -- that
+// state is carried as a mask (the first non-zero digit SETS the accumulator).  In the last window d 64^w may pass q; the one
+// collision is k = 0 (mod q), where H = 0, r != 0 and the formula returns Z3 = Z1 H = 0: the point at infinity, which is the
+// right answer and is reported.  (k = q is reachable in key generation only, which takes any d below 2^(2l).)
 template <int N>
+__device__ __forceinline__ void jac_madd_ct(jacT<N> &T, const affT<N> &E)
+{
+    feT<N> Z1Z1, U2, S2, H, HH, HHH, r, V, t;
+    fe_sqr(Z1Z1, T.Z);
+    fe_mul(U2, E.x, Z1Z1);
+    fe_mul(t, T.Z, Z1Z1);
+    fe_mul(S2, E.y, t);
+    fe_sub(H, U2, T.X);
+    fe_sub(r, S2, T.Y);
+    fe_sqr(HH, H);
+    fe_mul(HHH, H, HH);
+    fe_mul(V, T.X, HH);
+    fe_mul(T.Z, T.Z, H);                                // Z3 = Z1 H
+    fe_sqr(t, r);
+    fe_sub(t, t, HHH);
+    fe_dbl(U2, V);
+    fe_sub(T.X, t, U2);                                 // X3 = r^2 - H^3 - 2 V
+    fe_sub(t, V, T.X);
+    fe_mul(t, r, t);
+    fe_mul(S2, T.Y, HHH);
+    fe_sub(T.Y, t, S2);                                 // Y3 = r (V - X3) - Y1 H^3
+}
+
+template <int N, bool JAC>
 __device__ __forceinline__ uint32_t mul_base_ct6(feT<N> &x, feT<N> &y, const uint32_t (&k)[N], const uint32_t *__restrict__ gtab6)
 {
     uint32_t kk[N];
@@ -233,6 +264,11 @@ __device__ __forceinline__ uint32_t mul_base_ct6(feT<N> &x, feT<N> &y, const uin
     for (int i = 0; i < N; ++i) b.v[i] = curve_b<N>()[i];
     projT<N> acc;
     fe_set_zero(acc.X); fe_set_one(acc.Y); fe_set_zero(acc.Z);          // O
+    jacT<N> J;
+    fe_set_zero(J.X); fe_set_one(J.Y); fe_set_zero(J.Z);
+    uint32_t at_inf = ~0u;                                              // JAC: all-ones while no non-zero digit has been met
+    feT<N> one;
+    fe_set_one(one);
     uint32_t carry = 0;
 #pragma unroll 1
     for (int w = 0; w < Win6<N>::W; ++w) {
@@ -261,17 +297,53 @@ __device__ __forceinline__ uint32_t mul_base_ct6(feT<N> &x, feT<N> &y, const uin
         fe_neg(ny, E.y);                                                // p - y (p for the dummy entry of digit 0)
 #pragma unroll
         for (int l = 0; l < N; ++l) E.y.v[l] = ct_sel(neg, ny.v[l], E.y.v[l]);
-        projT<N> sum = acc;
-        proj_madd_complete(sum, E, b);                                  // digit 0: (0, 0) is not a point; the old accumulator is kept
         const uint32_t keep = ct_eq_small(mag, 0u);
+        if constexpr (JAC) {
+            jacT<N> sum = J;
+            jac_madd_ct(sum, E);                                        // digit 0 or accumulator still O: computed, not used
+            const uint32_t set = at_inf & ~keep;                        // first non-zero digit: J <- (x, y, 1)
 #pragma unroll
-        for (int l = 0; l < N; ++l) {
-            acc.X.v[l] = ct_sel(keep, acc.X.v[l], sum.X.v[l]);
-            acc.Y.v[l] = ct_sel(keep, acc.Y.v[l], sum.Y.v[l]);
-            acc.Z.v[l] = ct_sel(keep, acc.Z.v[l], sum.Z.v[l]);
+            for (int l = 0; l < N; ++l) {
+                J.X.v[l] = ct_sel(keep, J.X.v[l], ct_sel(set, E.x.v[l], sum.X.v[l]));
+                J.Y.v[l] = ct_sel(keep, J.Y.v[l], ct_sel(set, E.y.v[l], sum.Y.v[l]));
+                J.Z.v[l] = ct_sel(keep, J.Z.v[l], ct_sel(set, one.v[l], sum.Z.v[l]));
+            }
+            at_inf &= keep;
+        } else {
+            projT<N> sum = acc;
+            proj_madd_complete(sum, E, b);                              // digit 0: (0, 0) is not a point; the old accumulator is kept
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                acc.X.v[l] = ct_sel(keep, acc.X.v[l], sum.X.v[l]);
+                acc.Y.v[l] = ct_sel(keep, acc.Y.v[l], sum.Y.v[l]);
+                acc.Z.v[l] = ct_sel(keep, acc.Z.v[l], sum.Z.v[l]);
+            }
         }
     }
-    return proj_to_affine_ct(x, y, acc);
+    if constexpr (JAC) {
+        // x = X / Z^2, y = Y / Z^3; Z = 0 (or nothing ever added: k = 0) is the point at infinity
+#pragma unroll
+        for (int l = 0; l < N; ++l) J.Z.v[l] &= ~at_inf;
+        feT<N> zc;
+        fe_canon(zc, J.Z);
+        const feT<N> zi = fe_inv_safegcd<N, true>(zc);
+        feT<N> chk, zi2;
+        fe_mul(chk, zc, zi);
+        fe_canon(chk, chk);
+        chk.v[0] ^= 1u;                                                 // 0 iff Z * Z^-1 == 1
+        fe_sqr(zi2, zi);
+        fe_mul(x, J.X, zi2);
+        fe_mul(zi2, zi2, zi);
+        fe_mul(y, J.Y, zi2);
+        fe_canon(x, x);
+        fe_canon(y, y);
+        const uint32_t inf = ct_is_zero(zc.v) | ~ct_is_zero(chk.v);
+#pragma unroll
+        for (int l = 0; l < N; ++l) { x.v[l] &= ~inf; y.v[l] &= ~inf; }
+        return inf;
+    } else {
+        return proj_to_affine_ct(x, y, acc);
+    }
 }
 
 template <int N>
@@ -445,10 +517,10 @@ void bign_mulbase_coop_kernel(const uint8_t *__restrict__ scalars, size_t n, uin
 #ifndef SIGN_MULBASE_WAVES
 #define SIGN_MULBASE_WAVES 3        // 168 VGPRs, 15 spilled: +2.2 % over 2 (186 VGPRs); 4 (128 VGPRs, 110-124 spilled): -31 %
 #endif
-template <int N, int MODE, bool X_ONLY, bool W6 = false>
+template <int N, int MODE, bool X_ONLY, int FORM = 0>          // FORM 0: 4-bit windows, 1: signed 6-bit + complete additions, 2: + Jacobian
 __global__ __launch_bounds__(256, (N == 8 ? SIGN_MULBASE_WAVES : 1))
 void bign_mulbase_ct_kernel(const uint8_t *__restrict__ scalars, size_t n, uint32_t *__restrict__ codes,
-                            uint8_t *__restrict__ xy_out, const uint32_t *__restrict__ gtab8)      // W6: the signed 6-bit table
+                            uint8_t *__restrict__ xy_out, const uint32_t *__restrict__ gtab8)      // FORM > 0: the signed 6-bit table
 {
     constexpr int NO = 4 * N;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -462,7 +534,8 @@ void bign_mulbase_ct_kernel(const uint8_t *__restrict__ scalars, size_t n, uint3
     }
     feT<N> x, y;
     uint32_t inf;
-    if constexpr (W6) inf = mul_base_ct6(x, y, k, gtab8);
+    if constexpr (FORM == 2) inf = mul_base_ct6<N, true>(x, y, k, gtab8);
+    else if constexpr (FORM == 1) inf = mul_base_ct6<N, false>(x, y, k, gtab8);
     else inf = mul_base_ct(x, y, k, gtab8);
     if constexpr (MODE == 2) {
         valid = ~inf;
@@ -804,23 +877,21 @@ static err_t sign_scratch(hipStream_t st, size_t n, SignScratch &S)
 }
 
 // k G by one lane per scalar (throughput) or by 64 / 16 / 4 lanes per scalar (latency; each form fills the device -- one
-// wavefront per SIMD -- at 2^10 / 2^12 / 2^14 scalars).  g_sign_lanes: 0 = by batch size, 1 / 101 = always one lane (signed
-// 6-bit / unsigned 4-bit windows), 4 / 16 / 64 forced (bee2hip_internal_tune 10).  tools/sign_coop_ab.py measures all five at
-// every size on the three curves (profiles/r03_sign_coop.txt): 64 lanes up to 2^10 scalars, 16 up to 2^13, 4 up to 2^15, one
-// lane with signed 6-bit windows above -- except on the 512-bit curve beyond 2^16 scalars, where the 4-bit windows stay faster
-// once several wavefronts share a SIMD (12.6 against 10.4 ms at 2^18).
+// wavefront per SIMD -- at 2^10 / 2^12 / 2^14 scalars).  g_sign_lanes: 0 = by batch size; 1 / 102 / 101 = always one lane
+// (signed 6-bit windows with Jacobian mixed additions / with complete additions / unsigned 4-bit windows), 4 / 16 / 64 forced
+// (bee2hip_internal_tune 10).  tools/sign_coop_ab.py measures all six at every size on the three curves
+// (profiles/r03_sign_coop.txt): 64 lanes up to 2^10 scalars, 16 up to 2^13, 4 up to 2^15, one lane above.
 static int g_sign_lanes = 0;
 void set_sign_coop(int v) { g_sign_lanes = v; }
-static inline int mulbase_lanes(size_t n, int N)
+static inline int mulbase_lanes(size_t n)
 {
-    if (g_sign_lanes == 1 || g_sign_lanes == 4 || g_sign_lanes == 16 || g_sign_lanes == 64 || g_sign_lanes == 101) return g_sign_lanes;
-    if (n <= ((size_t)1 << 10)) return 64;
-    if (n <= ((size_t)1 << 13)) return 16;
-    if (n <= ((size_t)1 << 15)) return 4;
-    return N == 16 && n > ((size_t)1 << 16) ? 101 : 1;
+    if (g_sign_lanes == 1 || g_sign_lanes == 4 || g_sign_lanes == 16 || g_sign_lanes == 64 || g_sign_lanes == 101 || g_sign_lanes == 102)
+        return g_sign_lanes;
+    return n <= ((size_t)1 << 10) ? 64 : n <= ((size_t)1 << 13) ? 16 : n <= ((size_t)1 << 15) ? 4 : 1;
 }
 // lanes: 64 / 16 / 4 = cooperative forms on the 4-bit windows of the seed table; 1 = one lane per scalar, signed 6-bit windows
-// (tab6); 101 = one lane per scalar on the 4-bit windows (the round-2 kernel, kept for A/B and as a second opinion in the tests)
+// (tab6), Jacobian mixed additions; 102 = the same windows with complete additions; 101 = one lane per scalar on the 4-bit
+// windows (the round-2 kernel) -- the last two kept for A/B and as second opinions in the tests
 template <int N, int MODE, bool X_ONLY>
 static void launch_mulbase(int lanes, const uint8_t *scalars, size_t n, uint32_t *codes, uint8_t *out, const uint32_t *tab,
                            const uint32_t *tab6, hipStream_t st)
@@ -833,10 +904,13 @@ static void launch_mulbase(int lanes, const uint8_t *scalars, size_t n, uint32_t
     else if (lanes == 4)
         hipLaunchKernelGGL((bign_mulbase_coop_kernel<N, MODE, X_ONLY, 4>), grid(4), dim3(64), 0, st, scalars, n, codes, out, tab);
     else if (lanes == 101)
-        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, MODE, X_ONLY, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scalars, n,
+        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, MODE, X_ONLY, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scalars, n,
                            codes, out, tab);
+    else if (lanes == 102)
+        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, MODE, X_ONLY, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scalars, n,
+                           codes, out, tab6);
     else
-        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, MODE, X_ONLY, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scalars, n,
+        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, MODE, X_ONLY, 2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scalars, n,
                            codes, out, tab6);
 }
 
@@ -847,9 +921,9 @@ static err_t launch_bign_pubkey_calc_t(bool keygen, const void *d_privkeys, size
     err_t code = bign_table6<N>(&tab, &tab6, st);
     if (code != ERR_OK) return code;
     if (!keygen)
-        launch_mulbase<N, 1, false>(mulbase_lanes(n, N), (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab, tab6, st);
+        launch_mulbase<N, 1, false>(mulbase_lanes(n), (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab, tab6, st);
     else
-        launch_mulbase<N, 2, false>(mulbase_lanes(n, N), (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab, tab6, st);
+        launch_mulbase<N, 2, false>(mulbase_lanes(n), (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab, tab6, st);
     B2H_TRY(hipGetLastError());
     return ERR_OK;
 }
@@ -894,7 +968,7 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
         B2H_TRY(hipMemcpyAsync(S.k, d_aux, n * 4 * N, hipMemcpyDeviceToDevice, st));
         kptr = S.k;
     }
-    launch_mulbase<N, 0, true>(mulbase_lanes(n, N), kptr, n, (uint32_t *)nullptr, S.rx, tab, tab6, st);
+    launch_mulbase<N, 0, true>(mulbase_lanes(n), kptr, n, (uint32_t *)nullptr, S.rx, tab, tab6, st);
     {
         constexpr int ROW = (OID_MAX + 2 * 64 + 31) / 32 * 8 + 1;
         const size_t lds = BeltTabTwo::kBytes + (size_t)SIGN_WG * ROW * 4;

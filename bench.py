@@ -655,15 +655,16 @@ def main():
         eng.bignVerifyL_batch_dev(l, LEVEL_OID[l], hsh, sigs, pubs, vc)        # not timed: every signature must verify
         torch.cuda.synchronize()
         # 32x32+64 multiply-adds per signature: 43 signed 6-bit windows (round 3; 64 windows of 4 bits before) x 13
-        # multiplications x (64 + 8) and 2 M for the affine coordinates; the inversion (fixed-count division steps,
+        # multiplications x (64 + 8) -- see below for the count of the Jacobian form -- and the affine coordinates; the inversion (fixed-count division steps,
         # fe_inv_safegcd<N, true>), the belt work (16 block encryptions) and the table scan have none
-        mads = 43 * 13 * 72 + 2 * 72
+        # (8 M + 3 S per Jacobian mixed addition: 8 x 72 + 3 x 52 multiply-adds with the reductions; 4 M + 1 S for x, y)
+        mads = 43 * (8 * 72 + 3 * 52) + 4 * 72 + 52
         others["bignSign2"] = {
             "metric": "bign-curve256v1 deterministic signatures/s", "value": N * n * ks / el, "unit": "signatures/s", "steps": ks,
             "ms_per_step": el / ks * 1e3, "all_verify": bool((vc == 0).all() and (sc == 0).all()),
             "config": {"workload": f"bignSign2 batch: {n} (hash, private key) pairs per GPU on bign-curve256v1, no additional input; "
                                    "constant-time kernels (nonce by belt-hash + belt-wbl, signed 6-bit windows with full-row table scans, "
-                                   "complete additions, inversion by a fixed number of division steps); every signature verified afterwards (untimed)"},
+                                   "masked Jacobian mixed additions, inversion by a fixed number of division steps); every signature verified afterwards (untimed)"},
             "roofline": {"kernels": "bign_sign_nonce + bign_mulbase_ct (one lane per signature at this size) + bign_sign_tail", "bound": "valu-int", "avg_batch_ms": ms_sign,
                          "mads_per_signature": mads, "achieved": mads * n / (ms_sign * 1e-3) / 1e12, "peak": MAD_PEAK_T,
                          "unit": "T v_mad_u64_u32 lane-ops/s", "frac": mads * n / (ms_sign * 1e-3) / 1e12 / MAD_PEAK_T,

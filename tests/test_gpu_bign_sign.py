@@ -92,10 +92,10 @@ def test_golden_cases_dropin(golden, l, mulbase):
             assert rng.pos[0] == 0                    # a bad private key must not consume the generator
 
 
-@pytest.fixture(params=[1, 101, 4, 16, 64], ids=lambda v: "1_lane_4bit_windows" if v == 101 else f"{v}_lanes_per_scalar")
+@pytest.fixture(params=[1, 101, 102, 4, 16, 64], ids=lambda v: {101: "1_lane_4bit_windows", 102: "1_lane_6bit_complete_additions"}.get(v, f"{v}_lanes_per_scalar"))
 def mulbase(request):
-    """k G of the signing side: one lane per scalar (bign_mulbase_ct_kernel: signed 6-bit windows, the throughput form; 101 =
-    its round-2 form on unsigned 4-bit windows) or 4 / 16 / 64 lanes per scalar (bign_mulbase_coop_kernel; the product picks
+    """k G of the signing side: one lane per scalar (bign_mulbase_ct_kernel: signed 6-bit windows and Jacobian mixed additions, the
+    throughput form; 102 = the same windows with complete additions, 101 = the round-2 form on unsigned 4-bit windows) or 4 / 16 / 64 lanes per scalar (bign_mulbase_coop_kernel; the product picks
     by batch size) -- each forced at every size, default restored"""
     eng = engine()
     eng.lib.bee2hip_internal_tune(10, request.param)

@@ -23,9 +23,9 @@ def clock(fn, reps=7):
     return best * 1e6
 
 
-FORMS = (101, 1, 4, 16, 64)
-print(f"l = {l}: us per batch, k G by 1 lane (4-bit windows) / 1 lane (signed 6-bit) / 4 / 16 / 64 lanes per scalar")
-for e in (0, 10, 12, 14, 16, 17, 18):
+FORMS = (101, 102, 1, 4, 16, 64)
+print(f"l = {l}: us per batch, k G by 1 lane (4-bit windows) / 1 lane (signed 6-bit, complete additions) / 1 lane (signed 6-bit, Jacobian) / 4 / 16 / 64 lanes per scalar")
+for e in (0, 14, 16, 17, 18):
     n = 1 << e
     pr = rng.integers(0, 256, no * n, dtype=np.uint8); pr[no - 1::no] &= 0x7F
     privs = torch.from_numpy(pr).cuda()
