@@ -654,18 +654,22 @@ static int num_cus()
     return g_num_cus[dev];
 }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize, once per (device, kernel) and safe from any thread (the flags used to be
-// plain static bools per call site: a benign race, but a race)
+// hipFuncAttributeMaxDynamicSharedMemorySize, once per (device, kernel) -- again only when a launch asks for more than the
+// kernel was granted so far -- and safe from any thread (the flags used to be plain static bools per call site: a benign
+// race, but a race)
 static hipError_t dyn_lds_once(const void *kern, size_t bytes)
 {
     static std::mutex mu;
-    static std::vector<std::pair<int, const void *>> done;
+    static std::vector<std::pair<std::pair<int, const void *>, size_t>> done;
     const std::pair<int, const void *> key(cur_dev(), kern);
     std::lock_guard<std::mutex> lk(mu);
-    if (std::find(done.begin(), done.end(), key) != done.end()) return hipSuccess;
+    auto it = std::find_if(done.begin(), done.end(), [&](const auto &e) { return e.first == key; });
+    if (it != done.end() && it->second >= bytes) return hipSuccess;
     const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess) done.push_back(key);
-    return e;
+    if (e != hipSuccess) return e;
+    if (it != done.end()) it->second = bytes;
+    else done.push_back({key, bytes});
+    return hipSuccess;
 }
 
 err_t upload_beltH(const uint8_t *H)

@@ -660,7 +660,7 @@ err_t sign_generic_t(const bign_params *params, int mode, const uint8_t *oid_der
         const uint8_t *tp = mode == 0 ? (const uint8_t *)d_aux : nullptr;
         hipLaunchKernelGGL(bign_sign_nonce_kernel<N>, dim3(grid), dim3(SIGN_WG), lds, st, (const uint8_t *)d_hashes,
                            (const uint8_t *)d_privkeys, tp, (uint32_t)(tp ? t_len : 0), (uint32_t)(t_shared ? 0 : t_len),
-                           mode == 2 ? (const uint8_t *)d_aux : nullptr, n, oa, qa, S.status, S.k);
+                           mode == 2 ? (const uint8_t *)d_aux : nullptr, n, oa, qa, S.status, S.k, (uint32_t)ROW);
     } else {
         hipLaunchKernelGGL(bign_sign_kcheck_kernel<N>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                            (const uint8_t *)d_privkeys, (const uint8_t *)d_aux, n, qa, S.status);

@@ -587,19 +587,22 @@ constexpr int SIGN_T_MAX = 64;                       // longest additional input
 // algorithm 6.3.3 (bign_sign.c:192-216): theta = belt-hash(oid || d || t), k = H, repeat k <- belt-wbl_theta(k) until
 // 0 < k < q.  Also range-checks d (:185-189).  Writes k (4N octets per signature) and status.
 // t: n x t_len octets (t_stride = t_len) or one shared string (t_stride = 0); may be null with t_len = 0.
-template <int N>
-__global__ __launch_bounds__(SIGN_WG)
+// row_words: 32-bit words of a lane's LDS row (odd; sign_row_words() of the message this launch hashes).  The rows used to be
+// sized for the longest OID and t the kernel accepts (65 words: with the 64 KiB table one workgroup of 256 lanes per CU, i.e.
+// ONE wavefront per SIMD walking dependent block encryptions); sized for the message at hand, 1024 lanes share a table.
+template <int N, int WG = SIGN_WG>
+__global__ __launch_bounds__(WG)
 void bign_sign_nonce_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ privkeys,
                             const uint8_t *__restrict__ t, uint32_t t_len, uint32_t t_stride,
                             const uint8_t *__restrict__ theta_in, size_t n, OidArg oid, QArg<N> qa,
-                            uint32_t *__restrict__ status, uint8_t *__restrict__ k_out)
+                            uint32_t *__restrict__ status, uint8_t *__restrict__ k_out, uint32_t row_words)
 {
     constexpr int NO = 4 * N;
-    constexpr int ROW = (OID_MAX + 64 + SIGN_T_MAX + 31) / 32 * 8 + 1;     // words, odd stride
+    const uint32_t ROW = row_words;
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     uint8_t *s_tab = s_dyn;
     uint32_t *s_rows = reinterpret_cast<uint32_t *>(s_dyn + BeltTabTwo::kBytes);
-    BeltTabTwo::fill(s_tab, threadIdx.x, SIGN_WG);
+    BeltTabTwo::fill(s_tab, threadIdx.x, WG);
     __syncthreads();
     const BeltTabTwo T(s_tab);
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -785,18 +788,19 @@ __device__ __forceinline__ void sub_mod_q_ct(uint32_t (&c)[N], const uint32_t (&
 
 // s0 = belt-hash(oid || <x_R> || H)[0 .. l bits), s1 = (k - (s0 + 2^l) d - H) mod q (bign_sign.c:221-238);
 // wipes k.  x_R and H are public, so this hash could use any table; it shares BeltTabTwo with the nonce kernel.
-template <int N>
-__global__ __launch_bounds__(SIGN_WG)
+template <int N, int WG = SIGN_WG>
+__global__ __launch_bounds__(WG)
 void bign_sign_tail_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ privkeys,
                            const uint8_t *__restrict__ rx, uint8_t *__restrict__ ks, size_t n, OidArg oid,
-                           const uint32_t *__restrict__ status, uint8_t *__restrict__ sigs, uint32_t *__restrict__ codes)
+                           const uint32_t *__restrict__ status, uint8_t *__restrict__ sigs, uint32_t *__restrict__ codes,
+                           uint32_t row_words)
 {
     constexpr int NO = 4 * N;
-    constexpr int ROW = (OID_MAX + 2 * 64 + 31) / 32 * 8 + 1;
+    const uint32_t ROW = row_words;
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     uint8_t *s_tab = s_dyn;
     uint32_t *s_rows = reinterpret_cast<uint32_t *>(s_dyn + BeltTabTwo::kBytes);
-    BeltTabTwo::fill(s_tab, threadIdx.x, SIGN_WG);
+    BeltTabTwo::fill(s_tab, threadIdx.x, WG);
     __syncthreads();
     const BeltTabTwo T(s_tab);
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -928,6 +932,23 @@ static err_t launch_bign_pubkey_calc_t(bool keygen, const void *d_privkeys, size
     return ERR_OK;
 }
 
+// LDS row of the hashing kernels: the message zero-padded to whole 32-octet blocks, as an odd number of 32-bit words
+static inline uint32_t sign_row_words(size_t msg_octets) { return (uint32_t)((msg_octets + 31) / 32 * 8) | 1u; }
+// lanes per workgroup (one 64 KiB table each): big batches take the largest that fits the CU's 160 KiB with its rows
+// (256-bit curve, no t: 1024 lanes for the nonce, 512 for the tail -- 4 and 2 wavefronts per SIMD where it used to be 1)
+static int g_sign_wg = 0;                                  // bee2hip_internal_tune 12: 0 = by size, 256 / 512 / 1024 = upper bound
+void set_sign_wg(int v) { g_sign_wg = v; }
+static inline int sign_wg(size_t n, uint32_t row_words)
+{
+    // ... as long as every CU still gets a workgroup: 2^16 signatures in 64 workgroups of 1024 lose 8 % (tools/sign_wg_ab.py)
+    if (n < ((size_t)1 << 17)) return SIGN_WG;
+    const int fit = n < ((size_t)1 << 18) ? 512 : 1024;
+    const int cap = g_sign_wg == 256 || g_sign_wg == 512 || g_sign_wg == 1024 ? (g_sign_wg < fit ? g_sign_wg : fit) : fit;
+    for (int wg = cap; wg > SIGN_WG; wg >>= 1)
+        if (BeltTabTwo::kBytes + (size_t)wg * row_words * 4 <= (size_t)160 * 1024) return wg;
+    return SIGN_WG;
+}
+
 // mode 0: deterministic (bignSign2): d_aux = t (n x t_len, or shared when t_shared), may be null
 // mode 1: one-time keys supplied (bignSign after its rng): d_aux = k, n x 4N octets
 // mode 2: deterministic with theta = belt-hash(oid || d || t) supplied: d_aux = n x 32 octets
@@ -948,19 +969,26 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
     SignScratch S;
     code = sign_scratch<N>(st, n, S);
     if (code != ERR_OK) return code;
-    const unsigned grid = (unsigned)((n + SIGN_WG - 1) / SIGN_WG);
     const uint8_t *kptr;
     QArg<N> qa;
     memset(&qa, 0, sizeof qa);
     qa.std = 1;
     if (mode == 0 || mode == 2) {
-        constexpr int ROW = (OID_MAX + 64 + SIGN_T_MAX + 31) / 32 * 8 + 1;
-        const size_t lds = BeltTabTwo::kBytes + (size_t)SIGN_WG * ROW * 4;
-        B2H_TRY(dyn_lds_once((const void *)bign_sign_nonce_kernel<N>, lds));
         const uint8_t *tp = mode == 0 ? (const uint8_t *)d_aux : nullptr;
-        hipLaunchKernelGGL(bign_sign_nonce_kernel<N>, dim3(grid), dim3(SIGN_WG), lds, st, (const uint8_t *)d_hashes,
-                           (const uint8_t *)d_privkeys, tp, (uint32_t)(tp ? t_len : 0),
-                           (uint32_t)(t_shared ? 0 : t_len), mode == 2 ? (const uint8_t *)d_aux : nullptr, n, oa, qa, S.status, S.k);
+        const uint32_t tl = (uint32_t)(tp ? t_len : 0);
+        const uint32_t rw = sign_row_words(oa.len + 4 * N + tl);
+        const int wg = sign_wg(n, rw);
+        const size_t lds = BeltTabTwo::kBytes + (size_t)wg * rw * 4;
+        const auto go = [&](auto kern) -> err_t {
+            B2H_TRY(dyn_lds_once((const void *)kern, lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)((n + wg - 1) / wg)), dim3(wg), lds, st, (const uint8_t *)d_hashes,
+                               (const uint8_t *)d_privkeys, tp, tl, (uint32_t)(t_shared ? 0 : t_len),
+                               mode == 2 ? (const uint8_t *)d_aux : nullptr, n, oa, qa, S.status, S.k, rw);
+            return ERR_OK;
+        };
+        code = wg == 1024 ? go(bign_sign_nonce_kernel<N, 1024>) : wg == 512 ? go(bign_sign_nonce_kernel<N, 512>)
+                                                                            : go(bign_sign_nonce_kernel<N, 256>);
+        if (code != ERR_OK) return code;
         kptr = S.k;
     } else {
         hipLaunchKernelGGL(bign_sign_kcheck_kernel<N>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
@@ -970,12 +998,19 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
     }
     launch_mulbase<N, 0, true>(mulbase_lanes(n), kptr, n, (uint32_t *)nullptr, S.rx, tab, tab6, st);
     {
-        constexpr int ROW = (OID_MAX + 2 * 64 + 31) / 32 * 8 + 1;
-        const size_t lds = BeltTabTwo::kBytes + (size_t)SIGN_WG * ROW * 4;
-        B2H_TRY(dyn_lds_once((const void *)bign_sign_tail_kernel<N>, lds));
-        hipLaunchKernelGGL(bign_sign_tail_kernel<N>, dim3(grid), dim3(SIGN_WG), lds, st, (const uint8_t *)d_hashes,
-                           (const uint8_t *)d_privkeys, (const uint8_t *)S.rx, S.k, n, oa, (const uint32_t *)S.status,
-                           (uint8_t *)d_sigs, (uint32_t *)d_codes);
+        const uint32_t rw = sign_row_words(oa.len + 8 * N);
+        const int wg = sign_wg(n, rw);
+        const size_t lds = BeltTabTwo::kBytes + (size_t)wg * rw * 4;
+        const auto go = [&](auto kern) -> err_t {
+            B2H_TRY(dyn_lds_once((const void *)kern, lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)((n + wg - 1) / wg)), dim3(wg), lds, st, (const uint8_t *)d_hashes,
+                               (const uint8_t *)d_privkeys, (const uint8_t *)S.rx, S.k, n, oa, (const uint32_t *)S.status,
+                               (uint8_t *)d_sigs, (uint32_t *)d_codes, rw);
+            return ERR_OK;
+        };
+        code = wg == 1024 ? go(bign_sign_tail_kernel<N, 1024>) : wg == 512 ? go(bign_sign_tail_kernel<N, 512>)
+                                                                           : go(bign_sign_tail_kernel<N, 256>);
+        if (code != ERR_OK) return code;
     }
     B2H_TRY(hipGetLastError());
     return ERR_OK;

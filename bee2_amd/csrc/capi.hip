@@ -1465,7 +1465,7 @@ extern "C" err_t bee2hip_bashHash_beltMAC_batch(const octet *msgs, size_t msg_le
 
 // ============================================================ internal tuning hook ===
 // A/B switch for experiment builds (tools/bashf_ab.py); not part of the product ABI (BEE2HIP_INTERNAL).
-namespace bee2hip { void set_bashF_variant(int v); void set_ctr_variant(int v); void set_verify_path(int v); void set_verify_split(int v); void set_sign_coop(int v); }
+namespace bee2hip { void set_bashF_variant(int v); void set_ctr_variant(int v); void set_verify_path(int v); void set_verify_split(int v); void set_sign_coop(int v); void set_sign_wg(int v); }
 extern "C" err_t bee2hip_internal_tune(int key, int value)
 {
     switch (key) {
@@ -1478,6 +1478,7 @@ extern "C" err_t bee2hip_internal_tune(int key, int value)
     case 8: bee2hip::set_verify_split(value); return ERR_OK;          // parts of a big verification batch (0 by size, 1 never, 2..4)
     case 6: bee2hip::g_duplex_log2_states = value; return ERR_OK;     // chunk of the duplex host pipeline, bashF states (log2)
     case 7: bee2hip::g_duplex_log2_blocks = value; return ERR_OK;     //                                   belt blocks (log2)
+    case 12: bee2hip::set_sign_wg(value); return ERR_OK;              // largest workgroup of the signing side's hashing kernels
     case 11: bee2hip::g_verify_pipe = value; return ERR_OK;           // chunked upload of big host-pointer verification batches
     case 10: bee2hip::set_sign_coop(value); return ERR_OK;            // lanes per scalar of k G, signing side (0 = by batch size)
     case 9: bee2hip::g_duplex_ramp = value; return ERR_OK;            // ramped chunk sizes at the ends of the pipeline

@@ -43,7 +43,8 @@ err_t bee2hip_internal_tune(int key, int value);
    pipeline in bashF states / belt blocks; key 8 = parts a big verification batch is split into (0 by size, 1 never);
    key 9 = quarter and half chunks at both ends of the duplex pipeline (0 = product: measured -2 %); key 10 = lanes per scalar of k G on the signing side
    (0 = by batch size: 64 / 16 / 4 / 1; 1, 4, 16, 64 forced; 101 = one lane on the 4-bit windows of round 2, 102 = one lane, signed 6-bit windows, complete additions); key 11 = chunked upload of host-pointer
-   verification batches of 2^19 signatures and more (1 = product)) */
+   verification batches of 2^19 signatures and more (1 = product); key 12 = largest workgroup of the signing side's hashing
+   kernels for batches of 2^16 and more (0 = 1024, the product; 256 = round 2)) */
 /* drop-in helper calls so far: which = 0 taken on the host path, 1 on the GPU, 2 finished on the host after the GPU path
    failed twice */
 unsigned long long bee2hip_internal_stat(int which);

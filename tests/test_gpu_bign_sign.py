@@ -183,12 +183,13 @@ def test_base_point_multiples_of_special_scalars(orc, l, mulbase):
         assert (kcodes[i], sigs[sg * i: sg * (i + 1)] if w[0] == 0 else None) == (w[0], w[1] if w[0] == 0 else None), i
 
 
-def test_device_batch_sign_verify_pipeline_2pow16(orc):
-    """device-resident: 2^16 keys -> public keys -> deterministic signatures (per-item t) -> verification, one
-    stream, no host round trip; a sample is compared with the oracle, all of it must verify"""
+@pytest.mark.parametrize("n", [1 << 16, (1 << 17) + 37, (1 << 18) + 74])
+def test_device_batch_sign_verify_pipeline_2pow16(orc, n):
+    """device-resident: 2^16 .. 2^18 keys -> public keys -> deterministic signatures (per-item t) -> verification, one
+    stream, no host round trip; a sample is compared with the oracle, all of it must verify.  (The three sizes take the
+    hashing kernels of the signing side through workgroups of 256, 512 and 1024 lanes.)"""
     eng = engine()
     l, no, sg = 128, 32, 48
-    n = 1 << 16
     oid = E.LEVEL_OID[l]
     privs = dev(orc.fill(no * n, 0xD16))
     hashes = dev(orc.fill(no * n, 0xE27))
