@@ -16,6 +16,7 @@
 #include <string.h>
 #include "common.hpp"
 #include "host_small.hpp"
+#include "host_bign.hpp"
 #include "bign_curves.inc"   // (#pragma once: shared with bign_kernels.hip in the unity build)
 
 namespace bee2hip {
@@ -238,13 +239,15 @@ static inline hipError_t zero_staging(void *d, size_t n)
 //   unset (auto)        by crossover: single primitives (bashF, one block), block-parallel modes below 8 KiB per call
 //                       and the serial chains of ONE message (sponge, CBC-MAC, belt-hash, CBC encryption, a belt-sde
 //                       sector: one lane of the GPU runs them at 3-7 MB/s, a host core at 60-170 MB/s) on the host;
-//                       everything else, every bign operation and EVERY batch / _dev / _multi entry point on the GPU.
+//                       and ONE signature verification on a standard curve (host_bign.hpp: ~40 us against a 0.4 ms
+//                       call through the GPU); everything else, every bign operation that touches a private or
+//                       one-time key, and EVERY batch / _dev / _multi entry point on the GPU.
 // In every mode the calling thread must have initialised its HIP device first (ensure_device): without a GPU the
 // library fails exactly as before.  In auto mode a GPU path that fails twice (once more after hipDeviceSynchronize) is
 // finished on the host with a warning on stderr instead of abort() -- bee2's Step functions cannot report errors and a
 // long-running service must survive a transient device fault.
 enum { FORCE_AUTO = 0, FORCE_GPU = 1, FORCE_CPU = 2 };
-enum { K_PRIM = 0, K_PARALLEL = 1, K_SERIAL = 2, K_POLY = 3 };
+enum { K_PRIM = 0, K_PARALLEL = 1, K_SERIAL = 2, K_POLY = 3, K_VERIFY1 = 4 };
 static std::atomic<int> g_force{-1};
 static std::atomic<unsigned long long> g_n_host{0}, g_n_gpu{0}, g_n_fallback{0};
 static std::atomic<int> g_inject_fail{0};                  // tests: make the next n GPU attempts of a drop-in helper fail
@@ -274,6 +277,7 @@ static bool host_wanted(int kind, size_t bytes)
     case K_PRIM: return bytes <= 1024;          // one permutation / up to 64 blocks: 0.3-0.5 us each vs ~20 us per launch
     case K_PARALLEL: return bytes < 8192;       // INTEGRATION.md crossover table (CTR: 16 KiB 36 us vs 79 us on one core)
     case K_POLY: return bytes <= 1024;          // the bit-serial host product: 0.4 us per block
+    case K_VERIFY1: return true;                // one signature: ~40 us on a core vs ~0.4 ms through the GPU
     default: return true;                       // K_SERIAL: one message = one dependent chain
     }
 }
@@ -880,17 +884,49 @@ extern "C" err_t bee2hip_bignVerify_batch(const bign_params *params, const octet
     return ERR_OK;
 }
 
+// the three standard curves for host_bign.hpp: c, q, y_G and the fixed tables of G, built at first use
+template <int N>
+static const hostb::Curve<N> &host_curve(int which, uint64_t c)
+{
+    static hostb::Curve<N> E;
+    static std::once_flag once;
+    std::call_once(once, [&] { E.init(c, k_curves[which].q, k_curves[which].yG); });
+    return E;
+}
+static err_t verify_one_host(size_t l, const octet oid_der[], size_t oid_len, const octet hash[], const octet sig[],
+                             const octet pubkey[])
+{
+    const hostp::BeltTables &T = hostT();
+    if (l == 128) return hostb::verify<4>(host_curve<4>(0, BIGN128_CRANDALL_C), T, host_beltH(), oid_der, oid_len, hash, sig, pubkey);
+    if (l == 192) return hostb::verify<6>(host_curve<6>(1, BIGN192_CRANDALL_C), T, host_beltH(), oid_der, oid_len, hash, sig, pubkey);
+    return hostb::verify<8>(host_curve<8>(2, BIGN256_CRANDALL_C), T, host_beltH(), oid_der, oid_len, hash, sig, pubkey);
+}
+
 extern "C" err_t bignVerify(const bign_params *params, const octet oid_der[], size_t oid_len,
                             const octet hash[], const octet sig[], const octet pubkey[])
 {
     err_t one = ERR_BAD_SIG;
+    bool standard;
+    err_t pc = params_check2(params, &standard);
     if (!hash || !sig || !pubkey) {
-        bool standard;
-        err_t pc = params_check2(params, &standard);
         if (pc == ERR_OK && !standard) pc = bign_generic_check(params);
         return pc != ERR_OK ? pc : ERR_BAD_INPUT;
     }
+    // ONE signature on a standard curve: the calling core (host_bign.hpp) unless BEE2HIP_FORCE=gpu; same order of checks
+    // as the batch entry (parameters, inputs, OID), same requirement of a usable device
+    if (pc == ERR_OK && standard && host_wanted(K_VERIFY1, 1) && oid_der_valid(oid_der, oid_len)) {
+        const err_t code = device_seen();
+        if (code != ERR_OK) return code;
+        g_n_host.fetch_add(1, std::memory_order_relaxed);
+        return verify_one_host(params->l, oid_der, oid_len, hash, sig, pubkey);
+    }
     const err_t code = bee2hip_bignVerify_batch(params, oid_der, oid_len, hash, sig, pubkey, 1, &one);
+    if (code == ERR_BEE2HIP_DEVICE && pc == ERR_OK && standard && force_mode() != FORCE_GPU) {
+        // a device fault under a single verification: finished on the host like the void drop-ins (with_host)
+        fprintf(stderr, "libbee2hip: bignVerify: device path failed (%s); finished on the host\n", t_err);
+        g_n_fallback.fetch_add(1, std::memory_order_relaxed);
+        return verify_one_host(params->l, oid_der, oid_len, hash, sig, pubkey);
+    }
     return code != ERR_OK ? code : one;
 }
 

@@ -11,14 +11,16 @@
  *      of those objects (bee2's own test/crypto sources pass against it:
  *      oracle/Makefile `reftests`).  States are caller-owned PODs of X_keep() bytes that
  *      may be memcpy-cloned, as in bee2; belt_ctr_st, belt_mac_st and bash_hash_st have
- *      bee2's exact layout, the other states are opaque.  Where a call runs: every bign
- *      operation and every large call evaluates its primitives (bashF, E_K / D_K,
- *      GF(2^128) products, the scalar multiplications) on the GPU; a SMALL single call
- *      -- one bashF, one block, a block-parallel mode under 8 KiB per call, the serial
- *      chain of one message (sponge, CBC-MAC, belt-hash, CBC encryption, one belt-sde
- *      sector) -- takes the library's own host path (bee2_amd/csrc/host_small.hpp;
+ *      bee2's exact layout, the other states are opaque.  Where a call runs: every large
+ *      call and every bign operation that touches a private or one-time key evaluates its
+ *      primitives (bashF, E_K / D_K, GF(2^128) products, the scalar multiplications) on the
+ *      GPU; a SMALL single call -- one bashF, one block, a block-parallel mode under 8 KiB
+ *      per call, the serial chain of one message (sponge, CBC-MAC, belt-hash, CBC
+ *      encryption, one belt-sde sector), ONE signature verification on a standard curve --
+ *      takes the library's own host path (bee2_amd/csrc/host_small.hpp, host_bign.hpp;
  *      SURVEY.md 8b "single-call path; may run on CPU"), because one launch costs 20 us
- *      where a host core needs 0.3.  BEE2HIP_FORCE=gpu|cpu overrides the choice.  In
+ *      where a host core needs 0.3 (one verification: 0.42 ms through the GPU, 27 us on
+ *      the calling core, 178 us in bee2).  BEE2HIP_FORCE=gpu|cpu overrides the choice.  In
  *      every mode the calling thread needs a working HIP device: there is no GPU-less
  *      operation.  A device failure inside a `void` function is retried once and then
  *      finished on the host with a message on stderr (BEE2HIP_FORCE=gpu: abort with a

@@ -31,7 +31,7 @@ def golden():
 # and once with =cpu (every drop-in call that has a host path takes it, at every size).  All other tests run in the
 # default "auto" mode (crossover by size), which is what a caller gets.
 DROPIN_TEST_MODULES = {"test_gpu_bash", "test_gpu_belt", "test_gpu_belt_bde", "test_gpu_belt_dwp", "test_gpu_belt_modes",
-                       "test_gpu_belt_sde", "test_gpu_threads"}
+                       "test_gpu_belt_sde", "test_gpu_threads", "test_gpu_bign"}
 FORCE_CODE = {"auto": 0, "gpu": 1, "cpu": 2}
 
 

@@ -67,6 +67,44 @@ def test_auto_mode_crossovers(orc):
     assert _stats(L)[0] == s4[0]
 
 
+def test_one_signature_is_verified_on_the_host_batches_never(orc, golden):
+    """bign128Verify / bign192Verify / bign256Verify / bignVerify on a standard curve: the calling core in auto mode
+    (bee2_amd/csrc/host_bign.hpp), the GPU under BEE2HIP_FORCE=gpu, the same verdicts either way; the batch entry point
+    stays on the GPU even for n = 1"""
+    eng = engine()
+    L = eng.lib
+    cases = [tuple(bytes.fromhex(k[x]) for x in ("hash", "sig", "pubkey")) + (k["code"],) for k in golden.kat["bign_verify"]]
+    cases += [tuple(bytes.fromhex(k[x]) for x in ("hash", "sig", "pubkey")) + (k["code"],) for k in golden.bign_edge[::7]]
+    for mode in (0, 1, 2):
+        L.bee2hip_internal_tune(4, mode)
+        s0 = _stats(L)
+        for h, s, p, code in cases:
+            assert eng.bign128Verify(h, s, p) == code
+        s1 = _stats(L)
+        assert (s1[0] - s0[0] == len(cases)) == (mode != 1), mode
+    L.bee2hip_internal_tune(4, 0)
+    for l in (192, 256):
+        fn = lambda h, s, p: eng.bignLVerify(l, h, s, p)   # noqa: E731
+        for e in golden.bign_big[str(l)]["edge"][::5] + golden.bign_big[str(l)]["base"][:8]:
+            h, s, p = (bytes.fromhex(e[x]) for x in ("hash", "sig", "pubkey"))
+            want = e.get("code", 0)
+            s0 = _stats(L)
+            assert fn(h, s, p) == want
+            assert _stats(L)[0] == s0[0] + 1
+            L.bee2hip_internal_tune(4, 1)
+            assert fn(h, s, p) == want
+            L.bee2hip_internal_tune(4, 0)
+    # n = 1 through the batch entry point: GPU
+    h, s, p, code = cases[0]
+    s0 = _stats(L)
+    rc, codes = eng.bignVerify_batch(h, s, p)
+    assert rc == 0 and codes == [code] and _stats(L)[0] == s0[0]
+    # a bad OID is still the batch entry's ERR_BAD_OID, a non-standard parameter set still goes to the general-curve kernels
+    params = eng.bignParamsStd(E.CURVE_NAME[128])
+    assert eng.bignVerify(params, b"\x06\x02\x2a", h, s, p) == 301
+    assert _stats(L)[0] == s0[0]
+
+
 def test_device_fault_is_retried_then_finished_on_the_host(orc):
     eng = engine()
     L = eng.lib
