@@ -998,6 +998,18 @@ extern "C" err_t bignPubkeyVal(const bign_params *params, const octet pubkey[])
         if (pc == ERR_OK && !standard) pc = bign_generic_check(params);
         return pc != ERR_OK ? pc : ERR_BAD_INPUT;
     }
+    {   // ONE key on a standard curve: the calling core (host_bign.hpp) unless BEE2HIP_FORCE=gpu
+        bool standard;
+        if (params_check2(params, &standard) == ERR_OK && standard && host_wanted(K_VERIFY1, 1)) {
+            const err_t code = device_seen();
+            if (code != ERR_OK) return code;
+            g_n_host.fetch_add(1, std::memory_order_relaxed);
+            const size_t l = params->l;
+            if (l == 128) return hostb::pubkey_val<4>(host_curve<4>(0, BIGN128_CRANDALL_C), k_curves[0].b, pubkey);
+            if (l == 192) return hostb::pubkey_val<6>(host_curve<6>(1, BIGN192_CRANDALL_C), k_curves[1].b, pubkey);
+            return hostb::pubkey_val<8>(host_curve<8>(2, BIGN256_CRANDALL_C), k_curves[2].b, pubkey);
+        }
+    }
     const err_t code = bee2hip_bignPubkeyVal_batch(params, pubkey, 1, &one);
     return code != ERR_OK ? code : one;
 }

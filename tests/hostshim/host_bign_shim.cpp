@@ -42,5 +42,11 @@ void hb_field(size_t l, int op, uint64_t *r, const uint64_t *a, const uint64_t *
     if (l == 128) HB_DO(4, BIGN128_CRANDALL_C) else if (l == 192) HB_DO(6, BIGN192_CRANDALL_C) else HB_DO(8, BIGN256_CRANDALL_C)
 #undef HB_DO
 }
+uint32_t hb_pubkey_val(size_t l, const uint8_t *pubkey)
+{
+    if (l == 128) return hostb::pubkey_val<4>(g_c128, k_bign128_b, pubkey);
+    if (l == 192) return hostb::pubkey_val<6>(g_c192, k_bign192_b, pubkey);
+    return hostb::pubkey_val<8>(g_c256, k_bign256_b, pubkey);
+}
 int hb_wnaf(int8_t *out, const uint64_t *k, int nl, int w) { return hostb::wnaf(out, k, nl, w); }
 }

@@ -94,6 +94,17 @@ def test_one_signature_is_verified_on_the_host_batches_never(orc, golden):
             L.bee2hip_internal_tune(4, 1)
             assert fn(h, s, p) == want
             L.bee2hip_internal_tune(4, 0)
+    # one public key: host in auto mode, GPU when forced, the reference's codes either way
+    for l in (128, 192, 256):
+        for c in golden.bign_pubkey_val[str(l)][::9]:
+            pub = bytes.fromhex(c["pubkey"])
+            s0 = _stats(L)
+            assert eng.bignLPubkeyVal(l, pub) == c["code"], (l, c["name"])
+            assert _stats(L)[0] == s0[0] + 1
+            L.bee2hip_internal_tune(4, 1)
+            assert eng.bignLPubkeyVal(l, pub) == c["code"], (l, c["name"])
+            assert _stats(L)[0] == s0[0] + 1
+            L.bee2hip_internal_tune(4, 0)
     # n = 1 through the batch entry point: GPU
     h, s, p, code = cases[0]
     s0 = _stats(L)

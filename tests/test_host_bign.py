@@ -21,6 +21,7 @@ def hb(tmp_path_factory, orc):
                            os.path.join(ROOT, "tests", "hostshim", "host_bign_shim.cpp")])
     lib = ctypes.CDLL(str(out))
     lib.hb_verify.restype = ctypes.c_uint32
+    lib.hb_pubkey_val.restype = ctypes.c_uint32
     lib.hb_init(orc.beltH())
     return lib
 
@@ -124,3 +125,12 @@ def test_sigvfy_pipeline_verdicts(hb, golden):
         for it in golden.sigvfy_pipeline[str(l)]:
             pub, sig, dig = (bytes.fromhex(it[k]) for k in ("pubkey", "sig", "digest"))
             assert _verify(hb, l, LEVEL_OID[l], dig, sig, pub) == it["verify"]
+
+
+@pytest.mark.parametrize("l", [128, 192, 256])
+def test_pubkey_val_reference_codes(hb, golden, l):
+    """bignPubkeyVal (bign_misc.c:319-365) on the reference-generated cases"""
+    cases = golden.bign_pubkey_val[str(l)]
+    bad = [(c["name"], c["code"]) for c in cases
+           if hb.hb_pubkey_val(ctypes.c_size_t(l), bytes.fromhex(c["pubkey"])) != c["code"]]
+    assert not bad, (l, bad[:5])
