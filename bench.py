@@ -730,7 +730,8 @@ def main():
             lat["bashF (192 B)"] = us_per_call(lambda: eng.lib.bashF(blk, None), 20000 if fast else 200)
             lat["beltCTRStepE (16 B)"] = us_per_call(lambda: eng.lib.beltCTRStepE(b16, ctypes.c_size_t(16), st_ctr), 20000 if fast else 200)
             lat["beltCTRStepE (64 KiB)"] = us_per_call(lambda: eng.lib.beltCTRStepE(b64k, ctypes.c_size_t(1 << 16), st_ctr), 100)
-            lat["bign128Verify"] = us_per_call(lambda: eng.lib.bign128Verify(h0, s0, p0), 50)
+            lat["bign128Verify"] = us_per_call(lambda: eng.lib.bign128Verify(h0, s0, p0), 1000 if fast else 50)
+            lat["bign128PubkeyVal"] = us_per_call(lambda: eng.lib.bign128PubkeyVal(p0), 20000 if fast else 100)
             lat["bign128Sign2"] = us_per_call(lambda: eng.lib.bign128Sign2(sg0, h0, d0, None, ctypes.c_size_t(0)), 50)
             lat["beltHash (1 KiB)"] = us_per_call(lambda: eng.lib.beltHash(ctypes.create_string_buffer(32), bytes(1024), ctypes.c_size_t(1024)), 2000 if fast else 100)
             return lat
@@ -739,8 +740,9 @@ def main():
         lat_gpu = measure(False)
         eng.lib.bee2hip_internal_tune(4, 0)
         entry = {"unit": "us per call", "dropin": lat, "dropin_forced_gpu": lat_gpu,
-                 "note": "dropin = the library as a caller gets it: single primitives, block-parallel modes under 8 KiB per call and "
-                         "one-message serial chains run on the host path (bee2_amd/csrc/host_small.hpp), everything else is H2D + "
+                 "note": "dropin = the library as a caller gets it: single primitives, block-parallel modes under 8 KiB per call, "
+                         "one-message serial chains and ONE signature verification / public-key validation run on the host path "
+                         "(bee2_amd/csrc/host_small.hpp, host_bign.hpp; nothing with a private key does), everything else is H2D + "
                          "launch(es) + D2H on the NULL stream; dropin_forced_gpu = BEE2HIP_FORCE=gpu (every primitive in a kernel); "
                          "the batch entry points are the fast path (INTEGRATION.md gives the crossover sizes)"}
         if do_cpu:
@@ -754,6 +756,7 @@ def main():
                 cpu["beltCTRStepE (16 B)"] = us_per_call(lambda: ref.beltCTRStepE(b16, ctypes.c_size_t(16), rst), 20000)
                 cpu["beltCTRStepE (64 KiB)"] = us_per_call(lambda: ref.beltCTRStepE(b64k, ctypes.c_size_t(1 << 16), rst), 500)
                 cpu["bign128Verify"] = us_per_call(lambda: ref.bign128Verify(h0, s0, p0), 300)
+                cpu["bign128PubkeyVal"] = us_per_call(lambda: ref.bign128PubkeyVal(p0), 5000)
                 cpu["bign128Sign2"] = us_per_call(lambda: ref.bign128Sign2(sg0, h0, d0, None, ctypes.c_size_t(0)), 300)
                 cpu["beltHash (1 KiB)"] = us_per_call(lambda: ref.beltHash(ctypes.create_string_buffer(32), bytes(1024), ctypes.c_size_t(1024)), 2000)
                 entry["cpu_reference"] = cpu
