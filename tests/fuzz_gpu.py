@@ -187,6 +187,16 @@ def f_verify_generic(rnd):
     return code == 0 and got == [OG.pubkey_val(P, K[2 * no * i:2 * no * (i + 1)]) for i in range(len(want))]
 
 
+_std = {}
+
+
+def _std_params(l):
+    from bee2_amd.engine import CURVE_NAME
+    if l not in _std:
+        _std[l] = eng.bignParamsStd(CURVE_NAME[l])
+    return _std[l]
+
+
 def f_verify(rnd):
     if rnd.randrange(12) == 0:
         return f_verify_generic(rnd)
@@ -230,10 +240,22 @@ def f_verify(rnd):
     got = [int(c) & 0xFFFFFFFF for c in codes.cpu().numpy()]
     if got != orc.verify_batch_l(l, oid, bytes(H), bytes(S), bytes(P), nthreads=16):
         return False
+    # the drop-in symbol on a sample of the same cases, one call each: the host path (host_bign.hpp) in the default mode
+    sg = no + no // 2
+    prm = _std_params(l)
+    pick = rnd.sample(range(n), min(n, 48))
+    for i in pick:
+        one = eng.bignVerify(prm, oid, bytes(H[no * i:no * (i + 1)]), bytes(S[sg * i:sg * (i + 1)]), bytes(P[2 * no * i:2 * no * (i + 1)]))
+        if (one & 0xFFFFFFFF) != got[i]:
+            return False
     # public-key validation over the same (partly damaged) keys
     eng.bignPubkeyValL_batch_dev(l, dev(P), codes)
     torch.cuda.synchronize()
-    return [int(c) & 0xFFFFFFFF for c in codes.cpu().numpy()] == orc.pubkey_val_batch(l, bytes(P))
+    pv = [int(c) & 0xFFFFFFFF for c in codes.cpu().numpy()]
+    for i in pick:
+        if (eng.bignLPubkeyVal(l, bytes(P[2 * no * i:2 * no * (i + 1)])) & 0xFFFFFFFF) != pv[i]:
+            return False
+    return pv == orc.pubkey_val_batch(l, bytes(P))
 
 
 def f_ragged_mixed(rnd):
@@ -419,6 +441,10 @@ FAMILIES = [("bashF", f_bashF), ("beltCTR", f_ctr), ("mac/hash", f_mac_hash), ("
 
 
 def main(seconds, seed):
+    global FAMILIES
+    only = os.environ.get("FUZZ_FAMILIES")                  # e.g. FUZZ_FAMILIES=verify,sign
+    if only:
+        FAMILIES = [f for f in FAMILIES if f[0] in only.split(",")]
     counts = {n: 0 for n, _ in FAMILIES}
     t_end = time.time() + seconds
     case = 0
