@@ -201,6 +201,112 @@ struct BeltTabHyb : BeltTabTwo {
     }
 };
 
+// EXPERIMENT (round 3, tools/belt_ab.py variant 15, profiles/r03_belt_sdwa_ab.txt): the two-table layout with every LDS address
+// made by ONE instruction.  The address is (byte << 8) | lane_base with lane_base < 128: byte 1 of a register whose other
+// bytes hold lane_base for good.  v_mov_b32_sdwa with dst_sel:BYTE_1 and dst_unused:UNUSED_PRESERVE drops byte k of x there
+// (half rate: the cycles of the shift + v_bitop3 pair it replaces, one issue slot instead of two).  Each G-box position of
+// the round owns its three address registers so that the two G-boxes the compiler keeps in flight do not meet in one.
+struct BeltTabTwoS : BeltTabTwo {
+    mutable uint32_t ar[7][3];
+    __device__ explicit BeltTabTwoS(const uint8_t *l) : BeltTabTwo(l)
+    {
+#pragma unroll
+        for (int s = 0; s < 7; ++s)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ar[s][k] = base;
+    }
+    template <int R0, int SLOT, int I>
+    __device__ __forceinline__ GParts gs(uint32_t x) const
+    {
+        uint32_t &a0 = ar[SLOT][0], &a2 = ar[SLOT][1], &a3 = ar[SLOT][2];
+        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(a0) : "v"(x));
+        const uint32_t a1 = and_or(x, 0xFF00u, base);
+        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(a2) : "v"(x));
+        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(a3) : "v"(x));
+        constexpr int r0 = (R0 + 0) & 3, r1 = (R0 + 1) & 3, r2 = (R0 + 2) & 3, r3 = (R0 + 3) & 3;
+        uint32_t t0 = *(lds_u32 *)(uintptr_t)(a0 + (r0 == 3 ? 128 : 0));
+        uint32_t t1 = *(lds_u32 *)(uintptr_t)(a1 + (r1 == 3 ? 128 : 0));
+        uint32_t t2 = *(lds_u32 *)(uintptr_t)(a2 + (r2 == 3 ? 128 : 0));
+        uint32_t t3 = *(lds_u32 *)(uintptr_t)(a3 + (r3 == 3 ? 128 : 0));
+        if (r0 == 1 || r0 == 2) t0 <<= 8 * r0;
+        if (r1 == 1 || r1 == 2) t1 <<= 8 * r1;
+        if (r2 == 1 || r2 == 2) t2 <<= 8 * r2;
+        if (r3 == 1 || r3 == 2) t3 <<= 8 * r3;
+        GParts r;
+        r.p = xor3(t0, t1, t2);
+        r.q = t3;
+        return r;
+    }
+};
+
+// EXPERIMENT (variant 16): BeltTabTwoS with the two post-shifts and the first xor folded into two v_lshl_or_b32 (the three T5
+// entries of a G-box occupy disjoint bit ranges once shifted): ((t_<<16 << 8) | t_<<8) << 8 | t_<<0 -- 8 VALU instructions per
+// G-box instead of 9, two of them half rate.
+struct BeltTabTwoL : BeltTabTwoS {
+    __device__ explicit BeltTabTwoL(const uint8_t *l) : BeltTabTwoS(l) {}
+    template <int R0, int SLOT, int I>
+    __device__ __forceinline__ GParts gs(uint32_t x) const
+    {
+        uint32_t &a0 = ar[SLOT][0], &a2 = ar[SLOT][1], &a3 = ar[SLOT][2];
+        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(a0) : "v"(x));
+        const uint32_t a1 = and_or(x, 0xFF00u, base);
+        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(a2) : "v"(x));
+        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(a3) : "v"(x));
+        const uint32_t a[4] = {a0, a1, a2, a3};
+        uint32_t t[4];                               // t[r]: the entry whose rotation is 5 + 8 r
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = (R0 + k) & 3;
+            t[r] = *(lds_u32 *)(uintptr_t)(a[k] + (r == 3 ? 128 : 0));
+        }
+        uint32_t u, v;
+        asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(u) : "v"(t[2]), "v"(t[1]));
+        asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(v) : "v"(u), "v"(t[0]));
+        GParts g;
+        g.p = v;
+        g.q = t[3];
+        return g;
+    }
+};
+
+// The round-3 product table of the bank-private kernels: BeltTabTwoL with THREE address-register sets instead of seven
+// (G-boxes that can be in flight together never share one: slots 0..6 of a round use sets 0 1 0 1 0 1 2, and slot 6 never
+// meets slot 0 of the next round in the same set), so that the kernels built around 64 VGPRs keep their occupancy.
+struct BeltTabTwoP : BeltTabTwo {
+    mutable uint32_t ar[3][3];
+    __device__ explicit BeltTabTwoP(const uint8_t *l) : BeltTabTwo(l)
+    {
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ar[s][k] = base;
+    }
+    template <int R0, int SLOT, int I>
+    __device__ __forceinline__ GParts gs(uint32_t x) const
+    {
+        constexpr int SET = SLOT == 6 ? 2 : (SLOT & 1);
+        uint32_t &a0 = ar[SET][0], &a2 = ar[SET][1], &a3 = ar[SET][2];
+        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(a0) : "v"(x));
+        const uint32_t a1 = and_or(x, 0xFF00u, base);
+        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(a2) : "v"(x));
+        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(a3) : "v"(x));
+        const uint32_t a[4] = {a0, a1, a2, a3};
+        uint32_t t[4];                               // t[r]: the entry whose rotation is 5 + 8 r
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = (R0 + k) & 3;
+            t[r] = *(lds_u32 *)(uintptr_t)(a[k] + (r == 3 ? 128 : 0));
+        }
+        uint32_t u, v;
+        asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(u) : "v"(t[2]), "v"(t[1]));
+        asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(v) : "v"(u), "v"(t[0]));
+        GParts g;
+        g.p = v;
+        g.q = t[3];
+        return g;
+    }
+};
+
 struct BeltTabSmall {
     static constexpr int kBytes = 4 * 256 * 4;             // 4096
     const uint8_t *lds;
@@ -229,6 +335,18 @@ struct BeltTabSmall {
 // G_r(x), r = 5 + 8*R0 (belt_block.c:210-215): table (R0 + k) & 3 serves byte k of x.
 // G5 = g<0>, G13 = g<1>, G21 = g<2>.
 
+// G-box number SLOT of a round: tables with a slot-aware accessor (BeltTabHyb) choose their path by it
+template <int R0, int SLOT, int I, class Tab>
+__device__ __forceinline__ auto gbox(const Tab &T, uint32_t x, int) -> decltype(T.template gs<R0, SLOT, I>(x))
+{
+    return T.template gs<R0, SLOT, I>(x);
+}
+template <int R0, int SLOT, int I, class Tab>
+__device__ __forceinline__ GParts gbox(const Tab &T, uint32_t x, long)
+{
+    return T.template g<R0>(x);
+}
+
 // one round, steps 2.1-2.9 of the standard (belt_block.c:231-240); I = round number,
 // key index (7 I - 7 + j) mod 8 (subkey_e, :242).  Every "x ^= G" is one more xor3.
 template <int I, class Tab>
@@ -237,16 +355,16 @@ __device__ __forceinline__ void belt_round(const Tab &T, uint32_t &a, uint32_t &
 {
     constexpr int o = 7 * I - 7;
     GParts g;
-    g = T.template g<0>(a + K[(o + 0) & 7]);   b = xor3(b, g.p, g.q);                 // b ^= G5(a + k)
-    g = T.template g<2>(d + K[(o + 1) & 7]);   c = xor3(c, g.p, g.q);                 // c ^= G21(d + k)
-    g = T.template g<1>(b + K[(o + 2) & 7]);   a -= g.p ^ g.q;                        // a -= G13(b + k)
-    g = T.template g<2>(b + c + K[(o + 3) & 7]);
+    g = gbox<0, 0, I>(T, a + K[(o + 0) & 7], 0);   b = xor3(b, g.p, g.q);                 // b ^= G5(a + k)
+    g = gbox<2, 1, I>(T, d + K[(o + 1) & 7], 0);   c = xor3(c, g.p, g.q);                 // c ^= G21(d + k)
+    g = gbox<1, 2, I>(T, b + K[(o + 2) & 7], 0);   a -= g.p ^ g.q;                        // a -= G13(b + k)
+    g = gbox<2, 3, I>(T, b + c + K[(o + 3) & 7], 0);
     const uint32_t e = xor3(g.p, g.q, (uint32_t)I);                                   // G21(b + c + k) ^ i
     b += e;
     c -= e;
-    g = T.template g<1>(c + K[(o + 4) & 7]);   d += g.p ^ g.q;                        // d += G13(c + k)
-    g = T.template g<2>(a + K[(o + 5) & 7]);   b = xor3(b, g.p, g.q);                 // b ^= G21(a + k)
-    g = T.template g<0>(d + K[(o + 6) & 7]);   c = xor3(c, g.p, g.q);                 // c ^= G5(d + k)
+    g = gbox<1, 4, I>(T, c + K[(o + 4) & 7], 0);   d += g.p ^ g.q;                        // d += G13(c + k)
+    g = gbox<2, 5, I>(T, a + K[(o + 5) & 7], 0);   b = xor3(b, g.p, g.q);                 // b ^= G21(a + k)
+    g = gbox<0, 6, I>(T, d + K[(o + 6) & 7], 0);   c = xor3(c, g.p, g.q);                 // c ^= G5(d + k)
 }
 
 // E_K on (x0..x3): eight rounds with the (a,b,c,d) <- (b,d,a,c) role change realised by
@@ -275,16 +393,16 @@ __device__ __forceinline__ void belt_round_d(const Tab &T, uint32_t &a, uint32_t
 {
     constexpr int o = 7 * I - 1;
     GParts g;
-    g = T.template g<0>(a + K[(o - 0) & 7]);   b = xor3(b, g.p, g.q);
-    g = T.template g<2>(d + K[(o - 1) & 7]);   c = xor3(c, g.p, g.q);
-    g = T.template g<1>(b + K[(o - 2) & 7]);   a -= g.p ^ g.q;
-    g = T.template g<2>(b + c + K[(o - 3) & 7]);
+    g = gbox<0, 0, I>(T, a + K[(o - 0) & 7], 0);   b = xor3(b, g.p, g.q);
+    g = gbox<2, 1, I>(T, d + K[(o - 1) & 7], 0);   c = xor3(c, g.p, g.q);
+    g = gbox<1, 2, I>(T, b + K[(o - 2) & 7], 0);   a -= g.p ^ g.q;
+    g = gbox<2, 3, I>(T, b + c + K[(o - 3) & 7], 0);
     const uint32_t e = xor3(g.p, g.q, (uint32_t)I);
     b += e;
     c -= e;
-    g = T.template g<1>(c + K[(o - 4) & 7]);   d += g.p ^ g.q;
-    g = T.template g<2>(a + K[(o - 5) & 7]);   b = xor3(b, g.p, g.q);
-    g = T.template g<0>(d + K[(o - 6) & 7]);   c = xor3(c, g.p, g.q);
+    g = gbox<1, 4, I>(T, c + K[(o - 4) & 7], 0);   d += g.p ^ g.q;
+    g = gbox<2, 5, I>(T, a + K[(o - 5) & 7], 0);   b = xor3(b, g.p, g.q);
+    g = gbox<0, 6, I>(T, d + K[(o - 6) & 7], 0);   c = xor3(c, g.p, g.q);
 }
 
 template <class Tab>
@@ -305,18 +423,6 @@ __device__ __forceinline__ void belt_decr(const Tab &T, uint32_t (&x)[4], const 
 // N independent blocks in lockstep: each G-box step is issued for all N blocks before the
 // next step, so 4N LDS reads are in flight per wave (the LDS round trip, not the VALU, is
 // what a single E_K chain waits on).
-// G-box number SLOT of a round: tables with a slot-aware accessor (BeltTabHyb) choose their path by it
-template <int R0, int SLOT, int I, class Tab>
-__device__ __forceinline__ auto gbox(const Tab &T, uint32_t x, int) -> decltype(T.template gs<R0, SLOT, I>(x))
-{
-    return T.template gs<R0, SLOT, I>(x);
-}
-template <int R0, int SLOT, int I, class Tab>
-__device__ __forceinline__ GParts gbox(const Tab &T, uint32_t x, long)
-{
-    return T.template g<R0>(x);
-}
-
 template <int N, int I, class Tab>
 __device__ __forceinline__ void belt_round_n(const Tab &T, uint32_t (&a)[N], uint32_t (&b)[N],
                                              uint32_t (&c)[N], uint32_t (&d)[N], const uint32_t (&K)[8])

@@ -31,7 +31,9 @@ __constant__ uint8_t c_beltH[256];
 __device__ uint32_t d_beltT4[1024];       // experiment only (BeltTabHyb): rotl(S, 5 / 13 / 21 / 29), 4 x 256 dwords
 
 constexpr int CTR_WG = 1024;
-typedef BeltTabTwo CtrTab;          // 64 KiB: two workgroups (32 wavefronts) per CU
+// 64 KiB, two workgroups (32 wavefronts) per CU; LDS addresses by one SDWA move each and the post-shifts folded into two
+// v_lshl_or_b32: 8 VALU instructions per G-box instead of 12 (round 3: beltCTR 835 -> 965 GiB/s on 16 GiB, profiles/r03_belt_sdwa_ab.txt)
+typedef BeltTabTwoP CtrTab;
 constexpr int CTR_ILP = 1;          // independent blocks per lane per step (r02 A/B: 1 beats 2 by 1.3-1.5 %, profiles/r02_belt_variants.txt)
 
 typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));      // what the non-temporal builtins accept
@@ -719,15 +721,23 @@ err_t launch_belt_ctr_blocks(void *d_buf, size_t nblocks, const uint32_t key[8],
     case 4: return launch_ctr_t<BeltTabWide, 2>(d_buf, nblocks, k, c, first, d_last_gamma, st);
     case 5: return launch_ctr_t<BeltTabWide, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);
     case 6: return launch_ctr_t<BeltTabWide, 4>(d_buf, nblocks, k, c, first, d_last_gamma, st);
-    case 7: return launch_ctr_t<CtrTab, CTR_ILP, 1>(d_buf, nblocks, k, c, first, d_last_gamma, st);
-    case 8: return launch_ctr_t<CtrTab, CTR_ILP, 2>(d_buf, nblocks, k, c, first, d_last_gamma, st);
-    case 9: return launch_ctr_t<CtrTab, CTR_ILP, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    case 7: return launch_ctr_t<BeltTabTwo, CTR_ILP, 1>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    case 8: return launch_ctr_t<BeltTabTwo, CTR_ILP, 2>(d_buf, nblocks, k, c, first, d_last_gamma, st);
+    case 9: return launch_ctr_t<BeltTabTwo, CTR_ILP, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);
     case 10: return launch_ctr_t<BeltTabHyb<0xFF>, 1>(d_buf, nblocks, k, c, first, d_last_gamma, st);   // 32 of 224 lookups via L1
     case 11: return launch_ctr_t<BeltTabHyb<0x55>, 1>(d_buf, nblocks, k, c, first, d_last_gamma, st);   // 16
     case 12: return launch_ctr_t<BeltTabHyb<0x11>, 1>(d_buf, nblocks, k, c, first, d_last_gamma, st);   // 8
-    case 13: return launch_ctr_t<CtrTab, CTR_ILP, 0>(d_buf, nblocks, k, c, first, d_last_gamma, st);   // the round-2 product
-    case 14: return launch_ctr_t<CtrTab, CTR_ILP, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);   // round 3 without the hoisted G-box
-    // product (round 3): contiguous tile ranges + non-temporal stream accesses, +1 % (profiles/r03_belt_mem_ab.txt)
+    case 13: return launch_ctr_t<BeltTabTwo, CTR_ILP, 0>(d_buf, nblocks, k, c, first, d_last_gamma, st);   // the round-2 product
+    case 14: return launch_ctr_t<BeltTabTwo, CTR_ILP, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);   // round 3 without the hoisted G-box
+    case 15: return launch_ctr_t<BeltTabTwoS, 1, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);    // one-instruction (SDWA) LDS addresses
+    case 16: return launch_ctr_t<BeltTabTwoL, 1, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);    // + v_lshl_or_b32 combine
+    case 17: return launch_ctr_t<BeltTabTwoS, 1, 7>(d_buf, nblocks, k, c, first, d_last_gamma, st);    // 15 + hoisted round-1 G-box
+    case 18: return launch_ctr_t<BeltTabTwoL, 1, 7>(d_buf, nblocks, k, c, first, d_last_gamma, st);    // 16 + hoisted round-1 G-box
+    case 19: return launch_ctr_t<BeltTabTwoS, 2, 7>(d_buf, nblocks, k, c, first, d_last_gamma, st);    // 17 with 2 blocks per lane
+    case 21: return launch_ctr_t<BeltTabTwo, 1, 7>(d_buf, nblocks, k, c, first, d_last_gamma, st);     // the product up to 4ab23f3
+    case 20: return launch_ctr_t<BeltTabTwoP, 1, 7>(d_buf, nblocks, k, c, first, d_last_gamma, st);    // 18 with three address-register sets
+    // product (round 3): contiguous tile ranges + non-temporal stream accesses, +1 % (profiles/r03_belt_mem_ab.txt); the table
+    // type CtrTab = BeltTabTwoP (one-instruction LDS addresses), +15 % (profiles/r03_belt_sdwa_ab.txt)
     default: {
         // block i uses ctr0 + ((first + 1 + i) mod 2^64): the upper 64 bits of that sum stay put over the launch unless the
         // lower 64 bits wrap inside it or the 64-bit offset itself does (then the carry into the upper half goes away again)

@@ -44,7 +44,7 @@ constexpr int FUSED_WG = 1024;
 #define BASH_FUSED_ORDER 101
 #endif
 
-template <int RW, bool HASH, bool MAC>
+template <int RW, bool HASH, bool MAC, class Tab = BeltTabWide>
 __global__ __launch_bounds__(FUSED_WG)
 void hash_mac_fused_kernel(const uint4 *__restrict__ msgs, size_t msg_len, size_t n, uint32_t level,
                            MacKey key, uint8_t *__restrict__ digests, uint8_t *__restrict__ tags)
@@ -52,10 +52,10 @@ void hash_mac_fused_kernel(const uint4 *__restrict__ msgs, size_t msg_len, size_
     constexpr int RB = RW / 2;                   // 16-byte blocks per rate block
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     if (MAC) {
-        BeltTabWide::fill(smem, threadIdx.x, FUSED_WG);
+        Tab::fill(smem, threadIdx.x, FUSED_WG);
         __syncthreads();
     }
-    const BeltTabWide T(smem);
+    const Tab T(smem);
     const size_t idx = (size_t)blockIdx.x * FUSED_WG + threadIdx.x;
     if (idx >= n) return;
 
@@ -826,12 +826,25 @@ err_t launch_belt_mac(void *d_states, const void *d_data, size_t stride, size_t 
     return ERR_OK;
 }
 
+// table of the MAC half: 0 = the product, 1 = BeltTabWide (four tables, 128 KiB: rounds 1-2), 2 = BeltTabTwoP (A/B: tune 13)
+static int g_fused_tab = 0;
+void set_fused_tab(int v) { g_fused_tab = v; }
+template <int RW, bool HASH, bool MAC, class Tab>
+static err_t launch_fused_tt(const void *d_msgs, size_t msg_len, size_t n, size_t l, const MacKey &key,
+                             void *d_digests, void *d_tags, hipStream_t st);
 template <int RW, bool HASH, bool MAC>
 static err_t launch_fused_t(const void *d_msgs, size_t msg_len, size_t n, size_t l, const MacKey &key,
                             void *d_digests, void *d_tags, hipStream_t st)
 {
-    auto kern = hash_mac_fused_kernel<RW, HASH, MAC>;
-    const size_t lds = MAC ? (size_t)BeltTabWide::kBytes : 0;
+    if (MAC && g_fused_tab == 2) return launch_fused_tt<RW, HASH, MAC, BeltTabTwoP>(d_msgs, msg_len, n, l, key, d_digests, d_tags, st);
+    return launch_fused_tt<RW, HASH, MAC, BeltTabWide>(d_msgs, msg_len, n, l, key, d_digests, d_tags, st);
+}
+template <int RW, bool HASH, bool MAC, class Tab>
+static err_t launch_fused_tt(const void *d_msgs, size_t msg_len, size_t n, size_t l, const MacKey &key,
+                             void *d_digests, void *d_tags, hipStream_t st)
+{
+    auto kern = hash_mac_fused_kernel<RW, HASH, MAC, Tab>;
+    const size_t lds = MAC ? (size_t)Tab::kBytes : 0;
     if (MAC) B2H_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), lds));
     const size_t grid = (n + FUSED_WG - 1) / FUSED_WG;
     if (grid > 0x7fffffffull) return ERR_BAD_INPUT;

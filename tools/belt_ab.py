@@ -14,8 +14,15 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import bee2_amd  # noqa: E402
 import orclib  # noqa: E402
 
-NAMES = {0: "product (round 3): two-table 64 KiB, 1 block/lane, contiguous ranges, nt accesses, round-1 G-box of (c, d) hoisted",
+NAMES = {0: "product: variant 20 (SDWA addresses, v_lshl_or combine, three register sets, hoisted G-box, contiguous ranges, nt accesses)",
+         21: "the product before the SDWA addresses: two-table 64 KiB, 1 block/lane, contiguous ranges, nt accesses, round-1 G-box of (c, d) hoisted",
          14: "round 3 without the hoisted round-1 G-box (56 G-boxes per block)",
+         16: "as 15 with the post-shifts folded into two v_lshl_or_b32",
+         17: "as 15 with the hoisted round-1 G-box",
+         18: "as 16 with the hoisted round-1 G-box",
+         19: "as 17 with 2 blocks per lane",
+         20: "as 18 with three address-register sets instead of seven",
+         15: "as 14 with every LDS address made by one v_mov_b32_sdwa (byte k of x into byte 1 of a register that holds the lane base)",
          13: "round-2 product: two-table 64 KiB, 1 block/lane, tiles dealt round-robin, plain loads/stores",
          1: "two-table, 2 blocks/lane, 8 w/SIMD (45 VGPRs) = the r01 product",
          2: "two-table, 3 blocks/lane, 8 w/SIMD (64 VGPRs, 2 spills)",
