@@ -1337,7 +1337,7 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
                        (int)k_inv, S);
     constexpr size_t row_bytes = (2 * N + 1) * 4;
     if (N == 8 && n >= 65536) {
-        auto kern = bign_tail_kernel<N, BeltTabTwo, 1024>;
+        auto kern = bign_tail_kernel<N, BeltTabTwoP, 1024>;
         const size_t lds = BeltTabTwo::kBytes + 1024 * row_bytes;
         B2H_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), lds, st, (const uint8_t *)d_hashes,

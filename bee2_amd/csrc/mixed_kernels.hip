@@ -777,14 +777,14 @@ err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, cons
         if (n >= 32768) {
             // big table; 256-thread workgroups until there are enough messages to fill 1024-thread ones on every CU
             const bool wide = n >= (size_t)num_cus() * 1024;
-            const void *kern = wide ? reinterpret_cast<const void *>(belt_hash_ragged_kernel<BeltTabTwo, 1024>)
-                                    : reinterpret_cast<const void *>(belt_hash_ragged_kernel<BeltTabTwo, 256>);
+            const void *kern = wide ? reinterpret_cast<const void *>(belt_hash_ragged_kernel<BeltTabTwoP, 1024>)
+                                    : reinterpret_cast<const void *>(belt_hash_ragged_kernel<BeltTabTwoP, 256>);
             B2H_TRY(dyn_lds_once(kern, BeltTabTwo::kBytes));
             if (wide)
-                hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabTwo, 1024>), dim3((unsigned)((n + 1023) / 1024)),
+                hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabTwoP, 1024>), dim3((unsigned)((n + 1023) / 1024)),
                                    dim3(1024), BeltTabTwo::kBytes, st, data, off, ord, n, dig, RAGGED_LONG);
             else
-                hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabTwo, 256>), dim3((unsigned)((n + 255) / 256)),
+                hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabTwoP, 256>), dim3((unsigned)((n + 255) / 256)),
                                    dim3(256), BeltTabTwo::kBytes, st, data, off, ord, n, dig, RAGGED_LONG);
         } else {
             hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabSmall, 64>), g, t, BeltTabSmall::kBytes, st, data, off,

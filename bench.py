@@ -48,7 +48,8 @@ MAD_PEAK_T = 30.0                # measured: 256 CU x 4 SIMD x 64 lanes x 2.31 G
 # 80 % of that.  Per-unit instruction counts are the ISA's (hipcc -S), not estimates.
 SIMD_CYCLES_PER_S = 1024 * 2.4e9
 BASHF_VALU = {"full_rate": 4 * 684, "half_rate": 4 * 384}          # per permutation-wavefront (24 rounds)
-CTR_VALU = {"full_rate": 681, "half_rate": 18, "ds_read_b32": 220}  # per block-wavefront (loop body of beltCTR_blocks_kernel<BeltTabTwo, 1, 7>, llvm-objdump)
+CTR_VALU = {"full_rate": 232, "half_rate": 293, "ds_read_b32": 220}  # per block-wavefront (loop body of beltCTR_blocks_kernel<BeltTabTwoP, 1, 7>, llvm-objdump;
+#                                                                       before the one-instruction LDS addresses: 681 / 18 / 220 -- a third more instructions, fewer VALU cycles, 15 % slower)
 
 
 def valu_picture(units_per_s, mix, lanes=64):
@@ -460,9 +461,10 @@ def main():
             "roofline": {"kernel": "beltCTR_blocks_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": ctr_traffic, "traffic_source": ctr_traffic_src,
                          "avg_launch_ms": ms_launch,
-                         "note": "VALU/LDS-issue bound, not HBM: per block ~700 VALU ops (VALU-only build 930 GiB/s) and "
-                                 "220 ds_read_b32 (LDS-only build 1146 GiB/s), 10.0 CU-cycles per block at every stream size "
-                                 "(profiles/r03_belt_mem_ab.txt), DESIGN.md 2 and 4.2",
+                         "note": "LDS-lookup / instruction-issue bound, not HBM: per block 220 ds_read_b32 (7 LDS clocks per block per CU: "
+                                 "`beltCTR_lds_frac`) and ~525 VALU instructions (8 per G-box since the LDS addresses are one SDWA "
+                                 "move each: profiles/r03_belt_sdwa_ab.txt; ~700 before, 10.0 CU-cycles per block then, ~8.4 now), "
+                                 "DESIGN.md 2 and 4.2",
                          "valu": valu_picture(nb / (ms_launch * 1e-3), CTR_VALU)},
         }
         if dist.rank == 0 and N == 1 and not args.headline_only:       # PCIe-inclusive rate: single-GPU runs only
