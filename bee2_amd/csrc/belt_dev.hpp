@@ -272,9 +272,10 @@ struct BeltTabTwoL : BeltTabTwoS {
 // The round-3 product table of the bank-private kernels: BeltTabTwoL with THREE address-register sets instead of seven
 // (G-boxes that can be in flight together never share one: slots 0..6 of a round use sets 0 1 0 1 0 1 2, and slot 6 never
 // meets slot 0 of the next round in the same set), so that the kernels built around 64 VGPRs keep their occupancy.
-struct BeltTabTwoP : BeltTabTwo {
+template <bool ONEWAIT>
+struct BeltTabTwoPT : BeltTabTwo {
     mutable uint32_t ar[3][3];
-    __device__ explicit BeltTabTwoP(const uint8_t *l) : BeltTabTwo(l)
+    __device__ explicit BeltTabTwoPT(const uint8_t *l) : BeltTabTwo(l)
     {
 #pragma unroll
         for (int s = 0; s < 3; ++s)
@@ -297,6 +298,9 @@ struct BeltTabTwoP : BeltTabTwo {
             const int r = (R0 + k) & 3;
             t[r] = *(lds_u32 *)(uintptr_t)(a[k] + (r == 3 ? 128 : 0));
         }
+        // ONEWAIT (experiment, variant 22): all four entries asked for at one point, so that ONE s_waitcnt serves the G-box
+        // instead of one per first use (the entries come back in order, a few cycles apart)
+        if constexpr (ONEWAIT) asm("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
         uint32_t u, v;
         asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(u) : "v"(t[2]), "v"(t[1]));
         asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(v) : "v"(u), "v"(t[0]));
@@ -306,6 +310,8 @@ struct BeltTabTwoP : BeltTabTwo {
         return g;
     }
 };
+typedef BeltTabTwoPT<false> BeltTabTwoP;
+typedef BeltTabTwoPT<true> BeltTabTwoQ;
 
 struct BeltTabSmall {
     static constexpr int kBytes = 4 * 256 * 4;             // 4096

@@ -735,6 +735,7 @@ err_t launch_belt_ctr_blocks(void *d_buf, size_t nblocks, const uint32_t key[8],
     case 18: return launch_ctr_t<BeltTabTwoL, 1, 7>(d_buf, nblocks, k, c, first, d_last_gamma, st);    // 16 + hoisted round-1 G-box
     case 19: return launch_ctr_t<BeltTabTwoS, 2, 7>(d_buf, nblocks, k, c, first, d_last_gamma, st);    // 17 with 2 blocks per lane
     case 21: return launch_ctr_t<BeltTabTwo, 1, 7>(d_buf, nblocks, k, c, first, d_last_gamma, st);     // the product up to 4ab23f3
+    case 22: return launch_ctr_t<BeltTabTwoQ, 1, 7>(d_buf, nblocks, k, c, first, d_last_gamma, st);    // 20 with one s_waitcnt per G-box
     case 20: return launch_ctr_t<BeltTabTwoP, 1, 7>(d_buf, nblocks, k, c, first, d_last_gamma, st);    // 18 with three address-register sets
     // product (round 3): contiguous tile ranges + non-temporal stream accesses, +1 % (profiles/r03_belt_mem_ab.txt); the table
     // type CtrTab = BeltTabTwoP (one-instruction LDS addresses), +15 % (profiles/r03_belt_sdwa_ab.txt)

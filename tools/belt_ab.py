@@ -21,6 +21,7 @@ NAMES = {0: "product: variant 20 (SDWA addresses, v_lshl_or combine, three regis
          17: "as 15 with the hoisted round-1 G-box",
          18: "as 16 with the hoisted round-1 G-box",
          19: "as 17 with 2 blocks per lane",
+         22: "as 20 with all four entries of a G-box awaited at one point (one s_waitcnt per G-box)",
          20: "as 18 with three address-register sets instead of seven",
          15: "as 14 with every LDS address made by one v_mov_b32_sdwa (byte k of x into byte 1 of a register that holds the lane base)",
          13: "round-2 product: two-table 64 KiB, 1 block/lane, tiles dealt round-robin, plain loads/stores",
