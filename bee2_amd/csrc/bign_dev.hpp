@@ -84,6 +84,36 @@ __device__ __forceinline__ void mac_col(uint64_t &acc, uint32_t &c2, uint32_t a,
     }
 }
 
+// TWO products of one column: mad, mad, addc, addc, each carry in its own SGPR pair.  gfx940+ wants a wait state between a VALU
+// that writes an SGPR and the VALU that reads it; alone, every v_mad_u64_u32 / v_addc_co_u32 pair gets an s_nop from the
+// compiler on both sides (3 878 of the 9 900 instructions of bign_main_kernel<8>).  Here the second multiply-add IS the wait
+// state of the first carry: same arithmetic, no s_nop -- +8.6 % multiply-add throughput at 4 wavefronts per SIMD, +21 % at 3,
+// +67 % on a lone wavefront in tools/ubench/mad_chain.hip (form D).  MEASURED IN THE KERNELS AND NOT TAKEN: bign_main_kernel<8>
+// drops from 9 932 to 7 974 instructions (s_nop 3 878 -> 1 900) and 2^18 verifications take the same 2.17 ms (120.4 against
+// 120.0-120.6 M/s), signing +1 % -- the s_nop of a wavefront are issue slots other wavefronts fill (profiles/r03_mad_pairs.txt).
+// BIGN_MAC_PAIRS=1 builds the paired form (all 232 bign GPU tests pass with it); 0, the product, is the audited order.
+#ifndef BIGN_MAC_PAIRS
+#define BIGN_MAC_PAIRS 0
+#endif
+template <bool FIRST>
+__device__ __forceinline__ void mac2(uint64_t &acc, uint32_t &c2, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1)
+{
+#if BIGN_MAC_PAIRS
+    uint64_t cy0, cy1;
+    if constexpr (FIRST)
+        asm("v_mad_u64_u32 %0, %2, %4, %5, %0\n\tv_mad_u64_u32 %0, %3, %6, %7, %0\n\t"
+            "v_addc_co_u32 %1, %2, 0, 0, %2\n\tv_addc_co_u32 %1, %3, 0, %1, %3"
+            : "+v"(acc), "=&v"(c2), "=&s"(cy0), "=&s"(cy1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+    else
+        asm("v_mad_u64_u32 %0, %2, %4, %5, %0\n\tv_mad_u64_u32 %0, %3, %6, %7, %0\n\t"
+            "v_addc_co_u32 %1, %2, 0, %1, %2\n\tv_addc_co_u32 %1, %3, 0, %1, %3"
+            : "+v"(acc), "+v"(c2), "=&s"(cy0), "=&s"(cy1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+#else
+    mac_col<FIRST>(acc, c2, a0, b0);
+    mac_col<false>(acc, c2, a1, b1);
+#endif
+}
+
 template <int N>
 __device__ __forceinline__ void fe_set_zero(feT<N> &r)
 {
@@ -265,10 +295,12 @@ __device__ __forceinline__ void fe_mul_body(feT<N> &r, const feT<N> &a, const fe
     static_for<0, 2 * N - 1>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         constexpr int i0 = k < N ? 0 : k - N + 1;          // first row with a product in column k
-        static_for<i0, (k < N ? k : N - 1) + 1>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            mac_col<i == i0, k == 0 || k == 2 * N - 2>(acc, c2, a.v[i], b.v[k - i]);
+        constexpr int cnt = (k < N ? k : N - 1) + 1 - i0;  // products in column k, taken two at a time (mac2)
+        static_for<0, cnt / 2>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int i = i0 + 2 * decltype(pc)::value;
+            mac2<i == i0>(acc, c2, a.v[i], b.v[k - i], a.v[i + 1], b.v[k - i - 1]);
         });
+        if constexpr (cnt % 2) mac_col<cnt == 1, k == 0 || k == 2 * N - 2>(acc, c2, a.v[i0 + cnt - 1], b.v[k - i0 - cnt + 1]);
         w[k] = (uint32_t)acc;
         acc = (acc >> 32) | ((uint64_t)c2 << 32);
     });
@@ -301,14 +333,24 @@ __device__ __forceinline__ void fe_sqr_body(feT<N> &r, const feT<N> &a)
     // (profiles/r01_bign512_sqr_fix.txt: SQ_INSTS_SALU > SQ_INSTS_VALU in bign_main_kernel<16>).
     static_for<0, 2 * N>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
-        static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int j = k - i;                 // position inside row i's vector
-            constexpr bool first = i == (k < N ? 0 : k - N);   // column k's first product (k <= 2N-2)
-            if constexpr (j == i) mac_col<first, k == 0 || k == 2 * N - 2>(acc, c2, a.v[i], a.v[i]);
-            else if constexpr (j == i + 1 && j < N) mac_col<first>(acc, c2, a.v[i], e[j]);
-            else if constexpr (j >= i + 2 && j <= N) mac_col<first>(acc, c2, a.v[i], d[j]);
+        // rows i0 .. k / 2 have a product in column k (none in column 2N - 1): row i meets position j = k - i of its vector,
+        // a_i itself for j = i, e_j for j = i + 1, d_j beyond; two products at a time (mac2)
+        constexpr int i0 = k < N ? 0 : k - N;
+        constexpr int cnt = k <= 2 * N - 2 ? k / 2 - i0 + 1 : 0;
+        auto other = [&](auto ic) __attribute__((always_inline)) -> uint32_t {
+            constexpr int i = decltype(ic)::value, j = k - i;
+            if constexpr (j == i) return a.v[i];
+            else if constexpr (j == i + 1) return e[j];
+            else return d[j];
+        };
+        static_for<0, cnt / 2>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int i = i0 + 2 * decltype(pc)::value;
+            mac2<i == i0>(acc, c2, a.v[i], other(IntC<i>{}), a.v[i + 1], other(IntC<i + 1>{}));
         });
+        if constexpr (cnt % 2) {
+            constexpr int i = i0 + cnt - 1;
+            mac_col<cnt == 1, k == 0 || k == 2 * N - 2>(acc, c2, a.v[i], other(IntC<i>{}));
+        }
         w[k] = (uint32_t)acc;
         acc = (acc >> 32) | ((uint64_t)c2 << 32);
         c2 = 0;

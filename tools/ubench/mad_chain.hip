@@ -24,6 +24,10 @@ template <int FORM> __global__ void k(uint32_t *out, uint32_t seed)
                 asm volatile("v_mad_u64_u32 %0, s[10:11], %4, %5, %0\n v_mad_u64_u32 %2, s[12:13], %5, %4, %2\n"
                              "v_addc_co_u32 %1, s[10:11], 0, %1, s[10:11]\n v_addc_co_u32 %3, s[12:13], 0, %3, s[12:13]"
                              : "+v"(accA), "+v"(cA), "+v"(accB), "+v"(cB) : "v"(a), "v"(b) : "s10", "s11", "s12", "s13");
+            if (FORM == 3)        // D: ONE column (same accumulator, same counter), the two carries in their own registers, no s_nop
+                asm volatile("v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n v_mad_u64_u32 %0, s[12:13], %3, %2, %0\n"
+                             "v_addc_co_u32 %1, s[10:11], 0, %1, s[10:11]\n v_addc_co_u32 %1, s[12:13], 0, %1, s[12:13]"
+                             : "+v"(accA), "+v"(cA) : "v"(a), "v"(b) : "s10", "s11", "s12", "s13");
             if (FORM == 2)
                 asm volatile("v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n v_addc_co_u32 %1, s[10:11], 0, %1, s[10:11]\n"
                              "v_mad_u64_u32 %0, s[10:11], %3, %2, %0\n v_addc_co_u32 %1, s[10:11], 0, %1, s[10:11]"
@@ -57,10 +61,20 @@ int main()
 {
     uint32_t *d;
     CHK(hipMalloc(&d, 256 * 4 * 8 * 64 * 4));
+    {   // same arithmetic in A, C and D: the outputs must agree if the hazard is respected (C: not guaranteed)
+        uint32_t h[3][64];
+        hipLaunchKernelGGL(k<0>, dim3(1), dim3(64), 0, 0, d, 777u); CHK(hipMemcpy(h[0], d, 256, hipMemcpyDeviceToHost));
+        hipLaunchKernelGGL(k<2>, dim3(1), dim3(64), 0, 0, d, 777u); CHK(hipMemcpy(h[1], d, 256, hipMemcpyDeviceToHost));
+        hipLaunchKernelGGL(k<3>, dim3(1), dim3(64), 0, 0, d, 777u); CHK(hipMemcpy(h[2], d, 256, hipMemcpyDeviceToHost));
+        int badC = 0, badD = 0;
+        for (int i = 0; i < 64; ++i) { badC += h[0][i] != h[1][i]; badD += h[0][i] != h[2][i]; }
+        printf("results: C differs from A in %d of 64 lanes, D in %d\n", badC, badD);
+    }
     for (int wps : {1, 2, 3, 4, 8}) {
         if (run<0>("A: one chain, s_nop as compiled", wps, d)) return 1;
         if (run<1>("B: two chains interleaved, no s_nop", wps, d)) return 1;
         if (run<2>("C: one chain, no s_nop (timing only)", wps, d)) return 1;
+        if (run<3>("D: one chain, carries in two registers, no nop", wps, d)) return 1;
     }
     return 0;
 }
