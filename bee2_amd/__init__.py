@@ -11,8 +11,10 @@ from .engine import (  # noqa: F401
     ERR_BAD_PUBKEY,
     ERR_BAD_SIG,
     ERR_OK,
+    EXP_LIB_PATH,
     LIB_PATH,
     build,
     lib_exports,
     load,
+    load_experiments,
 )

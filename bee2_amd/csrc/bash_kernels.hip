@@ -392,6 +392,7 @@ err_t launch_bashF_batch(void *d_states, size_t n, hipStream_t st)
 #define TILEF(L, S, O, W, F) launch_bashF_tile<L, S, O, W, F>((unsigned)grid, p, n, st)
     // Variants kept for the A/B record (profiles/r02_bashF_variants.txt lists every one that was measured; the
     // numbers there name them as below).  Product = default.
+#ifdef BEE2HIP_EXPERIMENTS      // the A/B record only (tools/ab_lib.sh builds it); the product library holds ONE instantiation
     switch (v) {
     case 0: hipLaunchKernelGGL(bashF_batch_kernel<1>, dim3((unsigned)grid), dim3(BASHF_WG), lds4, st, p, n); break;   // r01 product
     case 1: TILE(1, 1, 1, 3); break;         // LDS-DMA load, slab store, r01 staged order
@@ -409,6 +410,11 @@ err_t launch_bashF_batch(void *d_states, size_t n, hipStream_t st)
     case 72: TILEF(0, 2, 124, 6, 3 | 12); break;     // product + both
     default: TILEF(0, 2, 124, 6, 3);         // product (v61): W = 4, priority, direct load, half-slab store
     }
+    (void)lds4; (void)nwg; (void)nwaves;
+#else
+    (void)v; (void)lds4; (void)nwg; (void)nwaves;
+    TILEF(0, 2, 124, 6, 3);                  // W = 4, priority, direct load, half-slab store
+#endif
 #undef TILE
 #undef TILEF
     B2H_TRY(hipGetLastError());

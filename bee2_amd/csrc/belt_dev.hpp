@@ -23,8 +23,10 @@
 namespace bee2hip {
 
 // the belt S-box, generated at library load by the standard's LFSR recipe
-// (belt_block.c:21-35) -- see capi.cpp -- and uploaded once per device.
-extern __constant__ uint8_t c_beltH[256];
+// (belt_block.c:21-35) -- see capi.cpp -- and uploaded once per device.  The library is two translation units without
+// relocatable device code (bee2hip_tu_belt.hip, bee2hip_tu_bign.hip: they compile side by side), so each holds its own
+// 256-byte copy: upload_beltH() fills the one of the TU it is compiled in, upload_beltH_bign() the other.
+static __constant__ uint8_t c_beltH[256];
 
 __device__ __forceinline__ uint32_t rotl32c(uint32_t x, int r)
 {

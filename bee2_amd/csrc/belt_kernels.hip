@@ -27,7 +27,6 @@
 
 namespace bee2hip {
 
-__constant__ uint8_t c_beltH[256];
 __device__ uint32_t d_beltT4[1024];       // experiment only (BeltTabHyb): rotl(S, 5 / 13 / 21 / 29), 4 x 256 dwords
 
 constexpr int CTR_WG = 1024;
@@ -637,13 +636,13 @@ void belt_decr_blocks_kernel(uint4 *__restrict__ blocks, size_t nblocks, BeltKey
 
 // per-device launch facts (several devices may be driven from one process)
 static int g_num_cus[64];
-static int cur_dev()
+int cur_dev()
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     return dev;
 }
-static int num_cus()
+int num_cus()
 {
     const int dev = cur_dev();
     if (!g_num_cus[dev]) {
@@ -659,7 +658,7 @@ static int num_cus()
 // hipFuncAttributeMaxDynamicSharedMemorySize, once per (device, kernel) -- again only when a launch asks for more than the
 // kernel was granted so far -- and safe from any thread (the flags used to be plain static bools per call site: a benign
 // race, but a race)
-static hipError_t dyn_lds_once(const void *kern, size_t bytes)
+hipError_t dyn_lds_once(const void *kern, size_t bytes)
 {
     static std::mutex mu;
     static std::vector<std::pair<std::pair<int, const void *>, size_t>> done;
@@ -714,6 +713,7 @@ err_t launch_belt_ctr_blocks(void *d_buf, size_t nblocks, const uint32_t key[8],
     BeltKey k; BeltCtr c;
     for (int i = 0; i < 8; ++i) k.k[i] = key[i];
     for (int i = 0; i < 4; ++i) c.c[i] = ctr0[i];
+#ifdef BEE2HIP_EXPERIMENTS      // the A/B record (tools/belt_ab.py; built by tools/ab_lib.sh only)
     switch (g_ctr_variant) {          // A/B only (bee2hip_internal_tune(1, v)); 0 = the product
     case 1: return launch_ctr_t<BeltTabTwo, 2>(d_buf, nblocks, k, c, first, d_last_gamma, st);
     case 2: return launch_ctr_t<BeltTabTwo, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);
@@ -737,9 +737,12 @@ err_t launch_belt_ctr_blocks(void *d_buf, size_t nblocks, const uint32_t key[8],
     case 21: return launch_ctr_t<BeltTabTwo, 1, 7>(d_buf, nblocks, k, c, first, d_last_gamma, st);     // the product up to 4ab23f3
     case 22: return launch_ctr_t<BeltTabTwoQ, 1, 7>(d_buf, nblocks, k, c, first, d_last_gamma, st);    // 20 with one s_waitcnt per G-box
     case 20: return launch_ctr_t<BeltTabTwoP, 1, 7>(d_buf, nblocks, k, c, first, d_last_gamma, st);    // 18 with three address-register sets
+    default: break;
+    }
+#endif
     // product (round 3): contiguous tile ranges + non-temporal stream accesses, +1 % (profiles/r03_belt_mem_ab.txt); the table
     // type CtrTab = BeltTabTwoP (one-instruction LDS addresses), +15 % (profiles/r03_belt_sdwa_ab.txt)
-    default: {
+    {
         // block i uses ctr0 + ((first + 1 + i) mod 2^64): the upper 64 bits of that sum stay put over the launch unless the
         // lower 64 bits wrap inside it or the 64-bit offset itself does (then the carry into the upper half goes away again)
         const uint64_t lo = ((uint64_t)c.c[1] << 32) | c.c[0];
@@ -747,7 +750,6 @@ err_t launch_belt_ctr_blocks(void *d_buf, size_t nblocks, const uint32_t key[8],
         const uint64_t s0 = lo + a0, e0 = s0 + (nblocks - 1);
         if (e0 >= s0 && a1 >= a0) return launch_ctr_t<CtrTab, CTR_ILP, 7>(d_buf, nblocks, k, c, first, d_last_gamma, st);
         return launch_ctr_t<CtrTab, CTR_ILP, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);
-    }
     }
 }
 

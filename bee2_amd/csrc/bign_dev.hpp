@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "bash_dev.hpp"        // bitop3
 
 namespace bee2hip {
 

@@ -395,10 +395,11 @@ __device__ __forceinline__ uint32_t g_mul_base_ct(gfe<N> &x, gfe<N> &y, const ui
 
 // scalars n x 4N octets.  MODE 0: signing (x_R only, every lane computes), 1: bignPubkeyCalc (0 < d < q or ERR_BAD_PRIVKEY,
 // refused keys leave zeros), 2: bignKeypairGen (any d; ERR_BAD_PARAMS when d G = O) -- as bign_mulbase_ct_kernel
-template <int N, int MODE>
+// (the mode is a launch argument -- public, wavefront-uniform -- so each curve size is ONE kernel of the product library)
+template <int N>
 __global__ __launch_bounds__(64)
 void bign_generic_mulbase_kernel(const uint8_t *__restrict__ scalars, size_t n, uint32_t *__restrict__ codes,
-                                 uint8_t *__restrict__ xy_out, GenCurve<N> C, QArg<N> qa)
+                                 uint8_t *__restrict__ xy_out, GenCurve<N> C, QArg<N> qa, const int MODE)
 {
     constexpr int NO = 4 * N;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -406,20 +407,20 @@ void bign_generic_mulbase_kernel(const uint8_t *__restrict__ scalars, size_t n, 
     uint32_t k[N];
     load_words_bytes(k, scalars + NO * idx);
     uint32_t valid = ~0u;
-    if constexpr (MODE == 1) {
+    if (MODE == 1) {
         valid = ct_in_range_q(k, qa);
         codes[idx] = ct_sel(valid, (uint32_t)ERR_OK, ERR_BAD_PRIVKEY_V);
     }
     gfe<N> x, y;
     const uint32_t inf = g_mul_base_ct(x, y, k, C);
-    if constexpr (MODE == 2) {
+    if (MODE == 2) {
         valid = ~inf;
         codes[idx] = ct_sel(inf, (uint32_t)ERR_BAD_PARAMS, (uint32_t)ERR_OK);
     }
-    uint32_t *o = reinterpret_cast<uint32_t *>(xy_out + (MODE == 0 ? NO : 2 * NO) * idx);
+    uint32_t *o = reinterpret_cast<uint32_t *>(xy_out + (size_t)(MODE == 0 ? NO : 2 * NO) * idx);
 #pragma unroll
     for (int i = 0; i < N; ++i) o[i] = x.v[i] & valid;
-    if constexpr (MODE != 0) {
+    if (MODE != 0) {
 #pragma unroll
         for (int i = 0; i < N; ++i) o[N + i] = y.v[i] & valid;
     }
@@ -622,11 +623,11 @@ err_t pubkey_calc_generic_t(const bign_params *params, bool keygen, const void *
     h_load<N>(qa.q, params->q);
     const unsigned g64 = (unsigned)((n + 63) / 64);
     if (!keygen)
-        hipLaunchKernelGGL((bign_generic_mulbase_kernel<N, 1>), dim3(g64), dim3(64), 0, st, (const uint8_t *)d_privkeys, n,
-                           (uint32_t *)d_codes, (uint8_t *)d_pubkeys, C, qa);
+        hipLaunchKernelGGL((bign_generic_mulbase_kernel<N>), dim3(g64), dim3(64), 0, st, (const uint8_t *)d_privkeys, n,
+                           (uint32_t *)d_codes, (uint8_t *)d_pubkeys, C, qa, 1);
     else
-        hipLaunchKernelGGL((bign_generic_mulbase_kernel<N, 2>), dim3(g64), dim3(64), 0, st, (const uint8_t *)d_privkeys, n,
-                           (uint32_t *)d_codes, (uint8_t *)d_pubkeys, C, qa);
+        hipLaunchKernelGGL((bign_generic_mulbase_kernel<N>), dim3(g64), dim3(64), 0, st, (const uint8_t *)d_privkeys, n,
+                           (uint32_t *)d_codes, (uint8_t *)d_pubkeys, C, qa, 2);
     B2H_TRY(hipGetLastError());
     return ERR_OK;
 }
@@ -666,8 +667,8 @@ err_t sign_generic_t(const bign_params *params, int mode, const uint8_t *oid_der
                            (const uint8_t *)d_privkeys, (const uint8_t *)d_aux, n, qa, S.status);
         B2H_TRY(hipMemcpyAsync(S.k, d_aux, n * 4 * N, hipMemcpyDeviceToDevice, st));
     }
-    hipLaunchKernelGGL((bign_generic_mulbase_kernel<N, 0>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const uint8_t *)S.k, n,
-                       (uint32_t *)nullptr, S.rx, C, qa);
+    hipLaunchKernelGGL((bign_generic_mulbase_kernel<N>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const uint8_t *)S.k, n,
+                       (uint32_t *)nullptr, S.rx, C, qa, 0);
     {
         constexpr int ROW = (OID_MAX + 2 * 64 + 31) / 32 * 8 + 1;
         const size_t lds = BeltTabTwo::kBytes + (size_t)SIGN_WG * ROW * 4;

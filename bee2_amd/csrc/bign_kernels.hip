@@ -990,6 +990,7 @@ void bign_pubkey_val_kernel(const uint8_t *__restrict__ pubkeys, size_t n, uint3
     codes[idx] = ok ? ERR_OK : ERR_BAD_PUBKEY;
 }
 
+#ifdef BEE2HIP_EXPERIMENTS
 // --------------------------------------------------------- debug / self-test ---
 // element-wise field ops over arrays of N-limb values, used by tests/test_gpu_bign.py
 // to check the GF(p) layer against Python big integers.  op: 0 mul, 1 sqr, 2 add, 3 sub,
@@ -1100,6 +1101,8 @@ __global__ void bign_debug_fe_kernel(int op, const uint32_t *a, const uint32_t *
     fe_canon(r, r);
     for (int i = 0; i < N; ++i) out[N * idx + i] = r.v[i];
 }
+
+#endif   // BEE2HIP_EXPERIMENTS
 
 // ------------------------------------------------------------------ host side ---
 struct BignDevice {
@@ -1302,13 +1305,15 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
             const bool one_wave = g_verify_lanes == 9 || (g_verify_lanes != 10 && n > ((size_t)3 << 10) && n <= ((size_t)1 << 12));
             if (helper && one_wave) code = launch(bign_quad29_kernel<N, 64, 8>, 64, 8);
             else if (helper) code = launch(bign_quad29_kernel<N, 256, 8>, 256, 8);
+#ifdef BEE2HIP_EXPERIMENTS      // reachable only with the helper quad switched off (tune 2): A/B record
             else if (n <= ((size_t)1 << 13)) code = launch(bign_quad29_kernel<N, 64, 4>, 64, 4);
+#endif
             else code = launch(bign_quad29_kernel<N, 256, 4>, 256, 4);
         }
         if (code != ERR_OK) return code;
     }
     if (path != 3) {
-        if (N != 8)
+        if constexpr (N != 8)
             hipLaunchKernelGGL(bign_points_kernel<N>, dim3(g256), dim3(256), 0, st, (const uint8_t *)d_hashes,
                                (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S);
         hipLaunchKernelGGL(bign_prep_kernel<N>, dim3((unsigned)((plan + 255) / 256)), dim3(256), 0, st,
@@ -1415,6 +1420,7 @@ err_t launch_bign_pubkey_val(size_t l, const void *d_pubkeys, size_t n, void *d_
     return ERR_OK;
 }
 
+#ifdef BEE2HIP_EXPERIMENTS
 err_t launch_bign_debug_fe(size_t l, int op, const void *a, const void *b, void *out, size_t n, hipStream_t st)
 {
     if (n == 0) return ERR_OK;
@@ -1424,6 +1430,14 @@ err_t launch_bign_debug_fe(size_t l, int op, const void *a, const void *b, void 
     else if (l == 256) hipLaunchKernelGGL(bign_debug_fe_kernel<16>, g, t, 0, st, op, (const uint32_t *)a, (const uint32_t *)b, (uint32_t *)out, n);
     else return ERR_BAD_PARAMS;
     B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+#endif
+
+// this translation unit's copy of the belt S-box (belt_dev.hpp)
+err_t upload_beltH_bign(const uint8_t *H)
+{
+    B2H_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_beltH), H, 256));
     return ERR_OK;
 }
 

@@ -414,11 +414,11 @@ __device__ __forceinline__ void proj_add_complete(projT<N> &P, const projT<N> &Q
 // butterfly of log2(LANES) complete additions leaves the sum in every lane of the group.  No branch, address or shuffle
 // pattern depends on k.  LANES = 64 is the latency form (one window per lane on the 256-bit curve); 16 and 4 trade depth for
 // work and fill the device at 2^12 and 2^14 scalars (profiles/r03_sign_coop.txt).  Returns as mul_base_ct.
-template <int N, int LANES>
+// LANES is a launch argument (public, wavefront-uniform; a power of two, 2 .. 64): one kernel per curve serves 64 / 16 / 4.
+template <int N>
 __device__ __forceinline__ uint32_t mul_base_coop(feT<N> &x, feT<N> &y, const uint8_t *__restrict__ kbytes,
-                                                  const uint32_t *__restrict__ gtab8)
+                                                  const uint32_t *__restrict__ gtab8, const int LANES)
 {
-    static_assert(LANES >= 2 && LANES <= 64 && (LANES & (LANES - 1)) == 0, "lanes per scalar: a power of two within a wavefront");
     const int lane = (int)(threadIdx.x & (unsigned)(LANES - 1));
     feT<N> b;
 #pragma unroll
@@ -426,7 +426,7 @@ __device__ __forceinline__ uint32_t mul_base_coop(feT<N> &x, feT<N> &y, const ui
     projT<N> acc;
     fe_set_zero(acc.X); fe_set_one(acc.Y); fe_set_zero(acc.Z);          // O
 #pragma unroll 1
-    for (int t = 0; t < (8 * N + LANES - 1) / LANES; ++t) {
+    for (int t = 0; t < ((8 * N + LANES - 1) >> __builtin_ctz((unsigned)LANES)); ++t) {
         const int w = lane + LANES * t;
         const bool mine = w < 8 * N;                 // not a secret
         const int wc = mine ? w : 0;
@@ -478,30 +478,33 @@ __device__ __forceinline__ uint32_t mul_base_coop(feT<N> &x, feT<N> &y, const ui
 }
 
 // LANES lanes per scalar (block = one wavefront = 64 / LANES scalars); modes and outputs as bign_mulbase_ct_kernel.
-template <int N, int MODE, bool X_ONLY, int LANES>
+// MODE, X_ONLY and LANES are launch arguments (public, wavefront-uniform): one kernel per curve in the product library.
+template <int N>
 __global__ __launch_bounds__(64)
 void bign_mulbase_coop_kernel(const uint8_t *__restrict__ scalars, size_t n, uint32_t *__restrict__ codes,
-                              uint8_t *__restrict__ xy_out, const uint32_t *__restrict__ gtab8)
+                              uint8_t *__restrict__ xy_out, const uint32_t *__restrict__ gtab8, const int MODE, const int X_ONLY,
+                              const int LANES)
 {
     constexpr int NO = 4 * N;
-    const size_t idx = (size_t)blockIdx.x * (64 / LANES) + threadIdx.x / LANES;
+    const int lsh = __builtin_ctz((unsigned)LANES);
+    const size_t idx = (size_t)blockIdx.x * (64u >> lsh) + (threadIdx.x >> lsh);
     if (idx >= n) return;                            // a whole group leaves: no partner of a working lane goes missing
     uint32_t valid = ~0u;
-    if constexpr (MODE == 1) {
+    if (MODE == 1) {
         uint32_t k[N];
         load_words_bytes(k, scalars + NO * idx);
         valid = ct_in_range_q(k);
     }
     feT<N> x, y;
-    const uint32_t inf = mul_base_coop<N, LANES>(x, y, scalars + NO * idx, gtab8);
-    if constexpr (MODE == 2) valid = ~inf;
+    const uint32_t inf = mul_base_coop<N>(x, y, scalars + NO * idx, gtab8, LANES);
+    if (MODE == 2) valid = ~inf;
     if ((threadIdx.x & (unsigned)(LANES - 1)) != 0) return;
-    if constexpr (MODE == 1) codes[idx] = ct_sel(valid, (uint32_t)ERR_OK, ERR_BAD_PRIVKEY_V);
-    if constexpr (MODE == 2) codes[idx] = ct_sel(inf, (uint32_t)ERR_BAD_PARAMS, (uint32_t)ERR_OK);
-    uint32_t *o = reinterpret_cast<uint32_t *>(xy_out + (X_ONLY ? NO : 2 * NO) * idx);
+    if (MODE == 1) codes[idx] = ct_sel(valid, (uint32_t)ERR_OK, ERR_BAD_PRIVKEY_V);
+    if (MODE == 2) codes[idx] = ct_sel(inf, (uint32_t)ERR_BAD_PARAMS, (uint32_t)ERR_OK);
+    uint32_t *o = reinterpret_cast<uint32_t *>(xy_out + (size_t)(X_ONLY ? NO : 2 * NO) * idx);
 #pragma unroll
     for (int i = 0; i < N; ++i) o[i] = x.v[i] & valid;
-    if constexpr (!X_ONLY) {
+    if (!X_ONLY) {
 #pragma unroll
         for (int i = 0; i < N; ++i) o[N + i] = y.v[i] & valid;
     }
@@ -517,10 +520,11 @@ void bign_mulbase_coop_kernel(const uint8_t *__restrict__ scalars, size_t n, uin
 #ifndef SIGN_MULBASE_WAVES
 #define SIGN_MULBASE_WAVES 3        // 168 VGPRs, 15 spilled: +2.2 % over 2 (186 VGPRs); 4 (128 VGPRs, 110-124 spilled): -31 %
 #endif
-template <int N, int MODE, bool X_ONLY, int FORM = 0>          // FORM 0: 4-bit windows, 1: signed 6-bit + complete additions, 2: + Jacobian
+template <int N, int FORM = 0>          // FORM 0: 4-bit windows, 1: signed 6-bit + complete additions, 2: + Jacobian
 __global__ __launch_bounds__(256, (N == 8 ? SIGN_MULBASE_WAVES : 1))
 void bign_mulbase_ct_kernel(const uint8_t *__restrict__ scalars, size_t n, uint32_t *__restrict__ codes,
-                            uint8_t *__restrict__ xy_out, const uint32_t *__restrict__ gtab8)      // FORM > 0: the signed 6-bit table
+                            uint8_t *__restrict__ xy_out, const uint32_t *__restrict__ gtab8,      // FORM > 0: the signed 6-bit table
+                            const int MODE, const int X_ONLY)                                      // launch arguments: public, uniform
 {
     constexpr int NO = 4 * N;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -528,7 +532,7 @@ void bign_mulbase_ct_kernel(const uint8_t *__restrict__ scalars, size_t n, uint3
     uint32_t k[N];
     load_words_bytes(k, scalars + NO * idx);
     uint32_t valid = ~0u;
-    if constexpr (MODE == 1) {
+    if (MODE == 1) {
         valid = ct_in_range_q(k);
         codes[idx] = ct_sel(valid, (uint32_t)ERR_OK, ERR_BAD_PRIVKEY_V);
     }
@@ -537,14 +541,14 @@ void bign_mulbase_ct_kernel(const uint8_t *__restrict__ scalars, size_t n, uint3
     if constexpr (FORM == 2) inf = mul_base_ct6<N, true>(x, y, k, gtab8);
     else if constexpr (FORM == 1) inf = mul_base_ct6<N, false>(x, y, k, gtab8);
     else inf = mul_base_ct(x, y, k, gtab8);
-    if constexpr (MODE == 2) {
+    if (MODE == 2) {
         valid = ~inf;
         codes[idx] = ct_sel(inf, (uint32_t)ERR_BAD_PARAMS, (uint32_t)ERR_OK);
     }
-    uint32_t *o = reinterpret_cast<uint32_t *>(xy_out + (X_ONLY ? NO : 2 * NO) * idx);
+    uint32_t *o = reinterpret_cast<uint32_t *>(xy_out + (size_t)(X_ONLY ? NO : 2 * NO) * idx);
 #pragma unroll
     for (int i = 0; i < N; ++i) o[i] = x.v[i] & valid;
-    if constexpr (!X_ONLY) {
+    if (!X_ONLY) {
 #pragma unroll
         for (int i = 0; i < N; ++i) o[N + i] = y.v[i] & valid;
     }
@@ -590,8 +594,9 @@ constexpr int SIGN_T_MAX = 64;                       // longest additional input
 // row_words: 32-bit words of a lane's LDS row (odd; sign_row_words() of the message this launch hashes).  The rows used to be
 // sized for the longest OID and t the kernel accepts (65 words: with the 64 KiB table one workgroup of 256 lanes per CU, i.e.
 // ONE wavefront per SIMD walking dependent block encryptions); sized for the message at hand, 1024 lanes share a table.
-template <int N, int WG = SIGN_WG>
-__global__ __launch_bounds__(WG)
+// (workgroup size: a launch parameter, 256 .. 1024 -- one kernel per curve)
+template <int N>
+__global__ __launch_bounds__(1024)
 void bign_sign_nonce_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ privkeys,
                             const uint8_t *__restrict__ t, uint32_t t_len, uint32_t t_stride,
                             const uint8_t *__restrict__ theta_in, size_t n, OidArg oid, QArg<N> qa,
@@ -602,7 +607,7 @@ void bign_sign_nonce_kernel(const uint8_t *__restrict__ hashes, const uint8_t *_
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     uint8_t *s_tab = s_dyn;
     uint32_t *s_rows = reinterpret_cast<uint32_t *>(s_dyn + BeltTabTwo::kBytes);
-    BeltTabTwo::fill(s_tab, threadIdx.x, WG);
+    BeltTabTwo::fill(s_tab, threadIdx.x, blockDim.x);
     __syncthreads();
     const BeltTabTwo T(s_tab);
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -788,8 +793,8 @@ __device__ __forceinline__ void sub_mod_q_ct(uint32_t (&c)[N], const uint32_t (&
 
 // s0 = belt-hash(oid || <x_R> || H)[0 .. l bits), s1 = (k - (s0 + 2^l) d - H) mod q (bign_sign.c:221-238);
 // wipes k.  x_R and H are public, so this hash could use any table; it shares BeltTabTwo with the nonce kernel.
-template <int N, int WG = SIGN_WG>
-__global__ __launch_bounds__(WG)
+template <int N>
+__global__ __launch_bounds__(1024)
 void bign_sign_tail_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ privkeys,
                            const uint8_t *__restrict__ rx, uint8_t *__restrict__ ks, size_t n, OidArg oid,
                            const uint32_t *__restrict__ status, uint8_t *__restrict__ sigs, uint32_t *__restrict__ codes,
@@ -800,7 +805,7 @@ void bign_sign_tail_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     uint8_t *s_tab = s_dyn;
     uint32_t *s_rows = reinterpret_cast<uint32_t *>(s_dyn + BeltTabTwo::kBytes);
-    BeltTabTwo::fill(s_tab, threadIdx.x, WG);
+    BeltTabTwo::fill(s_tab, threadIdx.x, blockDim.x);
     __syncthreads();
     const BeltTabTwo T(s_tab);
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -900,22 +905,18 @@ template <int N, int MODE, bool X_ONLY>
 static void launch_mulbase(int lanes, const uint8_t *scalars, size_t n, uint32_t *codes, uint8_t *out, const uint32_t *tab,
                            const uint32_t *tab6, hipStream_t st)
 {
-    const auto grid = [n](int l) { return dim3((unsigned)((n * (size_t)l + 63) / 64)); };
-    if (lanes == 64)
-        hipLaunchKernelGGL((bign_mulbase_coop_kernel<N, MODE, X_ONLY, 64>), grid(64), dim3(64), 0, st, scalars, n, codes, out, tab);
-    else if (lanes == 16)
-        hipLaunchKernelGGL((bign_mulbase_coop_kernel<N, MODE, X_ONLY, 16>), grid(16), dim3(64), 0, st, scalars, n, codes, out, tab);
-    else if (lanes == 4)
-        hipLaunchKernelGGL((bign_mulbase_coop_kernel<N, MODE, X_ONLY, 4>), grid(4), dim3(64), 0, st, scalars, n, codes, out, tab);
+    const dim3 g256((unsigned)((n + 255) / 256));
+    if (lanes == 64 || lanes == 16 || lanes == 4)
+        hipLaunchKernelGGL((bign_mulbase_coop_kernel<N>), dim3((unsigned)((n * (size_t)lanes + 63) / 64)), dim3(64), 0, st, scalars, n,
+                           codes, out, tab, MODE, (int)X_ONLY, lanes);
+#ifdef BEE2HIP_EXPERIMENTS      // second opinions of the tests and the A/B record (tools/sign_coop_ab.py)
     else if (lanes == 101)
-        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, MODE, X_ONLY, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scalars, n,
-                           codes, out, tab);
+        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 0>), g256, dim3(256), 0, st, scalars, n, codes, out, tab, MODE, (int)X_ONLY);
     else if (lanes == 102)
-        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, MODE, X_ONLY, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scalars, n,
-                           codes, out, tab6);
+        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 1>), g256, dim3(256), 0, st, scalars, n, codes, out, tab6, MODE, (int)X_ONLY);
+#endif
     else
-        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, MODE, X_ONLY, 2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scalars, n,
-                           codes, out, tab6);
+        hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 2>), g256, dim3(256), 0, st, scalars, n, codes, out, tab6, MODE, (int)X_ONLY);
 }
 
 template <int N>
@@ -986,8 +987,7 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
                                mode == 2 ? (const uint8_t *)d_aux : nullptr, n, oa, qa, S.status, S.k, rw);
             return ERR_OK;
         };
-        code = wg == 1024 ? go(bign_sign_nonce_kernel<N, 1024>) : wg == 512 ? go(bign_sign_nonce_kernel<N, 512>)
-                                                                            : go(bign_sign_nonce_kernel<N, 256>);
+        code = go(bign_sign_nonce_kernel<N>);
         if (code != ERR_OK) return code;
         kptr = S.k;
     } else {
@@ -1008,8 +1008,7 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
                                (uint8_t *)d_sigs, (uint32_t *)d_codes, rw);
             return ERR_OK;
         };
-        code = wg == 1024 ? go(bign_sign_tail_kernel<N, 1024>) : wg == 512 ? go(bign_sign_tail_kernel<N, 512>)
-                                                                           : go(bign_sign_tail_kernel<N, 256>);
+        code = go(bign_sign_tail_kernel<N>);
         if (code != ERR_OK) return code;
     }
     B2H_TRY(hipGetLastError());

@@ -59,7 +59,6 @@ const uint8_t *host_beltH()
     return g_H;
 }
 
-extern err_t upload_beltH(const uint8_t *H);       // belt_kernels.hip
 
 constexpr int MAX_DEV = 64;
 static std::mutex g_dev_mu;
@@ -74,6 +73,7 @@ err_t ensure_device()
     std::lock_guard<std::mutex> lk(g_dev_mu);
     if (g_dev_ready[dev]) return ERR_OK;
     err_t code = upload_beltH(host_beltH());
+    if (code == ERR_OK) code = upload_beltH_bign(host_beltH());
     if (code != ERR_OK) return code;
     g_dev_ready[dev] = true;
     return ERR_OK;
@@ -1293,6 +1293,7 @@ B2H_LEVEL_FACADE(192, 1, k_oid_bash384, 48)
 B2H_LEVEL_FACADE(256, 2, k_oid_bash512, 64)
 #undef B2H_LEVEL_FACADE
 
+#ifdef BEE2HIP_EXPERIMENTS
 extern "C" err_t bee2hip_debug_fe(int op, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream)
 {
     return launch_bign_debug_fe(128, op, d_a, d_b, d_out, n, as_stream(stream));
@@ -1302,6 +1303,7 @@ extern "C" err_t bee2hip_debug_feL(size_t l, int op, const void *d_a, const void
 {
     return launch_bign_debug_fe(l, op, d_a, d_b, d_out, n, as_stream(stream));
 }
+#endif
 
 // ============================================================= bash hashing ===
 // bash_hash_st / belt_mac_st (bee2 layouts) are defined in mixed_kernels.hip
@@ -1511,6 +1513,21 @@ extern "C" err_t bee2hip_bashHash_beltMAC_batch(const octet *msgs, size_t msg_le
     return ERR_OK;
 }
 
+// ============================================================ path policy (product ABI) ===
+extern "C" int bee2hip_path_policy(int mode)
+{
+    const int was = bee2hip::force_mode();
+    if (mode >= 0) bee2hip::g_force.store(mode == 1 ? bee2hip::FORCE_GPU : mode == 2 ? bee2hip::FORCE_CPU : bee2hip::FORCE_AUTO);
+    return was;
+}
+// drop-in helper calls so far: which = 0 host path (by size or by BEE2HIP_FORCE=cpu), 1 GPU path, 2 finished on the host
+// after the GPU path failed twice
+extern "C" unsigned long long bee2hip_path_count(int which)
+{
+    return which == 0 ? bee2hip::g_n_host.load() : which == 1 ? bee2hip::g_n_gpu.load() : bee2hip::g_n_fallback.load();
+}
+
+#ifdef BEE2HIP_EXPERIMENTS      // everything from here to the end of the kernel-timing hook: libbee2hip_exp.so only
 // ============================================================ internal tuning hook ===
 // A/B switch for experiment builds (tools/bashf_ab.py); not part of the product ABI (BEE2HIP_INTERNAL).
 namespace bee2hip { void set_bashF_variant(int v); void set_ctr_variant(int v); void set_verify_path(int v); void set_verify_split(int v); void set_sign_coop(int v); void set_sign_wg(int v); void set_fused_tab(int v); }
@@ -1599,6 +1616,7 @@ extern "C" err_t bee2hip_time_kernel(int which, int reps, void *d_a, void *d_b, 
     *ms = total / (float)reps;
     return code;
 }
+#endif   // BEE2HIP_EXPERIMENTS
 
 // ============================================ 8f-1: block decrypt, ECB, CBC ===
 static err_t decr_host_blocks(uint32_t *blocks, size_t n, const u32 key[8])

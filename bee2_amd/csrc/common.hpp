@@ -5,7 +5,9 @@
 #include <stdint.h>
 #include <string.h>
 #include "../../include/bee2hip.h"
+#ifdef BEE2HIP_EXPERIMENTS      // test / A/B hooks: only in libbee2hip_exp.so (bee2_amd/csrc/Makefile, target exp)
 #include "../../include/bee2hip_internal.h"
+#endif
 
 namespace bee2hip {
 
@@ -25,6 +27,13 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 // Grown on demand; growing frees the old block only after the stream has drained.
 err_t scratch_for_stream(hipStream_t st, int slot, size_t bytes, void **out);
 const uint8_t *host_beltH();                              // the belt S-box, generated once on the host (capi.hip)
+
+// per-device launch facts and the once-per-(device, kernel) dynamic-LDS grant (belt_kernels.hip)
+int cur_dev();
+int num_cus();
+hipError_t dyn_lds_once(const void *kern, size_t bytes);
+err_t upload_beltH(const uint8_t *H);            // the S-box copy of bee2hip_tu_belt.hip
+err_t upload_beltH_bign(const uint8_t *H);       // ... of bee2hip_tu_bign.hip
 
 // ---- kernel launchers (defined next to their kernels) ----
 err_t launch_bashF_batch(void *d_states, size_t n, hipStream_t st);

@@ -836,7 +836,9 @@ template <int RW, bool HASH, bool MAC>
 static err_t launch_fused_t(const void *d_msgs, size_t msg_len, size_t n, size_t l, const MacKey &key,
                             void *d_digests, void *d_tags, hipStream_t st)
 {
+#ifdef BEE2HIP_EXPERIMENTS      // A/B only (tools/fused_tab_ab.py): +0.5 %, bash-f's VALU work bounds the kernel
     if (MAC && g_fused_tab == 2) return launch_fused_tt<RW, HASH, MAC, BeltTabTwoP>(d_msgs, msg_len, n, l, key, d_digests, d_tags, st);
+#endif
     return launch_fused_tt<RW, HASH, MAC, BeltTabWide>(d_msgs, msg_len, n, l, key, d_digests, d_tags, st);
 }
 template <int RW, bool HASH, bool MAC, class Tab>
@@ -860,7 +862,9 @@ static err_t launch_fused_rw(const void *d_msgs, size_t msg_len, size_t n, size_
 {
     if (do_hash && do_mac) return launch_fused_t<RW, true, true>(d_msgs, msg_len, n, l, key, d_digests, d_tags, st);
     if (do_hash) return launch_fused_t<RW, true, false>(d_msgs, msg_len, n, l, key, d_digests, d_tags, st);
-    return launch_fused_t<RW, false, true>(d_msgs, msg_len, n, l, key, d_digests, d_tags, st);
+    // MAC alone does not depend on the rate: launch_bashHash_beltMAC sends it to RW = 8 only (one instantiation)
+    if constexpr (RW == 8) return launch_fused_t<RW, false, true>(d_msgs, msg_len, n, l, key, d_digests, d_tags, st);
+    else return ERR_BAD_INPUT;
 }
 
 err_t launch_bashHash_beltMAC(const void *d_msgs, size_t msg_len, size_t n, size_t l,

@@ -8,6 +8,10 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB_PATH = os.path.join(PKG, "lib", "libbee2hip.so")
+# the same sources with -DBEE2HIP_EXPERIMENTS: rejected kernel variants kept for the A/B record and the bee2hip_internal_* /
+# bee2hip_debug_fe* / bee2hip_time_kernel hooks of include/bee2hip_internal.h.  tests/ and tools/ load it where they need a
+# hook; nothing a bee2 caller links against is in it only.
+EXP_LIB_PATH = os.path.join(PKG, "lib", "libbee2hip_exp.so")
 
 ERR_OK = 0
 ERR_BAD_INPUT = 109
@@ -36,9 +40,10 @@ class EngineError(RuntimeError):
     pass
 
 
-def build(verbose=False):
-    """compile libbee2hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)"""
-    cmd = ["make", "-C", os.path.join(PKG, "csrc")]
+def build(verbose=False, experiments=True):
+    """compile libbee2hip.so (and, for the tests' hooks, libbee2hip_exp.so) for gfx950 in-tree, side by side
+    (hipcc cross-compiles without a GPU)"""
+    cmd = ["make", "-j2", "-C", os.path.join(PKG, "csrc"), "all"] + (["exp"] if experiments else [])
     if not verbose:
         cmd.insert(1, "-s")
     subprocess.check_call(cmd)
@@ -84,7 +89,7 @@ BATCH_SYMBOLS = [
     "bee2hip_hash_ragged_multi",
     "bee2hip_bignPubkeyCalcL_batch_dev", "bee2hip_bignSign2L_batch_dev", "bee2hip_bignSignKL_batch_dev",
     "bee2hip_bashHash_beltMAC_batch_dev",
-    "bee2hip_set_device", "bee2hip_sync", "bee2hip_last_error", "bee2hip_version",
+    "bee2hip_set_device", "bee2hip_sync", "bee2hip_last_error", "bee2hip_version", "bee2hip_path_policy", "bee2hip_path_count",
 ]
 # include/bee2hip_internal.h: test / bench hooks, not product ABI
 INTERNAL_SYMBOLS = ["bee2hip_time_kernel", "bee2hip_debug_fe", "bee2hip_debug_feL", "bee2hip_internal_tune",
@@ -111,8 +116,12 @@ class Engine:
         for name in ("bee2hip_last_error", "bee2hip_version"):
             getattr(L, name).restype = ctypes.c_char_p
         L.beltH.restype = ctypes.POINTER(ctypes.c_ubyte)
-        if hasattr(L, "bee2hip_internal_stat"):
-            L.bee2hip_internal_stat.restype = ctypes.c_ulonglong
+        for name in ("bee2hip_internal_stat", "bee2hip_path_count"):
+            if hasattr(L, name):
+                getattr(L, name).restype = ctypes.c_ulonglong
+        if hasattr(L, "bee2hip_path_policy"):
+            L.bee2hip_path_policy.restype = ctypes.c_int
+        self.experiments = hasattr(L, "bee2hip_internal_tune")
         for name in ("bashF_deep", "bashHash_keep", "beltCTR_keep", "beltMAC_keep", "beltECB_keep", "beltCBC_keep"):
             if hasattr(L, name):
                 getattr(L, name).restype = _sz
@@ -121,7 +130,8 @@ class Engine:
             if f is not None and name.startswith(("bee2hip_", "bash", "belt", "bign")) and \
                     name not in ("bee2hip_last_error", "bee2hip_version", "beltH", "bashF_deep",
                                  "bashHash_keep", "beltCTR_keep", "beltMAC_keep", "beltECB_keep",
-                                 "beltCBC_keep", "bash_platform", "bee2hip_device_count", "bee2hip_internal_stat"):
+                                 "beltCBC_keep", "bash_platform", "bee2hip_device_count", "bee2hip_internal_stat",
+                                 "bee2hip_path_count", "bee2hip_path_policy"):
                 f.restype = _u32
 
     # ------------------------------------------------------------------ util
@@ -637,3 +647,19 @@ def load(path=LIB_PATH):
                               "(bee2_amd has no CPU fallback)")
         _engine = Engine(ctypes.CDLL(path))
     return _engine
+
+
+_exp_engine = None
+
+
+def load_experiments(path=EXP_LIB_PATH):
+    """Load libbee2hip_exp.so (the -DBEE2HIP_EXPERIMENTS build: test hooks + the A/B variants).  A second, independent copy of
+    the library in the process: its own staging buffers, scratch pools and policy switches."""
+    global _exp_engine
+    if _exp_engine is None:
+        path = os.environ.get("BEE2HIP_EXP_LIB", path)
+        if not os.path.exists(path):
+            raise EngineError(f"{path} not found: `make -C bee2_amd/csrc exp` (or __graft_entry__.build())")
+        _exp_engine = Engine(ctypes.CDLL(path))
+        assert _exp_engine.experiments, f"{path} was not built with -DBEE2HIP_EXPERIMENTS"
+    return _exp_engine

@@ -46,17 +46,68 @@ MAD_PEAK_T = 30.0                # measured: 256 CU x 4 SIMD x 64 lanes x 2.31 G
 # VALU-issue picture: a wave64 full-rate op occupies its SIMD for 2 cycles, a half-rate op
 # for 4 (157 TFLOP/s fp32 = 1024 SIMDs x 2.4 GHz x 32 lanes x 2); tools/ubench/valu_rates.hip sustains
 # 80 % of that.  Per-unit instruction counts are the ISA's (hipcc -S), not estimates.
-SIMD_CYCLES_PER_S = 1024 * 2.4e9
+N_SIMD = 1024                     # 256 CUs x 4
+NOMINAL_GHZ = 2.4
 BASHF_VALU = {"full_rate": 4 * 684, "half_rate": 4 * 384}          # per permutation-wavefront (24 rounds)
 CTR_VALU = {"full_rate": 232, "half_rate": 293, "ds_read_b32": 220}  # per block-wavefront (loop body of beltCTR_blocks_kernel<BeltTabTwoP, 1, 7>, llvm-objdump;
 #                                                                       before the one-instruction LDS addresses: 681 / 18 / 220 -- a third more instructions, fewer VALU cycles, 15 % slower)
 
 
-def valu_picture(units_per_s, mix, lanes=64):
-    """fraction of the SIMDs' issue cycles the arithmetic itself needs at the measured rate"""
+def valu_picture(units_per_s, mix, clock_ghz=None, lanes=64):
+    """The 2-cycle / 4-cycle cost MODEL of the instruction mix against the SIMD cycles there were: `model_ratio` = modelled
+    issue cycles needed per second / SIMD cycles per second at the clock the chip actually ran (measured beside the kernel;
+    the nominal 2.4 GHz only when no measurement exists).  It is a DESCRIPTION, not a ceiling: the half-rate and the
+    full-rate unit of a SIMD overlap once the half-rate runs are issued at raised priority, so the ratio
+    passes 1 for bash-f -- by how much is exactly that overlap."""
     cyc = 2 * mix["full_rate"] + 4 * mix["half_rate"]
-    return {"issue_cycles_per_wave_unit": cyc, "frac_of_simd_cycles": units_per_s / lanes * cyc / SIMD_CYCLES_PER_S,
-            "mix": mix}
+    ghz = clock_ghz or NOMINAL_GHZ
+    return {"issue_cycles_per_wave_unit": cyc, "model_ratio": units_per_s / lanes * cyc / (N_SIMD * ghz * 1e9),
+            "clock_ghz_used": ghz, "clock_measured": clock_ghz is not None, "mix": mix}
+
+
+# ISA instruction counts of the fused bash512 + beltMAC kernel's two halves per 4 KiB message (65 permutations, 257 block
+# encryptions; llvm-objdump of hash_mac_fused_kernel<8, true, true, BeltTabWide> and of its parts): what SURVEY 8d row 4 asks for
+MIXED_WORK = {"perms": 65, "blocks": 257, "valu_full_rate": 65 * 2736 + 257 * 232, "valu_half_rate": 65 * 1536 + 257 * 293,
+              "ds_read_b32": 257 * 220}
+
+
+def mixed_roofline(msgs_per_s_per_gpu, perms_per_s, blocks_per_s, src):
+    """configs[4]: the fused kernel against its two parts measured in THIS run on the same GPU -- the bash-f kernel (VALU
+    bound) and the belt block kernel (LDS-lookup bound).  sum_of_parts = what two back-to-back passes would give, i.e. no
+    overlap at all; overlap = the slower part alone, i.e. the other part entirely hidden.  `frac` is against the overlap
+    ceiling (the roof), `overlap_got` = share of the possible overlap the fusion realised."""
+    t_hash, t_mac = MIXED_WORK["perms"] / perms_per_s, MIXED_WORK["blocks"] / blocks_per_s
+    t = 1.0 / msgs_per_s_per_gpu
+    t_sum, t_max = t_hash + t_mac, max(t_hash, t_mac)
+    return {"bound": "valu-int+lds", "achieved": msgs_per_s_per_gpu, "peak": 1.0 / t_max, "unit": "messages/s",
+            "frac": t_max / t, "traffic": None,
+            "sum_of_parts_ceiling": 1.0 / t_sum, "frac_sum_of_parts": t_sum / t,
+            "overlap_got": (t_sum - t) / (t_sum - t_max) if t_sum > t_max else None,
+            "part_rates": {"bashF_perms_per_s": perms_per_s, "belt_blocks_per_s": blocks_per_s, "source": src},
+            "work_per_message": MIXED_WORK,
+            "algorithmic_bytes_per_message": 4096 + 72}
+
+
+def device_identity(index):
+    """something that names the physical GPU behind a HIP device index (two ranks on one card must not count as two)"""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        for attr in ("uuid", "pci_bus_id"):
+            v = getattr(p, attr, None)
+            if v not in (None, ""):
+                return f"{attr}:{v}"
+    except Exception:
+        pass
+    return f"index:{index}"
+
+
+def check_distinct_devices(ids, world, backend):
+    """n_devices_distinct; with RCCL (one rank per GPU is the contract) anything but `world` distinct devices is an error"""
+    distinct = len(set(ids))
+    if backend == "nccl" and distinct != world:
+        raise SystemExit(f"[bench] {world} ranks on {distinct} distinct device(s) {sorted(set(ids))}: refusing to report "
+                         f"n_gpus={world} (BEE2_BENCH_BACKEND=gloo runs the N-rank code path on fewer devices)")
+    return distinct
 
 
 WORKLOADS = ("bashF", "ctr", "verify", "sign", "mixed", "modes", "ragged", "dwp", "latency")
@@ -77,6 +128,9 @@ def parse():
                     help="ranks only form the process group, reduce one number and rank 0 prints the line's launch fields "
                          "(no GPU work; tests/test_bench_launch.py runs this on CPU with BEE2_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
+    if not args.only and args.gpus > 1:
+        # eight ranks share one host: only the four BASELINE workloads by default (latency / ragged / modes legs are N = 1 matter)
+        args.only = "bashF,ctr,verify,mixed"
     bad = set(x for x in args.only.split(",") if x) - set(WORKLOADS)
     if bad:                                # fail before any GPU work, not with an empty JSON line
         ap.error(f"unknown --only name(s) {sorted(bad)}; choose from {list(WORKLOADS)}")
@@ -156,6 +210,14 @@ class Dist:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather(self, obj):
+        """every rank's object, in rank order, on every rank"""
+        if not self.on:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
     def bcast_bytes(self, b, n):
         """rank 0's bytes to everyone (the only payload that crosses GPUs: <= 48 bytes)"""
         t = torch.zeros(n, dtype=torch.uint8, device=self.cdev)
@@ -194,6 +256,7 @@ def timed(dist, steps, warmup, fn):
         fn()
     e1.record()
     torch.cuda.synchronize()
+    timed.own_wall = time.perf_counter() - t0                    # this rank alone, before it waits for the others
     dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -202,6 +265,57 @@ def timed(dist, steps, warmup, fn):
 
 
 timed.event_ms = 0.0
+timed.own_wall = 0.0
+
+
+class _Alone:
+    """stands in for Dist inside a solo leg: no collective"""
+    def barrier(self):
+        pass
+
+    def max(self, x):
+        return x
+
+
+def solo_timed(dist, steps, warmup, fn):
+    """rank 0 ALONE times the step while the other ranks wait at a barrier (N > 1 only): what one GPU of this node does
+    with the host and the fabric to itself.  Returns rank 0's seconds for `steps` steps on every rank."""
+    dist.barrier()
+    el = 0.0
+    if dist.rank == 0:
+        el = timed(_Alone(), steps, warmup, fn)
+    dist.barrier()
+    return dist.max(el)
+
+
+def clock_probe_lib():
+    path = os.path.join(ROOT, "bee2_amd", "lib", "libb2hprobe.so")
+    return ctypes.CDLL(path) if os.path.exists(path) else None
+
+
+def shader_clock_under(fn, ms_launch):
+    """GHz the chip sustained under fn(): one wavefront on a side stream spins beside ~100 more launches (outside any timed
+    region) and reads s_memtime against the 100 MHz s_memrealtime (tools/probe/clock_probe.hip).  None without the helper."""
+    lib = clock_probe_lib()
+    if lib is None:
+        return None, None
+    side = torch.cuda.Stream()
+    probe = torch.zeros(2, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(20):                                   # the queue is already full when the probe arrives
+        fn()
+    if lib.b2h_clock_probe(ctypes.c_void_p(probe.data_ptr()), ctypes.c_uint(max(50, int(ms_launch * 1e3 * 40 * 0.8))),
+                           ctypes.c_void_p(side.cuda_stream)) != 0:
+        return None, None
+    for _ in range(60):
+        fn()
+    torch.cuda.synchronize()
+    c = probe.cpu().numpy()
+    under = float(c[0]) / (float(c[1]) * 10.0)
+    lib.b2h_clock_probe(ctypes.c_void_p(probe.data_ptr()), ctypes.c_uint(2000), ctypes.c_void_p(side.cuda_stream))
+    torch.cuda.synchronize()
+    c = probe.cpu().numpy()
+    return under, float(c[0]) / (float(c[1]) * 10.0)
 
 
 def pmc_traffic(kernel_substr):
@@ -347,9 +461,16 @@ def main():
         dist = Dist(args.gpus, use_cuda=False)
         seen = int(dist.sum(1.0))             # one all-reduce: every rank counted
         slowest = dist.max(float(dist.rank))
+        # BEE2_BENCH_MOCK_DEVICES="0,0,1": the device each rank would report (CPU test of the distinct-device rule);
+        # BEE2_BENCH_MOCK_BACKEND=nccl applies RCCL's rule (one rank per GPU) to that list
+        mock = os.environ.get("BEE2_BENCH_MOCK_DEVICES")
+        me = f"mock:{mock.split(',')[dist.rank]}" if mock else f"cpu:{dist.local}"
+        ids = dist.gather(me)
+        distinct = check_distinct_devices(ids, dist.world, os.environ.get("BEE2_BENCH_MOCK_BACKEND", dist.backend))
         if dist.rank == 0:
-            print(json.dumps({"metric": "launch selftest", "n_gpus": dist.world, "roofline": {"n_ranks_seen": seen},
-                              "max_rank": int(slowest), "backend": dist.backend}))
+            print(json.dumps({"metric": "launch selftest", "n_gpus": dist.world,
+                              "roofline": {"n_ranks_seen": seen, "n_devices_distinct": distinct},
+                              "max_rank": int(slowest), "backend": dist.backend, "only": args.only}))
         dist.close()
         return
     dist = Dist(args.gpus)
@@ -357,6 +478,9 @@ def main():
     eng.set_device(torch.cuda.current_device())
     only = set(x for x in args.only.split(",") if x) or set(WORKLOADS)
     K, W, N = args.steps, args.warmup, dist.world
+    dev_ids = dist.gather(device_identity(dist.device))
+    n_distinct = check_distinct_devices(dev_ids, N, dist.backend)     # RCCL: N ranks on fewer than N GPUs is an error
+    diag = {}                                                          # N > 1 self-explanation, flat scalars (rank 0 prints)
     do_cpu = (not args.no_cpu) and dist.rank == 0 and N == 1
     cores = os.cpu_count() or 1
     H = eng.beltH()
@@ -371,17 +495,29 @@ def main():
 
     result = {}
     others = {}
+    rates = {}
 
     # ---------------------------------------------------------------- bashF (headline)
     if "bashF" in only:
         n = 1 << 20
         st = torch.empty(192 * n, dtype=torch.uint8, device="cuda")
         fill_seeded(st, 0xBA5F + dist.rank)                      # synthetic states, generated in HBM
-        el = timed(dist, K, W, lambda: eng.bashF_batch_dev(st))
+        step = lambda: eng.bashF_batch_dev(st)  # noqa: E731
+        solo_el = solo_timed(dist, K, W, step) if N > 1 else None      # rank 0 alone, before the group run
+        el = timed(dist, K, W, step)
         value = N * n * K / el
         ms_launch = timed.event_ms                                # hipEvents around the K timed launches themselves
+        own = dist.gather((n * K / timed.own_wall, n / (ms_launch * 1e-3)))   # each rank's own wall-clock and event rates
         ach = BASHF_BYTES * n / (ms_launch * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic("bashF_tile_kernel")
+        # the shader clock the chip sustained (power: ~1.8-1.9 GHz under this kernel is normal; one box of the pool ran everything
+        # at half speed): measured on every rank, outside the timed region
+        try:
+            ghz_under, ghz_idle = shader_clock_under(step, ms_launch)
+            clock_note = None if ghz_under else "libb2hprobe.so not built"
+        except Exception as e:                                    # the probe is a diagnostic, never a reason to fail the bench
+            ghz_under, ghz_idle, clock_note = None, None, repr(e)
+        clocks = [c for c in dist.gather(ghz_under) if c]
         result = {
             "metric": "bashF perms/s", "value": value, "unit": "perms/s", "n_gpus": N, "steps": K, "warmup": W,
             "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -389,34 +525,22 @@ def main():
             "config": {"workload": "bashF batch: 2^20 independent 192-byte sponge states per GPU (BASELINE configs[1])",
                        "states_per_gpu": n, "parallelism": f"dp{N} (index-sharded, no data-path collective)"},
             "roofline": {"kernel": "bashF_tile_kernel<0, 2, 124, 6, 3>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": ms_launch, "algorithmic_bytes_per_launch": BASHF_BYTES * n,
-                         "note": "power / VALU-issue bound in practice: the chip sustains 1.7-1.9 GHz under this kernel, see `valu` (DESIGN.md 2, 4.1)",
-                         "valu": valu_picture(n / (ms_launch * 1e-3), BASHF_VALU)},
+                         "shader_clock_ghz_under_kernel": ghz_under, "shader_clock_ghz_idle": ghz_idle},
         }
-        # the shader clock the chip sustained: one wavefront on a side stream spins beside 40 more launches (outside the
-        # timed region) and reads s_memtime against the 100 MHz s_memrealtime.  A box that clocks down (power: ~1.9 GHz
-        # under this kernel is normal; one box of the pool ran everything at half speed) shows up here.
-        try:
-            side = torch.cuda.Stream()
-            probe = torch.zeros(2, dtype=torch.int64, device="cuda")
-            torch.cuda.synchronize()
-            for _ in range(20):                                   # the queue is already full when the probe arrives
-                eng.bashF_batch_dev(st)
-            eng.lib.bee2hip_internal_clock_probe(ctypes.c_void_p(probe.data_ptr()), ctypes.c_uint(int(ms_launch * 1e3 * 40 * 0.8)),
-                                                 ctypes.c_void_p(side.cuda_stream))
-            for _ in range(60):
-                eng.bashF_batch_dev(st)
-            torch.cuda.synchronize()
-            c = probe.cpu().numpy()
-            result["roofline"]["shader_clock_ghz_under_kernel"] = float(c[0]) / (float(c[1]) * 10.0)
-            eng.lib.bee2hip_internal_clock_probe(ctypes.c_void_p(probe.data_ptr()), ctypes.c_uint(2000), ctypes.c_void_p(side.cuda_stream))
-            torch.cuda.synchronize()
-            c = probe.cpu().numpy()
-            result["roofline"]["shader_clock_ghz_idle"] = float(c[0]) / (float(c[1]) * 10.0)
-        except Exception as e:                                    # the probe is a diagnostic, never a reason to fail the bench
-            result["roofline"]["shader_clock_ghz_under_kernel"] = None
-            result["roofline"]["shader_clock_note"] = repr(e)
+        detail = {"traffic_source": traffic_src, "shader_clock_note": clock_note,
+                  "note": "power / VALU-issue bound in practice: the chip sustains 1.7-1.9 GHz under this kernel (DESIGN.md 2, 4.1)",
+                  "valu": valu_picture(n / (ms_launch * 1e-3), BASHF_VALU, ghz_under)}
+        others["bashF_detail"] = detail
+        result["roofline"]["valu_model_ratio"] = detail["valu"]["model_ratio"]
+        diag.update(per_rank_value_min=min(o[0] for o in own), per_rank_value_max=max(o[0] for o in own),
+                    per_rank_kernel_rate_min=min(o[1] for o in own), per_rank_kernel_rate_max=max(o[1] for o in own),
+                    clock_ghz_min=min(clocks) if clocks else None, clock_ghz_max=max(clocks) if clocks else None)
+        if solo_el is not None:
+            diag["solo_value"] = n * K / solo_el
+            diag["weak_efficiency"] = value / (N * diag["solo_value"])
+        rates["bashF_perms_per_s"] = n / (ms_launch * 1e-3)      # per GPU, kernel time: what the mixed roofline's parts use
         # the same kernel on a batch that cannot sit in the 256 MiB Infinity Cache: 2^22 states = 768 MiB read + written
         # per launch; reported as flat keys next to the cache-resident headline
         if not args.headline_only:
@@ -467,6 +591,7 @@ def main():
                                  "DESIGN.md 2 and 4.2",
                          "valu": valu_picture(nb / (ms_launch * 1e-3), CTR_VALU)},
         }
+        rates["belt_blocks_per_s"] = nb / (ms_launch * 1e-3)       # per GPU, kernel time
         if dist.rank == 0 and N == 1 and not args.headline_only:       # PCIe-inclusive rate: single-GPU runs only
             hn = 1 << 30                                          # 1 GiB through the drop-in one-shot beltCTR
             host = np.zeros(hn, dtype=np.uint8)
@@ -528,9 +653,17 @@ def main():
             small = {}
             for e in (10, 13, 14, 15, 16, 17):
                 m = 1 << e
-                for _ in range(2):
-                    eng.time_kernel(2, 3, dh, ds, dk, codes, n=m)
-                ms_b = eng.time_kernel(2, 20, dh, ds, dk, codes, n=m)
+                pre = (dh[: 32 * m], ds[: 48 * m], dk[: 64 * m], codes[:m])
+                for _ in range(6):
+                    eng.bign128Verify_batch_dev(*pre)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    eng.bign128Verify_batch_dev(*pre)
+                e1.record()
+                torch.cuda.synchronize()
+                ms_b = e0.elapsed_time(e1) / 20
                 small[f"2^{e}"] = {"ms_per_batch": ms_b, "verifies_per_s": m / (ms_b * 1e-3)}
             others["bignVerify"]["batch_size_sweep"] = small
         if dist.rank == 0 and N == 1:       # PCIe-inclusive rate: single-GPU runs only
@@ -738,9 +871,9 @@ def main():
             lat["beltHash (1 KiB)"] = us_per_call(lambda: eng.lib.beltHash(ctypes.create_string_buffer(32), bytes(1024), ctypes.c_size_t(1024)), 2000 if fast else 100)
             return lat
         lat = measure(True)                                        # the default: small calls on the host path, by size
-        eng.lib.bee2hip_internal_tune(4, 1)                        # as BEE2HIP_FORCE=gpu: every primitive in a kernel (rounds 1-2)
+        eng.lib.bee2hip_path_policy(1)                             # as BEE2HIP_FORCE=gpu: every primitive in a kernel (rounds 1-2)
         lat_gpu = measure(False)
-        eng.lib.bee2hip_internal_tune(4, 0)
+        eng.lib.bee2hip_path_policy(0)
         entry = {"unit": "us per call", "dropin": lat, "dropin_forced_gpu": lat_gpu,
                  "note": "dropin = the library as a caller gets it: single primitives, block-parallel modes under 8 KiB per call, "
                          "one-message serial chains and ONE signature verification / public-key validation run on the host path "
@@ -776,10 +909,27 @@ def main():
         tag = torch.empty(n * 8, dtype=torch.uint8, device="cuda")
         km = max(2, min(K, 5))
         el = timed(dist, km, 1, lambda: eng.bashHash_beltMAC_batch_dev(msgs, ml, 256, H[128:160], dig, tag))
+        ms_mixed = timed.event_ms
+        # the two parts on this GPU in this run: taken from the bashF / beltCTR legs above, or (--only mixed) short legs here
+        src = "the bashF and beltCTR legs of this run (kernel time, per GPU)"
+        if "bashF_perms_per_s" not in rates or "belt_blocks_per_s" not in rates:
+            src = "short bashF (2^20 states) and beltCTR (1 GiB) legs run for this roofline (kernel time, per GPU)"
+            if "bashF_perms_per_s" not in rates:
+                stp = msgs[: 192 << 20]
+                timed(dist, 20, 3, lambda: eng.bashF_batch_dev(stp))
+                rates["bashF_perms_per_s"] = (1 << 20) / (timed.event_ms * 1e-3)
+            if "belt_blocks_per_s" not in rates:
+                cb_ = msgs[: 1 << 30] if msgs.numel() >= (1 << 30) else msgs
+                timed(dist, 3, 1, lambda: eng.beltCTR_blocks_dev(cb_, kw, c0, 0))
+                rates["belt_blocks_per_s"] = (cb_.numel() // 16) / (timed.event_ms * 1e-3)
+            fill_seeded(msgs, 0x4D1C + dist.rank)                  # (the short legs ran in place over the messages)
         others["bash512_beltMAC"] = {
             "metric": "bash512+beltMAC messages/s", "value": N * n * km / el, "unit": "messages/s", "steps": km,
             "ms_per_step": el / km * 1e3, "GiB_per_s": N * n * ml * km / el / 2 ** 30,
             "config": {"workload": f"bash512 + beltMAC over {n} x 4 KiB messages per GPU (BASELINE configs[4] share of one GPU)"},
+            "roofline": dict(mixed_roofline(n / (ms_mixed * 1e-3), rates["bashF_perms_per_s"], rates["belt_blocks_per_s"], src),
+                             kernel="hash_mac_fused_kernel<8, true, true, BeltTabWide>", avg_launch_ms=ms_mixed,
+                             hbm_frac=(4096 + 72) * n / (ms_mixed * 1e-3) / 1e9 / HBM_PEAK_GBS),
         }
         if do_cpu:
             others["bash512_beltMAC"]["cpu_baseline"] = cpu_baseline("mixed", cores)
@@ -998,41 +1148,70 @@ def main():
                   "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": o.get("config", {"workload": k0})}
         for k, v in o.items():            # keep the workload's own fields (roofline, cpu_baseline, extras)
             result.setdefault(k, v)
-    # FLAT scalar copies of the other two BASELINE metrics (and what bounds them) inside the two objects the driver's
-    # record keeps -- `others` is nested and does not survive its parse.  Per-GPU figures for the
-    # fractions (value / N), whole-job figures for the rates.
-    rf = result.setdefault("roofline", {})
-    rf["n_ranks_seen"] = int(dist.sum(1.0))
-    rf["n_devices_visible"] = dist.ndev
-    if isinstance(rf.get("valu"), dict):
-        rf["valu_frac"] = rf["valu"]["frac_of_simd_cycles"]
+    # The driver's record keeps `roofline` and `cpu_baseline` as FLAT objects of about two dozen scalars, in order, and cuts
+    # strings at 120 characters (BENCH_r03.json lost bignVerify_frac that way): so every fraction and rate FIRST, in a fixed
+    # order, then the N > 1 diagnostics, then the rest; prose and nested objects live in `others`.
+    # Per-GPU figures for the fractions (value / N), whole-job figures for the rates.
+    rf0 = result.get("roofline") or {}
+    flat = {k: rf0.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    flat["frac_2p22"] = rf0.get("frac_2p22")
     cb = result.get("cpu_baseline")
     if cb is None:
         cb = result["cpu_baseline"] = {"value": None, "unit": result.get("unit"), "cores": cores, "kind": None,
                                        "sample": "not timed: cpu_baseline runs on rank 0 at N=1 only" if N > 1 else "not timed (--no-cpu)"}
+    late = {}
     o = others.get("beltCTR")
     if o:
-        rf["beltCTR_GiBps"] = o["value"]
-        rf["beltCTR_frac"] = o["roofline"]["frac"]
-        rf["beltCTR_lds_frac"] = o["value"] / N / LDS_CTR_CEIL_GIBPS
-        rf["beltCTR_ms"] = o["roofline"]["avg_launch_ms"]
+        flat["beltCTR_GiBps"] = o["value"]
+        flat["beltCTR_frac"] = o["roofline"]["frac"]
+        flat["beltCTR_lds_frac"] = o["value"] / N / LDS_CTR_CEIL_GIBPS
+        late["beltCTR_ms"] = o["roofline"]["avg_launch_ms"]
         if "cpu_baseline" in o:
             cb["beltCTR_GiBps"] = o["cpu_baseline"]["value"]
             cb["beltCTR_GiBps_single_thread"] = o["cpu_baseline"].get("single_thread")
     o = others.get("bignVerify")
     if o:
-        rf["bignVerify_sigs_per_s"] = o["value"]
-        rf["bignVerify_frac"] = o["roofline"]["frac"]
-        rf["bignVerify_ms"] = o["roofline"]["avg_batch_ms"]
-        rf["bignVerify_verdicts_ok"] = o["verdicts_as_expected"]
+        flat["bignVerify_sigs_per_s"] = o["value"]
+        flat["bignVerify_frac"] = o["roofline"]["frac"]
+        late["bignVerify_ms"] = o["roofline"]["avg_batch_ms"]
+        late["bignVerify_verdicts_ok"] = o["verdicts_as_expected"]
         if "cpu_baseline" in o:
             cb["bignVerify_sigs_per_s"] = o["cpu_baseline"]["value"]
             cb["bignVerify_sigs_per_s_single_thread"] = o["cpu_baseline"].get("single_thread")
     o = others.get("bash512_beltMAC")
     if o:
-        rf["mixed_msgs_per_s"] = o["value"]
+        flat["mixed_msgs_per_s"] = o["value"]
+        flat["mixed_frac"] = o["roofline"]["frac"]
+        late["mixed_frac_sum_of_parts"] = o["roofline"]["frac_sum_of_parts"]
+        late["mixed_overlap_got"] = o["roofline"]["overlap_got"]
         if "cpu_baseline" in o:
             cb["mixed_msgs_per_s"] = o["cpu_baseline"]["value"]
+    o = others.get("bignSign2")
+    if o:
+        late["bignSign2_sigs_per_s"] = o["value"]
+        late["bignSign2_frac"] = o["roofline"]["frac"]
+    flat["n_ranks_seen"] = int(dist.sum(1.0))
+    flat["n_devices_distinct"] = n_distinct
+    # N > 1: the line explains itself -- rank 0 alone beforehand, each rank's own rate, clocks
+    for k in ("weak_efficiency", "solo_value", "per_rank_value_min", "per_rank_value_max", "clock_ghz_min", "clock_ghz_max"):
+        flat[k] = diag.get(k)
+    flat["avg_launch_ms"] = rf0.get("avg_launch_ms", rf0.get("avg_batch_ms"))
+    flat["kernel"] = rf0.get("kernel", rf0.get("kernels"))
+    flat.update(late)
+    flat["n_devices_visible"] = dist.ndev
+    for k in ("per_rank_kernel_rate_min", "per_rank_kernel_rate_max"):
+        flat[k] = diag.get(k)
+    rest = {}
+    for k, v in rf0.items():              # what is left of the headline kernel's own object: scalars stay, prose / nested move out
+        if k in flat:
+            continue
+        if isinstance(v, (int, float, bool)) or v is None:
+            flat[k] = v
+        else:
+            rest[k] = v
+    if rest:
+        others.setdefault("headline_detail", {}).update(rest)
+    result["roofline"] = flat
     result["others"] = others
     result["host"] = {"cpu_count": cores, "device": torch.cuda.get_device_name(torch.cuda.current_device()),
                       "engine": eng.version()}

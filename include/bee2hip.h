@@ -439,6 +439,14 @@ err_t bee2hip_sync(void *stream);
 const char *bee2hip_last_error(void);
 /* "bee2hip <ver> gfx950" */
 const char *bee2hip_version(void);
+/* path of the drop-in layer's SMALL single calls (one permutation, one block, one message's serial chain, one
+   signature verification): 0 = by size (default), 1 = every primitive in a kernel, 2 = the host path wherever one
+   exists.  The run-time form of the environment variable BEE2HIP_FORCE=gpu|cpu; mode < 0 only queries.  Returns the
+   mode that was in force.  Batch, _dev and _multi entry points are never affected: they always launch kernels. */
+int bee2hip_path_policy(int mode);
+/* how many drop-in helper calls of this process went where: which = 0 host path, 1 GPU path, 2 finished on the host
+   after the GPU path failed twice (a warning is printed for each of those) */
+unsigned long long bee2hip_path_count(int which);
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

@@ -48,11 +48,11 @@ def force_path(request):
         return
     import bee2_amd
     lib = bee2_amd.load().lib
-    lib.bee2hip_internal_tune(4, FORCE_CODE[mode])
-    before = [lib.bee2hip_internal_stat(i) for i in range(3)]
+    lib.bee2hip_path_policy(FORCE_CODE[mode])              # product ABI (include/bee2hip.h): as BEE2HIP_FORCE
+    before = [lib.bee2hip_path_count(i) for i in range(3)]
     yield mode
-    after = [lib.bee2hip_internal_stat(i) for i in range(3)]
-    lib.bee2hip_internal_tune(4, 0)
+    after = [lib.bee2hip_path_count(i) for i in range(3)]
+    lib.bee2hip_path_policy(0)
     # the mode did what it says: no host-path call under "gpu", no GPU drop-in helper call under "cpu", no fault fallback
     if mode == "gpu":
         assert after[0] == before[0], "host path taken under BEE2HIP_FORCE=gpu"

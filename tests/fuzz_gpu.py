@@ -20,7 +20,16 @@ import goldenlib  # noqa: E402
 import orclib  # noqa: E402
 from bee2_amd.engine import LEVEL_OID  # noqa: E402
 
-eng = bee2_amd.load()
+# FUZZ_LIB=exp: the experiments build (libbee2hip_exp.so), whose hooks force each kernel family at every size; default: the
+# product library, dispatch by batch size as a caller gets it (the forcing calls below are then no-ops)
+eng = bee2_amd.load_experiments() if os.environ.get("FUZZ_LIB", "product") == "exp" else bee2_amd.load()
+
+
+def _tune(key, value):
+    if eng.experiments:
+        eng.lib.bee2hip_internal_tune(key, value)
+
+
 eng.set_device(0)
 orc = orclib.load()
 G = goldenlib.Golden()
@@ -231,12 +240,12 @@ def f_verify(rnd):
     # which kernels walk the scalar multiplication is a matter of batch size (32-bit limbs / 29-bit limbs / one
     # signature per quad on the 256-bit curve): half of the cases force one of the three instead
     path = rnd.choice((0, 0, 0, 0, 1, 2, 0x43, 0x23, 0x83))
-    eng.lib.bee2hip_internal_tune(2, path)
+    _tune(2, path)
     try:
         eng.bignVerifyL_batch_dev(l, oid, dev(H), dev(S), dev(P), codes)
         torch.cuda.synchronize()
     finally:
-        eng.lib.bee2hip_internal_tune(2, 0)
+        _tune(2, 0)
     got = [int(c) & 0xFFFFFFFF for c in codes.cpu().numpy()]
     if got != orc.verify_batch_l(l, oid, bytes(H), bytes(S), bytes(P), nthreads=16):
         return False
@@ -303,11 +312,11 @@ def f_sign(rnd):
         oid = bytes([0x06, k] if k < 128 else [0x06, 0x81, k]) + bytes([0x2A] + [rnd.randrange(1, 128) for _ in range(k - 1)])
     t = rnd.choice((None, b"", rnd.randbytes(rnd.randrange(1, 65)), rnd.randbytes(rnd.randrange(65, 200))))
     # k G by 1 (signed 6-bit or, 101, 4-bit windows) / 4 / 16 / 64 lanes per scalar, or as the product picks by batch size (0)
-    eng.lib.bee2hip_internal_tune(10, rnd.choice((0, 0, 1, 1, 101, 102, 4, 16, 64)))
+    _tune(10, rnd.choice((0, 0, 1, 1, 101, 102, 4, 16, 64)))
     try:
         return _sign_case(rnd, l, P, n, privs, hashes, oid, t)
     finally:
-        eng.lib.bee2hip_internal_tune(10, 0)
+        _tune(10, 0)
 
 
 def _sign_case(rnd, l, P, n, privs, hashes, oid, t):

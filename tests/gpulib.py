@@ -11,6 +11,15 @@ def engine():
     return eng
 
 
+def exp_engine():
+    """libbee2hip_exp.so (-DBEE2HIP_EXPERIMENTS): the same kernels plus the hooks of include/bee2hip_internal.h -- field
+    arithmetic self-test, forced kernel choices, fault injection.  Only tests that need a hook use it."""
+    eng = bee2_amd.load_experiments()
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    eng.set_device(torch.cuda.current_device())
+    return eng
+
+
 def dev(b):
     """bytes / numpy uint8 -> uint8 CUDA tensor (copy)"""
     if isinstance(b, (bytes, bytearray)):

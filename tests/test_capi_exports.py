@@ -42,8 +42,33 @@ def test_library_exports_every_declared_symbol(lib_path):
     exported = E.lib_exports(lib_path)
     missing = sorted(header_symbols() - exported)
     assert not missing, f"declared in include/bee2hip.h but not exported: {missing}"
-    missing = sorted(header_symbols("bee2hip_internal.h") - exported)
-    assert not missing, f"declared in include/bee2hip_internal.h but not exported: {missing}"
+
+
+def test_product_library_ships_no_hooks_and_no_experiment_kernels(lib_path):
+    """the library a bee2 maintainer links exports nothing of include/bee2hip_internal.h, and its code
+    object holds only kernels a product entry point dispatches (no rejected A/B variants, no debug / probe kernels)"""
+    exported = E.lib_exports(lib_path)
+    hooks = sorted(n for n in exported if "internal" in n or "debug" in n or "time_kernel" in n or "clock_probe" in n)
+    assert not hooks, hooks
+    assert not (header_symbols("bee2hip_internal.h") & exported)
+    import subprocess
+    names = subprocess.check_output([os.path.join(ROOT, "tools", "list_kernels.sh"), lib_path], text=True).splitlines()
+    kernels = sorted({n.split("(")[0] for n in names if n.strip()})
+    assert kernels and len(kernels) <= 125, len(kernels)
+    for bad in ("debug", "clock_probe", "bashF_batch_kernel", "bashF_walk_kernel", "BeltTabHyb", "BeltTabTwoS", "BeltTabTwoL",
+                "BeltTabTwoQ"):
+        assert not [k for k in kernels if bad in k], bad
+    assert len([k for k in kernels if "bashF_tile_kernel" in k]) == 1
+    assert len([k for k in kernels if "beltCTR_blocks_kernel" in k]) == 2          # with / without the hoisted round-1 G-box
+    assert len([k for k in kernels if "bign_mulbase_ct_kernel" in k]) == 3         # one per curve
+
+
+def test_experiments_library_exports_the_hooks():
+    if not os.path.exists(E.EXP_LIB_PATH):
+        pytest.skip("libbee2hip_exp.so not built")
+    exported = E.lib_exports(E.EXP_LIB_PATH)
+    assert not sorted(header_symbols() - exported)
+    assert not sorted(header_symbols("bee2hip_internal.h") - exported)
 
 
 def test_product_header_has_no_test_hooks():

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from bee2_amd import engine as E
-from gpulib import dev, engine, host
+from gpulib import dev, engine, exp_engine, host
 
 pytestmark = pytest.mark.gpu
 P = 2 ** 256 - 189
@@ -29,7 +29,7 @@ def _fe_run(eng, op, A, B):
 def test_field_ops_vs_python_ints():
     """regular GF(p) routines against big-int arithmetic on random and boundary values,
     including non-canonical inputs in [p, 2^256) (the kernels keep values weakly reduced)"""
-    eng = engine()
+    eng = exp_engine()          # hooks of include/bee2hip_internal.h
     rnd = random.Random(1)
     special = [0, 1, 2, 188, 189, 190, P - 2, P - 1, P, P + 1, P + 188, 2 ** 256 - 1, 2 ** 255,
                2 ** 128, 2 ** 128 - 1, 2 ** 224 - 1, (1 << 256) - (1 << 32)]
@@ -84,7 +84,7 @@ def test_field_ops_lazy_limbs_vs_python_ints(l):
     """bign_fe29.hpp (the small-batch form: signed 29 / 28 / 27-bit limbs on the three curves, lazy additions) against
     big-int arithmetic: multiplication / squaring with the folded small multiples, lazy differences and sums fed
     straight into multiplications at the bounds the point formulas use, the exact conversion back to 32-bit words"""
-    eng = engine()
+    eng = exp_engine()          # hooks of include/bee2hip_internal.h
     rnd = random.Random(29 + l)
     L, Bb, c = LAZY[l]
     P = 2 ** (2 * l) - c
@@ -109,7 +109,7 @@ def test_field_ops_lazy_limbs_vs_python_ints(l):
 def test_point_ops_lazy_limbs_match_the_group_law(golden, l):
     """2P and 3P = 2P + P of public keys from the fixtures: affine x from jac29_dbl / jac29_madd (one lane per point)
     and from quad29_dbl / quad29_add (a DPP quad per point: every point is passed four times) == the Python group law"""
-    eng = engine()
+    eng = exp_engine()          # hooks of include/bee2hip_internal.h
     c = LAZY[l][2]
     P = 2 ** (2 * l) - c
     no = l // 4
@@ -149,7 +149,7 @@ def test_bign_both_main_kernels_on_edge_and_base_sets(golden, path):
     by size, 0x43 = quads, 0x23 = pairs, 0x83 = quad + helper quad) over the 433 edge cases (exceptional group-law cases
     included: they must reach the slow path from either kernel), the valid base set, and a 70 000-signature tiling
     with every 7th signature corrupted -- a size the 29-bit kernel never sees unforced."""
-    eng = engine()
+    eng = exp_engine()          # hooks of include/bee2hip_internal.h
     tune = eng.lib.bee2hip_internal_tune
     tune.restype = ctypes.c_uint32
     assert tune(2, path) == 0
@@ -288,7 +288,7 @@ def test_bign_full_size_2pow18_tiled_and_corrupted(orc, golden):
 def test_bign_big_host_batch_is_uploaded_in_chunks(golden):
     """bee2hip_bignVerify_batch with host pointers and 2^19 + 777 signatures: chunks of 2^18 are uploaded while the previous
     chunk is verified (capi.hip, knob 11); the codes are those of the one-piece path and of the device-resident entry"""
-    eng = engine()
+    eng = exp_engine()          # hooks of include/bee2hip_internal.h
     hs, ss, ps = golden.bign_base_arrays()
     nb = len(hs) // 32
     n = (1 << 19) + 777
@@ -360,7 +360,7 @@ def test_oid_der_validation_matches_reference(golden):
 @pytest.mark.parametrize("l", [192, 256])
 def test_field_ops_big_curves(l):
     """GF(2^384 - 317) and GF(2^512 - 569) against Python integers"""
-    eng = engine()
+    eng = exp_engine()          # hooks of include/bee2hip_internal.h
     P = 2 ** (2 * l) - {192: 317, 256: 569}[l]
     nb = l // 4
     rnd = random.Random(l)
@@ -393,7 +393,7 @@ def test_crandall_reduction_carry_ripple(l):
     """fe_reduce on raw 2N-limb values (debug ops 9 / 10 = K 1 / 3) crafted so that the second fold
     lands within +-2 of 2^(32N): the carry of `t[0] + c*C` then ripples through every limb and (for
     delta >= 0) out of the top.  Random products almost never exercise that chain."""
-    eng = engine()
+    eng = exp_engine()          # hooks of include/bee2hip_internal.h
     rnd = random.Random(l)
     C = {128: 189, 192: 317, 256: 569}[l]
     bits = 2 * l
@@ -441,7 +441,7 @@ def test_field_ops_verification_flavour_rare_carry_branches(l):
     of ones above it (the carry ripples that far, and out of the top for a, b >= p), a - b = -(y) with limb 0 of
     2^(2l) - y below c over 0..N-1 zero limbs, folds that land within +-2 of 2^(32N) -- mixed with random lanes in the
     same wavefronts, and compared with Python integers AND with the straight-line (CtOps) form of the same operation."""
-    eng = engine()
+    eng = exp_engine()          # hooks of include/bee2hip_internal.h
     rnd = random.Random(1000 + l)
     C = {128: 189, 192: 317, 256: 569}[l]
     bits, nb = 2 * l, l // 4
@@ -499,7 +499,7 @@ def test_bign_big_curves_both_kernel_sets(golden, l, path):
     """the wider curves: the r01 kernels (32-bit limbs, one lane per signature) and the quad kernel on 28- / 27-bit
     limbs (bign_fe29.hpp LZ<12>, LZ<16>), each FORCED over the base and edge fixtures and a 20 000-signature tiling with
     every 5th signature corrupted (quads are chosen unforced up to 2^14)"""
-    eng = engine()
+    eng = exp_engine()          # hooks of include/bee2hip_internal.h
     tune = eng.lib.bee2hip_internal_tune
     tune.restype = ctypes.c_uint32
     assert tune(2, path) == 0

@@ -11,7 +11,7 @@ import torch
 
 import orclib
 from bee2_amd import engine as E
-from gpulib import dev, engine, host
+from gpulib import dev, engine, exp_engine, host
 
 pytestmark = pytest.mark.gpu
 
@@ -56,7 +56,7 @@ def test_stb_annex_G_vectors(golden):
 def test_golden_cases_dropin(golden, l, mulbase):
     """every case of the fixture through the drop-in functions: keys 0, 1, q-1, q-2, q, 2^2l - 1; hashes at and
     beyond q; additional input of 0..300 octets; rejected rng draws; foreign, long and malformed OIDs"""
-    eng = engine()
+    eng = mulbase
     P = _params(eng, l)
     L = golden.bign_sign[str(l)]
     no = l // 4
@@ -92,14 +92,21 @@ def test_golden_cases_dropin(golden, l, mulbase):
             assert rng.pos[0] == 0                    # a bad private key must not consume the generator
 
 
-@pytest.fixture(params=[1, 101, 102, 4, 16, 64], ids=lambda v: {101: "1_lane_4bit_windows", 102: "1_lane_6bit_complete_additions"}.get(v, f"{v}_lanes_per_scalar"))
+@pytest.fixture(params=[0, 1, 101, 102, 4, 16, 64],
+                ids=lambda v: {0: "product_library_dispatch_by_size", 101: "1_lane_4bit_windows",
+                               102: "1_lane_6bit_complete_additions"}.get(v, f"{v}_lanes_per_scalar"))
 def mulbase(request):
     """k G of the signing side: one lane per scalar (bign_mulbase_ct_kernel: signed 6-bit windows and Jacobian mixed additions, the
-    throughput form; 102 = the same windows with complete additions, 101 = the round-2 form on unsigned 4-bit windows) or 4 / 16 / 64 lanes per scalar (bign_mulbase_coop_kernel; the product picks
-    by batch size) -- each forced at every size, default restored"""
-    eng = engine()
+    throughput form; 102 = the same windows with complete additions, 101 = the round-2 form on unsigned 4-bit windows) or 4 / 16 / 64
+    lanes per scalar (bign_mulbase_coop_kernel).  0 = the PRODUCT library, which picks by batch size; every other form is forced at
+    every size through the hook of the experiments build (libbee2hip_exp.so, include/bee2hip_internal.h), default restored.
+    Yields the engine to use."""
+    if request.param == 0:
+        yield engine()
+        return
+    eng = exp_engine()
     eng.lib.bee2hip_internal_tune(10, request.param)
-    yield request.param
+    yield eng
     eng.lib.bee2hip_internal_tune(10, 0)
 
 
@@ -107,7 +114,7 @@ def mulbase(request):
 def test_batch_vs_oracle_and_verify_roundtrip(orc, l, mulbase):
     """host batch API on seeded random items with bad keys mixed in: codes and outputs per item as the oracle,
     outputs of refused items untouched; then every signature verifies under its public key on the device"""
-    eng = engine()
+    eng = mulbase
     P = _params(eng, l)
     no, sg = l // 4, 3 * l // 8
     oid = E.LEVEL_OID[l]
@@ -153,7 +160,7 @@ def test_batch_vs_oracle_and_verify_roundtrip(orc, l, mulbase):
 def test_base_point_multiples_of_special_scalars(orc, l, mulbase):
     """d G for d = 1, 2, 15, 16, 2^(4 j), q - 1, q - 2 and digit patterns that leave most windows empty or full; d = 0 and
     d >= q are refused with the reference's code; one-time key k = q - 1 and k = 1 sign like the oracle"""
-    eng = engine()
+    eng = mulbase
     P = _params(eng, l)
     no, sg = l // 4, 3 * l // 8
     q = int.from_bytes(bytes(P.q)[:no], "little")

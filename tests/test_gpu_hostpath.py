@@ -11,20 +11,20 @@ import numpy as np
 import pytest
 
 from bee2_amd import engine as E
-from gpulib import engine
+from gpulib import engine, exp_engine
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _stats(lib):
-    return [lib.bee2hip_internal_stat(i) for i in range(3)]
+    return [lib.bee2hip_path_count(i) for i in range(3)]
 
 
 def test_auto_mode_crossovers(orc):
     eng = engine()
     L = eng.lib
-    L.bee2hip_internal_tune(4, 0)
+    L.bee2hip_path_policy(0)
     H = orc.beltH()
     # one permutation, one block, a 16-byte CTR step: host
     s0 = _stats(L)
@@ -76,13 +76,13 @@ def test_one_signature_is_verified_on_the_host_batches_never(orc, golden):
     cases = [tuple(bytes.fromhex(k[x]) for x in ("hash", "sig", "pubkey")) + (k["code"],) for k in golden.kat["bign_verify"]]
     cases += [tuple(bytes.fromhex(k[x]) for x in ("hash", "sig", "pubkey")) + (k["code"],) for k in golden.bign_edge[::7]]
     for mode in (0, 1, 2):
-        L.bee2hip_internal_tune(4, mode)
+        L.bee2hip_path_policy(mode)
         s0 = _stats(L)
         for h, s, p, code in cases:
             assert eng.bign128Verify(h, s, p) == code
         s1 = _stats(L)
         assert (s1[0] - s0[0] == len(cases)) == (mode != 1), mode
-    L.bee2hip_internal_tune(4, 0)
+    L.bee2hip_path_policy(0)
     for l in (192, 256):
         fn = lambda h, s, p: eng.bignLVerify(l, h, s, p)   # noqa: E731
         for e in golden.bign_big[str(l)]["edge"][::5] + golden.bign_big[str(l)]["base"][:8]:
@@ -91,9 +91,9 @@ def test_one_signature_is_verified_on_the_host_batches_never(orc, golden):
             s0 = _stats(L)
             assert fn(h, s, p) == want
             assert _stats(L)[0] == s0[0] + 1
-            L.bee2hip_internal_tune(4, 1)
+            L.bee2hip_path_policy(1)
             assert fn(h, s, p) == want
-            L.bee2hip_internal_tune(4, 0)
+            L.bee2hip_path_policy(0)
     # one public key: host in auto mode, GPU when forced, the reference's codes either way
     for l in (128, 192, 256):
         for c in golden.bign_pubkey_val[str(l)][::9]:
@@ -101,10 +101,10 @@ def test_one_signature_is_verified_on_the_host_batches_never(orc, golden):
             s0 = _stats(L)
             assert eng.bignLPubkeyVal(l, pub) == c["code"], (l, c["name"])
             assert _stats(L)[0] == s0[0] + 1
-            L.bee2hip_internal_tune(4, 1)
+            L.bee2hip_path_policy(1)
             assert eng.bignLPubkeyVal(l, pub) == c["code"], (l, c["name"])
             assert _stats(L)[0] == s0[0] + 1
-            L.bee2hip_internal_tune(4, 0)
+            L.bee2hip_path_policy(0)
     # n = 1 through the batch entry point: GPU
     h, s, p, code = cases[0]
     s0 = _stats(L)
@@ -117,9 +117,9 @@ def test_one_signature_is_verified_on_the_host_batches_never(orc, golden):
 
 
 def test_device_fault_is_retried_then_finished_on_the_host(orc):
-    eng = engine()
+    eng = exp_engine()          # fault injection is a hook of the experiments build (bee2hip_internal_tune 5)
     L = eng.lib
-    L.bee2hip_internal_tune(4, 0)
+    L.bee2hip_path_policy(0)
     H = orc.beltH()
     msg = orc.fill(1 << 16, 5)
     cs = ctypes.create_string_buffer(L.beltCTR_keep())
@@ -144,7 +144,7 @@ def test_device_fault_is_retried_then_finished_on_the_host(orc):
 
 
 def test_forced_gpu_mode_stays_fatal_on_a_device_fault():
-    code = ("import ctypes, sys; sys.path[:0] = [%r, %r]; import bee2_amd; L = bee2_amd.load().lib; "
+    code = ("import ctypes, sys; sys.path[:0] = [%r, %r]; import bee2_amd; L = bee2_amd.load_experiments().lib; "
             "L.bee2hip_internal_tune(5, 2); b = ctypes.create_string_buffer(192); L.bashF(b, None); print('survived')"
             % (ROOT, os.path.join(ROOT, "tests")))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BEE2HIP_FORCE="gpu"), capture_output=True, text=True,

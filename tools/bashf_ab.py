@@ -44,7 +44,7 @@ ABLATION = {40, 41, 42, 43, 44, 45, 46}
 
 def main():
     variants = [int(x) for x in sys.argv[1:]] or [0, 1, 3, 4, 11, 31, 36, 53, 61, 40, 41, 42]
-    eng = bee2_amd.load()
+    eng = bee2_amd.load_experiments()
     eng.set_device(0)
     orc = orclib.load()
     tune = eng.lib.bee2hip_internal_tune

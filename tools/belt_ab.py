@@ -41,7 +41,7 @@ NAMES = {0: "product: variant 20 (SDWA addresses, v_lshl_or combine, three regis
 
 def main():
     variants = [int(x) for x in sys.argv[1:]] or sorted(NAMES)
-    eng = bee2_amd.load()
+    eng = bee2_amd.load_experiments()
     eng.set_device(0)
     orc = orclib.load()
     tune = eng.lib.bee2hip_internal_tune

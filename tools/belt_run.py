@@ -11,7 +11,7 @@ import bee2_amd  # noqa: E402
 v = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 logn = int(sys.argv[2]) if len(sys.argv) > 2 else 26
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-eng = bee2_amd.load()
+eng = bee2_amd.load_experiments()
 eng.set_device(0)
 eng.lib.bee2hip_internal_tune(1, v)
 kw, c0 = eng.beltCTRStart(bytes(range(32)), bytes(16))

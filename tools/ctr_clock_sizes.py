@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import torch
 import bee2_amd
-eng = bee2_amd.load(); eng.set_device(0)
+eng = bee2_amd.load_experiments(); eng.set_device(0)
 v = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 eng.lib.bee2hip_internal_tune(1, v)
 side = torch.cuda.Stream()

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import torch
 import bee2_amd
-eng = bee2_amd.load(); eng.set_device(0)
+eng = bee2_amd.load_experiments(); eng.set_device(0)
 for logn, rep_list in ((26, (5, 20, 100, 400, 800)), (30, (1, 2, 5, 20))):
     n = 1 << logn
     st = torch.empty(16 * n, dtype=torch.uint8, device="cuda"); st.random_(0, 256)

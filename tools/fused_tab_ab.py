@@ -14,7 +14,7 @@ import orclib  # noqa: E402
 
 
 def main():
-    eng = bee2_amd.load()
+    eng = bee2_amd.load_experiments()
     eng.set_device(0)
     orc = orclib.load()
     tune = eng.lib.bee2hip_internal_tune

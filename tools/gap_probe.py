@@ -2,7 +2,7 @@ import sys, os, time, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
 import torch, bee2_amd
-eng = bee2_amd.load(); eng.set_device(0)
+eng = bee2_amd.load_experiments(); eng.set_device(0)
 n = 1 << 20
 st = torch.empty(192*n, dtype=torch.uint8, device="cuda"); st.view(torch.int64).random_()
 for _ in range(50): eng.bashF_batch_dev(st)

@@ -4,7 +4,7 @@ import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import bee2_amd
-eng = bee2_amd.load(); eng.set_device(0)
+eng = bee2_amd.load_experiments(); eng.set_device(0)
 tune = eng.lib.bee2hip_internal_tune
 key = bytes(range(32)); iv = bytes(16)
 

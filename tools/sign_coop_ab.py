@@ -7,7 +7,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np, torch
 import bee2_amd
 from bee2_amd import engine as E
-eng = bee2_amd.load(); eng.set_device(0)
+eng = bee2_amd.load_experiments(); eng.set_device(0)
 L = eng.lib
 l = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 no, sg = l // 4, 3 * l // 8

@@ -7,7 +7,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np, torch
 import bee2_amd
 from bee2_amd import engine as E
-eng = bee2_amd.load(); eng.set_device(0)
+eng = bee2_amd.load_experiments(); eng.set_device(0)
 L = eng.lib
 rng = np.random.default_rng(5)
 for l in (128, 192, 256):

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np, torch
 import bee2_amd, goldenlib
-eng = bee2_amd.load(); eng.set_device(0)
+eng = bee2_amd.load_experiments(); eng.set_device(0)
 G = goldenlib.Golden(); H = eng.beltH()
 print("bashF: states  us/launch  Gperm/s  TB/s")
 for e in range(12, 25, 2):

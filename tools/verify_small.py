@@ -7,7 +7,7 @@ import numpy as np, torch
 import bee2_amd, goldenlib
 e = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-eng = bee2_amd.load(); eng.set_device(0)
+eng = bee2_amd.load_experiments(); eng.set_device(0)
 G = goldenlib.Golden()
 hs, ss, ps = G.bign_base_arrays()
 k = max(1, (1 << e) // 2048)

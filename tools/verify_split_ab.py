@@ -7,7 +7,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np, torch
 import bee2_amd, goldenlib
 from bee2_amd.engine import LEVEL_OID
-eng = bee2_amd.load(); eng.set_device(0)
+eng = bee2_amd.load_experiments(); eng.set_device(0)
 G = goldenlib.Golden()
 tune = eng.lib.bee2hip_internal_tune
 

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np, torch
 import bee2_amd, goldenlib
-eng = bee2_amd.load(); eng.set_device(0)
+eng = bee2_amd.load_experiments(); eng.set_device(0)
 G = goldenlib.Golden()
 e = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 hs, ss, ps = G.bign_base_arrays()
