@@ -145,6 +145,23 @@ err_t scratch_for_stream(hipStream_t st, int slot, size_t bytes, void **out)
     return ERR_OK;
 }
 
+// Entries keyed on a stream the LIBRARY owns (the per-thread duplex streams below) must go when that stream goes: nothing else
+// would ever free them (ThreadReaper only knows the NULL-stream entries of its thread), and a later stream that got the same
+// handle value would inherit a stale block.  The stream is drained first.
+static void scratch_release_stream(hipStream_t st)
+{
+    if (!st) return;
+    (void)hipStreamSynchronize(st);
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size();) {
+        if (g_pool[i].st == st) {
+            if (g_pool[i].p) (void)hipFree(g_pool[i].p);
+            g_pool[i] = g_pool.back();
+            g_pool.pop_back();
+        } else ++i;
+    }
+}
+
 // scratch device buffer for the host-pointer API, grown on demand, per thread
 // Staging for the host-pointer entry points, per thread and slot.  Small requests (<= 64 KiB: every drop-in call on a
 // block, a state, a signature ...) are served from a PINNED, device-mapped host buffer: the caller's bytes are copied
@@ -258,8 +275,23 @@ static const hostp::BeltTables &hostT()
     std::call_once(g_hostT_once, [] { hostp::belt_tables(g_hostT, host_beltH()); });
     return g_hostT;
 }
+// a call that hashes a SECRET through the drop-in's own streaming functions pins the path to the GPU for its duration
+// (ForceScope): the host path's table-driven belt is not constant-time and keeps its temporaries
+static thread_local int t_force_scope = -1;
+struct ForceScope {
+    int old;
+    explicit ForceScope(int m) : old(t_force_scope) { t_force_scope = m; }
+    ~ForceScope() { t_force_scope = old; }
+};
+// a wipe the optimiser may not drop (the buffer dies right afterwards)
+static inline void wipe_host(void *p, size_t n)
+{
+    volatile unsigned char *q = (volatile unsigned char *)p;
+    while (n--) *q++ = 0;
+}
 static int force_mode()
 {
+    if (t_force_scope >= 0) return t_force_scope;
     int m = g_force.load(std::memory_order_relaxed);
     if (m < 0) {
         const char *e = getenv("BEE2HIP_FORCE");
@@ -276,7 +308,7 @@ static bool host_wanted(int kind, size_t bytes)
     switch (kind) {
     case K_PRIM: return bytes <= 1024;          // one permutation / up to 64 blocks: 0.3-0.5 us each vs ~20 us per launch
     case K_PARALLEL: return bytes < 8192;       // INTEGRATION.md crossover table (CTR: 16 KiB 36 us vs 79 us on one core)
-    case K_POLY: return bytes <= 1024;          // the bit-serial host product: 0.4 us per block
+    case K_POLY: return bytes <= (hostp::gf_have_clmul() ? (size_t)32768 : (size_t)4096);   // host product: 7 ns per block with PCLMULQDQ (2.2 GB/s), 60 ns by table; a GPU call is ~30 us
     case K_VERIFY1: return true;                // one signature: ~40 us on a core vs ~0.4 ms through the GPU
     default: return true;                       // K_SERIAL: one message = one dependent chain
     }
@@ -327,6 +359,9 @@ static int g_duplex_log2_states = 16, g_duplex_log2_blocks = 20;   // chunk size
 constexpr size_t VERIFY_PIPE_MIN = (size_t)1 << 19, VERIFY_PIPE_CHUNK = (size_t)1 << 18;   // host-pointer verification batches
 static int g_verify_pipe = 1;                                      // (tune 11: A/B)
 static int g_duplex_ramp = 0;                                      // quarter / half chunks at both ends (tune 9): measured -2 %, off
+#ifdef BEE2HIP_EXPERIMENTS
+static std::atomic<int> g_duplex_fail_chunk{0}, g_duplex_fail_times{0};   // tests (tune 14 / 15): the next `times` pipelines fail at chunk `chunk`
+#endif
 struct DuplexStreams {
     hipStream_t up = nullptr, dn = nullptr;
     int dev = -1;
@@ -335,19 +370,33 @@ struct DuplexStreams {
         int cur = 0;
         B2H_TRY(hipGetDevice(&cur));
         if (up && cur == dev) return ERR_OK;
-        if (up) { (void)hipStreamDestroy(up); (void)hipStreamDestroy(dn); up = dn = nullptr; }
+        if (up) { drop(); }
         B2H_TRY(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
         B2H_TRY(hipStreamCreateWithFlags(&dn, hipStreamNonBlocking));
         dev = cur;
         return ERR_OK;
     }
-    ~DuplexStreams() { if (up && !on_loader_thread()) { (void)hipStreamDestroy(up); (void)hipStreamDestroy(dn); } }
+    // the launchers' scratch keyed on these streams (a 2^18-signature chunk of the verification pipeline: 275-550 MB) goes with them
+    void drop()
+    {
+        scratch_release_stream(up);
+        scratch_release_stream(dn);
+        if (up) (void)hipStreamDestroy(up);
+        if (dn) (void)hipStreamDestroy(dn);
+        up = dn = nullptr;
+    }
+    ~DuplexStreams() { if (up && !on_loader_thread()) drop(); }
 };
 static thread_local DuplexStreams t_duplex;
 
+// *done_units (may be null) = leading units whose results are back in the caller's buffer when the call returns: all of
+// them on success; after a failure the chunks whose download had completed.  A caller that retries or finishes on the host
+// MUST skip them -- they have been transformed in place already (a second CTR pass would decrypt them again).
 template <class Launch>
-static err_t duplex_inplace(octet *host, octet *dev, size_t unit_bytes, size_t units, size_t chunk_units, Launch launch)
+static err_t duplex_inplace(octet *host, octet *dev, size_t unit_bytes, size_t units, size_t chunk_units, Launch launch,
+                            size_t *done_units = nullptr)
 {
+    if (done_units) *done_units = 0;
     err_t code = t_duplex.get();
     if (code != ERR_OK) return code;
     // chunk boundaries: full chunks, with a quarter and a half chunk at either end when there are enough of them -- the first
@@ -369,47 +418,74 @@ static err_t duplex_inplace(octet *host, octet *dev, size_t unit_bytes, size_t u
         cut.push_back(units);
     }
     const size_t nch = cut.size() - 1;
-    std::vector<hipEvent_t> ev(nch, nullptr);
-    for (size_t c = 0; c < nch; ++c)
+    std::vector<hipEvent_t> ev(2 * nch, nullptr);         // [c] kernel of chunk c queued behind its upload; [nch + c] its download queued
+    for (size_t c = 0; c < 2 * nch; ++c)
         if (hipEventCreateWithFlags(&ev[c], hipEventDisableTiming) != hipSuccess) {
             for (size_t k = 0; k < c; ++k) (void)hipEventDestroy(ev[k]);
             return hip_fail(hipGetLastError(), "hipEventCreate");
         }
-    std::atomic<size_t> queued{0};
+    std::atomic<size_t> queued{0}, dn_queued{0};
     std::atomic<int> failed{0};
+    std::atomic<int> first_err{(int)hipSuccess};           // the first failing hipError_t of either thread
+    const auto fail = [&](hipError_t e) {
+        int ok = (int)hipSuccess;
+        first_err.compare_exchange_strong(ok, (int)(e == hipSuccess ? hipErrorUnknown : e));
+        failed.store(1);
+    };
     int devno = 0;
     (void)hipGetDevice(&devno);
     const hipStream_t sup = t_duplex.up, sdn = t_duplex.dn;
     std::thread down([&] {
-        if (hipSetDevice(devno) != hipSuccess) { failed.store(1); return; }
+        hipError_t e = hipSetDevice(devno);
+        if (e != hipSuccess) { fail(e); return; }
         for (size_t c = 0; c < nch; ++c) {
             while (queued.load(std::memory_order_acquire) <= c) {
-                if (failed.load()) return;
+                if (failed.load()) return;                 // (the caller drains sdn before it returns)
                 std::this_thread::yield();
             }
             const size_t first = cut[c], cnt = cut[c + 1] - first;
-            if (hipStreamWaitEvent(sdn, ev[c], 0) != hipSuccess ||
-                hipMemcpyAsync(host + first * unit_bytes, dev + first * unit_bytes, cnt * unit_bytes, hipMemcpyDeviceToHost, sdn) != hipSuccess) {
-                failed.store(1);
+            if ((e = hipStreamWaitEvent(sdn, ev[c], 0)) != hipSuccess ||
+                (e = hipMemcpyAsync(host + first * unit_bytes, dev + first * unit_bytes, cnt * unit_bytes, hipMemcpyDeviceToHost, sdn)) != hipSuccess ||
+                (e = hipEventRecord(ev[nch + c], sdn)) != hipSuccess) {
+                fail(e);
                 return;
             }
+            dn_queued.store(c + 1, std::memory_order_release);
         }
-        if (hipStreamSynchronize(sdn) != hipSuccess) failed.store(1);
     });
+#ifdef BEE2HIP_EXPERIMENTS
+    const size_t inject_at = g_duplex_fail_times.load() > 0 && g_duplex_fail_times.fetch_sub(1) > 0 ? (size_t)g_duplex_fail_chunk.load() : 0;
+#endif
     for (size_t c = 0; c < nch && !failed.load(); ++c) {
         const size_t first = cut[c], cnt = cut[c + 1] - first;
-        if (hipMemcpyAsync(dev + first * unit_bytes, host + first * unit_bytes, cnt * unit_bytes, hipMemcpyHostToDevice, sup) != hipSuccess) {
-            failed.store(1);
-            break;
-        }
+#ifdef BEE2HIP_EXPERIMENTS
+        if (inject_at && c + 1 == (inject_at < nch ? inject_at : nch)) { fail(hipErrorUnknown); break; }   // a device fault in mid-pipeline
+#endif
+        hipError_t e = hipMemcpyAsync(dev + first * unit_bytes, host + first * unit_bytes, cnt * unit_bytes, hipMemcpyHostToDevice, sup);
+        if (e != hipSuccess) { fail(e); break; }
         code = launch(dev + first * unit_bytes, first, cnt, sup);
-        if (code != ERR_OK || hipEventRecord(ev[c], sup) != hipSuccess) { failed.store(1); break; }
+        if (code != ERR_OK) { failed.store(1); break; }
+        if ((e = hipEventRecord(ev[c], sup)) != hipSuccess) { fail(e); break; }
         queued.store(c + 1, std::memory_order_release);
     }
     down.join();
-    (void)hipStreamSynchronize(sup);
-    for (size_t c = 0; c < nch; ++c) (void)hipEventDestroy(ev[c]);
-    if (failed.load()) return code != ERR_OK ? code : hip_fail(hipGetLastError(), "duplex staging");
+    // both streams are drained on EVERY path before the events go and the caller sees its buffer again: no copy into the
+    // caller's memory may still be in flight after this function has returned
+    hipError_t e = hipStreamSynchronize(sdn);
+    if (e != hipSuccess) fail(e);
+    e = hipStreamSynchronize(sup);
+    if (e != hipSuccess) fail(e);
+    size_t done = 0;
+    {
+        const size_t nq = dn_queued.load(std::memory_order_acquire);
+        while (done < nq && hipEventQuery(ev[nch + done]) == hipSuccess) ++done;
+    }
+    if (done_units) *done_units = failed.load() ? cut[done] : units;
+    for (size_t c = 0; c < 2 * nch; ++c) (void)hipEventDestroy(ev[c]);
+    if (failed.load()) {
+        (void)hipGetLastError();
+        return code != ERR_OK ? code : hip_fail((hipError_t)first_err.load(), "duplex staging");
+    }
     return ERR_OK;
 }
 
@@ -615,13 +691,16 @@ static err_t ctr_bulk(void *buf_, size_t count, void *ctr_state, bool allow_host
             pc = ps.need(pipe_blocks * 16);
             if (pc != ERR_OK) return pc;
             const u32 *key = st->key, *ctr = st->ctr;
+            size_t done = 0;
             pc = duplex_inplace(buf, (octet *)ps.p, 16, pipe_blocks, CH, [key, ctr](octet *d, size_t first, size_t cnt, hipStream_t s2) {
                 return launch_belt_ctr_blocks(d, cnt, key, ctr, first, nullptr, s2);
-            });
+            }, &done);
+            // the blocks that came back ARE encrypted in the caller's buffer, also when a later chunk failed: whoever goes on
+            // (the retry, the host fallback of with_host) starts behind them, from the advanced counter
+            ctr_add(st->ctr, done);
+            buf += done * 16;
+            count -= done * 16;
             if (pc != ERR_OK) return pc;
-            ctr_add(st->ctr, pipe_blocks);
-            buf += pipe_blocks * 16;
-            count -= pipe_blocks * 16;
         }
         const size_t full = count / 16, tail = count % 16;
         const size_t nblk = full + (tail ? 1 : 0);
@@ -1122,6 +1201,7 @@ static err_t sign_batch_host(int mode, const bign_params *params, const octet oi
     if (mode == 0 && t_len > 64) {
         theta.resize(32 * n);
         std::vector<octet> st(beltHash_keep());
+        const ForceScope on_device(FORCE_GPU);                 // the private key is hashed by the kernels, in every mode
         for (size_t i = 0; i < n; ++i) {
             beltHashStart(st.data());
             beltHashStepH(oid_der, oid_len, st.data());
@@ -1129,10 +1209,13 @@ static err_t sign_batch_host(int mode, const bign_params *params, const octet oi
             beltHashStepH(aux, t_len, st.data());
             beltHashStepG(theta.data() + 32 * i, st.data());
         }
-        memset(st.data(), 0, st.size());
-        // with BEE2HIP_FORCE=gpu the streaming belt-hash staged the private keys and its state through t_scr[2] (pinned or
-        // device memory): wipe it (in the default mode these hashes run on the host path and stage nothing)
-        if (t_scr[2].p) (void)zero_staging(t_scr[2].p, std::min<size_t>(t_scr[2].p == t_scr[2].pin ? PINNED_MAX : t_scr[2].cap, 4096));
+        wipe_host(st.data(), st.size());
+        // the streaming belt-hash staged the private keys and -- behind the data, at offset nblocks * 32 -- its chaining state
+        // through t_scr[2] (pinned or device memory): wipe everything a call of this size can have touched
+        if (t_scr[2].p) {
+            const size_t cap = t_scr[2].p == t_scr[2].pin ? PINNED_MAX : t_scr[2].cap;
+            (void)zero_staging(t_scr[2].p, std::min<size_t>(cap, ((std::max<size_t>(t_len, std::max<size_t>(oid_len, no)) + 31) & ~(size_t)31) + 128));
+        }
         aux = theta.data();
         ab = 32 * n;
         dev_mode = 2;
@@ -1164,7 +1247,7 @@ static err_t sign_batch_host(int mode, const bign_params *params, const octet oi
         if (e != hipSuccess) code = hip_fail(e, "bignSign copy");
         else for (size_t i = 0; i < n; ++i) if (codes[i] == ERR_OK) memcpy(sigs + sg * i, tmp.data() + sg * i, sg);
     }
-    if (!theta.empty()) memset(theta.data(), 0, theta.size());
+    if (!theta.empty()) wipe_host(theta.data(), theta.size());
     return code;
 }
 extern "C" err_t bee2hip_bignSign2_batch(const bign_params *params, const octet oid_der[], size_t oid_len, const octet *hashes,
@@ -1548,6 +1631,8 @@ extern "C" err_t bee2hip_internal_tune(int key, int value)
     case 10: bee2hip::set_sign_coop(value); return ERR_OK;            // lanes per scalar of k G, signing side (0 = by batch size)
     case 9: bee2hip::g_duplex_ramp = value; return ERR_OK;            // ramped chunk sizes at the ends of the pipeline
     case 13: bee2hip::set_fused_tab(value); return ERR_OK;            // belt table of the fused bash + belt-mac kernel (A/B)
+    case 14: bee2hip::g_duplex_fail_chunk.store(value); return ERR_OK;   // tests: the duplex host pipeline fails at this chunk (1-based) ...
+    case 15: bee2hip::g_duplex_fail_times.store(value); return ERR_OK;   // ... in the next `value` pipelines
     default: return ERR_BAD_INPUT;
     }
 }

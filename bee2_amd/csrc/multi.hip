@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 #include "common.hpp"
@@ -77,7 +78,14 @@ struct Pool {
                 k->cv.wait(lk, [k] { return k->has_job; });
                 std::function<err_t()> f = std::move(k->job);
                 lk.unlock();
-                const err_t c = bind != ERR_OK ? bind : f();
+                err_t c = bind;
+                if (c == ERR_OK) {
+                    // nothing may leave a worker as an exception (std::terminate would take the whole process down) nor
+                    // cross the C ABI: an allocation that fails inside a job is the job's ERR_OUTOFMEMORY
+                    try { c = f(); }
+                    catch (const std::bad_alloc &) { c = ERR_OUTOFMEMORY; }
+                    catch (...) { c = hip_fail(hipErrorUnknown, "exception in a multi-device job"); }
+                }
                 lk.lock();
                 k->code = c; k->has_job = false; k->done = true;
                 k->cv.notify_all();
@@ -96,7 +104,17 @@ Pool &pool()
 
 // run job(i, parts) on logical device i = 0 .. parts-1, each on its pool worker bound to real device i % real
 template <class F>
+err_t run_on_devices_unguarded(int ndev, F job);
+// the dispatcher allocates too (worker objects, std::function copies): same rule
+template <class F>
 err_t run_on_devices(int ndev, F job)
+{
+    try { return run_on_devices_unguarded(ndev, job); }
+    catch (const std::bad_alloc &) { return ERR_OUTOFMEMORY; }
+    catch (...) { return hip_fail(hipErrorUnknown, "exception in the multi-device dispatcher"); }
+}
+template <class F>
+err_t run_on_devices_unguarded(int ndev, F job)
 {
     const int real = real_device_count();
     if (real <= 0) return hip_fail(hipErrorNoDevice, "hipGetDeviceCount");
@@ -232,6 +250,7 @@ extern "C" err_t bee2hip_hash_ragged_multi(size_t alg, const octet *data, const 
     const size_t dlen = alg ? alg / 4 : 32;
     int parts = ndev > 0 ? ndev : bee2hip_device_count();
     if (parts <= 0) return hip_fail(hipErrorNoDevice, "hipGetDeviceCount");
+    try {
     // cut[i] = first message of range i: the first index whose start offset reaches i / parts of the bytes
     std::vector<size_t> cut((size_t)parts + 1, n);
     cut[0] = 0;
@@ -248,5 +267,77 @@ extern "C" err_t bee2hip_hash_ragged_multi(size_t alg, const octet *data, const 
         std::vector<uint64_t> off(hi - lo + 1);
         for (size_t k = lo; k <= hi; ++k) off[k - lo] = offsets[k] - offsets[lo];
         return bee2hip_hash_ragged(alg, data + offsets[lo], off.data(), hi - lo, digests + dlen * lo);
+    });
+    } catch (const std::bad_alloc &) { return ERR_OUTOFMEMORY; }      // (the per-range vectors are guarded in the worker)
+}
+
+// ---- shards that already live on the devices -------------------------------------------------
+// A caller whose data is resident -- shard i in the memory of device i -- must not be pushed through PCIe twice.  These
+// take one device pointer and one count per device; worker i (bound to device i) launches the single-device _dev entry on
+// its NULL stream and drains it, so the call returns when every device is done.  Nothing crosses devices; the parameter
+// block (key, counter, curve, OID) is an argument.  ndev = entries in the arrays (<= bee2hip_device_count()).
+static err_t multi_dev_args(const void *const ptrs, const size_t *counts, int ndev)
+{
+    if (ndev <= 0 || !ptrs || !counts) return ERR_BAD_INPUT;
+    if (ndev > bee2hip_device_count()) return ERR_BAD_INPUT;
+    return ERR_OK;
+}
+static inline err_t drain(err_t code)
+{
+    if (code != ERR_OK) return code;
+    B2H_TRY(hipStreamSynchronize(nullptr));
+    return ERR_OK;
+}
+
+extern "C" err_t bee2hip_bashF_batch_multi_dev(void *const d_states[], const size_t counts[], int ndev)
+{
+    err_t code = multi_dev_args(d_states, counts, ndev);
+    if (code != ERR_OK) return code;
+    return run_on_devices(ndev, [=](int i, int) { return drain(bee2hip_bashF_batch_dev(d_states[i], counts[i], nullptr)); });
+}
+
+// shard i holds blocks [first_block + sum of nblocks[0 .. i), ...) of ONE stream that started at ctr0 (beltCTRStart's E_K(iv)):
+// lanes compute ctr0 + offset + 1 directly, no state passes between devices
+extern "C" err_t bee2hip_beltCTR_blocks_multi_dev(void *const d_bufs[], const size_t nblocks[], const u32 key[8],
+                                                  const u32 ctr0[4], uint64_t first_block, int ndev)
+{
+    err_t code = multi_dev_args(d_bufs, nblocks, ndev);
+    if (code != ERR_OK) return code;
+    if (!key || !ctr0) return ERR_BAD_INPUT;
+    uint64_t first[64];
+    if (ndev > 64) return ERR_BAD_INPUT;
+    for (int i = 0; i < ndev; ++i) { first[i] = first_block; first_block += (uint64_t)nblocks[i]; }
+    return run_on_devices(ndev, [=](int i, int) {
+        return drain(bee2hip_beltCTR_blocks_dev(d_bufs[i], nblocks[i], key, ctr0, first[i], nullptr));
+    });
+}
+
+extern "C" err_t bee2hip_bignVerifyL_batch_multi_dev(size_t l, const octet oid_der[], size_t oid_len, const void *const d_hashes[],
+                                                     const void *const d_sigs[], const void *const d_pubkeys[],
+                                                     const size_t counts[], void *const d_codes[], int ndev)
+{
+    err_t code = multi_dev_args(d_hashes, counts, ndev);
+    if (code != ERR_OK) return code;
+    if (!d_sigs || !d_pubkeys || !d_codes) return ERR_BAD_INPUT;
+    // argument checks once (level, OID), in the single-device entry's order, through an empty call
+    code = bee2hip_bignVerifyL_batch_dev(l, oid_der, oid_len, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
+    if (code != ERR_OK) return code;
+    return run_on_devices(ndev, [=](int i, int) {
+        return drain(bee2hip_bignVerifyL_batch_dev(l, oid_der, oid_len, d_hashes[i], d_sigs[i], d_pubkeys[i], counts[i], d_codes[i], nullptr));
+    });
+}
+
+extern "C" err_t bee2hip_bashHash_beltMAC_batch_multi_dev(const void *const d_msgs[], size_t msg_len, const size_t counts[], size_t l,
+                                                          const octet key[], size_t key_len, void *const d_digests[],
+                                                          void *const d_tags[], int ndev)
+{
+    err_t code = multi_dev_args(d_msgs, counts, ndev);
+    if (code != ERR_OK) return code;
+    code = bee2hip_bashHash_beltMAC_batch_dev(nullptr, msg_len, 0, l, key, key_len, d_digests ? (void *)1 : nullptr,
+                                              d_tags ? (void *)1 : nullptr, nullptr);
+    if (code != ERR_OK) return code;
+    return run_on_devices(ndev, [=](int i, int) {
+        return drain(bee2hip_bashHash_beltMAC_batch_dev(d_msgs[i], msg_len, counts[i], l, key, key_len,
+                                                        d_digests ? d_digests[i] : nullptr, d_tags ? d_tags[i] : nullptr, nullptr));
     });
 }

@@ -87,6 +87,8 @@ BATCH_SYMBOLS = [
     "bee2hip_device_count", "bee2hip_multi_plan", "bee2hip_bashF_batch_multi", "bee2hip_beltCTR_bulk_multi",
     "bee2hip_bignVerify_batch_multi", "bee2hip_bignSign2_batch_multi", "bee2hip_bashHash_beltMAC_batch_multi",
     "bee2hip_hash_ragged_multi",
+    "bee2hip_bashF_batch_multi_dev", "bee2hip_beltCTR_blocks_multi_dev", "bee2hip_bignVerifyL_batch_multi_dev",
+    "bee2hip_bashHash_beltMAC_batch_multi_dev",
     "bee2hip_bignPubkeyCalcL_batch_dev", "bee2hip_bignSign2L_batch_dev", "bee2hip_bignSignKL_batch_dev",
     "bee2hip_bashHash_beltMAC_batch_dev",
     "bee2hip_set_device", "bee2hip_sync", "bee2hip_last_error", "bee2hip_version", "bee2hip_path_policy", "bee2hip_path_count",

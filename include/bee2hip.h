@@ -430,6 +430,21 @@ err_t bee2hip_bashHash_beltMAC_batch_dev(const void *d_msgs, size_t msg_len, siz
                                          const octet key[], size_t key_len,
                                          void *d_digests, void *d_tags, void *stream);
 
+/* Shards that already LIVE on the devices: entry i of each array belongs to device i (a pointer into its memory and an item
+   count); worker i launches the single-device _dev entry on that device's NULL stream and the call returns when all are
+   done.  Nothing is staged through the host and nothing crosses devices.  ndev = number of array entries,
+   1 <= ndev <= bee2hip_device_count().  CTR: shard i holds blocks first_block + nblocks[0] + .. + nblocks[i-1] onwards of
+   ONE stream with counter ctr0 (as bee2hip_beltCTR_blocks_dev); MAC / hash: d_digests or d_tags may be NULL as a whole. */
+err_t bee2hip_bashF_batch_multi_dev(void *const d_states[], const size_t counts[], int ndev);
+err_t bee2hip_beltCTR_blocks_multi_dev(void *const d_bufs[], const size_t nblocks[], const u32 key[8],
+                                       const u32 ctr0[4], uint64_t first_block, int ndev);
+err_t bee2hip_bignVerifyL_batch_multi_dev(size_t l, const octet oid_der[], size_t oid_len, const void *const d_hashes[],
+                                          const void *const d_sigs[], const void *const d_pubkeys[],
+                                          const size_t counts[], void *const d_codes[], int ndev);
+err_t bee2hip_bashHash_beltMAC_batch_multi_dev(const void *const d_msgs[], size_t msg_len, const size_t counts[], size_t l,
+                                               const octet key[], size_t key_len, void *const d_digests[],
+                                               void *const d_tags[], int ndev);
+
 /* ---- engine management --------------------------------------------------- */
 /* bind the calling thread's engine to HIP device `device` (default: current) */
 err_t bee2hip_set_device(int device);

@@ -1,7 +1,8 @@
 /* bee2hip_internal.h -- test / bench / experiment hooks of libbee2hip.so.
  *
- * NOT part of the product ABI: nothing here replaces a bee2 interface, a bee2 caller never needs
- * it, and the names may change between builds.  The product ABI is include/bee2hip.h (bee2's own
+ * NOT part of the product ABI and NOT in the product library: these functions exist only in libbee2hip_exp.so, the
+ * -DBEE2HIP_EXPERIMENTS build of the same sources (bee2_amd/csrc/Makefile, target exp).  Nothing here replaces a bee2
+ * interface, a bee2 caller never needs it, and the names may change between builds.  The product ABI is include/bee2hip.h (bee2's own
  * symbols plus the bee2hip_* batch entry points).  tests/, bench.py and tools/ use these hooks to
  * reach device code that has no entry point of its own (the field arithmetic) and to switch
  * experiment variants of a kernel inside one process.
@@ -44,7 +45,8 @@ err_t bee2hip_internal_tune(int key, int value);
    key 9 = quarter and half chunks at both ends of the duplex pipeline (0 = product: measured -2 %); key 10 = lanes per scalar of k G on the signing side
    (0 = by batch size: 64 / 16 / 4 / 1; 1, 4, 16, 64 forced; 101 = one lane on the 4-bit windows of round 2, 102 = one lane, signed 6-bit windows, complete additions); key 11 = chunked upload of host-pointer
    verification batches of 2^19 signatures and more (1 = product); key 12 = largest workgroup of the signing side's hashing
-   kernels for batches of 2^16 and more (0 = 1024, the product; 256 = round 2)) */
+   kernels for batches of 2^16 and more (0 = 1024, the product; 256 = round 2); key 13 = belt table of the fused kernel;
+   keys 14 / 15 = fault injection into the duplex host pipeline: the next `15` pipelines fail when they reach chunk `14`) */
 /* drop-in helper calls so far: which = 0 taken on the host path, 1 on the GPU, 2 finished on the host after the GPU path
    failed twice */
 unsigned long long bee2hip_internal_stat(int which);

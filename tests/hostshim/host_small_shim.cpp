@@ -23,6 +23,9 @@ void hs_mac(const uint32_t key[8], uint32_t s[4], uint32_t r[4], uint32_t mac[4]
 }
 void hs_hash(uint32_t hs[12], const uint8_t *data, size_t nblocks, int fin, uint64_t lo, uint64_t hi) { hash_stream(g_T, hs, data, nblocks, fin, lo, hi); }
 void hs_polyhash(uint32_t t[4], const uint32_t r[4], const uint8_t *data, size_t nbytes) { polyhash(t, r, data, nbytes); }
+// form 0 = what the product runs (PCLMULQDQ where the CPU has it), 1 = table of 16 multiples, 2 = bit-serial definition
+void hs_polyhash_form(uint32_t t[4], const uint32_t r[4], const uint8_t *data, size_t nbytes, int form) { polyhash(t, r, data, nbytes, form); }
+int hs_have_clmul(void) { return gf_have_clmul() ? 1 : 0; }
 void hs_modes(int mode, uint8_t *buf, size_t nblocks, const uint32_t key[8], const uint32_t iv[4]) { modes_blocks(g_T, mode, buf, nblocks, key, iv); }
 void hs_cbc_encr(uint8_t *buf, size_t nblocks, const uint32_t key[8], uint8_t chain[16]) { cbc_encr_blocks(g_T, buf, nblocks, key, chain); }
 void hs_bde(int decr, uint8_t *buf, size_t nblocks, const uint32_t key[8], uint32_t s[4]) { bde_blocks(g_T, decr, buf, nblocks, key, s); }

@@ -205,3 +205,45 @@ def test_duplex_pipeline_of_a_large_ctr_call_keeps_the_streaming_state(orc):
     assert L.beltCTR(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(msg2.ctypes.data), ctypes.c_size_t(n), H[128:160],
                      ctypes.c_size_t(32), H[192:208]) == 0
     assert out.tobytes() == pad2[:n].tobytes()
+
+
+@pytest.mark.parametrize("times", [1, 2])
+def test_device_fault_in_mid_duplex_pipeline_never_encrypts_a_block_twice(orc, times):
+    """the duplex CTR path downloads finished chunks into the caller's buffer while later chunks are still in
+    flight.  A fault in mid-pipeline (injected: experiments build, tune 14 / 15) must leave the call's result correct: the
+    retry (times = 1) or, after a second fault, the host fallback (times = 2) goes on BEHIND the chunks that came back,
+    from the advanced counter -- a second pass over them would turn them into plaintext again."""
+    eng = exp_engine()
+    L = eng.lib
+    L.bee2hip_path_policy(0)
+    H = orc.beltH()
+    n = (160 << 20) + 11                         # ten 16 MiB chunks; the fault hits chunk 4 of each attempt
+    kw, c0 = orc.ctr_start(H[128:160], H[192:208])
+    msg = np.frombuffer(orc.fill(n, 0xFA17), dtype=np.uint8).copy()
+    pad = np.zeros((n + 15) // 16 * 16, dtype=np.uint8)
+    pad[:n] = msg
+    orc.ctr_blocks_np(pad, kw, c0, first=0, nthreads=8)
+    want = pad[:n].tobytes()
+    st = ctypes.create_string_buffer(L.beltCTR_keep())
+    L.beltCTRStart(st, H[128:160], ctypes.c_size_t(32), H[192:208])
+    s0 = _stats(L)
+    L.bee2hip_internal_tune(14, 4)
+    L.bee2hip_internal_tune(15, times)
+    try:
+        L.beltCTRStepE(ctypes.c_void_p(msg.ctypes.data), ctypes.c_size_t(n), st)
+    finally:
+        L.bee2hip_internal_tune(15, 0)
+    s1 = _stats(L)
+    assert msg.tobytes() == want
+    if times == 1:
+        assert s1[1] == s0[1] + 1 and s1[2] == s0[2]          # the retry finished on the GPU
+    else:
+        assert s1[2] == s0[2] + 1                              # two faults: the rest on the host
+    # the streaming state is where a single clean pass would have left it: the next bytes continue the gamma
+    more = np.frombuffer(orc.fill(37, 0xFA18), dtype=np.uint8).copy()
+    pad2 = np.zeros((n + 37 + 15) // 16 * 16, dtype=np.uint8)
+    pad2[:n] = np.frombuffer(orc.fill(n, 0xFA17), dtype=np.uint8)
+    pad2[n: n + 37] = more
+    orc.ctr_blocks_np(pad2, kw, c0, first=0, nthreads=8)
+    L.beltCTRStepE(ctypes.c_void_p(more.ctypes.data), ctypes.c_size_t(37), st)
+    assert more.tobytes() == pad2[n: n + 37].tobytes()

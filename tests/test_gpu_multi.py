@@ -103,3 +103,75 @@ def test_verify_sign_and_ragged_multi(orc, golden, devices):
         for i, m in enumerate(msgs):
             want = orc.belt_hash(m) if alg == 0 else orc.bashHash(alg, m)[1]
             assert out.raw[dlen * i: dlen * (i + 1)] == want, (alg, i)
+
+
+def test_multi_dev_entries_on_resident_shards(orc, golden, devices):
+    """shards already in device memory, one pointer + count per device, no staging through the host.
+    With BEE2HIP_FAKE_DEVICES the k logical devices are the one real GPU, so every shard is a tensor on cuda:0; the CTR
+    shards are consecutive pieces of ONE stream (first_block offsets computed by the library)."""
+    import torch
+
+    from gpulib import dev, host
+    eng = engine()
+    k = devices
+    vp = ctypes.c_void_p
+    # uneven shards, one of them empty when there are enough devices
+    counts = [(1000 + 137 * i) if (i != 1 or k < 3) else 0 for i in range(k)]
+    CNT = (ctypes.c_size_t * k)(*counts)
+    # bashF
+    data = [orc.fill(192 * c, 0xBA50 + i) for i, c in enumerate(counts)]
+    ts = [dev(d) if d else torch.empty(0, dtype=torch.uint8, device="cuda") for d in data]
+    P = (vp * k)(*[t.data_ptr() if t.numel() else None for t in ts])
+    assert eng.lib.bee2hip_bashF_batch_multi_dev(P, CNT, k) == 0
+    for t, d in zip(ts, data):
+        assert host(t) == orc.bashF_batch(d)
+    # CTR: one stream of sum(counts) blocks, sharded; starts 5 blocks into the stream
+    H = golden.H
+    kw, c0 = eng.beltCTRStart(H[128:160], H[192:208])
+    total = sum(counts)
+    stream = np.frombuffer(orc.fill(16 * total, 0xBE17), dtype=np.uint8).copy()
+    want = stream.copy()
+    orc.ctr_blocks_np(want, kw, c0, first=5)
+    ts, pos = [], 0
+    for c in counts:
+        ts.append(dev(stream[16 * pos: 16 * (pos + c)]) if c else torch.empty(0, dtype=torch.uint8, device="cuda"))
+        pos += c
+    P = (vp * k)(*[t.data_ptr() if t.numel() else None for t in ts])
+    assert eng.lib.bee2hip_beltCTR_blocks_multi_dev(P, CNT, bytes(kw), bytes(c0), ctypes.c_uint64(5), k) == 0
+    assert b"".join(host(t) for t in ts) == want.tobytes()
+    # verify: the base set cut into shards, every 5th signature corrupted
+    hs, ss, ps = golden.bign_base_arrays()
+    vc = [min(c, 250) for c in counts]              # 8 x 250 <= the 2048 triples of the base set
+    VC = (ctypes.c_size_t * k)(*vc)
+    bad = bytearray(ss)
+    for i in range(0, len(ss) // 48, 5):
+        bad[48 * i + 7] ^= 4
+    th, tsg, tp, tc, pos = [], [], [], [], 0
+    for c in vc:
+        th.append(dev(hs[32 * pos: 32 * (pos + c)]) if c else None)
+        tsg.append(dev(bytes(bad[48 * pos: 48 * (pos + c)])) if c else None)
+        tp.append(dev(ps[64 * pos: 64 * (pos + c)]) if c else None)
+        tc.append(torch.full((max(c, 1),), -1, dtype=torch.int32, device="cuda"))
+        pos += c
+    arr = lambda xs: (vp * k)(*[x.data_ptr() if x is not None else None for x in xs])  # noqa: E731
+    oid = E.LEVEL_OID[128]
+    assert eng.lib.bee2hip_bignVerifyL_batch_multi_dev(_sz(128), oid, _sz(11), arr(th), arr(tsg), arr(tp), VC, arr(tc), k) == 0
+    got = [int(x) & 0xFFFFFFFF for t, c in zip(tc, vc) for x in t.cpu().numpy()[:c]]
+    assert got == orc.verify_batch(hs[:32 * pos], bytes(bad[:48 * pos]), ps[:64 * pos], nthreads=8)
+    # bash512 + beltMAC per message
+    ml = 512
+    mc = [min(c, 300) for c in counts]
+    MC = (ctypes.c_size_t * k)(*mc)
+    msgs = [orc.fill(ml * c, 0x4D10 + i) for i, c in enumerate(mc)]
+    tm = [dev(m) if m else None for m in msgs]
+    td = [torch.zeros(64 * max(c, 1), dtype=torch.uint8, device="cuda") for c in mc]
+    tt = [torch.zeros(8 * max(c, 1), dtype=torch.uint8, device="cuda") for c in mc]
+    key = H[128:160]
+    assert eng.lib.bee2hip_bashHash_beltMAC_batch_multi_dev(arr(tm), _sz(ml), MC, _sz(256), key, _sz(32), arr(td), arr(tt), k) == 0
+    for m, d, t, c in zip(msgs, td, tt, mc):
+        if c:
+            wd, wt = orc.mixed_batch(m, ml, key)
+            assert host(d)[: 64 * c] == wd and host(t)[: 8 * c] == wt
+    # misuse: more entries than devices, null arrays
+    assert eng.lib.bee2hip_bashF_batch_multi_dev(P, CNT, k + 1) == E.ERR_BAD_INPUT
+    assert eng.lib.bee2hip_bashF_batch_multi_dev(None, CNT, k) == E.ERR_BAD_INPUT

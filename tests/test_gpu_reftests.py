@@ -54,11 +54,68 @@ def test_reference_test_suite_passes_through_the_dropin():
     assert r.returncode == 0 and "Err" not in r.stdout
 
 
+# bee2's bench lines the library is ALLOWED to lose against the reference on the same box (each is named in INTEGRATION.md
+# "Known regressions of single calls" with its reason); everything else must be at least level (10 % measurement slack).
+# The test fails when a line NOT listed here is slower -- and also when a listed line stopped being slower, so that the
+# list cannot outlive its reasons.
+KNOWN_SLOWER = {
+    # bee2's loop makes ONE call per iteration; the private / one-time key never leaves the constant-time GPU kernels for the
+    # two wider curves (one launch chain per call: ~0.3-0.5 ms), and key generation adds the caller's rng on the host
+    "bign192Bench::KeypairGen", "bign192Bench::Sign", "bign192Bench::Sign2",
+    "bign256Bench::KeypairGen", "bign256Bench::Sign", "bign256Bench::Sign2",
+}
+BENCH_LINE = re.compile(r"^(\w+Bench::[\w-]+):\s+(\d+) ([\w/]+) \[\s*(\d+) ([\w/]+)\]", re.M)
+
+
+def _bench(binp, env=None, runs=1):
+    """-> (output of the last run, {line: (best rate over the runs, unit)}): bee2's loops are short (tens of milliseconds)
+    and a single run scatters by +-20 % on a shared host, so each side gets the best of `runs`"""
+    best, out = {}, ""
+    for _ in range(runs):
+        r = subprocess.run([binp, "bashbench", "beltbench", "bignbench"], capture_output=True, text=True, timeout=1800,
+                           env=dict(os.environ, **(env or {})))
+        assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+        out = r.stdout
+        for m in BENCH_LINE.finditer(out):
+            v = int(m.group(4))
+            if v > best.get(m.group(1), (0, ""))[0]:
+                best[m.group(1)] = (v, m.group(5))
+    return out, best
+
+
 @pytest.mark.gpu
 def test_reference_bench_functions_run_through_the_dropin():
-    """bashBench prints bash_platform (test/crypto/bash_bench.c:27,47 -- row a5) and times bee2's loops over our symbols"""
-    r = subprocess.run([BIN, "bashbench", "beltbench", "bignbench"], capture_output=True, text=True, timeout=1800)
-    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
-    assert "bashBench::platform = BASH_HIP" in r.stdout
+    """bashBench prints bash_platform (test/crypto/bash_bench.c:27,47 -- row a5) and times bee2's loops
+    (test/crypto/belt_bench.c:83-127, bign_bench.c:79-158, bash_bench.c:47-107) over our symbols.  The same binary linked
+    against the reference alone runs beside it on the same box; both outputs and the per-line ratio are RECORDED
+    (gpurun_out/r04_reftests_bench.txt -> profiles/), in auto mode (what a caller gets) and under BEE2HIP_FORCE=gpu."""
+    out_ref, ref = _bench(CTL, runs=3)
+    out_auto, auto = _bench(BIN, runs=3)
+    out_gpu, gpu = _bench(BIN, {"BEE2HIP_FORCE": "gpu"})
+    assert "bashBench::platform = BASH_HIP" in out_auto
     for m in ("beltBench", "bashBench", "bignBench"):
-        assert f"{m}: OK" in r.stdout, r.stdout
+        assert f"{m}: OK" in out_auto and f"{m}: OK" in out_gpu, out_auto + out_gpu
+    lines = ["bee2's own bench functions (test/crypto/{belt,bash,bign}_bench.c, compiled where they lie) on this box:",
+             "testbee2_ref = linked against the reference alone (one host core); testbee2_hip = linked -lbee2hip first.",
+             "rate = the bracketed figure bee2 prints (kBytes/sec, sigs/sec, ...), best of 3 runs for the reference and for auto mode;",
+             "ratio = hip / reference.", "",
+             f"{'line':34s} {'reference':>12s} {'hip auto':>12s} {'ratio':>7s} {'hip FORCE=gpu':>14s} {'ratio':>7s}  unit"]
+    slower, recovered = [], []
+    for name, (r0, unit) in ref.items():
+        a, g = auto.get(name, (0, unit))[0], gpu.get(name, (0, unit))[0]
+        mark = ""
+        if name.split("::")[1].startswith(("bash-prg", "belt-cfb", "KeyWrap", "KeyUnwrap")):
+            mark = "  (not a drop-in symbol: bee2's own code on both sides)"
+        elif a < 0.9 * r0:
+            mark = "  KNOWN regression (INTEGRATION.md)" if name in KNOWN_SLOWER else "  <-- SLOWER, not listed"
+            if name not in KNOWN_SLOWER:
+                slower.append((name, r0, a))
+        elif name in KNOWN_SLOWER:
+            recovered.append(name)
+        lines.append(f"{name:34s} {r0:12d} {a:12d} {a / max(r0, 1):7.2f} {g:14d} {g / max(r0, 1):7.2f}  {unit}{mark}")
+    lines += ["", "---- testbee2_ref", out_ref, "---- testbee2_hip (auto)", out_auto, "---- testbee2_hip (BEE2HIP_FORCE=gpu)", out_gpu]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r04_reftests_bench.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    assert not slower, f"slower than the reference on the same box and not a listed regression: {slower}"
+    assert not recovered, f"listed as known regressions but no longer slower -- shrink KNOWN_SLOWER: {recovered}"

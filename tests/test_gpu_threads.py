@@ -95,3 +95,46 @@ def test_short_lived_threads_do_not_leak_device_memory(orc, golden):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (4 << 20), f"device memory shrank by {(free0 - free1) >> 10} KiB over 150 threads"
+
+
+def test_threads_that_ran_the_chunked_host_pipelines_give_their_scratch_back(orc, golden):
+    """a host-pointer verification of 2^19 signatures and more, and a CTR call of 48 MiB and more, run on
+    library-owned per-thread streams; the launchers' scratch keyed on those streams (275 MB for a 2^18-signature chunk) must be
+    released with the streams when the thread exits -- it used to stay for the rest of the process."""
+    import threading
+
+    import numpy as np
+    import torch
+
+    from gpulib import engine
+    eng = engine()
+    hs, ss, ps = golden.bign_base_arrays()
+    nb = len(hs) // 32
+    reps = (1 << 19) // nb
+    H, S, K = hs * reps, ss * reps, ps * reps
+    key, iv = golden.H[128:160], golden.H[192:208]
+    big = np.zeros(64 << 20, dtype=np.uint8)
+    bad = []
+
+    def one():
+        eng.set_device(0)
+        code, codes = eng.bignVerify_batch(H, S, K)
+        if code != 0 or any(codes):
+            bad.append(code)
+        if eng.lib.beltCTR(big.ctypes.data_as(__import__("ctypes").c_void_p), big.ctypes.data_as(__import__("ctypes").c_void_p),
+                           __import__("ctypes").c_size_t(big.nbytes), key, __import__("ctypes").c_size_t(32), iv) != 0:
+            bad.append("ctr")
+
+    def burst(k):
+        for _ in range(k):
+            t = threading.Thread(target=one)
+            t.start()
+            t.join()
+    burst(2)                                   # tables, first-use allocations
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    burst(6)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert not bad, bad
+    assert free0 - free1 < (32 << 20), f"device memory shrank by {(free0 - free1) >> 20} MiB over 6 threads"

@@ -214,16 +214,24 @@ def test_polyhash_against_python_gf128(hs):
             if (r >> i) & 1:
                 r ^= MOD << (i - 128)
         return r
-    for n in (0, 1, 15, 16, 17, 32, 100, 1024):
-        t0, r0, data = rnd.getrandbits(128), rnd.getrandbits(128), rnd.randbytes(n)
-        t = (ctypes.c_uint32 * 4).from_buffer_copy(t0.to_bytes(16, "little"))
-        r = (ctypes.c_uint32 * 4).from_buffer_copy(r0.to_bytes(16, "little"))
-        hs.hs_polyhash(t, r, data, _sz(n))
+    # three forms of the product (host_small.hpp): 0 = what the library runs (the CPU's carry-less multiplier where it has
+    # one), 1 = table of 16 multiples of r, 2 = the bit-serial definition; sparse / dense / boundary operands included
+    specials = [0, 1, 2, 0x87, 1 << 63, 1 << 64, 1 << 127, (1 << 128) - 1, (1 << 127) | 1, 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF << 64]
+    cases = [(rnd.getrandbits(128), rnd.getrandbits(128), rnd.randbytes(n)) for n in (0, 1, 15, 16, 17, 32, 64, 65, 80, 100, 1024)]
+    cases += [(a, b, bytes(16)) for a in specials for b in specials]
+    cases += [(rnd.getrandbits(128), b, rnd.randbytes(160)) for b in specials]
+    for t0, r0, data in cases:
+        n = len(data)
         want = t0
         for off in range(0, n, 16):
             blk = data[off:off + 16]
             want = mul(want ^ int.from_bytes(blk + bytes(16 - len(blk)), "little"), r0)
-        assert int.from_bytes(bytes(t), "little") == want, n
+        for form in (0, 1, 2):
+            t = (ctypes.c_uint32 * 4).from_buffer_copy(t0.to_bytes(16, "little"))
+            r = (ctypes.c_uint32 * 4).from_buffer_copy(r0.to_bytes(16, "little"))
+            hs.hs_polyhash_form(t, r, data, _sz(n), form)
+            assert int.from_bytes(bytes(t), "little") == want, (n, form, hex(t0), hex(r0))
+    assert hs.hs_have_clmul() in (0, 1)
     # corner: the top bit of the accumulator set and r = x (a single shift with reduction)
     t = (ctypes.c_uint32 * 4).from_buffer_copy((1 << 127).to_bytes(16, "little"))
     r = (ctypes.c_uint32 * 4).from_buffer_copy((2).to_bytes(16, "little"))
