@@ -17,6 +17,7 @@
 #include "common.hpp"
 #include "host_small.hpp"
 #include "host_bign.hpp"
+#include "host_bign_ct.hpp"
 #include "bign_curves.inc"   // (#pragma once: shared with bign_kernels.hip in the unity build)
 
 namespace bee2hip {
@@ -264,7 +265,7 @@ static inline hipError_t zero_staging(void *d, size_t n)
 // finished on the host with a warning on stderr instead of abort() -- bee2's Step functions cannot report errors and a
 // long-running service must survive a transient device fault.
 enum { FORCE_AUTO = 0, FORCE_GPU = 1, FORCE_CPU = 2 };
-enum { K_PRIM = 0, K_PARALLEL = 1, K_SERIAL = 2, K_POLY = 3, K_VERIFY1 = 4 };
+enum { K_PRIM = 0, K_PARALLEL = 1, K_SERIAL = 2, K_POLY = 3, K_VERIFY1 = 4, K_SIGN1 = 5 };
 static std::atomic<int> g_force{-1};
 static std::atomic<unsigned long long> g_n_host{0}, g_n_gpu{0}, g_n_fallback{0};
 static std::atomic<int> g_inject_fail{0};                  // tests: make the next n GPU attempts of a drop-in helper fail
@@ -310,6 +311,7 @@ static bool host_wanted(int kind, size_t bytes)
     case K_PARALLEL: return bytes < 8192;       // INTEGRATION.md crossover table (CTR: 16 KiB 36 us vs 79 us on one core)
     case K_POLY: return bytes <= (hostp::gf_have_clmul() ? (size_t)32768 : (size_t)4096);   // host product: 7 ns per block with PCLMULQDQ (2.2 GB/s), 60 ns by table; a GPU call is ~30 us
     case K_VERIFY1: return true;                // one signature: ~40 us on a core vs ~0.4 ms through the GPU
+    case K_SIGN1: return true;                  // one key pair / signature: ~30 us in constant-time host arithmetic (host_bign_ct.hpp) vs ~190 us
     default: return true;                       // K_SERIAL: one message = one dependent chain
     }
 }
@@ -981,6 +983,40 @@ static err_t verify_one_host(size_t l, const octet oid_der[], size_t oid_len, co
     return hostb::verify<8>(host_curve<8>(2, BIGN256_CRANDALL_C), T, host_beltH(), oid_der, oid_len, hash, sig, pubkey);
 }
 
+// ONE key pair / public key / signature on a standard curve, on the calling core in constant-time arithmetic
+// (host_bign_ct.hpp; its header says what that covers).  BEE2HIP_FORCE=gpu keeps every secret in the GPU kernels.
+template <int N>
+static const hostct::SignCurve<N> &host_sign_curve(int which, uint64_t c)
+{
+    static hostct::SignCurve<N> S;
+    static std::once_flag once;
+    std::call_once(once, [&] { S.init(host_curve<N>(which, c)); });
+    return S;
+}
+static bool sign_on_host(const bign_params *params)
+{
+    bool standard;
+    return params_check2(params, &standard) == ERR_OK && standard && host_wanted(K_SIGN1, 1);
+}
+// -> an error code of bee2, or ERR_OUTOFMEMORY when the window table could not be built
+static err_t pubkey_calc_one_host(size_t l, bool keygen, const octet *privkey, octet *pubkey)
+{
+    if (l == 128) { const auto &S = host_sign_curve<4>(0, BIGN128_CRANDALL_C); return S.ready ? hostct::pubkey_calc<4>(S, keygen, privkey, pubkey) : ERR_OUTOFMEMORY; }
+    if (l == 192) { const auto &S = host_sign_curve<6>(1, BIGN192_CRANDALL_C); return S.ready ? hostct::pubkey_calc<6>(S, keygen, privkey, pubkey) : ERR_OUTOFMEMORY; }
+    const auto &S = host_sign_curve<8>(2, BIGN256_CRANDALL_C);
+    return S.ready ? hostct::pubkey_calc<8>(S, keygen, privkey, pubkey) : ERR_OUTOFMEMORY;
+}
+static err_t sign_one_host(size_t l, const octet oid_der[], size_t oid_len, const octet *hash, const octet *privkey, const octet *k,
+                           const void *t, size_t t_len, octet *sig)
+{
+    const hostp::BeltTables &T = hostT();
+    const octet *H = host_beltH();
+    if (l == 128) { const auto &S = host_sign_curve<4>(0, BIGN128_CRANDALL_C); return S.ready ? hostct::sign<4>(S, T, H, oid_der, oid_len, hash, privkey, k, t, t_len, sig) : ERR_OUTOFMEMORY; }
+    if (l == 192) { const auto &S = host_sign_curve<6>(1, BIGN192_CRANDALL_C); return S.ready ? hostct::sign<6>(S, T, H, oid_der, oid_len, hash, privkey, k, t, t_len, sig) : ERR_OUTOFMEMORY; }
+    const auto &S = host_sign_curve<8>(2, BIGN256_CRANDALL_C);
+    return S.ready ? hostct::sign<8>(S, T, H, oid_der, oid_len, hash, privkey, k, t, t_len, sig) : ERR_OUTOFMEMORY;
+}
+
 extern "C" err_t bignVerify(const bign_params *params, const octet oid_der[], size_t oid_len,
                             const octet hash[], const octet sig[], const octet pubkey[])
 {
@@ -1273,6 +1309,12 @@ extern "C" err_t bignPubkeyCalc(octet pubkey[], const bign_params *params, const
         const err_t pc = params_check(params);
         return pc != ERR_OK ? pc : ERR_BAD_INPUT;
     }
+    if (sign_on_host(params)) {
+        const err_t dc = device_seen();            // the library still needs its GPU (no GPU-less operation)
+        if (dc != ERR_OK) return dc;
+        g_n_host.fetch_add(1, std::memory_order_relaxed);
+        return pubkey_calc_one_host(params->l, false, privkey, pubkey);
+    }
     const err_t code = bee2hip_bignPubkeyCalc_batch(params, privkey, 1, pubkey, &one);
     return code != ERR_OK ? code : one;
 }
@@ -1303,6 +1345,14 @@ extern "C" err_t bignKeypairGen(octet privkey[], octet pubkey[], const bign_para
     if (!rand_nz_mod(d, params->p, no, rng, rng_state)) return ERR_BAD_RNG;
     // any d below 2^(2l) is multiplied, as bignMulBase does (no range check against q here)
     code = ensure_device();
+    if (code == ERR_OK && sign_on_host(params)) {
+        octet q2[128];
+        g_n_host.fetch_add(1, std::memory_order_relaxed);
+        code = pubkey_calc_one_host(params->l, true, d, q2);      // ERR_BAD_PARAMS when d G = O (bign_misc.c:214-218)
+        if (code == ERR_OK) { memcpy(privkey, d, no); memcpy(pubkey, q2, 2 * no); }
+        wipe_host(d, sizeof d);
+        return code;
+    }
     if (code == ERR_OK) {
         Scratch &s = t_scr[3];
         code = s.need(64 + 128 + 16);
@@ -1346,8 +1396,19 @@ extern "C" err_t bignSign(octet sig[], const bign_params *params, const octet oi
     octet k[64];
     if (!rand_nz_mod(k, params->q, no, rng, rng_state)) return ERR_BAD_RNG;
     err_t one = ERR_BAD_PRIVKEY;
+    if (sign_on_host(params)) {
+        code = device_seen();
+        if (code == ERR_OK) {
+            g_n_host.fetch_add(1, std::memory_order_relaxed);
+            octet out[96];
+            code = sign_one_host(params->l, oid_der, oid_len, hash, privkey, k, nullptr, 0, out);
+            if (code == ERR_OK) memcpy(sig, out, no + no / 2);
+        }
+        wipe_host(k, sizeof k);
+        return code;
+    }
     code = bee2hip_bignSignK_batch(params, oid_der, oid_len, hash, privkey, k, 1, sig, &one);
-    memset(k, 0, sizeof k);
+    wipe_host(k, sizeof k);
     return code != ERR_OK ? code : one;
 }
 extern "C" err_t bignSign2(octet sig[], const bign_params *params, const octet oid_der[], size_t oid_len, const octet hash[],
@@ -1359,6 +1420,15 @@ extern "C" err_t bignSign2(octet sig[], const bign_params *params, const octet o
     if (!hash || !privkey || !sig || (hash < sig + no + no / 2 && sig < hash + no)) return ERR_BAD_INPUT;
     if (!oid_der_valid(oid_der, oid_len)) return ERR_BAD_OID;
     err_t one = ERR_BAD_PRIVKEY;
+    if (sign_on_host(params)) {
+        code = device_seen();
+        if (code != ERR_OK) return code;
+        g_n_host.fetch_add(1, std::memory_order_relaxed);
+        octet out[96];                                   // sig may alias nothing else, but is written only on success
+        code = sign_one_host(params->l, oid_der, oid_len, hash, privkey, nullptr, t, t ? t_len : 0, out);
+        if (code == ERR_OK) memcpy(sig, out, no + no / 2);
+        return code;
+    }
     code = bee2hip_bignSign2_batch(params, oid_der, oid_len, hash, privkey, t, t_len, 1, sig, &one);
     return code != ERR_OK ? code : one;
 }

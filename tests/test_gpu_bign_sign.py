@@ -92,22 +92,34 @@ def test_golden_cases_dropin(golden, l, mulbase):
             assert rng.pos[0] == 0                    # a bad private key must not consume the generator
 
 
-@pytest.fixture(params=[0, 1, 101, 102, 4, 16, 64],
-                ids=lambda v: {0: "product_library_dispatch_by_size", 101: "1_lane_4bit_windows",
-                               102: "1_lane_6bit_complete_additions"}.get(v, f"{v}_lanes_per_scalar"))
+@pytest.fixture(params=["auto", "gpu", 1, 101, 102, 4, 16, 64],
+                ids=lambda v: {"auto": "product_library_auto_single_calls_on_the_host", "gpu": "product_library_forced_gpu",
+                               101: "1_lane_4bit_windows", 102: "1_lane_6bit_complete_additions"}.get(v, f"{v}_lanes_per_scalar"))
 def mulbase(request):
-    """k G of the signing side: one lane per scalar (bign_mulbase_ct_kernel: signed 6-bit windows and Jacobian mixed additions, the
-    throughput form; 102 = the same windows with complete additions, 101 = the round-2 form on unsigned 4-bit windows) or 4 / 16 / 64
-    lanes per scalar (bign_mulbase_coop_kernel).  0 = the PRODUCT library, which picks by batch size; every other form is forced at
-    every size through the hook of the experiments build (libbee2hip_exp.so, include/bee2hip_internal.h), default restored.
-    Yields the engine to use."""
-    if request.param == 0:
-        yield engine()
+    """Who computes k G.  "auto": the PRODUCT library as a caller gets it -- ONE key pair / signature through a drop-in symbol
+    on the calling core in constant-time host arithmetic (bee2_amd/csrc/host_bign_ct.hpp), batches on the GPU with the kernel
+    picked by batch size; "gpu": the product library under BEE2HIP_FORCE=gpu semantics (every secret in the kernels).  The
+    numbers: one GPU form FORCED at every size through the hook of the experiments build (libbee2hip_exp.so, also forced to the
+    GPU): one lane per scalar (bign_mulbase_ct_kernel: signed 6-bit windows and Jacobian mixed additions, the throughput form; 102 =
+    the same windows with complete additions, 101 = the round-2 form on unsigned 4-bit windows) or 4 / 16 / 64 lanes per scalar
+    (bign_mulbase_coop_kernel).  Yields the engine to use; defaults restored."""
+    if request.param in ("auto", "gpu"):
+        eng = engine()
+        was = eng.lib.bee2hip_path_policy(1 if request.param == "gpu" else 0)
+        before = [eng.lib.bee2hip_path_count(i) for i in range(3)]
+        yield eng
+        after = [eng.lib.bee2hip_path_count(i) for i in range(3)]
+        eng.lib.bee2hip_path_policy(was)
+        if request.param == "gpu":
+            assert after[0] == before[0], "host path taken under the forced GPU policy"
+        assert after[2] == before[2]
         return
     eng = exp_engine()
+    was = eng.lib.bee2hip_path_policy(1)
     eng.lib.bee2hip_internal_tune(10, request.param)
     yield eng
     eng.lib.bee2hip_internal_tune(10, 0)
+    eng.lib.bee2hip_path_policy(was)
 
 
 @pytest.mark.parametrize("l", [128, 192, 256])

@@ -116,6 +116,43 @@ def test_one_signature_is_verified_on_the_host_batches_never(orc, golden):
     assert _stats(L)[0] == s0[0]
 
 
+def test_one_signature_is_made_on_the_host_in_auto_mode_batches_never(orc, golden):
+    """bignSign2 / bignSign / bignPubkeyCalc / bignKeypairGen for ONE item on a standard curve: the calling core in auto
+    mode (constant-time host arithmetic, bee2_amd/csrc/host_bign_ct.hpp), the GPU kernels under BEE2HIP_FORCE=gpu -- the same
+    octets either way (the signatures are deterministic), and the batch entry point stays on the GPU even for n = 1"""
+    eng = engine()
+    L = eng.lib
+    for l in (128, 192, 256):
+        no = l // 4
+        P = eng.bignParamsStd(E.CURVE_NAME[l])
+        oid = E.LEVEL_OID[l]
+        d = bytes(orc.fill(no - 1, 0x5160 + l)) + b"\x3f"
+        h = orc.fill(no, 0x5161 + l)
+        outs = {}
+        for mode in (0, 1, 2):
+            L.bee2hip_path_policy(mode)
+            s0 = _stats(L)
+            pub = eng.bignPubkeyCalc(P, d)
+            sig = eng.bignSign2(P, oid, h, d, None)
+            sig_t = eng.bignSign2(P, oid, h, d, b"additional input " * 9)          # 153 octets: beyond the nonce kernel's 64
+            outs[mode] = (pub, sig, sig_t)
+            s1 = _stats(L)
+            assert (s1[0] - s0[0] >= 3) == (mode != 1), (l, mode, s0, s1)
+        L.bee2hip_path_policy(0)
+        assert outs[0] == outs[1] == outs[2]
+        assert outs[0][0] == orc.pubkey_calc(l, d) and outs[0][1] == orc.sign2(l, oid, h, d, None)
+        assert eng.bignLVerify(l, h, outs[0][1][1], outs[0][0][1]) == 0
+        # n = 1 through the batch entry point: GPU
+        s0 = _stats(L)
+        code, sigs, codes = eng.bignSign2_batch(P, oid, h, d, None)
+        assert code == 0 and codes == [0] and sigs == outs[0][1][1] and _stats(L)[0] == s0[0]
+        # a refused key: the reference's code from either path, nothing written
+        for mode in (0, 1):
+            L.bee2hip_path_policy(mode)
+            assert eng.bignPubkeyCalc(P, bytes(no))[0] == 504 and eng.bignSign2(P, oid, h, bytes(no), None)[0] == 504
+        L.bee2hip_path_policy(0)
+
+
 def test_device_fault_is_retried_then_finished_on_the_host(orc):
     eng = exp_engine()          # fault injection is a hook of the experiments build (bee2hip_internal_tune 5)
     L = eng.lib

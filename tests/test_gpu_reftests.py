@@ -58,12 +58,7 @@ def test_reference_test_suite_passes_through_the_dropin():
 # "Known regressions of single calls" with its reason); everything else must be at least level (10 % measurement slack).
 # The test fails when a line NOT listed here is slower -- and also when a listed line stopped being slower, so that the
 # list cannot outlive its reasons.
-KNOWN_SLOWER = {
-    # bee2's loop makes ONE call per iteration; the private / one-time key never leaves the constant-time GPU kernels for the
-    # two wider curves (one launch chain per call: ~0.3-0.5 ms), and key generation adds the caller's rng on the host
-    "bign192Bench::KeypairGen", "bign192Bench::Sign", "bign192Bench::Sign2",
-    "bign256Bench::KeypairGen", "bign256Bench::Sign", "bign256Bench::Sign2",
-}
+KNOWN_SLOWER = set()       # round 4: none (single signatures and key pairs moved to the constant-time host path)
 BENCH_LINE = re.compile(r"^(\w+Bench::[\w-]+):\s+(\d+) ([\w/]+) \[\s*(\d+) ([\w/]+)\]", re.M)
 
 
