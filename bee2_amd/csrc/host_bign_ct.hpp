@@ -44,7 +44,18 @@ using hostb::Aff;
 constexpr uint32_t kOk = 0, kBadRng = 304, kBadParams = 502, kBadPrivkey = 504;      // include/bee2/core/err.h
 
 // ---- masks -------------------------------------------------------------------------------------------------------
-static inline uint64_t m_zero(uint64_t x) { return (uint64_t)0 - ((~x & (x - 1)) >> 63); }      // all-ones iff x == 0
+// The optimiser must not know that a mask is 0 or all-ones: clang -O3 turns "x + (c & -carry)" into "if (carry) x += c" -- a
+// branch on secret data (found by tools/ct_audit_x86.py: `jae` after the adds of reduce / add / sub).  An empty asm that
+// claims to modify the value hides its origin; every mask is made through it.
+static inline uint64_t m_hide(uint64_t x)
+{
+#if defined(__GNUC__) || defined(__clang__)
+    __asm__("" : "+r"(x));
+#endif
+    return x;
+}
+static inline uint64_t m_bit(uint64_t bit01) { return m_hide((uint64_t)0 - bit01); }            // 0 / 1 -> 0 / all-ones
+static inline uint64_t m_zero(uint64_t x) { return m_bit((~x & (x - 1)) >> 63); }               // all-ones iff x == 0
 static inline uint64_t m_eq(uint64_t a, uint64_t b) { return m_zero(a ^ b); }
 static inline uint64_t m_sel(uint64_t m, uint64_t a, uint64_t b) { return b ^ (m & (a ^ b)); }  // m ? a : b
 // a wipe the optimiser may not drop
@@ -70,7 +81,7 @@ template <int N> static inline uint64_t m_lt(const uint64_t (&a)[N], const uint6
         const u128 d = (u128)a[i] - b[i] - borrow;
         borrow = (uint64_t)(d >> 64) & 1;
     }
-    return (uint64_t)0 - borrow;
+    return m_bit(borrow);
 }
 
 // ---- GF(p), p = 2^(64 N) - c.  Values are kept WEAKLY reduced: any N-limb number (the class mod p); canon() at the end.
@@ -87,7 +98,7 @@ struct FieldCt {
         for (int i = 0; i < N; ++i) { const u128 s = (u128)a.v[i] + b.v[i] + carry; t[i] = (uint64_t)s; carry = (uint64_t)(s >> 64); }
         // 2^(64 N) = c (mod p): the carry comes back as + c; that can wrap once more (then what is left is below c)
         for (int pass = 0; pass < 2; ++pass) {
-            u128 s = (u128)t[0] + (c & ((uint64_t)0 - carry));
+            u128 s = (u128)t[0] + (c & m_bit(carry));
             t[0] = (uint64_t)s;
             uint64_t k = (uint64_t)(s >> 64);
             for (int i = 1; i < N; ++i) { s = (u128)t[i] + k; t[i] = (uint64_t)s; k = (uint64_t)(s >> 64); }
@@ -100,7 +111,7 @@ struct FieldCt {
         uint64_t t[N], borrow = 0;
         for (int i = 0; i < N; ++i) { const u128 d = (u128)a.v[i] - b.v[i] - borrow; t[i] = (uint64_t)d; borrow = (uint64_t)(d >> 64) & 1; }
         for (int pass = 0; pass < 2; ++pass) {       // - 2^(64 N) = - c (mod p)
-            u128 d = (u128)t[0] - (c & ((uint64_t)0 - borrow));
+            u128 d = (u128)t[0] - (c & m_bit(borrow));
             t[0] = (uint64_t)d;
             uint64_t k = (uint64_t)(d >> 64) & 1;
             for (int i = 1; i < N; ++i) { d = (u128)t[i] - k; t[i] = (uint64_t)d; k = (uint64_t)(d >> 64) & 1; }
@@ -127,7 +138,7 @@ struct FieldCt {
         r.v[0] = (uint64_t)m;
         uint64_t k = (uint64_t)(m >> 64);
         for (int i = 1; i < N; ++i) { const u128 s = (u128)r.v[i] + k; r.v[i] = (uint64_t)s; k = (uint64_t)(s >> 64); }
-        m = (u128)r.v[0] + (c & ((uint64_t)0 - k));     // wrapped once more: what is left is below c^2, + c cannot wrap
+        m = (u128)r.v[0] + (c & m_bit(k));               // wrapped once more: what is left is below c^2, + c cannot wrap
         r.v[0] = (uint64_t)m;
         k = (uint64_t)(m >> 64);
         for (int i = 1; i < N; ++i) { const u128 s = (u128)r.v[i] + k; r.v[i] = (uint64_t)s; k = (uint64_t)(s >> 64); }
@@ -182,7 +193,7 @@ struct FieldCt {
         u128 w = (u128)a.v[0] + c;
         s[0] = (uint64_t)w;
         for (int i = 1; i < N; ++i) { w = (u128)a.v[i] + (uint64_t)(w >> 64); s[i] = (uint64_t)w; }
-        const uint64_t ge = (uint64_t)0 - (uint64_t)(w >> 64);
+        const uint64_t ge = m_bit((uint64_t)(w >> 64));
         for (int i = 0; i < N; ++i) r.v[i] = m_sel(ge, s[i], a.v[i]);
     }
     // a^(p - 2): the exponent is public (2^(64 N) - c - 2), so its windows may steer the code; 0 -> 0
@@ -314,7 +325,7 @@ struct SignCurve {
             kk[N - 1] >>= 6;
             carry = (t + 32u) >> 6;                                         // 1 iff t >= 32
             const uint64_t d = t - (carry << 6);                            // the digit, two's complement, -32 .. 31
-            const uint64_t neg = (uint64_t)((int64_t)d >> 63);
+            const uint64_t neg = m_hide((uint64_t)((int64_t)d >> 63));
             const uint64_t mag = (d ^ neg) - neg;                           // 0 .. 32
             // the whole row, every time: the addresses depend on w only
             const Aff<N> *row = tab6 + (size_t)w * 32;
@@ -379,7 +390,7 @@ struct SignCurve {
         }
         uint64_t s[N], borrow = 0;
         for (int i = 0; i < N; ++i) { const u128 d = (u128)a[i] - q[i] - borrow; s[i] = (uint64_t)d; borrow = (uint64_t)(d >> 64) & 1; }
-        const uint64_t lt = (uint64_t)0 - borrow;       // a < q: keep a
+        const uint64_t lt = m_bit(borrow);              // a < q: keep a
         for (int i = 0; i < N; ++i) r[i] = m_sel(lt, a[i], s[i]);
         wipe(a, sizeof a); wipe(t, sizeof t); wipe(s, sizeof s);
     }
@@ -388,7 +399,7 @@ struct SignCurve {
     {
         uint64_t t[N], borrow = 0;
         for (int i = 0; i < N; ++i) { const u128 d = (u128)a[i] - b[i] - borrow; t[i] = (uint64_t)d; borrow = (uint64_t)(d >> 64) & 1; }
-        const uint64_t m = (uint64_t)0 - borrow;
+        const uint64_t m = m_bit(borrow);
         uint64_t carry = 0;
         for (int i = 0; i < N; ++i) { const u128 s = (u128)t[i] + (q[i] & m) + carry; c[i] = (uint64_t)s; carry = (uint64_t)(s >> 64); }
         wipe(t, sizeof t);

@@ -58,6 +58,15 @@ void hc_field(size_t l, int op, uint64_t *r, const uint64_t *a, const uint64_t *
     if (l == 128) HC_DO(4, BIGN128_CRANDALL_C) else if (l == 192) HC_DO(6, BIGN192_CRANDALL_C) else HC_DO(8, BIGN256_CRANDALL_C)
 #undef HC_DO
 }
+// cycles (rdtsc) of ONE k G with its range check and output, for tools/ct_audit_x86.py's timing comparison of key classes
+uint64_t hc_time_pubkey_calc(size_t l, const uint8_t *priv, uint8_t *pub)
+{
+    unsigned lo, hi, lo2, hi2;
+    __asm__ volatile("lfence\n rdtsc" : "=a"(lo), "=d"(hi) :: "memory");
+    (void)hc_pubkey_calc(l, 1, priv, pub);
+    __asm__ volatile("lfence\n rdtsc" : "=a"(lo2), "=d"(hi2) :: "memory");
+    return (((uint64_t)hi2 << 32) | lo2) - (((uint64_t)hi << 32) | lo);
+}
 // x mod q for a 2N-limb x
 void hc_mod_q(size_t l, uint64_t *r, const uint64_t *x)
 {

@@ -168,3 +168,21 @@ def test_sign2_random_against_the_oracle(hc, orc, l):
         sig = ctypes.create_string_buffer(sg)
         assert hc.hc_sign(_sz(l), oid, _sz(len(oid)), h, d, None, t, _sz(len(t) if t else 0), sig) == 0
         assert (0, sig.raw) == orc.sign2(l, oid, h, d, t), i
+
+
+def test_compiled_arithmetic_has_no_branch_on_data():
+    """tools/ct_audit_x86.py, machine-checked part: in the object the PRODUCT's host compiler makes (hipcc's clang, -O3) the
+    functions that see secrets -- FieldCt add / sub / mul / sqr / reduce / canon / inv, jac_madd, mul_base, mod_q, sub_mod_q --
+    contain nothing but loop back-edges and the windows of the public exponent p - 2: no forward conditional jump, no jump on
+    the carry flag.  (clang -O3 had turned `x + (c & -carry)` into `if (carry) x += c` until the masks were hidden from it:
+    host_bign_ct.hpp m_hide.)  With g++ -O2 -- what the tests above ran -- no jump on the carry / overflow flag."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ct_audit_x86", os.path.join(ROOT, "tools", "ct_audit_x86.py"))
+    audit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(audit)
+    bad, seen = audit.violations(0)
+    if bad is None:
+        pytest.skip("the ROCm clang is not installed here")
+    assert seen >= 18 and not bad, "\n".join(bad)
+    bad, seen = audit.violations(1, carry_only=True)
+    assert bad is not None and seen >= 12 and not bad, "\n".join(bad)
