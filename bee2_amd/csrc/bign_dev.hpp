@@ -465,6 +465,11 @@ template <int N> struct SafeGcd {
         return x & 0x3FFFFFFFu;
     }
     static constexpr int MAX_ITER = (32 * N * 24 / 10 + 60) / 30;   // generous; the g == 0 test ends the loop
+    // the constant-time callers run a FIXED number of iterations: the proven bound of the half-delta variant for b-bit inputs,
+    // (45907 b + 26313) / 19929 division steps (592 / 886 / 1181 rounded up), in batches of 30: 20 / 30 / 40 iterations
+    // (round 4: was MAX_ITER = 22 / 32 / 42; the Z Z^-1 = 1 check of the callers would report a shortfall loudly)
+    static constexpr int CT_ITER = ((45907 * 32 * N + 26313 + 19928) / 19929 + 29) / 30;
+    static_assert(CT_ITER <= MAX_ITER && CT_ITER * 30 >= (45907 * 32 * N + 26313) / 19929 + 1, "division-step bound");
 };
 
 // 30 division steps on the low limbs; returns the new zeta = -(delta + 1/2), matrix t = (u v; q r) with
@@ -489,7 +494,7 @@ __device__ __forceinline__ int32_t sg_divsteps_30(int32_t zeta, uint32_t f, uint
 
 // a^-1 mod p for canonical a (0 -> 0); no fallback.  CT = true: no early exit -- all MAX_ITER iterations run whatever
 // the value (the bound of the half-delta variant, (45907 b + 26313) / 19929 division steps for b-bit inputs: 590 / 886 /
-// 1181 for the three curves, is below 30 MAX_ITER = 660 / 960 / 1260), and nothing else in the function depends on
+// 1181 for the three curves, is below 30 CT_ITER = 600 / 900 / 1200), and nothing else in the function depends on
 // the data (masks only): the form the signing kernels use on secret Z coordinates.
 template <int N, bool CT = false>
 __device__ __noinline__ feT<N> fe_inv_safegcd(feT<N> a)
@@ -508,7 +513,7 @@ __device__ __noinline__ feT<N> fe_inv_safegcd(feT<N> a)
     }
     int32_t zeta = -1;
 #pragma unroll 1
-    for (int it = 0; it < SG::MAX_ITER; ++it) {
+    for (int it = 0; it < (CT ? SG::CT_ITER : SG::MAX_ITER); ++it) {
         if (!CT) {
             int32_t nz = 0;
 #pragma unroll

@@ -921,15 +921,20 @@ void bign_gtable16_kernel(const uint4 *__restrict__ gtab8, uint4 *__restrict__ g
 // index i * 32 + j - 1; W6 = ceil((32N + 1) / 6) windows (43 / 65 / 86), the last one takes what is left of the scalar
 // plus the carry of the recoding (at most 16 / 1 / 4).  From the seed table: j 2^(6i) = lo 2^(8a) + hi 2^(8a + 8); the one
 // multiple outside it that a digit can ask for is 2^(32N) G = 2 (128 2^(32N - 8) G).  Entries no digit reaches are zero.
+// (round 4) WB = 7: the same with signed 7-bit windows -- 64 entries per window, ceil((32N + 1) / 7) windows (37 on the 256-bit
+// curve, whose top window starts at bit 252 like the 6-bit one's) -- for the kernel that looks its entry up in LDS
+// (bign_mulbase_lds_kernel): the row size no longer costs a masked scan there, so fewer, wider windows pay.
 template <int N> struct Win6 { static constexpr int W = (32 * N + 1 + 5) / 6; };
-template <int N>
+template <int N, int WB> struct WinW { static constexpr int W = (32 * N + 1 + WB - 1) / WB, ENT = 1 << (WB - 1); };
+template <int N, int WB = 6>
 __global__ __launch_bounds__(64)
 void bign_gtable6_kernel(const uint4 *__restrict__ gtab8, uint4 *__restrict__ gtab6)
 {
+    constexpr int ENT = WinW<N, WB>::ENT;
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= Win6<N>::W * 32) return;
-    const int i = id / 32, j = id % 32 + 1;
-    const int a = (6 * i) >> 3, r = (6 * i) & 7;
+    if (id >= WinW<N, WB>::W * ENT) return;
+    const int i = id / ENT, j = id % ENT + 1;
+    const int a = (WB * i) >> 3, r = (WB * i) & 7;
     const int v = j << r, part[2] = {v & 255, v >> 8};
     uint4 *e = gtab6 + (size_t)id * (N / 2);
     jacT<N> T, E;
@@ -1109,6 +1114,7 @@ struct BignDevice {
     uint4 *gtab8[3] = {nullptr, nullptr, nullptr};     // 8-bit seed table per curve (index N/4 - 2): 4N x 256 affine points
     uint4 *gtab[3] = {nullptr, nullptr, nullptr};      // 16-bit comb table per curve, built from the seed table
     uint4 *gtab6[3] = {nullptr, nullptr, nullptr};     // signed 6-bit windows (signing side, one lane per scalar)
+    uint4 *gtab7[3] = {nullptr, nullptr, nullptr};     // signed 7-bit windows (signing side, LDS look-up kernel: 256-bit curve)
 };
 static BignDevice g_bign[64];
 static std::mutex g_bign_mu;          // table construction is per device, shared by threads
@@ -1166,6 +1172,30 @@ static err_t bign_table6(const uint32_t **out8, const uint32_t **out6, hipStream
     }
     *out8 = reinterpret_cast<const uint32_t *>(t8);
     *out6 = reinterpret_cast<const uint32_t *>(slot);
+    return ERR_OK;
+}
+
+// the signed 7-bit table (148 KiB on the 256-bit curve), made from the seed table like the 6-bit one
+template <int N>
+static err_t bign_table7(const uint32_t **out7, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_bign_mu);
+    uint4 *t8 = nullptr;
+    err_t code = bign_table8_locked<N>(&t8, st);
+    if (code != ERR_OK) return code;
+    int dev = 0;
+    B2H_TRY(hipGetDevice(&dev));
+    uint4 *&slot = g_bign[dev].gtab7[N / 4 - 2];
+    if (!slot) {
+        uint4 *t7 = nullptr;
+        const size_t entries = (size_t)WinW<N, 7>::W * WinW<N, 7>::ENT;
+        if (hipMalloc((void **)&t7, entries * 8 * N) != hipSuccess) { (void)hipGetLastError(); return ERR_OUTOFMEMORY; }
+        hipLaunchKernelGGL((bign_gtable6_kernel<N, 7>), dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, st, (const uint4 *)t8, t7);
+        B2H_TRY(hipGetLastError());
+        B2H_TRY(hipStreamSynchronize(st));
+        slot = t7;
+    }
+    *out7 = reinterpret_cast<const uint32_t *>(slot);
     return ERR_OK;
 }
 

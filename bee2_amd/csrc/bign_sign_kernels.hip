@@ -31,6 +31,7 @@
 // profiles/r02_sign_ct_audit.txt lists every conditional branch of these kernels with what it tests.
 //
 // Kernels: pubkey calc = mulbase<CHECK_D>;  sign2 = nonce -> mulbase -> tail;  sign with given k = kcheck -> mulbase -> tail.
+#include <mutex>
 #include "belt_dev.hpp"
 #include "bign_dev.hpp"
 #include "common.hpp"
@@ -346,6 +347,102 @@ __device__ __forceinline__ uint32_t mul_base_ct6(feT<N> &x, feT<N> &y, const uin
     }
 }
 
+// ---- the same multiplication with the window's entry LOOKED UP in LDS (round 4) ---------------------------------------------
+// The masked scan above costs one full-rate VALU op per table word per entry: 512 + 96 of the ~3 800 instructions of a
+// window, and it is what kept the windows at 6 bits.  Here the 1024 lanes of a workgroup walk the windows together and the
+// window's row sits in LDS in 32 copies, copy r holding its 64-bit words at byte address (word * 32 + r) * 8: lane l reads
+// words (entry * N + i) of copy l mod 32, i.e. ALWAYS the two banks 2 (l mod 32), 2 (l mod 32) + 1 of the 64
+// (ds_read_b64: lane groups {0-31}, {32-63}, bank = (a / 4) mod 64, MI355X_MICROARCH.md LDS table).  Whatever the secret
+// entry numbers are, the 32 lanes of a group hit 32 disjoint bank pairs: no conflict, the same LDS cycles for every scalar --
+// the argument of the bank-private belt tables (belt_dev.hpp), with SQ_LDS_BANK_CONFLICT = 0 to show for it
+// (profiles/r04_sign_lds.txt).  A row of 2^(WB-1) entries x 8N octets x 32 copies must fit the CU's 160 KiB: signed 7-bit
+// windows on the 256-bit curve (64 entries: 128 KiB, one workgroup of 1024 lanes = 4 wavefronts per SIMD, 37 additions instead
+// of 43).  Per window: barrier, 16 broadcast loads + ds_write_b64 per lane to refill the row (addresses depend on the window
+// and the lane only), barrier, N ds_read_b64 -- ~60 instructions where the scan took ~730.  Digits, negation, the masked
+// Jacobian addition and the schedule argument are those of mul_base_ct6<N, true>: digits t - 128 [t >= 64] in [-64, 63],
+// |A| <= 64 (128^w - 1) / 127 < 128^w before window w, and the top window starts at bit 252 exactly as with 6-bit windows.
+template <int N, int WB>
+__device__ __forceinline__ uint32_t mul_base_ct_lds(feT<N> &x, feT<N> &y, const uint32_t (&k)[N], const uint64_t *__restrict__ tabw,
+                                                    uint64_t *s_row)
+{
+    constexpr int W = WinW<N, WB>::W, ENT = WinW<N, WB>::ENT, QW = ENT * N;       // 64-bit words of a row
+    static_assert(QW * 32 % 1024 == 0, "the refill is written for 1024 lanes");
+    const unsigned tid = threadIdx.x, rep = tid & 31u;
+    uint32_t kk[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) kk[i] = k[i];
+    jacT<N> J;
+    fe_set_zero(J.X); fe_set_one(J.Y); fe_set_zero(J.Z);
+    uint32_t at_inf = ~0u;
+    feT<N> one;
+    fe_set_one(one);
+    uint32_t carry = 0;
+#pragma unroll 1
+    for (int w = 0; w < W; ++w) {
+        __syncthreads();                                                // every lane is through with the previous row
+        {
+            const uint64_t *row = tabw + (size_t)w * QW;
+#pragma unroll
+            for (int i = 0; i < QW * 32 / 1024; ++i) {
+                const unsigned q = (tid >> 5) + 32u * i;                // the 32 lanes of a copy-group fetch the same word
+                s_row[q * 32u + rep] = row[q];
+            }
+        }
+        __syncthreads();
+        const uint32_t t = (kk[0] & (uint32_t)(2 * ENT - 1)) + carry;   // 0 .. 2 ENT
+#pragma unroll
+        for (int i = 0; i < N - 1; ++i) kk[i] = __builtin_amdgcn_alignbit(kk[i + 1], kk[i], WB);
+        kk[N - 1] >>= WB;
+        carry = (t + (uint32_t)ENT) >> WB;                              // 1 iff t >= ENT
+        const uint32_t d = t - (carry << WB);                           // two's complement of the digit
+        const uint32_t neg = (uint32_t)((int32_t)d >> 31);
+        const uint32_t mag = (d ^ neg) - neg;                           // 0 .. ENT
+        const uint32_t e = (mag - 1u) & (uint32_t)(ENT - 1);            // digit 0 reads entry ENT: looked up, added, not used
+        affT<N> E;
+#pragma unroll
+        for (int l = 0; l < N / 2; ++l) {
+            const uint64_t vx = s_row[(e * N + l) * 32u + rep], vy = s_row[(e * N + N / 2 + l) * 32u + rep];
+            E.x.v[2 * l] = (uint32_t)vx; E.x.v[2 * l + 1] = (uint32_t)(vx >> 32);
+            E.y.v[2 * l] = (uint32_t)vy; E.y.v[2 * l + 1] = (uint32_t)(vy >> 32);
+        }
+        feT<N> ny;
+        fe_neg(ny, E.y);
+#pragma unroll
+        for (int l = 0; l < N; ++l) E.y.v[l] = ct_sel(neg, ny.v[l], E.y.v[l]);
+        const uint32_t keep = ct_eq_small(mag, 0u);
+        jacT<N> sum = J;
+        jac_madd_ct(sum, E);                                            // digit 0 or accumulator still O: computed, not used
+        const uint32_t set = at_inf & ~keep;                            // first non-zero digit: J <- (x, y, 1)
+#pragma unroll
+        for (int l = 0; l < N; ++l) {
+            J.X.v[l] = ct_sel(keep, J.X.v[l], ct_sel(set, E.x.v[l], sum.X.v[l]));
+            J.Y.v[l] = ct_sel(keep, J.Y.v[l], ct_sel(set, E.y.v[l], sum.Y.v[l]));
+            J.Z.v[l] = ct_sel(keep, J.Z.v[l], ct_sel(set, one.v[l], sum.Z.v[l]));
+        }
+        at_inf &= keep;
+    }
+    // x = X / Z^2, y = Y / Z^3; Z = 0 (or nothing ever added: k = 0) is the point at infinity
+#pragma unroll
+    for (int l = 0; l < N; ++l) J.Z.v[l] &= ~at_inf;
+    feT<N> zc;
+    fe_canon(zc, J.Z);
+    const feT<N> zi = fe_inv_safegcd<N, true>(zc);
+    feT<N> chk, zi2;
+    fe_mul(chk, zc, zi);
+    fe_canon(chk, chk);
+    chk.v[0] ^= 1u;                                                     // 0 iff Z * Z^-1 == 1
+    fe_sqr(zi2, zi);
+    fe_mul(x, J.X, zi2);
+    fe_mul(zi2, zi2, zi);
+    fe_mul(y, J.Y, zi2);
+    fe_canon(x, x);
+    fe_canon(y, y);
+    const uint32_t inf = ct_is_zero(zc.v) | ~ct_is_zero(chk.v);
+#pragma unroll
+    for (int l = 0; l < N; ++l) { x.v[l] &= ~inf; y.v[l] &= ~inf; }
+    return inf;
+}
+
 template <int N>
 __device__ __forceinline__ void load_words_bytes(uint32_t (&r)[N], const uint8_t *p)
 {
@@ -541,6 +638,40 @@ void bign_mulbase_ct_kernel(const uint8_t *__restrict__ scalars, size_t n, uint3
     if constexpr (FORM == 2) inf = mul_base_ct6<N, true>(x, y, k, gtab8);
     else if constexpr (FORM == 1) inf = mul_base_ct6<N, false>(x, y, k, gtab8);
     else inf = mul_base_ct(x, y, k, gtab8);
+    if (MODE == 2) {
+        valid = ~inf;
+        codes[idx] = ct_sel(inf, (uint32_t)ERR_BAD_PARAMS, (uint32_t)ERR_OK);
+    }
+    uint32_t *o = reinterpret_cast<uint32_t *>(xy_out + (size_t)(X_ONLY ? NO : 2 * NO) * idx);
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = x.v[i] & valid;
+    if (!X_ONLY) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[N + i] = y.v[i] & valid;
+    }
+}
+
+// the LDS look-up form: modes and outputs as bign_mulbase_ct_kernel; blocks of 1024 lanes, all of which walk the windows
+// (a lane beyond n multiplies by 0 and writes nothing: the barriers need every lane)
+template <int N, int WB>
+__global__ __launch_bounds__(1024)
+void bign_mulbase_lds_kernel(const uint8_t *__restrict__ scalars, size_t n, uint32_t *__restrict__ codes,
+                             uint8_t *__restrict__ xy_out, const uint64_t *__restrict__ tabw, const int MODE, const int X_ONLY)
+{
+    constexpr int NO = 4 * N;
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_row_dyn[];
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = idx < n;                       // public
+    uint32_t k[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) k[i] = 0;
+    if (live) load_words_bytes(k, scalars + NO * idx);
+    uint32_t valid = ~0u;
+    if (MODE == 1) valid = ct_in_range_q(k);
+    feT<N> x, y;
+    const uint32_t inf = mul_base_ct_lds<N, WB>(x, y, k, tabw, s_row_dyn);
+    if (!live) return;
+    if (MODE == 1) codes[idx] = ct_sel(valid, (uint32_t)ERR_OK, ERR_BAD_PRIVKEY_V);
     if (MODE == 2) {
         valid = ~inf;
         codes[idx] = ct_sel(inf, (uint32_t)ERR_BAD_PARAMS, (uint32_t)ERR_OK);
@@ -892,11 +1023,36 @@ static err_t sign_scratch(hipStream_t st, size_t n, SignScratch &S)
 // (profiles/r03_sign_coop.txt): 64 lanes up to 2^10 scalars, 16 up to 2^13, 4 up to 2^15, one lane above.
 static int g_sign_lanes = 0;
 void set_sign_coop(int v) { g_sign_lanes = v; }
+// (round 4) 7 = one lane per scalar with the window's entry looked up in LDS (bign_mulbase_lds_kernel: 256-bit curve only,
+// workgroups of 1024 lanes): from 2^18 scalars on -- one workgroup for each of the 256 CUs; below that the 256-lane
+// blocks of the scanning kernel spread better
+constexpr size_t MULBASE_LDS_MIN = (size_t)1 << 18;
+template <int N>
 static inline int mulbase_lanes(size_t n)
 {
     if (g_sign_lanes == 1 || g_sign_lanes == 4 || g_sign_lanes == 16 || g_sign_lanes == 64 || g_sign_lanes == 101 || g_sign_lanes == 102)
         return g_sign_lanes;
+    if (N == 8 && (g_sign_lanes == 7 || (g_sign_lanes == 0 && n >= MULBASE_LDS_MIN))) return 7;
     return n <= ((size_t)1 << 10) ? 64 : n <= ((size_t)1 << 13) ? 16 : n <= ((size_t)1 << 15) ? 4 : 1;
+}
+// the table the chosen form reads: the signed 7-bit one for form 7, the signed 6-bit one otherwise (`tab6` of launch_mulbase)
+template <int N>
+static err_t mulbase_tables(int lanes, const uint32_t **tab, const uint32_t **tabw, hipStream_t st)
+{
+    err_t code = bign_table6<N>(tab, tabw, st);
+    if (code == ERR_OK && lanes == 7) {
+        code = bign_table7<N>(tabw, st);
+        if (code == ERR_OK) {
+            static std::once_flag once[64];
+            hipError_t e = hipSuccess;
+            std::call_once(once[cur_dev() & 63], [&] {
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(bign_mulbase_lds_kernel<8, 7>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WinW<8, 7>::ENT * 8 * 32 * 8));
+            });
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(bign_mulbase_lds_kernel)");
+        }
+    }
+    return code;
 }
 // lanes: 64 / 16 / 4 = cooperative forms on the 4-bit windows of the seed table; 1 = one lane per scalar, signed 6-bit windows
 // (tab6), Jacobian mixed additions; 102 = the same windows with complete additions; 101 = one lane per scalar on the 4-bit
@@ -915,6 +1071,14 @@ static void launch_mulbase(int lanes, const uint8_t *scalars, size_t n, uint32_t
     else if (lanes == 102)
         hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 1>), g256, dim3(256), 0, st, scalars, n, codes, out, tab6, MODE, (int)X_ONLY);
 #endif
+    else if (lanes == 7) {
+        // 256-bit curve, batches that give every CU a workgroup of 1024 lanes: signed 7-bit windows looked up in LDS (tab6 = that table)
+        if constexpr (N == 8) {
+            constexpr size_t lds = (size_t)WinW<N, 7>::ENT * N * 32 * 8;
+            hipLaunchKernelGGL((bign_mulbase_lds_kernel<N, 7>), dim3((unsigned)((n + 1023) / 1024)), dim3(1024), lds, st, scalars, n, codes,
+                               out, reinterpret_cast<const uint64_t *>(tab6), MODE, (int)X_ONLY);
+        }
+    }
     else
         hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 2>), g256, dim3(256), 0, st, scalars, n, codes, out, tab6, MODE, (int)X_ONLY);
 }
@@ -923,12 +1087,13 @@ template <int N>
 static err_t launch_bign_pubkey_calc_t(bool keygen, const void *d_privkeys, size_t n, void *d_pubkeys, void *d_codes, hipStream_t st)
 {
     const uint32_t *tab = nullptr, *tab6 = nullptr;
-    err_t code = bign_table6<N>(&tab, &tab6, st);
+    const int lanes = mulbase_lanes<N>(n);
+    err_t code = mulbase_tables<N>(lanes, &tab, &tab6, st);
     if (code != ERR_OK) return code;
     if (!keygen)
-        launch_mulbase<N, 1, false>(mulbase_lanes(n), (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab, tab6, st);
+        launch_mulbase<N, 1, false>(lanes, (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab, tab6, st);
     else
-        launch_mulbase<N, 2, false>(mulbase_lanes(n), (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab, tab6, st);
+        launch_mulbase<N, 2, false>(lanes, (const uint8_t *)d_privkeys, n, (uint32_t *)d_codes, (uint8_t *)d_pubkeys, tab, tab6, st);
     B2H_TRY(hipGetLastError());
     return ERR_OK;
 }
@@ -965,7 +1130,8 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
     err_t code = make_oid_arg(oa, oid_der, oid_len, st);
     if (code != ERR_OK) return code;
     const uint32_t *tab = nullptr, *tab6 = nullptr;
-    code = bign_table6<N>(&tab, &tab6, st);
+    const int lanes = mulbase_lanes<N>(n);
+    code = mulbase_tables<N>(lanes, &tab, &tab6, st);
     if (code != ERR_OK) return code;
     SignScratch S;
     code = sign_scratch<N>(st, n, S);
@@ -996,7 +1162,7 @@ static err_t launch_bign_sign_t(int mode, const uint8_t *oid_der, size_t oid_len
         B2H_TRY(hipMemcpyAsync(S.k, d_aux, n * 4 * N, hipMemcpyDeviceToDevice, st));
         kptr = S.k;
     }
-    launch_mulbase<N, 0, true>(mulbase_lanes(n), kptr, n, (uint32_t *)nullptr, S.rx, tab, tab6, st);
+    launch_mulbase<N, 0, true>(lanes, kptr, n, (uint32_t *)nullptr, S.rx, tab, tab6, st);
     {
         const uint32_t rw = sign_row_words(oa.len + 8 * N);
         const int wg = sign_wg(n, rw);

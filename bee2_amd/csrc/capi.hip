@@ -2522,8 +2522,15 @@ extern "C" err_t bee2hip_hash_ragged_dev(size_t alg, const void *d_data, const v
     return bee2hip_hash_ragged_ordered_dev(alg, d_data, d_offsets, nullptr, n, d_digests, stream);
 }
 
+static err_t hash_ragged_host(size_t alg, const octet *data, const uint64_t *offsets, size_t n, octet *digests);
 extern "C" err_t bee2hip_hash_ragged(size_t alg, const octet *data, const uint64_t *offsets, size_t n,
                                      octet *digests)
+{
+    try { return hash_ragged_host(alg, data, offsets, n, digests); }
+    catch (const std::bad_alloc &) { return ERR_OUTOFMEMORY; }             // nothing may unwind through the C ABI
+    catch (...) { return hip_fail(hipErrorUnknown, "bee2hip_hash_ragged: exception"); }
+}
+static err_t hash_ragged_host(size_t alg, const octet *data, const uint64_t *offsets, size_t n, octet *digests)
 {
     if (alg != 0 && alg != 128 && alg != 192 && alg != 256) return ERR_BAD_PARAMS;
     if (n == 0) return ERR_OK;
@@ -2540,6 +2547,66 @@ extern "C" err_t bee2hip_hash_ragged(size_t alg, const octet *data, const uint64
     std::stable_sort(ord.begin(), ord.end(), [offsets](uint32_t a, uint32_t b) {
         return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b];
     });
+    // A message is ONE dependent chain: a GPU lane (pair) walks it at ~0.12-0.15 us per octet, a host core at ~0.008.  When a
+    // few messages are far longer than the rest the batch would wait for their chains (a 256 KiB message: 30-40 ms; a 1 GiB
+    // file: minutes) with the device otherwise idle, so this HOST-pointer entry -- the data is in host memory anyway --
+    // hands the K longest messages to host threads (host_small.hpp, as the drop-in beltHash / bashHash of one message
+    // does) while the GPU takes the rest.  K balances the two sides: it grows while the host threads would finish before
+    // the GPU's longest remaining chain.  The device-pointer entries never do this.  BEE2HIP_FORCE=gpu: K = 0.
+    size_t K = 0;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t T = std::min<size_t>(hw ? hw : 1, 16);
+    if (force_mode() != FORCE_GPU && n >= 2) {
+        const double c_host = (alg ? 5.0e-9 : 8.4e-9) / (double)T, c_gpu = alg ? 4.0e-8 : 1.2e-7;    // seconds per octet (bench.py ragged leg)
+        double host_s = 0;
+        while (K + 1 < n) {
+            const double len_k = (double)(offsets[ord[K] + 1] - offsets[ord[K]]), len_next = (double)(offsets[ord[K + 1] + 1] - offsets[ord[K + 1]]);
+            if (len_k < 65536.0) break;                                   // chains under ~8 ms are the GPU's
+            if (host_s + len_k * c_host > len_k * c_gpu) break;           // the host side would become the longer one
+            host_s += len_k * c_host;
+            ++K;
+            if (len_next * c_gpu <= host_s) break;                         // the GPU's longest remaining chain is already shorter
+        }
+    }
+    std::vector<octet> hdig(K * dlen);
+    std::vector<std::thread> workers;
+    std::atomic<size_t> next{0};
+    const auto host_job = [&] {
+        const hostp::BeltTables &HT = hostT();
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= K) return;
+            const size_t i = ord[k];
+            const octet *m = data + offsets[i];
+            const size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+            octet *out = hdig.data() + k * dlen;
+            if (alg == 0) {
+                hostb::BeltHashPieces bh(HT, host_beltH());
+                bh.absorb(m, len);
+                bh.digest(out);
+            } else {
+                octet st[192];
+                memset(st, 0, sizeof st);
+                st[192 - 8] = (octet)(alg / 4);                             // bashHashStart (bash_hash.c:38-48)
+                const size_t rate = 192 - alg / 2;
+                size_t pos = 0;
+                hostp::sponge_absorb(st, rate, &pos, m, len);
+                memset(st + pos, 0, rate - pos);                            // bashHashStepG (bash_hash.c:84-102)
+                st[pos] = 0x40;
+                hostp::bashF(st);
+                memcpy(out, st, dlen);
+            }
+        }
+    };
+    struct Joiner {                                                        // joined on every way out
+        std::vector<std::thread> &w;
+        ~Joiner() { for (std::thread &t : w) if (t.joinable()) t.join(); }
+    } joiner{workers};
+    if (K) {
+        g_n_host.fetch_add(1, std::memory_order_relaxed);
+        for (size_t t = 0; t < std::min(T, K); ++t) workers.emplace_back(host_job);
+    }
+    const size_t ng = n - K;                                               // slots of the GPU launch: ord[K .. n)
     const size_t ob = (n + 1) * 8, oo = (total + 15) & ~(size_t)15, ro = (oo + ob + 15) & ~(size_t)15,
                  go = (ro + n * 4 + 15) & ~(size_t)15;
     Scratch &s = t_scr[3];
@@ -2548,9 +2615,11 @@ extern "C" err_t bee2hip_hash_ragged(size_t alg, const octet *data, const uint64
     octet *d = (octet *)s.p;
     if (total) B2H_TRY(h2d(d, data, total));
     B2H_TRY(h2d(d + oo, offsets, ob));
-    B2H_TRY(h2d(d + ro, ord.data(), n * 4));
-    code = bee2hip_hash_ragged_ordered_dev(alg, d, d + oo, d + ro, n, d + go, nullptr);
+    B2H_TRY(h2d(d + ro, ord.data() + K, ng * 4));
+    code = bee2hip_hash_ragged_ordered_dev(alg, d, d + oo, d + ro, ng, d + go, nullptr);
     if (code != ERR_OK) return code;
     B2H_TRY(d2h(digests, d + go, n * dlen));
+    for (std::thread &t : workers) t.join();
+    for (size_t k = 0; k < K; ++k) memcpy(digests + (size_t)ord[k] * dlen, hdig.data() + k * dlen, dlen);
     return ERR_OK;
 }

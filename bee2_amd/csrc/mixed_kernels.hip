@@ -624,22 +624,32 @@ err_t launch_belt_hash_stream(void *d_hs, const void *d_data, size_t nblocks, in
 // Long belt-hash messages (>= long_from bytes): a PAIR of lanes per message (belt_compress_pair): of the
 // three encryptions of a block the last two are independent, so the chain step is 2 E instead of 3.
 // Launched over all n messages (2 lanes each); pairs whose message is short leave at once.
-__global__ __launch_bounds__(64)
+// (round 4) Tab = BeltTabTwoP, the CTR kernel's table: a lone wavefront issues an instruction every ~6 cycles whatever its
+// class, so the chain's time is its instruction count -- 8 VALU + 4 ds_read per G-box with the one-instruction (SDWA) LDS
+// addresses instead of 12 + 4 with BeltTabSmall.  64 KiB per workgroup of LONG_WG lanes; a workgroup none of whose pairs has
+// a long message leaves before it fills the table (the caller sorts long messages to the front).
+constexpr int LONG_WG = 256;
+template <class Tab>
+__global__ __launch_bounds__(LONG_WG)
 void belt_hash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off,
                            const uint32_t *__restrict__ order, size_t n, uint8_t *__restrict__ digests,
                            uint64_t long_from)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[BeltTabSmall::kBytes];
-    BeltTabSmall::fill(smem, threadIdx.x, 64);
-    __syncthreads();
-    const BeltTabSmall T(smem);
-    const size_t slot = ((size_t)blockIdx.x * 64 + threadIdx.x) >> 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const size_t slot = ((size_t)blockIdx.x * LONG_WG + threadIdx.x) >> 1;
     const uint32_t odd = (threadIdx.x & 1u) ? ~0u : 0u;
-    if (slot >= n) return;
-    const size_t i = order ? order[slot] : slot;
+    size_t i = 0, len = 0;
+    if (slot < n) {
+        i = order ? order[slot] : slot;
+        len = (size_t)(off[i + 1] - off[i]);
+    }
+    const bool mine = slot < n && len >= long_from;
+    if (!__syncthreads_or(mine ? 1 : 0)) return;       // nothing long in this workgroup: no table, no work
+    Tab::fill(smem, threadIdx.x, LONG_WG);
+    __syncthreads();
+    const Tab T(smem);
+    if (!mine) return;
     const uint8_t *p = data + off[i];
-    const size_t len = (size_t)(off[i + 1] - off[i]);
-    if (len < long_from) return;
     size_t left = len;
     uint32_t h[8], s[4] = {0, 0, 0, 0}, X[8], s1[4];
 #pragma unroll
@@ -772,8 +782,12 @@ err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, cons
     // the rest stay one lane each; both launches cover all n messages and each skips what is not its own
     const dim3 gl((unsigned)((n * 8 + 63) / 64));
     if (alg == 0) {
-        hipLaunchKernelGGL(belt_hash_long_kernel, dim3((unsigned)((n * 2 + 63) / 64)), t, 0, st, data, off, ord, n, dig,
-                           RAGGED_LONG);
+        {
+            auto kern = belt_hash_long_kernel<BeltTabTwoP>;
+            B2H_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), BeltTabTwo::kBytes));
+            hipLaunchKernelGGL(kern, dim3((unsigned)((n * 2 + LONG_WG - 1) / LONG_WG)), dim3(LONG_WG), BeltTabTwo::kBytes, st, data, off,
+                               ord, n, dig, RAGGED_LONG);
+        }
         if (n >= 32768) {
             // big table; 256-thread workgroups until there are enough messages to fill 1024-thread ones on every CU
             const bool wide = n >= (size_t)num_cus() * 1024;

@@ -43,7 +43,7 @@ err_t bee2hip_internal_tune(int key, int value);
    next `value` GPU attempts of drop-in helpers report a device failure; keys 6 / 7 = log2 of the chunk of the duplex host
    pipeline in bashF states / belt blocks; key 8 = parts a big verification batch is split into (0 by size, 1 never);
    key 9 = quarter and half chunks at both ends of the duplex pipeline (0 = product: measured -2 %); key 10 = lanes per scalar of k G on the signing side
-   (0 = by batch size: 64 / 16 / 4 / 1; 1, 4, 16, 64 forced; 101 = one lane on the 4-bit windows of round 2, 102 = one lane, signed 6-bit windows, complete additions); key 11 = chunked upload of host-pointer
+   (0 = by batch size: 64 / 16 / 4 / 1, and 7 from 2^18 scalars on the 256-bit curve; 1, 4, 16, 64 forced; 7 = one lane, signed 7-bit windows looked up in LDS (256-bit curve; elsewhere as 1); 101 = one lane on the 4-bit windows of round 2, 102 = one lane, signed 6-bit windows, complete additions); key 11 = chunked upload of host-pointer
    verification batches of 2^19 signatures and more (1 = product); key 12 = largest workgroup of the signing side's hashing
    kernels for batches of 2^16 and more (0 = 1024, the product; 256 = round 2); key 13 = belt table of the fused kernel;
    keys 14 / 15 = fault injection into the duplex host pipeline: the next `15` pipelines fail when they reach chunk `14`) */

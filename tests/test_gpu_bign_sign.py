@@ -92,15 +92,17 @@ def test_golden_cases_dropin(golden, l, mulbase):
             assert rng.pos[0] == 0                    # a bad private key must not consume the generator
 
 
-@pytest.fixture(params=["auto", "gpu", 1, 101, 102, 4, 16, 64],
+@pytest.fixture(params=["auto", "gpu", 1, 7, 101, 102, 4, 16, 64],
                 ids=lambda v: {"auto": "product_library_auto_single_calls_on_the_host", "gpu": "product_library_forced_gpu",
-                               101: "1_lane_4bit_windows", 102: "1_lane_6bit_complete_additions"}.get(v, f"{v}_lanes_per_scalar"))
+                               7: "1_lane_7bit_windows_looked_up_in_LDS", 101: "1_lane_4bit_windows",
+                               102: "1_lane_6bit_complete_additions"}.get(v, f"{v}_lanes_per_scalar"))
 def mulbase(request):
     """Who computes k G.  "auto": the PRODUCT library as a caller gets it -- ONE key pair / signature through a drop-in symbol
     on the calling core in constant-time host arithmetic (bee2_amd/csrc/host_bign_ct.hpp), batches on the GPU with the kernel
     picked by batch size; "gpu": the product library under BEE2HIP_FORCE=gpu semantics (every secret in the kernels).  The
     numbers: one GPU form FORCED at every size through the hook of the experiments build (libbee2hip_exp.so, also forced to the
-    GPU): one lane per scalar (bign_mulbase_ct_kernel: signed 6-bit windows and Jacobian mixed additions, the throughput form; 102 =
+    GPU): one lane per scalar (bign_mulbase_ct_kernel: signed 6-bit windows and Jacobian mixed additions; 7 = signed 7-bit windows with the
+    entry looked up in LDS, bign_mulbase_lds_kernel: the throughput form of the 256-bit curve from 2^18 scalars on -- the other curves fall back to 1; 102 =
     the same windows with complete additions, 101 = the round-2 form on unsigned 4-bit windows) or 4 / 16 / 64 lanes per scalar
     (bign_mulbase_coop_kernel).  Yields the engine to use; defaults restored."""
     if request.param in ("auto", "gpu"):

@@ -341,3 +341,46 @@ def test_ragged_belt_hash_many_short_messages_every_table_variant(orc, n):
             m = blob[offs[i]:offs[i + 1]]
             want = orc.belt_hash(m) if alg == 0 else orc.bashHash(alg, m)[1]
             assert got[dl * i: dl * i + dl] == want, (alg, n, i, len(m))
+
+
+@pytest.mark.gpu
+def test_host_pointer_ragged_batch_hands_its_few_giant_messages_to_host_threads(orc):
+    """bee2hip_hash_ragged (HOST pointers): a message is one dependent chain, which a GPU lane walks 15x slower than a host
+    core -- a batch of small messages with a few very long ones would wait tens of milliseconds for those chains.  The entry
+    hashes the K longest on host threads while the GPU takes the rest (capi.hip); the digests are the oracle's either way,
+    BEE2HIP_FORCE=gpu keeps everything on the device, and the device-pointer entry never offloads."""
+    import ctypes
+    import random
+    import time
+
+    import numpy as np
+
+    from gpulib import engine
+    eng = engine()
+    L = eng.lib
+    rnd = random.Random(77)
+    lens = [rnd.randrange(0, 3000) for _ in range(3000)] + [1 << 20, (1 << 19) + 13, 300_001, 70_000, 65_536, 65_535]
+    rnd.shuffle(lens)
+    data = orc.fill(sum(lens), 0x4D1C)
+    offs = np.zeros(len(lens) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    for alg, dlen in ((0, 32), (128, 32), (256, 64)):
+        want = []
+        for i, n in enumerate(lens):
+            m = data[int(offs[i]): int(offs[i + 1])]
+            want.append(orc.belt_hash(m) if alg == 0 else orc.bashHash(alg, m)[1])
+        times = {}
+        for mode in (0, 1):
+            L.bee2hip_path_policy(mode)
+            out = ctypes.create_string_buffer(dlen * len(lens))
+            s0 = L.bee2hip_path_count(0)
+            t0 = time.perf_counter()
+            assert L.bee2hip_hash_ragged(ctypes.c_size_t(alg), data, offs.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(lens)), out) == 0
+            times[mode] = time.perf_counter() - t0
+            offloaded = L.bee2hip_path_count(0) - s0
+            assert (offloaded == 1) == (mode == 0), (alg, mode, offloaded)
+            for i in range(len(lens)):
+                assert out.raw[dlen * i: dlen * (i + 1)] == want[i], (alg, mode, i, lens[i])
+        L.bee2hip_path_policy(0)
+        if alg == 0:
+            assert times[0] < 0.5 * times[1], times          # the 1 MiB belt-hash chain alone is ~0.13 s on a lane pair
