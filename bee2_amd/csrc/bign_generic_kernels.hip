@@ -441,7 +441,7 @@ void bign_generic_sign_tail_kernel(const uint8_t *__restrict__ hashes, const uin
     uint32_t *s_rows = reinterpret_cast<uint32_t *>(s_dyn + BeltTabTwo::kBytes);
     BeltTabTwo::fill(s_tab, threadIdx.x, SIGN_WG);
     __syncthreads();
-    const BeltTabTwo T(s_tab);
+    const BeltTabTwoP T(s_tab);
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const uint32_t st = status[idx];

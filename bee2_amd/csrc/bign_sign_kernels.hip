@@ -363,7 +363,7 @@ __device__ __forceinline__ uint32_t mul_base_ct6(feT<N> &x, feT<N> &y, const uin
 // |A| <= 64 (128^w - 1) / 127 < 128^w before window w, and the top window starts at bit 252 exactly as with 6-bit windows.
 template <int N, int WB>
 __device__ __forceinline__ uint32_t mul_base_ct_lds(feT<N> &x, feT<N> &y, const uint32_t (&k)[N], const uint64_t *__restrict__ tabw,
-                                                    uint64_t *s_row)
+                                                    uint64_t *s_row, const int x_only /* public: signing needs x_R alone */)
 {
     constexpr int W = WinW<N, WB>::W, ENT = WinW<N, WB>::ENT, QW = ENT * N;       // 64-bit words of a row
     static_assert(QW * 32 % 1024 == 0, "the refill is written for 1024 lanes");
@@ -433,10 +433,13 @@ __device__ __forceinline__ uint32_t mul_base_ct_lds(feT<N> &x, feT<N> &y, const 
     chk.v[0] ^= 1u;                                                     // 0 iff Z * Z^-1 == 1
     fe_sqr(zi2, zi);
     fe_mul(x, J.X, zi2);
-    fe_mul(zi2, zi2, zi);
-    fe_mul(y, J.Y, zi2);
     fe_canon(x, x);
-    fe_canon(y, y);
+    fe_set_zero(y);
+    if (!x_only) {
+        fe_mul(zi2, zi2, zi);
+        fe_mul(y, J.Y, zi2);
+        fe_canon(y, y);
+    }
     const uint32_t inf = ct_is_zero(zc.v) | ~ct_is_zero(chk.v);
 #pragma unroll
     for (int l = 0; l < N; ++l) { x.v[l] &= ~inf; y.v[l] &= ~inf; }
@@ -669,7 +672,7 @@ void bign_mulbase_lds_kernel(const uint8_t *__restrict__ scalars, size_t n, uint
     uint32_t valid = ~0u;
     if (MODE == 1) valid = ct_in_range_q(k);
     feT<N> x, y;
-    const uint32_t inf = mul_base_ct_lds<N, WB>(x, y, k, tabw, s_row_dyn);
+    const uint32_t inf = mul_base_ct_lds<N, WB>(x, y, k, tabw, s_row_dyn, X_ONLY);
     if (!live) return;
     if (MODE == 1) codes[idx] = ct_sel(valid, (uint32_t)ERR_OK, ERR_BAD_PRIVKEY_V);
     if (MODE == 2) {
@@ -740,7 +743,7 @@ void bign_sign_nonce_kernel(const uint8_t *__restrict__ hashes, const uint8_t *_
     uint32_t *s_rows = reinterpret_cast<uint32_t *>(s_dyn + BeltTabTwo::kBytes);
     BeltTabTwo::fill(s_tab, threadIdx.x, blockDim.x);
     __syncthreads();
-    const BeltTabTwo T(s_tab);
+    const BeltTabTwoP T(s_tab);         // (round 4) the SDWA-address form of the same bank-private table: 8 instead of 12 VALU per G-box
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
 
@@ -938,7 +941,7 @@ void bign_sign_tail_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__
     uint32_t *s_rows = reinterpret_cast<uint32_t *>(s_dyn + BeltTabTwo::kBytes);
     BeltTabTwo::fill(s_tab, threadIdx.x, blockDim.x);
     __syncthreads();
-    const BeltTabTwo T(s_tab);
+    const BeltTabTwoP T(s_tab);         // (round 4) the SDWA-address form of the same bank-private table: 8 instead of 12 VALU per G-box
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const uint32_t st = status[idx];

@@ -624,12 +624,9 @@ err_t launch_belt_hash_stream(void *d_hs, const void *d_data, size_t nblocks, in
 // Long belt-hash messages (>= long_from bytes): a PAIR of lanes per message (belt_compress_pair): of the
 // three encryptions of a block the last two are independent, so the chain step is 2 E instead of 3.
 // Launched over all n messages (2 lanes each); pairs whose message is short leave at once.
-// (round 4) Tab = BeltTabTwoP, the CTR kernel's table: a lone wavefront issues an instruction every ~6 cycles whatever its
-// class, so the chain's time is its instruction count -- 8 VALU + 4 ds_read per G-box with the one-instruction (SDWA) LDS
-// addresses instead of 12 + 4 with BeltTabSmall.  64 KiB per workgroup of LONG_WG lanes; a workgroup none of whose pairs has
-// a long message leaves before it fills the table (the caller sorts long messages to the front).
-constexpr int LONG_WG = 256;
-template <class Tab>
+// (round 4) templated on the table and the workgroup for the A/B of profiles/r04_long_hash_ab.txt; a workgroup none of whose
+// pairs has a long message leaves before it fills the table (the caller sorts long messages to the front).
+template <class Tab, int LONG_WG>
 __global__ __launch_bounds__(LONG_WG)
 void belt_hash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off,
                            const uint32_t *__restrict__ order, size_t n, uint8_t *__restrict__ digests,
@@ -644,7 +641,18 @@ void belt_hash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__r
         len = (size_t)(off[i + 1] - off[i]);
     }
     const bool mine = slot < n && len >= long_from;
-    if (!__syncthreads_or(mine ? 1 : 0)) return;       // nothing long in this workgroup: no table, no work
+    {
+        // "is anything long here?" through the first word of the (dynamic) table area itself: a static __shared__ flag -- what
+        // __syncthreads_or allocates -- would push the table off LDS address 0, which its OR-composed addresses need
+        volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(smem);
+        if (threadIdx.x == 0) *flag = 0;
+        __syncthreads();
+        if (mine) *flag = 1;
+        __syncthreads();
+        const uint32_t any = *flag;
+        __syncthreads();                                // everyone has read it before the fill overwrites it
+        if (!any) return;                               // nothing long in this workgroup: no table, no work
+    }
     Tab::fill(smem, threadIdx.x, LONG_WG);
     __syncthreads();
     const Tab T(smem);
@@ -754,6 +762,10 @@ void ragged_scatter_kernel(const uint64_t *__restrict__ off, size_t n, unsigned 
     if (i < n) order[base[b] + rank] = (uint32_t)i;
 }
 
+#ifdef BEE2HIP_EXPERIMENTS
+static int g_long_hash_form = 0;
+void set_long_hash_form(int v) { g_long_hash_form = v; }
+#endif
 constexpr uint64_t RAGGED_LONG = 4096;     // bytes; see bench.py --only ragged and DESIGN.md 4.7
 err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, const void *d_order, size_t n,
                          void *d_digests, hipStream_t st)
@@ -782,13 +794,27 @@ err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, cons
     // the rest stay one lane each; both launches cover all n messages and each skips what is not its own
     const dim3 gl((unsigned)((n * 8 + 63) / 64));
     if (alg == 0) {
-        {
-            auto kern = belt_hash_long_kernel<BeltTabTwoP>;
-            B2H_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), BeltTabTwo::kBytes));
-            hipLaunchKernelGGL(kern, dim3((unsigned)((n * 2 + LONG_WG - 1) / LONG_WG)), dim3(LONG_WG), BeltTabTwo::kBytes, st, data, off,
-                               ord, n, dig, RAGGED_LONG);
-        }
-        if (n >= 32768) {
+#ifdef BEE2HIP_EXPERIMENTS      // A/B (tune 16, tools/long_hash_ab.py, profiles/r04_long_hash_ab.txt): the SDWA table in one-wavefront / four-wavefront workgroups
+        if (g_long_hash_form == 2 || g_long_hash_form == 3) {
+            const int wg = g_long_hash_form == 2 ? 64 : 256;
+            const void *kern = wg == 64 ? reinterpret_cast<const void *>(belt_hash_long_kernel<BeltTabTwoP, 64>)
+                                        : reinterpret_cast<const void *>(belt_hash_long_kernel<BeltTabTwoP, 256>);
+            B2H_TRY(dyn_lds_once(kern, BeltTabTwo::kBytes));
+            if (wg == 64)
+                hipLaunchKernelGGL((belt_hash_long_kernel<BeltTabTwoP, 64>), dim3((unsigned)((n * 2 + 63) / 64)), dim3(64), BeltTabTwo::kBytes, st,
+                                   data, off, ord, n, dig, RAGGED_LONG);
+            else
+                hipLaunchKernelGGL((belt_hash_long_kernel<BeltTabTwoP, 256>), dim3((unsigned)((n * 2 + 255) / 256)), dim3(256), BeltTabTwo::kBytes,
+                                   st, data, off, ord, n, dig, RAGGED_LONG);
+        } else
+#endif
+        // product: the 4 KiB table in one-wavefront workgroups.  A long message is ONE dependent chain on a lone wavefront, bound by
+        // the LATENCY of its dependent instructions, not by their number: the SDWA-address table that gave the CTR kernel
+        // +15 % (8 instead of 12 VALU per G-box, but a deeper chain behind each look-up) makes this kernel 1.55x SLOWER
+        // (39 -> 61 ms for a 256 KiB message, profiles/r04_long_hash_ab.txt)
+        hipLaunchKernelGGL((belt_hash_long_kernel<BeltTabSmall, 64>), dim3((unsigned)((n * 2 + 63) / 64)), dim3(64), BeltTabSmall::kBytes, st,
+                           data, off, ord, n, dig, RAGGED_LONG);
+    if (n >= 32768) {
             // big table; 256-thread workgroups until there are enough messages to fill 1024-thread ones on every CU
             const bool wide = n >= (size_t)num_cus() * 1024;
             const void *kern = wide ? reinterpret_cast<const void *>(belt_hash_ragged_kernel<BeltTabTwoP, 1024>)

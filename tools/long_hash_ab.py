@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""A/B of belt_hash_long_kernel's table / workgroup form on the GPU box (experiments build, tune 16): one 256 KiB chain alone,
+many long chains, and bench.py's ragged distribution.  usage: python tools/long_hash_ab.py"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import bee2_amd  # noqa: E402
+
+eng = bee2_amd.load_experiments(); eng.set_device(0)
+
+
+def run(lens, form, reps=3):
+    lens = np.asarray(lens, dtype=np.int64)
+    offs = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    data = torch.zeros(int(offs[-1]) // 8 * 8 + 16, dtype=torch.uint8, device="cuda")
+    torch.manual_seed(1234)
+    data.view(torch.int64).random_()
+    doff = torch.from_numpy(offs).cuda()
+    order = torch.from_numpy(np.argsort(-lens, kind="stable").astype(np.int32)).cuda()
+    dig = torch.empty(32 * len(lens), dtype=torch.uint8, device="cuda")
+    eng.lib.bee2hip_internal_tune(16, form)
+    best, ref = 1e9, None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.hash_ragged_dev(0, data, doff, dig, len(lens), order=order)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    eng.lib.bee2hip_internal_tune(16, 0)
+    return best * 1e3, dig.cpu().numpy().tobytes()
+
+
+rng = np.random.default_rng(0x4D1C)
+cases = {"one 256 KiB message": [1 << 18], "64 x 256 KiB": [1 << 18] * 64, "4096 x 256 KiB": [1 << 18] * 4096,
+         "4096 x 16 KiB": [1 << 14] * 4096,
+         "bench ragged (65536, log-uniform < 256 KiB)": (np.floor(2.0 ** (18.0 * rng.random(1 << 16))).astype(np.int64) - 1).tolist()}
+print("ms per batch: 4 KiB table, one-wavefront workgroups (product) | SDWA table WG 64 | SDWA table WG 256")
+for name, lens in cases.items():
+    out = [run(lens, f) for f in (0, 2, 3)]
+    assert out[0][1] == out[1][1] == out[2][1], name
+    print(f"{name:48s} {out[0][0]:9.2f} {out[1][0]:9.2f} {out[2][0]:9.2f}")
