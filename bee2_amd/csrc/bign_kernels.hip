@@ -1115,6 +1115,7 @@ struct BignDevice {
     uint4 *gtab[3] = {nullptr, nullptr, nullptr};      // 16-bit comb table per curve, built from the seed table
     uint4 *gtab6[3] = {nullptr, nullptr, nullptr};     // signed 6-bit windows (signing side, one lane per scalar)
     uint4 *gtab7[3] = {nullptr, nullptr, nullptr};     // signed 7-bit windows (signing side, LDS look-up kernel: 256-bit curve)
+    uint4 *gtabw8[3] = {nullptr, nullptr, nullptr};    // signed 8-bit windows (the same kernel with 16 copies of the row and 16-octet reads)
 };
 static BignDevice g_bign[64];
 static std::mutex g_bign_mu;          // table construction is per device, shared by threads
@@ -1175,27 +1176,28 @@ static err_t bign_table6(const uint32_t **out8, const uint32_t **out6, hipStream
     return ERR_OK;
 }
 
-// the signed 7-bit table (148 KiB on the 256-bit curve), made from the seed table like the 6-bit one
-template <int N>
-static err_t bign_table7(const uint32_t **out7, hipStream_t st)
+// the signed 7- / 8-bit window tables (148 / 264 KiB on the 256-bit curve), made from the seed table like the 6-bit one
+template <int N, int WB>
+static err_t bign_tablew(const uint32_t **outw, hipStream_t st)
 {
+    static_assert(WB == 7 || WB == 8, "window tables of the LDS look-up kernel");
     std::lock_guard<std::mutex> lk(g_bign_mu);
     uint4 *t8 = nullptr;
     err_t code = bign_table8_locked<N>(&t8, st);
     if (code != ERR_OK) return code;
     int dev = 0;
     B2H_TRY(hipGetDevice(&dev));
-    uint4 *&slot = g_bign[dev].gtab7[N / 4 - 2];
+    uint4 *&slot = (WB == 7 ? g_bign[dev].gtab7 : g_bign[dev].gtabw8)[N / 4 - 2];
     if (!slot) {
-        uint4 *t7 = nullptr;
-        const size_t entries = (size_t)WinW<N, 7>::W * WinW<N, 7>::ENT;
-        if (hipMalloc((void **)&t7, entries * 8 * N) != hipSuccess) { (void)hipGetLastError(); return ERR_OUTOFMEMORY; }
-        hipLaunchKernelGGL((bign_gtable6_kernel<N, 7>), dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, st, (const uint4 *)t8, t7);
+        uint4 *tw = nullptr;
+        const size_t entries = (size_t)WinW<N, WB>::W * WinW<N, WB>::ENT;
+        if (hipMalloc((void **)&tw, entries * 8 * N) != hipSuccess) { (void)hipGetLastError(); return ERR_OUTOFMEMORY; }
+        hipLaunchKernelGGL((bign_gtable6_kernel<N, WB>), dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, st, (const uint4 *)t8, tw);
         B2H_TRY(hipGetLastError());
         B2H_TRY(hipStreamSynchronize(st));
-        slot = t7;
+        slot = tw;
     }
-    *out7 = reinterpret_cast<const uint32_t *>(slot);
+    *outw = reinterpret_cast<const uint32_t *>(slot);
     return ERR_OK;
 }
 

@@ -789,11 +789,11 @@ def main():
         vc = torch.empty(n, dtype=torch.int32, device="cuda")
         eng.bignVerifyL_batch_dev(l, LEVEL_OID[l], hsh, sigs, pubs, vc)        # not timed: every signature must verify
         torch.cuda.synchronize()
-        # 32x32+64 multiply-adds per signature: 37 signed 7-bit windows (round 4; 43 of 6 bits in round 3, 64 of 4 bits before) x 11
+        # 32x32+64 multiply-adds per signature: 33 signed 8-bit windows (round 4; 43 of 6 bits in round 3, 64 of 4 bits before) x 11
         # multiplications x (64 + 8) -- see below for the count of the Jacobian form -- and the affine coordinates; the inversion (fixed-count division steps,
         # fe_inv_safegcd<N, true>), the belt work (16 block encryptions) and the table scan have none
         # (8 M + 3 S per Jacobian mixed addition: 8 x 72 + 3 x 52 multiply-adds with the reductions; 4 M + 1 S for x, y)
-        mads = 37 * (8 * 72 + 3 * 52) + 2 * 72 + 52     # round 4: 37 signed 7-bit windows looked up in LDS (bign_mulbase_lds_kernel); x_R only
+        mads = 33 * (8 * 72 + 3 * 52) + 2 * 72 + 52     # round 4: 33 signed 8-bit windows looked up in LDS (bign_mulbase_lds_kernel); x_R only
         others["bignSign2"] = {
             "metric": "bign-curve256v1 deterministic signatures/s", "value": N * n * ks / el, "unit": "signatures/s", "steps": ks,
             "ms_per_step": el / ks * 1e3, "all_verify": bool((vc == 0).all() and (sc == 0).all()),

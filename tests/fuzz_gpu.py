@@ -312,7 +312,7 @@ def f_sign(rnd):
         oid = bytes([0x06, k] if k < 128 else [0x06, 0x81, k]) + bytes([0x2A] + [rnd.randrange(1, 128) for _ in range(k - 1)])
     t = rnd.choice((None, b"", rnd.randbytes(rnd.randrange(1, 65)), rnd.randbytes(rnd.randrange(65, 200))))
     # k G by 1 (signed 6-bit or, 101, 4-bit windows) / 4 / 16 / 64 lanes per scalar, or as the product picks by batch size (0)
-    _tune(10, rnd.choice((0, 0, 1, 1, 7, 7, 101, 102, 4, 16, 64)))
+    _tune(10, rnd.choice((0, 0, 1, 1, 7, 8, 8, 72, 101, 102, 4, 16, 64)))
     try:
         return _sign_case(rnd, l, P, n, privs, hashes, oid, t)
     finally:

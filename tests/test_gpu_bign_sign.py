@@ -92,9 +92,9 @@ def test_golden_cases_dropin(golden, l, mulbase):
             assert rng.pos[0] == 0                    # a bad private key must not consume the generator
 
 
-@pytest.fixture(params=["auto", "gpu", 1, 7, 101, 102, 4, 16, 64],
+@pytest.fixture(params=["auto", "gpu", 1, 7, 72, 8, 101, 102, 4, 16, 64],
                 ids=lambda v: {"auto": "product_library_auto_single_calls_on_the_host", "gpu": "product_library_forced_gpu",
-                               7: "1_lane_7bit_windows_looked_up_in_LDS", 101: "1_lane_4bit_windows",
+                               7: "1_lane_7bit_windows_looked_up_in_LDS", 72: "1_lane_7bit_LDS_other_coordinates", 8: "1_lane_8bit_windows_LDS_16_copies", 101: "1_lane_4bit_windows",
                                102: "1_lane_6bit_complete_additions"}.get(v, f"{v}_lanes_per_scalar"))
 def mulbase(request):
     """Who computes k G.  "auto": the PRODUCT library as a caller gets it -- ONE key pair / signature through a drop-in symbol

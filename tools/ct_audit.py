@@ -15,7 +15,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
-KERNELS = ("bign_mulbase_ct_kernel", "bign_mulbase_coop_kernel", "bign_sign_nonce_kernel", "bign_sign_kcheck_kernel", "bign_sign_tail_kernel",
+KERNELS = ("bign_mulbase_ct_kernel", "bign_mulbase_lds_kernel", "bign_mulbase_coop_kernel", "bign_sign_nonce_kernel", "bign_sign_kcheck_kernel", "bign_sign_tail_kernel",
            "bign_generic_mulbase_kernel", "bign_generic_sign_tail_kernel")
 
 
@@ -24,8 +24,8 @@ def disasm(lib):
     name = os.path.join(tmp, "lib.so")
     subprocess.check_call(["cp", lib, name])
     subprocess.check_call([f"{LLVM}/llvm-objdump", "--offloading", name], cwd=tmp, stdout=subprocess.DEVNULL)
-    co = [f for f in os.listdir(tmp) if "amdgcn" in f][0]
-    return subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", os.path.join(tmp, co)], text=True)
+    return "\n".join(subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", os.path.join(tmp, co)], text=True)
+                     for co in sorted(os.listdir(tmp)) if "amdgcn" in co)          # one code object per translation unit
 
 
 def demangle(n):

@@ -3,9 +3,9 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/ct_dyn; rm -rf $O; mkdir -p $O
-E=${1:-14}          # log2 of the batch: 14 = one lane per scalar, 10 = one wavefront per scalar (bign_mulbase_coop_kernel)
+E=${1:-14}          # log2 of the batch: 18 = one lane per scalar with LDS look-ups (bign_mulbase_lds_kernel), 14 = one lane per scalar (scan), 10 = one wavefront per scalar (bign_mulbase_coop_kernel)
 for c in random small ones sparse dense; do
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT SQ_WAVES --output-format csv -d $O/$c -o b -- python $R/tools/ct_dynamic.py $c 128 $E > $O/$c.log 2>&1
+  timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT SQ_WAVES --output-format csv -d $O/$c -o b -- python $R/tools/ct_dynamic.py $c 128 $E > $O/$c.log 2>&1
 done
 cd $R
 python - <<PY
