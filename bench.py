@@ -85,7 +85,12 @@ def mixed_roofline(msgs_per_s_per_gpu, perms_per_s, blocks_per_s, src):
             "overlap_got": (t_sum - t) / (t_sum - t_max) if t_sum > t_max else None,
             "part_rates": {"bashF_perms_per_s": perms_per_s, "belt_blocks_per_s": blocks_per_s, "source": src},
             "work_per_message": MIXED_WORK,
-            "algorithmic_bytes_per_message": 4096 + 72}
+            "algorithmic_bytes_per_message": 4096 + 72,
+            # why the overlap ceiling is out of reach: the belt half is not only LDS look-ups, it has VALU work of its own, and VALU
+            # work of two wavefronts does not overlap.  Modelled VALU issue cycles per 64 messages (2 / 4 cycles per full- / half-rate
+            # instruction) against the SIMD cycles there are at the nominal clock: near 1 = the fused kernel is VALU-bound
+            "valu_model_ratio_nominal_clock": msgs_per_s_per_gpu / 64 * (2 * MIXED_WORK["valu_full_rate"] + 4 * MIXED_WORK["valu_half_rate"])
+                                              / (N_SIMD * NOMINAL_GHZ * 1e9)}
 
 
 def device_identity(index):
