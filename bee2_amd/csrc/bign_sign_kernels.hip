@@ -660,12 +660,14 @@ void bign_mulbase_ct_kernel(const uint8_t *__restrict__ scalars, size_t n, uint3
 // (MI355X_MICROARCH.md, LDS table) -- and within each of them l mod 16 takes every value once (also within plain runs of 16
 // lanes), so the 16 lanes of a group read 16 disjoint 16-octet slots = all 64 banks once, whatever their entries: no
 // conflict, SQ_LDS_BANK_CONFLICT = 0 for every key class (profiles/r04_sign_lds.txt).  Four reads per look-up.
-template <int N, int WB>
+// WGL = lanes of the workgroup (1024, or 512 for batches that would leave CUs empty otherwise: two wavefronts per SIMD still reach
+// ~95 % of the multiply-add rate).
+template <int N, int WB, int WGL>
 __device__ __forceinline__ uint32_t mul_base_ct_lds16(feT<N> &x, feT<N> &y, const uint32_t (&k)[N], const uint4 *__restrict__ tabw,
                                                       uint4 *s_row, const int x_only)
 {
     constexpr int W = WinW<N, WB>::W, ENT = WinW<N, WB>::ENT, OW = ENT * N / 2;     // 16-octet words of a row
-    static_assert(OW * 16 % 1024 == 0 && N % 4 == 0, "the refill is written for 1024 lanes");
+    static_assert(OW * 16 % WGL == 0 && N % 4 == 0 && WGL % 16 == 0, "the refill covers the row with whole passes of the workgroup");
     const unsigned tid = threadIdx.x, rep = tid & 15u;
     uint32_t kk[N];
 #pragma unroll
@@ -682,8 +684,8 @@ __device__ __forceinline__ uint32_t mul_base_ct_lds16(feT<N> &x, feT<N> &y, cons
         {
             const uint4 *row = tabw + (size_t)w * OW;
 #pragma unroll
-            for (int i = 0; i < OW * 16 / 1024; ++i) {
-                const unsigned q = (tid >> 4) + 64u * i;                // the 16 lanes of a copy-group fetch the same word
+            for (int i = 0; i < OW * 16 / WGL; ++i) {
+                const unsigned q = (tid >> 4) + (unsigned)(WGL / 16) * i;   // the 16 lanes of a copy-group fetch the same word
                 s_row[q * 16u + rep] = row[q];
             }
         }
@@ -865,8 +867,8 @@ __device__ __forceinline__ uint32_t mul_base_ct_lds_xyzz(feT<N> &x, feT<N> &y, c
 
 // the LDS look-up form: modes and outputs as bign_mulbase_ct_kernel; blocks of 1024 lanes, all of which walk the windows
 // (a lane beyond n multiplies by 0 and writes nothing: the barriers need every lane)
-template <int N, int WB, bool XYZZ>
-__global__ __launch_bounds__(1024)
+template <int N, int WB, bool XYZZ, int WGL = 1024>
+__global__ __launch_bounds__(WGL)
 void bign_mulbase_lds_kernel(const uint8_t *__restrict__ scalars, size_t n, uint32_t *__restrict__ codes,
                              uint8_t *__restrict__ xy_out, const uint64_t *__restrict__ tabw, const int MODE, const int X_ONLY)
 {
@@ -883,7 +885,7 @@ void bign_mulbase_lds_kernel(const uint8_t *__restrict__ scalars, size_t n, uint
     feT<N> x, y;
     uint32_t inf;
     if constexpr (WB == 8)
-        inf = mul_base_ct_lds16<N, WB>(x, y, k, reinterpret_cast<const uint4 *>(tabw), reinterpret_cast<uint4 *>(s_row_dyn), X_ONLY);
+        inf = mul_base_ct_lds16<N, WB, WGL>(x, y, k, reinterpret_cast<const uint4 *>(tabw), reinterpret_cast<uint4 *>(s_row_dyn), X_ONLY);
     else if constexpr (XYZZ) inf = mul_base_ct_lds_xyzz<N, WB>(x, y, k, tabw, s_row_dyn, X_ONLY);
     else inf = mul_base_ct_lds<N, WB>(x, y, k, tabw, s_row_dyn, X_ONLY);
     if (!live) return;
@@ -1243,7 +1245,7 @@ void set_sign_coop(int v) { g_sign_lanes = v; }
 // workgroups of 1024 lanes; signed 8-bit windows and 16 copies of the row -- the product -- or signed 7-bit windows and 32
 // copies): from 3 * 2^16 scalars on, where its one round of <= 256 workgroups (0.63 ms) beats the scanning kernel's 256-lane
 // blocks (0.55 ms at 2^17, 0.97 ms at 2^18: tools/sign_lds_ab.py)
-constexpr size_t MULBASE_LDS_MIN = (size_t)3 << 16;
+constexpr size_t MULBASE_LDS_MIN = (size_t)3 << 14, MULBASE_LDS_512_MAX = (size_t)1 << 17;   // (512-lane workgroups from 3 * 2^14 scalars: tools/sign_lds_ab.py)
 constexpr bool LDS_XYZZ = false;       // accumulator of the 7-bit LDS form: Jacobian (8M + 3S).  XYZZ (8M + 2S, one more coordinate) measured: +-0 % (profiles/r04_sign_lds.txt)
 template <int N>
 static inline int mulbase_lanes(size_t n)
@@ -1260,7 +1262,14 @@ static err_t mulbase_tables(int lanes, const uint32_t **tab, const uint32_t **ta
 {
     err_t code = bign_table6<N>(tab, tabw, st);
     if (code == ERR_OK && (lanes == 7 || lanes == 72 || lanes == 8)) {
+        if constexpr (N != 8) return ERR_BAD_INPUT;                      // (never: mulbase_lanes picks these forms on the 256-bit curve only)
+        else {
+#ifdef BEE2HIP_EXPERIMENTS
         code = lanes == 8 ? bign_tablew<N, 8>(tabw, st) : bign_tablew<N, 7>(tabw, st);
+#else
+        code = bign_tablew<N, 8>(tabw, st);
+#endif
+        }
         if (code == ERR_OK) {
             static std::once_flag once[64];
             hipError_t e = hipSuccess;
@@ -1268,6 +1277,9 @@ static err_t mulbase_tables(int lanes, const uint32_t **tab, const uint32_t **ta
                 const int bytes = (int)((size_t)WinW<8, 7>::ENT * 8 * 32 * 8);          // = 128 entries x 64 octets x 16 copies too
                 e = hipFuncSetAttribute(reinterpret_cast<const void *>(bign_mulbase_lds_kernel<8, 8, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute(reinterpret_cast<const void *>(bign_mulbase_lds_kernel<8, 8, false, 512>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 #ifdef BEE2HIP_EXPERIMENTS
                 if (e == hipSuccess)
                     e = hipFuncSetAttribute(reinterpret_cast<const void *>(bign_mulbase_lds_kernel<8, 7, LDS_XYZZ>),
@@ -1303,8 +1315,13 @@ static void launch_mulbase(int lanes, const uint8_t *scalars, size_t n, uint32_t
         // signed 8-bit windows, 16 copies of the row read with ds_read_b128 (tab6 = the 8-bit window table): 33 additions
         if constexpr (N == 8) {
             constexpr size_t lds = (size_t)WinW<N, 8>::ENT * N * 8 * 16;
-            hipLaunchKernelGGL((bign_mulbase_lds_kernel<N, 8, false>), dim3((unsigned)((n + 1023) / 1024)), dim3(1024), lds, st, scalars, n,
-                               codes, out, reinterpret_cast<const uint64_t *>(tab6), MODE, (int)X_ONLY);
+            // up to 2^17 scalars: workgroups of 512 lanes (<= 256 of them: one per CU, two wavefronts per SIMD); above: 1024 lanes
+            if (n <= MULBASE_LDS_512_MAX)
+                hipLaunchKernelGGL((bign_mulbase_lds_kernel<N, 8, false, 512>), dim3((unsigned)((n + 511) / 512)), dim3(512), lds, st, scalars,
+                                   n, codes, out, reinterpret_cast<const uint64_t *>(tab6), MODE, (int)X_ONLY);
+            else
+                hipLaunchKernelGGL((bign_mulbase_lds_kernel<N, 8, false>), dim3((unsigned)((n + 1023) / 1024)), dim3(1024), lds, st, scalars, n,
+                                   codes, out, reinterpret_cast<const uint64_t *>(tab6), MODE, (int)X_ONLY);
         }
     }
     else if (lanes == 7 || lanes == 72) {

@@ -517,7 +517,11 @@ void belt_hash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *_
                              const uint32_t *__restrict__ order, size_t n, uint8_t *__restrict__ digests,
                              uint64_t long_from)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // (the 4 KiB table in STATIC shared memory: look-up addresses with immediate offsets -- see belt_hash_long_kernel)
+    constexpr bool STATIC_TAB = Tab::kBytes <= 4096;
+    __shared__ __attribute__((aligned(16))) uint8_t smem_static[STATIC_TAB ? Tab::kBytes : 16];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_dyn[];
+    uint8_t *smem = STATIC_TAB ? smem_static : smem_dyn;
     Tab::fill(smem, threadIdx.x, WG);
     __syncthreads();
     const Tab T(smem);
@@ -632,7 +636,14 @@ void belt_hash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__r
                            const uint32_t *__restrict__ order, size_t n, uint8_t *__restrict__ digests,
                            uint64_t long_from)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // the 4 KiB table of the product sits in STATIC shared memory: its LDS address is then a compile-time constant and every
+    // look-up address is "byte * 4 + immediate"; through the dynamic segment the base is a run-time value and each look-up pays
+    // one more dependent add -- +16 % on a chain that is bound by exactly that latency (45.3 against 39.0 ms for a 256 KiB
+    // message, profiles/r04_long_hash_ab.txt).  The 64 KiB tables of the A/B forms need the dynamic segment (LDS address 0).
+    constexpr bool STATIC_TAB = Tab::kBytes <= 4096;
+    __shared__ __attribute__((aligned(16))) uint8_t smem_static[STATIC_TAB ? Tab::kBytes : 16];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_dyn[];
+    uint8_t *smem = STATIC_TAB ? smem_static : smem_dyn;
     const size_t slot = ((size_t)blockIdx.x * LONG_WG + threadIdx.x) >> 1;
     const uint32_t odd = (threadIdx.x & 1u) ? ~0u : 0u;
     size_t i = 0, len = 0;
@@ -641,7 +652,7 @@ void belt_hash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__r
         len = (size_t)(off[i + 1] - off[i]);
     }
     const bool mine = slot < n && len >= long_from;
-    {
+    if constexpr (!STATIC_TAB) {
         // "is anything long here?" through the first word of the (dynamic) table area itself: a static __shared__ flag -- what
         // __syncthreads_or allocates -- would push the table off LDS address 0, which its OR-composed addresses need
         volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(smem);
@@ -812,8 +823,8 @@ err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, cons
         // the LATENCY of its dependent instructions, not by their number: the SDWA-address table that gave the CTR kernel
         // +15 % (8 instead of 12 VALU per G-box, but a deeper chain behind each look-up) makes this kernel 1.55x SLOWER
         // (39 -> 61 ms for a 256 KiB message, profiles/r04_long_hash_ab.txt)
-        hipLaunchKernelGGL((belt_hash_long_kernel<BeltTabSmall, 64>), dim3((unsigned)((n * 2 + 63) / 64)), dim3(64), BeltTabSmall::kBytes, st,
-                           data, off, ord, n, dig, RAGGED_LONG);
+        hipLaunchKernelGGL((belt_hash_long_kernel<BeltTabSmall, 64>), dim3((unsigned)((n * 2 + 63) / 64)), dim3(64), 0, st, data, off, ord, n, dig,
+                           RAGGED_LONG);
     if (n >= 32768) {
             // big table; 256-thread workgroups until there are enough messages to fill 1024-thread ones on every CU
             const bool wide = n >= (size_t)num_cus() * 1024;
@@ -827,8 +838,7 @@ err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, cons
                 hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabTwoP, 256>), dim3((unsigned)((n + 255) / 256)),
                                    dim3(256), BeltTabTwo::kBytes, st, data, off, ord, n, dig, RAGGED_LONG);
         } else {
-            hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabSmall, 64>), g, t, BeltTabSmall::kBytes, st, data, off,
-                               ord, n, dig, RAGGED_LONG);
+            hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabSmall, 64>), g, t, 0, st, data, off, ord, n, dig, RAGGED_LONG);
         }
     }
     else if (alg == 256) {

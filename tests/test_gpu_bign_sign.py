@@ -290,3 +290,42 @@ def test_sign_from_many_threads(orc):
     [t.start() for t in th]
     [t.join() for t in th]
     assert not errs
+
+
+@pytest.mark.parametrize("n", [3 << 14, (1 << 17) - 5, (1 << 17) + 1, 1 << 18])
+def test_lds_lookup_forms_at_their_own_sizes_match_the_scanning_kernel(n):
+    """From 3 * 2^14 scalars on the 256-bit curve k G looks its window entries up in LDS (bign_mulbase_lds_kernel: workgroups of 512
+    lanes up to 2^17 scalars, of 1024 above); the same batch through the scanning kernel (forced, experiments build) must give the
+    same public keys and -- deterministic signatures -- the same octets; a sample of both is checked against the oracle."""
+    import orclib
+    orc = orclib.load()
+    eng = exp_engine()
+    l, no, sg = 128, 32, 48
+    g = torch.Generator(device="cuda")
+    g.manual_seed(n)
+    privs = torch.empty(no * n, dtype=torch.uint8, device="cuda")
+    privs.view(torch.int64).random_(generator=g)
+    privs.view(-1, no)[:, no - 1] &= 0x7F
+    privs.view(-1, no)[:, 0] |= 1
+    hsh = torch.empty(no * n, dtype=torch.uint8, device="cuda")
+    hsh.view(torch.int64).random_(generator=g)
+    out = {}
+    for form in (0, 1):
+        eng.lib.bee2hip_internal_tune(10, form)
+        pubs = torch.zeros(2 * no * n, dtype=torch.uint8, device="cuda")
+        sigs = torch.zeros(sg * n, dtype=torch.uint8, device="cuda")
+        sc = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        eng.bignPubkeyCalcL_batch_dev(l, privs, pubs, sc)
+        torch.cuda.synchronize()
+        assert int(sc.abs().sum()) == 0
+        eng.bignSign2L_batch_dev(l, E.LEVEL_OID[l], hsh, privs, sigs, sc)
+        torch.cuda.synchronize()
+        assert int(sc.abs().sum()) == 0
+        out[form] = (host(pubs), host(sigs))
+    eng.lib.bee2hip_internal_tune(10, 0)
+    assert out[0] == out[1]
+    pv, hv = host(privs), host(hsh)
+    for i in (0, 1, 63, 64, 511, 512, 1023, 1024, n // 2, n - 1):
+        d, h = pv[no * i: no * i + no], hv[no * i: no * i + no]
+        assert orc.pubkey_calc(l, d) == (0, out[0][0][2 * no * i: 2 * no * (i + 1)])
+        assert orc.sign2(l, E.LEVEL_OID[l], h, d, None) == (0, out[0][1][sg * i: sg * (i + 1)])
