@@ -340,6 +340,31 @@ struct BeltTabSmall {
     }
 };
 
+// EXPERIMENT (round 4, tools/long_hash_ab.py form 4): BeltTabSmall with each look-up address made by ONE instruction,
+// v_lshlrev_b32_sdwa (byte k of x, shifted by 2), instead of extract + shift -- one dependent instruction less on a chain that is
+// bound by dependent latency (profiles/r04_long_hash_ab.txt).  Same table, same bank behaviour.
+struct BeltTabSmallS : BeltTabSmall {
+    __device__ explicit BeltTabSmallS(const uint8_t *l) : BeltTabSmall(l) {}
+    template <int R0>
+    __device__ __forceinline__ GParts g(uint32_t x) const
+    {
+        uint32_t a0, a1, a2, a3;
+        const uint32_t two = 2u;
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a0) : "v"(two), "v"(x));
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a1) : "v"(two), "v"(x));
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a2) : "v"(two), "v"(x));
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a3) : "v"(two), "v"(x));
+        const uint32_t t0 = *reinterpret_cast<const uint32_t *>(lds + ((R0 + 0) & 3) * 1024 + a0);
+        const uint32_t t1 = *reinterpret_cast<const uint32_t *>(lds + ((R0 + 1) & 3) * 1024 + a1);
+        const uint32_t t2 = *reinterpret_cast<const uint32_t *>(lds + ((R0 + 2) & 3) * 1024 + a2);
+        const uint32_t t3 = *reinterpret_cast<const uint32_t *>(lds + ((R0 + 3) & 3) * 1024 + a3);
+        GParts r;
+        r.p = xor3(t0, t1, t2);
+        r.q = t3;
+        return r;
+    }
+};
+
 // G_r(x), r = 5 + 8*R0 (belt_block.c:210-215): table (R0 + k) & 3 serves byte k of x.
 // G5 = g<0>, G13 = g<1>, G21 = g<2>.
 
@@ -589,6 +614,195 @@ __device__ __forceinline__ void belt_compress_pair(const Tab &T, uint32_t (&s1)[
     for (int i = 0; i < 4; ++i) {
         const uint32_t mine = y[i] ^ xs[i];                     // h0' in the even lane, h1' in the odd one
         const uint32_t other = (uint32_t)__shfl_xor((int)mine, 1, 64);
+        h[i] = (mine & ~odd) | (other & odd);
+        h[4 + i] = (other & ~odd) | (mine & odd);
+    }
+}
+
+// ---- E_K walked by a PAIR of lanes (round 4: long belt-hash chains) -------------------------------------------------------
+// A lone chain is bound by the latency of its dependent instructions and LDS round trips (profiles/r04_long_hash_ab.txt), and
+// the seven G-boxes of a round have dependency depth FOUR:
+//     level 1   b ^= G5(a + k0)        ||  c ^= G21(d + k1)
+//     level 2   a -= G13(b + k2)       ||  e = G21(b + c + k3) ^ i;  b += e;  c -= e
+//     level 3   d += G13(c + k4)       ||  b ^= G21(a + k5)
+//     level 4   c ^= G5(d + k6)
+// Lane P (rQ = 0) takes the left column, lane Q (rQ = all-ones) the right one; each G-box result goes to the partner by DPP
+// (quad_perm 1,0,3,2), folded into the consuming instruction where the compiler can.  So that both lanes run the SAME
+// instructions on the same registers, Q keeps the state mirrored -- (w, u, v, z) = (a, b, c, d) in P, (d, c, b, a) in Q -- its
+// round keys shifted by one (Ks[j] = K[j + 1]), and the rotation its G-box needs on top of the table's (G21 from the G5 / G13
+// look-up: 16 / 8 more) is one v_alignbit with a per-lane amount.  Both lanes end with the whole block.
+__device__ __forceinline__ uint32_t dpp_swap1(uint32_t x)      // the value of the other lane of the pair
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);    // quad_perm [1, 0, 3, 2]
+}
+template <int I, class Tab>
+__device__ __forceinline__ void belt_round_split(const Tab &T, uint32_t &w, uint32_t &u, uint32_t &v, uint32_t &z,
+                                                 const uint32_t (&K)[8], const uint32_t (&Ks)[8], uint32_t rQ, uint32_t sh16,
+                                                 uint32_t sh8)
+{
+    constexpr int o = 7 * I - 7;
+    const uint32_t nQ = ~rQ;
+    GParts g;
+    uint32_t gg, og, t;
+    // level 1
+    g = T.template g<0>(w + Ks[(o + 0) & 7]);
+    gg = __builtin_amdgcn_alignbit(g.p ^ g.q, g.p ^ g.q, sh16);
+    u ^= gg;
+    v ^= dpp_swap1(gg);
+    // level 2
+    g = T.template g<1>(u + (v & rQ) + Ks[(o + 2) & 7]);
+    t = xor3(g.p, g.q, ((uint32_t)I << 24) & rQ);               // e = G21(..) ^ i: i goes in BEFORE the 8 extra bits of rotation
+    gg = __builtin_amdgcn_alignbit(t, t, sh8);
+    og = dpp_swap1(gg);
+    t = (og & nQ) | ((0u - gg) & rQ);                           // P: e from Q;  Q: -e (its own)
+    u += t;
+    v -= t;
+    w -= gg & nQ;                                               // P: a -= G13(b + k2)
+    z -= og & rQ;                                               // Q: the same a, from P
+    // level 3
+    g = T.template g<1>(((v & nQ) | (z & rQ)) + Ks[(o + 4) & 7]);
+    gg = __builtin_amdgcn_alignbit(g.p ^ g.q, g.p ^ g.q, sh8);
+    og = dpp_swap1(gg);
+    z += gg & nQ;                                               // P: d += G13(c + k4)
+    v ^= gg & rQ;                                               // Q: b ^= G21(a + k5)
+    u ^= og & nQ;                                               // P: b ^= (from Q)
+    w += og & rQ;                                               // Q: d += (from P)
+    // level 4: both lanes the same G-box
+    g = T.template g<0>(((z & nQ) | (w & rQ)) + K[(o + 6) & 7]);
+    t = g.p ^ g.q;
+    v ^= t & nQ;
+    u ^= t & rQ;
+}
+template <class Tab>
+__device__ __forceinline__ void belt_encr_split(const Tab &T, uint32_t (&x)[4], const uint32_t (&K)[8], uint32_t rQ)
+{
+    const uint32_t nQ = ~rQ;
+    const uint32_t sh16 = rQ & 16u, sh8 = rQ & 24u;             // v_alignbit amounts: rotate left by 16 / 8 in lane Q, by 0 in lane P
+    uint32_t Ks[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Ks[j] = (K[j] & nQ) | (K[(j + 1) & 7] & rQ);
+    uint32_t w = (x[0] & nQ) | (x[3] & rQ), u = (x[1] & nQ) | (x[2] & rQ), v = (x[2] & nQ) | (x[1] & rQ), z = (x[3] & nQ) | (x[0] & rQ);
+    belt_round_split<1>(T, w, u, v, z, K, Ks, rQ, sh16, sh8);
+    belt_round_split<2>(T, u, z, w, v, K, Ks, rQ, sh16, sh8);
+    belt_round_split<3>(T, z, v, u, w, K, Ks, rQ, sh16, sh8);
+    belt_round_split<4>(T, v, w, z, u, K, Ks, rQ, sh16, sh8);
+    belt_round_split<5>(T, w, u, v, z, K, Ks, rQ, sh16, sh8);
+    belt_round_split<6>(T, u, z, w, v, K, Ks, rQ, sh16, sh8);
+    belt_round_split<7>(T, z, v, u, w, K, Ks, rQ, sh16, sh8);
+    belt_round_split<8>(T, v, w, z, u, K, Ks, rQ, sh16, sh8);
+    // logical (a, b, c, d) = (w, u, v, z) in P, (z, v, u, w) in Q; the block is (b, d, a, c)
+    x[0] = (u & nQ) | (v & rQ);
+    x[1] = (z & nQ) | (w & rQ);
+    x[2] = (w & nQ) | (z & rQ);
+    x[3] = (v & nQ) | (u & rQ);
+}
+
+// The compression by a QUAD of lanes that all hold h and X: lanes {0, 1} and {2, 3} are two such pairs; the first encryption
+// is walked by both pairs (the same values), the two independent ones of the second stage by one pair each (`odd` = all-ones
+// in lanes 2, 3), and the halves are swapped across the pairs.
+template <class Tab>
+__device__ __forceinline__ void belt_compress_quad(const Tab &T, uint32_t (&s1)[4], uint32_t (&h)[8], const uint32_t (&X)[8],
+                                                   uint32_t rQ /* lane bit 0 */, uint32_t odd /* lane bit 1 */)
+{
+    uint32_t uu[4], key[8], y[4], xs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { uu[i] = h[i] ^ h[4 + i]; s1[i] = uu[i]; }
+    belt_encr_split(T, s1, X, rQ);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s1[i] ^= uu[i];
+        key[i] = s1[i] ^ odd;                                   // s1 | ~s1
+        key[4 + i] = (h[4 + i] & ~odd) | (h[i] & odd);          // h1 | h0
+        xs[i] = (X[i] & ~odd) | (X[4 + i] & odd);               // X0 | X1
+        y[i] = xs[i];
+    }
+    belt_encr_split(T, y, key, rQ);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t mine = y[i] ^ xs[i];                     // h0' in lanes 0, 1; h1' in lanes 2, 3
+        const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x4E, 0xF, 0xF, false);   // quad_perm [2, 3, 0, 1]
+        h[i] = (mine & ~odd) | (other & odd);
+        h[4 + i] = (other & ~odd) | (mine & odd);
+    }
+}
+
+// ---- E_K with every G-box shared by a QUAD of lanes, one S-box byte each (round 4) -----------------------------------------
+// The level-split above leaves the chain as slow as it was (profiles/r04_long_hash_ab.txt: same instruction count per lane --
+// a lone wavefront is bound by the instructions it issues, ~5 cycles each, with the LDS round trip mostly hidden).  This form
+// cuts the instructions per G-box instead: all four lanes of a quad hold the same (a, b, c, d) and compute x = a + k, lane j
+// extracts byte j (v_bfe with its own shift), looks up ONE entry -- table (R0 + j) mod 4, a per-lane offset -- and two
+// v_xor_b32_dpp (quad_perm 1,0,3,2 then 2,3,0,1) leave G(x) in all four: add, bfe, shift-add, ds_read, wait, xor, xor, apply =
+// 8 instructions where one lane alone needs 13.
+struct BeltQuadLane {
+    uint32_t sh;            // 8 j
+    uint32_t off[3];        // byte offsets of table (R0 + j) mod 4 for R0 = 0 (G5), 1 (G13), 2 (G21)
+    __device__ explicit BeltQuadLane(unsigned j)
+    {
+        sh = 8u * j;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) off[r] = ((r + j) & 3u) * 1024u;
+    }
+};
+template <int R0>
+__device__ __forceinline__ uint32_t gbox_quad(const uint8_t *lds, const BeltQuadLane &Q, uint32_t x)
+{
+    const uint32_t b = __builtin_amdgcn_ubfe(x, Q.sh, 8u);
+    uint32_t t = *reinterpret_cast<const uint32_t *>(lds + ((b << 2) + Q.off[R0]));
+    t ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0xB1, 0xF, 0xF, false);      // quad_perm [1, 0, 3, 2]
+    t ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x4E, 0xF, 0xF, false);      // quad_perm [2, 3, 0, 1]
+    return t;
+}
+template <int I>
+__device__ __forceinline__ void belt_round_quad(const uint8_t *lds, const BeltQuadLane &Q, uint32_t &a, uint32_t &b, uint32_t &c,
+                                                uint32_t &d, const uint32_t (&K)[8])
+{
+    constexpr int o = 7 * I - 7;
+    b ^= gbox_quad<0>(lds, Q, a + K[(o + 0) & 7]);
+    c ^= gbox_quad<2>(lds, Q, d + K[(o + 1) & 7]);
+    a -= gbox_quad<1>(lds, Q, b + K[(o + 2) & 7]);
+    const uint32_t e = gbox_quad<2>(lds, Q, b + c + K[(o + 3) & 7]) ^ (uint32_t)I;
+    b += e;
+    c -= e;
+    d += gbox_quad<1>(lds, Q, c + K[(o + 4) & 7]);
+    b ^= gbox_quad<2>(lds, Q, a + K[(o + 5) & 7]);
+    c ^= gbox_quad<0>(lds, Q, d + K[(o + 6) & 7]);
+}
+// lds: a BeltTabSmall image (4 tables of 256 dwords, rotations 5, 13, 21, 29)
+__device__ __forceinline__ void belt_encr_quad(const uint8_t *lds, const BeltQuadLane &Q, uint32_t (&x)[4], const uint32_t (&K)[8])
+{
+    uint32_t a = x[0], b = x[1], c = x[2], d = x[3];
+    belt_round_quad<1>(lds, Q, a, b, c, d, K);
+    belt_round_quad<2>(lds, Q, b, d, a, c, K);
+    belt_round_quad<3>(lds, Q, d, c, b, a, K);
+    belt_round_quad<4>(lds, Q, c, a, d, b, K);
+    belt_round_quad<5>(lds, Q, a, b, c, d, K);
+    belt_round_quad<6>(lds, Q, b, d, a, c, K);
+    belt_round_quad<7>(lds, Q, d, c, b, a, K);
+    belt_round_quad<8>(lds, Q, c, a, d, b, K);
+    x[0] = b; x[1] = d; x[2] = a; x[3] = c;
+}
+// the compression by EIGHT lanes that all hold h and X: two such quads; the first encryption by both (the same values), the two
+// independent ones of the second stage by one quad each (`odd` = all-ones in lanes 4-7), halves swapped across the quads
+__device__ __forceinline__ void belt_compress_oct(const uint8_t *lds, const BeltQuadLane &Q, uint32_t (&s1)[4], uint32_t (&h)[8],
+                                                  const uint32_t (&X)[8], uint32_t odd)
+{
+    uint32_t uu[4], key[8], y[4], xs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { uu[i] = h[i] ^ h[4 + i]; s1[i] = uu[i]; }
+    belt_encr_quad(lds, Q, s1, X);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s1[i] ^= uu[i];
+        key[i] = s1[i] ^ odd;
+        key[4 + i] = (h[4 + i] & ~odd) | (h[i] & odd);
+        xs[i] = (X[i] & ~odd) | (X[4 + i] & odd);
+        y[i] = xs[i];
+    }
+    belt_encr_quad(lds, Q, y, key);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t mine = y[i] ^ xs[i];
+        const uint32_t other = (uint32_t)__shfl_xor((int)mine, 4, 64);
         h[i] = (mine & ~odd) | (other & odd);
         h[4 + i] = (other & ~odd) | (mine & odd);
     }

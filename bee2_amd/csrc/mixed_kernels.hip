@@ -630,7 +630,11 @@ err_t launch_belt_hash_stream(void *d_hs, const void *d_data, size_t nblocks, in
 // Launched over all n messages (2 lanes each); pairs whose message is short leave at once.
 // (round 4) templated on the table and the workgroup for the A/B of profiles/r04_long_hash_ab.txt; a workgroup none of whose
 // pairs has a long message leaves before it fills the table (the caller sorts long messages to the front).
-template <class Tab, int LONG_WG>
+// LANES = 2: a pair per message (belt_compress_pair); LANES = 4 (round 4): a quad -- each encryption walked by two lanes that
+// split the rounds' G-boxes (belt_encr_split: 4 levels of a round instead of 7 steps), the two second-stage encryptions by
+// the two pairs of the quad.  LANES = 8: every G-box shared by a quad, one S-box byte per lane (belt_encr_quad), two quads for the
+// second stage.
+template <class Tab, int LONG_WG, int LANES = 2>
 __global__ __launch_bounds__(LONG_WG)
 void belt_hash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off,
                            const uint32_t *__restrict__ order, size_t n, uint8_t *__restrict__ digests,
@@ -644,8 +648,17 @@ void belt_hash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__r
     __shared__ __attribute__((aligned(16))) uint8_t smem_static[STATIC_TAB ? Tab::kBytes : 16];
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_dyn[];
     uint8_t *smem = STATIC_TAB ? smem_static : smem_dyn;
-    const size_t slot = ((size_t)blockIdx.x * LONG_WG + threadIdx.x) >> 1;
-    const uint32_t odd = (threadIdx.x & 1u) ? ~0u : 0u;
+    static_assert(LANES == 2 || LANES == 4 || LANES == 8, "lanes per message");
+    const size_t slot = ((size_t)blockIdx.x * LONG_WG + threadIdx.x) / LANES;
+    const uint32_t odd = (threadIdx.x & (unsigned)(LANES / 2)) ? ~0u : 0u;        // which second-stage encryption the lane (pair / quad) walks
+    const uint32_t rQ = (threadIdx.x & 1u) ? ~0u : 0u;                           // LANES == 4: the lane's column of the split rounds
+    const BeltQuadLane QL(threadIdx.x & 3u);                                     // LANES == 8: the lane's S-box byte
+    (void)rQ; (void)QL;
+    const auto compress = [&](uint32_t (&s1)[4], uint32_t (&h)[8], const uint32_t (&X)[8], const Tab &T) {
+        if constexpr (LANES == 8) belt_compress_oct(T.lds, QL, s1, h, X, odd);     // (a BeltTabSmall image)
+        else if constexpr (LANES == 4) belt_compress_quad(T, s1, h, X, rQ, odd);
+        else belt_compress_pair(T, s1, h, X, odd);
+    };
     size_t i = 0, len = 0;
     if (slot < n) {
         i = order ? order[slot] : slot;
@@ -695,7 +708,7 @@ void belt_hash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__r
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) X[k] = __builtin_amdgcn_alignbit(W[k + 1], W[k], sh);
-            belt_compress_pair(T, s1, h, X, odd);
+            compress(s1, h, X, T);
 #pragma unroll
             for (int k = 0; k < 4; ++k) s[k] ^= s1[k];
 #pragma unroll
@@ -714,14 +727,14 @@ void belt_hash_long_kernel(const uint8_t *__restrict__ data, const uint64_t *__r
             }
             X[k] = v;
         }
-        belt_compress_pair(T, s1, h, X, odd);
+        compress(s1, h, X, T);
 #pragma unroll
         for (int k = 0; k < 4; ++k) s[k] ^= s1[k];
     }
     const uint64_t bits_lo = (uint64_t)len << 3, bits_hi = (uint64_t)len >> 61;
     X[0] = (uint32_t)bits_lo; X[1] = (uint32_t)(bits_lo >> 32); X[2] = (uint32_t)bits_hi; X[3] = 0;
     X[4] = s[0]; X[5] = s[1]; X[6] = s[2]; X[7] = s[3];
-    belt_compress_pair(T, s1, h, X, odd);
+    compress(s1, h, X, T);
     if (!odd) {
         uint8_t *d = digests + 32 * i;
 #pragma unroll
@@ -806,7 +819,22 @@ err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, cons
     const dim3 gl((unsigned)((n * 8 + 63) / 64));
     if (alg == 0) {
 #ifdef BEE2HIP_EXPERIMENTS      // A/B (tune 16, tools/long_hash_ab.py, profiles/r04_long_hash_ab.txt): the SDWA table in one-wavefront / four-wavefront workgroups
-        if (g_long_hash_form == 2 || g_long_hash_form == 3) {
+        if (g_long_hash_form == 1) {      // the pair form (round 3's product) at every size
+            hipLaunchKernelGGL((belt_hash_long_kernel<BeltTabSmall, 64, 2>), dim3((unsigned)((n * 2 + 63) / 64)), dim3(64), 0, st, data, off, ord, n,
+                               dig, RAGGED_LONG);
+        } else if (g_long_hash_form == 7) {      // eight lanes per message: each G-box shared by a quad (one byte look-up per lane)
+            hipLaunchKernelGGL((belt_hash_long_kernel<BeltTabSmall, 64, 8>), dim3((unsigned)((n * 8 + 63) / 64)), dim3(64), 0, st, data, off, ord,
+                               n, dig, RAGGED_LONG);
+        } else if (g_long_hash_form == 5 || g_long_hash_form == 6) {      // a quad per message, rounds split over two lanes (4 KiB table / + SDWA addresses)
+            const dim3 gq((unsigned)((n * 4 + 63) / 64));
+            if (g_long_hash_form == 5)
+                hipLaunchKernelGGL((belt_hash_long_kernel<BeltTabSmall, 64, 4>), gq, dim3(64), 0, st, data, off, ord, n, dig, RAGGED_LONG);
+            else
+                hipLaunchKernelGGL((belt_hash_long_kernel<BeltTabSmallS, 64, 4>), gq, dim3(64), 0, st, data, off, ord, n, dig, RAGGED_LONG);
+        } else if (g_long_hash_form == 4) {
+            hipLaunchKernelGGL((belt_hash_long_kernel<BeltTabSmallS, 64>), dim3((unsigned)((n * 2 + 63) / 64)), dim3(64), 0, st, data, off, ord, n,
+                               dig, RAGGED_LONG);
+        } else if (g_long_hash_form == 2 || g_long_hash_form == 3) {
             const int wg = g_long_hash_form == 2 ? 64 : 256;
             const void *kern = wg == 64 ? reinterpret_cast<const void *>(belt_hash_long_kernel<BeltTabTwoP, 64>)
                                         : reinterpret_cast<const void *>(belt_hash_long_kernel<BeltTabTwoP, 256>);
@@ -819,12 +847,20 @@ err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, cons
                                    st, data, off, ord, n, dig, RAGGED_LONG);
         } else
 #endif
-        // product: the 4 KiB table in one-wavefront workgroups.  A long message is ONE dependent chain on a lone wavefront, bound by
-        // the LATENCY of its dependent instructions, not by their number: the SDWA-address table that gave the CTR kernel
-        // +15 % (8 instead of 12 VALU per G-box, but a deeper chain behind each look-up) makes this kernel 1.55x SLOWER
-        // (39 -> 61 ms for a 256 KiB message, profiles/r04_long_hash_ab.txt)
-        hipLaunchKernelGGL((belt_hash_long_kernel<BeltTabSmall, 64>), dim3((unsigned)((n * 2 + 63) / 64)), dim3(64), 0, st, data, off, ord, n, dig,
-                           RAGGED_LONG);
+        // product (round 4): EIGHT lanes per long message -- every G-box shared by a quad, one S-box byte per lane, the two second-stage
+        // encryptions on two quads (belt_compress_oct: 11.6 instead of 17 instructions per G-box and lane; a lone wavefront's chain
+        // goes with the instructions it issues): 256 KiB in 26.6 ms against 32.5 ms for the pair form (round 3: 39).  Four times
+        // the lanes, though: batches of more than 2^16 messages (where long ones could fill the SIMDs many times over) keep the pair
+        // form.  4 KiB table in STATIC shared memory either way.  profiles/r04_long_hash_ab.txt has the A/B of all forms, incl.
+        // the SDWA-address table (1.9x slower on a chain) and the rounds split over two lanes (no gain).
+        {
+        if (n <= ((size_t)1 << 16))
+            hipLaunchKernelGGL((belt_hash_long_kernel<BeltTabSmall, 64, 8>), dim3((unsigned)((n * 8 + 63) / 64)), dim3(64), 0, st, data, off, ord, n,
+                               dig, RAGGED_LONG);
+        else
+            hipLaunchKernelGGL((belt_hash_long_kernel<BeltTabSmall, 64, 2>), dim3((unsigned)((n * 2 + 63) / 64)), dim3(64), 0, st, data, off, ord, n,
+                               dig, RAGGED_LONG);
+        }
     if (n >= 32768) {
             // big table; 256-thread workgroups until there are enough messages to fill 1024-thread ones on every CU
             const bool wide = n >= (size_t)num_cus() * 1024;

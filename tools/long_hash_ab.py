@@ -38,11 +38,11 @@ def run(lens, form, reps=3):
 
 
 rng = np.random.default_rng(0x4D1C)
-cases = {"one 256 KiB message": [1 << 18], "64 x 256 KiB": [1 << 18] * 64, "4096 x 256 KiB": [1 << 18] * 4096,
+cases = {"131072 x 8 KiB (beyond 2^16 messages: product = pair form)": [1 << 13] * (1 << 17), "one 256 KiB message": [1 << 18], "64 x 256 KiB": [1 << 18] * 64, "4096 x 256 KiB": [1 << 18] * 4096,
          "4096 x 16 KiB": [1 << 14] * 4096,
          "bench ragged (65536, log-uniform < 256 KiB)": (np.floor(2.0 ** (18.0 * rng.random(1 << 16))).astype(np.int64) - 1).tolist()}
-print("ms per batch: 4 KiB table, one-wavefront workgroups (product) | SDWA table WG 64 | SDWA table WG 256")
+print("ms per batch: pair per message, 4 KiB table (r03 product) | pair, SDWA shift addresses | QUAD (rounds split over 2 lanes) | EIGHT lanes (each G-box shared by a quad: one byte per lane) = product up to 2^16 messages")
 for name, lens in cases.items():
-    out = [run(lens, f) for f in (0, 2, 3)]
-    assert out[0][1] == out[1][1] == out[2][1], name
-    print(f"{name:48s} {out[0][0]:9.2f} {out[1][0]:9.2f} {out[2][0]:9.2f}")
+    out = [run(lens, f) for f in (1, 4, 5, 0)]
+    assert all(o[1] == out[0][1] for o in out), name
+    print(f"{name:48s} " + " ".join(f"{o[0]:9.2f}" for o in out))
