@@ -391,6 +391,43 @@ struct DuplexStreams {
 };
 static thread_local DuplexStreams t_duplex;
 
+// A second queue of the calling thread on the current device, with the two events of a fork / join around it (common.hpp
+// side_stream): launchers whose two kernels are independent put the second one there -- launch_hash_ragged's long chains
+// (latency-bound, a few wavefronts) and its short messages (throughput-bound) then share the chip instead of queueing.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int dev = -1;
+    void drop()
+    {
+        if (s) { scratch_release_stream(s); (void)hipStreamDestroy(s); }
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
+        s = nullptr; fork = join = nullptr;
+    }
+    err_t get()
+    {
+        int cur = 0;
+        B2H_TRY(hipGetDevice(&cur));
+        if (s && cur == dev) return ERR_OK;
+        drop();
+        B2H_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        B2H_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        B2H_TRY(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+        dev = cur;
+        return ERR_OK;
+    }
+    ~SideStream() { if (s && !on_loader_thread()) drop(); }
+};
+static thread_local SideStream t_side;
+err_t side_stream(hipStream_t *side, hipEvent_t *fork, hipEvent_t *join)
+{
+    const err_t code = t_side.get();
+    if (code != ERR_OK) { t_side.drop(); return code; }
+    *side = t_side.s; *fork = t_side.fork; *join = t_side.join;
+    return ERR_OK;
+}
+
 // *done_units (may be null) = leading units whose results are back in the caller's buffer when the call returns: all of
 // them on success; after a failure the chunks whose download had completed.  A caller that retries or finishes on the host
 // MUST skip them -- they have been transformed in place already (a second CTR pass would decrypt them again).
@@ -1683,7 +1720,7 @@ extern "C" unsigned long long bee2hip_path_count(int which)
 #ifdef BEE2HIP_EXPERIMENTS      // everything from here to the end of the kernel-timing hook: libbee2hip_exp.so only
 // ============================================================ internal tuning hook ===
 // A/B switch for experiment builds (tools/bashf_ab.py); not part of the product ABI (BEE2HIP_INTERNAL).
-namespace bee2hip { void set_bashF_variant(int v); void set_ctr_variant(int v); void set_verify_path(int v); void set_verify_split(int v); void set_sign_coop(int v); void set_sign_wg(int v); void set_fused_tab(int v); void set_long_hash_form(int v); }
+namespace bee2hip { void set_bashF_variant(int v); void set_ctr_variant(int v); void set_verify_path(int v); void set_verify_split(int v); void set_sign_coop(int v); void set_sign_wg(int v); void set_fused_tab(int v); void set_long_hash_form(int v); void set_ragged_fork(int v); }
 extern "C" err_t bee2hip_internal_tune(int key, int value)
 {
     switch (key) {
@@ -1702,6 +1739,7 @@ extern "C" err_t bee2hip_internal_tune(int key, int value)
     case 9: bee2hip::g_duplex_ramp = value; return ERR_OK;            // ramped chunk sizes at the ends of the pipeline
     case 13: bee2hip::set_fused_tab(value); return ERR_OK;            // belt table of the fused bash + belt-mac kernel (A/B)
     case 16: bee2hip::set_long_hash_form(value); return ERR_OK;        // table / workgroup of the long belt-hash kernel (A/B)
+    case 17: bee2hip::set_ragged_fork(value); return ERR_OK;           // ragged hashing: long chains and short messages on two queues (1) or one (0)
     case 14: bee2hip::g_duplex_fail_chunk.store(value); return ERR_OK;   // tests: the duplex host pipeline fails at this chunk (1-based) ...
     case 15: bee2hip::g_duplex_fail_times.store(value); return ERR_OK;   // ... in the next `value` pipelines
     default: return ERR_BAD_INPUT;

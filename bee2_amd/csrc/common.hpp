@@ -26,6 +26,8 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 // different streams never share a buffer, two on the same stream are ordered by the stream.
 // Grown on demand; growing frees the old block only after the stream has drained.
 err_t scratch_for_stream(hipStream_t st, int slot, size_t bytes, void **out);
+// a library-owned second queue of the calling thread on the current device and the events of a fork / join around it (capi.hip)
+err_t side_stream(hipStream_t *side, hipEvent_t *fork, hipEvent_t *join);
 const uint8_t *host_beltH();                              // the belt S-box, generated once on the host (capi.hip)
 
 // per-device launch facts and the once-per-(device, kernel) dynamic-LDS grant (belt_kernels.hip)

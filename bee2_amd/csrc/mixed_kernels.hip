@@ -790,6 +790,10 @@ void ragged_scatter_kernel(const uint64_t *__restrict__ off, size_t n, unsigned 
 static int g_long_hash_form = 0;
 void set_long_hash_form(int v) { g_long_hash_form = v; }
 #endif
+static int g_ragged_fork = 1;               // long chains and short messages on two queues (0: one queue, the A/B of tools/long_hash_ab.py)
+#ifdef BEE2HIP_EXPERIMENTS
+void set_ragged_fork(int v) { g_ragged_fork = v; }
+#endif
 constexpr uint64_t RAGGED_LONG = 4096;     // bytes; see bench.py --only ragged and DESIGN.md 4.7
 err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, const void *d_order, size_t n,
                          void *d_digests, hipStream_t st)
@@ -817,6 +821,18 @@ err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, cons
     // bash: messages of >= RAGGED_LONG bytes go to the 8-lanes-per-message kernel (a 4x shorter serial chain),
     // the rest stay one lane each; both launches cover all n messages and each skips what is not its own
     const dim3 gl((unsigned)((n * 8 + 63) / 64));
+    // The two launches are independent (disjoint messages, disjoint digests): the long chains are a few latency-bound wavefronts
+    // that leave most of the chip idle for tens of milliseconds, the short messages a throughput kernel.  Queued on ONE stream the
+    // second waits for the first; forked onto the thread's side stream (joined before returning to the caller's stream order) they
+    // share the chip (round 4: the bench's ragged batch 32.4 -> 31.0 ms, profiles/r04_long_hash_ab.txt).  Small batches stay on one queue.
+    hipStream_t st2 = st;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    const bool forked = n >= 1024 && g_ragged_fork && side_stream(&st2, &ev_fork, &ev_join) == ERR_OK;
+    if (forked) {
+        B2H_TRY(hipEventRecord(ev_fork, st));
+        B2H_TRY(hipStreamWaitEvent(st2, ev_fork, 0));
+    } else
+        st2 = st;
     if (alg == 0) {
 #ifdef BEE2HIP_EXPERIMENTS      // A/B (tune 16, tools/long_hash_ab.py, profiles/r04_long_hash_ab.txt): the SDWA table in one-wavefront / four-wavefront workgroups
         if (g_long_hash_form == 1) {      // the pair form (round 3's product) at every size
@@ -869,26 +885,30 @@ err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, cons
             B2H_TRY(dyn_lds_once(kern, BeltTabTwo::kBytes));
             if (wide)
                 hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabTwoP, 1024>), dim3((unsigned)((n + 1023) / 1024)),
-                                   dim3(1024), BeltTabTwo::kBytes, st, data, off, ord, n, dig, RAGGED_LONG);
+                                   dim3(1024), BeltTabTwo::kBytes, st2, data, off, ord, n, dig, RAGGED_LONG);
             else
                 hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabTwoP, 256>), dim3((unsigned)((n + 255) / 256)),
-                                   dim3(256), BeltTabTwo::kBytes, st, data, off, ord, n, dig, RAGGED_LONG);
+                                   dim3(256), BeltTabTwo::kBytes, st2, data, off, ord, n, dig, RAGGED_LONG);
         } else {
-            hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabSmall, 64>), g, t, 0, st, data, off, ord, n, dig, RAGGED_LONG);
+            hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabSmall, 64>), g, t, 0, st2, data, off, ord, n, dig, RAGGED_LONG);
         }
     }
     else if (alg == 256) {
         hipLaunchKernelGGL(bash_long_kernel<8>, gl, t, 0, st, data, off, ord, n, 256u, dig, RAGGED_LONG);
-        hipLaunchKernelGGL(bash_ragged_kernel<8>, g, t, 0, st, data, off, ord, n, 256u, dig, RAGGED_LONG);
+        hipLaunchKernelGGL(bash_ragged_kernel<8>, g, t, 0, st2, data, off, ord, n, 256u, dig, RAGGED_LONG);
     } else if (alg == 192) {
         hipLaunchKernelGGL(bash_long_kernel<12>, gl, t, 0, st, data, off, ord, n, 192u, dig, RAGGED_LONG);
-        hipLaunchKernelGGL(bash_ragged_kernel<12>, g, t, 0, st, data, off, ord, n, 192u, dig, RAGGED_LONG);
+        hipLaunchKernelGGL(bash_ragged_kernel<12>, g, t, 0, st2, data, off, ord, n, 192u, dig, RAGGED_LONG);
     } else if (alg == 128) {
         hipLaunchKernelGGL(bash_long_kernel<16>, gl, t, 0, st, data, off, ord, n, 128u, dig, RAGGED_LONG);
-        hipLaunchKernelGGL(bash_ragged_kernel<16>, g, t, 0, st, data, off, ord, n, 128u, dig, RAGGED_LONG);
+        hipLaunchKernelGGL(bash_ragged_kernel<16>, g, t, 0, st2, data, off, ord, n, 128u, dig, RAGGED_LONG);
     }
     else return ERR_NOT_IMPLEMENTED;
     B2H_TRY(hipGetLastError());
+    if (forked) {
+        B2H_TRY(hipEventRecord(ev_join, st2));
+        B2H_TRY(hipStreamWaitEvent(st, ev_join, 0));
+    }
     return ERR_OK;
 }
 

@@ -384,3 +384,41 @@ def test_host_pointer_ragged_batch_hands_its_few_giant_messages_to_host_threads(
         L.bee2hip_path_policy(0)
         if alg == 0:
             assert times[0] < 0.5 * times[1], times          # the 1 MiB belt-hash chain alone is ~0.13 s on a lane pair
+
+
+def test_ragged_batch_on_two_queues_keeps_the_callers_stream_order(orc):
+    """bee2hip_hash_ragged_dev puts the long chains on the caller's stream and the short messages on the calling thread's side
+    stream (batches of 1024 messages and more): the fork must wait for what the caller queued before the call (the upload of the
+    messages), the join must hold back what the caller queues after it (here: the buffer is overwritten and the digests are
+    copied out, all on one non-default stream, no synchronisation in between).  Digests against the oracle, three rounds, belt-hash
+    and bash256; a batch under 1024 messages (one queue) beside it."""
+    import random
+    eng = engine()
+    rnd = random.Random(4242)
+    for n in (1500, 700):
+        lens = [rnd.choice((0, 7, 32, 100, 999, 2000, 4095)) for _ in range(n)]
+        for k in rnd.sample(range(n), 12):
+            lens[k] = rnd.choice((4096, 5000, 20000, 70001))
+        offs = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=offs[1:])
+        total = int(offs[-1])
+        doff = torch.from_numpy(offs).cuda()
+        side = torch.cuda.Stream()
+        for rnd_no, (alg, dl) in enumerate(((0, 32), (128, 32), (0, 32))):
+            blob = rnd.randbytes(total)
+            staged = torch.from_numpy(np.frombuffer(blob + bytes(16), dtype=np.uint8).copy()).pin_memory()
+            data = torch.empty(total + 16, dtype=torch.uint8, device="cuda")
+            dig = torch.zeros(n * dl, dtype=torch.uint8, device="cuda")
+            out = torch.empty(n * dl, dtype=torch.uint8).pin_memory()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                data.copy_(staged, non_blocking=True)               # queued BEFORE the call
+                eng.hash_ragged_dev(alg, data, doff, dig, n)
+                data.fill_(0xA5)                                    # queued AFTER it: must not reach either kernel
+                out.copy_(dig, non_blocking=True)
+            side.synchronize()
+            got = out.numpy().tobytes()
+            for i in range(n):
+                m = blob[offs[i]:offs[i + 1]]
+                want = orc.belt_hash(m) if alg == 0 else orc.bashHash(alg, m)[1]
+                assert got[dl * i: dl * i + dl] == want, (n, rnd_no, alg, i, len(m))
