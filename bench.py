@@ -94,16 +94,20 @@ def mixed_roofline(msgs_per_s_per_gpu, perms_per_s, blocks_per_s, src):
 
 
 def device_identity(index):
-    """something that names the physical GPU behind a HIP device index (two ranks on one card must not count as two)"""
+    """something that names the physical GPU behind a HIP device index (two ranks on one card must not count as two): the index
+    itself AND whatever the runtime knows about the card.  All parts together: a box whose cards all report the same (e.g. zero)
+    uuid still counts N devices when the ranks sit on N indices, and ranks that each see one card as index 0 (a launcher that
+    sets HIP_VISIBLE_DEVICES per rank) are told apart by uuid / PCI bus id."""
+    parts = [f"index:{index}"]
     try:
         p = torch.cuda.get_device_properties(index)
-        for attr in ("uuid", "pci_bus_id"):
+        for attr in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
             v = getattr(p, attr, None)
             if v not in (None, ""):
-                return f"{attr}:{v}"
+                parts.append(f"{attr}:{v}")
     except Exception:
         pass
-    return f"index:{index}"
+    return "|".join(parts)
 
 
 def check_distinct_devices(ids, world, backend):

@@ -57,6 +57,25 @@ def test_distinct_device_rule_and_mixed_roofline_arithmetic():
     assert b.check_distinct_devices(["a", "a"], 2, "gloo") == 1
     with pytest.raises(SystemExit):
         b.check_distinct_devices(["a", "a"], 2, "nccl")
+    # a card's identity = its index AND what the runtime reports: cards that all report one uuid still count by index, ranks
+    # that each see their card as index 0 are told apart by uuid, two ranks on one card are one device
+    class P:
+        def __init__(self, uuid, bus): self.uuid, self.pci_bus_id = uuid, bus
+    props = {}
+    real = b.torch.cuda.get_device_properties
+    b.torch.cuda.get_device_properties = lambda i: props[i]
+    try:
+        props.update({0: P("00000000", 1), 1: P("00000000", 1)})
+        assert b.check_distinct_devices([b.device_identity(0), b.device_identity(1)], 2, "nccl") == 2
+        ids = []
+        for u in ("GPU-aa", "GPU-bb"):
+            props[0] = P(u, 3)
+            ids.append(b.device_identity(0))
+        assert b.check_distinct_devices(ids, 2, "nccl") == 2
+        props[0] = P("GPU-aa", 3)
+        assert b.check_distinct_devices([b.device_identity(0), b.device_identity(0)], 2, "gloo") == 1
+    finally:
+        b.torch.cuda.get_device_properties = real
     # round 3's numbers: 11.05 G perm/s and 941 GiB/s of blocks -> sum of parts 100.4 M msg/s, overlap ceiling 170 M
     r = b.mixed_roofline(99.9e6, 11.05e9, 941.4 * 2 ** 30 / 16, "test")
     assert abs(r["sum_of_parts_ceiling"] / 1e6 - 100.5) < 0.5 and abs(r["peak"] / 1e6 - 170.0) < 0.5
