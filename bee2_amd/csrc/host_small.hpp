@@ -208,6 +208,21 @@ static inline void mac_step(const BeltTables &T, const uint32_t key[8], uint32_t
     }
     if (mode & 2) {
         size_t f = *filled;
+        if (f == 16 && count) {                  // whole blocks straight from the caller's buffer: the buffered block goes first, and
+            uint32_t b[4];                       // the LAST 1..16 octets of buf stay behind in `block` (belt_mac.c:75-99)
+            ld_block(b, block);
+            for (int q = 0; q < 4; ++q) s[q] ^= b[q];
+            belt_encr(T, s, key);
+            f = 0;
+        }
+        if (f == 0)
+            while (count > 16) {
+                uint32_t b[4];
+                ld_block(b, buf);
+                for (int q = 0; q < 4; ++q) s[q] ^= b[q];
+                belt_encr(T, s, key);
+                buf += 16; count -= 16;
+            }
         for (size_t k = 0; k < count; ++k) {
             if (f == 16) {                       // the buffered block is absorbed only when more data follows
                 uint32_t b[4];
@@ -447,39 +462,46 @@ static inline void che_blocks(const BeltTables &T, uint8_t *buf, size_t nblocks,
 }
 // belt-wbl on n >= 2 blocks (STB 34.101.31 6.2 / belt_wbl.c: 2n rounds, round i: s <- r_1 ^ ... ^ r_{n-1};
 // r* <- r_n ^ E_K(s) ^ <i>_128; (r_1 .. r_n) <- (r_2 .. r_{n-1}, r*, s)); decryption runs the rounds backwards.
-// Written from the definition with an explicit shift (n is small on this path).
+// Rolling form (the one of belt_sde_kernel, belt_kernels.hip): the blocks stay where they are and a cyclic head h names the
+// position of the logical r_1; the block a round needs as r_n is the s the previous round wrote, so it is carried in registers,
+// and the XOR of r_1 .. r_{n-1} is updated by the two blocks that change instead of recomputed -- one block read and one block
+// written per round instead of n (round 4: bee2's own beltBench::belt-sde through the drop-in 0.91 -> above the reference).
+// After 2n rounds h is back where it started.
 static inline void wbl(const BeltTables &T, int decr, uint8_t *a, size_t n, const uint32_t key[8])
 {
     const uint64_t rounds = 2ull * n;
-    uint32_t s[4], e[4], rn[4], w[4];
+    uint32_t cur[4] = {0, 0, 0, 0}, w[4], e[4], x[4];
+    for (size_t q = 0; q + 1 < n; ++q) { ld_block(w, a + 16 * q); for (int k = 0; k < 4; ++k) cur[k] ^= w[k]; }
     if (!decr) {
+        uint32_t prev[4];
+        ld_block(prev, a + 16 * (n - 1));                       // logical r_n
+        size_t h = 0;
         for (uint64_t i = 1; i <= rounds; ++i) {
-            s[0] = s[1] = s[2] = s[3] = 0;
-            for (size_t q = 0; q + 1 < n; ++q) { ld_block(w, a + 16 * q); for (int k = 0; k < 4; ++k) s[k] ^= w[k]; }
-            for (int k = 0; k < 4; ++k) e[k] = s[k];
+            for (int k = 0; k < 4; ++k) e[k] = cur[k];
             belt_encr(T, e, key);
             e[0] ^= (uint32_t)i; e[1] ^= (uint32_t)(i >> 32);
-            ld_block(rn, a + 16 * (n - 1));
-            for (int k = 0; k < 4; ++k) rn[k] ^= e[k];
-            memmove(a, a + 16, 16 * (n - 2));                   // r_1 .. r_{n-2} <- r_2 .. r_{n-1}
-            st_block(a + 16 * (n - 2), rn);
-            st_block(a + 16 * (n - 1), s);
+            for (int k = 0; k < 4; ++k) x[k] = prev[k] ^ e[k];  // r* = r_n ^ E_K(s) ^ <i>
+            ld_block(w, a + 16 * h);                            // the r_1 that leaves the sum
+            st_block(a + 16 * (h ? h - 1 : n - 1), x);
+            for (int k = 0; k < 4; ++k) { prev[k] = cur[k]; cur[k] ^= w[k] ^ x[k]; }
+            h = h + 1 == n ? 0 : h + 1;
         }
+        st_block(a + 16 * (n - 1), prev);                       // h == 0 again
     } else {
+        uint32_t sv[4];
+        ld_block(sv, a + 16 * (n - 1));                         // s = logical r_n
+        size_t h = n - 1;
         for (uint64_t i = rounds; i >= 1; --i) {
-            // inverse of a round: r* = r_{n-1}, s = r_n; r_n(old) = r* ^ E_K(s) ^ <i>; r_1(old) = s ^ r_1 ^ .. ^ r_{n-2}
-            ld_block(rn, a + 16 * (n - 2));
-            ld_block(s, a + 16 * (n - 1));
-            for (int k = 0; k < 4; ++k) e[k] = s[k];
+            for (int k = 0; k < 4; ++k) e[k] = sv[k];
             belt_encr(T, e, key);
             e[0] ^= (uint32_t)i; e[1] ^= (uint32_t)(i >> 32);
-            for (int k = 0; k < 4; ++k) rn[k] ^= e[k];
-            uint32_t first[4] = {s[0], s[1], s[2], s[3]};
-            for (size_t q = 0; q + 2 < n; ++q) { ld_block(w, a + 16 * q); for (int k = 0; k < 4; ++k) first[k] ^= w[k]; }
-            memmove(a + 16, a, 16 * (n - 2));                   // r_2 .. r_{n-1} <- r_1 .. r_{n-2}
-            st_block(a, first);
-            st_block(a + 16 * (n - 1), rn);
+            ld_block(x, a + 16 * (h ? h - 1 : n - 1));          // r*
+            for (int k = 0; k < 4; ++k) w[k] = cur[k] ^ sv[k] ^ x[k];
+            st_block(a + 16 * h, w);                            // the r_1 of before the round
+            for (int k = 0; k < 4; ++k) { cur[k] = sv[k]; sv[k] = x[k] ^ e[k]; }
+            h = h ? h - 1 : n - 1;
         }
+        st_block(a + 16 * h, sv);                               // h == n - 1 again
     }
 }
 // belt-sde on one sector (belt_sde.c:47-76): XEX around belt-wbl with the tweak E_K(iv) on the first block

@@ -971,6 +971,20 @@ def main():
                 entry["value"] = entry["belt_hash_longest_first"]
                 entry["steps"] = kr
                 entry["ms_per_step"] = el / kr * 1e3
+                # what bounds it: belt-hash of ONE message is a serial chain (two dependent encryptions per 32 bytes), so the batch
+                # cannot finish before its longest message does -- that message alone, beside the batch
+                big = int(np.argmax(lens))
+                one_off = torch.from_numpy(np.array([0, int(lens[big])], dtype=np.int64)).cuda()
+                one = data[int(offs[big]) // 8 * 8:]                   # (an aligned view; the chain's time does not depend on the bytes)
+                one_dig = torch.empty(32, dtype=torch.uint8, device="cuda")
+                el1 = timed(dist, kr, 1, lambda: eng.hash_ragged_dev(0, one, one_off, one_dig, 1))
+                entry["roofline"] = {"bound": "latency of one serial chain", "longest_message_bytes": int(lens[big]),
+                                     "longest_chain_alone_ms": el1 / kr * 1e3,
+                                     "frac": (el1 / kr) / (el / kr),
+                                     "note": "frac = the longest message hashed ALONE / the whole batch: a lone wavefront gets one "
+                                             "issue slot per 4 cycles and ~56 cycles per LDS round trip, ~3600 cycles per belt "
+                                             "encryption (profiles/r04_long_hash_ab.txt, tools/ubench/lone_chain.hip)"}
+                del one, one_off, one_dig
             if do_cpu:
                 import refgen
                 if refgen.have_ref():

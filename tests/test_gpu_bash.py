@@ -97,3 +97,29 @@ def test_config0_bash256_1MiB_dropin(orc, golden):
     big = orc.fill(golden.big["len"], golden.big["seed"])
     code, d = eng.bashHash(128, big)
     assert code == 0 and d.hex() == golden.big["bash256"]
+
+
+def test_bashF_batch_beyond_4GiB(orc):
+    """Sized for the card: 2^26 states = 12 GiB in ONE launch (byte offsets past 2^32, lane indices past 2^24).  Every state
+    is its own index (in its first 8 octets) over zeros; windows of 2^12 states at the start, either side of byte 2^32 and
+    2^33, and at the end against the oracle; a guard state behind the batch stays untouched."""
+    eng = engine()
+    n = 1 << 26
+    free, _ = torch.cuda.mem_get_info()
+    if free < 192 * n + (2 << 30):
+        pytest.skip("not enough HBM free for the 12 GiB case")
+    t = torch.zeros(192 * (n + 1), dtype=torch.uint8, device="cuda")
+    v = t.view(torch.int64)
+    v[0:24 * n:24] = torch.arange(n, dtype=torch.int64, device="cuda")
+    t[192 * n:] = 0xA5
+    eng.bashF_batch_dev(t[: 192 * n])
+    torch.cuda.synchronize()
+    w = 1 << 12
+    for first in (0, (1 << 32) // 192 - w // 2, (1 << 33) // 192 - w // 2, n // 2 + 12345, n - w):
+        plain = np.zeros((w, 24), dtype=np.int64)
+        plain[:, 0] = np.arange(first, first + w, dtype=np.int64)
+        want = plain.view(np.uint8).reshape(-1).copy()
+        orc.bashF_batch_np(want, nthreads=8)
+        got = t[192 * first: 192 * (first + w)].cpu().numpy()
+        assert np.array_equal(got, want), first
+    assert bool((t[192 * n:] == 0xA5).all())

@@ -163,3 +163,51 @@ def test_belt_mac_A17_and_golden_dropin(orc, golden):
         assert eng.beltMAC(msg, key)[1].hex() == c["mac"]
         tag, ok = eng.beltMAC_steps(msg, key, c["splits"])
         assert tag.hex() == c["mac"] and ok
+
+
+def test_belt_ctr_and_ecb_streams_beyond_2_32_blocks(orc, golden):
+    """Sized for the card (288 GB of HBM): ONE launch over an 80 GiB stream = 5 * 2^30 blocks, i.e. block indices and byte
+    offsets past 2^32 / 2^36.  The plaintext is zero, so the CTR ciphertext is the gamma: windows of 1 MiB at the start, either
+    side of block 2^32, at 3/4 of the stream and at its end against the oracle (which jumps to any block index), then decryption
+    of the whole stream back to zero.  The same buffer through the ECB kernel pair: E at the windows against the oracle, D(E(x)) = x."""
+    import os
+    eng = engine()
+    nbytes = 80 << 30
+    free, _ = torch.cuda.mem_get_info()
+    if free < nbytes + (4 << 30):
+        pytest.skip("not enough HBM free for the 80 GiB case")
+    kw, c0 = orc.ctr_start(golden.H[128:160], golden.H[192:208])
+    buf = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    eng.beltCTR_blocks_dev(buf, kw, c0, 0)
+    torch.cuda.synchronize()
+    win = 1 << 20
+    threads = min(os.cpu_count() or 8, 32)
+    starts = [0, (1 << 36) - win, 1 << 36, (1 << 36) + (1 << 33) + 5 * win, 60 << 30, nbytes - win]
+    for s in starts:
+        want = np.zeros(win, dtype=np.uint8)
+        orc.ctr_blocks_np(want, kw, c0, first=s // 16, nthreads=threads)
+        assert np.array_equal(buf[s:s + win].cpu().numpy(), want), f"CTR window at byte {s}"
+    eng.beltCTR_blocks_dev(buf, kw, c0, 0)
+    torch.cuda.synchronize()
+    assert int(buf.view(torch.int64).count_nonzero().item()) == 0
+    # ECB over the same 5 * 2^30 blocks: a plaintext that differs per block (the block index in its first 8 octets)
+    v = buf.view(torch.int64)
+    step = 1 << 28
+    for a in range(0, v.numel(), step):                       # even positions = block index, odd positions stay 0
+        b = min(a + step, v.numel())
+        v[a:b:2] = torch.arange(a // 2, (b + 1) // 2, dtype=torch.int64, device="cuda")
+    key = golden.H[128:160]
+    eng.beltModes_blocks_dev(0, buf, buf, kw)
+    torch.cuda.synchronize()
+    for s in starts:
+        idx = np.arange(s // 16, (s + win) // 16, dtype=np.int64)
+        plain = np.zeros((win // 16, 2), dtype=np.int64)
+        plain[:, 0] = idx
+        code, want = orc.ecb(plain.tobytes(), key)
+        assert code == 0 and buf[s:s + win].cpu().numpy().tobytes() == want, f"ECB window at byte {s}"
+    eng.beltModes_blocks_dev(1, buf, buf, kw)
+    torch.cuda.synchronize()
+    for s in starts:
+        got = buf[s:s + win].cpu().numpy().view(np.int64).reshape(-1, 2)
+        assert np.array_equal(got[:, 0], np.arange(s // 16, (s + win) // 16, dtype=np.int64)) and not got[:, 1].any(), s
+    assert int(v[1::2].count_nonzero().item()) == 0

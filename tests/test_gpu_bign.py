@@ -730,3 +730,37 @@ def test_bign_big_batch_every_entry_against_the_oracle(orc, golden):
     diff = np.nonzero(got != want)[0]
     assert diff.size == 0, (diff[:5], got[diff[:5]], want[diff[:5]])
     assert int((want == 0).sum()) >= n // 2 - 128 and {505, 510} <= set(np.unique(want).tolist())
+
+
+def test_bign_device_batch_of_2pow22_signatures(orc, golden):
+    """Sized for the card: 2^22 + 5 signatures resident in HBM in ONE call (16x BASELINE's configs[3]; scratch of the
+    verification pipeline ~4.5 GB).  One entry in 64 damaged by a bit flip in s0 / s1 / the hash / the key: every untouched entry
+    verifies, every damaged one does not, and 4096 of the damaged ones are compared with the oracle's codes."""
+    eng = engine()
+    hs, ss, ps = golden.bign_base_arrays()
+    nb = len(hs) // 32
+    n = (1 << 22) + 5
+    reps = -(-n // nb)
+    H = np.tile(np.frombuffer(hs, dtype=np.uint8), reps).reshape(-1, 32)[:n].copy()
+    S = np.tile(np.frombuffer(ss, dtype=np.uint8), reps).reshape(-1, 48)[:n].copy()
+    K = np.tile(np.frombuffer(ps, dtype=np.uint8), reps).reshape(-1, 64)[:n].copy()
+    rng = np.random.default_rng(0x2B22)
+    bad = np.sort(rng.choice(n, n // 64, replace=False))
+    bad[:3] = (0, 1 << 18, n - 1)
+    bad = np.unique(bad)
+    kind = rng.integers(0, 3, bad.size)
+    bit = (1 << rng.integers(0, 8, bad.size)).astype(np.uint8)
+    for arr, k, width in ((H, 0, 32), (S, 1, 48), (K, 2, 64)):
+        sel = bad[kind == k]
+        arr[sel, rng.integers(0, width, sel.size)] ^= bit[kind == k]
+    codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    eng.bign128Verify_batch_dev(dev(H.reshape(-1)), dev(S.reshape(-1)), dev(K.reshape(-1)), codes)
+    torch.cuda.synchronize()
+    got = codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    mask = np.zeros(n, dtype=bool)
+    mask[bad] = True
+    assert int((got[~mask] != 0).sum()) == 0
+    assert int((got[mask] == 0).sum()) == 0
+    sample = bad[rng.choice(bad.size, 4096, replace=False)]
+    want = np.array(orc.verify_batch(H[sample].tobytes(), S[sample].tobytes(), K[sample].tobytes(), nthreads=32), dtype=np.int64)
+    assert np.array_equal(got[sample], want)

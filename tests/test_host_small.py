@@ -116,7 +116,7 @@ def test_ctr_blocks_with_state(hs, orc):
 
 def test_mac_any_split(hs, orc, golden):
     rnd = random.Random(11)
-    for n in (0, 1, 15, 16, 17, 31, 32, 33, 48, 100, 1000):
+    for n in (0, 1, 15, 16, 17, 31, 32, 33, 48, 100, 1000, 1024, 1025, 4096 + 16, 5000) * 3:
         key, msg = rnd.randbytes(32), rnd.randbytes(n)
         kw = _kw(orc, key)
         s, r, mac = ((ctypes.c_uint32 * 4)() for _ in range(3))
@@ -124,7 +124,7 @@ def test_mac_any_split(hs, orc, golden):
         hs.hs_mac(kw, s, r, mac, block, ctypes.byref(filled), None, _sz(0), 1)
         off = 0
         while off < n:
-            take = min(n - off, rnd.choice([1, 5, 16, 17, 64]))
+            take = min(n - off, rnd.choice([1, 5, 16, 17, 32, 48, 64, 200, 1024]))   # whole blocks go straight from the caller's buffer
             hs.hs_mac(kw, s, r, mac, block, ctypes.byref(filled), msg[off:off + take], _sz(take), 2)
             off += take
         hs.hs_mac(kw, s, r, mac, block, ctypes.byref(filled), None, _sz(0), 4)
@@ -190,7 +190,7 @@ def test_bde_che_blocks_and_state(hs, orc):
 
 def test_sde_sectors(hs, orc):
     rnd = random.Random(23)
-    for nb in (2, 3, 4, 7, 32, 33):
+    for nb in (2, 3, 4, 5, 7, 32, 33, 64, 256):
         key, iv, msg = rnd.randbytes(32), rnd.randbytes(16), rnd.randbytes(16 * nb)
         kw = _kw(orc, key)
         for decr in (0, 1):
