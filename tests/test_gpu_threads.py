@@ -138,3 +138,43 @@ def test_threads_that_ran_the_chunked_host_pipelines_give_their_scratch_back(orc
     free1, _ = torch.cuda.mem_get_info()
     assert not bad, bad
     assert free0 - free1 < (32 << 20), f"device memory shrank by {(free0 - free1) >> 20} MiB over 6 threads"
+
+
+def test_ragged_batches_on_two_queues_from_six_threads(orc):
+    """bee2hip_hash_ragged with 1200-1700 messages per call (long chains on the thread's stream, short messages on ITS side
+    stream -- thread-local, created on first use, released when the thread exits) from six threads at once, three rounds each,
+    belt-hash and bash256 alternating: every digest against the oracle; then the threads are gone and six NEW ones do it again
+    (their side streams are new objects: nothing of the old ones may be reused)."""
+    import random
+    eng = engine()
+    batches = []
+    for t in range(6):
+        rnd = random.Random(900 + t)
+        msgs = [rnd.randbytes(rnd.choice((0, 3, 32, 33, 200, 999))) for _ in range(1200 + 100 * t)]
+        for k in rnd.sample(range(len(msgs)), 5):
+            msgs[k] = rnd.randbytes(rnd.choice((4096, 9000, 40001)))
+        want = {0: [orc.belt_hash(m) for m in msgs], 128: [orc.bashHash(128, m)[1] for m in msgs]}
+        batches.append((msgs, want))
+    for wave in range(2):
+        errors = []
+        start = threading.Barrier(6)
+
+        def run(t):
+            try:
+                msgs, want = batches[t]
+                start.wait()
+                for r in range(3):
+                    alg = (0, 128)[(r + t) & 1]
+                    code, got = eng.hash_ragged(alg, msgs)
+                    if code != 0 or got != want[alg]:
+                        errors.append((wave, t, r, code))
+                        return
+            except Exception as e:                                            # noqa: BLE001
+                errors.append((wave, t, repr(e)))
+        threads = [threading.Thread(target=run, args=(t,)) for t in range(6)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout=300)
+        assert not any(th.is_alive() for th in threads), "a thread is stuck"
+        assert not errors, errors[:5]
