@@ -32,6 +32,25 @@ def t(fn, reps=5):
 
 
 both = t(lambda: eng.bashHash_beltMAC_batch_dev(msgs, ml, 256, key, dig, tag, n))
+d0, t0 = dig.clone(), tag.clone()
+# the two halves as two kernels on two streams at once
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+
+def two():
+    ev = torch.cuda.Event(); ev.record()
+    s1.wait_event(ev); s2.wait_event(ev)
+    with torch.cuda.stream(s1):
+        eng.bashHash_beltMAC_batch_dev(msgs, ml, 256, key, dig, None, n)
+    with torch.cuda.stream(s2):
+        eng.bashHash_beltMAC_batch_dev(msgs, ml, 256, key, None, tag, n)
+    torch.cuda.current_stream().wait_stream(s1); torch.cuda.current_stream().wait_stream(s2)
+
+
+dig.zero_(); tag.zero_()
+twok = t(two)
+assert torch.equal(d0, dig) and torch.equal(t0, tag)
+print(f"hash-only and MAC-only kernels on two streams at once {twok:7.3f} ms   {n / twok / 1e3:8.1f} M msg/s")
 honly = t(lambda: eng.bashHash_beltMAC_batch_dev(msgs, ml, 256, key, dig, None, n))
 monly = t(lambda: eng.bashHash_beltMAC_batch_dev(msgs, ml, 256, key, None, tag, n))
 states = msgs[: (n * ml) // 192 * 192]
