@@ -2587,7 +2587,7 @@ static err_t hash_ragged_host(size_t alg, const octet *data, const uint64_t *off
         return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b];
     });
     // A message is ONE dependent chain: a GPU lane (pair) walks it at ~0.12-0.15 us per octet, a host core at ~0.008.  When a
-    // few messages are far longer than the rest the batch would wait for their chains (a 256 KiB message: 30-40 ms; a 1 GiB
+    // few messages are far longer than the rest the batch would wait for their chains (a 256 KiB message: 26-30 ms; a 1 GiB
     // file: minutes) with the device otherwise idle, so this HOST-pointer entry -- the data is in host memory anyway --
     // hands the K longest messages to host threads (host_small.hpp, as the drop-in beltHash / bashHash of one message
     // does) while the GPU takes the rest.  K balances the two sides: it grows while the host threads would finish before
