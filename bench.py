@@ -807,7 +807,7 @@ def main():
             "metric": "bign-curve256v1 deterministic signatures/s", "value": N * n * ks / el, "unit": "signatures/s", "steps": ks,
             "ms_per_step": el / ks * 1e3, "all_verify": bool((vc == 0).all() and (sc == 0).all()),
             "config": {"workload": f"bignSign2 batch: {n} (hash, private key) pairs per GPU on bign-curve256v1, no additional input; "
-                                   "constant-time kernels (nonce by belt-hash + belt-wbl, signed 6-bit windows with full-row table scans, "
+                                   "constant-time kernels (nonce by belt-hash + belt-wbl, k G on signed 8-bit windows whose entry is looked up in bank-private LDS copies of the row, "
                                    "masked Jacobian mixed additions, inversion by a fixed number of division steps); every signature verified afterwards (untimed)"},
             "roofline": {"kernels": "bign_sign_nonce + bign_mulbase_lds (one lane per signature, window entries looked up in LDS) + bign_sign_tail", "bound": "valu-int", "avg_batch_ms": ms_sign,
                          "mads_per_signature": mads, "achieved": mads * n / (ms_sign * 1e-3) / 1e12, "peak": MAD_PEAK_T,
