@@ -517,9 +517,13 @@ void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
 #pragma unroll
         for (int k = 0; k < 4 / QL; ++k) {
             const int fi = (int)q + QL * k;
-            const lzT<N> &f = fi == 0 ? P.X : fi == 1 ? P.Y : fi == 2 ? P.Z : P.D;
+            // (selected limb by limb, by VALUE: a reference picked by the lane's number made the compiler park the whole point in
+            // scratch and index it there -- 436 / 676 / 916 bytes of scratch in the quad kernels, a round trip to memory per entry)
 #pragma unroll
-            for (int l = 0; l < L; ++l) s_tab[((e * 4 + fi) * L + l) * NS + sl] = f.l[l];
+            for (int l = 0; l < L; ++l) {
+                const int32_t v = fi == 0 ? P.X.l[l] : fi == 1 ? P.Y.l[l] : fi == 2 ? P.Z.l[l] : P.D.l[l];
+                s_tab[((e * 4 + fi) * L + l) * NS + sl] = v;
+            }
         }
     };
     const auto dbl = [&](lqjacT<N> &P) { if constexpr (QL == 4) quad29_dbl(P, q); else pair29_dbl(P, q); };

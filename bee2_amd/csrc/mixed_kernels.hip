@@ -394,11 +394,17 @@ __global__ void init_states_kernel(bash_hash_st *hs, belt_mac_st *ms, size_t n, 
 // ragged input).  This is the device side of a `bee2cmd bsum`-style front-end that hashes many
 // files per launch instead of one file per bashHashStepH loop (cmd/bsum/bsum.c:133-221).
 
-// ALG = 8 / 12 / 16: bash512 / bash384 / bash256 (rate in u64 words); digests are l/4 bytes each
-// (bash256 compiled to 276 VGPRs = one wavefront per SIMD; held to 256 it keeps two, which many-message batches
-// need: 2^18 x 1000 B 558 -> 662 GiB/s, 2^20 x 256 B 373 -> 447; bash384 / bash512 have two / three as they come)
+// ALG = 8 / 12 / 16: bash512 / bash384 / bash256 (rate in u64 words); digests are l/4 bytes each.
+// (round 4, second session) ONE absorb-and-permute site: a block is read as the aligned 32-bit words that hold its octets (never a
+// word without an octet of the message), shifted into place by v_alignbit, and the LAST block -- shorter than the rate, possibly empty
+// -- gets its zeros and the 0x40 by masks on the same words, so the loop body serves every block and bash-f is in the kernel once,
+// in the staged order with the class-following priority of the fused kernel.  Before: two copies of the compact bash-f, octet loads
+// for the tail, 256-276 VGPRs with 40 of them spilled (two wavefronts per SIMD); now 4 wavefronts per SIMD without scratch.
+#ifndef BASH_RAGGED_WAVES
+#define BASH_RAGGED_WAVES 4
+#endif
 template <int RW>
-__global__ __launch_bounds__(64, (RW == 16 ? 2 : 1))
+__global__ __launch_bounds__(64, BASH_RAGGED_WAVES)
 void bash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off,
                         const uint32_t *__restrict__ order, size_t n,
                         uint32_t level, uint8_t *__restrict__ digests, uint64_t long_from)
@@ -409,33 +415,57 @@ void bash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *__rest
     const uint8_t *p = data + off[i];
     size_t left = (size_t)(off[i + 1] - off[i]);
     if (left >= long_from) return;                    // long messages: bash_long_kernel, 8 lanes each
-    constexpr int RATE = 8 * RW;
+    constexpr uint32_t RATE = 8 * RW, NW = 2 * RW;
     u64x2 a[24];
 #pragma unroll
     for (int k = 0; k < 24; ++k) a[k].lo = a[k].hi = 0;
     a[23].lo = level / 4;
-    while (left >= RATE) {
+    // 16-octet loads: a lane's block sits in its own cache lines, so every load instruction of the wavefront is 64 separate line
+    // accesses whatever its width -- 9 of them per 128-octet block instead of 33 dword loads (the texture path, not the VALU, bounded the
+    // dword form: 718 GiB/s on 1000-octet messages where bash-f alone allows ~1.2 TiB/s).  The block starts mis16 = p mod 16 octets into
+    // the first quad: a dword shift d = mis16 / 4 (two rounds of selects) and a bit shift (v_alignbit) bring it into place.
+    const uint4 *qp = reinterpret_cast<const uint4 *>((uintptr_t)p & ~(uintptr_t)15);
+    const uint32_t mis16 = (uint32_t)(uintptr_t)p & 15u, sh = (mis16 & 3u) * 8u;
+    const uint32_t m1 = (mis16 & 4u) ? ~0u : 0u, m2 = (mis16 & 8u) ? ~0u : 0u;
+    constexpr uint32_t NQ = NW / 4 + 1;                                 // quads that can hold octets of one block
+    for (;;) {
+        const uint32_t cnt = left < RATE ? (uint32_t)left : RATE;       // octets of this block (the last one: 0 .. RATE - 1)
+        const uint32_t span = mis16 + cnt;                              // aligned quad j holds octets of the block iff 16 j < span
+        uint32_t W[4 * NQ + 4];
 #pragma unroll
-        for (int w = 0; w < RW; ++w) {
-            const uint64_t v = load64_any(p + 8 * w);
-            a[w].lo = (uint32_t)v; a[w].hi = (uint32_t)(v >> 32);
+        for (uint32_t j = 0; j < NQ; ++j) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (16u * j < span) v = qp[j];
+            W[4 * j] = v.x; W[4 * j + 1] = v.y; W[4 * j + 2] = v.z; W[4 * j + 3] = v.w;
         }
-        bash_f(a);
-        p += RATE; left -= RATE;
-    }
-    // tail || 0x40 || 0..
 #pragma unroll
-    for (int w = 0; w < RW; ++w) {
-        uint64_t v = 0;
+        for (uint32_t j = 4 * NQ; j < 4 * NQ + 4; ++j) W[j] = 0;
+        // (selects by MASK, one v_bitop3 each: written as `d ? W[j + 1] : W[j]` the compiler selects the ADDRESS and parks W in scratch)
+        uint32_t A[NW + 3], B[NW + 1];
 #pragma unroll
-        for (int k = 7; k >= 0; --k) {
-            const size_t pos = (size_t)(8 * w + k);
-            const uint32_t b = pos < left ? p[pos] : (pos == left ? 0x40u : 0u);
-            v = (v << 8) | b;
+        for (uint32_t j = 0; j < NW + 3; ++j) A[j] = __builtin_amdgcn_bitop3_b32(W[j], W[j + 1], m1, 0xD8);       // m1 ? W[j + 1] : W[j]
+#pragma unroll
+        for (uint32_t j = 0; j <= NW; ++j) B[j] = __builtin_amdgcn_bitop3_b32(A[j], A[j + 2], m2, 0xD8);
+        uint32_t x[NW];
+#pragma unroll
+        for (uint32_t j = 0; j < NW; ++j) x[j] = __builtin_amdgcn_alignbit(B[j + 1], B[j], sh);
+        if (cnt < RATE) {
+            // tail || 0x40 || 0.. (bash_hash.c:84-102): word j keeps its first r = cnt - 4 j octets, 0x40 follows the last octet
+#pragma unroll
+            for (uint32_t j = 0; j < NW; ++j) {
+                const int32_t r = (int32_t)cnt - (int32_t)(4u * j);
+                const uint32_t keep = r >= 4 ? ~0u : r <= 0 ? 0u : (1u << (8 * r)) - 1u;
+                const uint32_t pad = (r >= 0 && r < 4) ? 0x40u << (8 * r) : 0u;
+                x[j] = (x[j] & keep) | pad;
+            }
         }
-        a[w].lo = (uint32_t)v; a[w].hi = (uint32_t)(v >> 32);
+        // absorb = overwrite the first RW words (bash_hash.c:69-75)
+#pragma unroll
+        for (int w = 0; w < RW; ++w) { a[w].lo = x[2 * w]; a[w].hi = x[2 * w + 1]; }
+        bash_f<BASH_FUSED_ORDER>(a);
+        if (cnt < RATE) break;
+        qp += NW / 4; left -= RATE;
     }
-    bash_f(a);
     uint8_t *d = digests + (size_t)(level / 4) * i;
     const int nw = (int)(level / 32);
 #pragma unroll
