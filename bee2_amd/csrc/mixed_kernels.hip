@@ -567,28 +567,52 @@ void belt_hash_ragged_kernel(const uint8_t *__restrict__ data, const uint64_t *_
     for (int k = 0; k < 8; ++k)
         h[k] = (uint32_t)c_beltH[4 * k] | (uint32_t)c_beltH[4 * k + 1] << 8 |
                (uint32_t)c_beltH[4 * k + 2] << 16 | (uint32_t)c_beltH[4 * k + 3] << 24;
-    while (left >= 32) {
+    // (round 4, second session) ONE compression site for the whole blocks, the zero-padded last one and the closing block
+    // <bit length> || s (belt_hash.c:115-135): three inlined copies of the three encryptions were 86 KB of code for a 64 KB
+    // instruction cache.  A block is read as the aligned 16-octet quads that hold its octets (a lane's load instruction is 64 line
+    // accesses whatever its width: 3 instead of 9 per block; never a quad without an octet of the message), brought into place by
+    // a dword shift (mask selects) and v_alignbit -- as bash_ragged_kernel.
+    const uint4 *qp = reinterpret_cast<const uint4 *>((uintptr_t)p & ~(uintptr_t)15);
+    const uint32_t mis16 = (uint32_t)(uintptr_t)p & 15u, sh = (mis16 & 3u) * 8u;
+    const uint32_t m1 = (mis16 & 4u) ? ~0u : 0u, m2 = (mis16 & 8u) ? ~0u : 0u;
+    const size_t nblk = (len + 31) / 32;               // data blocks, the partial one included
+#pragma unroll 1
+    for (size_t blk = 0; blk <= nblk; ++blk) {
+        const bool is_data = blk < nblk;
+        if (is_data) {
+            const uint32_t cnt = left < 32 ? (uint32_t)left : 32u;
+            const uint32_t span = mis16 + cnt;          // aligned quad j holds octets of the block iff 16 j < span
+            uint32_t W[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) X[k] = load32_any(p + 4 * k);
-        belt_compress(T, s1, h, X);
+            for (uint32_t j = 0; j < 3; ++j) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (16u * j < span) v = qp[j];
+                W[4 * j] = v.x; W[4 * j + 1] = v.y; W[4 * j + 2] = v.z; W[4 * j + 3] = v.w;
+            }
+            W[12] = W[13] = W[14] = W[15] = 0;
+            uint32_t A[11], B[9];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] ^= s1[k];
-        p += 32; left -= 32;
-    }
-    if (left) {                                        // last, partial block: zero padded
+            for (uint32_t j = 0; j < 11; ++j) A[j] = __builtin_amdgcn_bitop3_b32(W[j], W[j + 1], m1, 0xD8);     // m1 ? W[j + 1] : W[j]
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t have = left > (size_t)(4 * k) ? (uint32_t)(left - 4 * k) : 0u;
-            X[k] = have >= 4 ? load32_any(p + 4 * k) : have ? load32_head(p + 4 * k, have) : 0u;
+            for (uint32_t j = 0; j < 9; ++j) B[j] = __builtin_amdgcn_bitop3_b32(A[j], A[j + 2], m2, 0xD8);
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                const int32_t r = (int32_t)cnt - (int32_t)(4u * j);                 // octets of word j that belong to the message
+                const uint32_t keep = r >= 4 ? ~0u : r <= 0 ? 0u : (1u << (8 * r)) - 1u;
+                X[j] = __builtin_amdgcn_alignbit(B[j + 1], B[j], sh) & keep;
+            }
+            qp += 2; left -= cnt;
+        } else {
+            const uint64_t bits_lo = (uint64_t)len << 3, bits_hi = (uint64_t)len >> 61;
+            X[0] = (uint32_t)bits_lo; X[1] = (uint32_t)(bits_lo >> 32); X[2] = (uint32_t)bits_hi; X[3] = 0;
+            X[4] = s[0]; X[5] = s[1]; X[6] = s[2]; X[7] = s[3];
         }
         belt_compress(T, s1, h, X);
+        if (is_data) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] ^= s1[k];
+            for (int k = 0; k < 4; ++k) s[k] ^= s1[k];
+        }
     }
-    const uint64_t bits_lo = (uint64_t)len << 3, bits_hi = (uint64_t)len >> 61;
-    X[0] = (uint32_t)bits_lo; X[1] = (uint32_t)(bits_lo >> 32); X[2] = (uint32_t)bits_hi; X[3] = 0;
-    X[4] = s[0]; X[5] = s[1]; X[6] = s[2]; X[7] = s[3];
-    belt_compress(T, s1, h, X);
     uint32_t *d = reinterpret_cast<uint32_t *>(digests + 32 * i);      // 32-byte slots of an aligned buffer
 #pragma unroll
     for (int k = 0; k < 8; ++k) d[k] = h[k];
