@@ -49,8 +49,10 @@ template <int N> struct feT { uint32_t v[N]; };
 // overflows on +c) resp. 2^-40 per lane -- is skipped by a wavefront-uniform branch on the carry mask the first
 // pass leaves in an SGPR pair, and the carry chains are written as v_add(c)_co_u32 chains instead of 64-bit adds of
 // zero-extended limbs.  Results are identical, bit for bit; only the instruction count depends on the data.
-struct CtOps { static constexpr bool VT = false; };
-struct VtOps { static constexpr bool VT = true; };
+struct CtOps { static constexpr bool VT = false, PAIRS = false; };
+struct VtOps { static constexpr bool VT = true, PAIRS = false; };
+// VtOps with the two multiply-adds of a column pair issued back to back (mac2): for kernels that run at ONE wavefront per SIMD
+struct VtOpsP { static constexpr bool VT = true, PAIRS = true; };
 template <int N> struct jacT { feT<N> X, Y, Z; };          // O <=> Z == 0 (mod p)
 template <int N> struct affT { feT<N> x, y; };
 typedef feT<8> fe;
@@ -93,13 +95,18 @@ __device__ __forceinline__ void mac_col(uint64_t &acc, uint32_t &c2, uint32_t a,
 // drops from 9 932 to 7 974 instructions (s_nop 3 878 -> 1 900) and 2^18 verifications take the same 2.17 ms (120.4 against
 // 120.0-120.6 M/s), signing +1 % -- the s_nop of a wavefront are issue slots other wavefronts fill (profiles/r03_mad_pairs.txt).
 // BIGN_MAC_PAIRS=1 builds the paired form (all 232 bign GPU tests pass with it); 0, the product, is the audited order.
+// (round 4, second session) TAKEN where it pays: the ops class VtOpsP (PAIRS) builds the paired form.  What round 3 measured was the
+// main kernel of the 256-bit curve at FOUR wavefronts per SIMD, where other wavefronts fill the wait states.  At ONE wavefront per
+// SIMD a wait state is an issue slot lost (a lone wavefront gets one slot per 4 cycles, s_nop included: tools/ubench/lone_chain.hip):
+// the 384- / 512-bit pipelines at 2^16 signatures 2.83 -> 2.12 ms and 6.16 -> 4.67 ms; at two wavefronts and more the paired form
+// LOSES 1-6 % (two quarter-rate instructions back to back).  launch_bign_verify_t picks by batch size; profiles/r04_mad_pairs_vt.txt.
 #ifndef BIGN_MAC_PAIRS
 #define BIGN_MAC_PAIRS 0
 #endif
-template <bool FIRST>
+template <bool FIRST, bool PAIRS = false>
 __device__ __forceinline__ void mac2(uint64_t &acc, uint32_t &c2, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1)
 {
-#if BIGN_MAC_PAIRS
+  if constexpr (BIGN_MAC_PAIRS || PAIRS) {
     uint64_t cy0, cy1;
     if constexpr (FIRST)
         asm("v_mad_u64_u32 %0, %2, %4, %5, %0\n\tv_mad_u64_u32 %0, %3, %6, %7, %0\n\t"
@@ -109,10 +116,10 @@ __device__ __forceinline__ void mac2(uint64_t &acc, uint32_t &c2, uint32_t a0, u
         asm("v_mad_u64_u32 %0, %2, %4, %5, %0\n\tv_mad_u64_u32 %0, %3, %6, %7, %0\n\t"
             "v_addc_co_u32 %1, %2, 0, %1, %2\n\tv_addc_co_u32 %1, %3, 0, %1, %3"
             : "+v"(acc), "+v"(c2), "=&s"(cy0), "=&s"(cy1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
-#else
+  } else {
     mac_col<FIRST>(acc, c2, a0, b0);
     mac_col<false>(acc, c2, a1, b1);
-#endif
+  }
 }
 
 template <int N>
@@ -299,7 +306,7 @@ __device__ __forceinline__ void fe_mul_body(feT<N> &r, const feT<N> &a, const fe
         constexpr int cnt = (k < N ? k : N - 1) + 1 - i0;  // products in column k, taken two at a time (mac2)
         static_for<0, cnt / 2>([&](auto pc) __attribute__((always_inline)) {
             constexpr int i = i0 + 2 * decltype(pc)::value;
-            mac2<i == i0>(acc, c2, a.v[i], b.v[k - i], a.v[i + 1], b.v[k - i - 1]);
+            mac2<i == i0, P::PAIRS>(acc, c2, a.v[i], b.v[k - i], a.v[i + 1], b.v[k - i - 1]);
         });
         if constexpr (cnt % 2) mac_col<cnt == 1, k == 0 || k == 2 * N - 2>(acc, c2, a.v[i0 + cnt - 1], b.v[k - i0 - cnt + 1]);
         w[k] = (uint32_t)acc;
@@ -346,7 +353,7 @@ __device__ __forceinline__ void fe_sqr_body(feT<N> &r, const feT<N> &a)
         };
         static_for<0, cnt / 2>([&](auto pc) __attribute__((always_inline)) {
             constexpr int i = i0 + 2 * decltype(pc)::value;
-            mac2<i == i0>(acc, c2, a.v[i], other(IntC<i>{}), a.v[i + 1], other(IntC<i + 1>{}));
+            mac2<i == i0, P::PAIRS>(acc, c2, a.v[i], other(IntC<i>{}), a.v[i + 1], other(IntC<i + 1>{}));
         });
         if constexpr (cnt % 2) {
             constexpr int i = i0 + cnt - 1;

@@ -236,7 +236,7 @@ __device__ __forceinline__ bool prep_scalars(const uint8_t *__restrict__ hashes,
 
 // one signature: prep_scalars, then 1Q..8Q (1Q affine, 2Q..8Q Jacobian: X, Y in the table rows, Z aside).  Sets
 // the status; returns true when the table is to be normalised (no exceptional case).
-template <int N>
+template <int N, class OPS = VtOps>
 __device__ __forceinline__ bool prep_points(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
                                             const uint8_t *__restrict__ pubkeys, size_t idx, const VerifyScratch &S)
 {
@@ -258,24 +258,24 @@ __device__ __forceinline__ bool prep_points(const uint8_t *__restrict__ hashes, 
     jacT<N> A, T;
     store_qxy(S, 0, idx, Q.x, Q.y);
     A.X = Q.x; A.Y = Q.y; fe_set_one(A.Z);
-    jac_dbl<N, VtOps>(A);                           put(1, A);      // 2Q
-    T = A;   ok &= jac_madd<N, VtOps>(T, Q);        put(2, T);      // 3Q
-    jac_dbl<N, VtOps>(A);                           put(3, A);      // 4Q
-    jac_dbl<N, VtOps>(T);                           put(5, T);      // 6Q
-    ok &= jac_madd<N, VtOps>(T, Q);                 put(6, T);      // 7Q
-    T = A;   ok &= jac_madd<N, VtOps>(T, Q);        put(4, T);      // 5Q
-    jac_dbl<N, VtOps>(A);                           put(7, A);      // 8Q
+    jac_dbl<N, OPS>(A);                           put(1, A);      // 2Q
+    T = A;   ok &= jac_madd<N, OPS>(T, Q);        put(2, T);      // 3Q
+    jac_dbl<N, OPS>(A);                           put(3, A);      // 4Q
+    jac_dbl<N, OPS>(T);                           put(5, T);      // 6Q
+    ok &= jac_madd<N, OPS>(T, Q);                 put(6, T);      // 7Q
+    T = A;   ok &= jac_madd<N, OPS>(T, Q);        put(4, T);      // 5Q
+    jac_dbl<N, OPS>(A);                           put(7, A);      // 8Q
     S.status[idx] = ok ? ST_PENDING : ST_SLOW;
     return ok;
 }
 
-template <int N>
+template <int N, class OPS = VtOps>
 __global__ __launch_bounds__(256, 2)
 void bign_points_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
                         const uint8_t *__restrict__ pubkeys, size_t n, VerifyScratch S)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n) prep_points<N>(hashes, sigs, pubkeys, idx, S);
+    if (idx < n) prep_points<N, OPS>(hashes, sigs, pubkeys, idx, S);
 }
 
 // The table is made AFFINE so that the main loop adds with the mixed formula (8M + 3S instead of 12M + 4S, 31
@@ -286,7 +286,7 @@ void bign_points_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
 // the slow path and stay out of the product.
 // (two wavefronts per SIMD on every curve: 196 VGPRs on the 256-bit one as it comes; the wider ones, 311 / 409
 // VGPRs unbounded, are held to 256 -- +3 % on their whole pipelines)
-template <int N>
+template <int N, class OPS = VtOps>
 __global__ __launch_bounds__(256, (N == 8 ? 1 : 2))
 void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
                       const uint8_t *__restrict__ pubkeys, size_t n, size_t lanes, int SP, VerifyScratch S)
@@ -306,13 +306,13 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
         const size_t idx = (size_t)sp * lanes + j;
         if (idx >= n) break;
         if (SPLIT) { if (S.status[idx] != ST_PENDING) continue; }
-        else if (!prep_points<N>(hashes, sigs, pubkeys, idx, S)) continue;
+        else if (!prep_points<N, OPS>(hashes, sigs, pubkeys, idx, S)) continue;
         todo |= 1u << sp;
 #pragma unroll 1
         for (int k = 0; k < 7; ++k) {
             store_soa(Cs + (size_t)k * N * S.n_pad, S.n_pad, idx, acc);
             load_soa(z, Zs + (size_t)k * N * S.n_pad, S.n_pad, idx);
-            fe_mul<1, VtOps>(acc, acc, z);
+            fe_mul<1, OPS>(acc, acc, z);
         }
     }
     if (!todo) return;
@@ -324,17 +324,17 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
 #pragma unroll 1
         for (int k = 6; k >= 0; --k) {
             load_soa(v, Cs + (size_t)k * N * S.n_pad, S.n_pad, idx);
-            fe_mul<1, VtOps>(zi, inv, v);                           // 1 / Z_k
+            fe_mul<1, OPS>(zi, inv, v);                           // 1 / Z_k
             load_soa(z, Zs + (size_t)k * N * S.n_pad, S.n_pad, idx);
-            fe_mul<1, VtOps>(inv, inv, z);                          // 1 / (product before Z_k)
+            fe_mul<1, OPS>(inv, inv, z);                          // 1 / (product before Z_k)
             uint32_t *b = S.qtab + (size_t)(k + 1) * 2 * N * S.n_pad;
-            fe_sqr<1, VtOps>(zi2, zi);
+            fe_sqr<1, OPS>(zi2, zi);
             load_soa(v, b, S.n_pad, idx);
-            fe_mul<1, VtOps>(v, v, zi2);
+            fe_mul<1, OPS>(v, v, zi2);
             store_soa(b, S.n_pad, idx, v);                // x = X / Z^2
-            fe_mul<1, VtOps>(zi2, zi2, zi);
+            fe_mul<1, OPS>(zi2, zi2, zi);
             load_soa(v, b + (size_t)N * S.n_pad, S.n_pad, idx);
-            fe_mul<1, VtOps>(v, v, zi2);
+            fe_mul<1, OPS>(v, v, zi2);
             store_soa(b + (size_t)N * S.n_pad, S.n_pad, idx, v);   // y = Y / Z^3
         }
     }
@@ -346,7 +346,7 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
 // registers above the 128 that four wavefronts allow unless told so; the 512-bit one took 292 VGPRs, i.e. ONE
 // wavefront per SIMD, which issues at under half a SIMD's rate -- held to 256 (36 spills) it runs 1.5x as fast.
 // The 384-bit kernel has two wavefronts at 224 VGPRs; forcing three costs 92 spills and 12 %.)
-template <int N>
+template <int N, class OPS = VtOps>
 __global__ __launch_bounds__(256, (N == 8 ? 4 : N == 12 ? 1 : 2))
 void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
 {
@@ -372,7 +372,7 @@ void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
 #pragma unroll 1
     for (int i = 4 * N - 1; i >= 0; --i) {
 #pragma unroll 1
-        for (int k = 0; k < 4; ++k) jac_dbl<N, VtOps>(T);
+        for (int k = 0; k < 4; ++k) jac_dbl<N, OPS>(T);
         const int d = (int)(w[NW - 2] >> 28) - 8;       // next digit, in [-8, 7]
 #pragma unroll
         for (int l = NW - 2; l > 0; --l) w[l] = (w[l] << 4) | (w[l - 1] >> 28);
@@ -380,8 +380,8 @@ void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
         if (d != 0) {
             affT<N> E;
             load_qaff(E, S, (d < 0 ? -d : d) - 1, idx);
-            if (d < 0) fe_neg<VtOps>(E.y, E.y);
-            ok &= jac_madd<N, VtOps>(T, E);
+            if (d < 0) fe_neg<OPS>(E.y, E.y);
+            ok &= jac_madd<N, OPS>(T, E);
         }
     }
     // + u G : comb over the W-bit windows of u (mixed additions only)
@@ -396,7 +396,7 @@ void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
         if (b != 0) {
             affT<N> E;
             load_aff(E, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
-            ok &= jac_madd<N, VtOps>(T, E);
+            ok &= jac_madd<N, OPS>(T, E);
         }
     }
     ok &= !fe_is_zero(T.Z);
@@ -1271,6 +1271,12 @@ struct AuxStreams {
         return ERR_OK;
     }
 };
+// multiply-adds in pairs in the verification MAIN kernel: -1 = by curve and batch size (launch_bign_verify_t), 0 never, else always
+// (A/B: bee2hip_internal_tune 19)
+static int g_verify_pairs = -1;
+#ifdef BEE2HIP_EXPERIMENTS
+void set_verify_pairs(int v) { g_verify_pairs = v; }
+#endif
 static thread_local AuxStreams t_aux;
 
 template <int N>
@@ -1349,10 +1355,16 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
         if (code != ERR_OK) return code;
     }
     if (path != 3) {
+        // The MAIN kernel takes its multiply-adds in pairs (VtOpsP, bign_dev.hpp mac2) where that pays -- measured, tools/verify_pairs_ab.py,
+        // profiles/r04_mad_pairs_vt.txt: the 384- / 512-bit curves up to 2^16 signatures (ONE wavefront per SIMD: 2.85 -> 2.14 ms and
+        // 6.26 -> 4.82 ms at 2^16), the 256-bit curve from 2^18 on (four wavefronts: +0.8 % at 2^18, +1.7 % at 2^19); at two wavefronts
+        // per SIMD the paired form loses 2-5 % on every curve, and points / prep do not care.  g_verify_pairs: -1 by size, 0 never, else always (A/B).
+        const bool pair_main = g_verify_pairs >= 0 ? g_verify_pairs != 0
+                             : N == 8 ? n >= ((size_t)1 << 18) : n <= ((size_t)1 << 16);
         if constexpr (N != 8)
-            hipLaunchKernelGGL(bign_points_kernel<N>, dim3(g256), dim3(256), 0, st, (const uint8_t *)d_hashes,
+            hipLaunchKernelGGL((bign_points_kernel<N>), dim3(g256), dim3(256), 0, st, (const uint8_t *)d_hashes,
                                (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, S);
-        hipLaunchKernelGGL(bign_prep_kernel<N>, dim3((unsigned)((plan + 255) / 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL((bign_prep_kernel<N>), dim3((unsigned)((plan + 255) / 256)), dim3(256), 0, st,
                            (const uint8_t *)d_hashes, (const uint8_t *)d_sigs, (const uint8_t *)d_pubkeys, n, plan,
                            (int)sp, S);
         if (ev_prep) B2H_TRY(hipEventRecord(ev_prep, st));
@@ -1363,7 +1375,14 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
                                    (const uint4 *)gtab);
             }
         }
-        if (path != 2) hipLaunchKernelGGL(bign_main_kernel<N>, dim3(g256), dim3(256), 0, st, n, S, (const uint4 *)gtab);
+        if (path != 2) {
+            bool main_done = false;
+            if (pair_main) {
+                hipLaunchKernelGGL((bign_main_kernel<N, VtOpsP>), dim3(g256), dim3(256), 0, st, n, S, (const uint4 *)gtab);
+                main_done = true;
+            }
+            if (!main_done) hipLaunchKernelGGL((bign_main_kernel<N, VtOps>), dim3(g256), dim3(256), 0, st, n, S, (const uint4 *)gtab);
+        }
     }
     hipLaunchKernelGGL(bign_slow_kernel<N>, dim3(g64), dim3(64), 0, st, (const uint8_t *)d_sigs,
                        (const uint8_t *)d_pubkeys, n, S);

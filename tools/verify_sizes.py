@@ -34,7 +34,7 @@ def t(fn, reps=20):
 
 hs, ss, ps = G.bign_base_arrays()
 out = []
-for e in (10, 12, 13, 14, 15):
+for e in (10, 12, 13, 14, 15, 16, 17, 18, 19):
     k = max(1, (1 << e) // 2048)
     dh, ds, dp = (torch.from_numpy(np.frombuffer(x * k, dtype=np.uint8).copy()).cuda() for x in (hs, ss, ps))
     n = min(1 << e, 2048 * k)
@@ -46,12 +46,12 @@ print(f"{tag:6s} bign-curve256v1, ms per batch: " + "  ".join(out))
 from bee2_amd.engine import LEVEL_OID  # noqa: E402
 for l in (192, 256):
     base = G.bign_big[str(l)]["base"]
-    reps_l = (1 << 15) // len(base) + 1
+    reps_l = (1 << 18) // len(base) + 1
     th, ts, tp = (torch.from_numpy(np.frombuffer(b"".join(bytes.fromhex(x[k]) for x in base) * reps_l, dtype=np.uint8).copy()).cuda()
                   for k in ("hash", "sig", "pubkey"))
     no = l // 4
     out = []
-    for e in (10, 13, 14, 15):
+    for e in (10, 13, 14, 15, 16, 17, 18):
         m = 1 << e
         tc = torch.empty(m, dtype=torch.int32, device="cuda")
         args = (th[: no * m], ts[: (no + no // 2) * m], tp[: 2 * no * m], tc)
