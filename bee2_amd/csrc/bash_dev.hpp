@@ -358,27 +358,46 @@ __device__ __forceinline__ u64x2 bash_col_rot(const u64x2 x, const BashCol &c)
     r.hi = __builtin_amdgcn_alignbit(b, a, c.sh[P]);
     return r;
 }
+// (round 4, second session) A chain of permutations is walked by a LONE wavefront (one issue slot per 4 cycles, LDS round trip ~56
+// cycles: tools/ubench/lone_chain.hip), so the round is written for its slot count and ONE exposed round trip: the 24 rounds are
+// unrolled with their constants as literals (the rolled loop spent 13 of its 55 slots on the LFSR, its copy into lane 7 and the loop
+// itself), and the ds_bpermute of a round are issued back to back (the rolled loop waited for the first three before it sent the
+// others: two round trips per round).
+constexpr uint64_t bash_round_const(int r)
+{
+    uint64_t c = 0x3BF5080AC8BA94B1ull;
+    for (int i = 0; i < r; ++i) c = (c >> 1) ^ (0xDC2BE1997FE0D8AEull & (0ull - (c & 1ull)));
+    return c;
+}
+template <int R>
+__device__ __forceinline__ void bash_round_cols(u64x2 &w0, u64x2 &w1, u64x2 &w2, const BashCol &c)
+{
+    constexpr uint64_t rc = bash_round_const(R);
+    u64x2 u0, t, u1, u2, r, r2;
+    u0.lo = bitop3<TT_XOR3>(w0.lo, w1.lo, w2.lo); u0.hi = bitop3<TT_XOR3>(w0.hi, w1.hi, w2.hi);
+    r = bash_col_rot<1>(u0, c);  t.lo = w1.lo ^ r.lo;  t.hi = w1.hi ^ r.hi;
+    r = bash_col_rot<0>(w0, c);  u1.lo = t.lo ^ r.lo;  u1.hi = t.hi ^ r.hi;
+    r = bash_col_rot<2>(w2, c);
+    r2 = bash_col_rot<3>(t, c);
+    u2.lo = bitop3<TT_XOR3>(w2.lo, r.lo, r2.lo); u2.hi = bitop3<TT_XOR3>(w2.hi, r.hi, r2.hi);
+    const uint32_t s0l = bitop3<TT_S0>(u0.lo, u1.lo, u2.lo), s0h = bitop3<TT_S0>(u0.hi, u1.hi, u2.hi);
+    const uint32_t s1l = bitop3<TT_S1>(u0.lo, u1.lo, u2.lo), s1h = bitop3<TT_S1>(u0.hi, u1.hi, u2.hi);
+    const uint32_t p1l = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a1, (int)s1l), p1h = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a1, (int)s1h);
+    const uint32_t p0l = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a0, (int)s0l), p0h = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a0, (int)s0h);
+    // pi2 = (1,0,3,2,5,4,7,6) is a DPP quad_perm: computed and moved WHILE the four ds_bpermute are on their round trip (its wait
+    // states cost nothing there), which also takes two of six operations off the LDS crossbar
+    const uint32_t s2l = bitop3<TT_S2>(u0.lo, u1.lo, u2.lo), s2h = bitop3<TT_S2>(u0.hi, u1.hi, u2.hi);
+    w1.lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s2l, 0xB1, 0xF, 0xF, true);
+    w1.hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s2h, 0xB1, 0xF, 0xF, true);
+    w0.lo = p1l; w0.hi = p1h;
+    w2.lo = p0l ^ ((uint32_t)rc & c.last);
+    w2.hi = p0h ^ ((uint32_t)(rc >> 32) & c.last);
+}
+template <int R = 0>
 __device__ __forceinline__ void bash_f_cols(u64x2 &w0, u64x2 &w1, u64x2 &w2, const BashCol &c)
 {
-    uint64_t rc = 0x3BF5080AC8BA94B1ull;
-#pragma unroll 1
-    for (int round = 0; round < 24; ++round) {
-        u64x2 u0, t, u1, u2, r, r2;
-        u0.lo = bitop3<TT_XOR3>(w0.lo, w1.lo, w2.lo); u0.hi = bitop3<TT_XOR3>(w0.hi, w1.hi, w2.hi);
-        r = bash_col_rot<1>(u0, c);  t.lo = w1.lo ^ r.lo;  t.hi = w1.hi ^ r.hi;
-        r = bash_col_rot<0>(w0, c);  u1.lo = t.lo ^ r.lo;  u1.hi = t.hi ^ r.hi;
-        r = bash_col_rot<2>(w2, c);
-        r2 = bash_col_rot<3>(t, c);
-        u2.lo = bitop3<TT_XOR3>(w2.lo, r.lo, r2.lo); u2.hi = bitop3<TT_XOR3>(w2.hi, r.hi, r2.hi);
-        const uint32_t s0l = bitop3<TT_S0>(u0.lo, u1.lo, u2.lo), s0h = bitop3<TT_S0>(u0.hi, u1.hi, u2.hi);
-        const uint32_t s1l = bitop3<TT_S1>(u0.lo, u1.lo, u2.lo), s1h = bitop3<TT_S1>(u0.hi, u1.hi, u2.hi);
-        const uint32_t s2l = bitop3<TT_S2>(u0.lo, u1.lo, u2.lo), s2h = bitop3<TT_S2>(u0.hi, u1.hi, u2.hi);
-        w0.lo = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a1, (int)s1l); w0.hi = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a1, (int)s1h);
-        w1.lo = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a2, (int)s2l); w1.hi = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a2, (int)s2h);
-        w2.lo = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a0, (int)s0l) ^ ((uint32_t)rc & c.last);
-        w2.hi = (uint32_t)__builtin_amdgcn_ds_bpermute(c.a0, (int)s0h) ^ ((uint32_t)(rc >> 32) & c.last);
-        rc = bash_next_const(rc);
-    }
+    bash_round_cols<R>(w0, w1, w2, c);
+    if constexpr (R + 1 < 24) bash_f_cols<R + 1>(w0, w1, w2, c);
 }
 
 }  // namespace bee2hip
