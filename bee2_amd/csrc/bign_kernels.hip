@@ -40,6 +40,8 @@
 // HBM traffic is irrelevant here (148 B of input per ~5e5 VALU ops at l = 128): the bound is
 // the integer multiplier rate.
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -170,12 +172,14 @@ __device__ __forceinline__ void to_affine(feT<N> &x, feT<N> &y, const jacT<N> &T
 template <int N>
 __device__ __forceinline__ bool prep_scalars(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
                                              const uint8_t *__restrict__ pubkeys, size_t idx, const VerifyScratch &S,
-                                             bool write, affT<N> &Q, feT<N> &u, uint32_t (&w)[N / 2 + 1])
+                                             bool write, affT<N> &Q, feT<N> &u, uint32_t (&w)[N / 2 + 1],
+                                             size_t pk_stride = 8 * N)
 {
     constexpr int NO = 4 * N;                       // octets per field element
 
-    load_fe_bytes(Q.x, pubkeys + 2 * NO * idx);
-    load_fe_bytes(Q.y, pubkeys + 2 * NO * idx + NO);
+    // pk_stride: octets between public keys (2 NO; 0 = ONE key for the whole batch, bign_onekey_kernel)
+    load_fe_bytes(Q.x, pubkeys + pk_stride * idx);
+    load_fe_bytes(Q.y, pubkeys + pk_stride * idx + NO);
     feT<N> s1, H;
     const uint8_t *sig = sigs + (NO + NO / 2) * idx;   // s0 (NO/2 octets) || s1 (NO octets)
     load_fe_words(s1, sig + NO / 2);
@@ -645,7 +649,7 @@ __device__ __forceinline__ bool bit_at(const uint32_t *k, int i) { return (k[i >
 template <int N>
 __global__ __launch_bounds__(64)
 void bign_slow_kernel(const uint8_t *__restrict__ sigs, const uint8_t *__restrict__ pubkeys,
-                      size_t n, VerifyScratch S)
+                      size_t n, VerifyScratch S, size_t pk_stride)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
@@ -662,8 +666,8 @@ void bign_slow_kernel(const uint8_t *__restrict__ sigs, const uint8_t *__restric
     fe_set_zero(G.X);
     for (int i = 0; i < N; ++i) G.Y.v[i] = curve_yG<N>()[i];
     fe_set_one(G.Z);
-    load_fe_bytes(Q.X, pubkeys + 2 * NO * idx);
-    load_fe_bytes(Q.Y, pubkeys + 2 * NO * idx + NO);
+    load_fe_bytes(Q.X, pubkeys + pk_stride * idx);             // pk_stride = 2 NO, or 0 for a batch under one key
+    load_fe_bytes(Q.Y, pubkeys + pk_stride * idx + NO);
     fe_set_one(Q.Z);
     fe_set_zero(T.X); fe_set_one(T.Y); fe_set_zero(T.Z);
 #pragma unroll 1
@@ -919,6 +923,100 @@ void bign_gtable16_kernel(const uint4 *__restrict__ gtab8, uint4 *__restrict__ g
     feT<N> x, y;
     to_affine(x, y, T);
     store_aff(e, x, y);
+}
+
+// ------------------------------------------------------ one signer (round 4) ---
+// Many signatures under ONE public key -- the shape of `bee2cmd sig vfy` over a tree of files (cmd/core/cmd_sig.c:484-490), of a
+// signed log or package repository.  Q is then a FIXED base like G: a comb table of Q (8-bit windows, entry (win, b) =
+// b 2^(8 win) Q affine, win = 0 .. 2N: v = s0 + 2^l has 16 N + 1 bits) replaces the 16 N doublings, the 4 N additions on the
+// signed radix-16 digits and the per-signature table 1Q..8Q with its normalisation of bign_prep / bign_main: R = u G + v Q
+// is 2 N mixed additions for v (the top window is always 1: the accumulator starts there) and 2 N for u on the 16-bit
+// table of G -- 32 instead of 128 doublings + 48 additions on the 256-bit curve.  The table (278 / 612 / 1 072 KiB) is built
+// once per (device, key) from the 2N + 1 points 2^(8 win) Q the host hands over (a chain of 16 N doublings: 25 us on a host
+// core, 0.5 ms for a lone wavefront) and cached.  Same verdicts as bign_main: exceptional additions send the signature to
+// bign_slow_kernel (which reads the one key with stride 0).
+template <int N>
+__global__ __launch_bounds__(64)
+void bign_ktable_kernel(const uint4 *__restrict__ base, uint4 *__restrict__ ktab)
+{
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (2 * N + 1) * GT8_ENTRIES) return;
+    const int win = id / GT8_ENTRIES, b = id % GT8_ENTRIES;
+    uint4 *e = ktab + (size_t)id * (N / 2);
+    if (b == 0) { for (int k = 0; k < N / 2; ++k) e[k] = make_uint4(0, 0, 0, 0); return; }
+    affT<N> B;
+    load_aff(B, base + (size_t)win * (N / 2));
+    jacT<N> P, T;
+    P.X = B.x; P.Y = B.y; fe_set_one(P.Z);
+    fe_set_zero(T.X); fe_set_one(T.Y); fe_set_zero(T.Z);
+#pragma unroll 1
+    for (int i = 7; i >= 0; --i) {
+        jac_dbl(T);
+        if ((b >> i) & 1) jac_add_complete(T, P);
+    }
+    // b 2^(8 win) < q and Q is a point of the (prime-order) curve -- the host checked -- so T != O
+    feT<N> x, y;
+    to_affine(x, y, T);
+    store_aff(e, x, y);
+}
+
+// one lane per signature: range checks and scalars (prep_scalars with the one key), then the two combs; leaves (X, Z) of R for
+// bign_inv_kernel like bign_main_kernel.  key = the public key in device memory (2 NO octets, behind the table).
+template <int N, class OPS = VtOps>
+__global__ __launch_bounds__(256, (N == 8 ? 4 : N == 12 ? 1 : 2))
+void bign_onekey_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs, const uint8_t *__restrict__ key,
+                        size_t n, VerifyScratch S, const uint4 *__restrict__ gtab, const uint4 *__restrict__ ktab)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    constexpr int W = Comb<N>::W;
+    constexpr int NO = 4 * N;
+    feT<N> u;
+    {
+        affT<N> Q;
+        uint32_t w[N / 2 + 1];
+        if (!prep_scalars<N>(hashes, sigs, key, idx, S, true, Q, u, w, 0)) return;      // status = the error code
+    }
+    bool ok = true;
+    jacT<N> T;
+    {
+        affT<N> E;                                                           // the top window of v = s0 + 2^l is 1
+        load_aff(E, ktab + ((size_t)(2 * N) * GT8_ENTRIES + 1) * (N / 2));
+        T.X = E.x; T.Y = E.y; fe_set_one(T.Z);
+    }
+    const uint32_t *s0 = reinterpret_cast<const uint32_t *>(sigs + (NO + NO / 2) * idx);
+#pragma unroll 1
+    for (int l = 0; l < N / 2; ++l) {
+        uint32_t word = s0[l];
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t b = word & 255u;
+            word >>= 8;
+            if (b != 0) {
+                affT<N> E;
+                load_aff(E, ktab + ((size_t)(4 * l + k) * GT8_ENTRIES + b) * (N / 2));
+                ok &= jac_madd<N, OPS>(T, E);
+            }
+        }
+    }
+    // + u G : comb over the W-bit windows of u, as bign_main_kernel
+#pragma unroll 1
+    for (int win = 0; win < 32 * N / W; ++win) {
+        const uint32_t b = u.v[0] & ((1u << W) - 1u);
+#pragma unroll
+        for (int l = 0; l < N - 1; ++l) u.v[l] = (u.v[l] >> W) | (u.v[l + 1] << (32 - W));
+        u.v[N - 1] >>= W;
+        if (b != 0) {
+            affT<N> E;
+            load_aff(E, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
+            ok &= jac_madd<N, OPS>(T, E);
+        }
+    }
+    ok &= !fe_is_zero(T.Z);
+    if (!ok) { S.status[idx] = ST_SLOW; return; }
+    S.status[idx] = ST_PENDING;
+    store_soa(S.rx, S.n_pad, idx, T.X);
+    store_soa(S.u, S.n_pad, idx, T.Z);
 }
 
 // Table of the signing side's one-lane kernel (round 3): signed 6-bit windows, entry (i, j) = j 2^(6i) G, j = 1..32, at
@@ -1385,7 +1483,7 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
         }
     }
     hipLaunchKernelGGL(bign_slow_kernel<N>, dim3(g64), dim3(64), 0, st, (const uint8_t *)d_sigs,
-                       (const uint8_t *)d_pubkeys, n, S);
+                       (const uint8_t *)d_pubkeys, n, S, (size_t)(2 * NO_));
     // signatures per inversion.  Each lane runs one chain (division steps, then 5 multiplications per
     // signature) and a lone wavefront issues at about a third of a SIMD's rate, so fewer, longer lanes cost
     // little until the lanes no longer cover the SIMDs: measured best at 2^18 signatures K = 8 on the 256-bit
@@ -1460,6 +1558,130 @@ err_t launch_bign_verify(size_t l, const uint8_t *oid_der, size_t oid_len, const
     if (l == 192) return launch_bign_verify_t<12>(oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, st);
     if (l == 256) return launch_bign_verify_t<16>(oid_der, oid_len, d_hashes, d_sigs, d_pubkeys, n, d_codes, st);
     return ERR_BAD_PARAMS;
+}
+
+// ---- one signer: table cache and launcher --------------------------------------------------------------------------
+// The comb table of a public key lives in device memory, keyed by (device, curve, key octets); the last KEYTAB_SLOTS keys per
+// process are kept (a table is 278 KiB .. 1 MiB: the card holds as many as anybody wants, the limit only bounds the scan).
+// A launcher holds a reference while it queues its kernels; the table is freed when the last reference goes, and hipFree
+// waits for the device, so a kernel already queued never loses its table.
+struct KeyTab {
+    int dev = -1, n_limbs = 0;
+    uint8_t key[128] = {0};
+    uint4 *tab = nullptr;              // (2N + 1) x 256 affine points, then the key itself (2 NO octets)
+    uint64_t stamp = 0;
+    ~KeyTab() { if (tab) (void)hipFree(tab); }
+};
+constexpr size_t KEYTAB_SLOTS = 16;
+static std::vector<std::shared_ptr<KeyTab>> &g_keytabs = *new std::vector<std::shared_ptr<KeyTab>>;   // (never destroyed: no hipFree behind the runtime's back at exit)
+static uint64_t g_keytab_clock = 0;
+static std::atomic<unsigned long long> g_keytab_builds{0};
+unsigned long long bign_onekey_table_builds() { return g_keytab_builds.load(); }
+
+template <int N>
+static err_t bign_key_table(std::shared_ptr<KeyTab> &out, const uint8_t *pubkey, const uint8_t *base, hipStream_t st)
+{
+    constexpr size_t NO = 4 * N, pt = 8 * N;
+    int dev = 0;
+    B2H_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_bign_mu);
+    for (auto &k : g_keytabs)
+        if (k->dev == dev && k->n_limbs == N && memcmp(k->key, pubkey, 2 * NO) == 0) { k->stamp = ++g_keytab_clock; out = k; return ERR_OK; }
+    auto k = std::make_shared<KeyTab>();
+    const size_t entries = (size_t)(2 * N + 1) * GT8_ENTRIES;
+    // the base points are staged behind the key, in the same block: [table | key | base points]
+    if (hipMalloc((void **)&k->tab, entries * pt + 2 * NO + (size_t)(2 * N + 1) * pt) != hipSuccess) { (void)hipGetLastError(); k->tab = nullptr; return ERR_OUTOFMEMORY; }
+    uint8_t *d_key = reinterpret_cast<uint8_t *>(k->tab) + entries * pt;
+    uint8_t *d_base = d_key + 2 * NO;
+    B2H_TRY(hipMemcpyAsync(d_key, pubkey, 2 * NO, hipMemcpyHostToDevice, st));
+    B2H_TRY(hipMemcpyAsync(d_base, base, (size_t)(2 * N + 1) * pt, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(bign_ktable_kernel<N>, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, st, (const uint4 *)d_base, k->tab);
+    B2H_TRY(hipGetLastError());
+    B2H_TRY(hipStreamSynchronize(st));          // (the host buffers are the caller's; other streams may use the table next)
+    k->dev = dev; k->n_limbs = N;
+    memcpy(k->key, pubkey, 2 * NO);
+    k->stamp = ++g_keytab_clock;
+    g_keytab_builds.fetch_add(1);
+    if (g_keytabs.size() >= KEYTAB_SLOTS) {
+        size_t old = 0;
+        for (size_t i = 1; i < g_keytabs.size(); ++i) if (g_keytabs[i]->stamp < g_keytabs[old]->stamp) old = i;
+        g_keytabs[old] = k;                      // the evicted table goes when its last user lets go of it
+    } else g_keytabs.push_back(k);
+    out = k;
+    return ERR_OK;
+}
+
+template <int N>
+static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len, const void *d_hashes, const void *d_sigs,
+                                         const uint8_t *pubkey, const uint8_t *base, size_t n, void *d_codes, hipStream_t st)
+{
+    uint4 *gtab = nullptr;
+    err_t code;
+    {
+        std::lock_guard<std::mutex> lk(g_bign_mu);
+        code = bign_table<N>(&gtab, st);
+    }
+    if (code != ERR_OK) return code;
+    std::shared_ptr<KeyTab> kt;
+    code = bign_key_table<N>(kt, pubkey, base, st);
+    if (code != ERR_OK) return code;
+    const uint8_t *d_key = reinterpret_cast<const uint8_t *>(kt->tab) + (size_t)(2 * N + 1) * GT8_ENTRIES * 8 * N;
+    VerifyScratch S;
+    code = bign_scratch<N>(st, n, S);
+    if (code != ERR_OK) return code;
+    OidArg oid;
+    code = make_oid_arg(oid, oid_der, oid_len, st);
+    if (code != ERR_OK) return code;
+    const unsigned g256 = (unsigned)((n + 255) / 256), g64 = (unsigned)((n + 63) / 64);
+    hipLaunchKernelGGL((bign_onekey_kernel<N, VtOps>), dim3(g256), dim3(256), 0, st, (const uint8_t *)d_hashes, (const uint8_t *)d_sigs,
+                       d_key, n, S, (const uint4 *)gtab, (const uint4 *)kt->tab);
+    hipLaunchKernelGGL(bign_slow_kernel<N>, dim3(g64), dim3(64), 0, st, (const uint8_t *)d_sigs, d_key, n, S, (size_t)0);
+    // shared inversions and the hash tail: as launch_bign_verify_t
+    constexpr size_t inv_lanes = N == 8 ? 32768 : 65536;
+    const size_t k_inv = std::min<size_t>(16, std::max<size_t>(1, n / inv_lanes));
+    const size_t lanes = (n + k_inv - 1) / k_inv;
+    hipLaunchKernelGGL(bign_inv_kernel<N>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, n, lanes, (int)k_inv, S);
+    constexpr size_t row_bytes = (2 * N + 1) * 4;
+    if (N == 8 && n >= 65536) {
+        auto kern = bign_tail_kernel<N, BeltTabTwoP, 1024>;
+        const size_t lds = BeltTabTwo::kBytes + 1024 * row_bytes;
+        B2H_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), lds, st, (const uint8_t *)d_hashes,
+                           (const uint8_t *)d_sigs, n, S, oid, (uint32_t *)d_codes);
+    } else {
+        hipLaunchKernelGGL((bign_tail_kernel<N, BeltTabSmall, 64>), dim3(g64), dim3(64), BeltTabSmall::kBytes + 64 * row_bytes, st,
+                           (const uint8_t *)d_hashes, (const uint8_t *)d_sigs, n, S, oid, (uint32_t *)d_codes);
+    }
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
+}
+
+// n signatures under ONE public key of a standard curve.  pubkey (2 NO octets) and base ((2N + 1) affine points 2^(8 w) Q,
+// 2 NO octets each, canonical) are HOST memory; the caller (capi.hip) has checked that Q is on the curve.
+err_t launch_bign_verify_onekey(size_t l, const uint8_t *oid_der, size_t oid_len, const void *d_hashes, const void *d_sigs,
+                                const uint8_t *pubkey, const uint8_t *base, size_t n, void *d_codes, hipStream_t st)
+{
+    if (n == 0) return ERR_OK;
+    if (l == 128) return launch_bign_verify_onekey_t<8>(oid_der, oid_len, d_hashes, d_sigs, pubkey, base, n, d_codes, st);
+    if (l == 192) return launch_bign_verify_onekey_t<12>(oid_der, oid_len, d_hashes, d_sigs, pubkey, base, n, d_codes, st);
+    if (l == 256) return launch_bign_verify_onekey_t<16>(oid_der, oid_len, d_hashes, d_sigs, pubkey, base, n, d_codes, st);
+    return ERR_BAD_PARAMS;
+}
+
+// the fallback of the one-key entries (a key off the curve, a non-standard parameter set): the key n times, then the general path
+__global__ __launch_bounds__(256)
+void bign_replicate_key_kernel(const uint4 *__restrict__ key, uint4 *__restrict__ out, size_t quads_per_key, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) out[i] = key[i % quads_per_key];
+}
+err_t launch_replicate_key(const void *d_key, size_t key_bytes, size_t n, void *d_out, hipStream_t st)
+{
+    if (n == 0) return ERR_OK;
+    const size_t q = key_bytes / 16, total = q * n;
+    hipLaunchKernelGGL(bign_replicate_key_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint4 *)d_key, (uint4 *)d_out, q, total);
+    B2H_TRY(hipGetLastError());
+    return ERR_OK;
 }
 
 // pubkeys n*(l/2) octets (16-byte aligned), codes n err_t

@@ -718,6 +718,37 @@ def main():
                 others["bignPubkeyVal"]["cpu_baseline"] = {
                     "value": cnt / (time.perf_counter() - t0), "unit": "keys/s", "cores": 1, "kind": "reference",
                     "sample": "1 s of bign128PubkeyVal calls, one thread"}
+        # many signatures of ONE signer (the `sig vfy` batch over a tree of files): the key is a fixed base with a comb
+        # table of its own, no doublings left.  2^18 DISTINCT valid signatures made here by the signing entry (untimed), 1/16 damaged.
+        from bee2_amd.engine import OID_BELT_HASH_DER as _OID
+        n1 = 1 << 18
+        g1 = torch.Generator(device="cuda"); g1.manual_seed(0x51D + dist.rank)
+        h1 = torch.empty(32 * n1, dtype=torch.uint8, device="cuda"); h1.view(torch.int64).random_(generator=g1)
+        d1 = bytes(range(7, 39))[:31] + b"\x21"
+        p1 = torch.empty(64, dtype=torch.uint8, device="cuda"); c1 = torch.empty(1, dtype=torch.int32, device="cuda")
+        eng.bignPubkeyCalcL_batch_dev(128, torch.from_numpy(np.frombuffer(d1, dtype=np.uint8).copy()).cuda(), p1, c1)
+        s1 = torch.empty(48 * n1, dtype=torch.uint8, device="cuda"); cs = torch.empty(n1, dtype=torch.int32, device="cuda")
+        eng.bignSign2L_batch_dev(128, _OID, h1, torch.from_numpy(np.frombuffer(d1 * n1, dtype=np.uint8).copy()).cuda(), s1, cs)
+        torch.cuda.synchronize()
+        pub1 = p1.cpu().numpy().tobytes()
+        bad1 = torch.from_numpy(rng.choice(n1, n1 // 16, replace=False)).cuda()
+        s1.view(n1, 48)[bad1, 5] ^= 0x10
+        codes1 = torch.empty(n1, dtype=torch.int32, device="cuda")
+        eng.bignVerifyL_onekey_batch_dev(128, _OID, h1, s1, pub1, codes1)            # builds and caches the key's table (untimed)
+        el = timed(dist, kv, 2, lambda: eng.bignVerifyL_onekey_batch_dev(128, _OID, h1, s1, pub1, codes1))
+        ms1 = timed.event_ms
+        want1 = torch.zeros(n1, dtype=torch.int32, device="cuda"); want1[bad1] = 510
+        MADS_ONEKEY = 32 * 732 + 5 * 72          # 16 + 16 mixed additions (8M + 3S) + x_R; inversions are division steps
+        others["bignVerify_onekey"] = {
+            "metric": "bign-curve256v1 verifies/s, one signer", "value": N * n1 * kv / el, "unit": "verifies/s", "steps": kv,
+            "ms_per_step": el / kv * 1e3, "verdicts_as_expected": bool((codes1 == want1).all() and int(cs.abs().sum()) == 0),
+            "vs_general_entry": (n1 * kv / el) / (n * kv / (others["bignVerify"]["ms_per_step"] * 1e-3 * kv)),
+            "config": {"workload": "bee2hip_bignVerifyL_onekey_batch_dev: 2^18 distinct signatures under ONE public key per GPU "
+                                   "(made by the signing entry, 1/16 damaged); the key's comb table cached"},
+            "roofline": {"kernels": "bign_onekey + slow + inv + tail", "bound": "valu-int", "avg_batch_ms": ms1,
+                         "mads_per_verify": MADS_ONEKEY, "achieved": MADS_ONEKEY * n1 / (ms1 * 1e-3) / 1e12, "peak": MAD_PEAK_T,
+                         "unit": "T v_mad_u64_u32 lane-ops/s", "frac": MADS_ONEKEY * n1 / (ms1 * 1e-3) / 1e12 / MAD_PEAK_T}}
+        del h1, s1, cs, codes1, want1
         del dh, ds, dk, codes, kk, kcodes
 
     # ------------------------------------------------- 8f-4: the 384- and 512-bit curves

@@ -1,0 +1,147 @@
+"""n signatures under ONE public key (bee2hip_bignVerify_onekey_batch / bee2hip_bignVerifyL_onekey_batch_dev; bign_kernels.hip
+"one signer"): the same verdict per signature as bignVerify (bign_sign.c:268-361) -- checked against the oracle, against the
+general batch entry on the same inputs with the key repeated, and on the reference's own fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from bee2_amd import engine as E
+from gpulib import dev, engine, host
+
+pytestmark = pytest.mark.gpu
+
+
+def _signed_under_one_key(eng, orc, l, n, seed):
+    """n valid signatures of random hashes under one private key (the signing kernels are pinned to the oracle elsewhere;
+    a sample is checked here again) -> (pubkey bytes, hashes, sigs) as numpy rows"""
+    no, sg = l // 4, 3 * l // 8
+    oid = E.LEVEL_OID[l]
+    priv = bytearray(orc.fill(no, seed))
+    priv[no - 1] &= 0x3F
+    priv = bytes(priv)
+    code, pub = orc.pubkey_calc(l, priv)
+    assert code == 0
+    hashes = dev(orc.fill(no * n, seed + 1))
+    privs = dev(priv * n)
+    sigs = torch.empty(sg * n, dtype=torch.uint8, device="cuda")
+    c = torch.empty(n, dtype=torch.int32, device="cuda")
+    eng.bignSign2L_batch_dev(l, oid, hashes, privs, sigs, c)
+    torch.cuda.synchronize()
+    assert int(c.abs().sum()) == 0
+    H = np.frombuffer(host(hashes), dtype=np.uint8).reshape(n, no).copy()
+    S = np.frombuffer(host(sigs), dtype=np.uint8).reshape(n, sg).copy()
+    for i in (0, n // 2, n - 1):
+        assert orc.sign2(l, oid, H[i].tobytes(), priv) == (0, S[i].tobytes())
+    return pub, H, S
+
+
+def _onekey_dev(eng, l, H, S, pub):
+    n = H.shape[0]
+    codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    eng.bignVerifyL_onekey_batch_dev(l, E.LEVEL_OID[l], dev(H.reshape(-1)), dev(S.reshape(-1)), pub, codes)
+    torch.cuda.synchronize()
+    return codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+
+
+def _general_dev(eng, l, H, S, pub):
+    n = H.shape[0]
+    codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    K = np.tile(np.frombuffer(pub, dtype=np.uint8), n)
+    eng.bignVerifyL_batch_dev(l, E.LEVEL_OID[l], dev(H.reshape(-1)), dev(S.reshape(-1)), dev(K), codes)
+    torch.cuda.synchronize()
+    return codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("l,n", [(128, 1), (128, 63), (128, 5000), (192, 1500), (256, 1200)])
+def test_onekey_batch_against_the_oracle(orc, l, n):
+    """valid signatures, a third of them damaged (hash, s0, s1; s1 >= q; s0 = 0 and s0 = ff..ff: every window of v empty / full):
+    every verdict against the oracle's bignVerify restatement"""
+    eng = engine()
+    no = l // 4
+    pub, H, S = _signed_under_one_key(eng, orc, l, n, 0x1C0 + l + n)
+    rng = np.random.default_rng(l * 7 + n)
+    bad = rng.choice(n, n // 3, replace=False)
+    kind = rng.integers(0, 3, bad.size)
+    bit = (1 << rng.integers(0, 8, bad.size)).astype(np.uint8)
+    sel = bad[kind == 0]; H[sel, rng.integers(0, no, sel.size)] ^= bit[kind == 0]
+    sel = bad[kind == 1]; S[sel, rng.integers(0, no // 2, sel.size)] ^= bit[kind == 1]
+    sel = bad[kind == 2]; S[sel, no // 2 + rng.integers(0, no, sel.size)] ^= bit[kind == 2]
+    if n >= 60:
+        S[5, no // 2:] = 0xFF                         # s1 >= q
+        S[6, : no // 2] = 0                           # v = 2^l: only the top window
+        S[7, : no // 2] = 0xFF
+        S[8, : no // 2] = 0; S[8, 3] = 0x80           # one window of v
+    got = _onekey_dev(eng, l, H, S, pub)
+    want = np.array(orc.verify_batch_l(l, E.LEVEL_OID[l], H.tobytes(), S.tobytes(), pub * n, nthreads=32), dtype=np.int64)
+    diff = np.nonzero(got != want)[0]
+    assert diff.size == 0, (diff[:5], got[diff[:5]], want[diff[:5]])
+    assert int((want == 0).sum()) >= n - n // 3 - 4
+    if n >= 60:
+        assert want[5] == 510 and 510 in want[bad]
+    # the general entry with the key repeated says the same
+    assert np.array_equal(_general_dev(eng, l, H, S, pub), want)
+    # host-pointer form
+    code, hc = eng.bignVerify_onekey_batch(H.tobytes(), S.tobytes(), pub, oid_der=E.LEVEL_OID[l], params=eng.bignParamsStd(E.CURVE_NAME[l]))
+    assert code == 0 and np.array_equal(np.array(hc, dtype=np.int64), want)
+
+
+def test_onekey_reference_fixtures_grouped_by_key(golden):
+    """the 2048 genuine triples of the reference (64 key pairs) and its edge fixtures, one call per distinct key: the codes of
+    the fixtures -- among them keys off the curve and coordinates >= p (the general path with the key repeated)"""
+    eng = engine()
+    hs, ss, ps = golden.bign_base_arrays()
+    n = len(hs) // 32
+    cases = [(hs[32 * i: 32 * i + 32], ss[48 * i: 48 * i + 48], ps[64 * i: 64 * i + 64], 0) for i in range(n)]
+    cases += [tuple(bytes.fromhex(c[k]) for k in ("hash", "sig", "pubkey")) + (c["code"],) for c in golden.bign_edge
+              if len(bytes.fromhex(c["sig"])) == 48 and len(bytes.fromhex(c["pubkey"])) == 64 and len(bytes.fromhex(c["hash"])) == 32]
+    groups = {}
+    for h, s, p, code in cases:
+        groups.setdefault(p, []).append((h, s, code))
+    assert len(groups) >= 64
+    seen = set()
+    for p, items in groups.items():
+        H = np.frombuffer(b"".join(x[0] for x in items), dtype=np.uint8).reshape(-1, 32)
+        S = np.frombuffer(b"".join(x[1] for x in items), dtype=np.uint8).reshape(-1, 48)
+        got = _onekey_dev(eng, 128, H, S, p)
+        want = np.array([x[2] for x in items], dtype=np.int64)
+        assert np.array_equal(got, want), (p.hex(), got, want)
+        seen |= set(want.tolist())
+    assert {0, 505, 510} <= seen
+
+
+def test_onekey_full_size_against_the_general_entry(orc):
+    """2^18 + 5 signatures under one key, 1/16 of them damaged: every verdict equal to the general batch entry's (itself compared with
+    the oracle entry by entry in test_gpu_bign.py), a sample against the oracle; a second key evicts nothing it should not"""
+    eng = engine()
+    l, n = 128, (1 << 18) + 5
+    pub, H, S = _signed_under_one_key(eng, orc, l, n, 0x51D)
+    rng = np.random.default_rng(0x51D)
+    bad = rng.choice(n, n // 16, replace=False)
+    S[bad, rng.integers(0, 48, bad.size)] ^= 0x04
+    got = _onekey_dev(eng, l, H, S, pub)
+    want = _general_dev(eng, l, H, S, pub)
+    assert np.array_equal(got, want)
+    assert int((got == 510).sum()) == bad.size and int((got == 0).sum()) == n - bad.size
+    idx = list(range(0, n, 4099))
+    o = orc.verify_batch_l(l, E.LEVEL_OID[l], H[idx].tobytes(), S[idx].tobytes(), pub * len(idx), nthreads=8)
+    assert np.array_equal(np.array(o, dtype=np.int64), got[idx])
+    # 20 other keys in between (more than the cache keeps), then the first one again
+    for k in range(20):
+        p2, H2, S2 = _signed_under_one_key(eng, orc, l, 40, 0x700 + k)
+        assert not _onekey_dev(eng, l, H2, S2, p2).any()
+        assert (_onekey_dev(eng, l, H2, S2, pub) == 510).all()          # the wrong key
+    assert np.array_equal(_onekey_dev(eng, l, H[:4096], S[:4096], pub), want[:4096])
+
+
+def test_onekey_argument_checks(orc):
+    eng = engine()
+    pub, H, S = _signed_under_one_key(eng, orc, 128, 4, 0x99)
+    params = eng.bignParamsStd(E.CURVE_NAME[128])
+    assert eng.bignVerify_onekey_batch(H.tobytes(), S.tobytes(), pub, oid_der=b"\x06\x01", params=params)[0] == E.ERR_BAD_OID
+    assert eng.bignVerify_onekey_batch(b"", b"", pub, params=params) == (0, [])
+    bad = bytearray(pub); bad[0] ^= 1                                     # off the curve: the general path's verdicts
+    code, c1 = eng.bignVerify_onekey_batch(H.tobytes(), S.tobytes(), bytes(bad), params=params)
+    code2, c2 = eng.bignVerify_batch(H.tobytes(), S.tobytes(), bytes(bad) * 4, params=params)
+    assert code == 0 and code2 == 0 and c1 == c2 and all(c != 0 for c in c1)
+    big = b"\xff" * 64                                                    # coordinates >= p
+    assert eng.bignVerify_onekey_batch(H.tobytes(), S.tobytes(), big, params=params) == (0, [505] * 4)
