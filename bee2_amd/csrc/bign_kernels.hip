@@ -962,10 +962,13 @@ void bign_ktable_kernel(const uint4 *__restrict__ base, uint4 *__restrict__ ktab
 
 // one lane per signature: range checks and scalars (prep_scalars with the one key), then the two combs; leaves (X, Z) of R for
 // bign_inv_kernel like bign_main_kernel.  key = the public key in device memory (2 NO octets, behind the table).
-template <int N, class OPS = VtOps>
+// Q16: the windows of v are 16 bits wide and read from ktab16 (entry (w, b) = b 2^(16 w) Q, w = 0 .. N - 1: the table a key gets
+// once enough signatures have been verified under it, bign_key_table) -- N instead of 2N additions for v.
+template <int N, class OPS = VtOps, bool Q16 = false>
 __global__ __launch_bounds__(256, (N == 8 ? 4 : N == 12 ? 1 : 2))
 void bign_onekey_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs, const uint8_t *__restrict__ key,
-                        size_t n, VerifyScratch S, const uint4 *__restrict__ gtab, const uint4 *__restrict__ ktab)
+                        size_t n, VerifyScratch S, const uint4 *__restrict__ gtab, const uint4 *__restrict__ ktab,
+                        const uint4 *__restrict__ ktab16)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
@@ -989,12 +992,13 @@ void bign_onekey_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
     for (int l = 0; l < N / 2; ++l) {
         uint32_t word = s0[l];
 #pragma unroll 1
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t b = word & 255u;
-            word >>= 8;
+        for (int k = 0; k < (Q16 ? 2 : 4); ++k) {
+            const uint32_t b = word & (Q16 ? 65535u : 255u);
+            word >>= Q16 ? 16 : 8;
             if (b != 0) {
                 affT<N> E;
-                load_aff(E, ktab + ((size_t)(4 * l + k) * GT8_ENTRIES + b) * (N / 2));
+                if (Q16) load_aff(E, ktab16 + ((size_t)(2 * l + k) * 65536 + b) * (N / 2));
+                else load_aff(E, ktab + ((size_t)(4 * l + k) * GT8_ENTRIES + b) * (N / 2));
                 ok &= jac_madd<N, OPS>(T, E);
             }
         }
@@ -1569,8 +1573,9 @@ struct KeyTab {
     int dev = -1, n_limbs = 0;
     uint8_t key[128] = {0};
     uint4 *tab = nullptr;              // (2N + 1) x 256 affine points, then the key itself (2 NO octets)
-    uint64_t stamp = 0;
-    ~KeyTab() { if (tab) (void)hipFree(tab); }
+    uint4 *tab16 = nullptr;            // N x 65536 affine points (32 / 72 / 128 MiB): once `used` says the key is a busy one
+    uint64_t stamp = 0, used = 0;      // signatures verified under the key so far
+    ~KeyTab() { if (tab) (void)hipFree(tab); if (tab16) (void)hipFree(tab16); }
 };
 constexpr size_t KEYTAB_SLOTS = 16;
 static std::vector<std::shared_ptr<KeyTab>> &g_keytabs = *new std::vector<std::shared_ptr<KeyTab>>;   // (never destroyed: no hipFree behind the runtime's back at exit)
@@ -1578,15 +1583,40 @@ static uint64_t g_keytab_clock = 0;
 static std::atomic<unsigned long long> g_keytab_builds{0};
 unsigned long long bign_onekey_table_builds() { return g_keytab_builds.load(); }
 
+// A key under which KEYTAB16_AFTER signatures have been verified gets the 16-bit table as well (0.3 / 1 / 2 ms to build -- the work
+// of ~2^17 signatures -- against a quarter of the additions saved from then on): made from the 8-bit one like G's (bign_gtable16_kernel).
+static int g_keytab16_log2 = -1;                     // -1: by curve (2^19 on the 256-bit curve, 2^20 on the wider ones); tests / A/B: tune 20
+void set_onekey_tab16(int v) { g_keytab16_log2 = v; }
 template <int N>
-static err_t bign_key_table(std::shared_ptr<KeyTab> &out, const uint8_t *pubkey, const uint8_t *base, hipStream_t st)
+static err_t bign_key_table16_locked(KeyTab &k, hipStream_t st)
 {
+    const size_t pt = 8 * N;
+    uint4 *t16 = nullptr;
+    if (hipMalloc((void **)&t16, (size_t)N * 65536 * pt) != hipSuccess) { (void)hipGetLastError(); return ERR_OK; }   // no room: the 8-bit table serves
+    hipLaunchKernelGGL(bign_gtable16_kernel<N>, dim3(N * 65536 / 256), dim3(256), 0, st, (const uint4 *)k.tab, t16);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(t16); return hip_fail(hipGetLastError(), "bign_gtable16_kernel (key)"); }
+    k.tab16 = t16;
+    return ERR_OK;
+}
+template <int N>
+static err_t bign_key_table(std::shared_ptr<KeyTab> &out, const uint4 **tab16, const uint8_t *pubkey, const uint8_t *base, size_t n, hipStream_t st)
+{
+    *tab16 = nullptr;                                 // (read under the lock: another thread may be giving the key its 16-bit table)
     constexpr size_t NO = 4 * N, pt = 8 * N;
     int dev = 0;
     B2H_TRY(hipGetDevice(&dev));
+    const int lg = g_keytab16_log2 >= 0 ? g_keytab16_log2 : N == 8 ? 19 : 20;
+    const uint64_t after = lg >= 63 ? ~(uint64_t)0 : (uint64_t)1 << lg;
     std::lock_guard<std::mutex> lk(g_bign_mu);
     for (auto &k : g_keytabs)
-        if (k->dev == dev && k->n_limbs == N && memcmp(k->key, pubkey, 2 * NO) == 0) { k->stamp = ++g_keytab_clock; out = k; return ERR_OK; }
+        if (k->dev == dev && k->n_limbs == N && memcmp(k->key, pubkey, 2 * NO) == 0) {
+            k->stamp = ++g_keytab_clock;
+            k->used += n;
+            if (!k->tab16 && k->used >= after) { const err_t c = bign_key_table16_locked<N>(*k, st); if (c != ERR_OK) return c; }
+            out = k;
+            *tab16 = k->tab16;
+            return ERR_OK;
+        }
     auto k = std::make_shared<KeyTab>();
     const size_t entries = (size_t)(2 * N + 1) * GT8_ENTRIES;
     // the base points are staged behind the key, in the same block: [table | key | base points]
@@ -1601,13 +1631,16 @@ static err_t bign_key_table(std::shared_ptr<KeyTab> &out, const uint8_t *pubkey,
     k->dev = dev; k->n_limbs = N;
     memcpy(k->key, pubkey, 2 * NO);
     k->stamp = ++g_keytab_clock;
+    k->used = n;
     g_keytab_builds.fetch_add(1);
+    if (k->used >= after) { const err_t c = bign_key_table16_locked<N>(*k, st); if (c != ERR_OK) return c; }
     if (g_keytabs.size() >= KEYTAB_SLOTS) {
         size_t old = 0;
         for (size_t i = 1; i < g_keytabs.size(); ++i) if (g_keytabs[i]->stamp < g_keytabs[old]->stamp) old = i;
         g_keytabs[old] = k;                      // the evicted table goes when its last user lets go of it
     } else g_keytabs.push_back(k);
     out = k;
+    *tab16 = k->tab16;
     return ERR_OK;
 }
 
@@ -1623,7 +1656,8 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
     }
     if (code != ERR_OK) return code;
     std::shared_ptr<KeyTab> kt;
-    code = bign_key_table<N>(kt, pubkey, base, st);
+    const uint4 *tab16 = nullptr;
+    code = bign_key_table<N>(kt, &tab16, pubkey, base, n, st);
     if (code != ERR_OK) return code;
     const uint8_t *d_key = reinterpret_cast<const uint8_t *>(kt->tab) + (size_t)(2 * N + 1) * GT8_ENTRIES * 8 * N;
     VerifyScratch S;
@@ -1633,8 +1667,12 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
     code = make_oid_arg(oid, oid_der, oid_len, st);
     if (code != ERR_OK) return code;
     const unsigned g256 = (unsigned)((n + 255) / 256), g64 = (unsigned)((n + 63) / 64);
-    hipLaunchKernelGGL((bign_onekey_kernel<N, VtOps>), dim3(g256), dim3(256), 0, st, (const uint8_t *)d_hashes, (const uint8_t *)d_sigs,
-                       d_key, n, S, (const uint4 *)gtab, (const uint4 *)kt->tab);
+    if (tab16)
+        hipLaunchKernelGGL((bign_onekey_kernel<N, VtOps, true>), dim3(g256), dim3(256), 0, st, (const uint8_t *)d_hashes, (const uint8_t *)d_sigs,
+                           d_key, n, S, (const uint4 *)gtab, (const uint4 *)kt->tab, tab16);
+    else
+        hipLaunchKernelGGL((bign_onekey_kernel<N, VtOps, false>), dim3(g256), dim3(256), 0, st, (const uint8_t *)d_hashes, (const uint8_t *)d_sigs,
+                           d_key, n, S, (const uint4 *)gtab, (const uint4 *)kt->tab, (const uint4 *)nullptr);
     hipLaunchKernelGGL(bign_slow_kernel<N>, dim3(g64), dim3(64), 0, st, (const uint8_t *)d_sigs, d_key, n, S, (size_t)0);
     // shared inversions and the hash tail: as launch_bign_verify_t
     constexpr size_t inv_lanes = N == 8 ? 32768 : 65536;

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from bee2_amd import engine as E
-from gpulib import dev, engine, host
+from gpulib import dev, engine, exp_engine, host
 
 pytestmark = pytest.mark.gpu
 
@@ -145,3 +145,33 @@ def test_onekey_argument_checks(orc):
     assert code == 0 and code2 == 0 and c1 == c2 and all(c != 0 for c in c1)
     big = b"\xff" * 64                                                    # coordinates >= p
     assert eng.bignVerify_onekey_batch(H.tobytes(), S.tobytes(), big, params=params) == (0, [505] * 4)
+
+
+@pytest.mark.parametrize("l", [128, 192, 256])
+def test_onekey_both_table_forms(orc, l):
+    """the 8-bit table of a key and the 16-bit one it gets after enough signatures, each FORCED (experiments build, tune 20), and
+    the switch from one to the other in mid-life of a key: verdicts of the general entry, valid and damaged signatures"""
+    eng = exp_engine()
+    tune = eng.lib.bee2hip_internal_tune
+    n = 3000
+    pub, H, S = _signed_under_one_key(eng, orc, l, n, 0x616 + l)
+    S[::7, 2] ^= 0x40
+    S[5, : l // 8] = 0
+    S[6, : l // 8] = 0xFF
+    want = _general_dev(eng, l, H, S, pub)
+    assert int((want == 510).sum()) >= n // 7 and int((want == 0).sum()) >= n - n // 7 - 4
+    try:
+        assert tune(20, 63) == 0                       # never: 8-bit windows
+        assert np.array_equal(_onekey_dev(eng, l, H, S, pub), want)
+        assert tune(20, 13) == 0                       # after 2^13 signatures: this key has 3000 behind it, two more calls cross the line
+        assert np.array_equal(_onekey_dev(eng, l, H, S, pub), want)
+        assert np.array_equal(_onekey_dev(eng, l, H, S, pub), want)
+        assert np.array_equal(_onekey_dev(eng, l, H[:100], S[:100], pub), want[:100])
+        assert tune(20, 0) == 0                        # a new key gets both tables at once
+        pub2, H2, S2 = _signed_under_one_key(eng, orc, l, 257, 0x717 + l)
+        S2[3, 1] ^= 1
+        assert np.array_equal(_onekey_dev(eng, l, H2, S2, pub2), _general_dev(eng, l, H2, S2, pub2))
+        o = orc.verify_batch_l(l, E.LEVEL_OID[l], H2.tobytes(), S2.tobytes(), pub2 * 257, nthreads=8)
+        assert np.array_equal(np.array(o, dtype=np.int64), _onekey_dev(eng, l, H2, S2, pub2))
+    finally:
+        tune(20, -1)
