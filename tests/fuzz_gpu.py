@@ -445,7 +445,60 @@ def f_sign_generic(rnd):
     return code != 0 or eng.bignVerify(Ps, oid, hs[0], sig, eng.bignPubkeyCalc(Ps, d)[1]) == orc.verify_l(l, oid, hs[0], sig, orc.pubkey_calc(l, d)[1]) == 0
 
 
-FAMILIES = [("bashF", f_bashF), ("beltCTR", f_ctr), ("mac/hash", f_mac_hash), ("modes", f_modes), ("dwp/che", f_aead),
+def f_onekey(rnd):
+    """n signatures under ONE key (bee2hip_bignVerifyL_onekey_batch_dev / the host-pointer form): a random key -- sometimes a fixture's
+    (Q = G among them), sometimes off the curve or >= p (the fallback) --, signatures of the fixtures and fresh ones made by the signing
+    entry, random damage; the oracle's bignVerify on every entry.  Experiments build: the 8-bit / 16-bit table of the key forced."""
+    l = rnd.choice((128, 128, 192, 256))
+    no, sg = l // 4, 3 * l // 8
+    oid = LEVEL_OID[l]
+    base = _triples(l)
+    n = max(1, size(rnd, 3000 if l == 128 else 500, (64, 256, 1024)))
+    mode = rnd.randrange(5)
+    H, S = bytearray(), bytearray()
+    if mode == 0:                                               # a fixture's key with that fixture's and other fixtures' signatures
+        h0, s0, pub = (bytes(x) for x in rnd.choice(base))
+        for _ in range(n):
+            h, s, p = rnd.choice(base) if rnd.randrange(3) else (h0, s0, pub)
+            H += h; S += s
+    else:                                                       # a fresh key, fresh signatures
+        d = bytearray(orc.fill(no, rnd.randrange(1 << 30))); d[no - 1] &= 0x3F
+        pub = orc.pubkey_calc(l, bytes(d))[1]
+        hs = orc.fill(no * n, rnd.randrange(1 << 30))
+        sigs = torch.empty(sg * n, dtype=torch.uint8, device="cuda"); c = torch.empty(n, dtype=torch.int32, device="cuda")
+        eng.bignSign2L_batch_dev(l, oid, dev(hs), dev(bytes(d) * n), sigs, c)
+        torch.cuda.synchronize()
+        H += hs; S += host(sigs)
+        if mode == 1:
+            pub = bytearray(pub); pub[rnd.randrange(2 * no)] ^= 1 << rnd.randrange(8); pub = bytes(pub)     # off the curve
+        elif mode == 2 and rnd.randrange(3) == 0:
+            pub = (b"\xff" * no + pub[no:]) if rnd.randrange(2) else (pub[:no] + b"\xff" * no)              # a coordinate >= p
+    for i in range(n):
+        k = rnd.randrange(12)
+        if k == 1:
+            S[sg * i + rnd.randrange(sg)] ^= 1 << rnd.randrange(8)
+        elif k == 2:
+            H[no * i + rnd.randrange(no)] ^= 1 << rnd.randrange(8)
+        elif k == 3:
+            S[sg * i + no // 2: sg * (i + 1)] = b"\xff" * no     # s1 >= q
+        elif k == 4:
+            S[sg * i: sg * i + no // 2] = bytes(no // 2) if rnd.randrange(2) else b"\xff" * (no // 2)
+    want = orc.verify_batch_l(l, oid, bytes(H), bytes(S), bytes(pub) * n, nthreads=16)
+    _tune(20, rnd.choice((-1, 63, 0, 8)))
+    try:
+        if rnd.randrange(3) == 0:
+            code, got = eng.bignVerify_onekey_batch(bytes(H), bytes(S), bytes(pub), oid_der=oid, params=eng.bignParamsStd(bee2_amd.engine.CURVE_NAME[l]))
+            return code == 0 and got == list(want)
+        codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        for _ in range(rnd.choice((1, 1, 3))):                  # (a key crosses its table threshold between calls)
+            eng.bignVerifyL_onekey_batch_dev(l, oid, dev(H), dev(S), bytes(pub), codes)
+        torch.cuda.synchronize()
+        return [int(x) & 0xFFFFFFFF for x in codes.cpu().numpy()] == list(want)
+    finally:
+        _tune(20, -1)
+
+
+FAMILIES = [("onekey", f_onekey), ("bashF", f_bashF), ("beltCTR", f_ctr), ("mac/hash", f_mac_hash), ("modes", f_modes), ("dwp/che", f_aead),
             ("verify", f_verify), ("ragged/mixed", f_ragged_mixed), ("sign", f_sign), ("multi", f_multi), ("sign-generic", f_sign_generic)]
 
 

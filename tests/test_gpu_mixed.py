@@ -246,6 +246,24 @@ def test_sigvfy_front_end_example(orc, golden, tmp_path):
     lst.write_text("\n".join(l for l, w in zip(lines, want) if w.endswith("OK")) + "\n")
     r = subprocess.run([str(exe), str(lst)], capture_output=True, text=True)
     assert r.returncode == 0 and all(x.endswith(": OK") for x in r.stdout.splitlines()) and len(r.stdout.splitlines()) == 4
+    # a list under ONE key: the example takes the one-signer entry (bee2hip_bignVerifyL_onekey_batch_dev)
+    d = orc.fill(32, 0x1516)
+    code, pub = eng.bignLPubkeyCalc(128, d)
+    assert code == 0
+    lines, want = [], []
+    for i, n in enumerate((5, 0, 3000, 77, 64)):
+        p = tmp_path / f"k{i}.bin"
+        data = orc.fill(n, 700 + i)
+        p.write_bytes(data)
+        code, sig = eng.bignLSign2(128, orc.belt_hash(data), d)
+        assert code == 0
+        if i == 3:
+            sig = sig[:20] + bytes([sig[20] ^ 8]) + sig[21:]
+        lines.append(f"{p} {sig.hex()} {pub.hex()}")
+        want.append(f"{p}: {'FAILED [signature]' if i == 3 else 'OK'}")
+    lst.write_text("\n".join(lines) + "\n")
+    r = subprocess.run([str(exe), str(lst)], capture_output=True, text=True)
+    assert r.returncode == 1 and sorted(r.stdout.splitlines()) == sorted(want), (r.stdout, r.stderr)
 
 
 def test_c_selftest_example_runs_the_stb_vectors(golden, tmp_path):
