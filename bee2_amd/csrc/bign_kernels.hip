@@ -43,6 +43,8 @@
 #include <atomic>
 #include <memory>
 #include <mutex>
+#include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 #include "belt_dev.hpp"
@@ -50,6 +52,7 @@
 #include "bign_fe29.hpp"
 #include "bign_quad29.hpp"
 #include "common.hpp"
+#include "host_bign.hpp"          // host arithmetic of the one-signer path: the points 2^(8 w) Q (verification: no secrets)
 #include "bign_curves.inc"
 
 namespace bee2hip {
@@ -666,8 +669,14 @@ void bign_slow_kernel(const uint8_t *__restrict__ sigs, const uint8_t *__restric
     fe_set_zero(G.X);
     for (int i = 0; i < N; ++i) G.Y.v[i] = curve_yG<N>()[i];
     fe_set_one(G.Z);
-    load_fe_bytes(Q.X, pubkeys + pk_stride * idx);             // pk_stride = 2 NO, or 0 for a batch under one key
-    load_fe_bytes(Q.Y, pubkeys + pk_stride * idx + NO);
+    if (pk_stride == ~(size_t)0) {                             // K signers: the main kernel left Q in qtab row 0
+        affT<N> A;
+        load_qaff(A, S, 0, idx);
+        Q.X = A.x; Q.Y = A.y;
+    } else {
+        load_fe_bytes(Q.X, pubkeys + pk_stride * idx);         // pk_stride = 2 NO, or 0 for a batch under one key
+        load_fe_bytes(Q.Y, pubkeys + pk_stride * idx + NO);
+    }
     fe_set_one(Q.Z);
     fe_set_zero(T.X); fe_set_one(T.Y); fe_set_zero(T.Z);
 #pragma unroll 1
@@ -964,21 +973,35 @@ void bign_ktable_kernel(const uint4 *__restrict__ base, uint4 *__restrict__ ktab
 // bign_inv_kernel like bign_main_kernel.  key = the public key in device memory (2 NO octets, behind the table).
 // Q16: the windows of v are 16 bits wide and read from ktab16 (entry (w, b) = b 2^(16 w) Q, w = 0 .. N - 1: the table a key gets
 // once enough signatures have been verified under it, bign_key_table) -- N instead of 2N additions for v.
-template <int N, class OPS = VtOps, bool Q16 = false>
+// KEYED: K signers -- key = K public keys (2 NO octets each), key_index[i] < nkeys says whose signature i is, tabs[k] = the 8-bit
+// table of key k, or null for a key that is not a point of the curve: such signatures go to bign_slow_kernel, which like bee2 does not
+// look (it finds Q in qtab row 0, where the general path keeps it).  An index out of range is ERR_BAD_INPUT for that signature.
+template <int N, class OPS = VtOps, bool Q16 = false, bool KEYED = false>
 __global__ __launch_bounds__(256, (N == 8 ? 4 : N == 12 ? 1 : 2))
 void bign_onekey_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs, const uint8_t *__restrict__ key,
                         size_t n, VerifyScratch S, const uint4 *__restrict__ gtab, const uint4 *__restrict__ ktab,
-                        const uint4 *__restrict__ ktab16)
+                        const uint4 *__restrict__ ktab16, const uint32_t *__restrict__ key_index,
+                        const uint4 *const *__restrict__ tabs, uint32_t nkeys)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     constexpr int W = Comb<N>::W;
     constexpr int NO = 4 * N;
+    if (KEYED) {
+        const uint32_t k = key_index[idx];
+        if (k >= nkeys) { S.status[idx] = ERR_BAD_INPUT; return; }
+        key += (size_t)2 * NO * k;
+        ktab = tabs[k];
+    }
     feT<N> u;
     {
         affT<N> Q;
         uint32_t w[N / 2 + 1];
         if (!prep_scalars<N>(hashes, sigs, key, idx, S, true, Q, u, w, 0)) return;      // status = the error code
+        if (KEYED) {
+            store_qxy(S, 0, idx, Q.x, Q.y);                                             // (for bign_slow_kernel)
+            if (!ktab) { S.status[idx] = ST_SLOW; return; }
+        }
     }
     bool ok = true;
     jacT<N> T;
@@ -1564,6 +1587,54 @@ err_t launch_bign_verify(size_t l, const uint8_t *oid_der, size_t oid_len, const
     return ERR_BAD_PARAMS;
 }
 
+// ---- one signer: the host's share ----------------------------------------------------------------------------------
+// Is Q a point of the curve, and the 2N + 1 points 2^(8 w) Q the table kernel starts from: a chain of l doublings, ~25 us on a
+// host core (0.5 ms for a lone wavefront), made affine with one inversion.  NL = 64-bit limbs (N = 2 NL).
+template <int NL>
+static bool onekey_base_t(uint64_t crandall_c, const uint8_t *b_le, const uint8_t *pubkey, std::vector<uint8_t> &base)
+{
+    hostb::Curve<NL> E;                                 // (group law and field only: its tables of G are not needed)
+    E.F.c = crandall_c;
+    if (hostb::pubkey_val<NL>(E, b_le, pubkey) != ERR_OK) return false;
+    constexpr int W = 4 * NL + 1;                       // windows of 8 bits over l + 1 bits
+    const hostb::Field<NL> &F = E.F;
+    hostb::Aff<NL> Q;
+    for (int i = 0; i < NL; ++i) { Q.x.v[i] = hostp::ld64le(pubkey + 8 * i); Q.y.v[i] = hostp::ld64le(pubkey + 8 * NL + 8 * i); }
+    std::vector<hostb::Jac<NL>> P(W);
+    E.from_aff(P[0], Q, false);
+    for (int w = 1; w < W; ++w) {
+        P[w] = P[w - 1];
+        for (int k = 0; k < 8; ++k) { hostb::Jac<NL> t; E.dbl(t, P[w]); P[w] = t; }
+    }
+    // to affine with ONE inversion (Z != 0: a point of prime order q > 2^(l + 8) is doubled)
+    std::vector<hostb::Fe<NL>> pre(W);
+    hostb::Fe<NL> acc = P[0].Z;
+    pre[0] = acc;
+    for (int w = 1; w < W; ++w) { F.mul(acc, acc, P[w].Z); pre[w] = acc; }
+    if (hostb::Field<NL>::is_zero(acc)) return false;
+    hostb::Fe<NL> inv;
+    F.inv(inv, acc);
+    base.resize((size_t)W * 16 * NL);
+    for (int w = W - 1; w >= 0; --w) {
+        hostb::Fe<NL> zi, zi2, x, y;
+        if (w) { F.mul(zi, inv, pre[w - 1]); F.mul(inv, inv, P[w].Z); } else zi = inv;
+        F.sqr(zi2, zi);
+        F.mul(x, P[w].X, zi2);
+        F.mul(zi2, zi2, zi);
+        F.mul(y, P[w].Y, zi2);
+        uint8_t *o = base.data() + (size_t)w * 16 * NL;
+        for (int i = 0; i < NL; ++i) { hostp::st64le(o + 8 * i, x.v[i]); hostp::st64le(o + 8 * NL + 8 * i, y.v[i]); }
+    }
+    return true;
+}
+template <int N>
+static bool onekey_base(const uint8_t *pubkey, std::vector<uint8_t> &base)
+{
+    if (N == 8) return onekey_base_t<4>(BIGN128_CRANDALL_C, k_bign128_b, pubkey, base);
+    if (N == 12) return onekey_base_t<6>(BIGN192_CRANDALL_C, k_bign192_b, pubkey, base);
+    return onekey_base_t<8>(BIGN256_CRANDALL_C, k_bign256_b, pubkey, base);
+}
+
 // ---- one signer: table cache and launcher --------------------------------------------------------------------------
 // The comb table of a public key lives in device memory, keyed by (device, curve, key octets); the last KEYTAB_SLOTS keys per
 // process are kept (a table is 278 KiB .. 1 MiB: the card holds as many as anybody wants, the limit only bounds the scan).
@@ -1571,14 +1642,13 @@ err_t launch_bign_verify(size_t l, const uint8_t *oid_der, size_t oid_len, const
 // waits for the device, so a kernel already queued never loses its table.
 struct KeyTab {
     int dev = -1, n_limbs = 0;
-    uint8_t key[128] = {0};
     uint4 *tab = nullptr;              // (2N + 1) x 256 affine points, then the key itself (2 NO octets)
     uint4 *tab16 = nullptr;            // N x 65536 affine points (32 / 72 / 128 MiB): once `used` says the key is a busy one
     uint64_t stamp = 0, used = 0;      // signatures verified under the key so far
     ~KeyTab() { if (tab) (void)hipFree(tab); if (tab16) (void)hipFree(tab16); }
 };
-constexpr size_t KEYTAB_SLOTS = 16;
-static std::vector<std::shared_ptr<KeyTab>> &g_keytabs = *new std::vector<std::shared_ptr<KeyTab>>;   // (never destroyed: no hipFree behind the runtime's back at exit)
+constexpr size_t KEYTAB_SLOTS = 1024;                // (0.3 - 1 GiB of 8-bit tables when full)
+static std::unordered_map<std::string, std::shared_ptr<KeyTab>> &g_keytabs = *new std::unordered_map<std::string, std::shared_ptr<KeyTab>>;   // (never destroyed: no hipFree behind the runtime's back at exit)
 static uint64_t g_keytab_clock = 0;
 static std::atomic<unsigned long long> g_keytab_builds{0};
 unsigned long long bign_onekey_table_builds() { return g_keytab_builds.load(); }
@@ -1599,7 +1669,7 @@ static err_t bign_key_table16_locked(KeyTab &k, hipStream_t st)
     return ERR_OK;
 }
 template <int N>
-static err_t bign_key_table(std::shared_ptr<KeyTab> &out, const uint4 **tab16, const uint8_t *pubkey, const uint8_t *base, size_t n, hipStream_t st)
+static err_t bign_key_table(std::shared_ptr<KeyTab> &out, const uint4 **tab16, const uint8_t *pubkey, size_t n, hipStream_t st, bool want16 = true)
 {
     *tab16 = nullptr;                                 // (read under the lock: another thread may be giving the key its 16-bit table)
     constexpr size_t NO = 4 * N, pt = 8 * N;
@@ -1607,16 +1677,26 @@ static err_t bign_key_table(std::shared_ptr<KeyTab> &out, const uint4 **tab16, c
     B2H_TRY(hipGetDevice(&dev));
     const int lg = g_keytab16_log2 >= 0 ? g_keytab16_log2 : N == 8 ? 19 : 20;
     const uint64_t after = lg >= 63 ? ~(uint64_t)0 : (uint64_t)1 << lg;
+    std::string id(2 + 2 * NO, '\0');
+    id[0] = (char)dev; id[1] = (char)N;
+    memcpy(&id[2], pubkey, 2 * NO);
     std::lock_guard<std::mutex> lk(g_bign_mu);
-    for (auto &k : g_keytabs)
-        if (k->dev == dev && k->n_limbs == N && memcmp(k->key, pubkey, 2 * NO) == 0) {
+    {
+        const auto it = g_keytabs.find(id);
+        if (it != g_keytabs.end()) {
+            KeyTab *k = it->second.get();
             k->stamp = ++g_keytab_clock;
             k->used += n;
-            if (!k->tab16 && k->used >= after) { const err_t c = bign_key_table16_locked<N>(*k, st); if (c != ERR_OK) return c; }
-            out = k;
+            if (want16 && !k->tab16 && k->used >= after) { const err_t c = bign_key_table16_locked<N>(*k, st); if (c != ERR_OK) return c; }
+            out = it->second;
             *tab16 = k->tab16;
             return ERR_OK;
         }
+    }
+    // a key this process has not met (or has dropped): on the curve?  then its 2N + 1 starting points
+    std::vector<uint8_t> base_v;
+    if (!onekey_base<N>(pubkey, base_v)) return ERR_KEY_NOT_ON_CURVE;
+    const uint8_t *base = base_v.data();
     auto k = std::make_shared<KeyTab>();
     const size_t entries = (size_t)(2 * N + 1) * GT8_ENTRIES;
     // the base points are staged behind the key, in the same block: [table | key | base points]
@@ -1627,27 +1707,31 @@ static err_t bign_key_table(std::shared_ptr<KeyTab> &out, const uint4 **tab16, c
     B2H_TRY(hipMemcpyAsync(d_base, base, (size_t)(2 * N + 1) * pt, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(bign_ktable_kernel<N>, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, st, (const uint4 *)d_base, k->tab);
     B2H_TRY(hipGetLastError());
-    B2H_TRY(hipStreamSynchronize(st));          // (the host buffers are the caller's; other streams may use the table next)
+    B2H_TRY(hipStreamSynchronize(st));          // (base_v goes out of scope; other streams may use the table next)
     k->dev = dev; k->n_limbs = N;
-    memcpy(k->key, pubkey, 2 * NO);
     k->stamp = ++g_keytab_clock;
     k->used = n;
     g_keytab_builds.fetch_add(1);
-    if (k->used >= after) { const err_t c = bign_key_table16_locked<N>(*k, st); if (c != ERR_OK) return c; }
-    if (g_keytabs.size() >= KEYTAB_SLOTS) {
-        size_t old = 0;
-        for (size_t i = 1; i < g_keytabs.size(); ++i) if (g_keytabs[i]->stamp < g_keytabs[old]->stamp) old = i;
-        g_keytabs[old] = k;                      // the evicted table goes when its last user lets go of it
-    } else g_keytabs.push_back(k);
+    if (want16 && k->used >= after) { const err_t c = bign_key_table16_locked<N>(*k, st); if (c != ERR_OK) return c; }
+    if (g_keytabs.size() >= KEYTAB_SLOTS) {      // the least recently used one goes (when its last user lets go of it)
+        auto old = g_keytabs.begin();
+        for (auto it = g_keytabs.begin(); it != g_keytabs.end(); ++it) if (it->second->stamp < old->second->stamp) old = it;
+        g_keytabs.erase(old);
+    }
+    g_keytabs[id] = k;
     out = k;
     *tab16 = k->tab16;
     return ERR_OK;
 }
 
+// keys: nkeys public keys on the host; d_key_index: null = ONE key (nkeys = 1), else n x uint32 on the device
 template <int N>
 static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len, const void *d_hashes, const void *d_sigs,
-                                         const uint8_t *pubkey, const uint8_t *base, size_t n, void *d_codes, hipStream_t st)
+                                         const uint8_t *keys, size_t nkeys, const void *d_key_index, size_t n, void *d_codes,
+                                         hipStream_t st)
 {
+    constexpr size_t NO = 4 * N, TAB = (size_t)(2 * N + 1) * GT8_ENTRIES * 8 * N;       // octets of an 8-bit table; the key follows it
+    const bool keyed = d_key_index != nullptr;
     uint4 *gtab = nullptr;
     err_t code;
     {
@@ -1655,11 +1739,34 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
         code = bign_table<N>(&gtab, st);
     }
     if (code != ERR_OK) return code;
-    std::shared_ptr<KeyTab> kt;
+    std::vector<std::shared_ptr<KeyTab>> kts(nkeys);
     const uint4 *tab16 = nullptr;
-    code = bign_key_table<N>(kt, &tab16, pubkey, base, n, st);
-    if (code != ERR_OK) return code;
-    const uint8_t *d_key = reinterpret_cast<const uint8_t *>(kt->tab) + (size_t)(2 * N + 1) * GT8_ENTRIES * 8 * N;
+    const uint8_t *d_keys = nullptr;
+    const uint4 *const *d_tabs = nullptr;
+    if (!keyed) {
+        code = bign_key_table<N>(kts[0], &tab16, keys, n, st);
+        if (code != ERR_OK) return code;                           // (ERR_KEY_NOT_ON_CURVE: the caller's general path)
+        d_keys = reinterpret_cast<const uint8_t *>(kts[0]->tab) + TAB;
+    } else {
+        // every key's 8-bit table (a key off the curve has none: null); the pointers and the keys go up in one block
+        std::vector<uint8_t> blk(nkeys * (8 + 2 * NO));
+        uint64_t *ptrs = reinterpret_cast<uint64_t *>(blk.data());
+        for (size_t k = 0; k < nkeys; ++k) {
+            const uint4 *dummy = nullptr;
+            code = bign_key_table<N>(kts[k], &dummy, keys + 2 * NO * k, 0, st, false);
+            if (code == ERR_KEY_NOT_ON_CURVE) { ptrs[k] = 0; continue; }
+            if (code != ERR_OK) return code;
+            ptrs[k] = (uint64_t)(uintptr_t)kts[k]->tab;
+        }
+        memcpy(blk.data() + 8 * nkeys, keys, 2 * NO * nkeys);
+        void *d_blk = nullptr;
+        code = scratch_for_stream(st, 13, blk.size(), &d_blk);
+        if (code != ERR_OK) return code;
+        B2H_TRY(hipMemcpyAsync(d_blk, blk.data(), blk.size(), hipMemcpyHostToDevice, st));
+        B2H_TRY(hipStreamSynchronize(st));                          // (blk is pageable and goes out of scope)
+        d_tabs = reinterpret_cast<const uint4 *const *>(d_blk);
+        d_keys = reinterpret_cast<const uint8_t *>(d_blk) + 8 * nkeys;
+    }
     VerifyScratch S;
     code = bign_scratch<N>(st, n, S);
     if (code != ERR_OK) return code;
@@ -1667,13 +1774,17 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
     code = make_oid_arg(oid, oid_der, oid_len, st);
     if (code != ERR_OK) return code;
     const unsigned g256 = (unsigned)((n + 255) / 256), g64 = (unsigned)((n + 63) / 64);
-    if (tab16)
-        hipLaunchKernelGGL((bign_onekey_kernel<N, VtOps, true>), dim3(g256), dim3(256), 0, st, (const uint8_t *)d_hashes, (const uint8_t *)d_sigs,
-                           d_key, n, S, (const uint4 *)gtab, (const uint4 *)kt->tab, tab16);
+    const uint8_t *dh = (const uint8_t *)d_hashes, *dsg = (const uint8_t *)d_sigs;
+    if (keyed)
+        hipLaunchKernelGGL((bign_onekey_kernel<N, VtOps, false, true>), dim3(g256), dim3(256), 0, st, dh, dsg, d_keys, n, S, (const uint4 *)gtab,
+                           (const uint4 *)nullptr, (const uint4 *)nullptr, (const uint32_t *)d_key_index, d_tabs, (uint32_t)nkeys);
+    else if (tab16)
+        hipLaunchKernelGGL((bign_onekey_kernel<N, VtOps, true, false>), dim3(g256), dim3(256), 0, st, dh, dsg, d_keys, n, S, (const uint4 *)gtab,
+                           (const uint4 *)kts[0]->tab, tab16, (const uint32_t *)nullptr, (const uint4 *const *)nullptr, 1u);
     else
-        hipLaunchKernelGGL((bign_onekey_kernel<N, VtOps, false>), dim3(g256), dim3(256), 0, st, (const uint8_t *)d_hashes, (const uint8_t *)d_sigs,
-                           d_key, n, S, (const uint4 *)gtab, (const uint4 *)kt->tab, (const uint4 *)nullptr);
-    hipLaunchKernelGGL(bign_slow_kernel<N>, dim3(g64), dim3(64), 0, st, (const uint8_t *)d_sigs, d_key, n, S, (size_t)0);
+        hipLaunchKernelGGL((bign_onekey_kernel<N, VtOps, false, false>), dim3(g256), dim3(256), 0, st, dh, dsg, d_keys, n, S, (const uint4 *)gtab,
+                           (const uint4 *)kts[0]->tab, (const uint4 *)nullptr, (const uint32_t *)nullptr, (const uint4 *const *)nullptr, 1u);
+    hipLaunchKernelGGL(bign_slow_kernel<N>, dim3(g64), dim3(64), 0, st, dsg, d_keys, n, S, keyed ? ~(size_t)0 : (size_t)0);
     // shared inversions and the hash tail: as launch_bign_verify_t
     constexpr size_t inv_lanes = N == 8 ? 32768 : 65536;
     const size_t k_inv = std::min<size_t>(16, std::max<size_t>(1, n / inv_lanes));
@@ -1684,25 +1795,38 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
         auto kern = bign_tail_kernel<N, BeltTabTwoP, 1024>;
         const size_t lds = BeltTabTwo::kBytes + 1024 * row_bytes;
         B2H_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), lds, st, (const uint8_t *)d_hashes,
-                           (const uint8_t *)d_sigs, n, S, oid, (uint32_t *)d_codes);
+        hipLaunchKernelGGL(kern, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), lds, st, dh, dsg, n, S, oid, (uint32_t *)d_codes);
     } else {
         hipLaunchKernelGGL((bign_tail_kernel<N, BeltTabSmall, 64>), dim3(g64), dim3(64), BeltTabSmall::kBytes + 64 * row_bytes, st,
-                           (const uint8_t *)d_hashes, (const uint8_t *)d_sigs, n, S, oid, (uint32_t *)d_codes);
+                           dh, dsg, n, S, oid, (uint32_t *)d_codes);
     }
     B2H_TRY(hipGetLastError());
     return ERR_OK;
 }
 
-// n signatures under ONE public key of a standard curve.  pubkey (2 NO octets) and base ((2N + 1) affine points 2^(8 w) Q,
-// 2 NO octets each, canonical) are HOST memory; the caller (capi.hip) has checked that Q is on the curve.
+// n signatures under ONE public key of a standard curve; pubkey (2 NO octets) is HOST memory.  ERR_KEY_NOT_ON_CURVE: see common.hpp.
 err_t launch_bign_verify_onekey(size_t l, const uint8_t *oid_der, size_t oid_len, const void *d_hashes, const void *d_sigs,
-                                const uint8_t *pubkey, const uint8_t *base, size_t n, void *d_codes, hipStream_t st)
+                                const uint8_t *pubkey, size_t n, void *d_codes, hipStream_t st)
 {
     if (n == 0) return ERR_OK;
-    if (l == 128) return launch_bign_verify_onekey_t<8>(oid_der, oid_len, d_hashes, d_sigs, pubkey, base, n, d_codes, st);
-    if (l == 192) return launch_bign_verify_onekey_t<12>(oid_der, oid_len, d_hashes, d_sigs, pubkey, base, n, d_codes, st);
-    if (l == 256) return launch_bign_verify_onekey_t<16>(oid_der, oid_len, d_hashes, d_sigs, pubkey, base, n, d_codes, st);
+    try {
+        if (l == 128) return launch_bign_verify_onekey_t<8>(oid_der, oid_len, d_hashes, d_sigs, pubkey, 1, nullptr, n, d_codes, st);
+        if (l == 192) return launch_bign_verify_onekey_t<12>(oid_der, oid_len, d_hashes, d_sigs, pubkey, 1, nullptr, n, d_codes, st);
+        if (l == 256) return launch_bign_verify_onekey_t<16>(oid_der, oid_len, d_hashes, d_sigs, pubkey, 1, nullptr, n, d_codes, st);
+    } catch (const std::bad_alloc &) { return ERR_OUTOFMEMORY; }
+    return ERR_BAD_PARAMS;
+}
+// n signatures of nkeys signers (pubkeys: HOST, nkeys x 2 NO octets; d_key_index: n x uint32 on the device)
+err_t launch_bign_verify_keyed(size_t l, const uint8_t *oid_der, size_t oid_len, const void *d_hashes, const void *d_sigs,
+                               const uint8_t *pubkeys, size_t nkeys, const void *d_key_index, size_t n, void *d_codes, hipStream_t st)
+{
+    if (n == 0) return ERR_OK;
+    if (nkeys == 0 || !d_key_index) return ERR_BAD_INPUT;
+    try {
+        if (l == 128) return launch_bign_verify_onekey_t<8>(oid_der, oid_len, d_hashes, d_sigs, pubkeys, nkeys, d_key_index, n, d_codes, st);
+        if (l == 192) return launch_bign_verify_onekey_t<12>(oid_der, oid_len, d_hashes, d_sigs, pubkeys, nkeys, d_key_index, n, d_codes, st);
+        if (l == 256) return launch_bign_verify_onekey_t<16>(oid_der, oid_len, d_hashes, d_sigs, pubkeys, nkeys, d_key_index, n, d_codes, st);
+    } catch (const std::bad_alloc &) { return ERR_OUTOFMEMORY; }
     return ERR_BAD_PARAMS;
 }
 

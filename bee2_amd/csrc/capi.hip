@@ -1055,63 +1055,17 @@ static err_t sign_one_host(size_t l, const octet oid_der[], size_t oid_len, cons
 }
 
 // ---- n signatures under ONE public key (bign_kernels.hip "one signer") ----
-// The host's share: is Q a point of the curve (else the general path: no on-curve check there either, bign_sign.c:306-311,
-// and the comb table of a point off the curve proves nothing about the reference's walk), and the 2N + 1 points 2^(8 w) Q
-// the table kernel starts from -- a chain of l doublings, ~25 us here, 0.5 ms for a lone wavefront.
-template <int NL>
-static bool onekey_base_t(const hostb::Curve<NL> &E, const octet *b_le, const octet *pubkey, std::vector<octet> &base)
-{
-    if (hostb::pubkey_val<NL>(E, b_le, pubkey) != ERR_OK) return false;
-    constexpr int W = 4 * NL + 1;                       // windows of 8 bits over l + 1 bits
-    const hostb::Field<NL> &F = E.F;
-    hostb::Aff<NL> Q;
-    for (int i = 0; i < NL; ++i) { Q.x.v[i] = hostp::ld64le(pubkey + 8 * i); Q.y.v[i] = hostp::ld64le(pubkey + 8 * NL + 8 * i); }
-    std::vector<hostb::Jac<NL>> P(W);
-    E.from_aff(P[0], Q, false);
-    for (int w = 1; w < W; ++w) {
-        P[w] = P[w - 1];
-        for (int k = 0; k < 8; ++k) { hostb::Jac<NL> t; E.dbl(t, P[w]); P[w] = t; }
-    }
-    // to affine with ONE inversion (Z != 0: a point of prime order q > 2^(l + 8) is doubled)
-    std::vector<hostb::Fe<NL>> pre(W);
-    hostb::Fe<NL> acc = P[0].Z;
-    pre[0] = acc;
-    for (int w = 1; w < W; ++w) { F.mul(acc, acc, P[w].Z); pre[w] = acc; }
-    if (hostb::Field<NL>::is_zero(acc)) return false;
-    hostb::Fe<NL> inv;
-    F.inv(inv, acc);
-    base.resize((size_t)W * 16 * NL);
-    for (int w = W - 1; w >= 0; --w) {
-        hostb::Fe<NL> zi, zi2, x, y;
-        if (w) { F.mul(zi, inv, pre[w - 1]); F.mul(inv, inv, P[w].Z); } else zi = inv;
-        F.sqr(zi2, zi);
-        F.mul(x, P[w].X, zi2);
-        F.mul(zi2, zi2, zi);
-        F.mul(y, P[w].Y, zi2);
-        octet *o = base.data() + (size_t)w * 16 * NL;
-        for (int i = 0; i < NL; ++i) { hostp::st64le(o + 8 * i, x.v[i]); hostp::st64le(o + 8 * NL + 8 * i, y.v[i]); }
-    }
-    return true;
-}
-static bool onekey_base(size_t l, const octet *pubkey, std::vector<octet> &base)
-{
-    if (l == 128) return onekey_base_t<4>(host_curve<4>(0, BIGN128_CRANDALL_C), k_curves[0].b, pubkey, base);
-    if (l == 192) return onekey_base_t<6>(host_curve<6>(1, BIGN192_CRANDALL_C), k_curves[1].b, pubkey, base);
-    return onekey_base_t<8>(host_curve<8>(2, BIGN256_CRANDALL_C), k_curves[2].b, pubkey, base);
-}
 // device-resident hashes / signatures, the key on the host; standard curve
 static err_t verify_onekey_dev(size_t l, const octet oid_der[], size_t oid_len, const void *d_hashes, const void *d_sigs,
                                const octet pubkey[], size_t n, void *d_codes, hipStream_t st)
 {
     const size_t no = l / 4;
-    try {
-        std::vector<octet> base;
-        if (onekey_base(l, pubkey, base))
-            return launch_bign_verify_onekey(l, oid_der, oid_len, d_hashes, d_sigs, pubkey, base.data(), n, d_codes, st);
-    } catch (const std::bad_alloc &) { return ERR_OUTOFMEMORY; }
-    // a key off the curve (or with a coordinate >= p): the general path with the key n times -- the reference's codes
+    err_t code = launch_bign_verify_onekey(l, oid_der, oid_len, d_hashes, d_sigs, pubkey, n, d_codes, st);
+    if (code != ERR_KEY_NOT_ON_CURVE) return code;
+    // a key off the curve (or with a coordinate >= p): bee2 does not check (bign_sign.c:306-311), and the comb table of such a
+    // point proves nothing about the reference's walk -- the general path with the key n times gives the reference's codes
     void *rep = nullptr;
-    err_t code = scratch_for_stream(st, 7, 2 * no * (n + 1), &rep);
+    code = scratch_for_stream(st, 7, 2 * no * (n + 1), &rep);
     if (code != ERR_OK) return code;
     octet *d_key = (octet *)rep + 2 * no * n;
     B2H_TRY(hipMemcpyAsync(d_key, pubkey, 2 * no, hipMemcpyHostToDevice, st));
@@ -1167,6 +1121,67 @@ extern "C" err_t bee2hip_bignVerify_onekey_batch(const bign_params *params, cons
     B2H_TRY(h2d(d, hashes, hb));
     B2H_TRY(h2d(d + so, sigs, sb));
     code = verify_onekey_dev(params->l, oid_der, oid_len, d, d + so, pubkey, n, d + co, nullptr);
+    if (code != ERR_OK) return code;
+    B2H_TRY(d2h(codes, d + co, 4 * n));
+    return ERR_OK;
+}
+
+// ---- n signatures of K signers: key_index[i] < nkeys says whose signature i is ----
+extern "C" err_t bee2hip_bignVerifyL_keyed_batch_dev(size_t l, const octet oid_der[], size_t oid_len, const void *d_hashes,
+                                                     const void *d_sigs, const octet pubkeys[], size_t nkeys,
+                                                     const void *d_key_index, size_t n, void *d_codes, void *stream)
+{
+    if (misaligned(d_hashes, 16) || misaligned(d_sigs, 16) || misaligned(d_codes, 4) || misaligned(d_key_index, 4)) return ERR_BAD_INPUT;
+    if (l != 128 && l != 192 && l != 256) return ERR_BAD_PARAMS;
+    if (n && (!d_hashes || !d_sigs || !pubkeys || !nkeys || !d_key_index || !d_codes)) return ERR_BAD_INPUT;
+    if (nkeys > 4096) return ERR_BAD_INPUT;             // (more signers than that: the general entry)
+    if (!oid_der_valid(oid_der, oid_len)) return ERR_BAD_OID;
+    if (n == 0) return ERR_OK;
+    err_t code = ensure_device();
+    if (code != ERR_OK) return code;
+    return launch_bign_verify_keyed(l, oid_der, oid_len, d_hashes, d_sigs, pubkeys, nkeys, d_key_index, n, d_codes, as_stream(stream));
+}
+
+extern "C" err_t bee2hip_bignVerify_keyed_batch(const bign_params *params, const octet oid_der[], size_t oid_len,
+                                                const octet *hashes, const octet *sigs, const octet *pubkeys, size_t nkeys,
+                                                const u32 *key_index, size_t n, err_t *codes)
+{
+    bool standard;
+    err_t code = params_check2(params, &standard);
+    if (code != ERR_OK) return code;
+    if (!standard) {
+        code = bign_generic_check(params);
+        if (code != ERR_OK) return code;
+    }
+    if (n && (!hashes || !sigs || !pubkeys || !nkeys || !key_index || !codes)) return ERR_BAD_INPUT;
+    if (!oid_der_valid(oid_der, oid_len)) return ERR_BAD_OID;
+    if (n == 0) return ERR_OK;
+    const size_t no = params->l / 4;
+    if (!standard || nkeys > 4096) {                   // general-curve kernels / a crowd of signers: every signature with its key, the general entry
+        try {
+            std::vector<octet> rep(2 * no * n);
+            std::vector<size_t> bad;
+            for (size_t i = 0; i < n; ++i) {
+                if (key_index[i] >= nkeys) { bad.push_back(i); memcpy(rep.data() + 2 * no * i, pubkeys, 2 * no); }
+                else memcpy(rep.data() + 2 * no * i, pubkeys + 2 * no * key_index[i], 2 * no);
+            }
+            code = bee2hip_bignVerify_batch(params, oid_der, oid_len, hashes, sigs, rep.data(), n, codes);
+            if (code == ERR_OK) for (size_t i : bad) codes[i] = ERR_BAD_INPUT;
+            return code;
+        } catch (const std::bad_alloc &) { return ERR_OUTOFMEMORY; }
+    }
+    code = ensure_device();
+    if (code != ERR_OK) return code;
+    const size_t hb = no * n, sb = (no + no / 2) * n;
+    const size_t so = (hb + 15) & ~(size_t)15, io = (so + sb + 15) & ~(size_t)15, co = (io + 4 * n + 15) & ~(size_t)15;
+    Scratch &s = t_scr[3];
+    code = s.need(co + n * 4);
+    if (code != ERR_OK) return code;
+    octet *d = (octet *)s.p;
+    B2H_TRY(h2d(d, hashes, hb));
+    B2H_TRY(h2d(d + so, sigs, sb));
+    B2H_TRY(h2d(d + io, key_index, 4 * n));
+    code = launch_bign_verify_keyed(params->l, oid_der, oid_len, d, d + so, pubkeys, nkeys, d + io, n, d + co, nullptr);
     if (code != ERR_OK) return code;
     B2H_TRY(d2h(codes, d + co, 4 * n));
     return ERR_OK;

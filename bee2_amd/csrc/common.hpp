@@ -75,10 +75,16 @@ err_t launch_belt_hash_stream(void *d_hs, const void *d_data, size_t nblocks, in
 err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, const void *d_order, size_t n,
                          void *d_digests, hipStream_t st);
 err_t launch_bign_pubkey_val(size_t l, const void *d_pubkeys, size_t n, void *d_codes, hipStream_t st);
-// n signatures under ONE key of a standard curve (bign_kernels.hip "one signer"): pubkey and base = the points 2^(8 w) Q,
-// w = 0 .. l / 8, affine -- HOST memory; the key is on the curve (capi.hip checks)
+// n signatures under ONE key of a standard curve (bign_kernels.hip "one signer"): pubkey = HOST memory.  Returns
+// ERR_KEY_NOT_ON_CURVE (not a bee2 code; never leaves the library) when the key is not a point of the curve: the caller
+// then takes the general path, which like bee2 does not look (bign_sign.c:306-311).
+constexpr err_t ERR_KEY_NOT_ON_CURVE = 0xFFFFFFF1u;
 err_t launch_bign_verify_onekey(size_t l, const uint8_t *oid_der, size_t oid_len, const void *d_hashes, const void *d_sigs,
-                                const uint8_t *pubkey, const uint8_t *base, size_t n, void *d_codes, hipStream_t st);
+                                const uint8_t *pubkey, size_t n, void *d_codes, hipStream_t st);
+// ... of nkeys signers: pubkeys HOST (nkeys keys), d_key_index n x uint32 on the device (an index >= nkeys: ERR_BAD_INPUT for that
+// signature); a key off the curve costs its signatures the slow kernel, not the call
+err_t launch_bign_verify_keyed(size_t l, const uint8_t *oid_der, size_t oid_len, const void *d_hashes, const void *d_sigs,
+                               const uint8_t *pubkeys, size_t nkeys, const void *d_key_index, size_t n, void *d_codes, hipStream_t st);
 err_t launch_replicate_key(const void *d_key, size_t key_bytes, size_t n, void *d_out, hipStream_t st);
 unsigned long long bign_onekey_table_builds();
 // non-standard parameter sets (bign_generic_kernels.hip): params already through bignParamsCheck's tests

@@ -83,6 +83,7 @@ BATCH_SYMBOLS = [
     "bee2hip_beltModes_blocks_dev", "bee2hip_beltCBCEncr_batch_dev", "bee2hip_beltBDE_blocks_dev", "bee2hip_beltSDE_sectors_dev", "bee2hip_beltDWP_absorb_dev", "bee2hip_beltCHE_blocks_dev",
     "bee2hip_bign128Verify_batch_dev", "bee2hip_bignVerify_batch_dev", "bee2hip_bignVerifyL_batch_dev",
     "bee2hip_bignVerify_onekey_batch", "bee2hip_bignVerifyL_onekey_batch_dev",
+    "bee2hip_bignVerify_keyed_batch", "bee2hip_bignVerifyL_keyed_batch_dev",
     "bee2hip_bignPubkeyVal_batch", "bee2hip_bignPubkeyValL_batch_dev",
     "bee2hip_bignPubkeyCalc_batch", "bee2hip_bignSign2_batch", "bee2hip_bignSignK_batch",
     "bee2hip_device_count", "bee2hip_multi_plan", "bee2hip_bashF_batch_multi", "bee2hip_beltCTR_bulk_multi",
@@ -308,6 +309,15 @@ class Engine:
             _sz(l), bytes(oid_der), _sz(len(oid_der)), self._ptr(hashes), self._ptr(sigs), bytes(pubkey),
             _sz(n), self._ptr(codes), self._stream()), "bignVerifyL_onekey_batch_dev")
 
+    def bignVerifyL_keyed_batch_dev(self, l, oid_der, hashes, sigs, pubkeys, key_index, codes):
+        """n signatures of K signers: pubkeys = K keys (host bytes), key_index = n x int32 / uint32 device tensor"""
+        n = hashes.numel() // (l // 4)
+        nkeys = len(pubkeys) // (l // 2)
+        assert sigs.numel() == (3 * l // 8) * n and key_index.numel() == n and codes.numel() >= n and key_index.element_size() == 4
+        self._check(self.lib.bee2hip_bignVerifyL_keyed_batch_dev(
+            _sz(l), bytes(oid_der), _sz(len(oid_der)), self._ptr(hashes), self._ptr(sigs), bytes(pubkeys), _sz(nkeys),
+            self._ptr(key_index), _sz(n), self._ptr(codes), self._stream()), "bignVerifyL_keyed_batch_dev")
+
     def bignPubkeyValL_batch_dev(self, l, pubkeys, codes):
         n = pubkeys.numel() // (l // 2)
         assert codes.numel() >= n
@@ -363,6 +373,17 @@ class Engine:
         codes = (_u32 * max(n, 1))()
         code = self.lib.bee2hip_bignVerify_onekey_batch(ctypes.byref(params), bytes(oid_der), _sz(len(oid_der)),
                                                         bytes(hashes), bytes(sigs), bytes(pubkey), _sz(n), codes)
+        return code, list(codes)[:n]
+
+    def bignVerify_keyed_batch(self, hashes, sigs, pubkeys, key_index, oid_der=OID_BELT_HASH_DER, params=None):
+        if params is None:
+            params = self.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
+        n = len(hashes) // (params.l // 4)
+        nkeys = len(pubkeys) // (params.l // 2)
+        codes = (_u32 * max(n, 1))()
+        idx = (_u32 * max(n, 1))(*key_index)
+        code = self.lib.bee2hip_bignVerify_keyed_batch(ctypes.byref(params), bytes(oid_der), _sz(len(oid_der)), bytes(hashes),
+                                                       bytes(sigs), bytes(pubkeys), _sz(nkeys), idx, _sz(n), codes)
         return code, list(codes)[:n]
 
     def bignPubkeyVal_batch(self, pubkeys, params):

@@ -751,7 +751,31 @@ def main():
             "roofline": {"kernels": "bign_onekey + slow + inv + tail", "bound": "valu-int", "avg_batch_ms": ms1,
                          "mads_per_verify": MADS_ONEKEY, "achieved": MADS_ONEKEY * n1 / (ms1 * 1e-3) / 1e12, "peak": MAD_PEAK_T,
                          "unit": "T v_mad_u64_u32 lane-ops/s", "frac": MADS_ONEKEY * n1 / (ms1 * 1e-3) / 1e12 / MAD_PEAK_T}}
-        del h1, s1, cs, codes1, want1
+        # ... and of a FEW signers: the population SURVEY 8d describes (64 key pairs), every signature distinct, 1/16 damaged
+        nk = 64
+        dks = [bytes(((k * 37 + i * 11 + 5) & 255) for i in range(31)) + b"\x21" for k in range(nk)]
+        pk = torch.empty(64 * nk, dtype=torch.uint8, device="cuda"); ck = torch.empty(nk, dtype=torch.int32, device="cuda")
+        eng.bignPubkeyCalcL_batch_dev(128, torch.from_numpy(np.frombuffer(b"".join(dks), dtype=np.uint8).copy()).cuda(), pk, ck)
+        kidx = torch.from_numpy(rng.integers(0, nk, n1).astype(np.int32)).cuda()
+        dall = torch.from_numpy(np.frombuffer(b"".join(dks), dtype=np.uint8).copy()).cuda().view(nk, 32)[kidx.long()].reshape(-1).contiguous()
+        eng.bignSign2L_batch_dev(128, _OID, h1, dall, s1, cs)
+        torch.cuda.synchronize()
+        s1.view(n1, 48)[bad1, 5] ^= 0x10
+        pubs_k = pk.cpu().numpy().tobytes()
+        eng.bignVerifyL_keyed_batch_dev(128, _OID, h1, s1, pubs_k, kidx, codes1)       # untimed: the 64 tables are built and cached
+        el = timed(dist, kv, 2, lambda: eng.bignVerifyL_keyed_batch_dev(128, _OID, h1, s1, pubs_k, kidx, codes1))
+        msk = timed.event_ms
+        MADS_KEYED = 32 * 732 + 5 * 72           # 16 (u G) + 16 (v Q, 8-bit windows) mixed additions + x_R
+        others["bignVerify_keyed"] = {
+            "metric": "bign-curve256v1 verifies/s, 64 signers", "value": N * n1 * kv / el, "unit": "verifies/s", "steps": kv,
+            "ms_per_step": el / kv * 1e3, "verdicts_as_expected": bool((codes1 == want1).all() and int(cs.abs().sum()) == 0 and int(ck.abs().sum()) == 0),
+            "vs_general_entry": (n1 * kv / el) / (n / (others["bignVerify"]["ms_per_step"] * 1e-3)),
+            "config": {"workload": "bee2hip_bignVerifyL_keyed_batch_dev: 2^18 distinct signatures of 64 signers per GPU (random signer per "
+                                   "signature, 1/16 damaged); the signers' 8-bit comb tables cached (17 MiB)"},
+            "roofline": {"kernels": "bign_onekey<keyed> + slow + inv + tail", "bound": "valu-int", "avg_batch_ms": msk,
+                         "mads_per_verify": MADS_KEYED, "achieved": MADS_KEYED * n1 / (msk * 1e-3) / 1e12, "peak": MAD_PEAK_T,
+                         "unit": "T v_mad_u64_u32 lane-ops/s", "frac": MADS_KEYED * n1 / (msk * 1e-3) / 1e12 / MAD_PEAK_T}}
+        del h1, s1, cs, codes1, want1, kidx, dall, pk
         del dh, ds, dk, codes, kk, kcodes
 
     # ------------------------------------------------- 8f-4: the 384- and 512-bit curves

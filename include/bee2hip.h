@@ -415,7 +415,7 @@ err_t bee2hip_bignVerifyL_batch_dev(size_t l, const octet oid_der[], size_t oid_
 /* n signatures under ONE public key -- the batch `bee2cmd sig vfy` makes of a tree of files signed by one party
    (cmd/core/cmd_sig.c:484-490), a signed log, a package repository.  Same verdict per signature as
    bignVerify(params, oid, hash_i, sig_i, pubkey) (bign_sign.c:268-361), in about a fifth of the work: the key becomes a
-   fixed base with a comb table of its own (built once per key and device, cached), so the scalar multiplication has no
+   fixed base with a comb table of its own (built once per key and device, cached: the last 1024 keys), so the scalar multiplication has no
    doublings left.  pubkey is HOST memory in both forms (l/2 octets).  A key that is not a point of the curve, and a
    non-standard parameter set, take the general path with the key repeated -- same codes, general speed.
    The _dev form synchronises `stream` the first time it meets a key (table construction); later calls with that key
@@ -426,6 +426,16 @@ err_t bee2hip_bignVerify_onekey_batch(const bign_params *params, const octet oid
 err_t bee2hip_bignVerifyL_onekey_batch_dev(size_t l, const octet oid_der[], size_t oid_len,
                                            const void *d_hashes, const void *d_sigs, const octet pubkey[],
                                            size_t n, void *d_codes, void *stream);
+/* ... and of a FEW signers: pubkeys = nkeys keys (HOST memory, nkeys <= 4096 on the device form), key_index[i] < nkeys says whose
+   signature i is (n x u32; device memory in the _dev form).  codes[i] = bignVerify(params, oid, hash_i, sig_i, pubkeys[key_index[i]]);
+   an index out of range gives ERR_BAD_INPUT for that signature.  Every key gets its cached 8-bit comb table (the last 1024 keys
+   per process); a key that is not a point of the curve costs ITS signatures the complete slow kernel, nothing else. */
+err_t bee2hip_bignVerify_keyed_batch(const bign_params *params, const octet oid_der[], size_t oid_len,
+                                     const octet *hashes, const octet *sigs, const octet *pubkeys, size_t nkeys,
+                                     const u32 *key_index, size_t n, err_t *codes);
+err_t bee2hip_bignVerifyL_keyed_batch_dev(size_t l, const octet oid_der[], size_t oid_len,
+                                          const void *d_hashes, const void *d_sigs, const octet pubkeys[], size_t nkeys,
+                                          const void *d_key_index, size_t n, void *d_codes, void *stream);
 /* n public keys of l/2 octets, l in {128, 192, 256}; d_pubkeys 16-byte aligned, d_codes n x err_t */
 /* 8f-4 tail, device resident (private keys, one-time keys and t 4-byte aligned, hashes 16-byte).  d_codes as the
    host forms; outputs of refused items are zero.  t: n x t_len octets, or one string of t_len octets when

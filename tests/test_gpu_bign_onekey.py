@@ -125,7 +125,7 @@ def test_onekey_full_size_against_the_general_entry(orc):
     idx = list(range(0, n, 4099))
     o = orc.verify_batch_l(l, E.LEVEL_OID[l], H[idx].tobytes(), S[idx].tobytes(), pub * len(idx), nthreads=8)
     assert np.array_equal(np.array(o, dtype=np.int64), got[idx])
-    # 20 other keys in between (more than the cache keeps), then the first one again
+    # 20 other keys in between, then the first one again
     for k in range(20):
         p2, H2, S2 = _signed_under_one_key(eng, orc, l, 40, 0x700 + k)
         assert not _onekey_dev(eng, l, H2, S2, p2).any()
@@ -175,3 +175,94 @@ def test_onekey_both_table_forms(orc, l):
         assert np.array_equal(np.array(o, dtype=np.int64), _onekey_dev(eng, l, H2, S2, pub2))
     finally:
         tune(20, -1)
+
+
+def _keyed_case(eng, orc, l, nkeys, n, seed, bogus=()):
+    """n signatures of nkeys signers, round robin with a twist; bogus = indices of keys replaced by junk AFTER signing"""
+    no, sg = l // 4, 3 * l // 8
+    oid = E.LEVEL_OID[l]
+    privs = []
+    for k in range(nkeys):
+        d = bytearray(orc.fill(no, seed + 31 * k)); d[no - 1] &= 0x3F
+        privs.append(bytes(d))
+    pubs = [orc.pubkey_calc(l, d)[1] for d in privs]
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, nkeys, n).astype(np.uint32)
+    hashes = dev(orc.fill(no * n, seed + 1))
+    dd = dev(b"".join(privs[int(k)] for k in idx))
+    sigs = torch.empty(sg * n, dtype=torch.uint8, device="cuda")
+    c = torch.empty(n, dtype=torch.int32, device="cuda")
+    eng.bignSign2L_batch_dev(l, oid, hashes, dd, sigs, c)
+    torch.cuda.synchronize()
+    assert int(c.abs().sum()) == 0
+    H = np.frombuffer(host(hashes), dtype=np.uint8).reshape(n, no).copy()
+    S = np.frombuffer(host(sigs), dtype=np.uint8).reshape(n, sg).copy()
+    for k in bogus:
+        p = bytearray(pubs[k])
+        if k % 2:
+            p[3] ^= 0x20                                  # off the curve
+        else:
+            p[:no] = b"\xff" * no                         # x >= p
+        pubs[k] = bytes(p)
+    return pubs, idx, H, S
+
+
+@pytest.mark.parametrize("l,nkeys,n", [(128, 1, 300), (128, 64, 6000), (128, 700, 3000), (192, 9, 900), (256, 5, 700)])
+def test_keyed_batch_against_the_oracle(orc, l, nkeys, n):
+    """n signatures of K signers (bee2hip_bignVerifyL_keyed_batch_dev and the host-pointer form): a fifth damaged, two of the keys junk
+    (off the curve: the slow kernel for their signatures; a coordinate >= p: ERR_BAD_PUBKEY), indices out of range -- the oracle's
+    bignVerify with the signature's key on every entry, and the general entry with the keys expanded"""
+    eng = engine()
+    no = l // 4
+    bogus = (1, 2) if nkeys >= 5 else ()
+    pubs, idx, H, S = _keyed_case(eng, orc, l, nkeys, n, 0xE00 + l + nkeys, bogus)
+    rng = np.random.default_rng(nkeys)
+    bad = rng.choice(n, n // 5, replace=False)
+    S[bad, rng.integers(0, S.shape[1], bad.size)] ^= (1 << rng.integers(0, 8, bad.size)).astype(np.uint8)
+    K = np.frombuffer(b"".join(pubs), dtype=np.uint8).reshape(nkeys, 2 * no)
+    want = np.array(orc.verify_batch_l(l, E.LEVEL_OID[l], H.tobytes(), S.tobytes(), K[idx].tobytes(), nthreads=32), dtype=np.int64)
+    idx2 = idx.copy()
+    out_of_range = rng.choice(n, 3, replace=False)
+    idx2[out_of_range] = nkeys + np.arange(3, dtype=np.uint32) * 1000
+    want2 = want.copy(); want2[out_of_range] = E.ERR_BAD_INPUT if hasattr(E, "ERR_BAD_INPUT") else 109
+    codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    eng.bignVerifyL_keyed_batch_dev(l, E.LEVEL_OID[l], dev(H.reshape(-1)), dev(S.reshape(-1)), b"".join(pubs),
+                                    torch.from_numpy(idx2.astype(np.int32)).cuda(), codes)
+    torch.cuda.synchronize()
+    got = codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    diff = np.nonzero(got != want2)[0]
+    assert diff.size == 0, (diff[:5], got[diff[:5]], want2[diff[:5]], idx2[diff[:5]])
+    if bogus:
+        assert (want[idx == 2] == 505).all() and (want[idx == 1] != 0).all()
+    assert int((want == 0).sum()) >= n // 4
+    # the general entry with every signature's key beside it
+    g = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    eng.bignVerifyL_batch_dev(l, E.LEVEL_OID[l], dev(H.reshape(-1)), dev(S.reshape(-1)), dev(K[idx].reshape(-1)), g)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, want)
+    # host-pointer form
+    code, hc = eng.bignVerify_keyed_batch(H.tobytes(), S.tobytes(), b"".join(pubs), [int(x) for x in idx2], oid_der=E.LEVEL_OID[l],
+                                          params=eng.bignParamsStd(E.CURVE_NAME[l]))
+    assert code == 0 and np.array_equal(np.array(hc, dtype=np.int64), want2)
+
+
+def test_keyed_reference_fixtures_in_one_call(golden):
+    """all 2048 genuine triples of the reference and its 433 edge fixtures in ONE call: their distinct keys as the signers (Q = G, keys
+    off the curve and >= p among them), the fixtures' codes"""
+    eng = engine()
+    hs, ss, ps = golden.bign_base_arrays()
+    n0 = len(hs) // 32
+    cases = [(hs[32 * i: 32 * i + 32], ss[48 * i: 48 * i + 48], ps[64 * i: 64 * i + 64], 0) for i in range(n0)]
+    cases += [tuple(bytes.fromhex(c[k]) for k in ("hash", "sig", "pubkey")) + (c["code"],) for c in golden.bign_edge]
+    keys = sorted({c[2] for c in cases})
+    pos = {k: i for i, k in enumerate(keys)}
+    idx = np.array([pos[c[2]] for c in cases], dtype=np.int32)
+    H = b"".join(c[0] for c in cases); S = b"".join(c[1] for c in cases)
+    codes = torch.full((len(cases),), -1, dtype=torch.int32, device="cuda")
+    eng.bignVerifyL_keyed_batch_dev(128, E.LEVEL_OID[128], dev(H), dev(S), b"".join(keys), torch.from_numpy(idx).cuda(), codes)
+    torch.cuda.synchronize()
+    got = codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    want = np.array([c[3] for c in cases], dtype=np.int64)
+    diff = np.nonzero(got != want)[0]
+    assert diff.size == 0, (diff[:8], got[diff[:8]], want[diff[:8]])
+    assert len(keys) >= 64 and {0, 505, 510} <= set(want.tolist())
