@@ -44,6 +44,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -944,12 +945,16 @@ void bign_gtable16_kernel(const uint4 *__restrict__ gtab8, uint4 *__restrict__ g
 // once per (device, key) from the 2N + 1 points 2^(8 win) Q the host hands over (a chain of 16 N doublings: 25 us on a host
 // core, 0.5 ms for a lone wavefront) and cached.  Same verdicts as bign_main: exceptional additions send the signature to
 // bign_slow_kernel (which reads the one key with stride 0).
+// blockIdx.y = the key of a slab of tables being built together (table y at ktab + y * tab_quads, its starting points at base + y *
+// base_quads): the keys a call meets for the first time share one allocation, one upload and this one launch.
 template <int N>
 __global__ __launch_bounds__(64)
-void bign_ktable_kernel(const uint4 *__restrict__ base, uint4 *__restrict__ ktab)
+void bign_ktable_kernel(const uint4 *__restrict__ base, uint4 *__restrict__ ktab, size_t base_quads, size_t tab_quads)
 {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= (2 * N + 1) * GT8_ENTRIES) return;
+    base += (size_t)blockIdx.y * base_quads;
+    ktab += (size_t)blockIdx.y * tab_quads;
     const int win = id / GT8_ENTRIES, b = id % GT8_ENTRIES;
     uint4 *e = ktab + (size_t)id * (N / 2);
     if (b == 0) { for (int k = 0; k < N / 2; ++k) e[k] = make_uint4(0, 0, 0, 0); return; }
@@ -1640,12 +1645,17 @@ static bool onekey_base(const uint8_t *pubkey, std::vector<uint8_t> &base)
 // process are kept (a table is 278 KiB .. 1 MiB: the card holds as many as anybody wants, the limit only bounds the scan).
 // A launcher holds a reference while it queues its kernels; the table is freed when the last reference goes, and hipFree
 // waits for the device, so a kernel already queued never loses its table.
+struct KeySlab {                       // the tables of the keys one call met for the first time, in one device allocation
+    void *p = nullptr;
+    ~KeySlab() { if (p) (void)hipFree(p); }
+};
 struct KeyTab {
-    int dev = -1, n_limbs = 0;
-    uint4 *tab = nullptr;              // (2N + 1) x 256 affine points, then the key itself (2 NO octets)
+    std::shared_ptr<KeySlab> slab;     // (freed with the last of its tables)
+    const uint4 *tab = nullptr;        // (2N + 1) x 256 affine points
+    const uint8_t *d_key = nullptr;    // the key itself in device memory (2 NO octets)
     uint4 *tab16 = nullptr;            // N x 65536 affine points (32 / 72 / 128 MiB): once `used` says the key is a busy one
     uint64_t stamp = 0, used = 0;      // signatures verified under the key so far
-    ~KeyTab() { if (tab) (void)hipFree(tab); if (tab16) (void)hipFree(tab16); }
+    ~KeyTab() { if (tab16) (void)hipFree(tab16); }
 };
 constexpr size_t KEYTAB_SLOTS = 1024;                // (0.3 - 1 GiB of 8-bit tables when full)
 static std::unordered_map<std::string, std::shared_ptr<KeyTab>> &g_keytabs = *new std::unordered_map<std::string, std::shared_ptr<KeyTab>>;   // (never destroyed: no hipFree behind the runtime's back at exit)
@@ -1663,64 +1673,105 @@ static err_t bign_key_table16_locked(KeyTab &k, hipStream_t st)
     const size_t pt = 8 * N;
     uint4 *t16 = nullptr;
     if (hipMalloc((void **)&t16, (size_t)N * 65536 * pt) != hipSuccess) { (void)hipGetLastError(); return ERR_OK; }   // no room: the 8-bit table serves
-    hipLaunchKernelGGL(bign_gtable16_kernel<N>, dim3(N * 65536 / 256), dim3(256), 0, st, (const uint4 *)k.tab, t16);
+    hipLaunchKernelGGL(bign_gtable16_kernel<N>, dim3(N * 65536 / 256), dim3(256), 0, st, k.tab, t16);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(t16); return hip_fail(hipGetLastError(), "bign_gtable16_kernel (key)"); }
     k.tab16 = t16;
     return ERR_OK;
 }
+
+// The tables of nkeys keys (host memory, 2 NO octets each): out[k] = the cached entry, or null for a key that is not a point of
+// the curve.  The keys this process has not met (or has dropped) are built TOGETHER: their starting points on host threads (~35 us
+// a key), one allocation [tables | key, starting points per key], one upload, one launch of bign_ktable_kernel (0.17 ms for one key,
+// ~0.3 ms for 64: lone wavefronts fill the chip), one synchronisation.  n = signatures of this call (counted towards the 16-bit
+// table of a key when want16).
 template <int N>
-static err_t bign_key_table(std::shared_ptr<KeyTab> &out, const uint4 **tab16, const uint8_t *pubkey, size_t n, hipStream_t st, bool want16 = true)
+static err_t bign_key_tables(std::vector<std::shared_ptr<KeyTab>> &out, const uint8_t *keys, size_t nkeys, size_t n, bool want16,
+                             hipStream_t st)
 {
-    *tab16 = nullptr;                                 // (read under the lock: another thread may be giving the key its 16-bit table)
     constexpr size_t NO = 4 * N, pt = 8 * N;
+    constexpr size_t TAB = (size_t)(2 * N + 1) * GT8_ENTRIES * pt, AUX = 2 * NO + (size_t)(2 * N + 1) * pt;     // table; key + starting points
     int dev = 0;
     B2H_TRY(hipGetDevice(&dev));
     const int lg = g_keytab16_log2 >= 0 ? g_keytab16_log2 : N == 8 ? 19 : 20;
     const uint64_t after = lg >= 63 ? ~(uint64_t)0 : (uint64_t)1 << lg;
-    std::string id(2 + 2 * NO, '\0');
-    id[0] = (char)dev; id[1] = (char)N;
-    memcpy(&id[2], pubkey, 2 * NO);
+    out.assign(nkeys, nullptr);
+    const auto id_of = [&](const uint8_t *key) {
+        std::string id(2 + 2 * NO, '\0');
+        id[0] = (char)dev; id[1] = (char)N;
+        memcpy(&id[2], key, 2 * NO);
+        return id;
+    };
     std::lock_guard<std::mutex> lk(g_bign_mu);
-    {
+    std::vector<size_t> miss;                          // first occurrence of every key the cache does not hold
+    std::unordered_map<std::string, size_t> miss_at;   // id -> position in miss
+    std::vector<size_t> dup_of(nkeys, (size_t)-1);     // later occurrences of a missing key
+    for (size_t k = 0; k < nkeys; ++k) {
+        std::string id = id_of(keys + 2 * NO * k);
         const auto it = g_keytabs.find(id);
         if (it != g_keytabs.end()) {
-            KeyTab *k = it->second.get();
-            k->stamp = ++g_keytab_clock;
-            k->used += n;
-            if (want16 && !k->tab16 && k->used >= after) { const err_t c = bign_key_table16_locked<N>(*k, st); if (c != ERR_OK) return c; }
-            out = it->second;
-            *tab16 = k->tab16;
-            return ERR_OK;
+            KeyTab *t = it->second.get();
+            t->stamp = ++g_keytab_clock;
+            t->used += n;
+            if (want16 && !t->tab16 && t->used >= after) { const err_t c = bign_key_table16_locked<N>(*t, st); if (c != ERR_OK) return c; }
+            out[k] = it->second;
+            continue;
         }
+        const auto m = miss_at.find(id);
+        if (m != miss_at.end()) { dup_of[k] = miss[m->second]; continue; }
+        miss_at.emplace(std::move(id), miss.size());
+        miss.push_back(k);
     }
-    // a key this process has not met (or has dropped): on the curve?  then its 2N + 1 starting points
-    std::vector<uint8_t> base_v;
-    if (!onekey_base<N>(pubkey, base_v)) return ERR_KEY_NOT_ON_CURVE;
-    const uint8_t *base = base_v.data();
-    auto k = std::make_shared<KeyTab>();
-    const size_t entries = (size_t)(2 * N + 1) * GT8_ENTRIES;
-    // the base points are staged behind the key, in the same block: [table | key | base points]
-    if (hipMalloc((void **)&k->tab, entries * pt + 2 * NO + (size_t)(2 * N + 1) * pt) != hipSuccess) { (void)hipGetLastError(); k->tab = nullptr; return ERR_OUTOFMEMORY; }
-    uint8_t *d_key = reinterpret_cast<uint8_t *>(k->tab) + entries * pt;
-    uint8_t *d_base = d_key + 2 * NO;
-    B2H_TRY(hipMemcpyAsync(d_key, pubkey, 2 * NO, hipMemcpyHostToDevice, st));
-    B2H_TRY(hipMemcpyAsync(d_base, base, (size_t)(2 * N + 1) * pt, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(bign_ktable_kernel<N>, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, st, (const uint4 *)d_base, k->tab);
-    B2H_TRY(hipGetLastError());
-    B2H_TRY(hipStreamSynchronize(st));          // (base_v goes out of scope; other streams may use the table next)
-    k->dev = dev; k->n_limbs = N;
-    k->stamp = ++g_keytab_clock;
-    k->used = n;
-    g_keytab_builds.fetch_add(1);
-    if (want16 && k->used >= after) { const err_t c = bign_key_table16_locked<N>(*k, st); if (c != ERR_OK) return c; }
-    if (g_keytabs.size() >= KEYTAB_SLOTS) {      // the least recently used one goes (when its last user lets go of it)
-        auto old = g_keytabs.begin();
-        for (auto it = g_keytabs.begin(); it != g_keytabs.end(); ++it) if (it->second->stamp < old->second->stamp) old = it;
-        g_keytabs.erase(old);
+    if (!miss.empty()) {
+        // on the curve?  then the 2N + 1 starting points -- host threads when there are many keys
+        std::vector<std::vector<uint8_t>> base(miss.size());
+        std::vector<char> on_curve(miss.size(), 0);
+        const auto work = [&](size_t from, size_t to) {
+            for (size_t i = from; i < to; ++i) on_curve[i] = onekey_base<N>(keys + 2 * NO * miss[i], base[i]) ? 1 : 0;
+        };
+        const size_t nthr = std::min<size_t>(16, miss.size() / 4);
+        if (nthr >= 2) {
+            std::vector<std::thread> th;
+            const size_t per = (miss.size() + nthr - 1) / nthr;
+            for (size_t t = 0; t < nthr; ++t) th.emplace_back(work, std::min(miss.size(), t * per), std::min(miss.size(), (t + 1) * per));
+            for (auto &t : th) t.join();
+        } else work(0, miss.size());
+        std::vector<size_t> good;
+        for (size_t i = 0; i < miss.size(); ++i) if (on_curve[i]) good.push_back(i);
+        if (!good.empty()) {
+            const size_t M = good.size();
+            auto slab = std::make_shared<KeySlab>();
+            if (hipMalloc(&slab->p, M * (TAB + AUX)) != hipSuccess) { (void)hipGetLastError(); slab->p = nullptr; return ERR_OUTOFMEMORY; }
+            uint8_t *d_tabs = reinterpret_cast<uint8_t *>(slab->p), *d_aux = d_tabs + M * TAB;
+            std::vector<uint8_t> aux(M * AUX);
+            for (size_t j = 0; j < M; ++j) {
+                memcpy(aux.data() + j * AUX, keys + 2 * NO * miss[good[j]], 2 * NO);
+                memcpy(aux.data() + j * AUX + 2 * NO, base[good[j]].data(), AUX - 2 * NO);
+            }
+            B2H_TRY(hipMemcpyAsync(d_aux, aux.data(), aux.size(), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(bign_ktable_kernel<N>, dim3((unsigned)(((size_t)(2 * N + 1) * GT8_ENTRIES + 63) / 64), (unsigned)M), dim3(64), 0, st,
+                               reinterpret_cast<const uint4 *>(d_aux + 2 * NO), reinterpret_cast<uint4 *>(d_tabs), AUX / 16, TAB / 16);
+            B2H_TRY(hipGetLastError());
+            B2H_TRY(hipStreamSynchronize(st));          // (aux goes out of scope; other streams may use the tables next)
+            for (size_t j = 0; j < M; ++j) {
+                auto t = std::make_shared<KeyTab>();
+                t->slab = slab;
+                t->tab = reinterpret_cast<const uint4 *>(d_tabs + j * TAB);
+                t->d_key = d_aux + j * AUX;
+                t->stamp = ++g_keytab_clock;
+                t->used = n;
+                g_keytab_builds.fetch_add(1);
+                if (want16 && t->used >= after) { const err_t c = bign_key_table16_locked<N>(*t, st); if (c != ERR_OK) return c; }
+                if (g_keytabs.size() >= KEYTAB_SLOTS) {      // the least recently used one goes (when its last user lets go of it)
+                    auto old = g_keytabs.begin();
+                    for (auto it = g_keytabs.begin(); it != g_keytabs.end(); ++it) if (it->second->stamp < old->second->stamp) old = it;
+                    g_keytabs.erase(old);
+                }
+                g_keytabs[id_of(keys + 2 * NO * miss[good[j]])] = t;
+                out[miss[good[j]]] = t;
+            }
+        }
+        for (size_t k = 0; k < nkeys; ++k) if (dup_of[k] != (size_t)-1) out[k] = out[dup_of[k]];
     }
-    g_keytabs[id] = k;
-    out = k;
-    *tab16 = k->tab16;
     return ERR_OK;
 }
 
@@ -1730,7 +1781,7 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
                                          const uint8_t *keys, size_t nkeys, const void *d_key_index, size_t n, void *d_codes,
                                          hipStream_t st)
 {
-    constexpr size_t NO = 4 * N, TAB = (size_t)(2 * N + 1) * GT8_ENTRIES * 8 * N;       // octets of an 8-bit table; the key follows it
+    constexpr size_t NO = 4 * N;
     const bool keyed = d_key_index != nullptr;
     uint4 *gtab = nullptr;
     err_t code;
@@ -1739,25 +1790,24 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
         code = bign_table<N>(&gtab, st);
     }
     if (code != ERR_OK) return code;
-    std::vector<std::shared_ptr<KeyTab>> kts(nkeys);
+    std::vector<std::shared_ptr<KeyTab>> kts;
+    code = bign_key_tables<N>(kts, keys, nkeys, keyed ? 0 : n, !keyed, st);
+    if (code != ERR_OK) return code;
     const uint4 *tab16 = nullptr;
     const uint8_t *d_keys = nullptr;
     const uint4 *const *d_tabs = nullptr;
     if (!keyed) {
-        code = bign_key_table<N>(kts[0], &tab16, keys, n, st);
-        if (code != ERR_OK) return code;                           // (ERR_KEY_NOT_ON_CURVE: the caller's general path)
-        d_keys = reinterpret_cast<const uint8_t *>(kts[0]->tab) + TAB;
+        if (!kts[0]) return ERR_KEY_NOT_ON_CURVE;                  // (the caller's general path)
+        {
+            std::lock_guard<std::mutex> lk(g_bign_mu);             // another thread may be giving the key its 16-bit table
+            tab16 = kts[0]->tab16;
+        }
+        d_keys = kts[0]->d_key;
     } else {
-        // every key's 8-bit table (a key off the curve has none: null); the pointers and the keys go up in one block
+        // the tables' addresses (a key off the curve has none: null) and the keys go up in one block
         std::vector<uint8_t> blk(nkeys * (8 + 2 * NO));
         uint64_t *ptrs = reinterpret_cast<uint64_t *>(blk.data());
-        for (size_t k = 0; k < nkeys; ++k) {
-            const uint4 *dummy = nullptr;
-            code = bign_key_table<N>(kts[k], &dummy, keys + 2 * NO * k, 0, st, false);
-            if (code == ERR_KEY_NOT_ON_CURVE) { ptrs[k] = 0; continue; }
-            if (code != ERR_OK) return code;
-            ptrs[k] = (uint64_t)(uintptr_t)kts[k]->tab;
-        }
+        for (size_t k = 0; k < nkeys; ++k) ptrs[k] = kts[k] ? (uint64_t)(uintptr_t)kts[k]->tab : 0;
         memcpy(blk.data() + 8 * nkeys, keys, 2 * NO * nkeys);
         void *d_blk = nullptr;
         code = scratch_for_stream(st, 13, blk.size(), &d_blk);
@@ -1780,10 +1830,10 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
                            (const uint4 *)nullptr, (const uint4 *)nullptr, (const uint32_t *)d_key_index, d_tabs, (uint32_t)nkeys);
     else if (tab16)
         hipLaunchKernelGGL((bign_onekey_kernel<N, VtOps, true, false>), dim3(g256), dim3(256), 0, st, dh, dsg, d_keys, n, S, (const uint4 *)gtab,
-                           (const uint4 *)kts[0]->tab, tab16, (const uint32_t *)nullptr, (const uint4 *const *)nullptr, 1u);
+                           kts[0]->tab, tab16, (const uint32_t *)nullptr, (const uint4 *const *)nullptr, 1u);
     else
         hipLaunchKernelGGL((bign_onekey_kernel<N, VtOps, false, false>), dim3(g256), dim3(256), 0, st, dh, dsg, d_keys, n, S, (const uint4 *)gtab,
-                           (const uint4 *)kts[0]->tab, (const uint4 *)nullptr, (const uint32_t *)nullptr, (const uint4 *const *)nullptr, 1u);
+                           kts[0]->tab, (const uint4 *)nullptr, (const uint32_t *)nullptr, (const uint4 *const *)nullptr, 1u);
     hipLaunchKernelGGL(bign_slow_kernel<N>, dim3(g64), dim3(64), 0, st, dsg, d_keys, n, S, keyed ? ~(size_t)0 : (size_t)0);
     // shared inversions and the hash tail: as launch_bign_verify_t
     constexpr size_t inv_lanes = N == 8 ? 32768 : 65536;
