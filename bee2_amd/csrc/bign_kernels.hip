@@ -1655,8 +1655,13 @@ struct KeyTab {
     const uint8_t *d_key = nullptr;    // the key itself in device memory (2 NO octets)
     uint4 *tab16 = nullptr;            // N x 65536 affine points (32 / 72 / 128 MiB): once `used` says the key is a busy one
     uint64_t stamp = 0, used = 0;      // signatures verified under the key so far
-    ~KeyTab() { if (tab16) (void)hipFree(tab16); }
+    ~KeyTab();
 };
+// at most KEYTAB16_MAX keys hold a 16-bit table at a time (<= 1 / 2.3 / 4 GiB per process): a key that becomes busy while they are
+// all taken stays on its 8-bit table
+constexpr int KEYTAB16_MAX = 32;
+static std::atomic<int> g_keytab16_live{0};
+KeyTab::~KeyTab() { if (tab16) { (void)hipFree(tab16); g_keytab16_live.fetch_sub(1); } }
 constexpr size_t KEYTAB_SLOTS = 1024;                // (0.3 - 1 GiB of 8-bit tables when full)
 static std::unordered_map<std::string, std::shared_ptr<KeyTab>> &g_keytabs = *new std::unordered_map<std::string, std::shared_ptr<KeyTab>>;   // (never destroyed: no hipFree behind the runtime's back at exit)
 static uint64_t g_keytab_clock = 0;
@@ -1672,10 +1677,12 @@ static err_t bign_key_table16_locked(KeyTab &k, hipStream_t st)
 {
     const size_t pt = 8 * N;
     uint4 *t16 = nullptr;
+    if (g_keytab16_live.load() >= KEYTAB16_MAX) return ERR_OK;                                                        // enough busy keys already
     if (hipMalloc((void **)&t16, (size_t)N * 65536 * pt) != hipSuccess) { (void)hipGetLastError(); return ERR_OK; }   // no room: the 8-bit table serves
     hipLaunchKernelGGL(bign_gtable16_kernel<N>, dim3(N * 65536 / 256), dim3(256), 0, st, k.tab, t16);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(t16); return hip_fail(hipGetLastError(), "bign_gtable16_kernel (key)"); }
     k.tab16 = t16;
+    g_keytab16_live.fetch_add(1);
     return ERR_OK;
 }
 

@@ -2,7 +2,7 @@
  * sigvfy_hip.c -- the batch shape of `bee2cmd sig vfy` (cmd/core/cmd_sig.c:461-490): for every
  * file, hash it, validate the signer's public key, verify the signature -- here for MANY files with three
  * launches on one stream (ragged belt-hash -> bign128PubkeyVal -> bign128Verify), digests never leaving the GPU;
- * a list under ONE public key takes the one-signer entry (bee2hip_bignVerifyL_onekey_batch_dev).
+ * a list under ONE public key takes the one-signer entry (bee2hip_bignVerifyL_onekey_batch_dev), one of a few signers the keyed one.
  *
  * Input: a list file, one line per signed file:   <file name>  <hex signature, 48 octets>  <hex public key, 64 octets>
  * (bee2cmd keeps signature and certificate chain in a DER container appended to the file, cmd_sig.c:121-330;
@@ -14,6 +14,7 @@
  *   cc -Iinclude examples/sigvfy_hip.c -Lbee2_amd/lib -lbee2hip -L/opt/rocm/lib -lamdhip64 \
  *      -Wl,-rpath,$PWD/bee2_amd/lib -Wl,-rpath,/opt/rocm/lib -o sigvfy_hip
  */
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -88,14 +89,30 @@ int main(int argc, char **argv)
         /* hash (belt-hash, bign128's pre-hash) -> key validation -> verification: one stream, no host round trip */
         err_t code = bee2hip_hash_ragged_dev(0, d_data, d_off, n, d_hash, NULL);
         if (code == ERR_OK) code = bee2hip_bignPubkeyValL_batch_dev(128, d_pub, n, d_c1, NULL);
-        /* one signer for the whole list (the usual tree of files under one key): the key is a fixed base with a comb table of
-           its own -- about a fifth of the work of the general entry, same verdicts */
-        int one_key = 1;
-        for (size_t i = 1; i < n && one_key; ++i) one_key = memcmp(pubs, pubs + 64 * i, 64) == 0;
+        /* the signers of the list: ONE key (the usual tree of files under one key) or a FEW take the entries that treat a key as a
+           fixed base with a comb table of its own -- a fifth to a quarter of the general entry's work, same verdicts; a crowd of
+           signers (more than 256 here) takes the general entry */
+        enum { MAX_SIGNERS = 256 };
+        octet *keys = (octet *)malloc((size_t)MAX_SIGNERS * 64);
+        uint32_t *kidx = (uint32_t *)malloc(n * sizeof *kidx);
+        size_t nkeys = 0;
+        for (size_t i = 0; i < n && nkeys <= MAX_SIGNERS; ++i) {
+            size_t k = 0;
+            while (k < nkeys && memcmp(keys + 64 * k, pubs + 64 * i, 64)) ++k;
+            if (k == nkeys) { if (nkeys == MAX_SIGNERS) { nkeys++; break; } memcpy(keys + 64 * nkeys++, pubs + 64 * i, 64); }
+            kidx[i] = (uint32_t)k;
+        }
         static const octet oid_belt_hash[11] = {0x06, 0x09, 0x2A, 0x70, 0x00, 0x02, 0x00, 0x22, 0x65, 0x1F, 0x51};
-        if (code == ERR_OK)
-            code = one_key ? bee2hip_bignVerifyL_onekey_batch_dev(128, oid_belt_hash, sizeof oid_belt_hash, d_hash, d_sig, pubs, n, d_c2, NULL)
-                           : bee2hip_bign128Verify_batch_dev(d_hash, d_sig, d_pub, n, d_c2, NULL);
+        if (code == ERR_OK) {
+            if (nkeys == 1)
+                code = bee2hip_bignVerifyL_onekey_batch_dev(128, oid_belt_hash, sizeof oid_belt_hash, d_hash, d_sig, keys, n, d_c2, NULL);
+            else if (nkeys <= MAX_SIGNERS) {
+                hipMemcpy(d_pub, kidx, n * 4, 1);         /* the key indices take the place of the keys on the device */
+                code = bee2hip_bignVerifyL_keyed_batch_dev(128, oid_belt_hash, sizeof oid_belt_hash, d_hash, d_sig, keys, nkeys, d_pub, n, d_c2, NULL);
+            } else
+                code = bee2hip_bign128Verify_batch_dev(d_hash, d_sig, d_pub, n, d_c2, NULL);
+        }
+        free(keys); free(kidx);
         if (code != ERR_OK) { fprintf(stderr, "sigvfy_hip: err %u %s\n", code, bee2hip_last_error()); return 1; }
         err_t *c1 = (err_t *)malloc(n * 4), *c2 = (err_t *)malloc(n * 4);
         hipMemcpy(c1, d_c1, n * 4, 2); hipMemcpy(c2, d_c2, n * 4, 2);
