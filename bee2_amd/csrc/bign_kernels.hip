@@ -1662,7 +1662,8 @@ struct KeyTab {
 constexpr int KEYTAB16_MAX = 32;
 static std::atomic<int> g_keytab16_live{0};
 KeyTab::~KeyTab() { if (tab16) { (void)hipFree(tab16); g_keytab16_live.fetch_sub(1); } }
-constexpr size_t KEYTAB_SLOTS = 1024;                // (0.3 - 1 GiB of 8-bit tables when full)
+static size_t KEYTAB_SLOTS = 1024;                   // (0.3 - 1 GiB of 8-bit tables when full; tests: tune 21)
+void set_onekey_slots(int v) { KEYTAB_SLOTS = v < 1 ? 1 : (size_t)v; }
 static std::unordered_map<std::string, std::shared_ptr<KeyTab>> &g_keytabs = *new std::unordered_map<std::string, std::shared_ptr<KeyTab>>;   // (never destroyed: no hipFree behind the runtime's back at exit)
 static uint64_t g_keytab_clock = 0;
 static std::atomic<unsigned long long> g_keytab_builds{0};

@@ -266,3 +266,52 @@ def test_keyed_reference_fixtures_in_one_call(golden):
     diff = np.nonzero(got != want)[0]
     assert diff.size == 0, (diff[:8], got[diff[:8]], want[diff[:8]])
     assert len(keys) >= 64 and {0, 505, 510} <= set(want.tolist())
+
+
+def test_onekey_and_keyed_from_six_threads_with_a_tiny_cache(orc):
+    """six host threads, each on its own stream-less calls: its own key, a key all of them share, and a keyed batch over all the keys --
+    with the table cache cut to THREE keys (experiments build, tune 21), so tables are evicted while other threads still queue kernels
+    on them (a table lives until its last user lets go; hipFree waits for the device).  Every verdict as computed beforehand."""
+    import threading
+    eng = exp_engine()
+    tune = eng.lib.bee2hip_internal_tune
+    l, n, nthr = 128, 700, 6
+    cases = [_signed_under_one_key(eng, orc, l, n, 0xA00 + 13 * t) for t in range(nthr + 1)]      # [nthr] = the shared key
+    for pub, H, S in cases:
+        S[::9, 7] ^= 2
+    want = [_general_dev(eng, l, H, S, pub) for pub, H, S in cases]
+    pubs_all = b"".join(c[0] for c in cases)
+    Hk = np.concatenate([c[1] for c in cases]); Sk = np.concatenate([c[2] for c in cases])
+    idxk = np.repeat(np.arange(nthr + 1, dtype=np.int32), n)
+    wantk = np.concatenate(want)
+    errors = []
+    start = threading.Barrier(nthr)
+
+    def run(t):
+        try:
+            torch.cuda.set_device(0)
+            eng.set_device(0)
+            start.wait()
+            for r in range(12):
+                for j in (t, nthr):
+                    pub, H, S = cases[j]
+                    if not np.array_equal(_onekey_dev(eng, l, H, S, pub), want[j]):
+                        errors.append((t, r, j)); return
+                codes = torch.full((idxk.size,), -1, dtype=torch.int32, device="cuda")
+                eng.bignVerifyL_keyed_batch_dev(l, E.LEVEL_OID[l], dev(Hk.reshape(-1)), dev(Sk.reshape(-1)), pubs_all,
+                                                torch.from_numpy(idxk).cuda(), codes)
+                torch.cuda.synchronize()
+                if not np.array_equal(codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, wantk):
+                    errors.append((t, r, "keyed")); return
+        except Exception as e:                                            # noqa: BLE001
+            errors.append((t, repr(e)))
+    try:
+        assert tune(21, 3) == 0
+        threads = [threading.Thread(target=run, args=(t,)) for t in range(nthr)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    finally:
+        tune(21, 1024)
+    assert not errors, errors[:5]
