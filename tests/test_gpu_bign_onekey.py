@@ -315,3 +315,39 @@ def test_onekey_and_keyed_from_six_threads_with_a_tiny_cache(orc):
     finally:
         tune(21, 1024)
     assert not errors, errors[:5]
+
+
+def test_onekey_entry_replays_from_a_hip_graph(orc):
+    """once a key has its table (one eager call on the stream) the one-signer _dev entry is plain stream work: captured into a
+    hipGraph and replayed on fresh signatures in the same buffers (INTEGRATION "hipGraph capture")"""
+    eng = engine()
+    l, n = 128, 5000
+    pub, H, S = _signed_under_one_key(eng, orc, l, 3 * n, 0xC0DE)
+    dh = torch.empty(32 * n, dtype=torch.uint8, device="cuda"); ds = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
+    codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    cap = torch.cuda.Stream()
+
+    def load(part, damage):
+        Sp = S[part * n:(part + 1) * n].copy()
+        Sp[damage, 9] ^= 0x08
+        with torch.cuda.stream(cap):
+            dh.copy_(torch.from_numpy(H[part * n:(part + 1) * n].reshape(-1).copy()).cuda())
+            ds.copy_(torch.from_numpy(Sp.reshape(-1)).cuda())
+        cap.synchronize()
+
+    load(0, [])
+    with torch.cuda.stream(cap):
+        eng.bignVerifyL_onekey_batch_dev(l, E.LEVEL_OID[l], dh, ds, pub, codes)      # eager: the key's table, the stream's scratch
+    cap.synchronize()
+    assert not codes.any()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=cap):
+        eng.bignVerifyL_onekey_batch_dev(l, E.LEVEL_OID[l], dh, ds, pub, codes)
+    for part, damage in ((1, [3, 77, 4999]), (2, [0]), (0, list(range(0, n, 500)))):
+        load(part, damage)
+        codes.fill_(-1)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        want = np.zeros(n, dtype=np.int64); want[damage] = 510
+        assert np.array_equal(got, want), (part, np.nonzero(got != want)[0][:5])
