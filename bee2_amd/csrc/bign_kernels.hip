@@ -1051,6 +1051,106 @@ void bign_onekey_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
     store_soa(S.u, S.n_pad, idx, T.Z);
 }
 
+// The same sum on FOUR lanes per signature, for batches that leave the chip's SIMDs underfed (<= 2^16 signatures): R = u G + v Q is a
+// sum of 2N + N (+ 1) table points and nothing orders them -- lane `sub` of a quad adds the windows 4 i + sub of v, then of u (the top
+// window of v, always 1, starts lane 0), and two rounds of Jacobian additions across the quad fold the four partial sums: 6 + 2 point
+// additions deep instead of 24 on the 256-bit curve.  A lone wavefront pays for every instruction it issues, whatever the lane count
+// (DESIGN 2), so this is a third of the main kernel's latency.  A lane's digits come from memory at lane-dependent addresses (the
+// octets of s0; u from a private LDS row) -- a register array indexed by the lane would go to scratch.  Empty partial sums (all of a
+// lane's windows zero) are flags, not points; exceptional additions send the signature to bign_slow_kernel as everywhere.
+template <int N, class OPS = VtOps, bool Q16 = false, bool KEYED = false>
+__global__ __launch_bounds__(256, (N == 8 ? 2 : 1))
+void bign_onekey4_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs, const uint8_t *__restrict__ key,
+                         size_t n, VerifyScratch S, const uint4 *__restrict__ gtab, const uint4 *__restrict__ ktab,
+                         const uint4 *__restrict__ ktab16, const uint32_t *__restrict__ key_index,
+                         const uint4 *const *__restrict__ tabs, uint32_t nkeys)
+{
+    __shared__ uint32_t u_rows[256][N + 1];                       // (+ 1: rows on different banks)
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned sub = threadIdx.x & 3u;
+    size_t idx = gid >> 2;
+    bool live = idx < n;                                           // dead quads walk the last signature and store nothing
+    if (!live) idx = n - 1;
+    constexpr int W = Comb<N>::W;
+    constexpr int NO = 4 * N;
+    if (KEYED) {
+        const uint32_t k = key_index[idx];
+        if (k >= nkeys) { if (live && sub == 0) S.status[idx] = ERR_BAD_INPUT; live = false; }
+        else { key += (size_t)2 * NO * k; ktab = tabs[k]; }
+    }
+    {
+        affT<N> Q;
+        feT<N> u;
+        uint32_t w[N / 2 + 1];
+        const bool write = live && sub == 0;
+        if (!prep_scalars<N>(hashes, sigs, key, idx, S, write, Q, u, w, 0)) live = false;          // status = the error code (lane 0)
+        else if (KEYED) {
+            if (write) store_qxy(S, 0, idx, Q.x, Q.y);                                              // (for bign_slow_kernel)
+            if (!ktab) { if (write) S.status[idx] = ST_SLOW; live = false; }
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) u_rows[threadIdx.x][i] = u.v[i];
+    }
+    if (KEYED && !ktab) ktab = gtab;                               // (a dead quad still walks: any readable table)
+    bool ok = true, empty = sub != 0;
+    jacT<N> T;
+    fe_set_zero(T.X); fe_set_one(T.Y); fe_set_zero(T.Z);
+    if (sub == 0) {
+        affT<N> E;                                                 // the top window of v = s0 + 2^l is 1
+        load_aff(E, ktab + ((size_t)(2 * N) * GT8_ENTRIES + 1) * (N / 2));
+        T.X = E.x; T.Y = E.y; fe_set_one(T.Z);
+    }
+    const auto take = [&](const uint4 *entry) {
+        affT<N> E;
+        load_aff(E, entry);
+        if (empty) { T.X = E.x; T.Y = E.y; fe_set_one(T.Z); empty = false; }
+        else ok &= jac_madd<N, OPS>(T, E);
+    };
+    const uint8_t *s0 = sigs + (NO + NO / 2) * idx;
+    constexpr int NV = Q16 ? N : 2 * N;                            // windows of v below the top one
+#pragma unroll 1
+    for (int i = 0; i < NV / 4; ++i) {
+        const unsigned j = 4u * i + sub;
+        if (Q16) {
+            const uint32_t b = reinterpret_cast<const uint16_t *>(s0)[j];
+            if (b != 0) take(ktab16 + ((size_t)j * 65536 + b) * (N / 2));
+        } else {
+            const uint32_t b = s0[j];
+            if (b != 0) take(ktab + ((size_t)j * GT8_ENTRIES + b) * (N / 2));
+        }
+    }
+    static_assert(W == 16, "16-bit comb of G");
+#pragma unroll 1
+    for (int i = 0; i < 2 * N / 4; ++i) {
+        const unsigned j = 4u * i + sub;
+        const uint32_t b = (u_rows[threadIdx.x][j >> 1] >> (16u * (j & 1u))) & 65535u;
+        if (b != 0) take(gtab + ((size_t)j * 65536 + b) * (N / 2));
+    }
+    // fold the quad: lanes sub ^ 1, then sub ^ 2
+#pragma unroll 1
+    for (int step = 1; step <= 2; step <<= 1) {
+        jacT<N> P;
+#pragma unroll
+        for (int l = 0; l < N; ++l) {
+            P.X.v[l] = (uint32_t)__shfl_xor((int)T.X.v[l], step, 64);
+            P.Y.v[l] = (uint32_t)__shfl_xor((int)T.Y.v[l], step, 64);
+            P.Z.v[l] = (uint32_t)__shfl_xor((int)T.Z.v[l], step, 64);
+        }
+        const bool p_empty = __shfl_xor((int)empty, step, 64) != 0;
+        ok &= __shfl_xor((int)ok, step, 64) != 0;
+        if (!p_empty) {
+            if (empty) { T = P; empty = false; }
+            else ok &= jac_add<N, OPS>(T, P);
+        }
+    }
+    if (!live || sub != 0) return;
+    ok &= !empty && !fe_is_zero(T.Z);
+    if (!ok) { S.status[idx] = ST_SLOW; return; }
+    S.status[idx] = ST_PENDING;
+    store_soa(S.rx, S.n_pad, idx, T.X);
+    store_soa(S.u, S.n_pad, idx, T.Z);
+}
+
 // Table of the signing side's one-lane kernel (round 3): signed 6-bit windows, entry (i, j) = j 2^(6i) G, j = 1..32, at
 // index i * 32 + j - 1; W6 = ceil((32N + 1) / 6) windows (43 / 65 / 86), the last one takes what is left of the scalar
 // plus the carry of the recoding (at most 16 / 1 / 4).  From the seed table: j 2^(6i) = lo 2^(8a) + hi 2^(8a + 8); the one
@@ -1671,6 +1771,8 @@ unsigned long long bign_onekey_table_builds() { return g_keytab_builds.load(); }
 
 // A key under which KEYTAB16_AFTER signatures have been verified gets the 16-bit table as well (0.3 / 1 / 2 ms to build -- the work
 // of ~2^17 signatures -- against a quarter of the additions saved from then on): made from the 8-bit one like G's (bign_gtable16_kernel).
+static int g_onekey_quads = -1;                      // four lanes per signature: -1 by batch size (<= 2^16), 0 never, 1 always (tests / A/B: tune 22)
+void set_onekey_quads(int v) { g_onekey_quads = v; }
 static int g_keytab16_log2 = -1;                     // -1: by curve (2^19 on the 256-bit curve, 2^20 on the wider ones); tests / A/B: tune 20
 void set_onekey_tab16(int v) { g_keytab16_log2 = v; }
 template <int N>
@@ -1833,7 +1935,19 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
     if (code != ERR_OK) return code;
     const unsigned g256 = (unsigned)((n + 255) / 256), g64 = (unsigned)((n + 63) / 64);
     const uint8_t *dh = (const uint8_t *)d_hashes, *dsg = (const uint8_t *)d_sigs;
-    if (keyed)
+    // up to 2^16 signatures: four lanes per signature (a third of the latency; at 2^17 the one-lane kernels' two wavefronts per SIMD tie)
+    const bool quad = g_onekey_quads > 0 || (g_onekey_quads < 0 && n <= ((size_t)1 << 16));
+    const unsigned g4 = (unsigned)((4 * n + 255) / 256);
+    if (quad && keyed)
+        hipLaunchKernelGGL((bign_onekey4_kernel<N, VtOps, false, true>), dim3(g4), dim3(256), 0, st, dh, dsg, d_keys, n, S, (const uint4 *)gtab,
+                           (const uint4 *)nullptr, (const uint4 *)nullptr, (const uint32_t *)d_key_index, d_tabs, (uint32_t)nkeys);
+    else if (quad && tab16)
+        hipLaunchKernelGGL((bign_onekey4_kernel<N, VtOps, true, false>), dim3(g4), dim3(256), 0, st, dh, dsg, d_keys, n, S, (const uint4 *)gtab,
+                           kts[0]->tab, tab16, (const uint32_t *)nullptr, (const uint4 *const *)nullptr, 1u);
+    else if (quad)
+        hipLaunchKernelGGL((bign_onekey4_kernel<N, VtOps, false, false>), dim3(g4), dim3(256), 0, st, dh, dsg, d_keys, n, S, (const uint4 *)gtab,
+                           kts[0]->tab, (const uint4 *)nullptr, (const uint32_t *)nullptr, (const uint4 *const *)nullptr, 1u);
+    else if (keyed)
         hipLaunchKernelGGL((bign_onekey_kernel<N, VtOps, false, true>), dim3(g256), dim3(256), 0, st, dh, dsg, d_keys, n, S, (const uint4 *)gtab,
                            (const uint4 *)nullptr, (const uint4 *)nullptr, (const uint32_t *)d_key_index, d_tabs, (uint32_t)nkeys);
     else if (tab16)

@@ -485,6 +485,7 @@ def f_onekey(rnd):
             S[sg * i: sg * i + no // 2] = bytes(no // 2) if rnd.randrange(2) else b"\xff" * (no // 2)
     want = orc.verify_batch_l(l, oid, bytes(H), bytes(S), bytes(pub) * n, nthreads=16)
     _tune(20, rnd.choice((-1, 63, 0, 8)))
+    _tune(22, rnd.choice((-1, 0, 1)))
     try:
         if rnd.randrange(3) == 0:
             code, got = eng.bignVerify_onekey_batch(bytes(H), bytes(S), bytes(pub), oid_der=oid, params=eng.bignParamsStd(bee2_amd.engine.CURVE_NAME[l]))
@@ -496,6 +497,7 @@ def f_onekey(rnd):
         return [int(x) & 0xFFFFFFFF for x in codes.cpu().numpy()] == list(want)
     finally:
         _tune(20, -1)
+        _tune(22, -1)
 
 
 FAMILIES = [("onekey", f_onekey), ("bashF", f_bashF), ("beltCTR", f_ctr), ("mac/hash", f_mac_hash), ("modes", f_modes), ("dwp/che", f_aead),

@@ -54,7 +54,7 @@ def test_product_library_ships_no_hooks_and_no_experiment_kernels(lib_path):
     import subprocess
     names = subprocess.check_output([os.path.join(ROOT, "tools", "list_kernels.sh"), lib_path], text=True).splitlines()
     kernels = sorted({n.split("(")[0] for n in names if n.strip()})
-    assert kernels and len(kernels) <= 138, len(kernels)          # 124 + the one-signer / few-signers family (key table, main in three forms x 3 curves, the fallback's key replication)
+    assert kernels and len(kernels) <= 148, len(kernels)          # 124 + the one-signer / few-signers family (key table, main in three forms x 3 curves, the fallback's key replication)
     for bad in ("debug", "clock_probe", "bashF_batch_kernel", "bashF_walk_kernel", "BeltTabHyb", "BeltTabTwoS", "BeltTabTwoL",
                 "BeltTabTwoQ"):
         assert not [k for k in kernels if bad in k], bad

@@ -351,3 +351,41 @@ def test_onekey_entry_replays_from_a_hip_graph(orc):
         got = codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
         want = np.zeros(n, dtype=np.int64); want[damage] = 510
         assert np.array_equal(got, want), (part, np.nonzero(got != want)[0][:5])
+
+
+@pytest.mark.parametrize("l", [128, 192, 256])
+@pytest.mark.parametrize("quads", [1, 0])
+def test_onekey_one_and_four_lanes_per_signature(orc, l, quads):
+    """the four-lane form (the product's choice up to 2^16 signatures) and the one-lane form, each FORCED (tune 22) over both table forms,
+    one signer and a few: sizes around the quad / wavefront / workgroup edges, damaged signatures, s0 with empty and full windows (a
+    lane of the quad with nothing to add), junk keys and indices out of range in the keyed batch -- the oracle on every entry"""
+    eng = exp_engine()
+    tune = eng.lib.bee2hip_internal_tune
+    no = l // 4
+    try:
+        assert tune(22, quads) == 0
+        for n, t16 in ((1, 63), (5, 0), (63, 63), (64, 0), (65, 63), (1023, 0), (2100, 63)):
+            assert tune(20, t16) == 0
+            pub, H, S = _signed_under_one_key(eng, orc, l, n, 0x4A00 + l + n)
+            S[::6, 1] ^= 0x80
+            if n > 8:
+                S[2, : no // 2] = 0                      # only the top window of v: three lanes of the quad have no window of v
+                S[3, : no // 2] = 0; S[3, 1] = 7         # one window of v
+                S[4, : no // 2] = 0xFF
+                H[7] = 0
+            want = np.array(orc.verify_batch_l(l, E.LEVEL_OID[l], H.tobytes(), S.tobytes(), pub * n, nthreads=16), dtype=np.int64)
+            got = _onekey_dev(eng, l, H, S, pub)
+            assert np.array_equal(got, want), (n, t16, np.nonzero(got != want)[0][:5])
+        pubs, idx, H, S = _keyed_case(eng, orc, l, 6, 1500, 0x4B00 + l, bogus=(1, 2))
+        S[::5, 2] ^= 4
+        K = np.frombuffer(b"".join(pubs), dtype=np.uint8).reshape(6, 2 * no)
+        want = np.array(orc.verify_batch_l(l, E.LEVEL_OID[l], H.tobytes(), S.tobytes(), K[idx].tobytes(), nthreads=16), dtype=np.int64)
+        idx2 = idx.copy(); idx2[[0, 777]] = [6, 1 << 30]; want[[0, 777]] = E.ERR_BAD_INPUT
+        codes = torch.full((1500,), -1, dtype=torch.int32, device="cuda")
+        eng.bignVerifyL_keyed_batch_dev(l, E.LEVEL_OID[l], dev(H.reshape(-1)), dev(S.reshape(-1)), b"".join(pubs),
+                                        torch.from_numpy(idx2.astype(np.int32)).cuda(), codes)
+        torch.cuda.synchronize()
+        got = codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        assert np.array_equal(got, want), np.nonzero(got != want)[0][:5]
+    finally:
+        tune(22, -1); tune(20, -1)
