@@ -389,3 +389,31 @@ def test_onekey_one_and_four_lanes_per_signature(orc, l, quads):
         assert np.array_equal(got, want), np.nonzero(got != want)[0][:5]
     finally:
         tune(22, -1); tune(20, -1)
+
+
+def test_onekey_batch_of_2pow22_signatures(orc):
+    """2^22 + 3 signatures under one key in ONE call (4 GiB of scratch), every 4099th damaged: verdicts by position, a sample against the
+    oracle"""
+    eng = engine()
+    l, n = 128, (1 << 22) + 3
+    oid = E.LEVEL_OID[l]
+    d = bytearray(orc.fill(32, 0x2222)); d[31] &= 0x3F
+    pub = orc.pubkey_calc(l, bytes(d))[1]
+    g = torch.Generator(device="cuda"); g.manual_seed(22)
+    h = torch.empty(32 * n + 8, dtype=torch.uint8, device="cuda"); h[: (32 * n) // 8 * 8].view(torch.int64).random_(generator=g)
+    h = h[: 32 * n]
+    sigs = torch.empty(48 * n, dtype=torch.uint8, device="cuda"); c = torch.empty(n, dtype=torch.int32, device="cuda")
+    eng.bignSign2L_batch_dev(l, oid, h, dev(bytes(d)).repeat(n), sigs, c)
+    torch.cuda.synchronize()
+    assert int(c.abs().sum()) == 0
+    sigs.view(n, 48)[::4099, 30] ^= 1
+    codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    for _ in range(2):                                  # (the second call: the key has its 16-bit table)
+        eng.bignVerifyL_onekey_batch_dev(l, oid, h, sigs, pub, codes)
+        torch.cuda.synchronize()
+        want = torch.zeros(n, dtype=torch.int32, device="cuda"); want[::4099] = 510
+        assert bool((codes == want).all())
+    idx = list(range(0, n, 65537))[:40] + [4099 * 7, n - 1]
+    hh, ss = host(h.view(n, 32)[idx].reshape(-1)), host(sigs.view(n, 48)[idx].reshape(-1))
+    o = orc.verify_batch_l(l, oid, hh, ss, pub * len(idx), nthreads=8)
+    assert o == [int(x) for x in codes[idx].cpu().numpy()]
