@@ -1915,17 +1915,18 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
         d_keys = kts[0]->d_key;
     } else {
         // the tables' addresses (a key off the curve has none: null) and the keys go up in one block
-        std::vector<uint8_t> blk(nkeys * (8 + 2 * NO));
+        const size_t koff = (8 * nkeys + 15) & ~(size_t)15;        // (the kernels read keys with 16-octet loads)
+        std::vector<uint8_t> blk(koff + 2 * NO * nkeys);
         uint64_t *ptrs = reinterpret_cast<uint64_t *>(blk.data());
         for (size_t k = 0; k < nkeys; ++k) ptrs[k] = kts[k] ? (uint64_t)(uintptr_t)kts[k]->tab : 0;
-        memcpy(blk.data() + 8 * nkeys, keys, 2 * NO * nkeys);
+        memcpy(blk.data() + koff, keys, 2 * NO * nkeys);
         void *d_blk = nullptr;
         code = scratch_for_stream(st, 13, blk.size(), &d_blk);
         if (code != ERR_OK) return code;
         B2H_TRY(hipMemcpyAsync(d_blk, blk.data(), blk.size(), hipMemcpyHostToDevice, st));
         B2H_TRY(hipStreamSynchronize(st));                          // (blk is pageable and goes out of scope)
         d_tabs = reinterpret_cast<const uint4 *const *>(d_blk);
-        d_keys = reinterpret_cast<const uint8_t *>(d_blk) + 8 * nkeys;
+        d_keys = reinterpret_cast<const uint8_t *>(d_blk) + koff;
     }
     VerifyScratch S;
     code = bign_scratch<N>(st, n, S);
