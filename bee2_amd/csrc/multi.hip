@@ -203,6 +203,39 @@ extern "C" err_t bee2hip_bignVerify_batch_multi(const bign_params *params, const
     });
 }
 
+// one signer / a few signers over all GPUs: every device builds (and caches) the tables of the keys its part meets
+extern "C" err_t bee2hip_bignVerify_keyed_batch_multi(const bign_params *params, const octet oid_der[], size_t oid_len,
+                                                      const octet *hashes, const octet *sigs, const octet *pubkeys, size_t nkeys,
+                                                      const u32 *key_index, size_t n, err_t *codes, int ndev)
+{
+    err_t code = bee2hip_bignVerify_keyed_batch(params, oid_der, oid_len, hashes, sigs, pubkeys, nkeys, key_index, 0, codes);
+    if (code != ERR_OK) return code;
+    if (n && (!hashes || !sigs || !pubkeys || !nkeys || !key_index || !codes)) return ERR_BAD_INPUT;
+    if (n == 0) return ERR_OK;
+    const size_t no = params->l / 4;
+    return run_on_devices(ndev, [=](int i, int parts) {
+        size_t lo, cnt;
+        bee2hip_multi_plan(n, parts, i, &lo, &cnt);
+        return bee2hip_bignVerify_keyed_batch(params, oid_der, oid_len, hashes + no * lo, sigs + (no + no / 2) * lo, pubkeys, nkeys,
+                                              key_index + lo, cnt, codes + lo);
+    });
+}
+extern "C" err_t bee2hip_bignVerify_onekey_batch_multi(const bign_params *params, const octet oid_der[], size_t oid_len,
+                                                       const octet *hashes, const octet *sigs, const octet pubkey[], size_t n,
+                                                       err_t *codes, int ndev)
+{
+    err_t code = bee2hip_bignVerify_onekey_batch(params, oid_der, oid_len, hashes, sigs, pubkey, 0, codes);
+    if (code != ERR_OK) return code;
+    if (n && (!hashes || !sigs || !pubkey || !codes)) return ERR_BAD_INPUT;
+    if (n == 0) return ERR_OK;
+    const size_t no = params->l / 4;
+    return run_on_devices(ndev, [=](int i, int parts) {
+        size_t lo, cnt;
+        bee2hip_multi_plan(n, parts, i, &lo, &cnt);
+        return bee2hip_bignVerify_onekey_batch(params, oid_der, oid_len, hashes + no * lo, sigs + (no + no / 2) * lo, pubkey, cnt, codes + lo);
+    });
+}
+
 extern "C" err_t bee2hip_bignSign2_batch_multi(const bign_params *params, const octet oid_der[], size_t oid_len,
                                                const octet *hashes, const octet *privkeys, const void *t, size_t t_len,
                                                size_t n, octet *sigs, err_t *codes, int ndev)
@@ -324,6 +357,35 @@ extern "C" err_t bee2hip_bignVerifyL_batch_multi_dev(size_t l, const octet oid_d
     if (code != ERR_OK) return code;
     return run_on_devices(ndev, [=](int i, int) {
         return drain(bee2hip_bignVerifyL_batch_dev(l, oid_der, oid_len, d_hashes[i], d_sigs[i], d_pubkeys[i], counts[i], d_codes[i], nullptr));
+    });
+}
+
+extern "C" err_t bee2hip_bignVerifyL_onekey_batch_multi_dev(size_t l, const octet oid_der[], size_t oid_len, const void *const d_hashes[],
+                                                            const void *const d_sigs[], const octet pubkey[], const size_t counts[],
+                                                            void *const d_codes[], int ndev)
+{
+    err_t code = multi_dev_args(d_hashes, counts, ndev);
+    if (code != ERR_OK) return code;
+    if (!d_sigs || !pubkey || !d_codes) return ERR_BAD_INPUT;
+    code = bee2hip_bignVerifyL_onekey_batch_dev(l, oid_der, oid_len, nullptr, nullptr, pubkey, 0, nullptr, nullptr);
+    if (code != ERR_OK) return code;
+    return run_on_devices(ndev, [=](int i, int) {
+        return drain(bee2hip_bignVerifyL_onekey_batch_dev(l, oid_der, oid_len, d_hashes[i], d_sigs[i], pubkey, counts[i], d_codes[i], nullptr));
+    });
+}
+extern "C" err_t bee2hip_bignVerifyL_keyed_batch_multi_dev(size_t l, const octet oid_der[], size_t oid_len, const void *const d_hashes[],
+                                                           const void *const d_sigs[], const octet pubkeys[], size_t nkeys,
+                                                           const void *const d_key_index[], const size_t counts[], void *const d_codes[],
+                                                           int ndev)
+{
+    err_t code = multi_dev_args(d_hashes, counts, ndev);
+    if (code != ERR_OK) return code;
+    if (!d_sigs || !pubkeys || !nkeys || !d_key_index || !d_codes) return ERR_BAD_INPUT;
+    code = bee2hip_bignVerifyL_keyed_batch_dev(l, oid_der, oid_len, nullptr, nullptr, pubkeys, nkeys, nullptr, 0, nullptr, nullptr);
+    if (code != ERR_OK) return code;
+    return run_on_devices(ndev, [=](int i, int) {
+        return drain(bee2hip_bignVerifyL_keyed_batch_dev(l, oid_der, oid_len, d_hashes[i], d_sigs[i], pubkeys, nkeys, d_key_index[i], counts[i],
+                                                         d_codes[i], nullptr));
     });
 }
 

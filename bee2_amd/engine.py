@@ -84,6 +84,8 @@ BATCH_SYMBOLS = [
     "bee2hip_bign128Verify_batch_dev", "bee2hip_bignVerify_batch_dev", "bee2hip_bignVerifyL_batch_dev",
     "bee2hip_bignVerify_onekey_batch", "bee2hip_bignVerifyL_onekey_batch_dev",
     "bee2hip_bignVerify_keyed_batch", "bee2hip_bignVerifyL_keyed_batch_dev",
+    "bee2hip_bignVerify_onekey_batch_multi", "bee2hip_bignVerify_keyed_batch_multi",
+    "bee2hip_bignVerifyL_onekey_batch_multi_dev", "bee2hip_bignVerifyL_keyed_batch_multi_dev",
     "bee2hip_bignPubkeyVal_batch", "bee2hip_bignPubkeyValL_batch_dev",
     "bee2hip_bignPubkeyCalc_batch", "bee2hip_bignSign2_batch", "bee2hip_bignSignK_batch",
     "bee2hip_device_count", "bee2hip_multi_plan", "bee2hip_bashF_batch_multi", "bee2hip_beltCTR_bulk_multi",

@@ -348,6 +348,12 @@ err_t bee2hip_beltCTR_bulk_multi(void *buf, size_t count, void *ctr_state, int n
 err_t bee2hip_bignVerify_batch_multi(const bign_params *params, const octet oid_der[], size_t oid_len,
                                      const octet *hashes, const octet *sigs, const octet *pubkeys, size_t n,
                                      err_t *codes, int ndev);
+err_t bee2hip_bignVerify_onekey_batch_multi(const bign_params *params, const octet oid_der[], size_t oid_len,
+                                            const octet *hashes, const octet *sigs, const octet pubkey[], size_t n,
+                                            err_t *codes, int ndev);
+err_t bee2hip_bignVerify_keyed_batch_multi(const bign_params *params, const octet oid_der[], size_t oid_len,
+                                           const octet *hashes, const octet *sigs, const octet *pubkeys, size_t nkeys,
+                                           const u32 *key_index, size_t n, err_t *codes, int ndev);
 err_t bee2hip_bignSign2_batch_multi(const bign_params *params, const octet oid_der[], size_t oid_len,
                                     const octet *hashes, const octet *privkeys, const void *t, size_t t_len, size_t n,
                                     octet *sigs, err_t *codes, int ndev);
@@ -465,6 +471,14 @@ err_t bee2hip_beltCTR_blocks_multi_dev(void *const d_bufs[], const size_t nblock
 err_t bee2hip_bignVerifyL_batch_multi_dev(size_t l, const octet oid_der[], size_t oid_len, const void *const d_hashes[],
                                           const void *const d_sigs[], const void *const d_pubkeys[],
                                           const size_t counts[], void *const d_codes[], int ndev);
+/* one signer / a few signers, shards resident on the GPUs (the keys on the host, as in the single-device forms) */
+err_t bee2hip_bignVerifyL_onekey_batch_multi_dev(size_t l, const octet oid_der[], size_t oid_len, const void *const d_hashes[],
+                                                 const void *const d_sigs[], const octet pubkey[], const size_t counts[],
+                                                 void *const d_codes[], int ndev);
+err_t bee2hip_bignVerifyL_keyed_batch_multi_dev(size_t l, const octet oid_der[], size_t oid_len, const void *const d_hashes[],
+                                                const void *const d_sigs[], const octet pubkeys[], size_t nkeys,
+                                                const void *const d_key_index[], const size_t counts[], void *const d_codes[],
+                                                int ndev);
 err_t bee2hip_bashHash_beltMAC_batch_multi_dev(const void *const d_msgs[], size_t msg_len, const size_t counts[], size_t l,
                                                const octet key[], size_t key_len, void *const d_digests[],
                                                void *const d_tags[], int ndev);

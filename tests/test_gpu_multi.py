@@ -175,3 +175,57 @@ def test_multi_dev_entries_on_resident_shards(orc, golden, devices):
     # misuse: more entries than devices, null arrays
     assert eng.lib.bee2hip_bashF_batch_multi_dev(P, CNT, k + 1) == E.ERR_BAD_INPUT
     assert eng.lib.bee2hip_bashF_batch_multi_dev(None, CNT, k) == E.ERR_BAD_INPUT
+
+
+def test_onekey_and_keyed_multi(orc, golden, devices):
+    """the one-signer / few-signers entries over k (logical) devices: host-pointer forms cut by bee2hip_multi_plan, device-resident
+    shards with the keys on the host -- the base set's signatures by their signers, every 6th damaged, the oracle's verdicts"""
+    import torch
+
+    from gpulib import dev
+    eng = engine()
+    k = devices
+    vp = ctypes.c_void_p
+    P = eng.bignParamsStd(E.CURVE_NAME[128])
+    oid = E.LEVEL_OID[128]
+    hs, ss, ps = golden.bign_base_arrays()
+    n = 1800
+    bad = bytearray(ss[:48 * n])
+    for i in range(0, n, 6):
+        bad[48 * i + 11] ^= 2
+    keys = sorted({ps[64 * i: 64 * i + 64] for i in range(n)})
+    idx = np.array([keys.index(ps[64 * i: 64 * i + 64]) for i in range(n)], dtype=np.uint32)
+    want = orc.verify_batch(hs[:32 * n], bytes(bad), ps[:64 * n], nthreads=8)
+    codes = (ctypes.c_uint32 * n)()
+    assert eng.lib.bee2hip_bignVerify_keyed_batch_multi(ctypes.byref(P), oid, _sz(11), hs[:32 * n], bytes(bad), b"".join(keys), _sz(len(keys)),
+                                                        idx.ctypes.data_as(vp), _sz(n), codes, 0) == 0
+    assert list(codes) == want
+    # one signer: the signatures of the first key, and as the wrong key for the others
+    mine = [i for i in range(n) if idx[i] == idx[0]]
+    H1 = b"".join(hs[32 * i: 32 * i + 32] for i in mine) * 9
+    S1 = b"".join(bytes(bad[48 * i: 48 * i + 48]) for i in mine) * 9
+    m = len(mine) * 9
+    c1 = (ctypes.c_uint32 * m)()
+    assert eng.lib.bee2hip_bignVerify_onekey_batch_multi(ctypes.byref(P), oid, _sz(11), H1, S1, keys[idx[0]], _sz(m), c1, 0) == 0
+    assert list(c1) == [want[i] for i in mine] * 9
+    assert eng.lib.bee2hip_bignVerify_onekey_batch_multi(ctypes.byref(P), b"\x06\x01", _sz(2), H1, S1, keys[idx[0]], _sz(m), c1, 0) == E.ERR_BAD_OID
+    # resident shards
+    counts = [(100 + 17 * i) if (i != 1 or k < 3) else 0 for i in range(k)]
+    CNT = (ctypes.c_size_t * k)(*counts)
+    th, tsg, ti, tc, pos = [], [], [], [], 0
+    for c in counts:
+        th.append(dev(hs[32 * pos: 32 * (pos + c)]) if c else None)
+        tsg.append(dev(bytes(bad[48 * pos: 48 * (pos + c)])) if c else None)
+        ti.append(torch.from_numpy(idx[pos: pos + c].astype(np.int32)).cuda() if c else None)
+        tc.append(torch.full((max(c, 1),), -1, dtype=torch.int32, device="cuda"))
+        pos += c
+    arr = lambda xs: (vp * k)(*[x.data_ptr() if x is not None else None for x in xs])  # noqa: E731
+    assert eng.lib.bee2hip_bignVerifyL_keyed_batch_multi_dev(_sz(128), oid, _sz(11), arr(th), arr(tsg), b"".join(keys), _sz(len(keys)), arr(ti),
+                                                             CNT, arr(tc), k) == 0
+    got = [int(x) & 0xFFFFFFFF for t, c in zip(tc, counts) for x in t.cpu().numpy()[:c]]
+    assert got == want[:pos]
+    for t in tc:
+        t.fill_(-1)
+    assert eng.lib.bee2hip_bignVerifyL_onekey_batch_multi_dev(_sz(128), oid, _sz(11), arr(th), arr(tsg), keys[idx[0]], CNT, arr(tc), k) == 0
+    got = [int(x) & 0xFFFFFFFF for t, c in zip(tc, counts) for x in t.cpu().numpy()[:c]]
+    assert got == [want[i] if idx[i] == idx[0] else 510 for i in range(pos)]
