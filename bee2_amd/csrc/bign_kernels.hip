@@ -1477,6 +1477,8 @@ static err_t bign_scratch(hipStream_t st, size_t n, VerifyScratch &S)
     return ERR_OK;
 }
 
+static int g_inv_lanes_log2 = 0;                     // lanes of bign_inv_kernel (log2; 0 = by curve): A/B, tune 23
+void set_inv_lanes(int v) { g_inv_lanes_log2 = v; }
 static int g_verify_path = 0, g_verify_lanes = 0;
 void set_verify_path(int v) { g_verify_path = v & 15; g_verify_lanes = v >> 4; }   // 0x43: quads at every size
 static int g_verify_split = 0;                       // 0 = by size, 1 = never, 2 / 3 / 4 = that many parts (A/B)
@@ -1620,7 +1622,9 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
     // signature) and a lone wavefront issues at about a third of a SIMD's rate, so fewer, longer lanes cost
     // little until the lanes no longer cover the SIMDs: measured best at 2^18 signatures K = 8 on the 256-bit
     // curve (72 us; K = 2: 105 us) and K = 4 on the wider ones (profiles/r01_bign_ab_inv.txt)
-    constexpr size_t inv_lanes = N == 8 ? 32768 : 65536;
+    // (round 4, tools/inv_lanes_ab.py: with the division-step inversion the optimum is flat; up to 2^17 signatures on the 256-bit curve 2^16
+    //  lanes -- one wavefront per SIMD, two signatures each -- are 4-7 % ahead of 2^15; profiles/r04_inv_lanes_ab.txt)
+    const size_t inv_lanes = g_inv_lanes_log2 > 0 ? (size_t)1 << g_inv_lanes_log2 : N == 8 && n > ((size_t)1 << 17) ? 32768 : 65536;
     const size_t k_inv = std::min<size_t>(16, std::max<size_t>(1, n / inv_lanes));
     const size_t lanes = (n + k_inv - 1) / k_inv;
     hipLaunchKernelGGL(bign_inv_kernel<N>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, n, lanes,
@@ -1959,7 +1963,9 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
                            kts[0]->tab, (const uint4 *)nullptr, (const uint32_t *)nullptr, (const uint4 *const *)nullptr, 1u);
     hipLaunchKernelGGL(bign_slow_kernel<N>, dim3(g64), dim3(64), 0, st, dsg, d_keys, n, S, keyed ? ~(size_t)0 : (size_t)0);
     // shared inversions and the hash tail: as launch_bign_verify_t
-    constexpr size_t inv_lanes = N == 8 ? 32768 : 65536;
+    // (round 4, tools/inv_lanes_ab.py: with the division-step inversion the optimum is flat; up to 2^17 signatures on the 256-bit curve 2^16
+    //  lanes -- one wavefront per SIMD, two signatures each -- are 4-7 % ahead of 2^15; profiles/r04_inv_lanes_ab.txt)
+    const size_t inv_lanes = g_inv_lanes_log2 > 0 ? (size_t)1 << g_inv_lanes_log2 : N == 8 && n > ((size_t)1 << 17) ? 32768 : 65536;
     const size_t k_inv = std::min<size_t>(16, std::max<size_t>(1, n / inv_lanes));
     const size_t lanes = (n + k_inv - 1) / k_inv;
     hipLaunchKernelGGL(bign_inv_kernel<N>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, n, lanes, (int)k_inv, S);

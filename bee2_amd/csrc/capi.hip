@@ -1853,7 +1853,7 @@ extern "C" unsigned long long bee2hip_path_count(int which)
 #ifdef BEE2HIP_EXPERIMENTS      // everything from here to the end of the kernel-timing hook: libbee2hip_exp.so only
 // ============================================================ internal tuning hook ===
 // A/B switch for experiment builds (tools/bashf_ab.py); not part of the product ABI (BEE2HIP_INTERNAL).
-namespace bee2hip { void set_bashF_variant(int v); void set_ctr_variant(int v); void set_verify_path(int v); void set_verify_split(int v); void set_sign_coop(int v); void set_sign_wg(int v); void set_fused_tab(int v); void set_long_hash_form(int v); void set_ragged_fork(int v); void set_verify_pairs(int v); void set_onekey_tab16(int v); void set_onekey_slots(int v); void set_onekey_quads(int v); }
+namespace bee2hip { void set_bashF_variant(int v); void set_ctr_variant(int v); void set_verify_path(int v); void set_verify_split(int v); void set_sign_coop(int v); void set_sign_wg(int v); void set_fused_tab(int v); void set_long_hash_form(int v); void set_ragged_fork(int v); void set_verify_pairs(int v); void set_onekey_tab16(int v); void set_onekey_slots(int v); void set_onekey_quads(int v); void set_inv_lanes(int v); }
 extern "C" err_t bee2hip_internal_tune(int key, int value)
 {
     switch (key) {
@@ -1873,6 +1873,7 @@ extern "C" err_t bee2hip_internal_tune(int key, int value)
     case 13: bee2hip::set_fused_tab(value); return ERR_OK;            // belt table of the fused bash + belt-mac kernel (A/B)
     case 16: bee2hip::set_long_hash_form(value); return ERR_OK;        // table / workgroup of the long belt-hash kernel (A/B)
     case 19: bee2hip::set_verify_pairs(value); return ERR_OK;          // verification main kernel: multiply-adds in pairs (-1 by size, 0 never, else always)
+    case 23: bee2hip::set_inv_lanes(value); return ERR_OK;             // lanes of the shared-inversion kernel of verification (log2; 0 = by curve)
     case 22: bee2hip::set_onekey_quads(value); return ERR_OK;          // one-signer verification: four lanes per signature (-1 by size, 0 never, 1 always)
     case 21: bee2hip::set_onekey_slots(value); return ERR_OK;          // one-signer verification: keys the table cache keeps (tests: evictions under load)
     case 20: bee2hip::set_onekey_tab16(value); return ERR_OK;          // one-signer verification: log2 of the signatures after which a key gets its 16-bit table (-1 by curve, 63 never)

@@ -7,7 +7,7 @@ O=$R/gpurun_out/fin4; mkdir -p $O
 cd $R
 timeout 1200 python -m pytest tests -m gpu -q > $O/gputests.log 2>&1; echo "pytest rc=$?" >> $O/gputests.log; tail -4 $O/gputests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
+T0=$(date +%s); timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$? wall $(( $(date +%s) - T0 )) s"
 BEE2_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 20 --warmup 5 --ctr-gib 4 > $O/bench_gpus2_gloo.json 2> $O/bench_gpus2.err; echo "bench2 rc=$?"
 # rocprofv3: kernel stats of the bench command, bashF alone, FETCH / WRITE passes (each under a timeout; csv output)
 cd /tmp && export TMPDIR=/tmp
