@@ -751,6 +751,24 @@ def main():
             "roofline": {"kernels": "bign_onekey + slow + inv + tail", "bound": "valu-int", "avg_batch_ms": ms1,
                          "mads_per_verify": MADS_ONEKEY, "achieved": MADS_ONEKEY * n1 / (ms1 * 1e-3) / 1e12, "peak": MAD_PEAK_T,
                          "unit": "T v_mad_u64_u32 lane-ops/s", "frac": MADS_ONEKEY * n1 / (ms1 * 1e-3) / 1e12 / MAD_PEAK_T}}
+        if dist.rank == 0:
+            # the latency floor: prefixes of the same batch (up to 2^16 signatures four lanes share a signature)
+            small1 = {}
+            for e in (10, 14, 15, 16, 17):
+                m = 1 << e
+                pre = (h1[: 32 * m], s1[: 48 * m], pub1, codes1[:m])
+                for _ in range(4):
+                    eng.bignVerifyL_onekey_batch_dev(128, _OID, *pre)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    eng.bignVerifyL_onekey_batch_dev(128, _OID, *pre)
+                e1.record()
+                torch.cuda.synchronize()
+                ms_b = e0.elapsed_time(e1) / 20
+                small1[f"2^{e}"] = {"ms_per_batch": ms_b, "verifies_per_s": m / (ms_b * 1e-3)}
+            others["bignVerify_onekey"]["batch_size_sweep"] = small1
         # ... and of a FEW signers: the population SURVEY 8d describes (64 key pairs), every signature distinct, 1/16 damaged
         nk = 64
         dks = [bytes(((k * 37 + i * 11 + 5) & 255) for i in range(31)) + b"\x21" for k in range(nk)]
