@@ -1888,6 +1888,7 @@ extern "C" err_t bee2hip_internal_tune(int key, int value)
 // after the GPU path failed twice
 extern "C" unsigned long long bee2hip_internal_stat(int which)
 {
+    if (which == 3) return bee2hip::bign_onekey_table_builds();       // key tables built so far (one-signer / few-signers verification)
     return which == 0 ? bee2hip::g_n_host.load() : which == 1 ? bee2hip::g_n_gpu.load() : bee2hip::g_n_fallback.load();
 }
 

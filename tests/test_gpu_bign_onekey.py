@@ -417,3 +417,29 @@ def test_onekey_batch_of_2pow22_signatures(orc):
     hh, ss = host(h.view(n, 32)[idx].reshape(-1)), host(sigs.view(n, 48)[idx].reshape(-1))
     o = orc.verify_batch_l(l, oid, hh, ss, pub * len(idx), nthreads=8)
     assert o == [int(x) for x in codes[idx].cpu().numpy()]
+
+
+def test_key_tables_are_built_once_per_key(orc):
+    """the cache at work (experiments build: bee2hip_internal_stat 3 = key tables built so far): a key met again builds nothing, a keyed
+    batch builds one table per NEW distinct key, a key off the curve none"""
+    import ctypes
+    eng = exp_engine()
+    stat = eng.lib.bee2hip_internal_stat
+    stat.restype = ctypes.c_ulonglong
+    l = 128
+    pub, H, S = _signed_under_one_key(eng, orc, l, 50, 0x7A1)
+    b0 = stat(3)
+    assert not _onekey_dev(eng, l, H, S, pub).any()
+    assert stat(3) == b0 + 1
+    for _ in range(3):
+        assert not _onekey_dev(eng, l, H, S, pub).any()
+    assert stat(3) == b0 + 1
+    pubs, idx, Hk, Sk = _keyed_case(eng, orc, l, 9, 400, 0x7A2, bogus=(1,))       # key 1: off the curve
+    codes = torch.full((400,), -1, dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        eng.bignVerifyL_keyed_batch_dev(l, E.LEVEL_OID[l], dev(Hk.reshape(-1)), dev(Sk.reshape(-1)), b"".join(pubs + [pub, pubs[0]]),
+                                        torch.from_numpy(idx.astype(np.int32)).cuda(), codes)
+        torch.cuda.synchronize()
+        assert stat(3) == b0 + 1 + 8                                                # 8 new keys on the curve; `pub` cached, pubs[0] twice
+    got = codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert (got[idx != 1] == 0).all() and (got[idx == 1] != 0).all()
