@@ -997,6 +997,7 @@ void bign_onekey_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
         if (k >= nkeys) { S.status[idx] = ERR_BAD_INPUT; return; }
         key += (size_t)2 * NO * k;
         ktab = tabs[k];
+        ktab16 = tabs[nkeys + k];                                  // the 16-bit table of a busy key, or null
     }
     feT<N> u;
     {
@@ -1016,17 +1017,28 @@ void bign_onekey_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
         T.X = E.x; T.Y = E.y; fe_set_one(T.Z);
     }
     const uint32_t *s0 = reinterpret_cast<const uint32_t *>(sigs + (NO + NO / 2) * idx);
+    // KEYED: a lane whose key has a 16-bit table takes the word in two halves (steps 0 and 2, nothing at 1 and 3), the others in
+    // four octets -- one loop for both, so a wavefront of busy keys skips the odd steps altogether
+    const bool q16 = Q16 || (KEYED && ktab16 != nullptr);
 #pragma unroll 1
     for (int l = 0; l < N / 2; ++l) {
-        uint32_t word = s0[l];
+        const uint32_t word = s0[l];
 #pragma unroll 1
-        for (int k = 0; k < (Q16 ? 2 : 4); ++k) {
-            const uint32_t b = word & (Q16 ? 65535u : 255u);
-            word >>= Q16 ? 16 : 8;
-            if (b != 0) {
+        for (int k = 0; k < ((Q16 && !KEYED) ? 2 : 4); ++k) {
+            const uint4 *entry = nullptr;
+            if (Q16 && !KEYED) {
+                const uint32_t b = (word >> (16 * k)) & 65535u;
+                if (b != 0) entry = ktab16 + ((size_t)(2 * l + k) * 65536 + b) * (N / 2);
+            } else if (q16) {
+                const uint32_t b = (word >> (8 * k)) & 65535u;
+                if ((k & 1) == 0 && b != 0) entry = ktab16 + ((size_t)(2 * l + (k >> 1)) * 65536 + b) * (N / 2);
+            } else {
+                const uint32_t b = (word >> (8 * k)) & 255u;
+                if (b != 0) entry = ktab + ((size_t)(4 * l + k) * GT8_ENTRIES + b) * (N / 2);
+            }
+            if (entry) {
                 affT<N> E;
-                if (Q16) load_aff(E, ktab16 + ((size_t)(2 * l + k) * 65536 + b) * (N / 2));
-                else load_aff(E, ktab + ((size_t)(4 * l + k) * GT8_ENTRIES + b) * (N / 2));
+                load_aff(E, entry);
                 ok &= jac_madd<N, OPS>(T, E);
             }
         }
@@ -1076,7 +1088,7 @@ void bign_onekey4_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__re
     if (KEYED) {
         const uint32_t k = key_index[idx];
         if (k >= nkeys) { if (live && sub == 0) S.status[idx] = ERR_BAD_INPUT; live = false; }
-        else { key += (size_t)2 * NO * k; ktab = tabs[k]; }
+        else { key += (size_t)2 * NO * k; ktab = tabs[k]; ktab16 = tabs[nkeys + k]; }
     }
     {
         affT<N> Q;
@@ -1091,7 +1103,7 @@ void bign_onekey4_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__re
 #pragma unroll
         for (int i = 0; i < N; ++i) u_rows[threadIdx.x][i] = u.v[i];
     }
-    if (KEYED && !ktab) ktab = gtab;                               // (a dead quad still walks: any readable table)
+    if (KEYED && !ktab) { ktab = gtab; ktab16 = nullptr; }         // (a dead quad still walks: any readable table)
     bool ok = true, empty = sub != 0;
     jacT<N> T;
     fe_set_zero(T.X); fe_set_one(T.Y); fe_set_zero(T.Z);
@@ -1107,11 +1119,15 @@ void bign_onekey4_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__re
         else ok &= jac_madd<N, OPS>(T, E);
     };
     const uint8_t *s0 = sigs + (NO + NO / 2) * idx;
-    constexpr int NV = Q16 ? N : 2 * N;                            // windows of v below the top one
+    // windows of v below the top one: N of 16 bits (a key with a 16-bit table; KEYED: by the lane's key) or 2N of 8 bits
+    const bool q16 = (Q16 && !KEYED) || (KEYED && ktab16 != nullptr);
+    constexpr int NV_MAX = (Q16 && !KEYED) ? N : 2 * N;
+    const int nv = q16 ? N : 2 * N;
 #pragma unroll 1
-    for (int i = 0; i < NV / 4; ++i) {
+    for (int i = 0; i < NV_MAX / 4; ++i) {
         const unsigned j = 4u * i + sub;
-        if (Q16) {
+        if ((int)j >= nv) continue;
+        if (q16) {
             const uint32_t b = reinterpret_cast<const uint16_t *>(s0)[j];
             if (b != 0) take(ktab16 + ((size_t)j * 65536 + b) * (N / 2));
         } else {
@@ -1761,9 +1777,9 @@ struct KeyTab {
     uint64_t stamp = 0, used = 0;      // signatures verified under the key so far
     ~KeyTab();
 };
-// at most KEYTAB16_MAX keys hold a 16-bit table at a time (<= 1 / 2.3 / 4 GiB per process): a key that becomes busy while they are
+// at most KEYTAB16_MAX keys hold a 16-bit table at a time (<= 3 / 7 / 12 GiB per process): a key that becomes busy while they are
 // all taken stays on its 8-bit table
-constexpr int KEYTAB16_MAX = 32;
+constexpr int KEYTAB16_MAX = 96;
 static std::atomic<int> g_keytab16_live{0};
 KeyTab::~KeyTab() { if (tab16) { (void)hipFree(tab16); g_keytab16_live.fetch_sub(1); } }
 static size_t KEYTAB_SLOTS = 1024;                   // (0.3 - 1 GiB of 8-bit tables when full; tests: tune 21)
@@ -1905,7 +1921,8 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
     }
     if (code != ERR_OK) return code;
     std::vector<std::shared_ptr<KeyTab>> kts;
-    code = bign_key_tables<N>(kts, keys, nkeys, keyed ? 0 : n, !keyed, st);
+    // (keyed: every key is credited with its share of the batch -- the signers of a batch are taken to be about equally busy)
+    code = bign_key_tables<N>(kts, keys, nkeys, keyed ? (n + nkeys - 1) / nkeys : n, true, st);
     if (code != ERR_OK) return code;
     const uint4 *tab16 = nullptr;
     const uint8_t *d_keys = nullptr;
@@ -1919,10 +1936,16 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
         d_keys = kts[0]->d_key;
     } else {
         // the tables' addresses (a key off the curve has none: null) and the keys go up in one block
-        const size_t koff = (8 * nkeys + 15) & ~(size_t)15;        // (the kernels read keys with 16-octet loads)
+        const size_t koff = (16 * nkeys + 15) & ~(size_t)15;       // (the kernels read keys with 16-octet loads)
         std::vector<uint8_t> blk(koff + 2 * NO * nkeys);
         uint64_t *ptrs = reinterpret_cast<uint64_t *>(blk.data());
-        for (size_t k = 0; k < nkeys; ++k) ptrs[k] = kts[k] ? (uint64_t)(uintptr_t)kts[k]->tab : 0;
+        {
+            std::lock_guard<std::mutex> lk(g_bign_mu);             // (another thread may be giving a key its 16-bit table)
+            for (size_t k = 0; k < nkeys; ++k) {
+                ptrs[k] = kts[k] ? (uint64_t)(uintptr_t)kts[k]->tab : 0;
+                ptrs[nkeys + k] = kts[k] ? (uint64_t)(uintptr_t)kts[k]->tab16 : 0;
+            }
+        }
         memcpy(blk.data() + koff, keys, 2 * NO * nkeys);
         void *d_blk = nullptr;
         code = scratch_for_stream(st, 13, blk.size(), &d_blk);

@@ -500,7 +500,62 @@ def f_onekey(rnd):
         _tune(22, -1)
 
 
-FAMILIES = [("onekey", f_onekey), ("bashF", f_bashF), ("beltCTR", f_ctr), ("mac/hash", f_mac_hash), ("modes", f_modes), ("dwp/che", f_aead),
+def f_keyed(rnd):
+    """n signatures of a few signers (bee2hip_bignVerifyL_keyed_batch_dev / the host-pointer form): fixture triples with their keys as the
+    signers, some signatures handed to the wrong signer, junk keys, indices out of range, random damage; table forms and lane counts
+    forced at random in the experiments build; the oracle's bignVerify with the signature's key on every entry"""
+    l = rnd.choice((128, 128, 192, 256))
+    no, sg = l // 4, 3 * l // 8
+    oid = LEVEL_OID[l]
+    base = _triples(l)
+    n = max(1, size(rnd, 2500 if l == 128 else 400, (64, 256, 1024)))
+    picks = [rnd.choice(base) for _ in range(n)]
+    keys = sorted({p for _, _, p in rnd.sample(picks, min(n, rnd.choice((1, 2, 5, 17, 64))))} | {picks[0][2]})
+    pos = {k: i for i, k in enumerate(keys)}
+    idx, H, S = [], bytearray(), bytearray()
+    for h, s_, p in picks:
+        idx.append(pos.get(p, rnd.randrange(len(keys))) if rnd.randrange(8) else rnd.randrange(len(keys)))     # (the wrong signer now and then)
+        H += h; S += s_
+    for i in range(n):
+        k = rnd.randrange(12)
+        if k == 1:
+            S[sg * i + rnd.randrange(sg)] ^= 1 << rnd.randrange(8)
+        elif k == 2:
+            H[no * i + rnd.randrange(no)] ^= 1 << rnd.randrange(8)
+        elif k == 3:
+            S[sg * i + no // 2: sg * (i + 1)] = b"\xff" * no
+    keys = [bytearray(k) for k in keys]
+    for k in keys:
+        r = rnd.randrange(14)
+        if r == 0:
+            k[rnd.randrange(2 * no)] ^= 1 << rnd.randrange(8)                   # off the curve
+        elif r == 1:
+            k[:no] = b"\xff" * no                                               # x >= p
+    K = b"".join(bytes(k) for k in keys)
+    want = orc.verify_batch_l(l, oid, bytes(H), bytes(S), b"".join(K[2 * no * i: 2 * no * (i + 1)] for i in idx), nthreads=16)
+    idx2 = list(idx)
+    for _ in range(rnd.choice((0, 0, 2))):
+        j = rnd.randrange(n)
+        idx2[j] = len(keys) + rnd.randrange(1 << 20)
+        want[j] = 109                                                           # ERR_BAD_INPUT
+    _tune(20, rnd.choice((-1, 63, 0, 8)))
+    _tune(22, rnd.choice((-1, 0, 1)))
+    try:
+        if rnd.randrange(3) == 0:
+            code, got = eng.bignVerify_keyed_batch(bytes(H), bytes(S), K, idx2, oid_der=oid, params=eng.bignParamsStd(bee2_amd.engine.CURVE_NAME[l]))
+            return code == 0 and got == list(want)
+        codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        ti = torch.tensor(idx2, dtype=torch.int64).to(torch.int32).cuda()
+        for _ in range(rnd.choice((1, 1, 3))):
+            eng.bignVerifyL_keyed_batch_dev(l, oid, dev(H), dev(S), K, ti, codes)
+        torch.cuda.synchronize()
+        return [int(x) & 0xFFFFFFFF for x in codes.cpu().numpy()] == list(want)
+    finally:
+        _tune(20, -1)
+        _tune(22, -1)
+
+
+FAMILIES = [("onekey", f_onekey), ("keyed", f_keyed), ("bashF", f_bashF), ("beltCTR", f_ctr), ("mac/hash", f_mac_hash), ("modes", f_modes), ("dwp/che", f_aead),
             ("verify", f_verify), ("ragged/mixed", f_ragged_mixed), ("sign", f_sign), ("multi", f_multi), ("sign-generic", f_sign_generic)]
 
 

@@ -443,3 +443,39 @@ def test_key_tables_are_built_once_per_key(orc):
         assert stat(3) == b0 + 1 + 8                                                # 8 new keys on the curve; `pub` cached, pubs[0] twice
     got = codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     assert (got[idx != 1] == 0).all() and (got[idx == 1] != 0).all()
+
+
+@pytest.mark.parametrize("l", [128, 192, 256])
+@pytest.mark.parametrize("quads", [1, 0])
+def test_keyed_batches_with_busy_and_quiet_keys(orc, l, quads):
+    """a keyed batch in which SOME signers have their 16-bit table and the others only the 8-bit one (lanes of one wavefront on different
+    table forms), then all of them busy; one / four lanes per signature forced; junk keys among them -- the oracle on every entry"""
+    eng = exp_engine()
+    tune = eng.lib.bee2hip_internal_tune
+    no = l // 4
+    try:
+        assert tune(22, quads) == 0 and tune(20, 63) == 0
+        pubs, idx, H, S = _keyed_case(eng, orc, l, 7, 1100, 0x5C00 + l, bogus=(3,))
+        S[::4, 5] ^= 0x20
+        S[9, : no // 2] = 0; S[10, : no // 2] = 0xFF; S[11, : no // 2] = 0; S[11, 2] = 1
+        K = np.frombuffer(b"".join(pubs), dtype=np.uint8).reshape(7, 2 * no)
+        want = np.array(orc.verify_batch_l(l, E.LEVEL_OID[l], H.tobytes(), S.tobytes(), K[idx].tobytes(), nthreads=16), dtype=np.int64)
+
+        def keyed():
+            codes = torch.full((1100,), -1, dtype=torch.int32, device="cuda")
+            eng.bignVerifyL_keyed_batch_dev(l, E.LEVEL_OID[l], dev(H.reshape(-1)), dev(S.reshape(-1)), b"".join(pubs),
+                                            torch.from_numpy(idx.astype(np.int32)).cuda(), codes)
+            torch.cuda.synchronize()
+            return codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        assert np.array_equal(keyed(), want)                           # every key on its 8-bit table
+        assert tune(20, 0) == 0
+        for k in (0, 4, 5):                                            # three of them become busy (one-signer calls give them the table)
+            sel = idx == k
+            assert np.array_equal(_onekey_dev(eng, l, H[sel], S[sel], pubs[k]), want[sel])
+        assert tune(20, 63) == 0
+        assert np.array_equal(keyed(), want)                           # mixed forms in one batch
+        assert tune(20, 0) == 0
+        assert np.array_equal(keyed(), want)                           # the keyed call itself makes the rest busy
+        assert np.array_equal(keyed(), want)
+    finally:
+        tune(22, -1); tune(20, -1)
