@@ -435,7 +435,8 @@ err_t bee2hip_bignVerifyL_onekey_batch_dev(size_t l, const octet oid_der[], size
 /* ... and of a FEW signers: pubkeys = nkeys keys (HOST memory, nkeys <= 4096 on the device form), key_index[i] < nkeys says whose
    signature i is (n x u32; device memory in the _dev form).  codes[i] = bignVerify(params, oid, hash_i, sig_i, pubkeys[key_index[i]]);
    an index out of range gives ERR_BAD_INPUT for that signature.  Every key gets its cached 8-bit comb table (the last 1024 keys
-   per process); a key that is not a point of the curve costs ITS signatures the complete slow kernel, nothing else. */
+   per process) and, once it has been busy enough, the 16-bit one; a key that is not a point of the curve costs ITS signatures the
+   complete slow kernel, nothing else.  This form uploads keys and table addresses per call (a copy and a synchronisation). */
 err_t bee2hip_bignVerify_keyed_batch(const bign_params *params, const octet oid_der[], size_t oid_len,
                                      const octet *hashes, const octet *sigs, const octet *pubkeys, size_t nkeys,
                                      const u32 *key_index, size_t n, err_t *codes);
