@@ -334,6 +334,40 @@ def test_sigvfy_pipeline_on_one_stream(golden, l):
     assert [int(c) & 0xFFFFFFFF for c in vcodes.cpu().numpy()] == [it["verify"] for it in items]
 
 
+@pytest.mark.parametrize("l", [128, 192, 256])
+def test_sigvfy_pipeline_of_signers_in_one_keyed_call(golden, l):
+    """the same pipeline with the signers as a SET: the fixture's distinct public keys once, an index per file, the keyed entry in the
+    place of the general one -- the ragged hash, the key validation (of the few keys) and the verification on one stream; the
+    reference's verdicts (tests/golden/sigvfy_pipeline.json)"""
+    import numpy as np
+    from bee2_amd import engine as E
+    eng = engine()
+    items = golden.sigvfy_pipeline[str(l)] * 30
+    msgs = [bytes.fromhex(it["msg"]) for it in items]
+    offs = np.zeros(len(msgs) + 1, dtype=np.int64)
+    np.cumsum([len(m) for m in msgs], out=offs[1:])
+    data = dev(b"".join(msgs) + bytes(16))
+    doff = torch.from_numpy(offs).cuda()
+    sigs = dev(b"".join(bytes.fromhex(it["sig"]) for it in items))
+    keys = sorted({bytes.fromhex(it["pubkey"]) for it in items})
+    kidx = torch.tensor([keys.index(bytes.fromhex(it["pubkey"])) for it in items], dtype=torch.int32).cuda()
+    n = len(items)
+    digests = torch.zeros(n * (l // 4), dtype=torch.uint8, device="cuda")
+    kcodes = torch.full((len(keys),), -1, dtype=torch.int32, device="cuda")
+    vcodes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    dkeys = dev(b"".join(keys))
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        eng.hash_ragged_dev(0 if l == 128 else l, data, doff, digests, n)
+        eng.bignPubkeyValL_batch_dev(l, dkeys, kcodes)                               # every signer once
+        eng.bignVerifyL_keyed_batch_dev(l, E.LEVEL_OID[l], digests, sigs, b"".join(keys), kidx, vcodes)
+    st.synchronize()
+    assert host(digests) == b"".join(bytes.fromhex(it["digest"]) for it in items)
+    kc = [int(c) & 0xFFFFFFFF for c in kcodes.cpu().numpy()]
+    assert [kc[keys.index(bytes.fromhex(it["pubkey"]))] for it in items] == [it["pubkey_val"] for it in items]
+    assert [int(c) & 0xFFFFFFFF for c in vcodes.cpu().numpy()] == [it["verify"] for it in items]
+
+
 @pytest.mark.parametrize("n", [32767, 32768 + 3, 256 * 1024 + 5])
 def test_ragged_belt_hash_many_short_messages_every_table_variant(orc, n):
     """The short-message belt-hash kernel switches table and workgroup shape with the batch size (4 KiB table /
