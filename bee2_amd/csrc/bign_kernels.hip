@@ -1855,16 +1855,26 @@ static err_t bign_key_tables(std::vector<std::shared_ptr<KeyTab>> &out, const ui
         // on the curve?  then the 2N + 1 starting points -- host threads when there are many keys
         std::vector<std::vector<uint8_t>> base(miss.size());
         std::vector<char> on_curve(miss.size(), 0);
+        std::atomic<int> threw{0};                     // (an exception must not leave a worker thread: bad_alloc in a resize)
         const auto work = [&](size_t from, size_t to) {
-            for (size_t i = from; i < to; ++i) on_curve[i] = onekey_base<N>(keys + 2 * NO * miss[i], base[i]) ? 1 : 0;
+            try {
+                for (size_t i = from; i < to; ++i) on_curve[i] = onekey_base<N>(keys + 2 * NO * miss[i], base[i]) ? 1 : 0;
+            } catch (...) { threw.store(1); }
         };
         const size_t nthr = std::min<size_t>(16, miss.size() / 4);
         if (nthr >= 2) {
             std::vector<std::thread> th;
             const size_t per = (miss.size() + nthr - 1) / nthr;
-            for (size_t t = 0; t < nthr; ++t) th.emplace_back(work, std::min(miss.size(), t * per), std::min(miss.size(), (t + 1) * per));
+            size_t started = 0;
+            try {
+                for (; started < nthr; ++started)
+                    th.emplace_back(work, std::min(miss.size(), started * per), std::min(miss.size(), (started + 1) * per));
+            } catch (...) {                            // no more threads to be had: the rest on this one
+                work(std::min(miss.size(), started * per), miss.size());
+            }
             for (auto &t : th) t.join();
         } else work(0, miss.size());
+        if (threw.load()) return ERR_OUTOFMEMORY;
         std::vector<size_t> good;
         for (size_t i = 0; i < miss.size(); ++i) if (on_curve[i]) good.push_back(i);
         if (!good.empty()) {
@@ -2015,7 +2025,7 @@ err_t launch_bign_verify_onekey(size_t l, const uint8_t *oid_der, size_t oid_len
         if (l == 128) return launch_bign_verify_onekey_t<8>(oid_der, oid_len, d_hashes, d_sigs, pubkey, 1, nullptr, n, d_codes, st);
         if (l == 192) return launch_bign_verify_onekey_t<12>(oid_der, oid_len, d_hashes, d_sigs, pubkey, 1, nullptr, n, d_codes, st);
         if (l == 256) return launch_bign_verify_onekey_t<16>(oid_der, oid_len, d_hashes, d_sigs, pubkey, 1, nullptr, n, d_codes, st);
-    } catch (const std::bad_alloc &) { return ERR_OUTOFMEMORY; }
+    } catch (...) { return ERR_OUTOFMEMORY; }               // (bad_alloc, a thread that could not be started: nothing may leave the C ABI)
     return ERR_BAD_PARAMS;
 }
 // n signatures of nkeys signers (pubkeys: HOST, nkeys x 2 NO octets; d_key_index: n x uint32 on the device)
@@ -2028,7 +2038,7 @@ err_t launch_bign_verify_keyed(size_t l, const uint8_t *oid_der, size_t oid_len,
         if (l == 128) return launch_bign_verify_onekey_t<8>(oid_der, oid_len, d_hashes, d_sigs, pubkeys, nkeys, d_key_index, n, d_codes, st);
         if (l == 192) return launch_bign_verify_onekey_t<12>(oid_der, oid_len, d_hashes, d_sigs, pubkeys, nkeys, d_key_index, n, d_codes, st);
         if (l == 256) return launch_bign_verify_onekey_t<16>(oid_der, oid_len, d_hashes, d_sigs, pubkeys, nkeys, d_key_index, n, d_codes, st);
-    } catch (const std::bad_alloc &) { return ERR_OUTOFMEMORY; }
+    } catch (...) { return ERR_OUTOFMEMORY; }               // (bad_alloc, a thread that could not be started: nothing may leave the C ABI)
     return ERR_BAD_PARAMS;
 }
 
