@@ -11,6 +11,12 @@ states (BASELINE.json configs[1]).  Batches are independent, so ranks shard by i
 no data-path collective ("weak" scaling: per-GPU work fixed); RCCL is used for the one
 parameter broadcast (key / ctr0) and for the max-over-ranks of the timed region.
 
+`value` is the WEAK reading (every rank the full BASELINE batch).  SURVEY.md 8e partitions a FIXED N ("GPU g of G takes
+items [g N/G, (g+1) N/G)"), so the line carries the STRONG reading beside it, flat in `roofline`:
+  N = 1   strong_pred_{2,4,8}_{bashF,ctr,verify,mixed} = t(BASELINE total on this GPU) / t(total / G on this GPU), every share
+          timed like the headline (hipEvents around K launches): what a G-way split of the fixed job can reach at best
+  N > 1   strong_speedup_{...} = rate of the N ranks over their shard_range(rank, N, total) shares / rank 0 alone on the total
+
 Rank 0 prints ONE JSON line.  `value` = perms/s summed over all ranks.  Extra objects:
   roofline      dominant kernel (bashF_batch_kernel): algorithmic bytes / avg launch time,
                 launch time measured inside this run with hipEvents on the launch stream
@@ -41,6 +47,7 @@ CTR_BYTES_PER_BLOCK = 32         # 16 read + 16 written per 16-byte block
 LDS_CTR_CEIL_GIBPS = 256 * 2.17e9 / (220 * 2 / 64) * 16 / 2 ** 30   # 220 ds_read_b32 per block (round 3: 55 G-boxes) = 6.875 LDS clocks per block per CU
 MADS_PER_VERIFY = 976 * 72 + 685 * 52 + 3000   # v_mad_u64_u32 per signature: affine table, shared inversion
 MAD_PEAK_T = 30.0                # measured: 256 CU x 4 SIMD x 64 lanes x 2.31 GHz / 5.05 cycles
+MAD_PEAK_GHZ = 2.31              # the shader clock of that micro-benchmark run (profiles/r01_valu_rates_ubench.txt)
 
 
 # VALU-issue picture: a wave64 full-rate op occupies its SIMD for 2 cycles, a half-rate op
@@ -117,6 +124,34 @@ def check_distinct_devices(ids, world, backend):
         raise SystemExit(f"[bench] {world} ranks on {distinct} distinct device(s) {sorted(set(ids))}: refusing to report "
                          f"n_gpus={world} (BEE2_BENCH_BACKEND=gloo runs the N-rank code path on fewer devices)")
     return distinct
+
+
+STRONG_TOTALS = {"bashF": 1 << 20, "ctr": 1 << 30, "verify": 1 << 18, "mixed": 1 << 24}   # BASELINE configs[1..4]: states, 16-byte blocks, signatures, messages
+STRONG_WAYS = (2, 4, 8)
+
+
+def strong_shares(total, ways=STRONG_WAYS):
+    """{G: items of rank 0's share} of a fixed job of `total` items split G ways by shard.shard_range"""
+    return {g: shard.shard_range(0, g, total)[1] for g in ways}
+
+
+def strong_pred(t_total_ms, t_share_ms):
+    """one-GPU PREDICTION of the G-way strong speedup: {G: t(total) / t(total / G)}, both times measured on this GPU"""
+    return {g: (t_total_ms / t if t else None) for g, t in t_share_ms.items()}
+
+
+def event_ms(fn, steps, warmup=2):
+    """average milliseconds per call of fn(): hipEvents on the launch stream around `steps` calls, after `warmup` untimed ones"""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
 
 
 WORKLOADS = ("bashF", "ctr", "verify", "sign", "mixed", "modes", "ragged", "dwp", "latency")
@@ -367,11 +402,63 @@ def host_api_rate(call, units, reps=3):
     dt = (time.perf_counter() - t0) / reps
     return units / dt, dt * 1e3
 
-def cpu_baseline(which, cores):
-    """Time the reference (or the oracle port) on `cores` host threads.  Returns dict."""
+def host_cpus():
+    """How many host threads this process may really use: os.cpu_count() is the machine, the affinity mask and the cgroup CPU
+    quota are this process's share of it.  threads = min of the three; all of them are reported."""
+    count = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = count
+    quota = None
+    try:                                                   # cgroup v2: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(per)
+    except Exception:
+        try:                                               # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    threads = max(1, min(count, aff, int(quota) if quota and quota >= 1 else count))
+    phys = None
+    try:                                                   # physical cores behind the logical ones (SMT siblings share an ALU)
+        pairs, cur = set(), {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif not line.strip() and cur:
+                pairs.add((cur.get("physical id"), cur.get("core id")))
+                cur = {}
+        phys = len(pairs) or None
+    except Exception:
+        pass
+    return {"cpu_count": count, "affinity": aff, "cgroup_quota_cpus": quota, "threads": threads, "physical_cores": phys}
+
+
+def spin_scaling(orc, threads):
+    """measured: total rate of `threads` threads each running a dependent 64-bit multiply-add chain / the rate of one thread
+    (oracle/orc_threads.c orc_spin_rate): how many cores' worth of cycles the box really gives this process"""
+    orc.lib.orc_spin_rate.restype = ctypes.c_double
+    orc.lib.orc_spin_rate(int(threads), ctypes.c_double(0.5))    # untimed: the pool's threads are created here, and freshly created
+    #                                                              threads take a few hundred ms to spread over the CPUs
+    r1 = orc.lib.orc_spin_rate(1, ctypes.c_double(0.4))
+    # best of three: the first pass after a single-thread phase can run with the woken threads still queued on one CPU
+    rt = max(orc.lib.orc_spin_rate(int(threads), ctypes.c_double(0.5)) for _ in range(3))
+    return rt / r1 if r1 else None
+
+
+def cpu_baseline(which, hc):
+    """Time the reference (or the oracle port) on one host thread and on hc["threads"] threads of the oracle's persistent pool,
+    every thread >= ~100 ms of work per timed pass (its slice repeated: orc_set_slice_reps).  Returns dict."""
     import orclib
     import refgen
     orc = orclib.load()
+    cores = hc["threads"]
     cpuflags = open("/proc/cpuinfo").read() if os.path.exists("/proc/cpuinfo") else ""
     have_avx512 = " avx512f" in cpuflags
     ref = None
@@ -384,10 +471,12 @@ def cpu_baseline(which, cores):
         variant = "bee2 BASH_AVX512" if path == refgen.REF_AVX512_SO else "bee2 BASH_64 / scalar C"
     fnptr = lambda name: ctypes.cast(getattr(ref, name), ctypes.c_void_p)  # noqa: E731
     H = orc.beltH()
-    out = {"cores": cores, "kind": kind, "impl": variant}
+    if "spin" not in hc:
+        hc["spin"] = spin_scaling(orc, cores)
+    out = {"cores": cores, "kind": kind, "impl": variant, "cpu_count": hc["cpu_count"], "affinity": hc["affinity"],
+           "cgroup_quota_cpus": hc["cgroup_quota_cpus"], "physical_cores": hc["physical_cores"], "spin_scaling": hc["spin"]}
 
     def clock(run, units, min_s=2.0, max_reps=64):
-        run()                                     # warm caches / lazy init
         reps, t0 = 0, time.perf_counter()
         while True:
             run()
@@ -395,6 +484,32 @@ def cpu_baseline(which, cores):
             dt = time.perf_counter() - t0
             if dt >= min_s or reps >= max_reps:
                 return units * reps / dt, reps
+
+    def both(run, n, min_s=4.0):
+        """run(threads) over n units -> (all-threads rate, single-thread rate, note).  A short untimed single-thread probe sizes
+        the slice repetitions so that a pass is >= ~100 ms per thread in both legs."""
+        orc.lib.orc_set_slice_reps(1)
+        run(1)                                             # warm caches / lazy init (the reference's curve object)
+        t0 = time.perf_counter()
+        run(1)
+        t_unit = (time.perf_counter() - t0) / n            # seconds per unit on one thread
+        reps1 = max(1, int(0.1 / max(t_unit * n, 1e-9)) + 1)
+        repsN = max(1, int(0.1 / max(t_unit * n / cores, 1e-9)) + 1)
+        try:
+            orc.lib.orc_set_slice_reps(reps1)
+            v1, _ = clock(lambda: run(1), n * reps1, min_s=1.0, max_reps=8)
+            orc.lib.orc_set_slice_reps(repsN)
+            run(cores)                                     # the pool's threads exist from here on
+            vall, passes = clock(lambda: run(cores), n * repsN, min_s=min_s)
+        finally:
+            orc.lib.orc_set_slice_reps(1)
+        scal = vall / v1
+        note = None
+        if scal < 0.7 * cores:
+            note = (f"{cores} threads give {scal:.1f}x one thread; a dependent-multiply spin loop on the same pool gives "
+                    f"{hc['spin']:.1f}x: that is what the box lets this process have (SMT siblings / shared vCPUs / clocks), "
+                    "not a property of the code")
+        return vall, v1, scal, f"{passes} timed passes, each thread its slice x {repsN} (>= 100 ms per thread per pass), persistent pool", note
 
     if which == "bashF":
         n = 1 << 20
@@ -405,17 +520,16 @@ def cpu_baseline(which, cores):
             run = lambda th: orc.lib.orc_drive_ref_bashF(fnptr("bashF"), p, ctypes.c_size_t(n), th)  # noqa: E731
         else:
             run = lambda th: orc.lib.orc_bashF_batch(p, ctypes.c_size_t(n), th)  # noqa: E731
-        v1, _ = clock(lambda: run(1), n)
-        vall, reps = clock(lambda: run(cores), n, min_s=4.0)
-        out.update(value=vall, unit="perms/s", single_thread=v1,
-                   sample=f"{reps} passes over the same 2^20-state batch, {cores} threads over disjoint slices")
+        vall, v1, scal, how, note = both(run, n)
+        out.update(value=vall, unit="perms/s", single_thread=v1, scaling_over_single_thread=scal,
+                   sample=f"the 2^20-state batch, {cores} threads over disjoint slices; {how}", scaling_note=note)
         if ref is not None and variant != "bee2 BASH_64 / scalar C":
             ref64 = ctypes.CDLL(refgen.REF_SO)
             f64 = ctypes.cast(ref64.bashF, ctypes.c_void_p)
-            v64, _ = clock(lambda: orc.lib.orc_drive_ref_bashF(f64, p, ctypes.c_size_t(n), cores), n)
-            v64_1, _ = clock(lambda: orc.lib.orc_drive_ref_bashF(f64, p, ctypes.c_size_t(n), 1), n)
+            v64, v64_1, s64, _, _ = both(lambda th: orc.lib.orc_drive_ref_bashF(f64, p, ctypes.c_size_t(n), th), n, min_s=2.0)
             out["bash64_all_cores"] = v64
             out["bash64_single_thread"] = v64_1
+            out["bash64_scaling_over_single_thread"] = s64
     elif which == "ctr":
         nbytes = 256 << 20
         buf = np.zeros(nbytes, dtype=np.uint8)
@@ -426,39 +540,79 @@ def cpu_baseline(which, cores):
             run = lambda th: orc.lib.orc_drive_ref_ctr(fnptr("beltCTRStepE"), p, ctypes.c_size_t(nb), kw, c0, ctypes.c_uint64(0), th)  # noqa: E731
         else:
             run = lambda th: orc.lib.orc_beltCTR_blocks(p, ctypes.c_size_t(nb), kw, c0, ctypes.c_uint64(0), th)  # noqa: E731
-        v1, _ = clock(lambda: run(1), nbytes / 2 ** 30, min_s=2.0, max_reps=2)
-        vall, reps = clock(lambda: run(cores), nbytes / 2 ** 30, min_s=4.0)
-        out.update(value=vall, unit="GiB/s", single_thread=v1,
-                   sample=f"{reps} passes over a 256 MiB prefix of the stream, {cores} threads")
+        # (the single-thread leg runs over a 16 MiB prefix: 256 MiB would be 1.3 s per pass)
+        nb1 = nb // 16
+        run1 = lambda th: (orc.lib.orc_drive_ref_ctr(fnptr("beltCTRStepE"), p, ctypes.c_size_t(nb1 if th == 1 else nb), kw, c0, ctypes.c_uint64(0), th)  # noqa: E731
+                           if ref is not None else orc.lib.orc_beltCTR_blocks(p, ctypes.c_size_t(nb1 if th == 1 else nb), kw, c0, ctypes.c_uint64(0), th))
+        orc.lib.orc_set_slice_reps(1)
+        run1(1)
+        v1, _ = clock(lambda: run1(1), nb1 * 16 / 2 ** 30, min_s=1.5, max_reps=16)
+        t_unit = 1.0 / (v1 * 2 ** 30 / 16)                 # seconds per block, one thread
+        repsN = max(1, int(0.1 / (t_unit * nb / cores)) + 1)
+        try:
+            orc.lib.orc_set_slice_reps(repsN)
+            run(cores)
+            vall, passes = clock(lambda: run(cores), nbytes * repsN / 2 ** 30, min_s=4.0)
+        finally:
+            orc.lib.orc_set_slice_reps(1)
+        scal = vall / v1
+        out.update(value=vall, unit="GiB/s", single_thread=v1, scaling_over_single_thread=scal,
+                   sample=f"{passes} timed passes over a 256 MiB prefix of the stream, {cores} threads, each its slice x {repsN}; one thread: a 16 MiB prefix",
+                   scaling_note=None if scal >= 0.7 * cores else f"{scal:.1f}x over one thread against {hc['spin']:.1f}x for a spin loop on the same pool")
     elif which == "verify":
         G = orclib.Golden()
         hs, ss, ps = G.bign_base_arrays()
-        n = len(hs) // 32
+        nbase = len(hs) // 32
+        tile = max(1, min(64, (cores * 64 + nbase - 1) // nbase))   # >= 64 signatures per thread: 2048 x tile
+        hs, ss, ps = hs * tile, ss * tile, ps * tile
+        n = nbase * tile
         codes = (ctypes.c_uint32 * n)()
         if ref is not None:
             ref.bign128Verify.restype = ctypes.c_uint32
-            run = lambda th: orc.lib.orc_drive_ref_verify(fnptr("bign128Verify"), hs, ss, ps, ctypes.c_size_t(n), codes, th)  # noqa: E731
+            run = lambda th: orc.lib.orc_drive_ref_verify(fnptr("bign128Verify"), hs, ss, ps, ctypes.c_size_t(n if th > 1 else 256), codes, th)  # noqa: E731
         else:
-            run = lambda th: orc.lib.orc_bign128Verify_batch(hs, ss, ps, ctypes.c_size_t(n), codes, th)  # noqa: E731
-        v1, _ = clock(lambda: orc.lib.orc_drive_ref_verify(fnptr("bign128Verify"), hs, ss, ps, ctypes.c_size_t(256), codes, 1)
-                      if ref is not None else orc.lib.orc_bign128Verify_batch(hs, ss, ps, ctypes.c_size_t(256), codes, 1),
-                      256, min_s=1.0, max_reps=8)
-        vall, reps = clock(lambda: run(cores), n, min_s=4.0)
+            run = lambda th: orc.lib.orc_bign128Verify_batch(hs, ss, ps, ctypes.c_size_t(n if th > 1 else 256), codes, th)  # noqa: E731
+        orc.lib.orc_set_slice_reps(1)
+        run(1)
+        v1, _ = clock(lambda: run(1), 256, min_s=1.0, max_reps=16)
+        repsN = max(1, int(0.1 / (n / cores / v1)) + 1)
+        try:
+            orc.lib.orc_set_slice_reps(repsN)
+            run(cores)
+            vall, passes = clock(lambda: run(cores), n * repsN, min_s=4.0)
+        finally:
+            orc.lib.orc_set_slice_reps(1)
         assert all(c == 0 for c in codes)
-        out.update(value=vall, unit="verifies/s", single_thread=v1,
-                   sample=f"{reps} passes over the 2048 genuine signatures of tests/golden/bign_base.bin, {cores} threads")
+        scal = vall / v1
+        out.update(value=vall, unit="verifies/s", single_thread=v1, scaling_over_single_thread=scal,
+                   sample=f"{passes} timed passes over the 2048 genuine signatures of tests/golden/bign_base.bin tiled x {tile}, {cores} threads, "
+                          f"each its slice x {repsN} (>= 100 ms per thread per pass); one thread: the first 256",
+                   scaling_note=None if scal >= 0.7 * cores else f"{scal:.1f}x over one thread against {hc['spin']:.1f}x for a spin loop on the same pool")
     elif which == "mixed":
-        n, ml = 1 << 12, 4096
+        ml = 4096
+        n = max(1 << 12, min(1 << 16, cores * 64))         # >= 64 messages per thread
         msgs = orc.fill(n * ml, 0x4D1C)
         dig = ctypes.create_string_buffer(64 * n)
         tag = ctypes.create_string_buffer(8 * n)
         key = H[128:160]
         if ref is not None:
-            run = lambda th: orc.lib.orc_drive_ref_mixed(fnptr("bashHash"), fnptr("beltMAC"), msgs, ctypes.c_size_t(ml), ctypes.c_size_t(n), key, ctypes.c_size_t(32), dig, tag, th)  # noqa: E731
+            run = lambda th: orc.lib.orc_drive_ref_mixed(fnptr("bashHash"), fnptr("beltMAC"), msgs, ctypes.c_size_t(ml), ctypes.c_size_t(n if th > 1 else 256), key, ctypes.c_size_t(32), dig, tag, th)  # noqa: E731
         else:
-            run = lambda th: orc.lib.orc_bash512_beltMAC_batch(msgs, ctypes.c_size_t(ml), ctypes.c_size_t(n), key, ctypes.c_size_t(32), dig, tag, th)  # noqa: E731
-        vall, reps = clock(lambda: run(cores), n, min_s=4.0)
-        out.update(value=vall, unit="messages/s", sample=f"{reps} passes over 2^12 x 4 KiB messages, {cores} threads")
+            run = lambda th: orc.lib.orc_bash512_beltMAC_batch(msgs, ctypes.c_size_t(ml), ctypes.c_size_t(n if th > 1 else 256), key, ctypes.c_size_t(32), dig, tag, th)  # noqa: E731
+        orc.lib.orc_set_slice_reps(1)
+        run(1)
+        v1, _ = clock(lambda: run(1), 256, min_s=1.0, max_reps=64)
+        repsN = max(1, int(0.1 / (n / cores / v1)) + 1)
+        try:
+            orc.lib.orc_set_slice_reps(repsN)
+            run(cores)
+            vall, passes = clock(lambda: run(cores), n * repsN, min_s=4.0)
+        finally:
+            orc.lib.orc_set_slice_reps(1)
+        scal = vall / v1
+        out.update(value=vall, unit="messages/s", single_thread=v1, scaling_over_single_thread=scal,
+                   sample=f"{passes} timed passes over {n} x 4 KiB messages, {cores} threads, each its slice x {repsN}; one thread: the first 256",
+                   scaling_note=None if scal >= 0.7 * cores else f"{scal:.1f}x over one thread against {hc['spin']:.1f}x for a spin loop on the same pool")
     return out
 
 
@@ -476,9 +630,15 @@ def main():
         me = f"mock:{mock.split(',')[dist.rank]}" if mock else f"cpu:{dist.local}"
         ids = dist.gather(me)
         distinct = check_distinct_devices(ids, dist.world, os.environ.get("BEE2_BENCH_MOCK_BACKEND", dist.backend))
+        # the strong split: every rank's shard_range share of each fixed BASELINE job, summed over the ranks, must be the job
+        covered = {w: int(dist.sum(float(shard.shard_range(dist.rank, dist.world, t)[1] - shard.shard_range(dist.rank, dist.world, t)[0])))
+                   for w, t in STRONG_TOTALS.items()}
         if dist.rank == 0:
             print(json.dumps({"metric": "launch selftest", "n_gpus": dist.world,
-                              "roofline": {"n_ranks_seen": seen, "n_devices_distinct": distinct},
+                              "roofline": {"n_ranks_seen": seen, "n_devices_distinct": distinct,
+                                           **{f"strong_items_{w}": c for w, c in covered.items()}},
+                              "strong_keys": [f"strong_speedup_{w}" for w in STRONG_TOTALS] if dist.world > 1
+                                             else [f"strong_pred_{g}_{w}" for g in STRONG_WAYS for w in STRONG_TOTALS],
                               "max_rank": int(slowest), "backend": dist.backend, "only": args.only}))
         dist.close()
         return
@@ -491,7 +651,8 @@ def main():
     n_distinct = check_distinct_devices(dev_ids, N, dist.backend)     # RCCL: N ranks on fewer than N GPUs is an error
     diag = {}                                                          # N > 1 self-explanation, flat scalars (rank 0 prints)
     do_cpu = (not args.no_cpu) and dist.rank == 0 and N == 1
-    cores = os.cpu_count() or 1
+    hc = host_cpus()                           # cpu_count / affinity / cgroup quota: threads = what this process may really use
+    cores = hc["threads"]
     H = eng.beltH()
 
     # the only cross-GPU payload: expanded key (32 B) + ctr0 (16 B), broadcast once over RCCL
@@ -505,6 +666,29 @@ def main():
     result = {}
     others = {}
     rates = {}
+    strong = {}                                # the fixed-N (strong) reading of SURVEY 8e, flat scalars for `roofline`
+
+    def strong_leg(name, total, unit_fn, steps, to_value=1.0, t_total_ms=None):
+        """The FIXED job of `total` items (BASELINE's size) split by shard.shard_range.  unit_fn(lo, hi) returns the step over
+        items [lo, hi) of the resident job.  N = 1: time rank 0's share of a 2- / 4- / 8-way split on this GPU, like the headline
+        (hipEvents around `steps` launches) -> strong_pred_G_<name> = t(total) / t(total / G).  N > 1: every rank its own
+        share between barriers -> strong_value_<name> (whole job, in the metric's unit) and strong_speedup_<name> = rank 0
+        alone on the total / the N ranks on their shares."""
+        if N == 1:
+            t_tot = t_total_ms if t_total_ms is not None else event_ms(unit_fn(0, total), steps)
+            t_sh = {g: event_ms(unit_fn(0, m), steps) for g, m in strong_shares(total).items()}
+            for g, v in strong_pred(t_tot, t_sh).items():
+                strong[f"strong_pred_{g}_{name}"] = v
+            strong[f"strong_ms_total_{name}"] = t_tot
+            for g, t in t_sh.items():
+                strong[f"strong_ms_share{g}_{name}"] = t
+        else:
+            lo, hi = shard.shard_range(dist.rank, N, total)
+            solo = solo_timed(dist, steps, 2, unit_fn(0, total))          # rank 0 alone on the WHOLE job
+            el_s = timed(dist, steps, 2, unit_fn(lo, hi))                 # every rank its share, max over ranks
+            strong[f"strong_value_{name}"] = total * steps / el_s * to_value
+            strong[f"strong_solo_value_{name}"] = total * steps / solo * to_value
+            strong[f"strong_speedup_{name}"] = solo / el_s
 
     # ---------------------------------------------------------------- bashF (headline)
     if "bashF" in only:
@@ -532,7 +716,9 @@ def main():
             "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "bashF batch: 2^20 independent 192-byte sponge states per GPU (BASELINE configs[1])",
-                       "states_per_gpu": n, "parallelism": f"dp{N} (index-sharded, no data-path collective)"},
+                       "states_per_gpu": n, "parallelism": f"dp{N} (index-sharded, no data-path collective); `value` is the WEAK reading: every rank runs the full "
+                                      "BASELINE batch; the fixed-N (strong) split of SURVEY 8e is roofline.strong_pred_* (N = 1: one-GPU prediction) "
+                                      "/ roofline.strong_speedup_* (N > 1: measured)"},
             "roofline": {"kernel": "bashF_tile_kernel<0, 2, 124, 6, 3>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": ms_launch, "algorithmic_bytes_per_launch": BASHF_BYTES * n,
@@ -550,6 +736,9 @@ def main():
             diag["solo_value"] = n * K / solo_el
             diag["weak_efficiency"] = value / (N * diag["solo_value"])
         rates["bashF_perms_per_s"] = n / (ms_launch * 1e-3)      # per GPU, kernel time: what the mixed roofline's parts use
+        if not args.headline_only:
+            strong_leg("bashF", n, lambda lo, hi: (lambda: eng.bashF_batch_dev(st[192 * lo: 192 * hi])), K,
+                       t_total_ms=ms_launch if N == 1 else None)
         # the same kernel on a batch that cannot sit in the 256 MiB Infinity Cache: 2^22 states = 768 MiB read + written
         # per launch; reported as flat keys next to the cache-resident headline
         if not args.headline_only:
@@ -569,7 +758,7 @@ def main():
                                   "note": "host pointers, PCIe both ways inside the call; 1 GPU; not `value`"}
             del host
         if do_cpu:
-            result["cpu_baseline"] = cpu_baseline("bashF", cores)
+            result["cpu_baseline"] = cpu_baseline("bashF", hc)
         del st
 
     # ------------------------------------------------------------------------ beltCTR
@@ -601,6 +790,10 @@ def main():
                          "valu": valu_picture(nb / (ms_launch * 1e-3), CTR_VALU)},
         }
         rates["belt_blocks_per_s"] = nb / (ms_launch * 1e-3)       # per GPU, kernel time
+        if not args.headline_only:
+            # the fixed job: ONE stream of nb blocks; rank r encrypts blocks [lo, hi) with first_block = lo (no state passes between ranks)
+            strong_leg("ctr", nb, lambda lo, hi: (lambda: eng.beltCTR_blocks_dev(buf[16 * lo: 16 * hi], kw, c0, lo)), kc,
+                       to_value=16 / 2 ** 30, t_total_ms=ms_launch if N == 1 else None)
         if dist.rank == 0 and N == 1 and not args.headline_only:       # PCIe-inclusive rate: single-GPU runs only
             hn = 1 << 30                                          # 1 GiB through the drop-in one-shot beltCTR
             host = np.zeros(hn, dtype=np.uint8)
@@ -613,7 +806,7 @@ def main():
                                              "note": "host pointers, PCIe both ways inside the call; 1 GPU; not `value`"}
             del host
         if do_cpu:
-            others["beltCTR"]["cpu_baseline"] = cpu_baseline("ctr", cores)
+            others["beltCTR"]["cpu_baseline"] = cpu_baseline("ctr", hc)
         del buf
 
     # ------------------------------------------------------------------------- verify
@@ -656,6 +849,16 @@ def main():
                                  "v_mad_u64_u32 micro-benchmark (profiles/r01_valu_rates_ubench.txt); every mad is "
                                  "paired with a half-rate v_addc_co_u32, so 0.5 is the practical ceiling"},
         }
+        # MAD_PEAK_T is one micro-benchmark at 2.31 GHz; the verification kernels run at whatever the box gives under THEM (VERDICT r04
+        # weak 11): the shader clock beside bign_main_kernel, and the fraction against the multiplier rate at that clock
+        try:
+            ghz_v, _ = shader_clock_under(lambda: eng.bign128Verify_batch_dev(dh, ds, dk, codes), ms_launch)
+        except Exception:
+            ghz_v = None
+        rv = others["bignVerify"]["roofline"]
+        rv["shader_clock_ghz_under_kernels"] = ghz_v
+        rv["peak_at_measured_clock"] = MAD_PEAK_T * ghz_v / MAD_PEAK_GHZ if ghz_v else None
+        rv["frac_at_measured_clock"] = rv["achieved"] / rv["peak_at_measured_clock"] if ghz_v else None
         if dist.rank == 0:
             # the latency floor: prefixes of the same device-resident batch; up to 2^15 signatures run
             # one per DPP quad, up to 2^16 on 29-bit limbs, above on 32-bit limbs (profiles/r02_verify_small.txt)
@@ -675,6 +878,9 @@ def main():
                 ms_b = e0.elapsed_time(e1) / 20
                 small[f"2^{e}"] = {"ms_per_batch": ms_b, "verifies_per_s": m / (ms_b * 1e-3)}
             others["bignVerify"]["batch_size_sweep"] = small
+        strong_leg("verify", n, lambda lo, hi: (lambda: eng.bign128Verify_batch_dev(dh[32 * lo: 32 * hi], ds[48 * lo: 48 * hi],
+                                                                                     dk[64 * lo: 64 * hi], codes[lo: hi])), kv,
+                   t_total_ms=ms_launch if N == 1 else None)
         if dist.rank == 0 and N == 1:       # PCIe-inclusive rate: single-GPU runs only
             hcodes = np.empty(n, dtype=np.uint32)
             prm = eng.bignParamsStd("1.2.112.0.2.0.34.101.45.3.1")
@@ -688,7 +894,7 @@ def main():
                                                 "ms_per_call": ms, "same_verdicts": bool((hcodes == got.astype(np.uint32)).all()),
                                                 "note": "host pointers, PCIe both ways inside the call; 1 GPU; not `value`"}
         if do_cpu:
-            others["bignVerify"]["cpu_baseline"] = cpu_baseline("verify", cores)
+            others["bignVerify"]["cpu_baseline"] = cpu_baseline("verify", hc)
         # the step `sig vfy` runs before each verification: bign128PubkeyVal over the same keys (tiled 64x more: 1 GiB, beyond the 256 MiB MALL)
         kk = dk.repeat(64)
         nk = kk.numel() // 64
@@ -920,8 +1126,7 @@ def main():
                     cnt += 1
                 others["bignSign2"]["cpu_baseline"] = {
                     "value": cnt / (time.perf_counter() - t0), "unit": "signatures/s", "cores": 1, "kind": "reference",
-                    "sample": "3 s of bign128Sign2 calls on 512 of the same (hash, key) pairs, one thread "
-                              "(bee2's process-global curve object serialises threads, as for verification)"}
+                    "sample": "3 s of bign128Sign2 calls on 512 of the same (hash, key) pairs, one thread"}
         del privs, hsh, sigs, pubs, sc, vc
 
     # ------------------------------------------- single-call latency of the drop-in entry points (host pointers)
@@ -984,30 +1189,24 @@ def main():
 
     # -------------------------------------------------------------------------- mixed
     if "mixed" in only:
-        n, ml = 1 << 21, 4096                                      # 2^24 / 8 messages per GPU
+        n, ml = 1 << 21, 4096                                      # the weak leg: 2^24 / 8 messages per GPU
+        # the FIXED job of configs[4]: 2^24 x 4 KiB = 64 GiB, resident on this card when it fits (288 GB: four times over); the weak
+        # leg runs over its first 2^21 messages, the whole job is `bash512_beltMAC_2p24` and the total of the strong split
+        n_all = STRONG_TOTALS["mixed"]
         free, _ = torch.cuda.mem_get_info()
-        while n * ml + (1 << 30) > free and n > 1024:
-            n //= 2
-        msgs = torch.empty(n * ml, dtype=torch.uint8, device="cuda")
+        while n_all * (ml + 72) + (2 << 30) > free and n_all > 1024:
+            n_all //= 2
+        n = min(n, n_all)
+        msgs = torch.empty(n_all * ml, dtype=torch.uint8, device="cuda")
         fill_seeded(msgs, 0x4D1C + dist.rank)
-        dig = torch.empty(n * 64, dtype=torch.uint8, device="cuda")
-        tag = torch.empty(n * 8, dtype=torch.uint8, device="cuda")
+        dig_all = torch.empty(n_all * 64, dtype=torch.uint8, device="cuda")
+        tag_all = torch.empty(n_all * 8, dtype=torch.uint8, device="cuda")
+        dig, tag = dig_all[: n * 64], tag_all[: n * 8]
         km = max(2, min(K, 5))
-        el = timed(dist, km, 1, lambda: eng.bashHash_beltMAC_batch_dev(msgs, ml, 256, H[128:160], dig, tag))
+        mixed_unit = lambda lo, hi: (lambda: eng.bashHash_beltMAC_batch_dev(msgs[ml * lo: ml * hi], ml, 256, H[128:160],  # noqa: E731
+                                                                             dig_all[64 * lo: 64 * hi], tag_all[8 * lo: 8 * hi]))
+        el = timed(dist, km, 1, mixed_unit(0, n))
         ms_mixed = timed.event_ms
-        # the two parts on this GPU in this run: taken from the bashF / beltCTR legs above, or (--only mixed) short legs here
-        src = "the bashF and beltCTR legs of this run (kernel time, per GPU)"
-        if "bashF_perms_per_s" not in rates or "belt_blocks_per_s" not in rates:
-            src = "short bashF (2^20 states) and beltCTR (1 GiB) legs run for this roofline (kernel time, per GPU)"
-            if "bashF_perms_per_s" not in rates:
-                stp = msgs[: 192 << 20]
-                timed(dist, 20, 3, lambda: eng.bashF_batch_dev(stp))
-                rates["bashF_perms_per_s"] = (1 << 20) / (timed.event_ms * 1e-3)
-            if "belt_blocks_per_s" not in rates:
-                cb_ = msgs[: 1 << 30] if msgs.numel() >= (1 << 30) else msgs
-                timed(dist, 3, 1, lambda: eng.beltCTR_blocks_dev(cb_, kw, c0, 0))
-                rates["belt_blocks_per_s"] = (cb_.numel() // 16) / (timed.event_ms * 1e-3)
-            fill_seeded(msgs, 0x4D1C + dist.rank)                  # (the short legs ran in place over the messages)
         others["bash512_beltMAC"] = {
             "metric": "bash512+beltMAC messages/s", "value": N * n * km / el, "unit": "messages/s", "steps": km,
             "ms_per_step": el / km * 1e3, "GiB_per_s": N * n * ml * km / el / 2 ** 30,
@@ -1016,9 +1215,21 @@ def main():
                              kernel="hash_mac_fused_kernel<8, true, true, BeltTabWide>", avg_launch_ms=ms_mixed,
                              hbm_frac=(4096 + 72) * n / (ms_mixed * 1e-3) / 1e9 / HBM_PEAK_GBS),
         }
+        if n_all > n:
+            ks_ = max(2, min(K, 3))
+            if N == 1:
+                t_all = event_ms(mixed_unit(0, n_all), ks_, warmup=1)
+                others["bash512_beltMAC_2p24"] = {
+                    "metric": "bash512+beltMAC messages/s, the whole configs[4] job on ONE GPU", "value": n_all / (t_all * 1e-3),
+                    "unit": "messages/s", "steps": ks_, "ms_per_step": t_all, "GiB_per_s": n_all * ml / (t_all * 1e-3) / 2 ** 30,
+                    "config": {"workload": f"bash512 + beltMAC over {n_all} x 4 KiB messages = {n_all * ml / 2**30:.0f} GiB resident on one GPU, "
+                                           "ONE bee2hip_bashHash_beltMAC_batch_dev call per step (BASELINE configs[4], the N = 1 point)"}}
+                strong_leg("mixed", n_all, mixed_unit, ks_, t_total_ms=t_all)
+            else:
+                strong_leg("mixed", n_all, mixed_unit, ks_)
         if do_cpu:
-            others["bash512_beltMAC"]["cpu_baseline"] = cpu_baseline("mixed", cores)
-        del msgs, dig, tag
+            others["bash512_beltMAC"]["cpu_baseline"] = cpu_baseline("mixed", hc)
+        del msgs, dig, tag, dig_all, tag_all
 
     # ------------------------------------------------- 8f-3: ragged hash batches (bsum front-end)
     if "ragged" in only:
@@ -1268,15 +1479,19 @@ def main():
         if "cpu_baseline" in o:
             cb["beltCTR_GiBps"] = o["cpu_baseline"]["value"]
             cb["beltCTR_GiBps_single_thread"] = o["cpu_baseline"].get("single_thread")
+            cb["beltCTR_scaling_over_single_thread"] = o["cpu_baseline"].get("scaling_over_single_thread")
     o = others.get("bignVerify")
     if o:
         flat["bignVerify_sigs_per_s"] = o["value"]
         flat["bignVerify_frac"] = o["roofline"]["frac"]
         late["bignVerify_ms"] = o["roofline"]["avg_batch_ms"]
+        late["bignVerify_clock_ghz"] = o["roofline"].get("shader_clock_ghz_under_kernels")
+        late["bignVerify_frac_at_clock"] = o["roofline"].get("frac_at_measured_clock")
         late["bignVerify_verdicts_ok"] = o["verdicts_as_expected"]
         if "cpu_baseline" in o:
             cb["bignVerify_sigs_per_s"] = o["cpu_baseline"]["value"]
             cb["bignVerify_sigs_per_s_single_thread"] = o["cpu_baseline"].get("single_thread")
+            cb["bignVerify_scaling_over_single_thread"] = o["cpu_baseline"].get("scaling_over_single_thread")
     o = others.get("bash512_beltMAC")
     if o:
         flat["mixed_msgs_per_s"] = o["value"]
@@ -1285,14 +1500,29 @@ def main():
         late["mixed_overlap_got"] = o["roofline"]["overlap_got"]
         if "cpu_baseline" in o:
             cb["mixed_msgs_per_s"] = o["cpu_baseline"]["value"]
+            cb["mixed_msgs_per_s_single_thread"] = o["cpu_baseline"].get("single_thread")
+            cb["mixed_scaling_over_single_thread"] = o["cpu_baseline"].get("scaling_over_single_thread")
     o = others.get("bignSign2")
     if o:
         late["bignSign2_sigs_per_s"] = o["value"]
         late["bignSign2_frac"] = o["roofline"]["frac"]
+    # the strong (fixed-N) reading, SURVEY 8e: predictions from one GPU at N = 1, measured speedups at N > 1 -- the 8-way keys first
+    strong_order = ([f"strong_pred_8_{w}" for w in ("bashF", "ctr", "verify", "mixed")] if N == 1
+                    else [f"strong_speedup_{w}" for w in ("bashF", "ctr", "verify", "mixed")])
+    for k in strong_order:                # (always present, None when the workload was not run: the key order is part of the contract)
+        flat[k] = strong.get(k)
+    if cb.get("kind") is not None:       # scalars the record must keep first (the driver keeps ~24 entries, strings cut at 120 characters)
+        first = ("value", "unit", "cores", "kind", "sample", "single_thread", "scaling_over_single_thread", "spin_scaling", "cpu_count",
+                 "affinity", "cgroup_quota_cpus")
+        mid = [k for k in cb if k.startswith(("beltCTR_", "bignVerify_", "mixed_"))]
+        ordered = {k: cb.get(k) for k in first}
+        ordered.update({k: cb[k] for k in mid})
+        ordered.update({k: v for k, v in cb.items() if k not in ordered})
+        cb = result["cpu_baseline"] = ordered
     flat["n_ranks_seen"] = int(dist.sum(1.0))
     flat["n_devices_distinct"] = n_distinct
     # N > 1: the line explains itself -- rank 0 alone beforehand, each rank's own rate, clocks
-    for k in ("weak_efficiency", "solo_value", "per_rank_value_min", "per_rank_value_max", "clock_ghz_min", "clock_ghz_max"):
+    for k in ("weak_efficiency", "solo_value", "clock_ghz_min", "clock_ghz_max", "per_rank_value_min", "per_rank_value_max"):
         flat[k] = diag.get(k)
     flat["avg_launch_ms"] = rf0.get("avg_launch_ms", rf0.get("avg_batch_ms"))
     flat["kernel"] = rf0.get("kernel", rf0.get("kernels"))
@@ -1300,6 +1530,8 @@ def main():
     flat["n_devices_visible"] = dist.ndev
     for k in ("per_rank_kernel_rate_min", "per_rank_kernel_rate_max"):
         flat[k] = diag.get(k)
+    for k, v in strong.items():          # the rest of the strong-split record (2- / 4-way predictions, the times behind them, N > 1 rates)
+        flat.setdefault(k, v)
     rest = {}
     for k, v in rf0.items():              # what is left of the headline kernel's own object: scalars stay, prose / nested move out
         if k in flat:
@@ -1312,7 +1544,7 @@ def main():
         others.setdefault("headline_detail", {}).update(rest)
     result["roofline"] = flat
     result["others"] = others
-    result["host"] = {"cpu_count": cores, "device": torch.cuda.get_device_name(torch.cuda.current_device()),
+    result["host"] = {"cpu_count": hc["cpu_count"], "cpus": hc, "device": torch.cuda.get_device_name(torch.cuda.current_device()),
                       "engine": eng.version()}
     if dist.rank == 0:
         print(json.dumps(result))

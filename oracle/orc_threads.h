@@ -1,7 +1,8 @@
 /*
  * orc_threads.h -- TEST INFRASTRUCTURE (see oracle.h).
- * Minimal pthread "parallel for" so the CPU baseline can be timed on 1 thread
- * and on all host cores over disjoint slices of the same batch.
+ * "parallel for" over a PERSISTENT pool of pthreads (orc_threads.c), so that the CPU baseline can be timed on 1 thread and
+ * on all the host cores this process may use, over disjoint slices of the same batch, without paying a
+ * pthread_create / join per thread per pass (256 spawns around 1.4 ms of work each).
  */
 #ifndef BEE2_AMD_ORC_THREADS_H
 #define BEE2_AMD_ORC_THREADS_H
@@ -10,40 +11,16 @@
 
 typedef void (*orc_range_fn)(void *ctx, size_t lo, size_t hi);
 
-typedef struct {
-    orc_range_fn fn;
-    void *ctx;
-    size_t lo, hi;
-} orc_slice;
+/* fn(ctx, lo, hi) over [0, n) cut into `nthreads` contiguous slices, one per pool thread (the caller runs slice 0 itself);
+   returns when every slice is done.  nthreads <= 1: the caller runs [0, n) inline.  Not re-entrant: one job at a time
+   (concurrent callers are serialised). */
+void orc_parallel_for(size_t n, int nthreads, orc_range_fn fn, void *ctx);
 
-static void *orc_slice_main(void *p)
-{
-    orc_slice *s = (orc_slice *)p;
-    s->fn(s->ctx, s->lo, s->hi);
-    return 0;
-}
+/* bench only: from now on every slice of a job is run `reps` times back to back by its thread (default 1), so that a timed
+   pass gives each thread >= tens of milliseconds of work whatever the batch size (in-place work simply iterates) */
+void orc_set_slice_reps(int reps);
 
-static inline void orc_parallel_for(size_t n, int nthreads, orc_range_fn fn, void *ctx)
-{
-    if (nthreads <= 1 || n < 2) { fn(ctx, 0, n); return; }
-    if (nthreads > 256) nthreads = 256;
-    pthread_t tid[256];
-    orc_slice sl[256];
-    int started = 0;
-    for (int t = 0; t < nthreads; ++t) {
-        sl[t].fn = fn; sl[t].ctx = ctx;
-        sl[t].lo = n * (size_t)t / (size_t)nthreads;
-        sl[t].hi = n * (size_t)(t + 1) / (size_t)nthreads;
-        if (pthread_create(&tid[t], 0, orc_slice_main, &sl[t]) != 0) {
-            /* could not spawn: run the slice inline */
-            fn(ctx, sl[t].lo, sl[t].hi);
-            tid[t] = 0;
-            continue;
-        }
-        ++started;
-    }
-    (void)started;
-    for (int t = 0; t < nthreads; ++t)
-        if (tid[t]) pthread_join(tid[t], 0);
-}
+/* how many threads' worth of cycles this process gets: `nthreads` pool threads each run a dependent integer chain for about
+   `seconds`; returns the total iterations per second (compare with the value for nthreads = 1) */
+double orc_spin_rate(int nthreads, double seconds);
 #endif

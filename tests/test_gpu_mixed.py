@@ -78,6 +78,49 @@ def test_mixed_per_gpu_share_of_config4(orc, golden):
     assert torch.equal(dig, d1) and torch.equal(tag, t1)
 
 
+def test_config4_whole_job_on_one_gpu(orc, golden):
+    """BASELINE.json configs[4] as ONE job: 2^24 x 4 KiB = 64 GiB resident on one card, one
+    bee2hip_bashHash_beltMAC_batch_dev call (the reference's per-message loop: bash_hash.c:38-137, belt_mac.c:47-203;
+    VERDICT r04 item 4).  The byte offsets of the messages pass 2^32, 2^35 and end at 2^36: windows of 2^12 messages at the
+    start, either side of bytes 2^32 and 2^35 and at the end are compared with the oracle, the outputs in between are checked to have
+    been written, and a guard behind each output array must survive."""
+    import os
+    eng = engine()
+    n, msg_len, W = 1 << 24, 4096, 1 << 12
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 << 30:
+        pytest.skip("needs 80 GiB of free HBM")
+    key = golden.H[128:160]
+    msgs = torch.empty(n * msg_len, dtype=torch.uint8, device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x4D1C)
+    for lo in range(0, n * msg_len, 1 << 33):                       # (8 GiB at a time: the generator's counter)
+        msgs[lo: lo + (1 << 33)].view(torch.int64).random_(generator=g)
+    GUARD = 4096
+    dig = torch.full((n * 64 + GUARD,), 0xA5, dtype=torch.uint8, device="cuda")
+    tag = torch.full((n * 8 + GUARD,), 0x5A, dtype=torch.uint8, device="cuda")
+    eng.bashHash_beltMAC_batch_dev(msgs, msg_len, 256, key, dig[: n * 64], tag[: n * 8], n=n)
+    torch.cuda.synchronize()
+    assert bool((dig[n * 64:] == 0xA5).all()) and bool((tag[n * 8:] == 0x5A).all()), "wrote behind the outputs"
+    threads = len(os.sched_getaffinity(0))
+    windows = [0, (1 << 20) - W // 2, (1 << 23) - W // 2, n - W]     # message 2^20 starts at byte 2^32, message 2^23 at byte 2^35
+    for lo in windows:
+        m = host(msgs[lo * msg_len:(lo + W) * msg_len])
+        wd, wt = orc.mixed_batch(m, msg_len, key, nthreads=threads)
+        assert host(dig[64 * lo: 64 * (lo + W)]) == wd, f"digests of messages {lo}..{lo + W}"
+        assert host(tag[8 * lo: 8 * (lo + W)]) == wt, f"tags of messages {lo}..{lo + W}"
+    # every message got outputs: no 64-byte digest / 8-byte tag still holds the fill pattern (probability 2^-64 per tag otherwise)
+    assert not bool((dig[: n * 64].view(n, 64) == 0xA5).all(dim=1).any())
+    assert not bool((tag[: n * 8].view(n, 8) == 0x5A).all(dim=1).any())
+    # and the windows agree with a second, separate call over just that window (the kernel's indexing does not depend on the batch)
+    for lo in windows[1:]:
+        d2 = torch.empty(W * 64, dtype=torch.uint8, device="cuda")
+        t2 = torch.empty(W * 8, dtype=torch.uint8, device="cuda")
+        eng.bashHash_beltMAC_batch_dev(msgs[lo * msg_len:(lo + W) * msg_len], msg_len, 256, key, d2, t2, n=W)
+        torch.cuda.synchronize()
+        assert torch.equal(d2, dig[64 * lo: 64 * (lo + W)]) and torch.equal(t2, tag[8 * lo: 8 * (lo + W)])
+
+
 def test_ragged_hash_batches(orc, golden):
     """messages of different lengths in one launch, vs the oracle and the golden set"""
     import random

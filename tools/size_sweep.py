@@ -8,7 +8,7 @@ import bee2_amd, goldenlib
 eng = bee2_amd.load_experiments(); eng.set_device(0)
 G = goldenlib.Golden(); H = eng.beltH()
 print("bashF: states  us/launch  Gperm/s  TB/s")
-for e in range(12, 25, 2):
+for e in (12, 14, 16, 17, 18, 19, 20, 22, 24):
     n = 1 << e
     st = torch.empty(192 * n, dtype=torch.uint8, device="cuda"); st.view(torch.int64).random_()
     for _ in range(5): eng.time_kernel(0, 20, st, n=n)
