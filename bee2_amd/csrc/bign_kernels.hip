@@ -1765,9 +1765,18 @@ static bool onekey_base(const uint8_t *pubkey, std::vector<uint8_t> &base)
 // process are kept (a table is 278 KiB .. 1 MiB: the card holds as many as anybody wants, the limit only bounds the scan).
 // A launcher holds a reference while it queues its kernels; the table is freed when the last reference goes, and hipFree
 // waits for the device, so a kernel already queued never loses its table.
-struct KeySlab {                       // the tables of the keys one call met for the first time, in one device allocation
+// (round 5) A slab holds at most KEYSLAB_KEYS tables, so ONE busy key pins at most that many (4.4 - 16 MiB), and the
+// cache is bounded in BYTES as well (KEYTAB_BYTES_MAX of live slabs): before a new slab is allocated the least recently used
+// entries go until there is room, and when hipMalloc still refuses, every entry nobody holds goes and the allocation is tried
+// once more.  Keys that end up without a table are verified by the paths that need none (one signer: the general pipeline;
+// several: the complete-formula kernel) -- slower, same verdicts, no error.
+constexpr size_t KEYSLAB_KEYS = 16;
+constexpr size_t KEYTAB_BYTES_MAX = (size_t)8 << 30;
+static std::atomic<size_t> g_keyslab_bytes{0};
+struct KeySlab {                       // tables of keys one call met for the first time, in one device allocation
     void *p = nullptr;
-    ~KeySlab() { if (p) (void)hipFree(p); }
+    size_t bytes = 0;
+    ~KeySlab() { if (p) { (void)hipFree(p); g_keyslab_bytes.fetch_sub(bytes); } }
 };
 struct KeyTab {
     std::shared_ptr<KeySlab> slab;     // (freed with the last of its tables)
@@ -1803,7 +1812,9 @@ static err_t bign_key_table16_locked(KeyTab &k, hipStream_t st)
     if (g_keytab16_live.load() >= KEYTAB16_MAX) return ERR_OK;                                                        // enough busy keys already
     if (hipMalloc((void **)&t16, (size_t)N * 65536 * pt) != hipSuccess) { (void)hipGetLastError(); return ERR_OK; }   // no room: the 8-bit table serves
     hipLaunchKernelGGL(bign_gtable16_kernel<N>, dim3(N * 65536 / 256), dim3(256), 0, st, k.tab, t16);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(t16); return hip_fail(hipGetLastError(), "bign_gtable16_kernel (key)"); }
+    hipError_t e16 = hipGetLastError();
+    if (e16 == hipSuccess) e16 = hipStreamSynchronize(st);
+    if (e16 != hipSuccess) { (void)hipFree(t16); return hip_fail(e16, "bign_gtable16_kernel (key)"); }
     k.tab16 = t16;
     g_keytab16_live.fetch_add(1);
     return ERR_OK;
@@ -1877,15 +1888,36 @@ static err_t bign_key_tables(std::vector<std::shared_ptr<KeyTab>> &out, const ui
         if (threw.load()) return ERR_OUTOFMEMORY;
         std::vector<size_t> good;
         for (size_t i = 0; i < miss.size(); ++i) if (on_curve[i]) good.push_back(i);
-        if (!good.empty()) {
-            const size_t M = good.size();
+        const auto evict_lru = [&]() -> bool {                  // the least recently used entry leaves the cache (freed when its last user lets go)
+            if (g_keytabs.empty()) return false;
+            auto old = g_keytabs.begin();
+            for (auto it = g_keytabs.begin(); it != g_keytabs.end(); ++it) if (it->second->stamp < old->second->stamp) old = it;
+            g_keytabs.erase(old);
+            return true;
+        };
+        for (size_t g0 = 0; g0 < good.size(); g0 += KEYSLAB_KEYS) {
+            const size_t M = std::min(KEYSLAB_KEYS, good.size() - g0);
+            const size_t need = M * (TAB + AUX);
+            while (g_keyslab_bytes.load() + need > KEYTAB_BYTES_MAX && evict_lru()) {}
             auto slab = std::make_shared<KeySlab>();
-            if (hipMalloc(&slab->p, M * (TAB + AUX)) != hipSuccess) { (void)hipGetLastError(); slab->p = nullptr; return ERR_OUTOFMEMORY; }
+            if (hipMalloc(&slab->p, need) != hipSuccess) {
+                (void)hipGetLastError();
+                slab->p = nullptr;
+                // no room on the device: everything nobody is using right now goes, then one more try
+                for (auto it = g_keytabs.begin(); it != g_keytabs.end();) it = it->second.use_count() == 1 ? g_keytabs.erase(it) : std::next(it);
+                if (hipMalloc(&slab->p, need) != hipSuccess) {
+                    (void)hipGetLastError();
+                    slab->p = nullptr;
+                    break;                                      // the remaining keys stay without a table: out[] = null, the callers' table-free paths
+                }
+            }
+            slab->bytes = need;
+            g_keyslab_bytes.fetch_add(need);
             uint8_t *d_tabs = reinterpret_cast<uint8_t *>(slab->p), *d_aux = d_tabs + M * TAB;
             std::vector<uint8_t> aux(M * AUX);
             for (size_t j = 0; j < M; ++j) {
-                memcpy(aux.data() + j * AUX, keys + 2 * NO * miss[good[j]], 2 * NO);
-                memcpy(aux.data() + j * AUX + 2 * NO, base[good[j]].data(), AUX - 2 * NO);
+                memcpy(aux.data() + j * AUX, keys + 2 * NO * miss[good[g0 + j]], 2 * NO);
+                memcpy(aux.data() + j * AUX + 2 * NO, base[good[g0 + j]].data(), AUX - 2 * NO);
             }
             B2H_TRY(hipMemcpyAsync(d_aux, aux.data(), aux.size(), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(bign_ktable_kernel<N>, dim3((unsigned)(((size_t)(2 * N + 1) * GT8_ENTRIES + 63) / 64), (unsigned)M), dim3(64), 0, st,
@@ -1901,13 +1933,9 @@ static err_t bign_key_tables(std::vector<std::shared_ptr<KeyTab>> &out, const ui
                 t->used = n;
                 g_keytab_builds.fetch_add(1);
                 if (want16 && t->used >= after) { const err_t c = bign_key_table16_locked<N>(*t, st); if (c != ERR_OK) return c; }
-                if (g_keytabs.size() >= KEYTAB_SLOTS) {      // the least recently used one goes (when its last user lets go of it)
-                    auto old = g_keytabs.begin();
-                    for (auto it = g_keytabs.begin(); it != g_keytabs.end(); ++it) if (it->second->stamp < old->second->stamp) old = it;
-                    g_keytabs.erase(old);
-                }
-                g_keytabs[id_of(keys + 2 * NO * miss[good[j]])] = t;
-                out[miss[good[j]]] = t;
+                if (g_keytabs.size() >= KEYTAB_SLOTS) evict_lru();
+                g_keytabs[id_of(keys + 2 * NO * miss[good[g0 + j]])] = t;
+                out[miss[good[g0 + j]]] = t;
             }
         }
         for (size_t k = 0; k < nkeys; ++k) if (dup_of[k] != (size_t)-1) out[k] = out[dup_of[k]];
@@ -1934,6 +1962,18 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
     // (keyed: every key is credited with its share of the batch -- the signers of a batch are taken to be about equally busy)
     code = bign_key_tables<N>(kts, keys, nkeys, keyed ? (n + nkeys - 1) / nkeys : n, true, st);
     if (code != ERR_OK) return code;
+    {
+        // A stream CAPTURE bakes the tables' addresses into the graph, and nothing tells the library when that graph dies: the tables
+        // a capture refers to are pinned for the life of the process (a reference that is never dropped), so neither the LRU nor a
+        // later call's eviction can free memory a replay will read.  Bounded by the distinct keys ever captured.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
+            std::lock_guard<std::mutex> lk(g_bign_mu);
+            static std::vector<std::shared_ptr<KeyTab>> &pinned = *new std::vector<std::shared_ptr<KeyTab>>;
+            for (const auto &t : kts)
+                if (t && std::find(pinned.begin(), pinned.end(), t) == pinned.end()) pinned.push_back(t);
+        } else (void)hipGetLastError();
+    }
     const uint4 *tab16 = nullptr;
     const uint8_t *d_keys = nullptr;
     const uint4 *const *d_tabs = nullptr;

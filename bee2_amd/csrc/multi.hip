@@ -24,14 +24,14 @@ using namespace bee2hip;
 // range i of `parts` over n items: [n i / parts, n (i + 1) / parts) -- sizes differ by at most one; the same cut as
 // bee2_amd/shard.py shard_range, which bench.py and the torch.distributed tests use
 extern "C" err_t bee2hip_multi_plan(size_t n, int parts, int i, size_t *first, size_t *count)
-{
+try {
     if (parts <= 0 || i < 0 || i >= parts || !first || !count) return ERR_BAD_INPUT;
     const unsigned __int128 N = n;
     const size_t lo = (size_t)(N * (unsigned)i / (unsigned)parts), hi = (size_t)(N * ((unsigned)i + 1u) / (unsigned)parts);
     *first = lo;
     *count = hi - lo;
     return ERR_OK;
-}
+} B2H_CATCH
 
 static int real_device_count()
 {
@@ -142,7 +142,7 @@ err_t run_on_devices_unguarded(int ndev, F job)
 }  // namespace
 
 extern "C" err_t bee2hip_bashF_batch_multi(octet *states, size_t n, int ndev)
-{
+try {
     if (n == 0) return ERR_OK;
     if (!states) return ERR_BAD_INPUT;
     return run_on_devices(ndev, [=](int i, int parts) {
@@ -150,13 +150,13 @@ extern "C" err_t bee2hip_bashF_batch_multi(octet *states, size_t n, int ndev)
         bee2hip_multi_plan(n, parts, i, &lo, &cnt);
         return bee2hip_bashF_batch(states + 192 * lo, cnt);
     });
-}
+} B2H_CATCH
 
 // belt_ctr_st as in capi.hip / belt_lcl.h:135-141
 struct multi_ctr_st { u32 key[8]; u32 ctr[4]; octet block[16]; size_t reserved; };
 
 extern "C" err_t bee2hip_beltCTR_bulk_multi(void *buf_, size_t count, void *ctr_state, int ndev)
-{
+try {
     multi_ctr_st *st = (multi_ctr_st *)ctr_state;
     octet *buf = (octet *)buf_;
     if (!st || (count && !buf)) return ERR_BAD_INPUT;
@@ -183,12 +183,12 @@ extern "C" err_t bee2hip_beltCTR_bulk_multi(void *buf_, size_t count, void *ctr_
     if (code != ERR_OK) return code;
     *st = last;                                   // counter after all blocks, gamma of the final block, reserved
     return ERR_OK;
-}
+} B2H_CATCH
 
 extern "C" err_t bee2hip_bignVerify_batch_multi(const bign_params *params, const octet oid_der[], size_t oid_len,
                                                 const octet *hashes, const octet *sigs, const octet *pubkeys,
                                                 size_t n, err_t *codes, int ndev)
-{
+try {
     // argument checks once, in bignVerify's order, through an empty single-device call
     err_t code = bee2hip_bignVerify_batch(params, oid_der, oid_len, hashes, sigs, pubkeys, 0, codes);
     if (code != ERR_OK) return code;
@@ -201,13 +201,13 @@ extern "C" err_t bee2hip_bignVerify_batch_multi(const bign_params *params, const
         return bee2hip_bignVerify_batch(params, oid_der, oid_len, hashes + no * lo, sigs + (no + no / 2) * lo,
                                         pubkeys + 2 * no * lo, cnt, codes + lo);
     });
-}
+} B2H_CATCH
 
 // one signer / a few signers over all GPUs: every device builds (and caches) the tables of the keys its part meets
 extern "C" err_t bee2hip_bignVerify_keyed_batch_multi(const bign_params *params, const octet oid_der[], size_t oid_len,
                                                       const octet *hashes, const octet *sigs, const octet *pubkeys, size_t nkeys,
                                                       const u32 *key_index, size_t n, err_t *codes, int ndev)
-{
+try {
     err_t code = bee2hip_bignVerify_keyed_batch(params, oid_der, oid_len, hashes, sigs, pubkeys, nkeys, key_index, 0, codes);
     if (code != ERR_OK) return code;
     if (n && (!hashes || !sigs || !pubkeys || !nkeys || !key_index || !codes)) return ERR_BAD_INPUT;
@@ -219,11 +219,11 @@ extern "C" err_t bee2hip_bignVerify_keyed_batch_multi(const bign_params *params,
         return bee2hip_bignVerify_keyed_batch(params, oid_der, oid_len, hashes + no * lo, sigs + (no + no / 2) * lo, pubkeys, nkeys,
                                               key_index + lo, cnt, codes + lo);
     });
-}
+} B2H_CATCH
 extern "C" err_t bee2hip_bignVerify_onekey_batch_multi(const bign_params *params, const octet oid_der[], size_t oid_len,
                                                        const octet *hashes, const octet *sigs, const octet pubkey[], size_t n,
                                                        err_t *codes, int ndev)
-{
+try {
     err_t code = bee2hip_bignVerify_onekey_batch(params, oid_der, oid_len, hashes, sigs, pubkey, 0, codes);
     if (code != ERR_OK) return code;
     if (n && (!hashes || !sigs || !pubkey || !codes)) return ERR_BAD_INPUT;
@@ -234,12 +234,12 @@ extern "C" err_t bee2hip_bignVerify_onekey_batch_multi(const bign_params *params
         bee2hip_multi_plan(n, parts, i, &lo, &cnt);
         return bee2hip_bignVerify_onekey_batch(params, oid_der, oid_len, hashes + no * lo, sigs + (no + no / 2) * lo, pubkey, cnt, codes + lo);
     });
-}
+} B2H_CATCH
 
 extern "C" err_t bee2hip_bignSign2_batch_multi(const bign_params *params, const octet oid_der[], size_t oid_len,
                                                const octet *hashes, const octet *privkeys, const void *t, size_t t_len,
                                                size_t n, octet *sigs, err_t *codes, int ndev)
-{
+try {
     err_t code = bee2hip_bignSign2_batch(params, oid_der, oid_len, hashes, privkeys, t, t_len, 0, sigs, codes);
     if (code != ERR_OK) return code;
     if (n && (!hashes || !privkeys || !sigs || !codes)) return ERR_BAD_INPUT;
@@ -251,12 +251,12 @@ extern "C" err_t bee2hip_bignSign2_batch_multi(const bign_params *params, const 
         return bee2hip_bignSign2_batch(params, oid_der, oid_len, hashes + no * lo, privkeys + no * lo, t, t_len, cnt,
                                        sigs + (no + no / 2) * lo, codes + lo);
     });
-}
+} B2H_CATCH
 
 extern "C" err_t bee2hip_bashHash_beltMAC_batch_multi(const octet *msgs, size_t msg_len, size_t n, size_t l,
                                                       const octet key[], size_t key_len, octet *digests, octet *tags,
                                                       int ndev)
-{
+try {
     err_t code = bee2hip_bashHash_beltMAC_batch(msgs, msg_len, 0, l, key, key_len, digests, tags);
     if (code != ERR_OK) return code;
     if (n && msg_len && !msgs) return ERR_BAD_INPUT;
@@ -268,12 +268,12 @@ extern "C" err_t bee2hip_bashHash_beltMAC_batch_multi(const octet *msgs, size_t 
         return bee2hip_bashHash_beltMAC_batch(msgs + msg_len * lo, msg_len, cnt, l, key, key_len,
                                               digests ? digests + dlen * lo : nullptr, tags ? tags + 8 * lo : nullptr);
     });
-}
+} B2H_CATCH
 
 // ragged messages: ranges of whole messages with about equal BYTE counts (a range's cost is its bytes)
 extern "C" err_t bee2hip_hash_ragged_multi(size_t alg, const octet *data, const uint64_t *offsets, size_t n,
                                            octet *digests, int ndev)
-{
+try {
     if (alg != 0 && alg != 128 && alg != 192 && alg != 256) return ERR_BAD_PARAMS;
     if (n == 0) return ERR_OK;
     if (!offsets || !digests) return ERR_BAD_INPUT;
@@ -302,7 +302,7 @@ extern "C" err_t bee2hip_hash_ragged_multi(size_t alg, const octet *data, const 
         return bee2hip_hash_ragged(alg, data + offsets[lo], off.data(), hi - lo, digests + dlen * lo);
     });
     } catch (const std::bad_alloc &) { return ERR_OUTOFMEMORY; }      // (the per-range vectors are guarded in the worker)
-}
+} B2H_CATCH
 
 // ---- shards that already live on the devices -------------------------------------------------
 // A caller whose data is resident -- shard i in the memory of device i -- must not be pushed through PCIe twice.  These
@@ -323,17 +323,17 @@ static inline err_t drain(err_t code)
 }
 
 extern "C" err_t bee2hip_bashF_batch_multi_dev(void *const d_states[], const size_t counts[], int ndev)
-{
+try {
     err_t code = multi_dev_args(d_states, counts, ndev);
     if (code != ERR_OK) return code;
     return run_on_devices(ndev, [=](int i, int) { return drain(bee2hip_bashF_batch_dev(d_states[i], counts[i], nullptr)); });
-}
+} B2H_CATCH
 
 // shard i holds blocks [first_block + sum of nblocks[0 .. i), ...) of ONE stream that started at ctr0 (beltCTRStart's E_K(iv)):
 // lanes compute ctr0 + offset + 1 directly, no state passes between devices
 extern "C" err_t bee2hip_beltCTR_blocks_multi_dev(void *const d_bufs[], const size_t nblocks[], const u32 key[8],
                                                   const u32 ctr0[4], uint64_t first_block, int ndev)
-{
+try {
     err_t code = multi_dev_args(d_bufs, nblocks, ndev);
     if (code != ERR_OK) return code;
     if (!key || !ctr0) return ERR_BAD_INPUT;
@@ -343,12 +343,12 @@ extern "C" err_t bee2hip_beltCTR_blocks_multi_dev(void *const d_bufs[], const si
     return run_on_devices(ndev, [=](int i, int) {
         return drain(bee2hip_beltCTR_blocks_dev(d_bufs[i], nblocks[i], key, ctr0, first[i], nullptr));
     });
-}
+} B2H_CATCH
 
 extern "C" err_t bee2hip_bignVerifyL_batch_multi_dev(size_t l, const octet oid_der[], size_t oid_len, const void *const d_hashes[],
                                                      const void *const d_sigs[], const void *const d_pubkeys[],
                                                      const size_t counts[], void *const d_codes[], int ndev)
-{
+try {
     err_t code = multi_dev_args(d_hashes, counts, ndev);
     if (code != ERR_OK) return code;
     if (!d_sigs || !d_pubkeys || !d_codes) return ERR_BAD_INPUT;
@@ -358,12 +358,12 @@ extern "C" err_t bee2hip_bignVerifyL_batch_multi_dev(size_t l, const octet oid_d
     return run_on_devices(ndev, [=](int i, int) {
         return drain(bee2hip_bignVerifyL_batch_dev(l, oid_der, oid_len, d_hashes[i], d_sigs[i], d_pubkeys[i], counts[i], d_codes[i], nullptr));
     });
-}
+} B2H_CATCH
 
 extern "C" err_t bee2hip_bignVerifyL_onekey_batch_multi_dev(size_t l, const octet oid_der[], size_t oid_len, const void *const d_hashes[],
                                                             const void *const d_sigs[], const octet pubkey[], const size_t counts[],
                                                             void *const d_codes[], int ndev)
-{
+try {
     err_t code = multi_dev_args(d_hashes, counts, ndev);
     if (code != ERR_OK) return code;
     if (!d_sigs || !pubkey || !d_codes) return ERR_BAD_INPUT;
@@ -372,12 +372,12 @@ extern "C" err_t bee2hip_bignVerifyL_onekey_batch_multi_dev(size_t l, const octe
     return run_on_devices(ndev, [=](int i, int) {
         return drain(bee2hip_bignVerifyL_onekey_batch_dev(l, oid_der, oid_len, d_hashes[i], d_sigs[i], pubkey, counts[i], d_codes[i], nullptr));
     });
-}
+} B2H_CATCH
 extern "C" err_t bee2hip_bignVerifyL_keyed_batch_multi_dev(size_t l, const octet oid_der[], size_t oid_len, const void *const d_hashes[],
                                                            const void *const d_sigs[], const octet pubkeys[], size_t nkeys,
                                                            const void *const d_key_index[], const size_t counts[], void *const d_codes[],
                                                            int ndev)
-{
+try {
     err_t code = multi_dev_args(d_hashes, counts, ndev);
     if (code != ERR_OK) return code;
     if (!d_sigs || !pubkeys || !nkeys || !d_key_index || !d_codes) return ERR_BAD_INPUT;
@@ -387,12 +387,12 @@ extern "C" err_t bee2hip_bignVerifyL_keyed_batch_multi_dev(size_t l, const octet
         return drain(bee2hip_bignVerifyL_keyed_batch_dev(l, oid_der, oid_len, d_hashes[i], d_sigs[i], pubkeys, nkeys, d_key_index[i], counts[i],
                                                          d_codes[i], nullptr));
     });
-}
+} B2H_CATCH
 
 extern "C" err_t bee2hip_bashHash_beltMAC_batch_multi_dev(const void *const d_msgs[], size_t msg_len, const size_t counts[], size_t l,
                                                           const octet key[], size_t key_len, void *const d_digests[],
                                                           void *const d_tags[], int ndev)
-{
+try {
     err_t code = multi_dev_args(d_msgs, counts, ndev);
     if (code != ERR_OK) return code;
     code = bee2hip_bashHash_beltMAC_batch_dev(nullptr, msg_len, 0, l, key, key_len, d_digests ? (void *)1 : nullptr,
@@ -402,4 +402,4 @@ extern "C" err_t bee2hip_bashHash_beltMAC_batch_multi_dev(const void *const d_ms
         return drain(bee2hip_bashHash_beltMAC_batch_dev(d_msgs[i], msg_len, counts[i], l, key, key_len,
                                                         d_digests ? d_digests[i] : nullptr, d_tags ? d_tags[i] : nullptr, nullptr));
     });
-}
+} B2H_CATCH

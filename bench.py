@@ -1207,6 +1207,19 @@ def main():
                                                                              dig_all[64 * lo: 64 * hi], tag_all[8 * lo: 8 * hi]))
         el = timed(dist, km, 1, mixed_unit(0, n))
         ms_mixed = timed.event_ms
+        # the two parts on this GPU in this run: taken from the bashF / beltCTR legs above, or (--only mixed) short legs here
+        src = "the bashF and beltCTR legs of this run (kernel time, per GPU)"
+        if "bashF_perms_per_s" not in rates or "belt_blocks_per_s" not in rates:
+            src = "short bashF (2^20 states) and beltCTR (1 GiB) legs run for this roofline (kernel time, per GPU)"
+            if "bashF_perms_per_s" not in rates:
+                stp = msgs[: 192 << 20]
+                timed(dist, 20, 3, lambda: eng.bashF_batch_dev(stp))
+                rates["bashF_perms_per_s"] = (1 << 20) / (timed.event_ms * 1e-3)
+            if "belt_blocks_per_s" not in rates:
+                cb_ = msgs[: 1 << 30] if msgs.numel() >= (1 << 30) else msgs
+                timed(dist, 3, 1, lambda: eng.beltCTR_blocks_dev(cb_, kw, c0, 0))
+                rates["belt_blocks_per_s"] = (cb_.numel() // 16) / (timed.event_ms * 1e-3)
+            fill_seeded(msgs[: 1 << 30] if msgs.numel() >= (1 << 30) else msgs, 0x4D1C + dist.rank)   # (the short legs ran in place over the first messages)
         others["bash512_beltMAC"] = {
             "metric": "bash512+beltMAC messages/s", "value": N * n * km / el, "unit": "messages/s", "steps": km,
             "ms_per_step": el / km * 1e3, "GiB_per_s": N * n * ml * km / el / 2 ** 30,

@@ -496,7 +496,10 @@ const char *bee2hip_version(void);
 /* path of the drop-in layer's SMALL single calls (one permutation, one block, one message's serial chain, one
    signature verification): 0 = by size (default), 1 = every primitive in a kernel, 2 = the host path wherever one
    exists.  The run-time form of the environment variable BEE2HIP_FORCE=gpu|cpu; mode < 0 only queries.  Returns the
-   mode that was in force.  Batch, _dev and _multi entry points are never affected: they always launch kernels. */
+   mode that was in force.  The _dev and _multi entry points and the batch entries are never affected: they always launch
+   kernels -- with ONE exception: the host-pointer bee2hip_hash_ragged hands its few longest messages (>= 64 KiB, one serial
+   chain each) to host threads while the GPU takes the rest, unless the mode is 1; those messages are not uploaded, and the
+   call counts once in bee2hip_path_count(0). */
 int bee2hip_path_policy(int mode);
 /* how many drop-in helper calls of this process went where: which = 0 host path, 1 GPU path, 2 finished on the host
    after the GPU path failed twice (a warning is printed for each of those) */

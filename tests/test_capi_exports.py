@@ -145,3 +145,73 @@ def test_oid_der_validation_matches_reference_on_invalid_inputs(lib_path):
     for c in bad:
         der = bytes.fromhex(c["der"])
         assert eng.bignVerify(p, der, h, s, k) == E.ERR_BAD_OID, c["der"]
+
+
+# entries whose whole body cannot throw (a constant, a sizeof, a thread-local pointer, two atomic loads): the only ones allowed
+# without a function-try-block
+NO_THROW_BY_INSPECTION = {"bee2hip_last_error", "bee2hip_version", "bashF_deep", "bashHash_keep", "beltCTR_keep", "beltMAC_keep",
+                          "beltECB_keep", "beltDWP_keep", "beltHash_keep", "beltSDE_keep", "beltCHE_keep", "beltBDE_keep",
+                          "beltCBC_keep", "bee2hip_path_policy", "bee2hip_path_count", "bee2hip_internal_stat", "bee2hip_device_count"}
+
+
+def test_nothing_unwinds_through_the_c_abi_by_construction():
+    """every extern "C" entry point is a function-try-block that ends in one of staging.hpp's B2H_CATCH
+    macros (bad_alloc -> ERR_OUTOFMEMORY, anything else -> the device error code), read off the sources -- a new entry
+    without one fails here, on CPU.  (tests/test_gpu_oom_injection.py makes the n-th allocation fail on the GPU box.)"""
+    import glob
+    src = sorted(glob.glob(os.path.join(ROOT, "bee2_amd", "csrc", "capi*.hip"))) + [os.path.join(ROOT, "bee2_amd", "csrc", "multi.hip")]
+    assert len(src) >= 7
+    entries, guarded, bare = set(), set(), set()
+    for path in src:
+        lines = open(path).read().split("\n")
+        for i, line in enumerate(lines):
+            if not line.startswith('extern "C"') or "(" not in line or "[] =" in line or line.rstrip().endswith(";"):
+                continue
+            name = re.match(r'extern "C" .+?\b([A-Za-z_][A-Za-z0-9_]*)\(', line).group(1)
+            entries.add(name)
+            text = "\n".join(lines[i: i + 12])
+            pos, depth = text.index("(", text.index(name)), 0
+            while True:                                        # the parenthesis that closes the parameter list
+                depth += {"(": 1, ")": -1}.get(text[pos], 0)
+                pos += 1
+                if depth == 0:
+                    break
+            if re.match(r"\s*try \{", text[pos:]):
+                rest = "\n".join(lines[i:])
+                m = re.search(r"^\} (B2H_CATCH|catch \(\.\.\.\))|\} (B2H_CATCH(_VOID|_FALSE)?\b|catch \(\.\.\.\))[^\n]*$", rest, flags=re.M)
+                nxt = rest.find('\nextern "C"', 1)
+                assert m and (nxt < 0 or m.start() < nxt), (path, name)      # the catch belongs to THIS entry
+                guarded.add(name)
+            else:
+                bare.add(name)
+    # the level-fixed facades of capi_bign.hip come out of one macro: bign<L>PubkeyCalc / KeypairGen / Sign / Sign2 for L = 128, 192, 256
+    for path in src:
+        lines = open(path).read().split("\n")
+        for i, line in enumerate(lines):
+            m = re.match(r'\s+extern "C" err_t bign##L##(\w+)\(', line)
+            if m:
+                assert re.match(r"\s+try \{.*\} B2H_CATCH\b", lines[i + 1]), (path, m.group(1))
+                for lvl in (128, 192, 256):
+                    entries.add(f"bign{lvl}{m.group(1)}")
+                    guarded.add(f"bign{lvl}{m.group(1)}")
+    assert bare <= NO_THROW_BY_INSPECTION, sorted(bare - NO_THROW_BY_INSPECTION)
+    assert len(guarded) >= 130 and guarded | bare == entries
+    # and every symbol the headers declare is one of them
+    declared = header_symbols() | header_symbols("bee2hip_internal.h")
+    declared.discard("bash_platform")
+    assert declared <= entries, sorted(declared - entries)
+
+
+def test_dynamic_symbols_are_the_header_and_nothing_else(lib_path):
+    """hipcc gives every kernel's host stub default visibility, so 146 mangled _ZN7bee2hip... symbols used
+    to be exported beside the C ABI; bee2_amd/csrc/exports.map makes them local.  What is left DEFINED in the dynamic table is
+    exactly what include/bee2hip.h declares (the rest of `nm -D` are the undefined imports: HIP runtime, libc, libstdc++)."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib_path], text=True)
+    defined = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    assert not [s for s in defined if s.startswith("_Z")], "mangled symbols exported"
+    assert defined == header_symbols(), sorted(defined ^ header_symbols())
+    if os.path.exists(E.EXP_LIB_PATH):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", E.EXP_LIB_PATH], text=True)
+        d2 = {l.split()[-1] for l in out.splitlines() if l.strip()}
+        assert d2 == header_symbols() | header_symbols("bee2hip_internal.h"), sorted(d2 ^ (header_symbols() | header_symbols("bee2hip_internal.h")))
