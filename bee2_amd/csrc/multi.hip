@@ -47,6 +47,8 @@ extern "C" int bee2hip_device_count(void)
 }
 
 namespace {
+static thread_local hipStream_t t_wstream = nullptr;      // a pool worker's own non-blocking stream on its device
+static thread_local hipEvent_t t_wevent = nullptr;
 // Worker pool: ONE persistent thread per logical device, created on first use and kept for the life of the process
 // (fresh std::threads per call threw their per-thread staging -- pinned blocks, device scratch, the NULL-stream
 // pool -- away at every return and paid device-synchronising frees for it).  A worker binds its device once; its
@@ -72,7 +74,13 @@ struct Pool {
         Worker *k = new Worker;
         k->device = real_dev;
         k->th = std::thread([k, real_dev] {
-            const err_t bind = bee2hip_set_device(real_dev);
+            err_t bind = bee2hip_set_device(real_dev);
+            // the worker's own queue (round 5): the _multi_dev jobs launch here, so logical devices that share a card
+            // (BEE2HIP_FAKE_DEVICES, or a caller who cuts one card's data into several shards) run side by side instead of
+            // taking turns on the card's NULL stream
+            if (bind == ERR_OK && (hipStreamCreateWithFlags(&t_wstream, hipStreamNonBlocking) != hipSuccess ||
+                                   hipEventCreateWithFlags(&t_wevent, hipEventDisableTiming) != hipSuccess))
+                bind = hip_fail(hipGetLastError(), "worker stream");
             for (;;) {
                 std::unique_lock<std::mutex> lk(k->mu);
                 k->cv.wait(lk, [k] { return k->has_job; });
@@ -307,7 +315,8 @@ try {
 // ---- shards that already live on the devices -------------------------------------------------
 // A caller whose data is resident -- shard i in the memory of device i -- must not be pushed through PCIe twice.  These
 // take one device pointer and one count per device; worker i (bound to device i) launches the single-device _dev entry on
-// its NULL stream and drains it, so the call returns when every device is done.  Nothing crosses devices; the parameter
+// its OWN non-blocking stream -- ordered behind whatever the device's NULL stream had seen when the job started -- and drains
+// it, so the call returns when every device is done and logical devices that share a card overlap.  Nothing crosses devices; the parameter
 // block (key, counter, curve, OID) is an argument.  ndev = entries in the arrays (<= bee2hip_device_count()).
 static err_t multi_dev_args(const void *const ptrs, const size_t *counts, int ndev)
 {
@@ -315,18 +324,32 @@ static err_t multi_dev_args(const void *const ptrs, const size_t *counts, int nd
     if (ndev > bee2hip_device_count()) return ERR_BAD_INPUT;
     return ERR_OK;
 }
+// The worker's stream, ordered behind everything the device's NULL stream has seen so far -- the guarantee the NULL-stream launches
+// of rounds 3-4 gave a caller who produced his shards on the default stream (or on blocking streams) without synchronising.
+static inline err_t worker_stream(hipStream_t *st)
+{
+    *st = t_wstream;
+    if (!t_wstream) return ERR_OK;                          // (not a pool worker: the NULL stream, as before)
+    B2H_TRY(hipEventRecord(t_wevent, nullptr));
+    B2H_TRY(hipStreamWaitEvent(t_wstream, t_wevent, 0));
+    return ERR_OK;
+}
 static inline err_t drain(err_t code)
 {
     if (code != ERR_OK) return code;
-    B2H_TRY(hipStreamSynchronize(nullptr));
+    B2H_TRY(hipStreamSynchronize(t_wstream));
     return ERR_OK;
 }
+#define B2H_WSTREAM(st) hipStream_t st = nullptr; { const err_t c_ = worker_stream(&st); if (c_ != ERR_OK) return c_; }
 
 extern "C" err_t bee2hip_bashF_batch_multi_dev(void *const d_states[], const size_t counts[], int ndev)
 try {
     err_t code = multi_dev_args(d_states, counts, ndev);
     if (code != ERR_OK) return code;
-    return run_on_devices(ndev, [=](int i, int) { return drain(bee2hip_bashF_batch_dev(d_states[i], counts[i], nullptr)); });
+    return run_on_devices(ndev, [=](int i, int) -> err_t {
+        B2H_WSTREAM(st);
+        return drain(bee2hip_bashF_batch_dev(d_states[i], counts[i], st));
+    });
 } B2H_CATCH
 
 // shard i holds blocks [first_block + sum of nblocks[0 .. i), ...) of ONE stream that started at ctr0 (beltCTRStart's E_K(iv)):
@@ -340,8 +363,9 @@ try {
     uint64_t first[64];
     if (ndev > 64) return ERR_BAD_INPUT;
     for (int i = 0; i < ndev; ++i) { first[i] = first_block; first_block += (uint64_t)nblocks[i]; }
-    return run_on_devices(ndev, [=](int i, int) {
-        return drain(bee2hip_beltCTR_blocks_dev(d_bufs[i], nblocks[i], key, ctr0, first[i], nullptr));
+    return run_on_devices(ndev, [=](int i, int) -> err_t {
+        B2H_WSTREAM(st);
+        return drain(bee2hip_beltCTR_blocks_dev(d_bufs[i], nblocks[i], key, ctr0, first[i], st));
     });
 } B2H_CATCH
 
@@ -355,8 +379,9 @@ try {
     // argument checks once (level, OID), in the single-device entry's order, through an empty call
     code = bee2hip_bignVerifyL_batch_dev(l, oid_der, oid_len, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
     if (code != ERR_OK) return code;
-    return run_on_devices(ndev, [=](int i, int) {
-        return drain(bee2hip_bignVerifyL_batch_dev(l, oid_der, oid_len, d_hashes[i], d_sigs[i], d_pubkeys[i], counts[i], d_codes[i], nullptr));
+    return run_on_devices(ndev, [=](int i, int) -> err_t {
+        B2H_WSTREAM(st);
+        return drain(bee2hip_bignVerifyL_batch_dev(l, oid_der, oid_len, d_hashes[i], d_sigs[i], d_pubkeys[i], counts[i], d_codes[i], st));
     });
 } B2H_CATCH
 
@@ -369,8 +394,9 @@ try {
     if (!d_sigs || !pubkey || !d_codes) return ERR_BAD_INPUT;
     code = bee2hip_bignVerifyL_onekey_batch_dev(l, oid_der, oid_len, nullptr, nullptr, pubkey, 0, nullptr, nullptr);
     if (code != ERR_OK) return code;
-    return run_on_devices(ndev, [=](int i, int) {
-        return drain(bee2hip_bignVerifyL_onekey_batch_dev(l, oid_der, oid_len, d_hashes[i], d_sigs[i], pubkey, counts[i], d_codes[i], nullptr));
+    return run_on_devices(ndev, [=](int i, int) -> err_t {
+        B2H_WSTREAM(st);
+        return drain(bee2hip_bignVerifyL_onekey_batch_dev(l, oid_der, oid_len, d_hashes[i], d_sigs[i], pubkey, counts[i], d_codes[i], st));
     });
 } B2H_CATCH
 extern "C" err_t bee2hip_bignVerifyL_keyed_batch_multi_dev(size_t l, const octet oid_der[], size_t oid_len, const void *const d_hashes[],
@@ -383,9 +409,10 @@ try {
     if (!d_sigs || !pubkeys || !nkeys || !d_key_index || !d_codes) return ERR_BAD_INPUT;
     code = bee2hip_bignVerifyL_keyed_batch_dev(l, oid_der, oid_len, nullptr, nullptr, pubkeys, nkeys, nullptr, 0, nullptr, nullptr);
     if (code != ERR_OK) return code;
-    return run_on_devices(ndev, [=](int i, int) {
+    return run_on_devices(ndev, [=](int i, int) -> err_t {
+        B2H_WSTREAM(st);
         return drain(bee2hip_bignVerifyL_keyed_batch_dev(l, oid_der, oid_len, d_hashes[i], d_sigs[i], pubkeys, nkeys, d_key_index[i], counts[i],
-                                                         d_codes[i], nullptr));
+                                                         d_codes[i], st));
     });
 } B2H_CATCH
 
@@ -398,8 +425,9 @@ try {
     code = bee2hip_bashHash_beltMAC_batch_dev(nullptr, msg_len, 0, l, key, key_len, d_digests ? (void *)1 : nullptr,
                                               d_tags ? (void *)1 : nullptr, nullptr);
     if (code != ERR_OK) return code;
-    return run_on_devices(ndev, [=](int i, int) {
+    return run_on_devices(ndev, [=](int i, int) -> err_t {
+        B2H_WSTREAM(st);
         return drain(bee2hip_bashHash_beltMAC_batch_dev(d_msgs[i], msg_len, counts[i], l, key, key_len,
-                                                        d_digests ? d_digests[i] : nullptr, d_tags ? d_tags[i] : nullptr, nullptr));
+                                                        d_digests ? d_digests[i] : nullptr, d_tags ? d_tags[i] : nullptr, st));
     });
 } B2H_CATCH

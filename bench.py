@@ -140,11 +140,27 @@ def strong_pred(t_total_ms, t_share_ms):
     return {g: (t_total_ms / t if t else None) for g, t in t_share_ms.items()}
 
 
-def event_ms(fn, steps, warmup=2):
-    """average milliseconds per call of fn(): hipEvents on the launch stream around `steps` calls, after `warmup` untimed ones"""
+def event_ms(fn, steps, warmup=2, graph=False):
+    """average milliseconds per call of fn(): hipEvents on the launch stream around `steps` calls, after `warmup` untimed ones.
+    graph=True: the `steps` calls are captured into ONE hipGraph and the replay is timed -- for launches of a few microseconds,
+    where an eager Python loop would measure the host's launch rate (2^17 bashF states: 21 us eager, 17 us on the device)."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    if graph:
+        side = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(steps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(steps):
@@ -379,6 +395,22 @@ def pmc_traffic(kernel_substr):
     except Exception:
         pass
     return None, None
+
+
+def pmc_valu(kernel_substr):
+    """valu_busy of a kernel (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles) from the newest committed rocprofv3 --pmc summary: a REPLAY of that
+    profiling run, like `traffic` -- north_star's "VALU integer-op utilisation" beside each fraction"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_summary.json")))
+    for path in reversed(found):
+        try:
+            d = json.load(open(path))
+            for k, v in d.get("kernels", {}).items():
+                if kernel_substr in k and "valu_busy" in v:
+                    return v["valu_busy"]
+        except Exception:
+            pass
+    return None
 
 
 # ------------------------------------------------------------------------- CPU baseline
@@ -668,15 +700,15 @@ def main():
     rates = {}
     strong = {}                                # the fixed-N (strong) reading of SURVEY 8e, flat scalars for `roofline`
 
-    def strong_leg(name, total, unit_fn, steps, to_value=1.0, t_total_ms=None):
+    def strong_leg(name, total, unit_fn, steps, to_value=1.0, t_total_ms=None, graph=False):
         """The FIXED job of `total` items (BASELINE's size) split by shard.shard_range.  unit_fn(lo, hi) returns the step over
         items [lo, hi) of the resident job.  N = 1: time rank 0's share of a 2- / 4- / 8-way split on this GPU, like the headline
         (hipEvents around `steps` launches) -> strong_pred_G_<name> = t(total) / t(total / G).  N > 1: every rank its own
         share between barriers -> strong_value_<name> (whole job, in the metric's unit) and strong_speedup_<name> = rank 0
         alone on the total / the N ranks on their shares."""
         if N == 1:
-            t_tot = t_total_ms if t_total_ms is not None else event_ms(unit_fn(0, total), steps)
-            t_sh = {g: event_ms(unit_fn(0, m), steps) for g, m in strong_shares(total).items()}
+            t_tot = t_total_ms if t_total_ms is not None and not graph else event_ms(unit_fn(0, total), steps, graph=graph)
+            t_sh = {g: event_ms(unit_fn(0, m), steps, graph=graph) for g, m in strong_shares(total).items()}
             for g, v in strong_pred(t_tot, t_sh).items():
                 strong[f"strong_pred_{g}_{name}"] = v
             strong[f"strong_ms_total_{name}"] = t_tot
@@ -737,8 +769,8 @@ def main():
             diag["weak_efficiency"] = value / (N * diag["solo_value"])
         rates["bashF_perms_per_s"] = n / (ms_launch * 1e-3)      # per GPU, kernel time: what the mixed roofline's parts use
         if not args.headline_only:
-            strong_leg("bashF", n, lambda lo, hi: (lambda: eng.bashF_batch_dev(st[192 * lo: 192 * hi])), K,
-                       t_total_ms=ms_launch if N == 1 else None)
+            # (launches of 17-94 us: total and shares both as replays of a captured graph of K launches, no host launch gaps)
+            strong_leg("bashF", n, lambda lo, hi: (lambda: eng.bashF_batch_dev(st[192 * lo: 192 * hi])), K, graph=True)
         # the same kernel on a batch that cannot sit in the 256 MiB Infinity Cache: 2^22 states = 768 MiB read + written
         # per launch; reported as flat keys next to the cache-resident headline
         if not args.headline_only:
@@ -1537,6 +1569,12 @@ def main():
     # N > 1: the line explains itself -- rank 0 alone beforehand, each rank's own rate, clocks
     for k in ("weak_efficiency", "solo_value", "clock_ghz_min", "clock_ghz_max", "per_rank_value_min", "per_rank_value_max"):
         flat[k] = diag.get(k)
+    # measured VALU utilisation (SQ counters, replayed from the committed profile of this round like `traffic`)
+    for key, kern in (("valu_busy_bashF", "bashF_tile_kernel"), ("valu_busy_beltCTR", "beltCTR_blocks_kernel"),
+                      ("valu_busy_bign_main", "bign_main_kernel<8"), ("valu_busy_fused", "hash_mac_fused_kernel<8, true, true"),
+                      ("valu_busy_bign_mulbase", "bign_mulbase_lds_kernel<8"), ("valu_busy_bign_onekey", "bign_onekey_kernel<8"),
+                      ("valu_busy_belt_hash_long", "belt_hash_long"), ("valu_busy_bash_ragged", "bash_ragged_kernel")):
+        late[key] = pmc_valu(kern)
     flat["avg_launch_ms"] = rf0.get("avg_launch_ms", rf0.get("avg_batch_ms"))
     flat["kernel"] = rf0.get("kernel", rf0.get("kernels"))
     flat.update(late)

@@ -462,8 +462,10 @@ err_t bee2hip_bashHash_beltMAC_batch_dev(const void *d_msgs, size_t msg_len, siz
                                          void *d_digests, void *d_tags, void *stream);
 
 /* Shards that already LIVE on the devices: entry i of each array belongs to device i (a pointer into its memory and an item
-   count); worker i launches the single-device _dev entry on that device's NULL stream and the call returns when all are
-   done.  Nothing is staged through the host and nothing crosses devices.  ndev = number of array entries,
+   count); worker i launches the single-device _dev entry on its own non-blocking stream of that device, ordered behind
+   everything the device's NULL stream had been given when the call was made (a shard produced on the default stream or on a
+   blocking stream needs no synchronisation; one produced on a NON-blocking stream must be complete), and the call returns when
+   all are done.  Shards that share a card therefore run side by side.  Nothing is staged through the host and nothing crosses devices.  ndev = number of array entries,
    1 <= ndev <= bee2hip_device_count().  CTR: shard i holds blocks first_block + nblocks[0] + .. + nblocks[i-1] onwards of
    ONE stream with counter ctr0 (as bee2hip_beltCTR_blocks_dev); MAC / hash: d_digests or d_tags may be NULL as a whole. */
 err_t bee2hip_bashF_batch_multi_dev(void *const d_states[], const size_t counts[], int ndev);

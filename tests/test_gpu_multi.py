@@ -229,3 +229,92 @@ def test_onekey_and_keyed_multi(orc, golden, devices):
     assert eng.lib.bee2hip_bignVerifyL_onekey_batch_multi_dev(_sz(128), oid, _sz(11), arr(th), arr(tsg), keys[idx[0]], CNT, arr(tc), k) == 0
     got = [int(x) & 0xFFFFFFFF for t, c in zip(tc, counts) for x in t.cpu().numpy()[:c]]
     assert got == [want[i] if idx[i] == idx[0] else 510 for i in range(pos)]
+
+
+def test_logical_devices_that_share_a_card_run_side_by_side(orc, golden):
+    """the N > 1 library path cannot meet a second card here, so it meets a second QUEUE.  Every pool worker
+    launches its _multi_dev job on its own non-blocking stream: four latency-bound shards (2^12 signatures each -- a lone
+    wavefront's chain, 0.36 ms whatever the size) on four logical devices of ONE card must overlap, not take turns as they did on
+    the card's NULL stream (4 x the time of one shard)."""
+    import time
+
+    import torch
+
+    from gpulib import dev
+    os.environ["BEE2HIP_FAKE_DEVICES"] = "4"
+    try:
+        eng = engine()
+        vp = ctypes.c_void_p
+        hs, ss, ps = golden.bign_base_arrays()
+        m = 1 << 12
+        bad = bytearray(ss * 2)
+        for i in range(0, m, 7):
+            bad[48 * i + 3] ^= 1
+        th, tsg, tp = dev((hs * 2)[: 32 * m]), dev(bytes(bad[: 48 * m])), dev((ps * 2)[: 64 * m])
+        want = torch.tensor(orc.verify_batch((hs * 2)[: 32 * m], bytes(bad[: 48 * m]), (ps * 2)[: 64 * m], nthreads=8), dtype=torch.int64)
+        oid = E.LEVEL_OID[128]
+
+        def run(k):
+            tc = [torch.full((m,), -1, dtype=torch.int32, device="cuda") for _ in range(k)]
+            arr = lambda xs: (vp * k)(*[x.data_ptr() for x in xs])  # noqa: E731
+            CNT = (ctypes.c_size_t * k)(*([m] * k))
+            args = (_sz(128), oid, _sz(11), arr([th] * k), arr([tsg] * k), arr([tp] * k), CNT, arr(tc), k)
+            torch.cuda.synchronize()
+            assert eng.lib.bee2hip_bignVerifyL_batch_multi_dev(*args) == 0            # warm (worker threads, streams, scratch)
+            best = 1e9
+            for _ in range(7):
+                t0 = time.perf_counter()
+                assert eng.lib.bee2hip_bignVerifyL_batch_multi_dev(*args) == 0
+                best = min(best, time.perf_counter() - t0)
+            for t in tc:                                           # the call has drained the workers' streams: results are there
+                assert torch.equal(t.cpu().to(torch.int64) & 0xFFFFFFFF, want)
+            return best
+        t1, t4 = run(1), run(4)
+        assert t4 < 2.5 * t1, (t1, t4)                             # taking turns would be ~4x
+    finally:
+        os.environ.pop("BEE2HIP_FAKE_DEVICES", None)
+
+
+def test_two_host_threads_on_two_multi_entries_take_turns_and_both_finish(orc, golden):
+    """the pool runs ONE multi-device batch at a time (multi.hip call_mu: its workers are one thread per device): two host
+    threads that call two different _multi entries at once are serialised, not interleaved -- both must return the right
+    bytes, repeatedly"""
+    import threading
+    os.environ["BEE2HIP_FAKE_DEVICES"] = "3"
+    try:
+        eng = engine()
+        H = golden.H
+        n = 5000
+        states = orc.fill(192 * n, 0xBA5F)
+        want_f = orc.bashF_batch(states)
+        stream = np.frombuffer(orc.fill(16 * 70001, 0xBE17), dtype=np.uint8).copy()
+        kw, c0 = orc.ctr_start(H[128:160], H[192:208])
+        want_c = stream.copy()
+        orc.ctr_blocks_np(want_c, kw, c0, first=0)
+        errs = []
+
+        def f_bash():
+            try:
+                for _ in range(6):
+                    buf = ctypes.create_string_buffer(states, len(states))
+                    assert eng.lib.bee2hip_bashF_batch_multi(buf, _sz(n), 3) == 0
+                    assert buf.raw == want_f
+            except Exception as e:      # noqa: BLE001
+                errs.append(repr(e))
+
+        def f_ctr():
+            try:
+                for _ in range(6):
+                    st = ctypes.create_string_buffer(eng.lib.beltCTR_keep())
+                    eng.lib.beltCTRStart(st, bytes(H[128:160]), _sz(32), bytes(H[192:208]))
+                    buf = stream.copy()
+                    assert eng.lib.bee2hip_beltCTR_bulk_multi(ctypes.c_void_p(buf.ctypes.data), _sz(buf.size), st, 3) == 0
+                    assert np.array_equal(buf, want_c)
+            except Exception as e:      # noqa: BLE001
+                errs.append(repr(e))
+        ts = [threading.Thread(target=f_bash), threading.Thread(target=f_ctr)]
+        [t.start() for t in ts]
+        [t.join(300) for t in ts]
+        assert not errs and not any(t.is_alive() for t in ts), errs
+    finally:
+        os.environ.pop("BEE2HIP_FAKE_DEVICES", None)

@@ -14,7 +14,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bashF -o benc
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- $CMD --only bashF,ctr,verify --ctr-gib 4 --headline-only > $OUT/pmc_$c.log 2>&1
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $OUT/pmc_sq1 -o bench -- $CMD --ctr-gib 4 > $OUT/pmc_sq1.log 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq2 -o bench -- $CMD --ctr-gib 4 > $OUT/pmc_sq2.log 2>&1
+# SQ passes over every workload of the bench (verification incl. one signer / keyed, signing, the fused kernel, the ragged hashes):
+# pass 1 carries what valu_busy needs (SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES / 32 SEs x 1024 SIMDs)), pass 2 the LDS side
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq1 -o bench -- $CMD --ctr-gib 4 --only bashF,ctr,verify,sign,mixed,ragged > $OUT/pmc_sq1.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq2 -o bench -- $CMD --ctr-gib 4 --only bashF,ctr,verify,sign,mixed,ragged > $OUT/pmc_sq2.log 2>&1
 find $OUT -name '*.csv' | head -50
 du -sh $OUT

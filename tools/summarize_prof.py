@@ -45,6 +45,7 @@ def main(tag):
         shutil.copy(hb, os.path.join(DST, f"{tag}_kernel_stats_bashF_only.csv"))
     summary = {"command": "rocprofv3 --kernel-trace --stats / --pmc <set> -- python bench.py --steps 20 --warmup 3 --no-cpu "
                           "(PMC passes: --ctr-gib 4; FETCH/WRITE passes: --only bashF,ctr)",
+               "valu_busy": "kernels[*].valu_busy = SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES / 32 shader engines x 1024 SIMDs), pass pmc_sq1",
                "note": "counter values are per-launch averages; FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts "
                        "half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM) -> doubled in hbm_bytes_per_launch; "
                        "vgpr_count_rocprof is what rocprofv3 prints, which on gfx950 is HALF the allocated VGPRs "
@@ -72,6 +73,26 @@ def main(tag):
                            "hbm_bytes_per_launch": (2 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024,
                            "avg_duration_ns_under_pmc": fe["duration_ns"],
                            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x 2 (gfx950)"}
+    # VALU utilisation per kernel from the SQ pass (north_star: "VALU integer-op utilisation"): SQ_ACTIVE_INST_VALU counts, per SIMD, the
+    # quad-cycles a VALU instruction is executing; SQ_BUSY_CYCLES is summed over the 32 shader engines (8 XCDs x 4): cycles per SE x 1024
+    # SIMDs are the SIMD-cycles there were.  1.0 = the vector ALUs never idle (bign_main_kernel at four wavefronts per SIMD).
+    sq1, sq2 = summary.get("pmc_sq1", {}), summary.get("pmc_sq2", {})
+    for k, v in sq1.items():
+        busy, act = v.get("SQ_BUSY_CYCLES"), v.get("SQ_ACTIVE_INST_VALU")
+        if not busy or act is None:
+            continue
+        e = kernels.setdefault(k, {})
+        e["valu_busy"] = act * 4.0 / (busy / 32.0 * 1024.0)
+        e["valu_insts_per_wave"] = v.get("SQ_INSTS_VALU", 0.0) / max(1.0, v.get("SQ_WAVES", 1.0))
+        e["waves"] = v.get("SQ_WAVES")
+        e["wave_cycles_per_simd_cycle"] = v.get("SQ_WAVE_CYCLES", 0.0) * 4.0 / (busy * 32.0)
+        e["lds_insts_per_wave"] = v.get("SQ_INSTS_LDS", 0.0) / max(1.0, v.get("SQ_WAVES", 1.0))
+        e["duration_ns_under_sq_pass"] = v.get("duration_ns")
+        w = sq2.get(k)
+        if w and w.get("SQ_BUSY_CYCLES"):
+            e["lds_busy"] = w.get("SQ_ACTIVE_INST_LDS", 0.0) * 4.0 / (w["SQ_BUSY_CYCLES"] / 32.0 * 1024.0)
+            e["lds_bank_conflict_cycles"] = w.get("SQ_LDS_BANK_CONFLICT")
+        e.setdefault("note_valu", "valu_busy = SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES / 32 x 1024); rocprofv3 --pmc, own pass")
     summary["kernels"] = kernels
     summary["commit"] = commit
     with open(os.path.join(DST, f"{tag}_pmc_summary.json"), "w") as fh:
