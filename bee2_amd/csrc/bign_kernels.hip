@@ -244,9 +244,16 @@ __device__ __forceinline__ bool prep_scalars(const uint8_t *__restrict__ hashes,
 
 // one signature: prep_scalars, then 1Q..8Q (1Q affine, 2Q..8Q Jacobian: X, Y in the table rows, Z aside).  Sets
 // the status; returns true when the table is to be normalised (no exceptional case).
-template <int N, class OPS = VtOps>
+// order in which prep_points produces the entries 2Q..8Q (entry e = (e + 1) Q): slot k of the running product belongs to entry prep_ord(k) = 1, 2, 3, 5, 6, 4, 7
+// (nibble k of a literal: an array indexed by a loop counter would be parked in LDS / scratch)
+__device__ __forceinline__ constexpr int prep_ord(int k) { return (int)((0x7465321u >> (4 * k)) & 15u); }
+// ACC: acc is the running product of the Z of the points as they come out -- slot k of Cs gets the product BEFORE entry
+// prep_ord(k), then acc takes its Z.  Round 5: the normalisation's first pass used to read every Z back from memory, one dependent
+// load in front of every multiplication of a latency-bound kernel (bign_prep_kernel: 5.7 cycles per VALU instruction, valu_busy 0.68).
+template <int N, class OPS = VtOps, bool ACC = false>
 __device__ __forceinline__ bool prep_points(const uint8_t *__restrict__ hashes, const uint8_t *__restrict__ sigs,
-                                            const uint8_t *__restrict__ pubkeys, size_t idx, const VerifyScratch &S)
+                                            const uint8_t *__restrict__ pubkeys, size_t idx, const VerifyScratch &S,
+                                            feT<N> &acc, uint32_t *Cs)
 {
     affT<N> Q;
     {
@@ -257,10 +264,16 @@ __device__ __forceinline__ bool prep_points(const uint8_t *__restrict__ hashes, 
     // table 1Q..8Q: 1Q as given, 2Q..8Q Jacobian for now (bign_prep_kernel normalises them).  Any exceptional
     // case -> slow path.
     bool ok = true;
+    int slot = 0;
     const auto put = [&](int e, const jacT<N> &P) {      // entry e = (e+1) Q: X, Y in place, Z aside
         store_qxy(S, e, idx, P.X, P.Y);
         store_soa(S.qz + (size_t)(e - 1) * N * S.n_pad, S.n_pad, idx, P.Z);
         ok &= !fe_is_zero(P.Z);
+        if constexpr (ACC) {                                 // (acc by reference and a compile-time switch: through a pointer it was parked in LDS)
+            store_soa(Cs + (size_t)slot * N * S.n_pad, S.n_pad, idx, acc);
+            fe_mul<1, OPS>(acc, acc, P.Z);
+            ++slot;
+        }
     };
     // Two chains, two points in registers: A = 2Q -> 4Q -> 8Q and T = 3Q -> 6Q -> 7Q, then 5Q = 4Q + Q from A.
     jacT<N> A, T;
@@ -283,7 +296,8 @@ void bign_points_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
                         const uint8_t *__restrict__ pubkeys, size_t n, VerifyScratch S)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n) prep_points<N, OPS>(hashes, sigs, pubkeys, idx, S);
+    feT<N> none;
+    if (idx < n) prep_points<N, OPS, false>(hashes, sigs, pubkeys, idx, S, none, nullptr);
 }
 
 // The table is made AFFINE so that the main loop adds with the mixed formula (8M + 3S instead of 12M + 4S, 31
@@ -306,6 +320,10 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= lanes) return;
     uint32_t *Zs = S.qz, *Cs = S.qz + (size_t)7 * N * S.n_pad;     // Z of 2Q..8Q; product of all Z before it
+    // (round 5) Every load of this kernel sat directly in front of the multiplication that needs it, at two wavefronts per SIMD: the
+    // loops below ask for the NEXT step's operands before they multiply, and on the 256-bit curve the first pass takes the Z of a
+    // point while it is still in registers (prep_points' running product) -- slots in prep_ord order there, in entry order when the
+    // points come from bign_points_kernel.
     feT<N> acc, z, zi, zi2, v;
     fe_set_one(acc);
     unsigned todo = 0;
@@ -313,15 +331,19 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
     for (int sp = 0; sp < SP; ++sp) {
         const size_t idx = (size_t)sp * lanes + j;
         if (idx >= n) break;
-        if (SPLIT) { if (S.status[idx] != ST_PENDING) continue; }
-        else if (!prep_points<N, OPS>(hashes, sigs, pubkeys, idx, S)) continue;
-        todo |= 1u << sp;
+        if (SPLIT) {
+            if (S.status[idx] != ST_PENDING) continue;
 #pragma unroll 1
-        for (int k = 0; k < 7; ++k) {
-            store_soa(Cs + (size_t)k * N * S.n_pad, S.n_pad, idx, acc);
-            load_soa(z, Zs + (size_t)k * N * S.n_pad, S.n_pad, idx);
-            fe_mul<1, OPS>(acc, acc, z);
+            for (int k = 0; k < 7; ++k) {
+                store_soa(Cs + (size_t)k * N * S.n_pad, S.n_pad, idx, acc);
+                load_soa(z, Zs + (size_t)k * N * S.n_pad, S.n_pad, idx);
+                fe_mul<1, OPS>(acc, acc, z);
+            }
+        } else {
+            const feT<N> before = acc;
+            if (!prep_points<N, OPS, true>(hashes, sigs, pubkeys, idx, S, acc, Cs)) { acc = before; continue; }   // (slow path: out of the product)
         }
+        todo |= 1u << sp;
     }
     if (!todo) return;
     feT<N> inv = fe_inv_checked(acc);
@@ -329,21 +351,50 @@ void bign_prep_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__restr
     for (int sp = SP - 1; sp >= 0; --sp) {
         if (!((todo >> sp) & 1u)) continue;
         const size_t idx = (size_t)sp * lanes + j;
+        if constexpr (N != 8) {
+            // the wider curves hold this kernel to 256 VGPRs already: no second operand set there, the loads stay in front of their use
+            // (asking ahead measured +1..+4 % WORSE on their pipelines at 2^16..2^18, profiles/r05_ask_ahead_ab.txt)
+#pragma unroll 1
+            for (int k = 6; k >= 0; --k) {
+                load_soa(v, Cs + (size_t)k * N * S.n_pad, S.n_pad, idx);
+                fe_mul<1, OPS>(zi, inv, v);                           // 1 / Z_k
+                load_soa(z, Zs + (size_t)k * N * S.n_pad, S.n_pad, idx);
+                fe_mul<1, OPS>(inv, inv, z);                          // 1 / (product before Z_k)
+                uint32_t *b = S.qtab + (size_t)(k + 1) * 2 * N * S.n_pad;
+                fe_sqr<1, OPS>(zi2, zi);
+                load_soa(v, b, S.n_pad, idx);
+                fe_mul<1, OPS>(v, v, zi2);
+                store_soa(b, S.n_pad, idx, v);                // x = X / Z^2
+                fe_mul<1, OPS>(zi2, zi2, zi);
+                load_soa(v, b + (size_t)N * S.n_pad, S.n_pad, idx);
+                fe_mul<1, OPS>(v, v, zi2);
+                store_soa(b + (size_t)N * S.n_pad, S.n_pad, idx, v);   // y = Y / Z^3
+            }
+        } else {
+        feT<N> cn, zn, xn, yn, x, y;
+        const auto ask = [&](int k) {                        // the operands of slot k: product before it, its Z, its X and Y
+            const int e = prep_ord(k);
+            const uint32_t *b = S.qtab + (size_t)e * 2 * N * S.n_pad;
+            load_soa(cn, Cs + (size_t)k * N * S.n_pad, S.n_pad, idx);
+            load_soa(zn, Zs + (size_t)(e - 1) * N * S.n_pad, S.n_pad, idx);
+            load_soa(xn, b, S.n_pad, idx);
+            load_soa(yn, b + (size_t)N * S.n_pad, S.n_pad, idx);
+        };
+        ask(6);
 #pragma unroll 1
         for (int k = 6; k >= 0; --k) {
-            load_soa(v, Cs + (size_t)k * N * S.n_pad, S.n_pad, idx);
+            v = cn; z = zn; x = xn; y = yn;
+            if (k > 0) ask(k - 1);
             fe_mul<1, OPS>(zi, inv, v);                           // 1 / Z_k
-            load_soa(z, Zs + (size_t)k * N * S.n_pad, S.n_pad, idx);
             fe_mul<1, OPS>(inv, inv, z);                          // 1 / (product before Z_k)
-            uint32_t *b = S.qtab + (size_t)(k + 1) * 2 * N * S.n_pad;
+            uint32_t *b = S.qtab + (size_t)prep_ord(k) * 2 * N * S.n_pad;
             fe_sqr<1, OPS>(zi2, zi);
-            load_soa(v, b, S.n_pad, idx);
-            fe_mul<1, OPS>(v, v, zi2);
-            store_soa(b, S.n_pad, idx, v);                // x = X / Z^2
+            fe_mul<1, OPS>(x, x, zi2);
+            store_soa(b, S.n_pad, idx, x);                        // x = X / Z^2
             fe_mul<1, OPS>(zi2, zi2, zi);
-            load_soa(v, b + (size_t)N * S.n_pad, S.n_pad, idx);
-            fe_mul<1, OPS>(v, v, zi2);
-            store_soa(b + (size_t)N * S.n_pad, S.n_pad, idx, v);   // y = Y / Z^3
+            fe_mul<1, OPS>(y, y, zi2);
+            store_soa(b + (size_t)N * S.n_pad, S.n_pad, idx, y);  // y = Y / Z^3
+        }
         }
     }
 }
@@ -445,14 +496,17 @@ void bign_main29_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gta
     load_soa(u, S.u, S.n_pad, idx);
 
     // 4N digits of v (4 doublings + one addition from the table of Q each), then the 2N comb windows of u, through
-    // ONE addition site (the code of this kernel is what a lone wavefront pays for)
+    // ONE addition site (the code of this kernel is what a lone wavefront pays for).
+    // (round 5) A lone wavefront has nobody to hide a load behind: the table point of a digit is asked for BEFORE its four
+    // doublings, the comb point of a window during the addition of the step before it (En) -- 49 trips to memory (the comb table is
+    // 64 MiB: HBM / Infinity-Cache latency) used to sit directly in front of the addition that needs them.
+    affT<N> En;
+    bool have_n = false;
 #pragma unroll 1
     for (int it = 4 * N - 1 + 32 * N / W; it >= 0; --it) {
         bool have;
         bool negate = false;
         if (it >= 32 * N / W) {
-#pragma unroll 1
-            for (int k = 0; k < 4; ++k) jac29_dbl(T);
             const int d = (int)(w[NW - 2] >> 28) - 8;
 #pragma unroll
             for (int l = NW - 2; l > 0; --l) w[l] = (w[l] << 4) | (w[l - 1] >> 28);
@@ -460,14 +514,20 @@ void bign_main29_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gta
             have = d != 0;
             negate = d < 0;
             if (have) load_qaff(E, S, (d < 0 ? -d : d) - 1, idx);
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) jac29_dbl(T);
         } else {
-            const int win = 32 * N / W - 1 - it;
+            have = have_n;
+            E = En;
+        }
+        if (it >= 1 && it - 1 < 32 * N / W) {                  // the next step is a comb window: its point, behind this step's addition
+            const int win = 32 * N / W - 1 - (it - 1);
             const uint32_t b = u.v[0] & ((1u << W) - 1u);
 #pragma unroll
             for (int l = 0; l < N - 1; ++l) u.v[l] = (u.v[l] >> W) | (u.v[l + 1] << (32 - W));
             u.v[N - 1] >>= W;
-            have = b != 0;
-            if (have) load_aff(E, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
+            have_n = b != 0;
+            if (have_n) load_aff(En, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
         }
         if (have) {
             f29_from_words(E29.x, E.x);
@@ -582,6 +642,8 @@ void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
     get(E, (int)(w[NW - 1] & 15u) - 9);
     T.X = E.X; T.Y = E.Y; T.Z = E.Z; T.D = E.ZZ;
     bool empty = helper;                            // the helper's sum starts at O: its first point is copied, not added
+    affT<N> Gn;                                     // (no helper quad) the comb point asked for ahead, and its window value
+    uint32_t bn = 0;
 #pragma unroll 1
     for (int it = 4 * N - 1 + (HELPER ? 0 : 32 * N / W); it >= 0; --it) {
         const bool digit_step = HELPER || it >= 32 * N / W;
@@ -590,12 +652,35 @@ void bign_quad29_kernel(const uint8_t *__restrict__ hashes, const uint8_t *__res
         // doublings cover the trip to memory.
         affT<N> G;
         uint32_t b = 0;
-        if ((HELPER ? helper : !digit_step) && win < 32 * N / W) {
-            b = u.v[0] & ((1u << W) - 1u);
+        if constexpr (HELPER) {
+            if (helper && win < 32 * N / W) {
+                b = u.v[0] & ((1u << W) - 1u);
 #pragma unroll
-            for (int l = 0; l < N - 1; ++l) u.v[l] = (u.v[l] >> W) | (u.v[l + 1] << (32 - W));
-            u.v[N - 1] >>= W;
-            if (b != 0) load_aff(G, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
+                for (int l = 0; l < N - 1; ++l) u.v[l] = (u.v[l] >> W) | (u.v[l + 1] << (32 - W));
+                u.v[N - 1] >>= W;
+                if (b != 0) load_aff(G, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
+            }
+        } else {
+            // (round 5) no helper quad: the comb point of a window is asked for one step AHEAD -- during the addition of the step
+            // before it -- instead of directly in front of its own addition (2N trips to a 64 MiB table on a lone wavefront)
+            constexpr bool AHEAD = LANES == 2 || N != 8;       // measured: pairs -5.5 %, wide quads -2..-3 %, 256-bit quads +1 % (worse)
+            if (!AHEAD) {
+                if (!digit_step) {
+                    b = u.v[0] & ((1u << W) - 1u);
+#pragma unroll
+                    for (int l = 0; l < N - 1; ++l) u.v[l] = (u.v[l] >> W) | (u.v[l + 1] << (32 - W));
+                    u.v[N - 1] >>= W;
+                    if (b != 0) load_aff(G, gtab + ((size_t)win * (1u << W) + b) * (N / 2));
+                }
+            } else if (!digit_step) { G = Gn; b = bn; }
+            if (AHEAD && it >= 1 && it - 1 < 32 * N / W) {
+                const int wn = 32 * N / W - 1 - (it - 1);
+                bn = u.v[0] & ((1u << W) - 1u);
+#pragma unroll
+                for (int l = 0; l < N - 1; ++l) u.v[l] = (u.v[l] >> W) | (u.v[l + 1] << (32 - W));
+                u.v[N - 1] >>= W;
+                if (bn != 0) load_aff(Gn, gtab + ((size_t)wn * (1u << W) + bn) * (N / 2));
+            }
         }
         bool have = b != 0;
         if (digit_step && !helper) {                // a digit of v: 4 doublings, then +- |d| Q from the LDS table
@@ -710,6 +795,8 @@ void bign_inv_kernel(size_t n, size_t lanes, int K, VerifyScratch S)
 {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= lanes) return;
+    if constexpr (N != 8) {
+    // (the wider curves: loads in front of their use, as in rounds 1-4 -- asking ahead did not pay there, profiles/r05_ask_ahead_ab.txt)
     uint32_t *Z = S.u, *PZ = S.qz;
     feT<N> acc, z;
     fe_set_one(acc);
@@ -740,6 +827,53 @@ void bign_inv_kernel(size_t n, size_t lanes, int K, VerifyScratch S)
         fe_mul<1, VtOps>(zi, z, zi);
         fe_canon(zi, zi);
         store_soa(S.rx, S.n_pad, idx, zi);
+    }
+    } else {
+    uint32_t *Z = S.u, *PZ = S.qz;
+    // (round 5: every load is asked for one step ahead of the multiplication that needs it -- this kernel is a few lone wavefronts,
+    //  valu_busy 0.30, and its loads used to sit directly in front of their use)
+    feT<N> acc, z, zn, pn, xn;
+    fe_set_one(acc);
+    const auto pending = [&](int t) { const size_t i = (size_t)t * lanes + j; return t >= 0 && t < K && i < n && S.status[i] == ST_PENDING; };
+    if (pending(0)) load_soa(zn, Z, S.n_pad, j);
+#pragma unroll 1
+    for (int t = 0; t < K; ++t) {
+        const size_t idx = (size_t)t * lanes + j;
+        if (idx >= n) break;
+        const bool mine = S.status[idx] == ST_PENDING;
+        z = zn;
+        if (pending(t + 1)) load_soa(zn, Z, S.n_pad, idx + lanes);
+        if (mine) fe_mul<1, VtOps>(acc, acc, z);
+        store_soa(PZ, S.n_pad, idx, acc);             // product of the pending Z up to and including t
+    }
+    feT<N> inv = fe_inv_checked(acc);
+    const auto ask = [&](int t) {                      // operands of step t: the product up to t - 1, Z_t, X_t
+        const size_t i = (size_t)t * lanes + j;
+        if (t > 0) { load_soa(pn, PZ, S.n_pad, i - lanes); load_soa(zn, Z, S.n_pad, i); }
+        load_soa(xn, S.rx, S.n_pad, i);
+    };
+    int t = K - 1;
+    while (t >= 0 && !pending(t)) --t;
+    if (t >= 0) ask(t);
+#pragma unroll 1
+    while (t >= 0) {
+        const size_t idx = (size_t)t * lanes + j;
+        const feT<N> p = pn, x = xn;
+        z = zn;
+        int nt = t - 1;
+        while (nt >= 0 && !pending(nt)) --nt;
+        if (nt >= 0) ask(nt);
+        feT<N> zi = inv;
+        if (t > 0) {
+            fe_mul<1, VtOps>(zi, inv, p);                       // 1 / Z_t
+            fe_mul<1, VtOps>(inv, inv, z);                      // 1 / (product up to t - 1)
+        }
+        fe_sqr<1, VtOps>(zi, zi);
+        fe_mul<1, VtOps>(zi, x, zi);
+        fe_canon(zi, zi);
+        store_soa(S.rx, S.n_pad, idx, zi);
+        t = nt;
+    }
     }
 }
 

@@ -799,6 +799,7 @@ def main():
         free, _ = torch.cuda.mem_get_info()
         if free < nbytes + (1 << 30):
             nbytes = (int(free * 0.5) // (1 << 20)) << 20
+        nbytes = int(round(-dist.max(-float(nbytes))))             # one stream length for all ranks (the strong leg cuts ONE stream)
         buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         fill_seeded(buf, 0xBE17 + dist.rank)
         nb = nbytes // 16
@@ -1228,6 +1229,7 @@ def main():
         free, _ = torch.cuda.mem_get_info()
         while n_all * (ml + 72) + (2 << 30) > free and n_all > 1024:
             n_all //= 2
+        n_all = int(round(-dist.max(-float(n_all))))               # the same job on every rank (the strong legs are collective): the smallest
         n = min(n, n_all)
         msgs = torch.empty(n_all * ml, dtype=torch.uint8, device="cuda")
         fill_seeded(msgs, 0x4D1C + dist.rank)

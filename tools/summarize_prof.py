@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
-DST = os.path.join(ROOT, "profiles")
+DST = os.environ.get("PROF_DST", os.path.join(ROOT, "profiles"))     # (on the GPU box: a directory under gpurun_out/, copied into profiles/ afterwards)
 
 
 def short(name):
@@ -60,7 +60,7 @@ def main(tag):
     # per-kernel HBM traffic for bench.py's roofline.traffic (pmc_traffic() replays it, labelled with file + commit)
     import subprocess
     try:
-        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+        commit = os.environ.get("PROF_COMMIT") or subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
     except Exception:
         commit = "?"
     kernels = {}
