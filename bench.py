@@ -144,6 +144,12 @@ def event_ms(fn, steps, warmup=2, graph=False):
     """average milliseconds per call of fn(): hipEvents on the launch stream around `steps` calls, after `warmup` untimed ones.
     graph=True: the `steps` calls are captured into ONE hipGraph and the replay is timed -- for launches of a few microseconds,
     where an eager Python loop would measure the host's launch rate (2^17 bashF states: 21 us eager, 17 us on the device)."""
+    # (the chip drops its clock within milliseconds of going idle and needs ~0.2 s of load to come back -- timed() pre-warms the same way;
+    #  without this a 2.5 ms measurement behind an idle phase runs at the idle clock: 127 us per 2^20-state launch instead of 94)
+    t_end = time.perf_counter() + 0.25
+    while time.perf_counter() < t_end:
+        fn()
+        torch.cuda.synchronize()
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -398,8 +404,10 @@ def pmc_traffic(kernel_substr):
 
 
 def pmc_valu(kernel_substr):
-    """valu_busy of a kernel (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles) from the newest committed rocprofv3 --pmc summary: a REPLAY of that
-    profiling run, like `traffic` -- north_star's "VALU integer-op utilisation" beside each fraction"""
+    """valu_busy of a kernel from the newest committed rocprofv3 --pmc summary: a REPLAY of that profiling run, like `traffic` --
+    north_star's "VALU integer-op utilisation" beside each fraction.  valu_busy = SQ_ACTIVE_INST_VALU x 4 / SIMD cycles = the average
+    number of VALU instructions EXECUTING per SIMD: 1.0 = one pipe never idle (the multiply-add / carry kernels, whose classes do not
+    overlap), up to 2.0 where half-rate and full-rate instructions of different wavefronts run side by side (bash-f: 1.75)."""
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_summary.json")))
     for path in reversed(found):

@@ -45,7 +45,7 @@ def main(tag):
         shutil.copy(hb, os.path.join(DST, f"{tag}_kernel_stats_bashF_only.csv"))
     summary = {"command": "rocprofv3 --kernel-trace --stats / --pmc <set> -- python bench.py --steps 20 --warmup 3 --no-cpu "
                           "(PMC passes: --ctr-gib 4; FETCH/WRITE passes: --only bashF,ctr)",
-               "valu_busy": "kernels[*].valu_busy = SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES / 32 shader engines x 1024 SIMDs), pass pmc_sq1",
+               "valu_busy": "kernels[*].valu_busy = SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES / 32 shader engines x 1024 SIMDs), pass pmc_sq1: the average number of VALU instructions executing per SIMD (1.0 = one pipe never idle; up to 2.0 when half- and full-rate instructions of different wavefronts overlap)",
                "note": "counter values are per-launch averages; FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts "
                        "half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM) -> doubled in hbm_bytes_per_launch; "
                        "vgpr_count_rocprof is what rocprofv3 prints, which on gfx950 is HALF the allocated VGPRs "
@@ -75,7 +75,9 @@ def main(tag):
                            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x 2 (gfx950)"}
     # VALU utilisation per kernel from the SQ pass (north_star: "VALU integer-op utilisation"): SQ_ACTIVE_INST_VALU counts, per SIMD, the
     # quad-cycles a VALU instruction is executing; SQ_BUSY_CYCLES is summed over the 32 shader engines (8 XCDs x 4): cycles per SE x 1024
-    # SIMDs are the SIMD-cycles there were.  1.0 = the vector ALUs never idle (bign_main_kernel at four wavefronts per SIMD).
+    # SIMDs are the SIMD-cycles there were.  The counter sums over wavefronts, so it is the average number of VALU instructions
+    # EXECUTING per SIMD: 1.0 = one pipe never idle (bign_main_kernel: multiply-adds and carries do not overlap), up to 2.0 where
+    # half-rate and full-rate instructions of different wavefronts run side by side (bashF_tile_kernel: 1.75).
     sq1, sq2 = summary.get("pmc_sq1", {}), summary.get("pmc_sq2", {})
     for k, v in sq1.items():
         busy, act = v.get("SQ_BUSY_CYCLES"), v.get("SQ_ACTIVE_INST_VALU")
