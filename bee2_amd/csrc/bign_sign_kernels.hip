@@ -968,7 +968,7 @@ void bign_sign_nonce_kernel(const uint8_t *__restrict__ hashes, const uint8_t *_
     status[idx] = ct_sel(d_ok, ST_PENDING, ERR_BAD_PRIVKEY_V);
 
     // ---- theta = belt-hash(oid || d || t) (or taken from the caller: additional input longer than SIGN_T_MAX is
-    // hashed by the streaming belt-hash of the library, capi.hip)
+    // hashed by ONE ragged belt-hash launch over oid || d || t on the bank-private table, capi_bign.hip sign_batch_host)
     uint32_t theta[8];
     if (theta_in) {
 #pragma unroll

@@ -644,7 +644,7 @@ static err_t sign_batch_host(int mode, const bign_params *params, const octet oi
         const WipeGuard wipe_msgs{td, o_th + 32 * n};
         B2H_TRY(h2d(td, msgs.v.data(), n * ml));
         B2H_TRY(h2d(td + o_off, off.data(), 8 * (n + 1)));
-        code = launch_hash_ragged(0, td, td + o_off, nullptr, n, td + o_th, nullptr);
+        code = launch_hash_ragged(0, td, td + o_off, nullptr, n, td + o_th, nullptr, true);     // (bank-private table: the messages hold d)
         if (code != ERR_OK) return code;
         theta.v.resize(32 * n);
         B2H_TRY(d2h(theta.v.data(), td + o_th, 32 * n));

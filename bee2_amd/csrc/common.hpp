@@ -73,7 +73,7 @@ err_t launch_bash_sponge_cols(void *d_state, const void *d_data, size_t nblocks,
 err_t launch_belt_hash_stream(void *d_hs, const void *d_data, size_t nblocks, int fin, uint64_t bits_lo,
                               uint64_t bits_hi, hipStream_t st);
 err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, const void *d_order, size_t n,
-                         void *d_digests, hipStream_t st);
+                         void *d_digests, hipStream_t st, bool secret = false);
 err_t launch_bign_pubkey_val(size_t l, const void *d_pubkeys, size_t n, void *d_codes, hipStream_t st);
 // n signatures under ONE key of a standard curve (bign_kernels.hip "one signer"): pubkey = HOST memory.  Returns
 // ERR_KEY_NOT_ON_CURVE (not a bee2 code; never leaves the library) when the key is not a point of the curve: the caller

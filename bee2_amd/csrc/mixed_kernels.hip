@@ -849,10 +849,22 @@ static int g_ragged_fork = 1;               // long chains and short messages on
 void set_ragged_fork(int v) { g_ragged_fork = v; }
 #endif
 constexpr uint64_t RAGGED_LONG = 4096;     // bytes; see bench.py --only ragged and DESIGN.md 4.7
+// secret (belt-hash only): the messages hold private keys (theta of bignSign2 with long additional input) -- every message, whatever
+// its length, goes through the kernel with the BANK-PRIVATE S-box copies (lane l only touches bank l & 31: the LDS cycles of a look-up
+// do not depend on its index), never through the 4 KiB table whose bank conflicts follow the data
 err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, const void *d_order, size_t n,
-                         void *d_digests, hipStream_t st)
+                         void *d_digests, hipStream_t st, bool secret)
 {
     if (n == 0) return ERR_OK;
+    if (secret) {
+        if (alg != 0) return ERR_BAD_INPUT;
+        const void *kern = reinterpret_cast<const void *>(belt_hash_ragged_kernel<BeltTabTwoP, 256>);
+        B2H_TRY(dyn_lds_once(kern, BeltTabTwo::kBytes));
+        hipLaunchKernelGGL((belt_hash_ragged_kernel<BeltTabTwoP, 256>), dim3((unsigned)((n + 255) / 256)), dim3(256), BeltTabTwo::kBytes, st,
+                           (const uint8_t *)d_data, (const uint64_t *)d_off, (const uint32_t *)nullptr, n, (uint8_t *)d_digests, ~(size_t)0);
+        B2H_TRY(hipGetLastError());
+        return ERR_OK;
+    }
     if (n > 0xffffffffull) return ERR_BAD_INPUT;
     const uint32_t *ord = (const uint32_t *)d_order;
     const dim3 g((unsigned)((n + 63) / 64)), t(64);

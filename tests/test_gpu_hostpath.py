@@ -1,4 +1,4 @@
-"""-m gpu: the drop-in layer's path policy (bee2_amd/csrc/capi.hip "host path for small single calls").
+"""-m gpu: the drop-in layer's path policy (bee2_amd/csrc/staging.hpp "host path for small single calls").
 Default mode: small single calls on the host, large ones and every batch entry point on the GPU; a device failure in the
 middle of a void bee2 function is retried once and then finished on the host (never abort() in auto mode); with
 BEE2HIP_FORCE=gpu the failure is fatal, as in rounds 1-2."""
@@ -206,7 +206,7 @@ def test_reference_test_suite_passes_in_every_mode(mode):
 
 def test_duplex_pipeline_of_large_host_batches_bashF(orc):
     """>= 48 MiB through bee2hip_bashF_batch: chunks uploaded by the caller's thread and downloaded by a helper thread on a
-    second stream (capi.hip duplex_inplace); ragged last chunk; every state against the oracle"""
+    second stream (staging.hpp duplex_inplace); ragged last chunk; every state against the oracle"""
     eng = engine()
     n = (1 << 18) + 4099                       # 51 MB, 17 chunks of 2^14 states, the last one ragged
     data = np.frombuffer(orc.fill(192 * n, 0xD0B1), dtype=np.uint8).copy()

@@ -64,3 +64,12 @@ for _ in range(2):
     assert code == 0 and not any(gc)
     code, gpub, gcodes = eng.bignPubkeyCalc_batch(prm, gp)
     assert code == 0 and not any(gcodes)
+
+# round 5: additional input LONGER than 64 octets -- theta = belt-hash(oid || d || t) for the whole batch by ONE ragged belt-hash launch
+# on the bank-private S-box copies (belt_hash_ragged_kernel<BeltTabTwoP, 256>, launch_hash_ragged(..., secret = true)): the kernel's
+# instruction counters and its LDS bank conflicts (0) must not depend on the key class either
+Pstd = eng.bignParamsStd(E.CURVE_NAME[l])
+tl = orc.fill(100, 0x7A)
+for _ in range(2):
+    code, ls_, lc = eng.bignSign2_batch(Pstd, E.LEVEL_OID[l], gh, gp, tl)
+    assert code == 0 and not any(lc)

@@ -16,7 +16,7 @@ for f in sorted(glob.glob("gpurun_out/ct_dyn/*/b_counter_collection.csv")):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].split("::")[-1]
-        if "sign" not in k and "mulbase" not in k: continue
+        if "sign" not in k and "mulbase" not in k and "belt_hash_ragged" not in k: continue
         d[k][r["Counter_Name"]].append(int(float(r["Counter_Value"])))
     for k, v in d.items():
         tab.setdefault(k, {})[cls] = {c: x[-1] for c, x in v.items()}

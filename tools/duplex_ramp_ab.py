@@ -1,4 +1,4 @@
-"""ramped chunk sizes at the ends of the duplex host pipeline (capi.hip duplex_inplace, bee2hip_internal_tune 9), off / on
+"""ramped chunk sizes at the ends of the duplex host pipeline (staging.hpp duplex_inplace, bee2hip_internal_tune 9), off / on
 alternating: bee2hip_bashF_batch on 2^20 states and the one-shot beltCTR on 1 GiB, host pointers to pageable memory.
 python tools/duplex_ramp_ab.py   (on the GPU)"""
 import ctypes, os, sys, time

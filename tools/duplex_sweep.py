@@ -1,4 +1,4 @@
-"""chunk size of the duplex host pipeline (capi.hip duplex_inplace): bee2hip_bashF_batch on 2^20 states and the one-shot
+"""chunk size of the duplex host pipeline (staging.hpp duplex_inplace): bee2hip_bashF_batch on 2^20 states and the one-shot
 beltCTR on 1 GiB, host pointers (pageable numpy arrays).  python tools/duplex_sweep.py   (on the GPU)"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
