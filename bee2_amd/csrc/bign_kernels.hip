@@ -1928,6 +1928,10 @@ KeyTab::~KeyTab() { if (tab16) { (void)hipFree(tab16); g_keytab16_live.fetch_sub
 static size_t KEYTAB_SLOTS = 1024;                   // (0.3 - 1 GiB of 8-bit tables when full; tests: tune 21)
 void set_onekey_slots(int v) { KEYTAB_SLOTS = v < 1 ? 1 : (size_t)v; }
 static std::unordered_map<std::string, std::shared_ptr<KeyTab>> &g_keytabs = *new std::unordered_map<std::string, std::shared_ptr<KeyTab>>;   // (never destroyed: no hipFree behind the runtime's back at exit)
+// (round 5) the key-table cache has a lock of its own: building a key's tables (host arithmetic, a kernel, a synchronise:
+// 0.2-2 ms) holds it, and general verification -- which takes g_bign_mu to fetch G's table -- no longer waits behind that.  Never nested
+// with g_bign_mu.
+static std::mutex g_keytab_mu;
 static uint64_t g_keytab_clock = 0;
 static std::atomic<unsigned long long> g_keytab_builds{0};
 unsigned long long bign_onekey_table_builds() { return g_keytab_builds.load(); }
@@ -1976,7 +1980,7 @@ static err_t bign_key_tables(std::vector<std::shared_ptr<KeyTab>> &out, const ui
         memcpy(&id[2], key, 2 * NO);
         return id;
     };
-    std::lock_guard<std::mutex> lk(g_bign_mu);
+    std::lock_guard<std::mutex> lk(g_keytab_mu);
     std::vector<size_t> miss;                          // first occurrence of every key the cache does not hold
     std::unordered_map<std::string, size_t> miss_at;   // id -> position in miss
     std::vector<size_t> dup_of(nkeys, (size_t)-1);     // later occurrences of a missing key
@@ -2102,7 +2106,7 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
         // later call's eviction can free memory a replay will read.  Bounded by the distinct keys ever captured.
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
-            std::lock_guard<std::mutex> lk(g_bign_mu);
+            std::lock_guard<std::mutex> lk(g_keytab_mu);
             static std::vector<std::shared_ptr<KeyTab>> &pinned = *new std::vector<std::shared_ptr<KeyTab>>;
             for (const auto &t : kts)
                 if (t && std::find(pinned.begin(), pinned.end(), t) == pinned.end()) pinned.push_back(t);
@@ -2114,7 +2118,7 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
     if (!keyed) {
         if (!kts[0]) return ERR_KEY_NOT_ON_CURVE;                  // (the caller's general path)
         {
-            std::lock_guard<std::mutex> lk(g_bign_mu);             // another thread may be giving the key its 16-bit table
+            std::lock_guard<std::mutex> lk(g_keytab_mu);             // another thread may be giving the key its 16-bit table
             tab16 = kts[0]->tab16;
         }
         d_keys = kts[0]->d_key;
@@ -2124,7 +2128,7 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
         std::vector<uint8_t> blk(koff + 2 * NO * nkeys);
         uint64_t *ptrs = reinterpret_cast<uint64_t *>(blk.data());
         {
-            std::lock_guard<std::mutex> lk(g_bign_mu);             // (another thread may be giving a key its 16-bit table)
+            std::lock_guard<std::mutex> lk(g_keytab_mu);             // (another thread may be giving a key its 16-bit table)
             for (size_t k = 0; k < nkeys; ++k) {
                 ptrs[k] = kts[k] ? (uint64_t)(uintptr_t)kts[k]->tab : 0;
                 ptrs[nkeys + k] = kts[k] ? (uint64_t)(uintptr_t)kts[k]->tab16 : 0;

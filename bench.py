@@ -777,8 +777,16 @@ def main():
             diag["weak_efficiency"] = value / (N * diag["solo_value"])
         rates["bashF_perms_per_s"] = n / (ms_launch * 1e-3)      # per GPU, kernel time: what the mixed roofline's parts use
         if not args.headline_only:
-            # (launches of 17-94 us: total and shares both as replays of a captured graph of K launches, no host launch gaps)
-            strong_leg("bashF", n, lambda lo, hi: (lambda: eng.bashF_batch_dev(st[192 * lo: 192 * hi])), K, graph=True)
+            bash_unit = lambda lo, hi: (lambda: eng.bashF_batch_dev(st[192 * lo: 192 * hi]))  # noqa: E731
+            strong_leg("bashF", n, bash_unit, K, t_total_ms=ms_launch if N == 1 else None)
+            if N == 1:
+                # A 2^17-state share is a 17 us kernel: an eager Python loop measures the host's launch rate there (~21 us per step),
+                # which is also what the N > 1 strong legs will see.  The DEVICE side of the same split: the shares as replays of a
+                # captured graph of K launches (no host in the loop) against the headline's event-timed launch (device-bound at 94 us).
+                for g, m in strong_shares(n).items():
+                    t_dev = event_ms(bash_unit(0, m), K, graph=True)
+                    strong[f"strong_ms_share{g}_bashF_device"] = t_dev
+                    strong[f"strong_pred_{g}_bashF_device"] = ms_launch / t_dev
         # the same kernel on a batch that cannot sit in the 256 MiB Infinity Cache: 2^22 states = 768 MiB read + written
         # per launch; reported as flat keys next to the cache-resident headline
         if not args.headline_only:

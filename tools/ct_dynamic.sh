@@ -15,7 +15,7 @@ for f in sorted(glob.glob("gpurun_out/ct_dyn/*/b_counter_collection.csv")):
     cls = f.split("/")[2]
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].split("::")[-1]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("bee2hip::", "")
         if "sign" not in k and "mulbase" not in k and "belt_hash_ragged" not in k: continue
         d[k][r["Counter_Name"]].append(int(float(r["Counter_Value"])))
     for k, v in d.items():
