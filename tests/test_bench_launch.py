@@ -138,7 +138,7 @@ def test_bench_line_keeps_every_fraction_in_the_first_flat_keys():
     # the strong (fixed-N) reading predicted from this one GPU: t(total) / t(total / 8), with the 2- and 4-way splits and the times
     # behind them further down the object; a split can never be predicted to beat 8x, and the HBM- / LDS-bound stream must be near it
     for w in ("bashF", "ctr", "verify", "mixed"):
-        assert 1.0 < rf[f"strong_pred_2_{w}"] <= 2.05 and rf[f"strong_pred_2_{w}"] < rf[f"strong_pred_4_{w}"] < rf[f"strong_pred_8_{w}"] <= 9.0, w      # (a share can run at a better clock / cache residency than the total: CTR 8.6)
+        assert 1.0 < rf[f"strong_pred_2_{w}"] <= 2.3 and rf[f"strong_pred_2_{w}"] < rf[f"strong_pred_4_{w}"] < rf[f"strong_pred_8_{w}"] <= 9.0, w      # (a share can run at a better clock / cache residency than the total: CTR 8.6)
         assert rf[f"strong_ms_total_{w}"] > rf[f"strong_ms_share8_{w}"] > 0
     assert "WEAK" in d["config"]["parallelism"] and "strong_pred" in d["config"]["parallelism"]
     cbk = list(d["cpu_baseline"])
