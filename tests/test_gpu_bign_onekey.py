@@ -353,6 +353,55 @@ def test_onekey_entry_replays_from_a_hip_graph(orc):
         assert np.array_equal(got, want), (part, np.nonzero(got != want)[0][:5])
 
 
+def test_captured_graph_survives_the_eviction_of_its_key(orc):
+    """a stream capture bakes the key's table addresses into the graph, and the table cache drops its least recently used
+    keys.  With a cache of TWO keys (tune 21) the captured key is pushed out by eight other signers, device memory of the tables' size
+    is allocated and overwritten in between -- the replay must still give the right verdicts: tables a capture referred to are pinned."""
+    eng = exp_engine()
+    tune = eng.lib.bee2hip_internal_tune
+    l, n = 128, 3000
+    pub, H, S = _signed_under_one_key(eng, orc, l, 2 * n, 0xCA97)
+    dh = torch.empty(32 * n, dtype=torch.uint8, device="cuda"); ds = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
+    codes = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    cap = torch.cuda.Stream()
+
+    def load(part, damage):
+        Sp = S[part * n:(part + 1) * n].copy()
+        Sp[damage, 9] ^= 0x08
+        with torch.cuda.stream(cap):
+            dh.copy_(torch.from_numpy(H[part * n:(part + 1) * n].reshape(-1).copy()).cuda())
+            ds.copy_(torch.from_numpy(Sp.reshape(-1)).cuda())
+        cap.synchronize()
+    try:
+        tune(21, 2)
+        load(0, [])
+        with torch.cuda.stream(cap):
+            eng.bignVerifyL_onekey_batch_dev(l, E.LEVEL_OID[l], dh, ds, pub, codes)      # eager: the key's table
+        cap.synchronize()
+        assert not codes.any()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=cap):
+            eng.bignVerifyL_onekey_batch_dev(l, E.LEVEL_OID[l], dh, ds, pub, codes)
+        builds0 = eng.lib.bee2hip_internal_stat(3)
+        for k in range(8):                                   # eight other signers: the cache holds two
+            pk, Hk, Sk = _signed_under_one_key(eng, orc, l, 64, 0xD000 + 7 * k)
+            assert not _onekey_dev(eng, l, Hk, Sk, pk).any()
+        assert eng.lib.bee2hip_internal_stat(3) - builds0 == 8
+        junk = [torch.full((300 << 10,), 0xFF, dtype=torch.uint8, device="cuda") for _ in range(64)]   # what a freed 278 KiB table would be reused for
+        torch.cuda.synchronize()
+        for part, damage in ((1, [5, 2999]), (0, [0, 17])):
+            load(part, damage)
+            codes.fill_(-1)
+            graph.replay()
+            torch.cuda.synchronize()
+            got = codes.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            want = np.zeros(n, dtype=np.int64); want[damage] = 510
+            assert np.array_equal(got, want), (part, np.nonzero(got != want)[0][:5])
+        del junk
+    finally:
+        tune(21, 1024)
+
+
 @pytest.mark.parametrize("l", [128, 192, 256])
 @pytest.mark.parametrize("quads", [1, 0])
 def test_onekey_one_and_four_lanes_per_signature(orc, l, quads):
