@@ -1980,7 +1980,10 @@ static err_t bign_key_tables(std::vector<std::shared_ptr<KeyTab>> &out, const ui
         memcpy(&id[2], key, 2 * NO);
         return id;
     };
-    std::lock_guard<std::mutex> lk(g_keytab_mu);
+    //  entries that leave the cache are parked here and released AFTER the lock is dropped (declared before the lock:
+    // destroyed after it): their destructors call hipFree, a device-wide wait, and every other key-table user would stall behind it
+    std::vector<std::shared_ptr<KeyTab>> dropped;
+    std::unique_lock<std::mutex> lk(g_keytab_mu);
     std::vector<size_t> miss;                          // first occurrence of every key the cache does not hold
     std::unordered_map<std::string, size_t> miss_at;   // id -> position in miss
     std::vector<size_t> dup_of(nkeys, (size_t)-1);     // later occurrences of a missing key
@@ -2001,6 +2004,15 @@ static err_t bign_key_tables(std::vector<std::shared_ptr<KeyTab>> &out, const ui
         miss.push_back(k);
     }
     if (!miss.empty()) {
+        {
+            // a key this process has not met needs an allocation, an upload and a synchronisation: none of that is legal on a stream
+            // that is being captured (and would kill the capture).  Say so instead: verify once under the key outside the capture.
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
+                return hip_fail(hipErrorStreamCaptureUnsupported, "key-table miss under stream capture: verify once under each key before capturing");
+            }
+            (void)hipGetLastError();
+        }
         // on the curve?  then the 2N + 1 starting points -- host threads when there are many keys
         std::vector<std::vector<uint8_t>> base(miss.size());
         std::vector<char> on_curve(miss.size(), 0);
@@ -2030,19 +2042,52 @@ static err_t bign_key_tables(std::vector<std::shared_ptr<KeyTab>> &out, const ui
             if (g_keytabs.empty()) return false;
             auto old = g_keytabs.begin();
             for (auto it = g_keytabs.begin(); it != g_keytabs.end(); ++it) if (it->second->stamp < old->second->stamp) old = it;
+            dropped.push_back(std::move(old->second));
             g_keytabs.erase(old);
             return true;
+        };
+        // The BYTE bound evicts by slab: a slab's memory returns only when ALL of its (<= 16) tables are gone and nobody
+        // holds one, so the unit that leaves is the idle slab whose most recent use is the oldest; when no idle slab is left the loop
+        // stops -- it never empties the cache without freeing a byte.  Returns the bytes that will be freed once `dropped` is released.
+        size_t pending_free = 0;
+        const auto evict_idle_slab = [&]() -> size_t {
+            struct Seen { uint64_t newest = 0; bool busy = false; };
+            std::unordered_map<const KeySlab *, Seen> slabs;
+            for (const auto &kv : g_keytabs) {
+                Seen &e = slabs[kv.second->slab.get()];
+                e.newest = std::max(e.newest, kv.second->stamp);
+                e.busy |= kv.second.use_count() != 1;       // a launcher (or a captured graph) holds this table
+            }
+            const KeySlab *victim = nullptr;
+            uint64_t oldest = ~(uint64_t)0;
+            for (const auto &kv : slabs) if (kv.first && !kv.second.busy && kv.second.newest < oldest) { oldest = kv.second.newest; victim = kv.first; }
+            if (!victim) return 0;
+            const size_t bytes = victim->bytes;
+            for (auto it = g_keytabs.begin(); it != g_keytabs.end();)
+                if (it->second->slab.get() == victim) { dropped.push_back(std::move(it->second)); it = g_keytabs.erase(it); } else ++it;
+            return bytes;
         };
         for (size_t g0 = 0; g0 < good.size(); g0 += KEYSLAB_KEYS) {
             const size_t M = std::min(KEYSLAB_KEYS, good.size() - g0);
             const size_t need = M * (TAB + AUX);
-            while (g_keyslab_bytes.load() + need > KEYTAB_BYTES_MAX && evict_lru()) {}
+            while (g_keyslab_bytes.load() - std::min(pending_free, g_keyslab_bytes.load()) + need > KEYTAB_BYTES_MAX) {
+                const size_t freed = evict_idle_slab();
+                if (!freed) break;
+                pending_free += freed;
+            }
             auto slab = std::make_shared<KeySlab>();
             if (hipMalloc(&slab->p, need) != hipSuccess) {
                 (void)hipGetLastError();
                 slab->p = nullptr;
-                // no room on the device: everything nobody is using right now goes, then one more try
-                for (auto it = g_keytabs.begin(); it != g_keytabs.end();) it = it->second.use_count() == 1 ? g_keytabs.erase(it) : std::next(it);
+                // no room on the device: everything nobody is using right now goes -- released HERE, with the lock dropped, because the
+                // retry needs the memory back now -- then one more try.  (Another thread may cache one of this call's keys meanwhile:
+                // the assignment below then replaces its entry, which is harmless.)
+                for (auto it = g_keytabs.begin(); it != g_keytabs.end();)
+                    if (it->second.use_count() == 1) { dropped.push_back(std::move(it->second)); it = g_keytabs.erase(it); } else ++it;
+                lk.unlock();
+                dropped.clear();
+                pending_free = 0;
+                lk.lock();
                 if (hipMalloc(&slab->p, need) != hipSuccess) {
                     (void)hipGetLastError();
                     slab->p = nullptr;

@@ -79,8 +79,10 @@ struct Pool {
             // (BEE2HIP_FAKE_DEVICES, or a caller who cuts one card's data into several shards) run side by side instead of
             // taking turns on the card's NULL stream
             if (bind == ERR_OK && (hipStreamCreateWithFlags(&t_wstream, hipStreamNonBlocking) != hipSuccess ||
-                                   hipEventCreateWithFlags(&t_wevent, hipEventDisableTiming) != hipSuccess))
+                                   hipEventCreateWithFlags(&t_wevent, hipEventDisableTiming) != hipSuccess)) {
                 bind = hip_fail(hipGetLastError(), "worker stream");
+                if (t_wstream) { (void)hipStreamDestroy(t_wstream); t_wstream = nullptr; }     // (the stream went when the event could not be had)
+            }
             for (;;) {
                 std::unique_lock<std::mutex> lk(k->mu);
                 k->cv.wait(lk, [k] { return k->has_job; });
@@ -336,8 +338,11 @@ static inline err_t worker_stream(hipStream_t *st)
 }
 static inline err_t drain(err_t code)
 {
-    if (code != ERR_OK) return code;
-    B2H_TRY(hipStreamSynchronize(t_wstream));
+    // ALWAYS drained: when the launcher reports an error, kernels it had already queued on the worker's private stream may
+    // still be reading or writing the caller's shards -- the caller cannot name that stream, so the call must not return before it is idle
+    const hipError_t e = hipStreamSynchronize(t_wstream);
+    if (code != ERR_OK) { (void)hipGetLastError(); return code; }
+    B2H_TRY(e);
     return ERR_OK;
 }
 #define B2H_WSTREAM(st) hipStream_t st = nullptr; { const err_t c_ = worker_stream(&st); if (c_ != ERR_OK) return c_; }

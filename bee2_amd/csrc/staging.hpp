@@ -544,7 +544,7 @@ static err_t duplex_inplace(octet *host, octet *dev, size_t unit_bytes, size_t u
     const size_t inject_at = g_duplex_fail_times.load() > 0 && g_duplex_fail_times.fetch_sub(1) > 0 ? (size_t)g_duplex_fail_chunk.load() : 0;
 #endif
     // (a launcher may throw -- its scratch bookkeeping allocates: the helper thread is told, joined and both streams are drained
-    //  as on every other path before the exception goes on to the entry point's catch)
+    //  as on every other path, *done_units is set, and the exception becomes the error code the entry point would have made of it)
     std::exception_ptr thrown;
     try {
     for (size_t c = 0; c < nch && !failed.load(); ++c) {
@@ -575,7 +575,11 @@ static err_t duplex_inplace(octet *host, octet *dev, size_t unit_bytes, size_t u
     if (done_units) *done_units = failed.load() ? cut[done] : units;
     for (size_t c = 0; c < 2 * nch; ++c) (void)hipEventDestroy(ev[c]);
     ev_guard.armed = false;
-    if (thrown) std::rethrow_exception(thrown);
+    if (thrown) {
+        //  the exception does NOT go on past the done_units contract: callers apply *done_units (advance the counter, skip
+        // the chunks that are back) on an error CODE; an exception would skip that and a host fallback would transform them twice
+        try { std::rethrow_exception(thrown); } catch (...) { return caught(); }
+    }
     if (failed.load()) {
         (void)hipGetLastError();
         return code != ERR_OK ? code : hip_fail((hipError_t)first_err.load(), "duplex staging");

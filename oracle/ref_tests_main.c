@@ -35,6 +35,9 @@ extern bool_t beltBench(void);
 extern bool_t bignBench(void);
 extern const char bash_platform[];
 extern void bashF(unsigned char block[192], void *stack);   /* include/bee2/crypto/bash.h:136 */
+/* include/bee2hip.h: how many drop-in calls went to the host path (0), to a kernel (1), finished on the host after a GPU
+   failure (2).  Weak: absent in testbee2_ref (the control, linked against the reference alone). */
+extern unsigned long long bee2hip_path_count(int which) __attribute__((weak));
 
 static const struct {
 	const char *key, *label;
@@ -74,10 +77,25 @@ int main(int argc, char **argv)
 			want |= !strcmp(argv[a], mods[m].key);
 		if (!want)
 			continue;
+		struct timespec m0, m1;
+		unsigned long long h0 = 0, g0 = 0;
+		if (bee2hip_path_count)
+			h0 = bee2hip_path_count(0), g0 = bee2hip_path_count(1);
+		clock_gettime(CLOCK_MONOTONIC, &m0);
 		bool_t code = mods[m].fn();
+		clock_gettime(CLOCK_MONOTONIC, &m1);
 		printf("%s: %s\n", mods[m].label, code ? "OK" : "Err");
+		/* per module: wall time and where the drop-in calls went (tests/test_gpu_reftests.py asserts host = 0 under BEE2HIP_FORCE=gpu) */
+		if (bee2hip_path_count)
+			printf("%s: wall %.1f ms, drop-in calls: host %llu, gpu %llu\n", mods[m].label,
+				(m1.tv_sec - m0.tv_sec) * 1e3 + (m1.tv_nsec - m0.tv_nsec) * 1e-6,
+				bee2hip_path_count(0) - h0, bee2hip_path_count(1) - g0);
+		else
+			printf("%s: wall %.1f ms\n", mods[m].label, (m1.tv_sec - m0.tv_sec) * 1e3 + (m1.tv_nsec - m0.tv_nsec) * 1e-6);
 		fflush(stdout);
 		ret |= !code;
 	}
+	if (bee2hip_path_count)
+		printf("path counts: host %llu gpu %llu fallback %llu\n", bee2hip_path_count(0), bee2hip_path_count(1), bee2hip_path_count(2));
 	return ret;
 }

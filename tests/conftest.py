@@ -9,6 +9,15 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
         sys.path.insert(0, p)
 
 
+def hostshim_san_flags():
+    """extra g++ flags for the host-path shims (tests/hostshim/*.cpp = bee2_amd/csrc/host_*.hpp, product code): empty by default;
+    tests/test_host_sanitizers.py re-runs the host-path modules with BEE2_HOSTSHIM_SAN=address,undefined (and the sanitizer
+    runtime preloaded into the interpreter), the way the reference builds its ASan / check configurations
+    (/root/reference/CMakeLists.txt:94-101,126-132)"""
+    san = os.environ.get("BEE2_HOSTSHIM_SAN", "")
+    return ["-g", "-fno-omit-frame-pointer", f"-fsanitize={san}", "-fno-sanitize-recover=all"] if san else []
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "ref: needs oracle/_ref (the reference compiled in the build container)")

@@ -107,57 +107,126 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     assert r.returncode != 0 and "refusing" in r.stderr
 
 
-# what the driver's record must keep: the FIRST 24 keys of `roofline` (BENCH_r04.json: it cuts the object after 24 entries) --
-# every rate and fraction, the strong-split predictions (N = 1) / speedups (N > 1), then the N > 1 diagnostics
-FIRST_16 = ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_2p22", "beltCTR_GiBps", "beltCTR_frac", "beltCTR_lds_frac",
-            "bignVerify_sigs_per_s", "bignVerify_frac", "mixed_msgs_per_s", "mixed_frac", "strong_pred_8_bashF", "strong_pred_8_ctr")
-NEXT_8 = ("strong_pred_8_verify", "strong_pred_8_mixed", "n_ranks_seen", "n_devices_distinct", "weak_efficiency", "solo_value",
-          "clock_ghz_min", "clock_ghz_max")
+# what the driver's record must keep: `roofline` = 24 flat scalars in a fixed order (bench_legs/line.py) -- the headline kernel's
+# figures, the three other BASELINE rates with their fractions, the 8-way strong split (predicted at N = 1, measured at N > 1),
+# ranks / devices seen -- inside ONE strict-JSON line of at most 8000 characters (the record keeps 8081 characters of stdout)
+ROOFLINE_24_N1 = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms",
+                  "beltCTR_GiBps", "beltCTR_frac", "bignVerify_sigs_per_s", "bignVerify_frac", "mixed_msgs_per_s", "mixed_frac",
+                  "strong_pred_8_bashF", "strong_pred_8_ctr", "strong_pred_8_verify", "strong_pred_8_mixed",
+                  "n_ranks_seen", "n_devices_distinct", "valu_busy", "frac_2p22", "beltCTR_lds_frac", "weak_efficiency")
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline", "cpu_baseline")
+LINE_MAX = 8000
 
 
-@pytest.mark.gpu
-def test_bench_line_keeps_every_fraction_in_the_first_flat_keys():
-    """the driver's record keeps `roofline` and `cpu_baseline` but drops nested objects and everything after ~24 entries:
-    the three BASELINE rates, configs[4]'s rate and all their fractions must be flat scalars among the first 16 keys
-    (short run: 1 GiB stream, 3 steps, 2 s CPU legs are part of the same code)"""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "BEE2_BENCH_BACKEND")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                        "--only", "bashF,ctr,verify,mixed", "--ctr-gib", "1"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["metric"] == "bashF perms/s" and d["n_gpus"] == 1
-    keys = list(d["roofline"])
-    assert tuple(keys[:16]) == FIRST_16 and tuple(keys[16:24]) == NEXT_8, keys[:24]
-    for k in FIRST_16:
-        if k not in ("bound", "unit"):
-            assert isinstance(d["roofline"][k], (int, float)), k
+def _strict(s):
+    """json.loads that refuses NaN / Infinity (json.dumps' default would print them; a strict parser then drops the line)"""
+    def no(c):
+        raise ValueError(f"non-strict JSON constant {c}")
+    return json.loads(s, parse_constant=no)
+
+
+def _last_line(stdout):
+    lines = stdout.rstrip("\n").split("\n")
+    return lines[-1]
+
+
+def _check_line_shape(raw, n):
+    assert len(raw) <= LINE_MAX, len(raw)
+    d = _strict(raw)
+    for k in CONTRACT_KEYS:
+        assert k in d, k
+    want = tuple(k.replace("strong_pred_8_", "strong_speedup_") for k in ROOFLINE_24_N1) if n > 1 else ROOFLINE_24_N1
+    assert tuple(list(d["roofline"])[:24]) == want, list(d["roofline"])[:24]
     for k, v in d["roofline"].items():                 # flat: no nested object, no prose beyond the kernel's name
         assert not isinstance(v, (dict, list)), k
         assert not isinstance(v, str) or len(v) <= 60, k
+    for k, v in d["cpu_baseline"].items():
+        assert not isinstance(v, (dict, list)), k
+        assert not isinstance(v, str) or len(v) <= 120, k
+    assert isinstance(d["config"].get("workload"), str) and "model" not in d["config"]
+    return d
+
+
+@pytest.mark.parametrize("n", [1, 8])
+def test_line_is_strict_json_under_8000_characters_with_the_contract_keys(n):
+    """the LAST stdout line of an N-rank run, built by the very code the real run uses
+    (bench_legs/line.py) from stand-in numbers of the real magnitudes, parses strictly, is short enough for the driver's record and
+    carries the contract's keys with `roofline`'s 24 scalars in order.  N = 8 is the rehearsal of the first real 8-GPU launch: eight
+    gloo ranks, a mocked list of eight distinct devices under RCCL's one-rank-per-GPU rule, the shares of the four fixed jobs adding up."""
+    env = {"BEE2_BENCH_MOCK_DEVICES": ",".join(str(i) for i in range(n)), "BEE2_BENCH_MOCK_BACKEND": "nccl"} if n > 1 else {}
+    r = _run(["--gpus", str(n), "--launch-selftest"], env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    raw = _last_line(r.stdout)
+    d = _check_line_shape(raw, n)
+    assert d["n_gpus"] == n and d["roofline"]["n_ranks_seen"] == n and d["roofline"]["n_devices_distinct"] == n
+    assert d["roofline"]["strong_items_bashF"] == 1 << 20 and d["roofline"]["strong_items_ctr"] == 1 << 30
+    assert d["roofline"]["strong_items_verify"] == 1 << 18 and d["roofline"]["strong_items_mixed"] == 1 << 24
+    if n > 1:
+        assert d["cpu_baseline"]["value"] is None and "N=1 only" in d["cpu_baseline"]["sample"]
+        assert set(d["ranks"]) >= {"solo_value", "weak_efficiency", "clock_ghz_min", "clock_ghz_max"}
+        # eight ranks on seven cards: refused under RCCL's rule
+        r = _run(["--gpus", "8", "--launch-selftest"], {"BEE2_BENCH_MOCK_DEVICES": "0,1,2,3,4,5,6,6", "BEE2_BENCH_MOCK_BACKEND": "nccl"}, timeout=600)
+        assert r.returncode != 0 and "8 ranks on 7 distinct device" in r.stderr
+
+
+def test_line_builder_refuses_non_finite_numbers_and_oversize_lines():
+    from bench_legs import line as L
+    res = {"metric": "m", "value": float("nan"), "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": float("inf"),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic", "config": {"workload": "w"},
+           "roofline": {"bound": "hbm", "achieved": 1.0, "peak": 2.0, "unit": "GB/s", "frac": 0.5, "traffic": None, "kernel": "k" * 500}}
+    ln, detail = L.build(res, {}, {}, {}, 1, 1, 1, 1000.0)
+    s = L.dumps(ln)
+    d = _strict(s)
+    assert d["value"] is None and d["ms_per_step"] is None and len(d["roofline"]["kernel"]) <= 60
+    assert tuple(d["roofline"]) == ROOFLINE_24_N1
+    json.dumps(detail, allow_nan=False)
+    ln["config"]["workload"] = "x" * 9000
+    with pytest.raises(AssertionError):
+        L.dumps(ln)
+    # numbers keep 8 significant digits, integers stay exact
+    assert L.clean(402653184) == 402653184 and L.clean(0.123456789123) == 0.12345679
+
+
+@pytest.mark.gpu
+def test_bench_line_on_the_gpu_is_short_strict_and_complete():
+    """the real thing, short: the four BASELINE legs on 1 GiB of stream, 3 steps; the LAST stdout line is the contract's line (<= 8000
+    characters, strict JSON), the figures are in range, and the full record is in gpurun_out/bench_detail.json"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "BEE2_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--ctr-gib", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _check_line_shape(_last_line(r.stdout), 1)
+    assert d["metric"] == "bashF perms/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     rf = d["roofline"]
-    # the strong (fixed-N) reading predicted from this one GPU: t(total) / t(total / 8), with the 2- and 4-way splits and the times
-    # behind them further down the object; a split can never be predicted to beat 8x, and the HBM- / LDS-bound stream must be near it
-    for w in ("bashF", "ctr", "verify", "mixed"):
-        assert 1.0 < rf[f"strong_pred_2_{w}"] <= 2.3 and rf[f"strong_pred_2_{w}"] < rf[f"strong_pred_4_{w}"] < rf[f"strong_pred_8_{w}"] <= 9.0, w      # (a share can run at a better clock / cache residency than the total: CTR 8.6)
-        assert rf[f"strong_ms_total_{w}"] > rf[f"strong_ms_share8_{w}"] > 0
-    assert "WEAK" in d["config"]["parallelism"] and "strong_pred" in d["config"]["parallelism"]
-    cbk = list(d["cpu_baseline"])
-    assert cbk[:11] == ["value", "unit", "cores", "kind", "sample", "single_thread", "scaling_over_single_thread", "spin_scaling", "cpu_count",
-                        "affinity", "cgroup_quota_cpus"], cbk
-    assert d["cpu_baseline"]["cores"] <= d["cpu_baseline"]["affinity"] <= d["cpu_baseline"]["cpu_count"]
-    assert rf["n_ranks_seen"] == 1 and rf["n_devices_distinct"] == 1 and rf["bignVerify_verdicts_ok"] is True
-    assert rf["weak_efficiency"] is None and rf["solo_value"] is None           # N = 1: nothing to compare with
-    for k in ("frac", "beltCTR_frac", "beltCTR_lds_frac", "bignVerify_frac", "mixed_frac", "mixed_frac_sum_of_parts"):
+    for k in ROOFLINE_24_N1:
+        if k not in ("bound", "unit", "kernel", "traffic", "valu_busy", "weak_efficiency"):
+            assert isinstance(rf[k], (int, float)), k
+    assert rf["weak_efficiency"] is None                   # N = 1: nothing to compare with
+    assert rf["traffic"] is None or rf["traffic"] > 0      # replayed only when the committed PMC pass profiled this very launch
+    for k in ("frac", "beltCTR_frac", "beltCTR_lds_frac", "bignVerify_frac", "mixed_frac", "frac_2p22"):
         assert 0 < rf[k] < 1.05, (k, rf[k])
-    assert rf["clock_ghz_min"] and 1.0 < rf["clock_ghz_min"] <= rf["clock_ghz_max"] < 2.6
-    assert rf["per_rank_value_min"] == rf["per_rank_value_max"] > 1e9
-    # configs[4] has a roofline of its own now (SURVEY 8d row 4)
-    mr = d["others"]["bash512_beltMAC"]["roofline"]
+    for w in ("bashF", "ctr", "verify", "mixed"):          # a split can never be predicted to beat 8x by much (a share can run at a better clock)
+        assert 1.0 < rf[f"strong_pred_8_{w}"] <= 9.0, w
+    assert abs(rf["achieved"] - 384 * (1 << 20) / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 1e-3 * rf["achieved"]
+    assert rf["n_ranks_seen"] == 1 and rf["n_devices_distinct"] == 1
+    cb = d["cpu_baseline"]
+    assert list(cb)[:5] == ["value", "unit", "cores", "kind", "sample"] and cb["kind"] in ("reference", "port")
+    for k in ("value", "cores", "single_thread", "beltCTR_GiBps", "bignVerify_sigs_per_s", "mixed_msgs_per_s"):
+        assert isinstance(cb[k], (int, float)), k
+    assert cb["cores"] <= cb["cpu_count"]
+    # one figure per line before the JSON line
+    assert sum(1 for l in r.stdout.splitlines() if l.startswith("[bench] ")) >= 4
+    det = json.load(open(os.path.join(ROOT, d["detail"])))
+    st = det["strong"]
+    for w in ("bashF", "ctr", "verify", "mixed"):
+        assert 1.0 < st[f"strong_pred_2_{w}"] <= 2.3 and st[f"strong_pred_2_{w}"] < st[f"strong_pred_4_{w}"] < st[f"strong_pred_8_{w}"] <= 9.0, w
+        assert st[f"strong_ms_total_{w}"] > st[f"strong_ms_share8_{w}"] > 0
+    assert det["others"]["bignVerify"]["verdicts_as_expected"] is True
+    mr = det["others"]["bash512_beltMAC"]["roofline"]
     assert mr["bound"] == "valu-int+lds" and mr["peak"] >= mr["sum_of_parts_ceiling"] > 0 and mr["work_per_message"]["perms"] == 65
-    # the VALU figure is labelled as the model it is, at the measured clock
-    assert "valu_frac" not in rf and d["others"]["bashF_detail"]["valu"]["clock_measured"] is True
-    for k in ("value", "cores", "beltCTR_GiBps", "bignVerify_sigs_per_s", "mixed_msgs_per_s"):
-        assert isinstance(d["cpu_baseline"][k], (int, float)), k
+    assert det["others"]["bashF_detail"]["valu"]["clock_measured"] is True
+    assert det["headline"]["host_api"]["value"] > 0
 
 
 @pytest.mark.gpu
@@ -170,22 +239,20 @@ def test_bench_gpus_2_on_one_device_runs_two_ranks_and_explains_itself():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    d = json.loads(lines[0])
+    d = _check_line_shape(_last_line(r.stdout), 2)
     rf = d["roofline"]
     assert d["n_gpus"] == 2 and rf["n_ranks_seen"] == 2 and d["scaling"] == "weak"
     assert rf["n_devices_distinct"] == 1
-    first24 = tuple(k.replace("strong_pred_8_", "strong_speedup_") for k in FIRST_16 + NEXT_8)     # N > 1: measured speedups in the same slots
-    assert tuple(list(rf)[:24]) == first24, list(rf)[:24]
     # the strong split on two ranks that share ONE card: the same total in two halves side by side -- about 1x (the documented value
     # of this rehearsal; 2x needs a second card); what matters here is that every workload reports it and the rates are consistent
+    st = json.load(open(os.path.join(ROOT, d["detail"])))["strong"]
     for w in ("bashF", "ctr", "verify", "mixed"):
         assert 0.5 < rf[f"strong_speedup_{w}"] < 2.2, (w, rf[f"strong_speedup_{w}"])
-        assert abs(rf[f"strong_value_{w}"] / rf[f"strong_solo_value_{w}"] - rf[f"strong_speedup_{w}"]) < 1e-6
-    assert rf["solo_value"] > 1e9 and 0.35 < rf["weak_efficiency"] < 0.75, rf["weak_efficiency"]
-    assert 0 < rf["per_rank_value_min"] <= rf["per_rank_value_max"]
-    assert rf["clock_ghz_min"] and rf["clock_ghz_max"]
-    # the N > 1 default is the four BASELINE workloads
-    assert set(d["others"]) >= {"beltCTR", "bignVerify", "bash512_beltMAC"} and "single_call_latency_us" not in d["others"]
+        assert abs(st[f"strong_value_{w}"] / st[f"strong_solo_value_{w}"] - st[f"strong_speedup_{w}"]) < 1e-6
+    rk = d["ranks"]
+    assert rk["solo_value"] > 1e9 and 0.35 < rf["weak_efficiency"] < 0.75, rf["weak_efficiency"]
+    assert 0 < rk["per_rank_value_min"] <= rk["per_rank_value_max"]
+    assert rk["clock_ghz_min"] and rk["clock_ghz_max"]
     assert rf["mixed_frac"] and rf["bignVerify_frac"]
     assert d["cpu_baseline"]["value"] is None and "N=1 only" in d["cpu_baseline"]["sample"]
 

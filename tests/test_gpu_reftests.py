@@ -45,13 +45,38 @@ def test_reference_tests_bind_the_hot_path_to_the_hip_library():
     assert bound["beltBlockEncr2"] == {"libbee2hip.so"} and bound["beltKeyExpand2"] == {"libbee2hip.so"}
 
 
+PATHS = re.compile(r"^path counts: host (\d+) gpu (\d+) fallback (\d+)$", re.M)
+PER_MODULE = re.compile(r"^(\w+): wall ([\d.]+) ms, drop-in calls: host (\d+), gpu (\d+)$", re.M)
+
+
 @pytest.mark.gpu
-def test_reference_test_suite_passes_through_the_dropin():
-    r = subprocess.run([BIN], capture_output=True, text=True, timeout=1200)
+@pytest.mark.parametrize("force", [None, "gpu"])
+def test_reference_test_suite_passes_through_the_dropin(force):
+    """bee2's acceptance suite (test/test.c:43-173 -> test/crypto/belt_test.c:178-215,423-472, bash_test.c:41-154, bign_test.c:338-400, ...)
+    through the drop-in, twice: as a caller gets the library (KAT-sized calls take the host path by size), and under
+    BEE2HIP_FORCE=gpu, where EVERY drop-in call must have gone to a kernel -- bee2hip_path_count(0) == 0 -- so the STB vectors are
+    checked against the kernels themselves, not against host_small.hpp.  Per-module wall times are recorded."""
+    env = dict(os.environ)
+    env.pop("BEE2HIP_FORCE", None)
+    if force:
+        env["BEE2HIP_FORCE"] = force
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=1800, env=env)
     assert "bash_platform = BASH_HIP" in r.stdout, r.stdout + r.stderr
     for m in MODULES:
         assert f"{m}: OK" in r.stdout, r.stdout + r.stderr[-2000:]
     assert r.returncode == 0 and "Err" not in r.stdout
+    host, gpu, fallback = (int(x) for x in PATHS.search(r.stdout).groups())
+    per = {m.group(1): (float(m.group(2)), int(m.group(3)), int(m.group(4))) for m in PER_MODULE.finditer(r.stdout)}
+    assert set(per) == set(MODULES) and fallback == 0
+    if force == "gpu":
+        assert host == 0 and gpu > 1000, (host, gpu)          # nothing took the host path; the suite makes thousands of drop-in calls
+        for m in MODULES:
+            assert per[m][1] == 0 and per[m][2] > 0, (m, per[m])
+    else:
+        assert host > 0                                       # the default: KAT-sized calls run on the calling core
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"r06_reftests_{force or 'auto'}.txt"), "w") as f:
+        f.write(f"oracle/_ref/testbee2_hip (bee2's own test/crypto/*_test.c linked -lbee2hip first), BEE2HIP_FORCE={force or '(unset)'}\n" + r.stdout)
 
 
 # bee2's bench lines the library is ALLOWED to lose against the reference on the same box (each is named in INTEGRATION.md

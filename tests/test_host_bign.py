@@ -10,6 +10,8 @@ import subprocess
 
 import pytest
 
+from conftest import hostshim_san_flags
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 C = {128: 189, 192: 317, 256: 569}
 
@@ -17,7 +19,7 @@ C = {128: 189, 192: 317, 256: 569}
 @pytest.fixture(scope="module")
 def hb(tmp_path_factory, orc):
     out = tmp_path_factory.mktemp("hostshim") / "libhostbign.so"
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wextra", "-Werror", "-o", str(out),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wextra", "-Werror"] + hostshim_san_flags() + ["-o", str(out),
                            os.path.join(ROOT, "tests", "hostshim", "host_bign_shim.cpp")])
     lib = ctypes.CDLL(str(out))
     lib.hb_verify.restype = ctypes.c_uint32

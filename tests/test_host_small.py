@@ -9,13 +9,15 @@ import subprocess
 
 import pytest
 
+from conftest import hostshim_san_flags
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
 def hs(tmp_path_factory, orc):
     out = tmp_path_factory.mktemp("hostshim") / "libhostshim.so"
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wextra", "-Werror", "-o", str(out),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wextra", "-Werror"] + hostshim_san_flags() + ["-o", str(out),
                            os.path.join(ROOT, "tests", "hostshim", "host_small_shim.cpp")])
     lib = ctypes.CDLL(str(out))
     lib.hs_init(orc.beltH())
