@@ -392,7 +392,7 @@ err_t launch_bashF_batch(void *d_states, size_t n, hipStream_t st)
 #define TILEF(L, S, O, W, F) launch_bashF_tile<L, S, O, W, F>((unsigned)grid, p, n, st)
     // Variants kept for the A/B record (profiles/r02_bashF_variants.txt lists every one that was measured; the
     // numbers there name them as below).  Product = default.
-#ifdef BEE2HIP_EXPERIMENTS      // the A/B record only (tools/ab_lib.sh builds it); the product library holds ONE instantiation
+#ifdef BEE2HIP_EXPERIMENTS      // the A/B record only (tools/ab/ab_lib.sh builds it); the product library holds ONE instantiation
     switch (v) {
     case 0: hipLaunchKernelGGL(bashF_batch_kernel<1>, dim3((unsigned)grid), dim3(BASHF_WG), lds4, st, p, n); break;   // r01 product
     case 1: TILE(1, 1, 1, 3); break;         // LDS-DMA load, slab store, r01 staged order

@@ -172,7 +172,7 @@ struct BeltTabTwo {
     }
 };
 
-// EXPERIMENT (round 3; tools/belt_ab.py variants 10 / 11, profiles/r03_belt_hybrid.txt): the two-table
+// EXPERIMENT (round 3; tools/ab/belt_ab.py variants 10 / 11, profiles/r03_belt_hybrid.txt): the two-table
 // LDS layout for most G-boxes, and every G-box for which `via_l1<R0, SLOT>()` says so looked up through the vector L1
 // instead -- four rotated tables of 256 dwords in global memory (4 KiB, L1-resident), one global_load_dword per byte
 // with the table selector in the immediate offset -- so that TA/TCP cycles run beside the LDS pipe.  Not the product.
@@ -203,7 +203,7 @@ struct BeltTabHyb : BeltTabTwo {
     }
 };
 
-// EXPERIMENT (round 3, tools/belt_ab.py variant 15, profiles/r03_belt_sdwa_ab.txt): the two-table layout with every LDS address
+// EXPERIMENT (round 3, tools/ab/belt_ab.py variant 15, profiles/r03_belt_sdwa_ab.txt): the two-table layout with every LDS address
 // made by ONE instruction.  The address is (byte << 8) | lane_base with lane_base < 128: byte 1 of a register whose other
 // bytes hold lane_base for good.  v_mov_b32_sdwa with dst_sel:BYTE_1 and dst_unused:UNUSED_PRESERVE drops byte k of x there
 // (half rate: the cycles of the shift + v_bitop3 pair it replaces, one issue slot instead of two).  Each G-box position of
@@ -340,7 +340,7 @@ struct BeltTabSmall {
     }
 };
 
-// EXPERIMENT (round 4, tools/long_hash_ab.py form 4): BeltTabSmall with each look-up address made by ONE instruction,
+// EXPERIMENT (round 4, tools/ab/long_hash_ab.py form 4): BeltTabSmall with each look-up address made by ONE instruction,
 // v_lshlrev_b32_sdwa (byte k of x, shifted by 2), instead of extract + shift -- one dependent instruction less on a chain that is
 // bound by dependent latency (profiles/r04_long_hash_ab.txt).  Same table, same bank behaviour.
 struct BeltTabSmallS : BeltTabSmall {

@@ -713,7 +713,7 @@ err_t launch_belt_ctr_blocks(void *d_buf, size_t nblocks, const uint32_t key[8],
     BeltKey k; BeltCtr c;
     for (int i = 0; i < 8; ++i) k.k[i] = key[i];
     for (int i = 0; i < 4; ++i) c.c[i] = ctr0[i];
-#ifdef BEE2HIP_EXPERIMENTS      // the A/B record (tools/belt_ab.py; built by tools/ab_lib.sh only)
+#ifdef BEE2HIP_EXPERIMENTS      // the A/B record (tools/ab/belt_ab.py; built by tools/ab/ab_lib.sh only)
     switch (g_ctr_variant) {          // A/B only (bee2hip_internal_tune(1, v)); 0 = the product
     case 1: return launch_ctr_t<BeltTabTwo, 2>(d_buf, nblocks, k, c, first, d_last_gamma, st);
     case 2: return launch_ctr_t<BeltTabTwo, 3>(d_buf, nblocks, k, c, first, d_last_gamma, st);

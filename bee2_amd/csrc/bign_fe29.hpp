@@ -95,81 +95,109 @@ __device__ __forceinline__ void f29_set_one(lzT<N> &r)
     for (int i = 0; i < LZ<N>::L; ++i) r.l[i] = i == 0;
 }
 
-// c[0 .. 2L) (c[k] in [0, u) for k < 2L - 1, the last one signed) -> r = K (lo + 2^(B L) hi), N; K may be a per-lane value
-template <int N>
-__device__ __forceinline__ void f29_fold_k(lzT<N> &r, const int32_t (&c)[2 * LZ<N>::L], int32_t K, bool k_is_one)
+// ---- multiplication (round 6: two carry chains, the fold inside the low one) -------------------------------------
+// r = a b:  phase A  columns L .. 2L-2 on their own chain, from zero -> h[0 .. L-2] masked, h[L-1] = the rest (signed, < 2^31);
+//           phase B  columns 0 .. L-1: acc = carry + sum a[i] b[k-i] + h[k] FOLD -> r[k] = acc & M, carry = acc >> B;
+//           final    the carry out of column L-1 (weight 2^(B L) again, up to 34 bits) times FOLD into r[0], r[1].
+// The 256-bit curve takes the same steps as ONE inline-asm block (bign_fe29_asm.inc, generated by tools/gen_f29_asm.py, which says
+// why: the C++ below compiles to ~165 instructions per multiplication, the block is 135); the wider curves (14 / 19 limbs: more
+// operands than an asm statement may have) run this C++.  tools/fe29_bounds.py replays the order on intervals.
+template <int N, bool SQ>
+__device__ __forceinline__ void f29_mul2(lzT<N> &r, const lzT<N> &a, const lzT<N> &b)
 {
     constexpr int L = LZ<N>::L, B = LZ<N>::B;
-    const int32_t KF = K * LZ<N>::FOLD;                // <= 8 * 81152
-    int64_t cy = 0;
+    constexpr int32_t M = lzT<N>::M, F = LZ<N>::FOLD;
+    int32_t h[L], d[L], o[L];
+    if constexpr (SQ) {
 #pragma unroll
-    for (int j = 0; j < L; ++j) {
-        int64_t t = (int64_t)c[L + j] * KF + cy;
-        if (k_is_one) t += c[j];
-        else t += (int64_t)c[j] * K;
-        r.l[j] = (int32_t)t & lzT<N>::M;
-        cy = t >> B;
+        for (int i = 0; i < L; ++i) d[i] = a.l[i] * 2;
     }
-    // |cy| < 2^21: its weight is 2^(B L) again
-    const int64_t t0 = (int64_t)r.l[0] + cy * LZ<N>::FOLD;
-    r.l[0] = (int32_t)t0 & lzT<N>::M;
-    r.l[1] += (int32_t)(t0 >> B);
-}
-
-template <int N>
-__device__ __forceinline__ void f29_product(int32_t (&c)[2 * LZ<N>::L], const lzT<N> &a, const lzT<N> &b)
-{
-    constexpr int L = LZ<N>::L, B = LZ<N>::B;
-    int64_t acc = 0;
-    static_for<0, 2 * L - 1>([&](auto kc) __attribute__((always_inline)) {
+    const auto column = [&](int64_t &acc, auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         static_for<(k > L - 1 ? k - (L - 1) : 0), (k < L - 1 ? k : L - 1) + 1>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
-            acc += (int64_t)a.l[i] * b.l[k - i];
+            constexpr int j = k - i;
+            if constexpr (!SQ) acc += (int64_t)a.l[i] * b.l[j];
+            else if constexpr (i < j) acc += (int64_t)a.l[i] * d[j];
+            else if constexpr (i == j) acc += (int64_t)a.l[i] * a.l[i];
         });
-        c[k] = (int32_t)acc & lzT<N>::M;
+    };
+    int64_t acc = 0;
+    static_for<L, 2 * L - 1>([&](auto kc) __attribute__((always_inline)) {
+        column(acc, kc);
+        h[decltype(kc)::value - L] = (int32_t)acc & M;
         acc >>= B;
     });
-    c[2 * L - 1] = (int32_t)acc;
+    h[L - 1] = (int32_t)acc;
+    acc = 0;
+    static_for<0, L>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        column(acc, kc);
+        acc += (int64_t)h[k] * F;
+        o[k] = (int32_t)acc & M;
+        acc >>= B;
+    });
+    // c = cl + 2^B ch, |c| < 2^34: cl FOLD < 2^42 -> its low B bits into r[0] (carried once more), the rest and ch FOLD into r[1]
+    const int32_t cl = (int32_t)acc & M, ch = (int32_t)(acc >> B);
+    const int64_t t = (int64_t)cl * F;
+    const int32_t r0 = o[0] + ((int32_t)t & M);
+    o[1] += (int32_t)(t >> B) + ch * F + (int32_t)((uint32_t)r0 >> B);
+    o[0] = r0 & M;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r.l[i] = o[i];
 }
+// r <- K r, K in {1, 2, 3, 4, 8} (may differ per lane): N in (l[1] a little over u), N out
+template <int N>
+__device__ __forceinline__ void f29_scale(lzT<N> &r, int32_t K)
+{
+    constexpr int L = LZ<N>::L, B = LZ<N>::B;
+    constexpr int32_t M = lzT<N>::M, F = LZ<N>::FOLD;
+    int64_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        cy += (int64_t)r.l[i] * K;
+        r.l[i] = (int32_t)cy & M;
+        cy >>= B;
+    }
+    const int32_t r0 = r.l[0] + (int32_t)cy * F;          // |cy| <= 8: its weight is 2^(B L)
+    r.l[1] += r0 >> B;
+    r.l[0] = r0 & M;
+}
+#include "bign_fe29_asm.inc"
 
 template <int K = 1, int N>
 __device__ __forceinline__ void f29_mul(lzT<N> &r, const lzT<N> &a, const lzT<N> &b)
 {
-    int32_t c[2 * LZ<N>::L];
-    f29_product(c, a, b);
-    f29_fold_k(r, c, K, K == 1);
+    lzT<N> t;
+    if constexpr (N == 8 && K == 1) f29_mul9_asm(t, a, b);
+    else if constexpr (N == 8) f29_mul9k_asm(t, a, b, K);
+    else {
+        f29_mul2<N, false>(t, a, b);
+        if constexpr (K != 1) f29_scale(t, K);
+    }
+    r = t;
 }
 // r = K a b with a per-lane K in {1, 2, 3, 4, 8}
 template <int N>
 __device__ __forceinline__ void f29_mul_k(lzT<N> &r, const lzT<N> &a, const lzT<N> &b, int32_t K)
 {
-    int32_t c[2 * LZ<N>::L];
-    f29_product(c, a, b);
-    f29_fold_k(r, c, K, false);
+    lzT<N> t;
+    if constexpr (N == 8) f29_mul9k_asm(t, a, b, K);
+    else { f29_mul2<N, false>(t, a, b); f29_scale(t, K); }
+    r = t;
 }
 
 template <int K = 1, int N>
 __device__ __forceinline__ void f29_sqr(lzT<N> &r, const lzT<N> &a)
 {
-    constexpr int L = LZ<N>::L, B = LZ<N>::B;
-    int32_t c[2 * L], d[L];
-#pragma unroll
-    for (int i = 0; i < L; ++i) d[i] = a.l[i] * 2;
-    int64_t acc = 0;
-    static_for<0, 2 * L - 1>([&](auto kc) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
-        static_for<(k > L - 1 ? k - (L - 1) : 0), (k < L - 1 ? k : L - 1) + 1>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int j = k - i;
-            if constexpr (i < j) acc += (int64_t)a.l[i] * d[j];
-            else if constexpr (i == j) acc += (int64_t)a.l[i] * a.l[i];
-        });
-        c[k] = (int32_t)acc & lzT<N>::M;
-        acc >>= B;
-    });
-    c[2 * L - 1] = (int32_t)acc;
-    f29_fold_k(r, c, K, K == 1);
+    lzT<N> t;
+    if constexpr (N == 8 && K == 1) f29_sqr9_asm(t, a);
+    else if constexpr (N == 8) f29_sqr9k_asm(t, a, K);
+    else {
+        f29_mul2<N, true>(t, a, a);
+        if constexpr (K != 1) f29_scale(t, K);
+    }
+    r = t;
 }
 
 // any |l[i]| < 4 u -> N x 32-bit words, weakly reduced (a value in [0, 2^(32N)) congruent to the residue), exactly

@@ -1703,7 +1703,7 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
     //   <= 2^16           : one lane per signature, 29-bit limbs (at most one wavefront per SIMD: instruction count)
     //   above             : one lane per signature, 32-bit limbs (the throughput form)
     int path = 1;
-    if constexpr (N == 8) path = g_verify_path ? g_verify_path : n <= ((size_t)1 << 15) ? 3 : n <= ((size_t)1 << 16) ? 2 : 1;
+    if constexpr (N == 8) path = g_verify_path ? g_verify_path : n <= ((size_t)1 << 15) ? 3 : n <= ((size_t)1 << 18) ? 2 : 1;   // (round 6: the 29-bit kernel's multiplication is one asm block now -- it beats the 32-bit kernels up to 2^18: profiles/r06_f29_asm_ab.txt)
     // wider curves, quads only: up to 2^14 signatures they leave one wavefront per SIMD; up to 2^15 two, which costs twice
     // the time (2.4 / 4.7 ms) and still beats the one-lane kernels' latency floor (3.4 / 6.7 ms, profiles/r03_verify_wide.txt)
     else path = g_verify_path == 1 || g_verify_path == 3 ? g_verify_path : n <= ((size_t)1 << 15) ? 3 : 1;
@@ -1724,7 +1724,7 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
         if (lanes != 2) {
             // up to 2^13 signatures a helper quad per signature takes the comb of u off the main quad's chain (x1.05, x1.10
             // at 2^13).  Four-wave blocks, because wavefronts of a block share a CU's instruction fetches and this
-            // kernel is long; around 2^12 one-wave blocks spread over all CUs win (tools/verify_helper_ab.py).
+            // kernel is long; around 2^12 one-wave blocks spread over all CUs win (tools/ab/verify_helper_ab.py).
             const bool helper = g_verify_lanes >= 8 || (g_verify_lanes == 0 && n <= ((size_t)1 << 13));
             const bool one_wave = g_verify_lanes == 9 || (g_verify_lanes != 10 && n > ((size_t)3 << 10) && n <= ((size_t)1 << 12));
             if (helper && one_wave) code = launch(bign_quad29_kernel<N, 64, 8>, 64, 8);
@@ -1737,7 +1737,7 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
         if (code != ERR_OK) return code;
     }
     if (path != 3) {
-        // The MAIN kernel takes its multiply-adds in pairs (VtOpsP, bign_dev.hpp mac2) where that pays -- measured, tools/verify_pairs_ab.py,
+        // The MAIN kernel takes its multiply-adds in pairs (VtOpsP, bign_dev.hpp mac2) where that pays -- measured, tools/ab/verify_pairs_ab.py,
         // profiles/r04_mad_pairs_vt.txt: the 384- / 512-bit curves up to 2^16 signatures (ONE wavefront per SIMD: 2.85 -> 2.14 ms and
         // 6.26 -> 4.82 ms at 2^16), the 256-bit curve from 2^18 on (four wavefronts: +0.8 % at 2^18, +1.7 % at 2^19); at two wavefronts
         // per SIMD the paired form loses 2-5 % on every curve, and points / prep do not care.  g_verify_pairs: -1 by size, 0 never, else always (A/B).
@@ -1772,7 +1772,7 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
     // signature) and a lone wavefront issues at about a third of a SIMD's rate, so fewer, longer lanes cost
     // little until the lanes no longer cover the SIMDs: measured best at 2^18 signatures K = 8 on the 256-bit
     // curve (72 us; K = 2: 105 us) and K = 4 on the wider ones (profiles/r01_bign_ab_inv.txt)
-    // (round 4, tools/inv_lanes_ab.py: with the division-step inversion the optimum is flat; up to 2^17 signatures on the 256-bit curve 2^16
+    // (round 4, tools/ab/inv_lanes_ab.py: with the division-step inversion the optimum is flat; up to 2^17 signatures on the 256-bit curve 2^16
     //  lanes -- one wavefront per SIMD, two signatures each -- are 4-7 % ahead of 2^15; profiles/r04_inv_lanes_ab.txt)
     const size_t inv_lanes = g_inv_lanes_log2 > 0 ? (size_t)1 << g_inv_lanes_log2 : N == 8 && n > ((size_t)1 << 17) ? 32768 : 65536;
     const size_t k_inv = std::min<size_t>(16, std::max<size_t>(1, n / inv_lanes));
@@ -2219,7 +2219,7 @@ static err_t launch_bign_verify_onekey_t(const uint8_t *oid_der, size_t oid_len,
                            kts[0]->tab, (const uint4 *)nullptr, (const uint32_t *)nullptr, (const uint4 *const *)nullptr, 1u);
     hipLaunchKernelGGL(bign_slow_kernel<N>, dim3(g64), dim3(64), 0, st, dsg, d_keys, n, S, keyed ? ~(size_t)0 : (size_t)0);
     // shared inversions and the hash tail: as launch_bign_verify_t
-    // (round 4, tools/inv_lanes_ab.py: with the division-step inversion the optimum is flat; up to 2^17 signatures on the 256-bit curve 2^16
+    // (round 4, tools/ab/inv_lanes_ab.py: with the division-step inversion the optimum is flat; up to 2^17 signatures on the 256-bit curve 2^16
     //  lanes -- one wavefront per SIMD, two signatures each -- are 4-7 % ahead of 2^15; profiles/r04_inv_lanes_ab.txt)
     const size_t inv_lanes = g_inv_lanes_log2 > 0 ? (size_t)1 << g_inv_lanes_log2 : N == 8 && n > ((size_t)1 << 17) ? 32768 : 65536;
     const size_t k_inv = std::min<size_t>(16, std::max<size_t>(1, n / inv_lanes));

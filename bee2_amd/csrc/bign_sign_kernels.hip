@@ -1237,15 +1237,15 @@ static err_t sign_scratch(hipStream_t st, size_t n, SignScratch &S)
 // k G by one lane per scalar (throughput) or by 64 / 16 / 4 lanes per scalar (latency; each form fills the device -- one
 // wavefront per SIMD -- at 2^10 / 2^12 / 2^14 scalars).  g_sign_lanes: 0 = by batch size; 1 / 102 / 101 = always one lane
 // (signed 6-bit windows with Jacobian mixed additions / with complete additions / unsigned 4-bit windows), 4 / 16 / 64 forced
-// (bee2hip_internal_tune 10).  tools/sign_coop_ab.py measures all six at every size on the three curves
+// (bee2hip_internal_tune 10).  tools/ab/sign_coop_ab.py measures all six at every size on the three curves
 // (profiles/r03_sign_coop.txt): 64 lanes up to 2^10 scalars, 16 up to 2^13, 4 up to 2^15, one lane above.
 static int g_sign_lanes = 0;
 void set_sign_coop(int v) { g_sign_lanes = v; }
 // (round 4) 8 / 7 = one lane per scalar with the window's entry looked up in LDS (bign_mulbase_lds_kernel: 256-bit curve only,
 // workgroups of 1024 lanes; signed 8-bit windows and 16 copies of the row -- the product -- or signed 7-bit windows and 32
 // copies): from 3 * 2^16 scalars on, where its one round of <= 256 workgroups (0.63 ms) beats the scanning kernel's 256-lane
-// blocks (0.55 ms at 2^17, 0.97 ms at 2^18: tools/sign_lds_ab.py)
-constexpr size_t MULBASE_LDS_MIN = (size_t)3 << 14, MULBASE_LDS_512_MAX = (size_t)1 << 17;   // (512-lane workgroups from 3 * 2^14 scalars: tools/sign_lds_ab.py)
+// blocks (0.55 ms at 2^17, 0.97 ms at 2^18: tools/ab/sign_lds_ab.py)
+constexpr size_t MULBASE_LDS_MIN = (size_t)3 << 14, MULBASE_LDS_512_MAX = (size_t)1 << 17;   // (512-lane workgroups from 3 * 2^14 scalars: tools/ab/sign_lds_ab.py)
 constexpr bool LDS_XYZZ = false;       // accumulator of the 7-bit LDS form: Jacobian (8M + 3S).  XYZZ (8M + 2S, one more coordinate) measured: +-0 % (profiles/r04_sign_lds.txt)
 template <int N>
 static inline int mulbase_lanes(size_t n)
@@ -1305,7 +1305,7 @@ static void launch_mulbase(int lanes, const uint8_t *scalars, size_t n, uint32_t
     if (lanes == 64 || lanes == 16 || lanes == 4)
         hipLaunchKernelGGL((bign_mulbase_coop_kernel<N>), dim3((unsigned)((n * (size_t)lanes + 63) / 64)), dim3(64), 0, st, scalars, n,
                            codes, out, tab, MODE, (int)X_ONLY, lanes);
-#ifdef BEE2HIP_EXPERIMENTS      // second opinions of the tests and the A/B record (tools/sign_coop_ab.py)
+#ifdef BEE2HIP_EXPERIMENTS      // second opinions of the tests and the A/B record (tools/ab/sign_coop_ab.py)
     else if (lanes == 101)
         hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 0>), g256, dim3(256), 0, st, scalars, n, codes, out, tab, MODE, (int)X_ONLY);
     else if (lanes == 102)
@@ -1367,7 +1367,7 @@ static int g_sign_wg = 0;                                  // bee2hip_internal_t
 void set_sign_wg(int v) { g_sign_wg = v; }
 static inline int sign_wg(size_t n, uint32_t row_words)
 {
-    // ... as long as every CU still gets a workgroup: 2^16 signatures in 64 workgroups of 1024 lose 8 % (tools/sign_wg_ab.py)
+    // ... as long as every CU still gets a workgroup: 2^16 signatures in 64 workgroups of 1024 lose 8 % (tools/ab/sign_wg_ab.py)
     if (n < ((size_t)1 << 17)) return SIGN_WG;
     const int fit = n < ((size_t)1 << 18) ? 512 : 1024;
     const int cap = g_sign_wg == 256 || g_sign_wg == 512 || g_sign_wg == 1024 ? (g_sign_wg < fit ? g_sign_wg : fit) : fit;

@@ -1,7 +1,7 @@
 // capi_exp.hip -- the hooks of include/bee2hip_internal.h: libbee2hip_exp.so only.  Part of the C ABI (capi.hip).
 #ifdef BEE2HIP_EXPERIMENTS      // everything from here to the end of the kernel-timing hook: libbee2hip_exp.so only
 // ============================================================ internal tuning hook ===
-// A/B switch for experiment builds (tools/bashf_ab.py); not part of the product ABI (BEE2HIP_INTERNAL).
+// A/B switch for experiment builds (tools/ab/bashf_ab.py); not part of the product ABI (BEE2HIP_INTERNAL).
 namespace bee2hip { void set_bashF_variant(int v); void set_ctr_variant(int v); void set_verify_path(int v); void set_verify_split(int v); void set_sign_coop(int v); void set_sign_wg(int v); void set_fused_tab(int v); void set_long_hash_form(int v); void set_ragged_fork(int v); void set_verify_pairs(int v); void set_onekey_tab16(int v); void set_onekey_slots(int v); void set_onekey_quads(int v); void set_inv_lanes(int v); }
 extern "C" err_t bee2hip_internal_tune(int key, int value)
 try {

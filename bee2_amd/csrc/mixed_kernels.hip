@@ -844,7 +844,7 @@ void ragged_scatter_kernel(const uint64_t *__restrict__ off, size_t n, unsigned 
 static int g_long_hash_form = 0;
 void set_long_hash_form(int v) { g_long_hash_form = v; }
 #endif
-static int g_ragged_fork = 1;               // long chains and short messages on two queues (0: one queue, the A/B of tools/long_hash_ab.py)
+static int g_ragged_fork = 1;               // long chains and short messages on two queues (0: one queue, the A/B of tools/ab/long_hash_ab.py)
 #ifdef BEE2HIP_EXPERIMENTS
 void set_ragged_fork(int v) { g_ragged_fork = v; }
 #endif
@@ -900,7 +900,7 @@ err_t launch_hash_ragged(size_t alg, const void *d_data, const void *d_off, cons
     } else
         st2 = st;
     if (alg == 0) {
-#ifdef BEE2HIP_EXPERIMENTS      // A/B (tune 16, tools/long_hash_ab.py, profiles/r04_long_hash_ab.txt): the SDWA table in one-wavefront / four-wavefront workgroups
+#ifdef BEE2HIP_EXPERIMENTS      // A/B (tune 16, tools/ab/long_hash_ab.py, profiles/r04_long_hash_ab.txt): the SDWA table in one-wavefront / four-wavefront workgroups
         if (g_long_hash_form == 1) {      // the pair form (round 3's product) at every size
             hipLaunchKernelGGL((belt_hash_long_kernel<BeltTabSmall, 64, 2>), dim3((unsigned)((n * 2 + 63) / 64)), dim3(64), 0, st, data, off, ord, n,
                                dig, RAGGED_LONG);
@@ -1008,7 +1008,7 @@ template <int RW, bool HASH, bool MAC>
 static err_t launch_fused_t(const void *d_msgs, size_t msg_len, size_t n, size_t l, const MacKey &key,
                             void *d_digests, void *d_tags, hipStream_t st)
 {
-#ifdef BEE2HIP_EXPERIMENTS      // A/B only (tools/fused_tab_ab.py): +0.5 %, bash-f's VALU work bounds the kernel
+#ifdef BEE2HIP_EXPERIMENTS      // A/B only (tools/ab/fused_tab_ab.py): +0.5 %, bash-f's VALU work bounds the kernel
     if (MAC && g_fused_tab == 2) return launch_fused_tt<RW, HASH, MAC, BeltTabTwoP>(d_msgs, msg_len, n, l, key, d_digests, d_tags, st);
 #endif
     return launch_fused_tt<RW, HASH, MAC, BeltTabWide>(d_msgs, msg_len, n, l, key, d_digests, d_tags, st);

@@ -220,7 +220,7 @@ struct Scratch {
     int dev = -1;
     // `chain` = the kernel walks the input as one dependent chain on a lane or two (sponge absorption, the belt-hash
     // iteration): there every load is a PCIe round trip on the critical path, and pinned staging only pays below ~2 KiB
-    // (tools/pinned_ab.py: belt-hash of 16 KiB 2.49 ms pinned vs 2.23 ms copied; of 1 KiB 186 vs 200 us)
+    // (tools/ab/pinned_ab.py: belt-hash of 16 KiB 2.49 ms pinned vs 2.23 ms copied; of 1 KiB 186 vs 200 us)
     err_t need(size_t n, bool chain = false)
     {
         int cur = 0;

@@ -33,8 +33,8 @@ err_t bee2hip_debug_feL(size_t l, int op, const void *d_a, const void *d_b, void
 /* one wavefront spins for `us` microseconds on `stream` and writes {shader cycles, 100 MHz ticks} to d_out16:
    the clock the chip sustains under whatever runs beside it */
 err_t bee2hip_internal_clock_probe(void *d_out16, unsigned us, void *stream);
-/* experiment switch (process-wide, not thread-safe): key 0 = bashF batch kernel variant (tools/bashf_ab.py; -1 = product),
-   key 1 = beltCTR kernel variant (tools/belt_ab.py; 0 = product), key 2 = kernels of the 256-bit verification
+/* experiment switch (process-wide, not thread-safe): key 0 = bashF batch kernel variant (tools/ab/bashf_ab.py; -1 = product),
+   key 1 = beltCTR kernel variant (tools/ab/belt_ab.py; 0 = product), key 2 = kernels of the 256-bit verification
    (0 = by batch size, 1 = 32-bit limbs, 2 = 29-bit limbs, 3 = one signature per quad / pair by size, 0x43 = quads,
    0x23 = pairs, 0x83 = quad + helper quad; tests force each) */
 err_t bee2hip_internal_tune(int key, int value);

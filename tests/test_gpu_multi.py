@@ -235,7 +235,7 @@ def test_logical_devices_that_share_a_card_run_side_by_side(orc, golden):
     """the N > 1 library path cannot meet a second card here, so it meets a second QUEUE.  Every pool worker
     launches its _multi_dev job on its own non-blocking stream: four latency-bound shards (2^9 signatures each: 64 wavefronts, a
     chain of 0.36 ms whatever the size, on a chip with 1024 SIMDs) on four logical devices of ONE card must overlap, not take turns as
-    they did on the card's NULL stream (4 x the time of one shard).  Measured (tools/multi_ratio_probe.py): 0.41 ms for one shard, 0.81
+    they did on the card's NULL stream (4 x the time of one shard).  Measured (tools/ab/multi_ratio_probe.py): 0.41 ms for one shard, 0.81
     for four = x2.0 -- the rest is the host side of four workers launching five kernels each; bigger shards (2^12: x2.5) also meet
     in the VALU, which one wavefront of these kernels nearly fills."""
     import time

@@ -36,11 +36,6 @@ class Fe:
         return all(a >= c and b <= d for a, b, c, d in zip(self.lo, self.hi, other.lo, other.hi))
 
 
-def norm(slack0=1 << 20, slack1=1 << 9):
-    """N: l[2..] in [0, u), l[1] within slack1 and l[0] within slack0 of [0, u)"""
-    return Fe([-slack0, -slack1] + [0] * (L - 2), [M + slack0, M + slack1] + [M] * (L - 2))
-
-
 def lazy1():
     """L1: difference of two N values / negated N value"""
     n = norm()
@@ -72,47 +67,83 @@ def _prod(alo, ahi, blo, bhi):
     return min(c), max(c)
 
 
-def _fold(clo, chi, K, what):
-    """f29_fold: c[0..16] in [0, u), c[17] = [clo, chi]"""
-    lo, hi = [0] * L, [0] * L
-    cy_lo = cy_hi = 0
-    for j in range(L):
-        hlo, hhi = (0, M) if j < L - 1 else (clo, chi)
-        t_lo = hlo * FOLD * K + cy_lo + 0
-        t_hi = hhi * FOLD * K + cy_hi + M * K
-        assert -I64 <= t_lo and t_hi < I64, what
-        lo[j], hi[j] = 0, M
-        cy_lo, cy_hi = t_lo >> B, t_hi >> B
-    assert -I32 <= cy_lo and cy_hi < I32 and -I32 <= K * FOLD < I32, f"{what}: the fold carry / scale leaves int32"
-    t0_lo, t0_hi = cy_lo * FOLD, M + cy_hi * FOLD           # int64 in the device code
-    assert -I64 <= t0_lo and t0_hi < I64
-    lo[0], hi[0] = 0, M
-    lo[1], hi[1] = (t0_lo >> B), M + (t0_hi >> B)
-    return Fe(lo, hi)
+def norm(slack0=1 << 20, slack1=1 << 21):
+    """N: l[2..] in [0, u); l[0] within slack0 of [0, u) (f29_carry folds its last carry there), l[1] within slack1 (a
+    multiplication folds the carry out of column L-1 there)"""
+    return Fe([-slack0, -slack1] + [0] * (L - 2), [M + slack0, M + slack1] + [M] * (L - 2))
+
+
+def _column(a, b, k, square, acc_lo, acc_hi, what):
+    for i in range(max(0, k - (L - 1)), min(k, L - 1) + 1):
+        j = k - i
+        if square and i > j:
+            continue
+        if square and i < j:
+            assert -I32 <= 2 * a.lo[j] and 2 * a.hi[j] < I32, f"{what}: a doubled limb leaves int32"
+            p_lo, p_hi = _prod(a.lo[i], a.hi[i], 2 * a.lo[j], 2 * a.hi[j])
+        elif square:
+            p_hi = max(a.lo[i] ** 2, a.hi[i] ** 2)          # a_i^2 >= 0
+            p_lo = 0 if a.lo[i] <= 0 <= a.hi[i] else min(a.lo[i] ** 2, a.hi[i] ** 2)
+        else:
+            p_lo, p_hi = _prod(a.lo[i], a.hi[i], b.lo[j], b.hi[j])
+        acc_lo += p_lo
+        acc_hi += p_hi
+        assert -I64 <= acc_lo and acc_hi < I64, f"{what}: column {k} leaves int64 ({acc_lo / I64:.3f}, {acc_hi / I64:.3f})"
+    return acc_lo, acc_hi
 
 
 def mul(a, b, K=1, what="mul", square=False):
+    """f29_mul2 / bign_fe29_asm.inc, in their order: phase A (columns L .. 2L-2 on a chain of their own), phase B (columns
+    0 .. L-1 with h[k] FOLD), the 34-bit carry out of column L-1 folded into limbs 0 and 1, then the scaling chain (K != 1)"""
     acc_lo = acc_hi = 0
-    for k in range(2 * L - 1):
-        for i in range(max(0, k - (L - 1)), min(k, L - 1) + 1):
-            j = k - i
-            if square and i > j:
-                continue
-            if square and i < j:
-                p_lo, p_hi = _prod(a.lo[i], a.hi[i], 2 * a.lo[j], 2 * a.hi[j])
-            elif square:
-                # a_i^2 >= 0
-                p_hi = max(a.lo[i] ** 2, a.hi[i] ** 2)
-                p_lo = 0 if a.lo[i] <= 0 <= a.hi[i] else min(a.lo[i] ** 2, a.hi[i] ** 2)
-            else:
-                p_lo, p_hi = _prod(a.lo[i], a.hi[i], b.lo[j], b.hi[j])
-            acc_lo += p_lo
-            acc_hi += p_hi
-            assert -I64 <= acc_lo and acc_hi < I64, f"{what}: column {k} leaves int64 ({acc_lo / I64:.3f}, {acc_hi / I64:.3f})"
+    h_lo, h_hi = [], []
+    for k in range(L, 2 * L - 1):
+        acc_lo, acc_hi = _column(a, b, k, square, acc_lo, acc_hi, what)
+        h_lo.append(0)
+        h_hi.append(M)
         acc_lo >>= B
         acc_hi >>= B
-    assert -I32 <= acc_lo and acc_hi < I32, f"{what}: the top column leaves int32"
-    return _fold(acc_lo, acc_hi, K, what)
+    assert -I32 <= acc_lo and acc_hi < I32, f"{what}: the top of the high half leaves int32"
+    h_lo.append(acc_lo)
+    h_hi.append(acc_hi)
+    lo, hi = [0] * L, [M] * L
+    acc_lo = acc_hi = 0
+    for k in range(L):
+        acc_lo, acc_hi = _column(a, b, k, square, acc_lo, acc_hi, what)
+        acc_lo += min(h_lo[k] * FOLD, h_hi[k] * FOLD)
+        acc_hi += max(h_lo[k] * FOLD, h_hi[k] * FOLD)
+        assert -I64 <= acc_lo and acc_hi < I64, f"{what}: low column {k} with its fold term leaves int64"
+        acc_lo >>= B
+        acc_hi >>= B
+    # c = cl + 2^B ch: cl in [0, u), ch = c >> B must be a 24-bit multiplicand (v_mul_i32_i24) and FOLD too
+    ch_lo, ch_hi = acc_lo >> B, acc_hi >> B
+    assert -(1 << 23) <= ch_lo and ch_hi < (1 << 23) and FOLD < (1 << 23), f"{what}: ch / FOLD leave 24 bits"
+    t_hi = M * FOLD                                          # cl FOLD, int64 in the device code
+    r0_hi = M + M                                            # r[0] + low B bits: below 2^31
+    assert r0_hi < I32
+    l1_lo = 0 + 0 + ch_lo * FOLD + 0
+    l1_hi = M + (t_hi >> B) + ch_hi * FOLD + 1
+    assert -I32 <= l1_lo and l1_hi < I32, what
+    lo[1], hi[1] = l1_lo, l1_hi
+    r = Fe(lo, hi)
+    if K != 1:
+        r = scale(r, K, what)
+    return r
+
+
+def scale(a, K, what="scale"):
+    """f29_scale / the _k tail of the asm blocks: t = r[k] K + cy, the carry out of the top limb times FOLD into r[0], one carry step"""
+    lo, hi = [0] * L, [M] * L
+    c_lo = c_hi = 0
+    for i in range(L):
+        t_lo, t_hi = a.lo[i] * K + c_lo, a.hi[i] * K + c_hi
+        assert -I64 <= t_lo and t_hi < I64
+        c_lo, c_hi = t_lo >> B, t_hi >> B
+    assert -(1 << 23) <= c_lo and c_hi < (1 << 23), f"{what}: the scaling carry leaves 24 bits"
+    r0_lo, r0_hi = c_lo * FOLD, M + c_hi * FOLD
+    assert -I32 <= r0_lo and r0_hi < I32, what
+    lo[1], hi[1] = r0_lo >> B, M + (r0_hi >> B)
+    return Fe(lo, hi)
 
 
 def sqr(a, K=1, what="sqr"):
@@ -128,7 +159,7 @@ def carry(a, what="carry"):
         lo[i], hi[i] = 0, M
         c_lo, c_hi = t_lo >> B, t_hi >> B
     lo[0], hi[0] = c_lo * FOLD, M + c_hi * FOLD
-    return Fe(lo, hi)
+    return Fe(lo, hi)                                       # (l[0] within |c| FOLD of [0, u): checked against the contracts by the callers)
 
 
 def to_words_ok(a, what):

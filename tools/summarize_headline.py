@@ -21,7 +21,7 @@ N_CU, N_SE, N_SIMD = 256, 32, 1024
 LEGS = {
     "bashF": ("bashF_tile_kernel", 1 << 20, 384 * (1 << 20)),
     "ctr": ("beltCTR_blocks_kernel", 1 << 30, 32 * (1 << 30)),
-    "verify": ("bign_main_kernel<8", 1 << 18, 148 * (1 << 18)),
+    "verify": ("bign_main29_kernel", 1 << 18, 148 * (1 << 18)),      # (round 6: the 29-bit one-lane kernel carries 2^18)
     "mixed": ("hash_mac_fused_kernel", 1 << 21, (4096 + 72) * (1 << 21)),
 }
 
