@@ -34,6 +34,7 @@
 #include <mutex>
 #include "belt_dev.hpp"
 #include "bign_dev.hpp"
+#include "bign_fe29.hpp"
 #include "common.hpp"
 
 namespace bee2hip {
@@ -654,6 +655,101 @@ void bign_mulbase_ct_kernel(const uint8_t *__restrict__ scalars, size_t n, uint3
     }
 }
 
+// (round 6) The same window walk with the accumulator on nine signed 29-bit limbs (bign_fe29.hpp): the Jacobian mixed addition is
+// 8 multiplications + 3 squarings, each ONE asm block of 135 / 99 instructions with no carry flags, against ~190 / ~150 VALU
+// instructions (a third of them v_addc_co and v_mov) of the 32-bit product-scanning code -- per window 9 400 -> ~6 900 VALU cycles
+// (profiles/r06_sign_l29_ab.txt).  Constant-time as before: the limb arithmetic is masks, shifts and multiply-adds, the digit's
+// entry is looked up in the bank-private LDS copies, sign and "keep" are applied by ct_sel.  The table stays in 32-bit words
+// (converted on load: 2 instructions per limb); the result goes back to words for the fixed-count inversion.
+template <int WB, int WGL>
+__device__ __forceinline__ uint32_t mul_base_ct_lds16_l29(feT<8> &x, feT<8> &y, const uint32_t (&k)[8], const uint4 *__restrict__ tabw,
+                                                          uint4 *s_row, const int x_only)
+{
+    constexpr int N = 8, L = LZ<N>::L;
+    constexpr int W = WinW<N, WB>::W, ENT = WinW<N, WB>::ENT, OW = ENT * N / 2;     // 16-octet words of a row
+    static_assert(OW * 16 % WGL == 0 && WGL % 16 == 0, "the refill covers the row with whole passes of the workgroup");
+    const unsigned tid = threadIdx.x, rep = tid & 15u;
+    uint32_t kk[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) kk[i] = k[i];
+    jac29 J;
+#pragma unroll
+    for (int i = 0; i < L; ++i) { J.X.l[i] = 0; J.Y.l[i] = i == 0; J.Z.l[i] = 0; }
+    uint32_t at_inf = ~0u;
+    uint32_t carry = 0;
+#pragma unroll 1
+    for (int w = 0; w < W; ++w) {
+        __syncthreads();
+        {
+            const uint4 *row = tabw + (size_t)w * OW;
+#pragma unroll
+            for (int i = 0; i < OW * 16 / WGL; ++i) {
+                const unsigned q = (tid >> 4) + (unsigned)(WGL / 16) * i;   // the 16 lanes of a copy-group fetch the same word
+                s_row[q * 16u + rep] = row[q];
+            }
+        }
+        __syncthreads();
+        const uint32_t t = (kk[0] & (uint32_t)(2 * ENT - 1)) + carry;   // 0 .. 2 ENT
+#pragma unroll
+        for (int i = 0; i < N - 1; ++i) kk[i] = __builtin_amdgcn_alignbit(kk[i + 1], kk[i], WB);
+        kk[N - 1] >>= WB;
+        carry = (t + (uint32_t)ENT) >> WB;
+        const uint32_t d = t - (carry << WB);
+        const uint32_t neg = (uint32_t)((int32_t)d >> 31);
+        const uint32_t mag = (d ^ neg) - neg;                           // 0 .. ENT
+        const uint32_t e = (mag - 1u) & (uint32_t)(ENT - 1);            // digit 0 reads entry ENT: looked up, added, not used
+        affT<N> E;
+#pragma unroll
+        for (int l = 0; l < N / 4; ++l) {
+            const uint4 vx = s_row[(e * (N / 2) + l) * 16u + rep], vy = s_row[(e * (N / 2) + N / 4 + l) * 16u + rep];
+            E.x.v[4 * l] = vx.x; E.x.v[4 * l + 1] = vx.y; E.x.v[4 * l + 2] = vx.z; E.x.v[4 * l + 3] = vx.w;
+            E.y.v[4 * l] = vy.x; E.y.v[4 * l + 1] = vy.y; E.y.v[4 * l + 2] = vy.z; E.y.v[4 * l + 3] = vy.w;
+        }
+        aff29 E29;
+        f29_from_words(E29.x, E.x);
+        f29_from_words(E29.y, E.y);
+#pragma unroll
+        for (int l = 0; l < L; ++l) E29.y.l[l] = (int32_t)ct_sel(neg, (uint32_t)(-E29.y.l[l]), (uint32_t)E29.y.l[l]);
+        const uint32_t keep = ct_eq_small(mag, 0u);
+        jac29 sum = J;
+        jac29_madd(sum, E29);                                           // digit 0 or accumulator still O: computed, not used
+        const uint32_t set = at_inf & ~keep;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            J.X.l[l] = (int32_t)ct_sel(keep, (uint32_t)J.X.l[l], ct_sel(set, (uint32_t)E29.x.l[l], (uint32_t)sum.X.l[l]));
+            J.Y.l[l] = (int32_t)ct_sel(keep, (uint32_t)J.Y.l[l], ct_sel(set, (uint32_t)E29.y.l[l], (uint32_t)sum.Y.l[l]));
+            J.Z.l[l] = (int32_t)ct_sel(keep, (uint32_t)J.Z.l[l], ct_sel(set, l == 0 ? 1u : 0u, (uint32_t)sum.Z.l[l]));
+        }
+        at_inf &= keep;
+    }
+    jacT<N> Jw;
+    f29_to_words(Jw.X, J.X);
+    f29_to_words(Jw.Y, J.Y);
+    f29_to_words(Jw.Z, J.Z);
+#pragma unroll
+    for (int l = 0; l < N; ++l) Jw.Z.v[l] &= ~at_inf;
+    feT<N> zc;
+    fe_canon(zc, Jw.Z);
+    const feT<N> zi = fe_inv_safegcd<N, true>(zc);
+    feT<N> chk, zi2;
+    fe_mul(chk, zc, zi);
+    fe_canon(chk, chk);
+    chk.v[0] ^= 1u;
+    fe_sqr(zi2, zi);
+    fe_mul(x, Jw.X, zi2);
+    fe_canon(x, x);
+    fe_set_zero(y);
+    if (!x_only) {
+        fe_mul(zi2, zi2, zi);
+        fe_mul(y, Jw.Y, zi2);
+        fe_canon(y, y);
+    }
+    const uint32_t inf = ct_is_zero(zc.v) | ~ct_is_zero(chk.v);
+#pragma unroll
+    for (int l = 0; l < N; ++l) { x.v[l] &= ~inf; y.v[l] &= ~inf; }
+    return inf;
+}
+
 // Signed 8-bit windows (33 additions on the 256-bit curve): 128 entries x 64 octets = 8 KiB per row, which fits LDS in SIXTEEN
 // copies of 16-octet words, copy r at byte address (word * 16 + r) * 16, read with ds_read_b128 by lane l from copy l mod 16.
 // ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32
@@ -867,7 +963,7 @@ __device__ __forceinline__ uint32_t mul_base_ct_lds_xyzz(feT<N> &x, feT<N> &y, c
 
 // the LDS look-up form: modes and outputs as bign_mulbase_ct_kernel; blocks of 1024 lanes, all of which walk the windows
 // (a lane beyond n multiplies by 0 and writes nothing: the barriers need every lane)
-template <int N, int WB, bool XYZZ, int WGL = 1024>
+template <int N, int WB, bool XYZZ, int WGL = 1024, bool L29 = (N == 8 && WB == 8)>
 __global__ __launch_bounds__(WGL)
 void bign_mulbase_lds_kernel(const uint8_t *__restrict__ scalars, size_t n, uint32_t *__restrict__ codes,
                              uint8_t *__restrict__ xy_out, const uint64_t *__restrict__ tabw, const int MODE, const int X_ONLY)
@@ -884,7 +980,9 @@ void bign_mulbase_lds_kernel(const uint8_t *__restrict__ scalars, size_t n, uint
     if (MODE == 1) valid = ct_in_range_q(k);
     feT<N> x, y;
     uint32_t inf;
-    if constexpr (WB == 8)
+    if constexpr (WB == 8 && L29)
+        inf = mul_base_ct_lds16_l29<WB, WGL>(x, y, k, reinterpret_cast<const uint4 *>(tabw), reinterpret_cast<uint4 *>(s_row_dyn), X_ONLY);
+    else if constexpr (WB == 8)
         inf = mul_base_ct_lds16<N, WB, WGL>(x, y, k, reinterpret_cast<const uint4 *>(tabw), reinterpret_cast<uint4 *>(s_row_dyn), X_ONLY);
     else if constexpr (XYZZ) inf = mul_base_ct_lds_xyzz<N, WB>(x, y, k, tabw, s_row_dyn, X_ONLY);
     else inf = mul_base_ct_lds<N, WB>(x, y, k, tabw, s_row_dyn, X_ONLY);
@@ -1254,6 +1352,9 @@ static inline int mulbase_lanes(size_t n)
         return g_sign_lanes;
     if (N == 8 && (g_sign_lanes == 72 || g_sign_lanes == 7)) return g_sign_lanes;
     if (N == 8 && (g_sign_lanes == 8 || (g_sign_lanes == 0 && n >= MULBASE_LDS_MIN))) return 8;
+#ifdef BEE2HIP_EXPERIMENTS
+    if (N == 8 && g_sign_lanes == 81) return 81;            // the LDS look-up form on 32-bit limbs (round 4-5): A/B record against the 29-bit one
+#endif
     return n <= ((size_t)1 << 10) ? 64 : n <= ((size_t)1 << 13) ? 16 : n <= ((size_t)1 << 15) ? 4 : 1;
 }
 // the table the chosen form reads: the signed 7-bit one for form 7, the signed 6-bit one otherwise (`tab6` of launch_mulbase)
@@ -1261,11 +1362,11 @@ template <int N>
 static err_t mulbase_tables(int lanes, const uint32_t **tab, const uint32_t **tabw, hipStream_t st)
 {
     err_t code = bign_table6<N>(tab, tabw, st);
-    if (code == ERR_OK && (lanes == 7 || lanes == 72 || lanes == 8)) {
+    if (code == ERR_OK && (lanes == 7 || lanes == 72 || lanes == 8 || lanes == 81)) {
         if constexpr (N != 8) return ERR_BAD_INPUT;                      // (never: mulbase_lanes picks these forms on the 256-bit curve only)
         else {
 #ifdef BEE2HIP_EXPERIMENTS
-        code = lanes == 8 ? bign_tablew<N, 8>(tabw, st) : bign_tablew<N, 7>(tabw, st);
+        code = lanes == 8 || lanes == 81 ? bign_tablew<N, 8>(tabw, st) : bign_tablew<N, 7>(tabw, st);
 #else
         code = bign_tablew<N, 8>(tabw, st);
 #endif
@@ -1281,6 +1382,12 @@ static err_t mulbase_tables(int lanes, const uint32_t **tab, const uint32_t **ta
                     e = hipFuncSetAttribute(reinterpret_cast<const void *>(bign_mulbase_lds_kernel<8, 8, false, 512>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 #ifdef BEE2HIP_EXPERIMENTS
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute(reinterpret_cast<const void *>(bign_mulbase_lds_kernel<8, 8, false, 1024, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute(reinterpret_cast<const void *>(bign_mulbase_lds_kernel<8, 8, false, 512, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
                 if (e == hipSuccess)
                     e = hipFuncSetAttribute(reinterpret_cast<const void *>(bign_mulbase_lds_kernel<8, 7, LDS_XYZZ>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1310,6 +1417,19 @@ static void launch_mulbase(int lanes, const uint8_t *scalars, size_t n, uint32_t
         hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 0>), g256, dim3(256), 0, st, scalars, n, codes, out, tab, MODE, (int)X_ONLY);
     else if (lanes == 102)
         hipLaunchKernelGGL((bign_mulbase_ct_kernel<N, 1>), g256, dim3(256), 0, st, scalars, n, codes, out, tab6, MODE, (int)X_ONLY);
+#endif
+#ifdef BEE2HIP_EXPERIMENTS
+    else if (lanes == 81) {
+        if constexpr (N == 8) {
+            constexpr size_t lds = (size_t)WinW<N, 8>::ENT * N * 8 * 16;
+            if (n <= MULBASE_LDS_512_MAX)
+                hipLaunchKernelGGL((bign_mulbase_lds_kernel<N, 8, false, 512, false>), dim3((unsigned)((n + 511) / 512)), dim3(512), lds, st, scalars,
+                                   n, codes, out, reinterpret_cast<const uint64_t *>(tab6), MODE, (int)X_ONLY);
+            else
+                hipLaunchKernelGGL((bign_mulbase_lds_kernel<N, 8, false, 1024, false>), dim3((unsigned)((n + 1023) / 1024)), dim3(1024), lds, st, scalars, n,
+                                   codes, out, reinterpret_cast<const uint64_t *>(tab6), MODE, (int)X_ONLY);
+        }
+    }
 #endif
     else if (lanes == 8) {
         // signed 8-bit windows, 16 copies of the row read with ds_read_b128 (tab6 = the 8-bit window table): 33 additions

@@ -30,6 +30,7 @@ def ms(fn, reps=10):
     return e0.elapsed_time(e1) / reps
 
 
+FORMS = tuple(int(x) for x in sys.argv[1].split(",")) if len(sys.argv) > 1 else (1, 0, 7, 8)      # (round 6: 81 = the 8-bit LDS form on 32-bit limbs, 8 / 0 = on 29-bit limbs)
 print("ms per batch (pubkey calc | sign2) and M/s; forms: 1 = 6-bit scan, 0 = product dispatch by size (4 lanes up to 2^15, 8-bit LDS from 3*2^14: 512- / 1024-lane workgroups), 7 = 7-bit LDS, 8 = 8-bit LDS forced")
 for e in (15, 16, 17, 18, 19):
     n = 1 << e
@@ -40,7 +41,7 @@ for e in (15, 16, 17, 18, 19):
     hsh = torch.empty(no * n, dtype=torch.uint8, device="cuda"); hsh.view(torch.int64).random_(generator=g)
     out = {}
     line = f"2^{e}: "
-    for form in (1, 0, 7, 8):
+    for form in FORMS:
         eng.lib.bee2hip_internal_tune(10, form)
         pubs = torch.zeros(2 * no * n, dtype=torch.uint8, device="cuda")
         sigs = torch.zeros(sg * n, dtype=torch.uint8, device="cuda")
@@ -50,5 +51,5 @@ for e in (15, 16, 17, 18, 19):
         out[form] = (pubs.cpu().numpy().tobytes(), sigs.cpu().numpy().tobytes())
         line += f" form {form:2d}: {t_pk:.3f} | {t_sg:.3f} ms  ({n / t_pk / 1e3:6.1f} | {n / t_sg / 1e3:6.1f} M/s)"
     eng.lib.bee2hip_internal_tune(10, 0)
-    assert out[1] == out[0] == out[7] == out[8], e
+    assert all(out[f] == out[FORMS[0]] for f in FORMS), e
     print(line)
