@@ -730,7 +730,58 @@ __device__ __forceinline__ uint32_t mul_base_ct_lds16_l29(feT<8> &x, feT<8> &y, 
     for (int l = 0; l < N; ++l) Jw.Z.v[l] &= ~at_inf;
     feT<N> zc;
     fe_canon(zc, Jw.Z);
-    const feT<N> zi = fe_inv_safegcd<N, true>(zc);
+    // ---- 1 / Z, SHARED inside the workgroup (round 6).  The fixed-count division steps are ~20 000 instructions; with every lane
+    // inverting its own Z that was a quarter of this kernel on all 16 wavefronts of the workgroup.  Montgomery's trick over groups of
+    // INV_K = 4 lanes' values: Z (zero replaced by one) goes to LDS -- the window rows are dead by now --, the first WGL / 4 lanes (one
+    // wavefront per SIMD) each take four values: prefix products, ONE inversion, back-substitution (9 multiplications), and every lane
+    // reads its own inverse back.  Who does what depends on the lane index only (public); the staged values sit at lane-indexed
+    // addresses and are wiped afterwards.  A lane whose Z was zero gets an inverse that fails the z zi = 1 check below, as before.
+    constexpr int INV_K = 4;
+    static_assert(WGL % (64 * INV_K) == 0, "whole wavefronts of inverting lanes");
+    uint32_t *s_z = reinterpret_cast<uint32_t *>(s_row);                     // [word][lane]: N x WGL words; prefix products behind it
+    uint32_t *s_p = s_z + N * WGL;                                           // [k = 1 .. INV_K-2][word][inverting lane]
+    const uint32_t z_is0 = ct_is_zero(zc.v);
+    __syncthreads();                                                        // every lane is through with the window rows
+#pragma unroll
+    for (int l = 0; l < N; ++l) s_z[l * WGL + tid] = ct_sel(z_is0, l == 0 ? 1u : 0u, zc.v[l]);
+    __syncthreads();
+    if (tid < WGL / INV_K) {
+        constexpr unsigned G = WGL / INV_K;                                  // value j of lane t = the Z of lane j G + t
+        feT<N> zj, acc, t0;
+#pragma unroll
+        for (int l = 0; l < N; ++l) acc.v[l] = s_z[l * WGL + tid];
+#pragma unroll 1
+        for (int j = 1; j < INV_K; ++j) {
+            if (j > 1) {
+#pragma unroll
+                for (int l = 0; l < N; ++l) s_p[((j - 2) * N + l) * G + tid] = acc.v[l];     // product of values 0 .. j-1
+            }
+#pragma unroll
+            for (int l = 0; l < N; ++l) zj.v[l] = s_z[l * WGL + j * G + tid];
+            fe_mul(acc, acc, zj);
+        }
+        fe_canon(acc, acc);
+        feT<N> inv = fe_inv_safegcd<N, true>(acc);                           // 1 / (z_0 z_1 z_2 z_3)
+#pragma unroll 1
+        for (int j = INV_K - 1; j >= 1; --j) {
+#pragma unroll
+            for (int l = 0; l < N; ++l) t0.v[l] = j > 1 ? s_p[((j - 2) * N + l) * G + tid] : s_z[l * WGL + tid];   // product before value j
+#pragma unroll
+            for (int l = 0; l < N; ++l) zj.v[l] = s_z[l * WGL + j * G + tid];
+            fe_mul(t0, t0, inv);                                             // 1 / z_j
+            fe_mul(inv, inv, zj);
+#pragma unroll
+            for (int l = 0; l < N; ++l) s_z[l * WGL + j * G + tid] = t0.v[l];
+        }
+#pragma unroll
+        for (int l = 0; l < N; ++l) s_z[l * WGL + tid] = inv.v[l];           // 1 / z_0
+#pragma unroll 1
+        for (int j = 0; j < (INV_K - 2) * N; ++j) s_p[j * G + tid] = 0;      // the prefix products leave LDS
+    }
+    __syncthreads();
+    feT<N> zi;
+#pragma unroll
+    for (int l = 0; l < N; ++l) { zi.v[l] = s_z[l * WGL + tid]; s_z[l * WGL + tid] = 0; }
     feT<N> chk, zi2;
     fe_mul(chk, zc, zi);
     fe_canon(chk, chk);
