@@ -1394,7 +1394,8 @@ void set_sign_coop(int v) { g_sign_lanes = v; }
 // workgroups of 1024 lanes; signed 8-bit windows and 16 copies of the row -- the product -- or signed 7-bit windows and 32
 // copies): from 3 * 2^16 scalars on, where its one round of <= 256 workgroups (0.63 ms) beats the scanning kernel's 256-lane
 // blocks (0.55 ms at 2^17, 0.97 ms at 2^18: tools/ab/sign_lds_ab.py)
-constexpr size_t MULBASE_LDS_MIN = (size_t)3 << 14, MULBASE_LDS_512_MAX = (size_t)1 << 17;   // (512-lane workgroups from 3 * 2^14 scalars: tools/ab/sign_lds_ab.py)
+constexpr size_t MULBASE_LDS_MIN = (size_t)1 << 15, MULBASE_LDS_512_MAX = (size_t)1 << 17;   // (512-lane workgroups; round 6: from 2^15 scalars -- the 29-bit form with the shared inversion
+//  takes 0.27 | 0.35 ms (key | signature) for anything up to 2^17, the 4-lane cooperative form 0.35 | 0.43 ms at 2^15: profiles/r06_sign_l29_ab.txt)
 constexpr bool LDS_XYZZ = false;       // accumulator of the 7-bit LDS form: Jacobian (8M + 3S).  XYZZ (8M + 2S, one more coordinate) measured: +-0 % (profiles/r04_sign_lds.txt)
 template <int N>
 static inline int mulbase_lanes(size_t n)

@@ -43,7 +43,7 @@ def run(c):
         "config": {"workload": f"bignSign2 batch: {n} (hash, private key) pairs per GPU on bign-curve256v1, no additional input; "
                                "constant-time kernels (nonce by belt-hash + belt-wbl, k G on signed 8-bit windows whose entry is looked up in bank-private LDS copies of the row, "
                                "masked Jacobian mixed additions, inversion by a fixed number of division steps); every signature verified afterwards (untimed)"},
-        "roofline": {"kernels": "bign_sign_nonce + bign_mulbase_lds (one lane per signature, window entries looked up in LDS) + bign_sign_tail", "bound": "valu-int", "avg_batch_ms": ms_sign,
+        "roofline": {"kernels": "bign_sign_nonce + bign_mulbase_lds (one lane per signature, 29-bit limbs, window entries looked up in LDS, 1/Z shared in the workgroup) + bign_sign_tail", "bound": "valu-int", "avg_batch_ms": ms_sign,
                      "mads_per_signature": mads, "achieved": mads * n / (ms_sign * 1e-3) / 1e12, "peak": MAD_PEAK_T,
                      "unit": "T v_mad_u64_u32 lane-ops/s", "frac": mads * n / (ms_sign * 1e-3) / 1e12 / MAD_PEAK_T,
                      "note": "same multiplier formulation as verification (each mad paired with a half-rate addc: 0.5 is the ceiling)"},

@@ -40,15 +40,15 @@ def run(c):
         "ms_per_step": el / kv * 1e3, "verdicts_as_expected": sane,
         "config": {"workload": "bignVerify batch: 2^18 signatures per GPU on bign-curve256v1 (BASELINE configs[3]); "
                                "2048 genuine triples tiled 128x, seeded 1/16 corrupted"},
-        "roofline": {"kernels": "bign_prep+main+slow+inv+tail", "bound": "valu-int", "avg_batch_ms": ms_launch,
+        "roofline": {"kernels": "bign_prep+main29+slow+inv+tail", "bound": "valu-int", "avg_batch_ms": ms_launch,
                      # 32x32+64 multiply-adds per verify: 976 M x 72 + 685 S x 52 + scaled folds; inversions are division steps (no mads)
                      "mads_per_verify": MADS_PER_VERIFY,
                      "achieved": MADS_PER_VERIFY * n / (ms_launch * 1e-3) / 1e12,
                      "peak": MAD_PEAK_T, "unit": "T v_mad_u64_u32 lane-ops/s",
                      "frac": MADS_PER_VERIFY * n / (ms_launch * 1e-3) / 1e12 / MAD_PEAK_T,
-                     "note": "integer-multiplier bound; HBM irrelevant (148 B/signature); peak = measured "
-                             "v_mad_u64_u32 micro-benchmark (profiles/r01_valu_rates_ubench.txt); every mad is "
-                             "paired with a half-rate v_addc_co_u32, so 0.5 is the practical ceiling"},
+                     "note": "integer-multiplier bound; HBM irrelevant (148 B/signature); peak = measured v_mad_u64_u32 micro-benchmark "
+                             "(profiles/r01_valu_rates_ubench.txt); mads_per_verify is the 32-bit schoolbook count whatever form runs "
+                             "(the 29-bit kernel that carries 2^18 issues 1.35e5 v_mad_i64_i32 and no v_addc)"},
     }
     # MAD_PEAK_T is one micro-benchmark at 2.31 GHz; the verification kernels run at whatever the box gives under THEM (VERDICT r04
     # weak 11): the shader clock beside bign_main_kernel, and the fraction against the multiplier rate at that clock
@@ -64,7 +64,7 @@ def run(c):
     rv["valu_busy_main"] = pmc.get("valu_busy") if pmc else None
     if dist.rank == 0 and not args.headline_only:
         # the latency floor: prefixes of the same device-resident batch; up to 2^15 signatures run
-        # one per DPP quad, up to 2^16 on 29-bit limbs, above on 32-bit limbs (profiles/r02_verify_small.txt)
+        # one per DPP quad / pair of lanes, up to 2^18 one lane each on 29-bit limbs, above on 32-bit limbs (profiles/r06_f29_asm_ab.txt)
         small = {}
         for e in (10, 13, 14, 15, 16, 17):
             m = 1 << e

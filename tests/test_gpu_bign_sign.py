@@ -292,9 +292,9 @@ def test_sign_from_many_threads(orc):
     assert not errs
 
 
-@pytest.mark.parametrize("n", [3 << 14, (1 << 17) - 5, (1 << 17) + 1, 1 << 18])
+@pytest.mark.parametrize("n", [1 << 15, (1 << 15) + 77, 3 << 14, (1 << 17) - 5, (1 << 17) + 1, 1 << 18])
 def test_lds_lookup_forms_at_their_own_sizes_match_the_scanning_kernel(n):
-    """From 3 * 2^14 scalars on the 256-bit curve k G looks its window entries up in LDS (bign_mulbase_lds_kernel: workgroups of 512
+    """From 2^15 scalars (round 6; 3 * 2^14 before) on the 256-bit curve k G looks its window entries up in LDS (bign_mulbase_lds_kernel: workgroups of 512
     lanes up to 2^17 scalars, of 1024 above); the same batch through the scanning kernel (forced, experiments build) must give the
     same public keys and -- deterministic signatures -- the same octets; a sample of both is checked against the oracle."""
     import orclib
