@@ -8,9 +8,8 @@ from .common import *  # noqa: F401,F403
 
 
 def run(c):
-    dist, eng, args, K, W, N, H, kw, c0 = c.dist, c.eng, c.args, c.K, c.W, c.N, c.H, c.kw, c.c0
-    result, others, rates, strong, diag, hc, cores, do_cpu = c.result, c.others, c.rates, c.strong, c.diag, c.hc, c.cores, c.do_cpu
-    strong_leg = c.strong_leg
+    dist, eng, args, K, W, N, result = c.dist, c.eng, c.args, c.K, c.W, c.N, c.result
+    others, rates, strong, diag, hc, do_cpu, strong_leg = c.others, c.rates, c.strong, c.diag, c.hc, c.do_cpu, c.strong_leg
     n = 1 << 20
     st = torch.empty(192 * n, dtype=torch.uint8, device="cuda")
     fill_seeded(st, 0xBA5F + dist.rank)                      # synthetic states, generated in HBM
@@ -58,7 +57,7 @@ def run(c):
     rates["bashF_perms_per_s"] = n / (ms_launch * 1e-3)      # per GPU, kernel time: what the mixed roofline's parts use
     if not args.headline_only:
         bash_unit = lambda lo, hi: (lambda: eng.bashF_batch_dev(st[192 * lo: 192 * hi]))  # noqa: E731
-        strong_leg("bashF", n, bash_unit, K, t_total_ms=ms_launch if N == 1 else None)
+        strong_leg("bashF", n, bash_unit, K, t_total_ms=ms_launch if N == 1 else None, graph=N > 1)
         if N == 1:
             # A 2^17-state share is a 17 us kernel: an eager Python loop measures the host's launch rate there (~21 us per step),
             # which is also what the N > 1 strong legs will see.  The DEVICE side of the same split: the shares as replays of a

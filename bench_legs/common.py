@@ -152,6 +152,20 @@ def event_ms(fn, steps, warmup=2, graph=False):
     return e0.elapsed_time(e1) / steps
 
 
+def graph_of(fn, steps):
+    """`steps` calls of fn() captured into one hipGraph (on a side stream; the engine launches on torch's current stream)"""
+    fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(steps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    return g
+
+
 class Dist:
     """one process per GPU; RCCL ('nccl') by default.  BEE2_BENCH_BACKEND=gloo runs the same
     code with CPU-side collectives (lets the N>1 path be exercised on a box with one GPU)."""
@@ -380,8 +394,14 @@ class Ctx:
                 strong[f"strong_ms_share{g}_{name}"] = t
         else:
             lo, hi = shard.shard_range(dist.rank, N, total)
-            solo = solo_timed(dist, steps, 2, unit_fn(0, total))          # rank 0 alone on the WHOLE job
-            el_s = timed(dist, steps, 2, unit_fn(lo, hi))                 # every rank its share, max over ranks
+            f_tot, f_sh, k = unit_fn(0, total), unit_fn(lo, hi), steps
+            if graph:
+                # launches of a few microseconds (a 2^17-state bashF share: 17 us): `steps` of them captured into ONE hipGraph per leg,
+                # the replay timed between the barriers -- an eager Python loop would time the host's launch rate, not the N GPUs
+                g_tot, g_sh = graph_of(f_tot, steps), graph_of(f_sh, steps)
+                f_tot, f_sh, k = g_tot.replay, g_sh.replay, 1
+            solo = solo_timed(dist, k, 2, f_tot)                          # rank 0 alone on the WHOLE job
+            el_s = timed(dist, k, 2, f_sh)                                # every rank its share, max over ranks
             strong[f"strong_value_{name}"] = total * steps / el_s * to_value
             strong[f"strong_solo_value_{name}"] = total * steps / solo * to_value
             strong[f"strong_speedup_{name}"] = solo / el_s

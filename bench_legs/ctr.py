@@ -9,9 +9,8 @@ from .common import *  # noqa: F401,F403
 
 
 def run(c):
-    dist, eng, args, K, W, N, H, kw, c0 = c.dist, c.eng, c.args, c.K, c.W, c.N, c.H, c.kw, c.c0
-    result, others, rates, strong, diag, hc, cores, do_cpu = c.result, c.others, c.rates, c.strong, c.diag, c.hc, c.cores, c.do_cpu
-    strong_leg = c.strong_leg
+    dist, eng, args, K, N, H, kw = c.dist, c.eng, c.args, c.K, c.N, c.H, c.kw
+    c0, others, rates, strong, hc, do_cpu, strong_leg = c.c0, c.others, c.rates, c.strong, c.hc, c.do_cpu, c.strong_leg
     nbytes = int(args.ctr_gib * (1 << 30)) // 16 * 16
     free, _ = torch.cuda.mem_get_info()
     if free < nbytes + (1 << 30):

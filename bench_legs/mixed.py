@@ -5,9 +5,8 @@ from .common import *  # noqa: F401,F403
 
 
 def run(c):
-    dist, eng, args, K, W, N, H, kw, c0 = c.dist, c.eng, c.args, c.K, c.W, c.N, c.H, c.kw, c.c0
-    result, others, rates, strong, diag, hc, cores, do_cpu = c.result, c.others, c.rates, c.strong, c.diag, c.hc, c.cores, c.do_cpu
-    strong_leg = c.strong_leg
+    dist, eng, args, K, N, H, kw = c.dist, c.eng, c.args, c.K, c.N, c.H, c.kw
+    c0, others, rates, strong, hc, do_cpu, strong_leg = c.c0, c.others, c.rates, c.strong, c.hc, c.do_cpu, c.strong_leg
     n, ml = 1 << 21, 4096                                      # the weak leg: 2^24 / 8 messages per GPU
     # the FIXED job of configs[4]: 2^24 x 4 KiB = 64 GiB, resident on this card when it fits (288 GB: four times over); the weak
     # leg runs over its first 2^21 messages, the whole job is `bash512_beltMAC_2p24` and the total of the strong split

@@ -2,16 +2,13 @@
 import ctypes
 import time
 
-import numpy as np
 import torch
 
 from .common import *  # noqa: F401,F403
 
 
 def run(c):
-    dist, eng, args, K, W, N, H, kw, c0 = c.dist, c.eng, c.args, c.K, c.W, c.N, c.H, c.kw, c.c0
-    result, others, rates, strong, diag, hc, cores, do_cpu = c.result, c.others, c.rates, c.strong, c.diag, c.hc, c.cores, c.do_cpu
-    strong_leg = c.strong_leg
+    dist, eng, K, N, others, cores, do_cpu = c.dist, c.eng, c.K, c.N, c.others, c.cores, c.do_cpu
     from bee2_amd.engine import LEVEL_OID
     l, no, sg = 128, 32, 48
     n = 1 << 18

@@ -9,9 +9,8 @@ from .common import *  # noqa: F401,F403
 
 
 def run(c):
-    dist, eng, args, K, W, N, H, kw, c0 = c.dist, c.eng, c.args, c.K, c.W, c.N, c.H, c.kw, c.c0
-    result, others, rates, strong, diag, hc, cores, do_cpu = c.result, c.others, c.rates, c.strong, c.diag, c.hc, c.cores, c.do_cpu
-    strong_leg = c.strong_leg
+    dist, eng, args, K = c.dist, c.eng, c.args, c.K
+    N, others, hc, do_cpu, strong_leg = c.N, c.others, c.hc, c.do_cpu, c.strong_leg
     import goldenlib                      # committed fixtures only; the oracle is not imported here
     G = goldenlib.Golden()
     hs, ss, ps = G.bign_base_arrays()

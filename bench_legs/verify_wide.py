@@ -9,9 +9,7 @@ from .common import *  # noqa: F401,F403
 
 
 def run(c):
-    dist, eng, args, K, W, N, H, kw, c0 = c.dist, c.eng, c.args, c.K, c.W, c.N, c.H, c.kw, c.c0
-    result, others, rates, strong, diag, hc, cores, do_cpu = c.result, c.others, c.rates, c.strong, c.diag, c.hc, c.cores, c.do_cpu
-    strong_leg = c.strong_leg
+    dist, eng, args, K, N, others, cores, do_cpu = c.dist, c.eng, c.args, c.K, c.N, c.others, c.cores, c.do_cpu
     from bee2_amd.engine import LEVEL_OID
     import goldenlib
     G = goldenlib.Golden()
