@@ -1,21 +1,20 @@
 // bign_fe29.hpp -- GF(2^256 - 189) on nine SIGNED 29-bit limbs, for wavefronts that are alone on their SIMD.
 //
-// Why a second field representation (round 2, DESIGN.md 4.3 "small batches"): a wavefront that has its SIMD to
-// itself issues one instruction every ~5 cycles WHATEVER the instruction is (tools/ubench/valu_rates.hip section w),
-// so below ~2^16 signatures the time of a verification batch is its instruction COUNT, not its multiplier work.  The
-// product-scanning 8 x 32-bit multiplication of bign_dev.hpp is 64 v_mad_u64_u32 + 64 v_addc_co_u32 + 64 s_nop
-// (SGPR-carry wait state) + reduction = 232 instructions; with 29-bit limbs a column of nine products fits a 64-bit
-// accumulator without carries: 81 + 9 multiply-adds + ~70 full-rate shifts / masks = 160, a squaring 123 against
-// 180, an addition 9 against 20.  tools/ubench/fe29.hip: x1.40-1.42 per multiplication at <= 1 wavefront per SIMD,
-// x0.98-0.99 at 2 and 4 (there the half-rate instructions decide and the two forms tie) -- so this form serves the
-// small batches only (bign_main29_kernel) and the 32-bit form stays the throughput path.
+// Why a second field representation (round 2): a wavefront that has its SIMD to itself issues one instruction every
+// ~5 cycles WHATEVER the instruction is, so below ~2^16 signatures the time of a verification batch is its instruction COUNT.  The
+// product-scanning 8 x 32-bit multiplication of bign_dev.hpp is 64 v_mad_u64_u32 + 64 v_addc_co_u32 + 64 s_nop (SGPR-carry wait
+// state) + reduction = 232 instructions; with 29-bit limbs a column of nine products fits a 64-bit accumulator without carry flags.
+// Round 6 made the multiplication ONE inline-asm block (bign_fe29_asm.inc: 135 instructions, 91 of them v_mad_i64_i32; a squaring 99;
+// an addition 9 against 20): at that count the form also wins at four wavefronts per SIMD -- 91 multiply-adds and no v_addc against
+// 64 + 64 -- and carries every 256-bit batch up to 2^18 signatures (bign_main29_kernel) as well as the signing side's window walk.
 //
 // Representation: value = sum l[i] 2^(B i), i = 0..L-1, limbs int32, any value (positive or negative) congruent to
 // the residue; p = 2^(32N) - c.  256-bit curve (the graded one, after which the file is named): L = 9, B = 29,
 // 2^261 = 2^5 * 2^256 = 6048 (mod p).  384-bit: L = 14, B = 28, 2^392 = 2^8 * 317.  512-bit: L = 19, B = 27,
 // 2^513 = 2 * 569 (template LZ<N>).  "u" below = 2^B.
-//   N  (normalised) : output of f29_mul / f29_sqr / f29_carry: l[2..8] in [0, u), l[1] within 2 and l[0] within 2^16 of [0, u)
-//   L1 (lazy)       : |l[i]| <= u + 2^16: a difference of two N values, or the negation of one
+//   N  (normalised) : output of f29_mul / f29_sqr / f29_carry: l[2..] in [0, u); l[0] within 2^20 of [0, u) (f29_carry folds its last
+//                     carry there), l[1] within 2^21 (a multiplication folds the carry out of column L-1 there) -- tools/fe29_bounds.py norm()
+//   L1 (lazy)       : a difference of two N values, or the negation of one: |l[i]| <= u + 2^21
 // Additions and subtractions are limb-wise with no carries at all; a multiplication accepts operands whose limb
 // bounds A u and B u satisfy A * B <= 3 (nine products of 2^58 A B plus the carry-in stay below 2^63); the point
 // formulas below place a carry pass (f29_carry, 29 instructions) exactly where a value would exceed that

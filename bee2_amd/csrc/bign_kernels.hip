@@ -29,7 +29,7 @@
 //
 // Kernels per batch (same stream): [points ->] prep -> main -> slow -> inv -> tail; on the 256-bit curve the batch size
 // picks who walks the scalar multiplication: bign_quad29_kernel (= prep + main; a quad of lanes per signature up to
-// 2^14 signatures, a pair up to 2^15), prep + bign_main29_kernel (29-bit limbs, up to 2^16), prep + bign_main_kernel.
+// 2^14 signatures, a pair up to 2^15), prep + bign_main29_kernel (29-bit limbs, up to 2^18 since round 6), prep + bign_main_kernel.
 //   prep : range checks (bign_sign.c:306-318), u = s1 + H mod q (:320-327),
 //          v = s0 + 2^l (:329-330), affine Q table (on the wider curves the first half of this,
 //          everything up to the Jacobian table points, is a kernel of its own: points)
@@ -468,8 +468,8 @@ void bign_main_kernel(size_t n, VerifyScratch S, const uint4 *__restrict__ gtab)
 
 // ------------------------------------------------------- main, small batches ---
 // The same double-scalar multiplication on the signed 29-bit limbs of bign_fe29.hpp, for batches that leave a
-// wavefront alone on its SIMD (<= 2^16 signatures): there a kernel costs its instruction count and this form
-// has 0.69 of the instructions of the 32-bit one.  Reads the scratch bign_prep_kernel<8> wrote (affine 1Q..8Q in
+// wavefront alone on its SIMD (<= 2^16 signatures: there a kernel costs its instruction count) -- and, since round 6 made its
+// multiplication one asm block (228 k instructions per wavefront against the 32-bit kernel's 257 k, no v_addc), for everything up to 2^18.  Reads the scratch bign_prep_kernel<8> wrote (affine 1Q..8Q in
 // 32-bit words, converted on load: 2 instructions per limb) and leaves (X, Z) for bign_inv_kernel like the big
 // kernel.  Exceptional cases: every one of them (T = O, T = +-E, table point O) zeroes Z3 = Z1 H and all Z after it,
 // so ONE test of the final Z sends the same signatures to bign_slow_kernel as the per-addition flags of
@@ -1700,7 +1700,8 @@ static err_t launch_bign_verify_t(const uint8_t *oid_der, size_t oid_len, const 
     //   <= 2^14 signatures: one signature per quad, 29-bit limbs (prep + main in one kernel, no table inversion)
     //   <= 2^15           : one signature per pair of lanes, same kernel (256-bit curve; the wider ones use quads up
     //                       to 2^14 and the 32-bit kernels above: 28- / 27-bit limbs, LZ<N>)
-    //   <= 2^16           : one lane per signature, 29-bit limbs (at most one wavefront per SIMD: instruction count)
+    //   <= 2^18           : one lane per signature, 29-bit limbs, the multiplication one asm block (bign_fe29_asm.inc; round 6: it
+    //                       beats the 32-bit kernels at four wavefronts per SIMD too: 1 662 against 1 768 us at 2^18)
     //   above             : one lane per signature, 32-bit limbs (the throughput form)
     int path = 1;
     if constexpr (N == 8) path = g_verify_path ? g_verify_path : n <= ((size_t)1 << 15) ? 3 : n <= ((size_t)1 << 18) ? 2 : 1;   // (round 6: the 29-bit kernel's multiplication is one asm block now -- it beats the 32-bit kernels up to 2^18: profiles/r06_f29_asm_ab.txt)
