@@ -13,7 +13,8 @@ max-over-ranks of each timed region.
 Output (bench_legs/line.py): one figure per line for a reader, then -- LAST line of stdout, rank 0 -- ONE strict-JSON line of at
 most 8000 characters: the contract's fields, `roofline` (24 flat scalars: the headline kernel's algorithmic bytes / hipEvent
 launch time against the HBM peak, the other three BASELINE metrics with their fractions, the fixed-N (strong) split of SURVEY 8e
-as strong_pred_8_* at N = 1 / strong_speedup_* at N > 1, ranks / devices seen) and `cpu_baseline` (the reference itself,
+as strong_pred_8_* at N = 1 / strong_speedup_* at N > 1, ranks / devices seen; `traffic` = the PMC HBM bytes of the headline launch,
+taken in this very run by re-running that leg under rocprofv3 --pmc, bench_legs/pmc_live.py) and `cpu_baseline` (the reference itself,
 oracle/_ref, on this box's host cores; rank 0, N = 1).  Every leg's full record goes to gpurun_out/bench_detail.json.
 
 Default: the four BASELINE legs.  --all adds the SURVEY 8f legs (signing, bulk modes, ragged hashes, belt-dwp, the wider curves,
@@ -56,6 +57,9 @@ def parse(argv=None):
     ap.add_argument("--headline-only", action="store_true",
                     help="each leg launches ONLY its BASELINE-sized batch (no strong split, no sweeps, no host-pointer legs): what "
                          "tools/profile_headline.sh profiles, so that rocprofv3's per-kernel averages are over launches of ONE size")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not re-run the headline leg under rocprofv3 --pmc for `roofline.traffic` (then the committed profile of the "
+                         "same launch is replayed, or null)")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="ranks only form the process group, reduce one number and rank 0 prints the line's launch fields "
                          "(no GPU work; tests/test_bench_launch.py runs this on CPU with BEE2_BENCH_BACKEND=gloo)")
@@ -174,6 +178,17 @@ def main():
         torch.cuda.empty_cache()
 
     result, others = c.result, c.others
+    # HBM traffic of the headline launch, measured now (rank 0, N = 1; outside every timed region): bench_legs/pmc_live.py
+    if (dist.rank == 0 and N == 1 and "bashF" in only and not args.no_live_pmc and not args.headline_only
+            and isinstance(result.get("roofline"), dict)):
+        from bench_legs import pmc_live
+        live = pmc_live.headline_traffic("bashF", "bashF_tile_kernel", 1 << 20)
+        if live:
+            result["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
+            others.setdefault("bashF_detail", {})["traffic_source"] = live["source"]
+            others["bashF_detail"]["traffic_live"] = live
+        else:
+            others.setdefault("bashF_detail", {})["traffic_live"] = None     # (the replayed figure, if any, stays; its source is named beside it)
     if not result:                        # --only without bashF: promote the first other metric
         k0 = next(iter(others))
         o = others.pop(k0)
