@@ -185,6 +185,8 @@ def main():
         live = pmc_live.headline_traffic("bashF", "bashF_tile_kernel", 1 << 20)
         if live:
             result["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
+            if live.get("valu_busy") is not None:
+                result["roofline"]["valu_busy"] = live["valu_busy"]
             others.setdefault("bashF_detail", {})["traffic_source"] = live["source"]
             others["bashF_detail"]["traffic_live"] = live
         else:

@@ -13,13 +13,15 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _one_pass(counter, leg, timeout_s):
+def _one_pass(counters, leg, timeout_s):
+    """one rocprofv3 --pmc pass over the headline-only run of `leg`; -> {counter: {(kernel, grid): [values per launch]}}"""
+    counters = counters.split()
     exe = shutil.which("rocprofv3")
     if not exe:
         return None
     tmp = tempfile.mkdtemp(prefix="b2h_pmc_", dir="/tmp")
     try:
-        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "b", "--",
+        cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", tmp, "-o", "b", "--",
                sys.executable, os.path.join(ROOT, "bench.py"), "--only", leg, "--headline-only", "--no-cpu", "--no-live-pmc",
                "--steps", "5", "--warmup", "2"]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
@@ -33,12 +35,12 @@ def _one_pass(counter, leg, timeout_s):
                 path = os.path.join(d, "b_counter_collection.csv")
         if not path:
             return None
-        rows = {}
+        rows = {c: {} for c in counters}
         for row in csv.DictReader(open(path)):
-            if row["Counter_Name"] != counter:
+            if row["Counter_Name"] not in rows:
                 continue
             key = (row["Kernel_Name"].split("(")[0].replace("void ", "").replace("bee2hip::", "").strip(), int(row["Grid_Size"]))
-            rows.setdefault(key, []).append(float(row["Counter_Value"]))
+            rows[row["Counter_Name"]].setdefault(key, []).append(float(row["Counter_Value"]))
         return rows
     except Exception:
         return None
@@ -56,10 +58,18 @@ def headline_traffic(leg, kernel_prefix, grid, timeout_s=90):
     if not wr:
         return None
     pick = lambda rows: next((v for (k, g), v in rows.items() if k.startswith(kernel_prefix) and g == grid), None)  # noqa: E731
-    f, w = pick(fe), pick(wr)
+    f, w = pick(fe["FETCH_SIZE"]), pick(wr["WRITE_SIZE"])
     if not f or not w:
         return None
     fk, wk = sum(f) / len(f), sum(w) / len(w)
-    return {"hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "launches": min(len(f), len(w)),
-            "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH x 2) over bench.py --only "
-                      f"{leg} --headline-only"}
+    out = {"hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "launches": min(len(f), len(w)),
+           "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH x 2) over bench.py --only "
+                     f"{leg} --headline-only"}
+    # VALU utilisation of the same launch (north_star's "VALU integer-op utilisation"): SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES / 32
+    # shader engines x 1024 SIMDs) = VALU instructions executing per SIMD -- a third pass; its absence does not void the traffic figure
+    sq = _one_pass("SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES", leg, timeout_s)
+    if sq:
+        a, b = pick(sq["SQ_ACTIVE_INST_VALU"]), pick(sq["SQ_BUSY_CYCLES"])
+        if a and b and sum(b) > 0:
+            out["valu_busy"] = (sum(a) / len(a)) * 4.0 / ((sum(b) / len(b)) / 32.0 * 1024.0)
+    return out
